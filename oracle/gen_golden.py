@@ -1,0 +1,585 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the TeMP reference's OWN modules.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container (needs /root/reference, read-only);
+imports the reference in place under `oracle/ref_stubs` (dgl / pytorch_lightning stand-ins,
+see their docstrings) and records inputs + outputs as data.  No reference source is copied.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py            # all fixtures
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py G2 G10     # a subset
+
+Parameters are NOT drawn from the reference's initialisers: they come from
+`oracle.temp_oracle.init_model(seed)` (numpy PCG64, same shapes/ranges) and are loaded into the
+reference modules, so fixtures only need to carry the seed plus a checksum.  Random choices the
+reference makes from unseeded np.random (edge subsample, negatives -- SURVEY F11) are captured
+and stored as inputs.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from oracle import ref_harness as rh  # noqa: E402
+from oracle import temp_oracle as O  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+warnings.filterwarnings("ignore")
+N_TIMES = 24
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    clean = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        clean[k] = np.asarray(v)
+    np.savez_compressed(path, **clean)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def checksum(model):
+    return float(sum(v.double().abs().sum().item() for v in O.leaf_tensors(model).values()))
+
+
+def graph_arrays(g, prefix=""):
+    """reference DGL(stub) graph -> plain arrays (the hot path's input contract)."""
+    src, dst = g.edges()
+    d = {prefix + "n": g.number_of_nodes(), prefix + "src": src.numpy(), prefix + "dst": dst.numpy(),
+         prefix + "rel": g.edata['type_s'].numpy(), prefix + "ids": g.ndata['id'].view(-1).numpy(),
+         prefix + "nnorm": g.ndata['norm'].view(-1).numpy().astype(np.float32)}
+    if 'norm' in g.edata:
+        d[prefix + "enorm"] = g.edata['norm'].view(-1).numpy().astype(np.float32)
+    return d
+
+
+def to_ref_state_dict(model, type1=False):
+    """oracle parameter dict -> reference state_dict keys."""
+    sd = {'ent_embeds': model['ent_embeds'], 'rel_embeds': model['rel_embeds']}
+    for ln, d in model['ent_encoder'].items():
+        p = 'ent_encoder.%s.' % ln
+        for k in ('weight', 'loop_weight', 'time_embed', 'time_weight', 'time_weight_forward', 'time_weight_backward'):
+            if d.get(k) is not None:
+                sd[p + k] = d[k]
+        if d.get('h_bias') is not None:
+            sd[p + 'h_bias'] = d['h_bias']
+        for name in ('rnn', 'forward_rnn', 'backward_rnn'):
+            if name in d:
+                for li, q in enumerate(d[name]):
+                    suf = '' if type1 else '_l%d' % li
+                    sd[p + name + '.weight_ih' + suf] = q['w_ih']
+                    sd[p + name + '.weight_hh' + suf] = q['w_hh']
+                    sd[p + name + '.bias_ih' + suf] = q['b_ih']
+                    sd[p + name + '.bias_hh' + suf] = q['b_hh']
+        if d.get('exponential_decay') is not None:
+            sd[p + 'exponential_decay.weight'] = d['exponential_decay'][0]
+            sd[p + 'exponential_decay.bias'] = d['exponential_decay'][1]
+    return sd
+
+
+_CACHE = {}
+
+
+def graphs():
+    if 'g' not in _CACHE:
+        _CACHE['g'] = rh.build_graph_dicts(max_times=N_TIMES)
+    return _CACHE['g']
+
+
+# ----------------------------------------------------------------------------------------
+def gen_slice():
+    """The 'identical ICEWS14 inputs': quads of the first N_TIMES timestamps (public dataset
+    text, data not code) + the per-timestamp graphs the reference builds from them."""
+    from utils.dataset import load_quadruples
+    out = {}
+    tmax = None
+    for split in ('train', 'valid', 'test'):
+        q, times = load_quadruples('interpolation/icews14', split + '.txt')
+        if tmax is None:
+            _, all_t = load_quadruples('interpolation/icews14', 'train.txt', 'valid.txt', 'test.txt')
+            tmax = all_t[N_TIMES - 1]
+            out['times'] = all_t[:N_TIMES]
+        out[split] = q[q[:, 3] <= tmax].astype(np.int32)
+    num_e, num_r, tr, va, te = graphs()
+    out['num_ents'], out['num_rels'] = num_e, num_r
+    tkeys = list(tr.keys())
+    out['graph_times'] = np.array([int(tkeys[i]) for i in (0, 3, 20)])
+    for i in (0, 3, 20):
+        t = tkeys[i]
+        for nm, gd in (('train', tr), ('valid', va), ('test', te)):
+            out.update(graph_arrays(gd[t], 'g_%s_%d_' % (nm, int(t))))
+    save("icews14_slice", **out)
+
+
+def gen_G1():
+    """RGCNLayer.msg_func (models/RGCN.py:91-98)."""
+    from models.RGCN import RGCNLayer
+    import dgl
+    args = rh.make_args()
+    rng = np.random.default_rng(11)
+    out = {}
+    for ci, (D, B) in enumerate([(200, 100), (128, 128), (8, 2), (16, 4)]):
+        R2, n, E = 12, 40, 64
+        layer = RGCNLayer(args, D, D, R2, B, list(range(4)), bias=False, activation=None, self_loop=True, dropout=0.0)
+        w = O._xavier(rng, R2, layer.weight.shape[1])
+        layer.weight.data.copy_(w)
+        g = dgl.DGLGraph()
+        g.add_nodes(n)
+        src, dst = rng.integers(0, n, E), rng.integers(0, n, E)
+        g.add_edges(src, dst)
+        h = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32))
+        rel = torch.from_numpy(rng.integers(0, R2, E))
+        en = torch.from_numpy(rng.uniform(0.1, 1.0, (E, 1)).astype(np.float32))
+        g.ndata['h'] = h
+        g.edata['type_s'] = rel
+        g.edata['norm'] = en
+        msg = layer.msg_func(g._edge_batch())['msg']
+        pre = 'c%d_' % ci
+        out.update({pre + 'D': D, pre + 'B': B, pre + 'h': h, pre + 'src': src, pre + 'dst': dst, pre + 'rel': rel,
+                    pre + 'enorm': en.view(-1), pre + 'weight': w, pre + 'msg': msg})
+    save("G1_msg_func", ncases=4, **out)
+
+
+def _layer_params(rng, D, B, R2, T, bias):
+    s = D // B
+    return dict(weight=O._xavier(rng, R2, B * s * s), loop_weight=O._xavier(rng, D, D), time_embed=O._xavier(rng, T, D),
+                h_bias=(torch.from_numpy(rng.uniform(-0.5, 0.5, D).astype(np.float32)) if bias else None))
+
+
+def _set_layer(layer, p):
+    layer.weight.data.copy_(p['weight'])
+    layer.loop_weight.data.copy_(p['loop_weight'])
+    layer.time_embed.data.copy_(p['time_embed'])
+    if p.get('h_bias') is not None:
+        layer.h_bias.data.copy_(p['h_bias'])
+
+
+def gen_G2_G3():
+    """RGCNLayer.forward / forward_isolated on real ICEWS14 snapshots (models/RGCN.py:53-89)."""
+    import dgl
+    import torch.nn.functional as F
+    from models.RGCN import RGCNLayer
+    num_e, num_r, tr, va, te = graphs()
+    times = list(tr.keys())
+    args = rh.make_args()
+    gl = [tr[times[i]] for i in range(4)]
+    bg = dgl.batch(gl)
+    sizes = [g.number_of_nodes() for g in gl]
+    out = graph_arrays(bg)
+    out['node_sizes'] = sizes
+    out['times'] = [0, 1, 2, 3]
+    case = 0
+    for (D, B) in [(200, 100), (32, 32), (16, 4)]:
+        for bias in (False, True):
+            for act in (None, 'relu'):
+                if D == 200 and (bias != (act == 'relu')):
+                    continue            # keep the D=200 fixtures small: (no bias, no act) and (bias, relu)
+                seed = 100 + case
+                rng = np.random.default_rng(seed)
+                p = _layer_params(rng, D, B, 2 * num_r, len(times), bias)
+                ent = O._xavier(rng, num_e, D)
+                layer = RGCNLayer(args, D, D, 2 * num_r, B, times, bias=bias, activation=(F.relu if act else None),
+                                  self_loop=True, dropout=0.0)
+                _set_layer(layer, p)
+                h0 = ent[bg.ndata['id'].view(-1)].clone().requires_grad_(True)
+                bg.ndata['h'] = h0
+                rg, temb = layer(bg, [0, 1, 2, 3], sizes)
+                y = rg.ndata['h']
+                gy = torch.from_numpy(np.random.default_rng(seed + 1000).standard_normal(tuple(y.shape)).astype(np.float32))
+                y.backward(gy)
+                iso, t_iso = layer.forward_isolated(ent[:300].clone(), 2)
+                pre = 'c%d_' % case
+                out.update({pre + 'D': D, pre + 'B': B, pre + 'bias': int(bias), pre + 'act': (act or 'none'),
+                            pre + 'seed': seed, pre + 'y': y, pre + 'temb_sum': temb.double().sum().item(),
+                            pre + 'd_h0': h0.grad, pre + 'd_weight_rows': layer.weight.grad[:40],
+                            pre + 'd_weight_sum': layer.weight.grad.double().sum().item(),
+                            pre + 'd_weight_abs': layer.weight.grad.double().abs().sum().item(),
+                            pre + 'd_loop': layer.loop_weight.grad,
+                            pre + 'iso': iso, pre + 'param_checksum': checksum(p) + ent.double().abs().sum().item()})
+                if bias:
+                    out[pre + 'd_bias'] = layer.h_bias.grad
+                case += 1
+    save("G2_rgcn_layer", ncases=case, **out)
+
+
+def gen_G4_G5():
+    """GRRGCNLayer.forward (fixed & learnable decay, nn.GRU & type-1 cell) + aliasing check
+    (models/RRGCN.py:64-89, models/GRU_cell.py:7-31)."""
+    import dgl
+    from models.RRGCN import GRRGCNLayer
+    num_e, num_r, tr, va, te = graphs()
+    times = list(tr.keys())
+    gl = [tr[times[i]] for i in (5, 6)]
+    sizes = [g.number_of_nodes() for g in gl]
+    out = {}
+    case = 0
+    for (D, B, type1, learn, nl) in [(32, 16, False, False, 1), (32, 16, False, True, 1), (32, 16, True, False, 1),
+                                     (200, 100, False, False, 1), (16, 4, False, False, 2)]:
+        seed = 200 + case
+        rng = np.random.default_rng(seed)
+        args = rh.make_args(type1=type1, learnable_lambda=learn, num_layers=nl, inv_temperature=0.1)
+        layer = GRRGCNLayer(args, D, D, 2 * num_r, B, times, bias=False, activation=None, self_loop=True, dropout=0.0)
+        p = _layer_params(rng, D, B, 2 * num_r, len(times), False)
+        _set_layer(layer, p)
+        if type1:
+            k = 1.0
+            rp = [dict(w_ih=torch.from_numpy(rng.standard_normal((D, D)).astype(np.float32) * 0.1),
+                       w_hh=torch.from_numpy(rng.standard_normal((3 * D, D)).astype(np.float32) * 0.1),
+                       b_ih=torch.from_numpy(rng.standard_normal(D).astype(np.float32) * 0.1),
+                       b_hh=torch.from_numpy(rng.standard_normal(3 * D).astype(np.float32) * 0.1))]
+            layer.rnn.weight_ih.data.copy_(rp[0]['w_ih'])
+            layer.rnn.weight_hh.data.copy_(rp[0]['w_hh'])
+            layer.rnn.bias_ih.data.copy_(rp[0]['b_ih'])
+            layer.rnn.bias_hh.data.copy_(rp[0]['b_hh'])
+        else:
+            rp = O._gru_params(rng, D, nl)
+            for li, q in enumerate(rp):
+                getattr(layer.rnn, 'weight_ih_l%d' % li).data.copy_(q['w_ih'])
+                getattr(layer.rnn, 'weight_hh_l%d' % li).data.copy_(q['w_hh'])
+                getattr(layer.rnn, 'bias_ih_l%d' % li).data.copy_(q['b_ih'])
+                getattr(layer.rnn, 'bias_hh_l%d' % li).data.copy_(q['b_hh'])
+        if learn:
+            layer.exponential_decay.weight.data.fill_(0.3)
+            layer.exponential_decay.bias.data.fill_(-0.2)
+        ent = O._xavier(rng, num_e, D)
+        bg = dgl.batch(gl)
+        n = bg.number_of_nodes()
+        h0 = ent[bg.ndata['id'].view(-1)].clone().requires_grad_(True)
+        prev = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32) * 0.3)
+        prev[rng.random(n) < 0.4] = 0
+        prev = prev.requires_grad_(True)
+        dt = torch.from_numpy(rng.integers(0, 6, (n, 1)).astype(np.float32))
+        bg.ndata['h'] = h0
+        g_ret, temb = layer(bg, prev, dt, [5, 6], sizes)
+        aliased = int(g_ret is bg)
+        hid = bg.ndata['h']
+        gy = torch.from_numpy(np.random.default_rng(seed + 1000).standard_normal(tuple(hid.shape)).astype(np.float32))
+        hid.backward(gy)
+        pre = 'c%d_' % case
+        if case == 0:
+            out.update(graph_arrays(bg))
+            out['node_sizes'] = sizes
+        grads = {}
+        if type1:
+            grads = {'d_w_ih': layer.rnn.weight_ih.grad, 'd_w_hh': layer.rnn.weight_hh.grad,
+                     'd_b_ih': layer.rnn.bias_ih.grad, 'd_b_hh': layer.rnn.bias_hh.grad}
+        else:
+            grads = {'d_w_ih': layer.rnn.weight_ih_l0.grad, 'd_w_hh': layer.rnn.weight_hh_l0.grad,
+                     'd_b_ih': layer.rnn.bias_ih_l0.grad, 'd_b_hh': layer.rnn.bias_hh_l0.grad}
+        out.update({pre + 'D': D, pre + 'B': B, pre + 'type1': int(type1), pre + 'learn': int(learn), pre + 'nl': nl,
+                    pre + 'seed': seed, pre + 'prev': prev, pre + 'dt': dt.view(-1), pre + 'hid': hid,
+                    pre + 'aliased': aliased, pre + 'd_h0': h0.grad, pre + 'd_prev': prev.grad,
+                    pre + 'd_loop': layer.loop_weight.grad,
+                    pre + 'd_weight_abs': layer.weight.grad.double().abs().sum().item()})
+        if type1:
+            for k2, v in rp[0].items():
+                out[pre + 'rnn_' + k2] = v
+        if learn:
+            out[pre + 'd_decay_w'] = layer.exponential_decay.weight.grad
+            out[pre + 'd_decay_b'] = layer.exponential_decay.bias.grad
+        for k2, v in grads.items():
+            out[pre + k2] = v
+        case += 1
+    save("G4_grrgcn_layer", ncases=case, **out)
+
+
+def _encoder_case(enc_cls, module, rec_only, te, D, B, seed, bi):
+    """Shared G6/G7/G8 driver: builds the reference container, loads seeded params, returns
+    (encoder, oracle-format model, cfg)."""
+    num_e, num_r, tr, va, te_g = graphs()
+    times = np.array(list(tr.keys()))
+    args = rh.make_args(module=module, rec_only_last_layer=rec_only, use_time_embedding=te, hidden_size=D,
+                        embed_size=D, n_bases=B)
+    cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=te)
+    model = O.init_model(cfg, num_e, num_r, len(times), D, seed=seed)
+    enc = enc_cls(args, D, D, num_r, times)
+    sd = {k[len('ent_encoder.'):]: v for k, v in to_ref_state_dict(model).items() if k.startswith('ent_encoder.')}
+    enc.load_state_dict(sd, strict=True)
+    return enc, model, cfg, args
+
+
+def gen_G6():
+    """RRGCN.forward / forward_isolated / forward_post_ensemble (models/RRGCN.py:170-253)."""
+    import dgl
+    from models.RRGCN import RRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    gl = [tr[times[i]] for i in (7, 8, 9)]
+    sizes = [g.number_of_nodes() for g in gl]
+    tl = [7, 8, 9]
+    out = {}
+    case = 0
+    for (module, rec_only, te, D, B) in [('GRRGCN', True, False, 32, 16), ('GRRGCN', False, False, 32, 16),
+                                         ('GRRGCN', True, True, 32, 16), ('GRRGCN', False, True, 16, 4),
+                                         ('RRGCN', False, False, 32, 16), ('RRGCN', True, True, 32, 32),
+                                         ('GRRGCN', True, False, 200, 100)]:
+        seed = 300 + case
+        enc, model, cfg, args = _encoder_case(RRGCN, module, rec_only, te, D, B, seed, False)
+        rng = np.random.default_rng(seed + 5000)
+        bg = dgl.batch(gl)
+        n = bg.number_of_nodes()
+        ent = model['ent_embeds'].clone().requires_grad_(True)
+        bg.ndata['h'] = ent[bg.ndata['id'].view(-1)]
+        p1 = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32) * 0.3).requires_grad_(True)
+        p2 = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32) * 0.3).requires_grad_(True)
+        dt = torch.from_numpy(rng.integers(0, 6, (n, 1)).astype(np.float32))
+        first, second = enc(bg, p1, p2, dt, tl, sizes)
+        gy = torch.from_numpy(np.random.default_rng(seed + 1000).standard_normal(tuple(second.shape)).astype(np.float32))
+        (second * gy).sum().backward()
+        pre = 'c%d_' % case
+        if case == 0:
+            out.update(graph_arrays(bg))
+            out['node_sizes'] = sizes
+            out['times'] = tl
+        gsum = {k: v.grad.double().abs().sum().item() for k, v in enc.named_parameters() if v.grad is not None}
+        out.update({pre + 'module': module, pre + 'rec_only': int(rec_only), pre + 'te': int(te), pre + 'D': D, pre + 'B': B,
+                    pre + 'seed': seed, pre + 'second': second, pre + 'same': int(first is second),
+                    pre + 'd_p1': (p1.grad if p1.grad is not None else torch.zeros_like(p1)), pre + 'd_p2': p2.grad,
+                    pre + 'd_ent_rows': ent.grad[bg.ndata['id'].view(-1)],
+                    pre + 'param_checksum': checksum(model)})
+        if first is not second:
+            out[pre + 'first'] = first
+        for k, v in gsum.items():
+            out[pre + 'gabs_' + k] = v
+        # isolated pass over a slab of entities (models/RRGCN.py:206-217)
+        with torch.no_grad():
+            ne = 256
+            e = model['ent_embeds'][:ne]
+            q1 = torch.from_numpy(rng.standard_normal((ne, D)).astype(np.float32) * 0.3)
+            q2 = torch.from_numpy(rng.standard_normal((ne, D)).astype(np.float32) * 0.3)
+            dti = torch.from_numpy(rng.integers(0, 6, (ne, 1)).astype(np.float32))
+            iso = enc.forward_isolated(e, q1, q2, dti, 8)
+            out.update({pre + 'iso_q1': q1, pre + 'iso_q2': q2, pre + 'iso_dt': dti.view(-1), pre + 'iso': iso})
+        # post-ensemble entry point (GRU module only; models/RRGCN.py:219-233)
+        if module == 'GRRGCN':
+            enc.layer_2.post_ensemble = True
+            if not rec_only:
+                enc.layer_1.post_ensemble = True
+            with torch.no_grad():
+                bg2 = dgl.batch(gl)
+                bg2.ndata['h'] = model['ent_embeds'][bg2.ndata['id'].view(-1)]
+                loc, f2, s2 = enc.forward_post_ensemble(bg2, p1.detach(), p2.detach(), dt, tl, sizes)
+                out.update({pre + 'post_loc': loc, pre + 'post_second': s2})
+        case += 1
+    save("G6_rrgcn", ncases=case, **out)
+
+
+def gen_G7():
+    """BiRRGCN.forward / forward_one_direction / forward_isolated / post-ensemble
+    (models/BiRRGCN.py:188-293)."""
+    import dgl
+    from models.BiRRGCN import BiRRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    gl = [tr[times[i]] for i in (10, 11)]
+    sizes = [g.number_of_nodes() for g in gl]
+    tl = [10, 11]
+    out = {}
+    case = 0
+    for (module, rec_only, te, D, B) in [('BiGRRGCN', True, False, 32, 16), ('BiGRRGCN', False, False, 32, 16),
+                                         ('BiGRRGCN', True, True, 16, 4), ('BiRRGCN', False, False, 32, 16),
+                                         ('BiGRRGCN', True, False, 200, 100)]:
+        seed = 400 + case
+        enc, model, cfg, args = _encoder_case(BiRRGCN, module, rec_only, te, D, B, seed, True)
+        rng = np.random.default_rng(seed + 5000)
+        bg = dgl.batch(gl)
+        n = bg.number_of_nodes()
+        mk = lambda: torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32) * 0.3).requires_grad_(True)
+        f1, f2, b1, b2 = mk(), mk(), mk(), mk()
+        dtf = torch.from_numpy(rng.integers(0, 6, (n, 1)).astype(np.float32))
+        dtb = torch.from_numpy(rng.integers(0, 6, (n, 1)).astype(np.float32))
+        ent = model['ent_embeds'].clone().requires_grad_(True)
+        bg.ndata['h'] = ent[bg.ndata['id'].view(-1)]
+        second = enc(bg, f1, f2, dtf, b1, b2, dtb, tl, sizes)
+        gy = torch.from_numpy(np.random.default_rng(seed + 1000).standard_normal(tuple(second.shape)).astype(np.float32))
+        (second * gy).sum().backward()
+        pre = 'c%d_' % case
+        if case == 0:
+            out.update(graph_arrays(bg))
+            out['node_sizes'] = sizes
+            out['times'] = tl
+        z = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)
+        out.update({pre + 'module': module, pre + 'rec_only': int(rec_only), pre + 'te': int(te), pre + 'D': D, pre + 'B': B,
+                    pre + 'seed': seed, pre + 'second': second, pre + 'd_f1': z(f1), pre + 'd_f2': z(f2), pre + 'd_b1': z(b1),
+                    pre + 'd_b2': z(b2), pre + 'd_ent_rows': ent.grad[bg.ndata['id'].view(-1)],
+                    pre + 'param_checksum': checksum(model)})
+        for k, v in enc.named_parameters():
+            if v.grad is not None:
+                out[pre + 'gabs_' + k] = v.grad.double().abs().sum().item()
+        with torch.no_grad():
+            for fwd in (True, False):
+                bg2 = dgl.batch(gl)
+                bg2.ndata['h'] = model['ent_embeds'][bg2.ndata['id'].view(-1)]
+                a, b = enc.forward_one_direction(bg2, f1.detach(), f2.detach(), dtf, tl, sizes, fwd)
+                out[pre + ('one_fwd' if fwd else 'one_bwd')] = b
+                out[pre + ('one_same_fwd' if fwd else 'one_same_bwd')] = int(a is b)
+                if a is not b:
+                    out[pre + ('one_first_fwd' if fwd else 'one_first_bwd')] = a
+            ne = 256
+            e = model['ent_embeds'][:ne]
+            q = lambda: torch.from_numpy(rng.standard_normal((ne, D)).astype(np.float32) * 0.3)
+            q1, q2, q3, q4 = q(), q(), q(), q()
+            d1 = torch.from_numpy(rng.integers(0, 6, (ne, 1)).astype(np.float32))
+            d2 = torch.from_numpy(rng.integers(0, 6, (ne, 1)).astype(np.float32))
+            iso = enc.forward_isolated(e, q1, q2, d1, q3, q4, d2, 10)
+            out.update({pre + 'iso_f1': q1, pre + 'iso_f2': q2, pre + 'iso_b1': q3, pre + 'iso_b2': q4,
+                        pre + 'iso_dtf': d1.view(-1), pre + 'iso_dtb': d2.view(-1), pre + 'iso': iso})
+            if module == 'BiGRRGCN':
+                enc.layer_2.post_ensemble = True
+                if not rec_only:
+                    enc.layer_1.post_ensemble = True
+                bg3 = dgl.batch(gl)
+                bg3.ndata['h'] = model['ent_embeds'][bg3.ndata['id'].view(-1)]
+                loc, s2 = enc.forward_post_ensemble(bg3, f1.detach(), f2.detach(), dtf, b1.detach(), b2.detach(), dtb, tl, sizes)
+                out.update({pre + 'post_loc': loc, pre + 'post_second': s2})
+        case += 1
+    save("G7_birrgcn", ncases=case, **out)
+
+
+def gen_G9():
+    """utils/scores.py: 3 scorers x 3 modes."""
+    from utils import scores as S
+    rng = np.random.default_rng(9)
+    P, K, D = 7, 5, 16
+    s = torch.from_numpy(rng.standard_normal((P, D)).astype(np.float32))
+    r = torch.from_numpy(rng.standard_normal((P, D)).astype(np.float32))
+    o = torch.from_numpy(rng.standard_normal((P, D)).astype(np.float32))
+    cand = torch.from_numpy(rng.standard_normal((P, K, D)).astype(np.float32))
+    out = dict(s=s, r=r, o=o, cand=cand)
+    for name in ('distmult', 'complex', 'transE'):
+        fn = getattr(S, name)
+        out[name + '_single'] = fn(s, r, o)
+        out[name + '_tail'] = fn(s, r, cand, mode='tail')
+        out[name + '_head'] = fn(cand, r, o, mode='head')
+    save("G9_scores", **out)
+
+
+def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, trace=False, te=False):
+    num_e, num_r, tr, va, te_g = graphs()
+    args = rh.make_args(module=module, rec_only_last_layer=rec_only, hidden_size=D, embed_size=D, n_bases=B,
+                        train_seq_len=L, test_seq_len=L, batch_size=bsz_args, negative_rate=neg, use_time_embedding=te)
+    cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=te)
+    model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
+    torch.manual_seed(0)
+    m = cls(args, num_e, num_r, tr, va, te_g)
+    m.load_state_dict(to_ref_state_dict(model), strict=True)
+    np.random.seed(seed)
+    # capture the reference's unseeded random draws (F11) -----------------------------
+    choices, samples, trace_rec = [], [], []
+    orig_choice = np.random.choice
+
+    def rec_choice(*a, **k):
+        r = orig_choice(*a, **k)
+        choices.append(np.asarray(r).copy())
+        return r
+
+    orig_neg = m.corrupter.single_graph_negative_sampling
+
+    def rec_neg(t, g, n):
+        res = orig_neg(t, g, n)
+        samples.append([x.clone() for x in res[:3]])
+        return res
+
+    m.corrupter.single_graph_negative_sampling = rec_neg
+    if trace:
+        orig_upd = m.update_time_diff_hist_embeddings
+
+        def rec_upd(f, s, start, gl, cur_t, bsz):
+            res = orig_upd(f, s, start, gl, cur_t, bsz)
+            trace_rec.append((cur_t, res.detach().clone(), start.detach().clone()))
+            return res
+
+        m.update_time_diff_hist_embeddings = rec_upd
+    np.random.choice = rec_choice
+    try:
+        loss = m(torch.tensor(t_list))
+    finally:
+        np.random.choice = orig_choice
+    loss.backward()
+    times = list(tr.keys())
+    out = dict(module=module, rec_only=int(rec_only), D=D, B=B, seed=seed, L=L, neg=neg, te=int(te),
+               t_list=np.array(t_list), times=np.array(times), loss=loss.item(), param_checksum=checksum(model),
+               n_choices=len(choices), n_samples=len(samples))
+    for i, c in enumerate(choices):
+        out['choice_%d' % i] = c
+    for i, (trip, nt, nh) in enumerate(samples):
+        out['trip_%d' % i], out['negtail_%d' % i], out['neghead_%d' % i] = trip, nt, nh
+    eg = m.ent_embeds.grad
+    nz = torch.nonzero(eg.abs().sum(1)).view(-1)
+    out['d_ent_nz_rows'] = nz
+    out['d_ent_nz_vals'] = eg[nz]
+    out['d_rel'] = m.rel_embeds.grad
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            out['gabs_' + k] = v.grad.double().abs().sum().item()
+            out['gsum_' + k] = v.grad.double().sum().item()
+    if trace:
+        out['n_trace'] = len(trace_rec)
+        for i, (cur_t, res, start) in enumerate(trace_rec):
+            out['tr%d_cur_t' % i] = cur_t
+            for b in range(res.shape[0]):
+                rows = torch.nonzero(res[b, 1].abs().sum(1)).view(-1)
+                out['tr%d_b%d_rows' % (i, b)] = rows
+                out['tr%d_b%d_vals' % (i, b)] = res[b, 1][rows]
+                out['tr%d_b%d_same' % (i, b)] = int(torch.equal(res[b, 0], res[b, 1]))
+                srows = torch.nonzero(start[b]).view(-1)
+                out['tr%d_b%d_srows' % (i, b)] = srows
+                out['tr%d_b%d_svals' % (i, b)] = start[b][srows]
+    return out
+
+
+def gen_G10():
+    """Window level: DynamicRGCN.forward / BiDynamicRGCN.forward loss + grads on ICEWS14
+    (models/DynamicRGCN.py:176-194, models/BiDynamicRGCN.py:123-144); t=3 exercises the
+    None-padded window, t=0 the all-padding extreme.  G11 = the history trace (F8)."""
+    from models.DynamicRGCN import DynamicRGCN
+    from models.BiDynamicRGCN import BiDynamicRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    T = lambda idx: [int(times[i]) for i in idx]
+    save("G10_uni_grrgcn", **_run_window(DynamicRGCN, 'GRRGCN', False, 32, 16, 501, T([20, 15, 9, 3]), 8, 4, 20, trace=True))
+    save("G10_uni_grrgcn_rol", **_run_window(DynamicRGCN, 'GRRGCN', True, 32, 16, 502, T([12, 5, 0]), 6, 4, 20))
+    save("G10_bi_grrgcn_rol", **_run_window(BiDynamicRGCN, 'BiGRRGCN', True, 32, 16, 503, T([20, 15, 9, 3]), 8, 4, 20))
+    save("G10_bi_grrgcn", **_run_window(BiDynamicRGCN, 'BiGRRGCN', False, 16, 4, 504, T([22, 10, 1]), 5, 4, 20))
+    save("G10_uni_grrgcn_d200", **_run_window(DynamicRGCN, 'GRRGCN', True, 200, 100, 505, T([9, 4]), 4, 4, 10))
+
+
+def gen_G12():
+    """StaticRGCN (config 1): baselines/StaticRGCN.py:36-89, models/RGCN.py:145-164."""
+    from baselines.StaticRGCN import StaticRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    D, B, seed = 32, 16, 601
+    args = rh.make_args(module='SRGCN', hidden_size=D, embed_size=D, n_bases=B, negative_rate=20)
+    cfg = dict(module='SRGCN', n_bases=B, inv_temperature=0.1, rec_only_last_layer=False, use_time_embedding=False)
+    model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed, bias=True)
+    rng = np.random.default_rng(seed + 1)
+    for ln in ('layer_1', 'layer_2'):
+        model['ent_encoder'][ln]['h_bias'] = torch.from_numpy(rng.uniform(-0.3, 0.3, D).astype(np.float32))
+    m = StaticRGCN(args, num_e, num_r, tr, va, te_g)
+    m.load_state_dict(to_ref_state_dict(model), strict=True)
+    t_list = torch.tensor([int(times[i]) for i in (2, 6)])
+    gl = [tr[t.item()] for t in t_list]
+    with torch.no_grad():
+        embeds = m.get_per_graph_ent_embeds(t_list, gl, val=True)
+        iso = m.ent_encoder.forward_isolated(m.ent_embeds[:200], t_list[0])
+    out = dict(D=D, B=B, seed=seed, t_list=t_list.numpy(), times=np.array(times), iso=iso, param_checksum=checksum(model))
+    for i, e in enumerate(embeds):
+        out['emb_%d' % i] = e
+    save("G12_static_rgcn", **out)
+
+
+ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12)
+
+if __name__ == "__main__":
+    rh.activate()
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        print("== %s" % w)
+        ALL[w]()
