@@ -1,0 +1,197 @@
+/*
+ * temp_amd.h -- C ABI of the MI355X-native TeMP snapshot-encoder hot path (libtemp_amd.so).
+ *
+ * The TeMP reference (JiapengWu/TeMP) is pure Python and has no plugin / FFI layer; the seam this
+ * library plugs into is the `ent_encoder` object installed by `build_model()`
+ * (models/TKG_Module.py:37, models/DynamicRGCN.py:32-33, models/BiDynamicRGCN.py:14-15,
+ * baselines/StaticRGCN.py:14-18).  Each entry point below names the reference code it replaces.
+ * The Python mirror of the reference interface (package temp_amd) binds these symbols with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - All arithmetic is fp32; all indices are int32; all matrices are dense row-major.
+ *   - Every pointer is a DEVICE pointer unless stated otherwise.  The caller owns every buffer,
+ *     including workspaces; the library never allocates, frees or synchronises.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  The device is whatever
+ *     is current in the calling thread.
+ *   - Return value: 0 on success, a TEMP_E_* code otherwise (temp_error_string() describes it).
+ *     Nothing is thrown across the ABI.  All functions are re-entrant (no global mutable state),
+ *     so forward may run on one thread and backward on PyTorch's autograd thread.
+ *   - "nullable" arguments may be NULL.
+ */
+#ifndef TEMP_AMD_H
+#define TEMP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEMP_ABI_VERSION 1
+
+enum {
+  TEMP_OK = 0,
+  TEMP_E_BADARG = 1,      /* NULL / negative / inconsistent argument                          */
+  TEMP_E_UNSUPPORTED = 2, /* shape outside what the kernels implement (see each function)    */
+  TEMP_E_WORKSPACE = 3,   /* workspace too small                                             */
+  TEMP_E_LAUNCH = 4       /* hipLaunch / hipGetLastError failure                             */
+};
+
+enum { TEMP_ACT_NONE = 0, TEMP_ACT_RELU = 1 };
+enum { TEMP_GRU_TORCH = 0,   /* nn.GRU single step, gates r,z,n          (models/RRGCN.py:72,84)   */
+       TEMP_GRU_TYPE1 = 1 }; /* "type-1" GRUCell, r,z from hidden only   (models/GRU_cell.py:7-31) */
+
+int temp_abi_version(void);
+const char* temp_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmented edge lists.  One batched snapshot graph (the disjoint union `dgl.batch` builds at
+ * models/DynamicRGCN.py:92) is handed over as three sorted views of the same E edges, each cut
+ * into chunks of at most TEMP_CHUNK edges that never straddle a segment:
+ *
+ *   by destination  (forward aggregation,  RGCNLayer.propagate  models/RGCN.py:100-104)
+ *   by source       (d/dh of the aggregation)
+ *   by relation     (d/dweight of the aggregation, RGCNLayer.msg_func models/RGCN.py:91-98)
+ *
+ * A view holds, per edge in sorted order, the two "other" attributes (`a`, `b`), and per chunk the
+ * segment id (node or relation row), its [beg,end) edge range and a partial-result slot:
+ *   slot == -1 : the chunk is the whole segment, its result is final;
+ *   slot >= 0  : the segment spans several chunks; this chunk's partial goes to partial slot `slot`
+ *                and `fix_*` lists every such segment with its first slot and slot count (slots of
+ *                one segment are consecutive and are summed in order => deterministic).
+ * ---------------------------------------------------------------------------------------------- */
+#define TEMP_CHUNK 64
+
+typedef struct TempEdgeView {
+  int32_t n_seg;            /* number of segments (nodes, or relation rows)                        */
+  int32_t n_edges;          /* E                                                                   */
+  const int32_t* a;         /* [E]  by-dst: src node   | by-src: dst node | by-rel: src node       */
+  const int32_t* b;         /* [E]  by-dst: relation   | by-src: relation | by-rel: dst node       */
+  int32_t n_chunks;
+  const int32_t* chunk_seg; /* [n_chunks]                                                          */
+  const int32_t* chunk_beg; /* [n_chunks]                                                          */
+  const int32_t* chunk_end; /* [n_chunks]                                                          */
+  const int32_t* chunk_slot;/* [n_chunks]                                                          */
+  int32_t n_partial;        /* total partial slots                                                 */
+  int32_t n_fix;            /* segments that span more than one chunk                              */
+  const int32_t* fix_seg;   /* [n_fix]                                                             */
+  const int32_t* fix_slot;  /* [n_fix] first slot                                                  */
+  const int32_t* fix_cnt;   /* [n_fix] number of slots                                             */
+} TempEdgeView;
+
+typedef struct TempGraph {
+  int32_t n_nodes;          /* sum of nodes over the batched snapshots                             */
+  int32_t n_edges;
+  const float* nnorm;       /* [n_nodes] 1/in_degree, 0 for in_degree 0 (utils/utils.py:74-79)     */
+  const int32_t* in_deg;    /* [n_nodes]                                                           */
+  const int32_t* out_deg;   /* [n_nodes]                                                           */
+  TempEdgeView by_dst;
+  TempEdgeView by_src;      /* needed by temp_rgcn_bwd only                                        */
+  TempEdgeView by_rel;      /* needed by temp_rgcn_bwd only; n_seg = number of weight rows (2R)    */
+} TempGraph;
+
+/* ------------------------------------------------------------------------------------------------
+ * RGCN layer  (RGCNLayer.forward, models/RGCN.py:53-76, dropout = 0)
+ *
+ *   out[v] = act( nnorm[v]^2 * sum_{(u,r) in In(v)} h[u] . BD(W[r])  [+ bias]  +  h[v] . loop_w )
+ *
+ * BD(W[r]) is the block-diagonal matrix of `num_bases` blocks of (si x so), si = d_in/num_bases,
+ * so = d_out/num_bases, stored row-major per block (b*si*so + i*so + o) -- the `.view(-1, si, so)`
+ * of models/RGCN.py:92-93.  The double normalisation (edge norm then node norm) is the
+ * reference's.  `h_ids` (nullable) fuses the embedding gather of
+ * models/DynamicRGCN.py:93: row v of the input is h[h_ids[v]].
+ * Supported: d_in == d_out, d_in % 4 == 0, si == so in {1,2,4} (fast path) or any si,so
+ * (generic path).  workspace >= temp_rgcn_fwd_workspace().
+ * ---------------------------------------------------------------------------------------------- */
+size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out);
+int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids /*nullable*/,
+                  int d_in, int d_out, int num_bases, int n_rel_rows,
+                  const float* weight, const float* loop_w, const float* bias /*nullable*/, int act,
+                  float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the above (autograd of models/RGCN.py:53-104).
+ *   d_h      [n_nodes, d_in]   written (not accumulated)
+ *   d_weight [n_rel_rows, num_bases*si*so]  written; rows of unused relations are zeroed
+ *   d_loop_w [d_in, d_out]     written
+ *   d_bias   [d_out]           written (nullable iff bias was NULL)
+ * `out` is the forward output (used for the ReLU mask only when act == TEMP_ACT_RELU).
+ * `h` must be the materialised [n_nodes, d_in] input (no fused gather in backward). */
+size_t temp_rgcn_bwd_workspace(const TempGraph* g, int d_in, int d_out, int num_bases, int n_rel_rows);
+int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const float* d_out_grad,
+                  int d_in, int d_out, int num_bases, int n_rel_rows,
+                  const float* weight, const float* loop_w, int has_bias, int act,
+                  float* d_h, float* d_weight, float* d_loop_w, float* d_bias /*nullable*/,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Isolated-entity variant (RGCNLayer.forward_isolated, models/RGCN.py:78-89):
+ *   out = act( e + e . loop_w [+ bias] )          e: [n, d]                                    */
+int temp_rgcn_isolated_fwd(int n, int d, const float* e, const float* loop_w, const float* bias /*nullable*/,
+                           int act, float* out, void* stream);
+size_t temp_rgcn_isolated_bwd_workspace(int n, int d);
+int temp_rgcn_isolated_bwd(int n, int d, const float* e, const float* out, const float* d_out_grad,
+                           const float* loop_w, int has_bias, int act,
+                           float* d_e, float* d_loop_w, float* d_bias /*nullable*/,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Recurrent update: decay of the previous state + one GRU step
+ * (GRRGCNLayer.forward, models/RRGCN.py:77-89; BiGRRGCNLayer, models/BiRRGCN.py:27-63).
+ *
+ *   hdec[i] = prev[prev_idx ? prev_idx[i] : i] * exp(-lambda * dt[i])                (fixed)
+ *           = prev[...] * exp(-max(0, decay_w * dt[i] + decay_b))                    (learnable,
+ *                                                     RGCNLayer.decay_hidden models/RGCN.py:106-107)
+ *   prev_idx[i] == -1  =>  previous state is the zero vector (entity inactive at the previous
+ *                          window position: the reference re-zeroes its dense history every step,
+ *                          models/DynamicRGCN.py:47-54).
+ *   TEMP_GRU_TORCH:  r = sig(W_ir x + b_ir + W_hr hdec + b_hr),  z likewise,
+ *                    n = tanh(W_in x + b_in + r * (W_hn hdec + b_hn)),  h' = (1-z) n + z hdec
+ *                    w_ih, w_hh: [3d, d] rows ordered r,z,n;  b_ih, b_hh: [3d]
+ *   TEMP_GRU_TYPE1:  r = sig(W_hr hdec + b_hr), z = sig(W_hz hdec + b_hz),
+ *                    n = tanh(W_in x + b_in + r * (W_hn hdec + b_hn)),  h' = n + z (hdec - n)
+ *                    w_ih: [d, d], b_ih: [d];  w_hh: [3d, d], b_hh: [3d]
+ *   `learnable`: decay_wb points to 2 DEVICE floats {w, b}; otherwise decay_wb is NULL and
+ *   `lambda` is used.
+ *   saved: [5, n, d] scratch the backward needs (r, z, n, W_hn hdec + b_hn, hdec).
+ * Supported: d % 4 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int temp_gru_fwd(int n, int d, int variant,
+                 const float* x, const float* prev, const int32_t* prev_idx /*nullable*/, const float* dt,
+                 float lambda, const float* decay_wb /*nullable*/,
+                 const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                 float* h_out, float* saved, void* stream);
+
+/* Backward.  d_h_out: [n,d] upstream gradient.
+ *   d_x    [n,d]  written
+ *   d_prev [n,d]  written, in the row order of x (caller scatters through prev_idx)
+ *   d_w_ih, d_w_hh, d_b_ih, d_b_hh written
+ *   d_decay_wb: 2 device floats written when learnable (nullable otherwise)                       */
+size_t temp_gru_bwd_workspace(int n, int d, int variant);
+int temp_gru_bwd(int n, int d, int variant,
+                 const float* x, const float* prev, const int32_t* prev_idx /*nullable*/, const float* dt,
+                 float lambda, const float* decay_wb /*nullable*/,
+                 const float* w_ih, const float* w_hh,
+                 const float* saved, const float* d_h_out,
+                 float* d_x, float* d_prev, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh,
+                 float* d_decay_wb /*nullable*/,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row gather / scatter helpers of the window loop
+ * (get_prev_embeddings / update_time_diff_hist_embeddings / ent_embeds[id],
+ *  models/DynamicRGCN.py:35-54,93).
+ *   gather:       out[i] = idx[i] >= 0 ? table[idx[i]] : 0                 out: [n, d]
+ *   scatter_add:  table[idx[i]] += src[i]  for idx[i] >= 0 (atomic, rows may repeat)
+ * ---------------------------------------------------------------------------------------------- */
+int temp_gather_rows(int n, int d, const float* table, const int32_t* idx, float* out, void* stream);
+int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, float* table, void* stream);
+
+/* Device-memory bandwidth probe used by bench.py to calibrate the achievable HBM peak
+ * (float4 copy of `bytes` bytes, dst and src must not overlap). */
+int temp_copy_probe(const void* src, void* dst, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEMP_AMD_H */

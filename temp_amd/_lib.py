@@ -1,0 +1,84 @@
+"""ctypes binding of libtemp_amd.so (the C ABI declared in include/temp_amd.h).
+
+There is NO CPU fallback: if the shared library is missing or a symbol cannot be bound this module
+raises, and every op in the package fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtemp_amd.so")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_vp = ctypes.c_void_p
+
+ACT_NONE, ACT_RELU = 0, 1
+GRU_TORCH, GRU_TYPE1 = 0, 1
+CHUNK = 64
+
+
+class TempEdgeView(ctypes.Structure):
+    _fields_ = [("n_seg", ctypes.c_int32), ("n_edges", ctypes.c_int32), ("a", c_vp), ("b", c_vp),
+                ("n_chunks", ctypes.c_int32), ("chunk_seg", c_vp), ("chunk_beg", c_vp), ("chunk_end", c_vp),
+                ("chunk_slot", c_vp), ("n_partial", ctypes.c_int32), ("n_fix", ctypes.c_int32),
+                ("fix_seg", c_vp), ("fix_slot", c_vp), ("fix_cnt", c_vp)]
+
+
+class TempGraph(ctypes.Structure):
+    _fields_ = [("n_nodes", ctypes.c_int32), ("n_edges", ctypes.c_int32), ("nnorm", c_vp), ("in_deg", c_vp),
+                ("out_deg", c_vp), ("by_dst", TempEdgeView), ("by_src", TempEdgeView), ("by_rel", TempEdgeView)]
+
+
+# name -> (restype, argtypes); mirrors include/temp_amd.h one to one
+_G = ctypes.POINTER(TempGraph)
+_I, _F, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+SYMBOLS = {
+    "temp_abi_version": (_I, []),
+    "temp_error_string": (ctypes.c_char_p, [_I]),
+    "temp_rgcn_fwd_workspace": (_SZ, [_G, _I]),
+    "temp_rgcn_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp]),
+    "temp_rgcn_bwd_workspace": (_SZ, [_G, _I, _I, _I, _I]),
+    "temp_rgcn_bwd": (_I, [_G, c_vp, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_rgcn_isolated_fwd": (_I, [_I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp]),
+    "temp_rgcn_isolated_bwd_workspace": (_SZ, [_I, _I]),
+    "temp_rgcn_isolated_bwd": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_gru_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_bwd_workspace": (_SZ, [_I, _I, _I]),
+    "temp_gru_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp,
+                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
+    "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
+    "temp_copy_probe": (_I, [c_vp, c_vp, _SZ, c_vp]),
+}
+
+_lib = None
+
+
+class TempAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise TempAmdError when it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TempAmdError("libtemp_amd.so not found at %s -- run `python -m temp_amd.build` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.temp_abi_version() != 1:
+        raise TempAmdError("libtemp_amd.so ABI version %d != 1" % lib.temp_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().temp_error_string(rc).decode()
+        raise TempAmdError("%s failed: %s (code %d)" % (what, msg, rc))

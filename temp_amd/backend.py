@@ -1,0 +1,165 @@
+"""Kernel backend: the only place that crosses the C ABI (include/temp_amd.h).
+
+`HipBackend` hands raw device pointers of torch tensors (+ the current HIP stream) to
+libtemp_amd.so.  PyTorch is used for device memory and streams only.  There is no CPU
+implementation in the product: tensors that are not on a GPU, or a missing library, raise.
+(tests/ install a test-only backend through `set_backend` to exercise host logic without a GPU.)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_backend = None
+
+
+def set_backend(b):
+    """Install a backend object (tests only).  Passing None restores the HIP backend."""
+    global _backend
+    _backend = b
+
+
+def get_backend():
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.TempAmdError("%s must live on the GPU (got %s): temp_amd has no CPU path" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise _lib.TempAmdError("%s must be float32, got %s" % (name, t.dtype))
+    return t.detach().contiguous()
+
+
+def _i32(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.int32:
+        raise _lib.TempAmdError("%s must be an int32 GPU tensor" % name)
+    return t.contiguous()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def _ws(self, nbytes, device):
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+    # ---- RGCN layer ----------------------------------------------------------------------------
+    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act):
+        h, weight, loop_w, bias = _f32(h, "h"), _f32(weight, "weight"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
+        h_ids = _i32(h_ids, "h_ids")
+        d_in, d_out = loop_w.shape
+        out = torch.empty(dg.n_nodes, d_out, dtype=torch.float32, device=h.device)
+        nb = self.lib.temp_rgcn_fwd_workspace(dg.ref(), d_out)
+        ws = self._ws(nb, h.device)
+        rc = self.lib.temp_rgcn_fwd(dg.ref(), _ptr(h), _ptr(h_ids), d_in, d_out, num_bases, weight.shape[0], _ptr(weight),
+                                    _ptr(loop_w), _ptr(bias), act, _ptr(out), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_rgcn_fwd")
+        return out
+
+    def rgcn_bwd(self, dg, h, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
+        h, out, g = _f32(h, "h"), _f32(out, "out"), _f32(d_out_grad, "d_out")
+        weight, loop_w = _f32(weight, "weight"), _f32(loop_w, "loop_weight")
+        d_in, d_out = loop_w.shape
+        dev = h.device
+        d_h = torch.empty(dg.n_nodes, d_in, dtype=torch.float32, device=dev)
+        d_w = torch.empty_like(weight)
+        d_loop = torch.empty_like(loop_w)
+        d_bias = torch.empty(d_out, dtype=torch.float32, device=dev) if has_bias else None
+        nb = self.lib.temp_rgcn_bwd_workspace(dg.ref(), d_in, d_out, num_bases, weight.shape[0])
+        ws = self._ws(nb, dev)
+        rc = self.lib.temp_rgcn_bwd(dg.ref(), _ptr(h), _ptr(out), _ptr(g), d_in, d_out, num_bases, weight.shape[0], _ptr(weight),
+                                    _ptr(loop_w), int(has_bias), act, _ptr(d_h), _ptr(d_w), _ptr(d_loop), _ptr(d_bias), _ptr(ws),
+                                    ws.numel(), _stream())
+        _lib.check(rc, "temp_rgcn_bwd")
+        return d_h, d_w, d_loop, d_bias
+
+    def rgcn_isolated_fwd(self, e, loop_w, bias, act):
+        e, loop_w, bias = _f32(e, "e"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
+        out = torch.empty_like(e)
+        rc = self.lib.temp_rgcn_isolated_fwd(e.shape[0], e.shape[1], _ptr(e), _ptr(loop_w), _ptr(bias), act, _ptr(out), _stream())
+        _lib.check(rc, "temp_rgcn_isolated_fwd")
+        return out
+
+    def rgcn_isolated_bwd(self, e, out, d_out_grad, loop_w, has_bias, act):
+        e, out, g, loop_w = _f32(e, "e"), _f32(out, "out"), _f32(d_out_grad, "d_out"), _f32(loop_w, "loop_weight")
+        n, d = e.shape
+        d_e = torch.empty_like(e)
+        d_loop = torch.empty_like(loop_w)
+        d_bias = torch.empty(d, dtype=torch.float32, device=e.device) if has_bias else None
+        ws = self._ws(self.lib.temp_rgcn_isolated_bwd_workspace(n, d), e.device)
+        rc = self.lib.temp_rgcn_isolated_bwd(n, d, _ptr(e), _ptr(out), _ptr(g), _ptr(loop_w), int(has_bias), act, _ptr(d_e),
+                                             _ptr(d_loop), _ptr(d_bias), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_rgcn_isolated_bwd")
+        return d_e, d_loop, d_bias
+
+    # ---- decay + GRU step ------------------------------------------------------------------------
+    def gru_fwd(self, x, prev, prev_idx, dt, lam, decay_wb, w_ih, w_hh, b_ih, b_hh, variant):
+        x, prev, dt = _f32(x, "x"), _f32(prev, "prev"), _f32(dt, "dt")
+        w_ih, w_hh, b_ih, b_hh = _f32(w_ih, "w_ih"), _f32(w_hh, "w_hh"), _f32(b_ih, "b_ih"), _f32(b_hh, "b_hh")
+        decay_wb, prev_idx = _f32(decay_wb, "decay_wb"), _i32(prev_idx, "prev_idx")
+        n, d = x.shape
+        h_out = torch.empty_like(x)
+        saved = torch.empty(5, n, d, dtype=torch.float32, device=x.device)
+        rc = self.lib.temp_gru_fwd(n, d, variant, _ptr(x), _ptr(prev), _ptr(prev_idx), _ptr(dt), float(lam), _ptr(decay_wb),
+                                   _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(h_out), _ptr(saved), _stream())
+        _lib.check(rc, "temp_gru_fwd")
+        return h_out, saved
+
+    def gru_bwd(self, x, prev, prev_idx, dt, lam, decay_wb, w_ih, w_hh, saved, d_h, variant):
+        x, prev, dt, d_h = _f32(x, "x"), _f32(prev, "prev"), _f32(dt, "dt"), _f32(d_h, "d_h")
+        w_ih, w_hh, saved = _f32(w_ih, "w_ih"), _f32(w_hh, "w_hh"), _f32(saved, "saved")
+        decay_wb, prev_idx = _f32(decay_wb, "decay_wb"), _i32(prev_idx, "prev_idx")
+        n, d = x.shape
+        dev = x.device
+        d_x = torch.empty_like(x)
+        d_prev = torch.empty_like(x)
+        d_w_ih, d_w_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        d_b_ih = torch.empty(w_ih.shape[0], dtype=torch.float32, device=dev)
+        d_b_hh = torch.empty(w_hh.shape[0], dtype=torch.float32, device=dev)
+        d_wb = torch.empty(2, dtype=torch.float32, device=dev) if decay_wb is not None else None
+        ws = self._ws(self.lib.temp_gru_bwd_workspace(n, d, variant), dev)
+        rc = self.lib.temp_gru_bwd(n, d, variant, _ptr(x), _ptr(prev), _ptr(prev_idx), _ptr(dt), float(lam), _ptr(decay_wb),
+                                   _ptr(w_ih), _ptr(w_hh), _ptr(saved), _ptr(d_h), _ptr(d_x), _ptr(d_prev), _ptr(d_w_ih),
+                                   _ptr(d_w_hh), _ptr(d_b_ih), _ptr(d_b_hh), _ptr(d_wb), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_gru_bwd")
+        return d_x, d_prev, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_wb
+
+    # ---- row gather / scatter ---------------------------------------------------------------------
+    def gather_rows(self, table, idx):
+        table, idx = _f32(table, "table"), _i32(idx, "idx")
+        out = torch.empty(idx.shape[0], table.shape[1], dtype=torch.float32, device=table.device)
+        rc = self.lib.temp_gather_rows(idx.shape[0], table.shape[1], _ptr(table), _ptr(idx), _ptr(out), _stream())
+        _lib.check(rc, "temp_gather_rows")
+        return out
+
+    def scatter_add_rows(self, src, idx, table):
+        """table[idx[i]] += src[i] in place (table must be contiguous float32)."""
+        src, idx = _f32(src, "src"), _i32(idx, "idx")
+        if not (table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()):
+            raise _lib.TempAmdError("scatter target must be a contiguous float32 GPU tensor")
+        rc = self.lib.temp_scatter_add_rows(idx.shape[0], src.shape[1], _ptr(src), _ptr(idx), _ptr(table), _stream())
+        _lib.check(rc, "temp_scatter_add_rows")
+        return table
+
+    def copy_probe(self, src, dst):
+        rc = self.lib.temp_copy_probe(_ptr(src), _ptr(dst), src.numel() * src.element_size(), _stream())
+        _lib.check(rc, "temp_copy_probe")

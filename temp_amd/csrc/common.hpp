@@ -1,0 +1,79 @@
+// Shared device/host helpers for libtemp_amd (gfx950 / CDNA4 only: wave64, MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "temp_amd.h"
+
+#define TEMP_WAVE 64
+
+namespace temp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 fma4(float s, float4 b, float4 c) {
+  return make_float4(fmaf(s, b.x, c.x), fmaf(s, b.y, c.y), fmaf(s, b.z, c.z), fmaf(s, b.w, c.w));
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+__device__ __forceinline__ float4 shfl4(float4 v, int src) {
+  return make_float4(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src));
+}
+__device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
+  return make_float4(__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m), __shfl_xor(v.w, m));
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// Persistent, XCD-aware work partition: block b is observed to run on XCD b % 8 (each XCD has its
+// own 4 MB L2), so XCD x walks the x-th contiguous eighth of the item list and the rows gathered
+// by neighbouring items (same snapshot) stay in one L2.  Only a speed heuristic: any placement
+// computes the same result.  Requires gridDim.x % 8 == 0.
+struct ItemRange { int beg, end, stride; };
+__device__ __forceinline__ ItemRange xcd_items(int n_items, int per_block) {
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int per = (n_items + 7) >> 3;
+  ItemRange r;
+  const int base = xcd * per;
+  r.beg = base + lb * per_block;
+  r.end = min(n_items, base + per);
+  r.stride = bpx * per_block;
+  return r;
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? TEMP_OK : TEMP_E_LAUNCH;
+}
+
+// --- internal launch helpers shared across translation units (definitions in the .hip files) -----
+struct EpiAddBiasAct;   // gemm_kernels.hip
+
+// C[M,N] = act( (row_mask==NULL || row_mask[m] > 0 ? addend[m,n] : 0) + bias[n] + A[M,K] . B )
+//   A: row-major, lda; a_idx nullable row gather.  B: [K,N] row-major (ldb) or, if trans_b,
+//   stored as [N,K] row-major (ldb).  addend/bias/row_mask nullable.  out may alias addend.
+int gemm_add_bias_act(int M, int N, int K, const float* A, int lda, const int32_t* a_idx,
+                      const float* B, int ldb, int trans_b,
+                      const float* addend, int ld_add, const int32_t* row_mask, const float* bias, int act,
+                      float* out, int ldo, hipStream_t st);
+
+// out[Ka,Nb] = sum_m A[m,ka] * B[m,nb]   (split over m, deterministic two-pass reduce)
+size_t gemm_tn_workspace(int M, int Ka, int Nb);
+int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb,
+            float* out, int ldo, void* ws, size_t ws_bytes, hipStream_t st);
+
+// out[n_cols] = sum over rows of X[rows, n_cols]
+size_t colsum_workspace(int rows, int cols);
+int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+
+// dz = (y > 0) ? dy : 0
+int relu_bwd(size_t n, const float* y, const float* dy, float* dz, hipStream_t st);
+
+}  // namespace temp

@@ -1,0 +1,298 @@
+// Dense fp32 pieces of the snapshot encoder on MFMA (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD):
+//   * row-panel GEMM  C = epi(A[M,K] . B[K,N])   -- self-loop message (models/RGCN.py:57,80 of the
+//     TeMP reference), its d/dh, and the GRU d/dx, d/dh GEMMs, with fused epilogues;
+//   * TN split-K GEMM out[Ka,Nb] = sum_m A[m,ka] B[m,nb] -- every weight gradient;
+//   * column sums (bias gradients), ReLU mask, row gather / scatter-add, copy probe.
+//
+// Layout facts used (cdna_hip_programming.md section 3): for mfma_f32_32x32x2f32 lane l supplies
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of lane l is
+// C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+#include "common.hpp"
+#include "gemm_panel.hpp"
+
+namespace temp {
+
+// ---------------------------------------------------------------------------------------------
+// Row-panel GEMM.  A wave owns 32 rows x (NT*32) columns; the 4 waves of a block own 4
+// consecutive row tiles and share the B chunk staged in LDS.  A is read straight from global
+// memory: the MFMA sums over k in any order, so lane (row i, half hh) loads ONE float4 holding
+// k = k0 + 4*hh .. +3 and feeds its 4 components to 4 consecutive MFMAs whose B operand uses the
+// same k -- a 16-byte load per lane per 4 MFMAs and no LDS traffic for A.
+// ---------------------------------------------------------------------------------------------
+struct EpiAddBiasAct {
+  const float* addend; int ld_add; const int32_t* row_mask; const float* bias; int act; float* out; int ldo;
+  __device__ __forceinline__ void operator()(int row, int col, float acc) const {
+    float v = acc;
+    if (addend && (!row_mask || row_mask[row] > 0)) v += addend[(size_t)row * ld_add + col];
+    if (bias) v += bias[col];
+    if (act == TEMP_ACT_RELU) v = fmaxf(v, 0.f);
+    out[(size_t)row * ldo + col] = v;
+  }
+};
+
+int gemm_add_bias_act(int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
+                      const float* addend, int ld_add, const int32_t* row_mask, const float* bias, int act, float* out, int ldo,
+                      hipStream_t st) {
+  EpiAddBiasAct epi{addend, ld_add, row_mask, bias, act, out, ldo};
+  return launch_gemm_panel(M, N, K, A, lda, a_idx, B, ldb, trans_b, epi, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN split-K: out[Ka,Nb] = sum_m A[m,ka] * B[m,nb].  A wave owns a 32 x (NT*32) output tile over
+// one slice of m; both operands are read row-wise (coalesced 128 B per half wave), no LDS.
+// Slices are written to a workspace and summed in slice order by k_reduce_slices.
+// ---------------------------------------------------------------------------------------------
+#define TN_NT 4
+__global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
+                                                 const float* __restrict__ B, int ldb, int rows_per_slice, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const int ka0 = (blockIdx.x * 4 + wave) * 32;
+  const int nb0 = blockIdx.y * (TN_NT * 32);
+  const int slice = blockIdx.z;
+  if (ka0 >= Ka) return;
+  const int mbeg = slice * rows_per_slice, mend = min(M, mbeg + rows_per_slice);
+  f32x16 acc[TN_NT];
+#pragma unroll
+  for (int t = 0; t < TN_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool a_ok = ka0 + li < Ka;
+  bool b_ok[TN_NT];
+#pragma unroll
+  for (int t = 0; t < TN_NT; ++t) b_ok[t] = nb0 + t * 32 + li < Nb;
+  int ntv = (Nb - nb0 + 31) / 32;
+  if (ntv > TN_NT) ntv = TN_NT;
+  constexpr int U = 4;
+  for (int m = mbeg; m < mend; m += 2 * U) {
+    float av[U], bv[U][TN_NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = m + 2 * u + hh;
+      const bool rok = row < mend;
+      av[u] = (rok && a_ok) ? A[(size_t)row * lda + ka0 + li] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TN_NT; ++t) bv[u][t] = (rok && b_ok[t] && t < ntv) ? B[(size_t)row * ldb + nb0 + t * 32 + li] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TN_NT; ++t)
+        if (t < ntv) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+  }
+  float* p = part + (size_t)slice * Ka * Nb;
+#pragma unroll
+  for (int t = 0; t < TN_NT; ++t) {
+    if (t < ntv) {
+      const int col = nb0 + t * 32 + li;
+      if (col < Nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ka0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (row < Ka) p[(size_t)row * Nb + col] = acc[t][r];
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_reduce_slices(int n_slices, size_t elems, int width, const float* __restrict__ part,
+                                                       float* __restrict__ out, int ldo) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = 0; s < n_slices; ++s) acc += part[(size_t)s * elems + i];
+    const size_t r = i / width, c = i - r * width;
+    out[r * ldo + c] = acc;
+  }
+}
+
+static int tn_slices(int M, int Ka, int Nb) {
+  const long long tiles = (long long)ceil_div(ceil_div(Ka, 32), 4) * ceil_div(Nb, TN_NT * 32);
+  long long s = 1024 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  const long long max_s = (M + 63) / 64;      // at least 64 rows per slice
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+size_t gemm_tn_workspace(int M, int Ka, int Nb) {
+  return align_up((size_t)tn_slices(M, Ka, Nb) * Ka * Nb * sizeof(float), 256);
+}
+
+int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo, void* ws, size_t ws_bytes,
+            hipStream_t st) {
+  if (Ka <= 0 || Nb <= 0) return TEMP_OK;
+  const int S = tn_slices(M, Ka, Nb);
+  if (ws_bytes < (size_t)S * Ka * Nb * sizeof(float) || !ws) return TEMP_E_WORKSPACE;
+  int rps = ceil_div(M > 0 ? M : 1, S);
+  rps = (rps + 7) / 8 * 8;
+  dim3 grid(ceil_div(ceil_div(Ka, 32), 4), ceil_div(Nb, TN_NT * 32), S);
+  hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, (float*)ws);
+  const size_t elems = (size_t)Ka * Nb;
+  int rg = ceil_div((long long)elems, 256);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(k_reduce_slices, dim3(rg), dim3(256), 0, st, S, elems, Nb, (const float*)ws, out, ldo);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums: block (cx, cy) sums rows [cy*RPB, ...) of a 64-column strip into a partial, then
+// k_reduce_slices adds the partials in order.
+// ---------------------------------------------------------------------------------------------
+#define CS_RPB 512
+__global__ void __launch_bounds__(256) k_colsum_part(int rows, int cols, const float* __restrict__ X, int ldx, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * CS_RPB, r1 = min(rows, r0 + CS_RPB);
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = r0 + w; r < r1; r += 4) acc += X[(size_t)r * ldx + c];
+  red[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < cols) part[(size_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+size_t colsum_workspace(int rows, int cols) { return align_up((size_t)ceil_div(rows > 0 ? rows : 1, CS_RPB) * cols * sizeof(float), 256); }
+
+int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (cols <= 0) return TEMP_OK;
+  const int nb = ceil_div(rows > 0 ? rows : 1, CS_RPB);
+  if (!ws || ws_bytes < (size_t)nb * cols * sizeof(float)) return TEMP_E_WORKSPACE;
+  hipLaunchKernelGGL(k_colsum_part, dim3(ceil_div(cols, 64), nb), dim3(256), 0, st, rows, cols, X, ldx, (float*)ws);
+  hipLaunchKernelGGL(k_reduce_slices, dim3(ceil_div(cols, 256)), dim3(256), 0, st, nb, (size_t)cols, cols, (const float*)ws, out, cols);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_relu_bwd(size_t n4, const float4* __restrict__ y, const float4* __restrict__ dy,
+                                                  float4* __restrict__ dz) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = y[i], g = dy[i];
+    dz[i] = make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
+  }
+}
+int relu_bwd(size_t n, const float* y, const float* dy, float* dz, hipStream_t st) {
+  if (n == 0) return TEMP_OK;
+  if (n % 4) return TEMP_E_UNSUPPORTED;
+  const size_t n4 = n / 4;
+  int grid = ceil_div((long long)n4, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_relu_bwd, dim3(grid), dim3(256), 0, st, n4, (const float4*)y, (const float4*)dy, (float4*)dz);
+  return launch_status();
+}
+
+__global__ void __launch_bounds__(256) k_gather_rows(int n, int d4, const float4* __restrict__ table, const int32_t* __restrict__ idx,
+                                                     float4* __restrict__ out) {
+  const size_t total = (size_t)n * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / d4), c = (int)(i - (size_t)r * d4);
+    const int s = idx[r];
+    out[i] = (s >= 0) ? table[(size_t)s * d4 + c] : zero4();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scatter_add_rows(int n, int d, const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ table) {
+  const size_t total = (size_t)n * d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / d), c = (int)(i - (size_t)r * d);
+    const int s = idx[r];
+    if (s >= 0) atomicAdd(table + (size_t)s * d + c, src[i]);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_copy(size_t n16, const float4* __restrict__ src, float4* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace temp
+
+using namespace temp;
+
+extern "C" {
+
+int temp_abi_version(void) { return TEMP_ABI_VERSION; }
+
+const char* temp_error_string(int code) {
+  switch (code) {
+    case TEMP_OK: return "ok";
+    case TEMP_E_BADARG: return "bad argument (NULL, negative or inconsistent)";
+    case TEMP_E_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    case TEMP_E_WORKSPACE: return "workspace missing or too small";
+    case TEMP_E_LAUNCH: return "HIP launch failure";
+    default: return "unknown error";
+  }
+}
+
+int temp_rgcn_isolated_fwd(int n, int d, const float* e, const float* loop_w, const float* bias, int act, float* out, void* stream) {
+  if (n < 0 || d <= 0 || !loop_w || (n > 0 && (!e || !out))) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  return gemm_add_bias_act(n, d, d, e, d, nullptr, loop_w, d, 0, e, d, nullptr, bias, act, out, d, (hipStream_t)stream);
+}
+
+size_t temp_rgcn_isolated_bwd_workspace(int n, int d) {
+  if (n < 0 || d <= 0) return 0;
+  return align_up((size_t)n * d * sizeof(float), 256) + gemm_tn_workspace(n, d, d) + colsum_workspace(n, d) + 256;
+}
+
+int temp_rgcn_isolated_bwd(int n, int d, const float* e, const float* out, const float* d_out_grad, const float* loop_w, int has_bias,
+                           int act, float* d_e, float* d_loop_w, float* d_bias, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n < 0 || d <= 0 || !loop_w || !d_loop_w || (n > 0 && (!e || !d_out_grad || !d_e))) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (act == TEMP_ACT_RELU && !out) return TEMP_E_BADARG;
+  if (has_bias && !d_bias) return TEMP_E_BADARG;
+  if (!workspace || workspace_bytes < temp_rgcn_isolated_bwd_workspace(n, d)) return TEMP_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  float* dzbuf = (float*)base;
+  base += align_up((size_t)n * d * sizeof(float), 256);
+  void* tn = base;
+  const size_t tnb = gemm_tn_workspace(n, d, d);
+  base += tnb;
+  void* cs = base;
+  const size_t csb = colsum_workspace(n, d);
+  const float* dz = d_out_grad;
+  int rc;
+  if (act == TEMP_ACT_RELU) {
+    rc = relu_bwd((size_t)n * d, out, d_out_grad, dzbuf, st);
+    if (rc) return rc;
+    dz = dzbuf;
+  }
+  // d_e = dz + dz . loop_w^T
+  rc = gemm_add_bias_act(n, d, d, dz, d, nullptr, loop_w, d, 1, dz, d, nullptr, nullptr, TEMP_ACT_NONE, d_e, d, st);
+  if (rc) return rc;
+  rc = gemm_tn(n, d, d, e, d, dz, d, d_loop_w, d, tn, tnb, st);
+  if (rc) return rc;
+  if (has_bias) rc = colsum(n, d, dz, d, d_bias, cs, csb, st);
+  return rc;
+}
+
+int temp_gather_rows(int n, int d, const float* table, const int32_t* idx, float* out, void* stream) {
+  if (n < 0 || d <= 0 || (n > 0 && (!table || !idx || !out))) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (n == 0) return TEMP_OK;
+  int grid = ceil_div((long long)n * (d / 4), 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, d / 4, (const float4*)table, idx, (float4*)out);
+  return launch_status();
+}
+
+int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, float* table, void* stream) {
+  if (n < 0 || d <= 0 || (n > 0 && (!table || !idx || !src))) return TEMP_E_BADARG;
+  if (n == 0) return TEMP_OK;
+  int grid = ceil_div((long long)n * d, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, d, src, idx, table);
+  return launch_status();
+}
+
+int temp_copy_probe(const void* src, void* dst, size_t bytes, void* stream) {
+  if (!src || !dst || bytes % 16) return TEMP_E_BADARG;
+  if (bytes == 0) return TEMP_OK;
+  hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, (hipStream_t)stream, bytes / 16, (const float4*)src, (float4*)dst);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,488 @@
+// RGCN message passing for gfx950: chunked segmented reduce over sorted edge views.
+//
+// Replaces RGCNLayer.msg_func / propagate / apply_func (models/RGCN.py:91-104 of the TeMP
+// reference) and their autograd.  One wave owns one chunk (<= 64 edges of a single segment).
+// Lanes are split into 64/LPR groups of LPR lanes; a group owns one edge at a time and each lane
+// of the group owns 4 consecutive features (float4), so a feature row is one coalesced
+// LPR*16-byte read.  The per-relation block-diagonal weight row is read from LDS when the whole
+// table fits in 64 KB (GDELT: 40 rows x 1600 B), else through L2.  No atomics: segments that span
+// several chunks go through ordered partial slots + a fix-up pass, so results are deterministic.
+#include "common.hpp"
+
+namespace temp {
+
+enum { MODE_FWD = 0, MODE_DX = 1 };
+
+// acc += x . BD-block(s) (MODE_FWD) or acc += x . BD-block(s)^T (MODE_DX) for the 4 features of a lane.
+template <int S, int MODE>
+__device__ __forceinline__ void block_mac(float4& acc, const float4 x, const float4* w, const float c) {
+  if (S == 1) {
+    acc.x = fmaf(c * x.x, w[0].x, acc.x);
+    acc.y = fmaf(c * x.y, w[0].y, acc.y);
+    acc.z = fmaf(c * x.z, w[0].z, acc.z);
+    acc.w = fmaf(c * x.w, w[0].w, acc.w);
+  } else if (S == 2) {
+    // w[0] = block b: (w00 w01 w10 w11), w[1] = block b+1
+    const float x0 = c * x.x, x1 = c * x.y, x2 = c * x.z, x3 = c * x.w;
+    if (MODE == MODE_FWD) {
+      acc.x = fmaf(x0, w[0].x, fmaf(x1, w[0].z, acc.x));
+      acc.y = fmaf(x0, w[0].y, fmaf(x1, w[0].w, acc.y));
+      acc.z = fmaf(x2, w[1].x, fmaf(x3, w[1].z, acc.z));
+      acc.w = fmaf(x2, w[1].y, fmaf(x3, w[1].w, acc.w));
+    } else {
+      acc.x = fmaf(x0, w[0].x, fmaf(x1, w[0].y, acc.x));
+      acc.y = fmaf(x0, w[0].z, fmaf(x1, w[0].w, acc.y));
+      acc.z = fmaf(x2, w[1].x, fmaf(x3, w[1].y, acc.z));
+      acc.w = fmaf(x2, w[1].z, fmaf(x3, w[1].w, acc.w));
+    }
+  } else {  // S == 4: w[i] = row i of the 4x4 block
+    const float4 xs = scale4(x, c);
+    if (MODE == MODE_FWD) {
+      acc = fma4(xs.x, w[0], acc);
+      acc = fma4(xs.y, w[1], acc);
+      acc = fma4(xs.z, w[2], acc);
+      acc = fma4(xs.w, w[3], acc);
+    } else {
+      acc.x += dot4(xs, w[0]);
+      acc.y += dot4(xs, w[1]);
+      acc.z += dot4(xs, w[2]);
+      acc.w += dot4(xs, w[3]);
+    }
+  }
+}
+
+// Stage the weight table into LDS, permuted so that the j-th float4 of every lane of a feature row
+// is contiguous (conflict-free ds_read_b128):  Ws4[(r*S + j)*D4 + lr]  <-  W4[r*D4*S + lr*S + j].
+template <int S>
+__device__ __forceinline__ void stage_weights(float4* Ws4, const float* W, int n_rows, int D4) {
+  const int total = n_rows * D4 * S;
+  const float4* W4 = reinterpret_cast<const float4*>(W);
+  for (int q = threadIdx.x; q < total; q += blockDim.x) {
+    const int r = q / (D4 * S);
+    const int rem = q - r * (D4 * S);
+    const int lr = rem / S, j = rem - lr * S;
+    Ws4[(r * S + j) * D4 + lr] = W4[q];
+  }
+}
+
+// One kernel for the forward aggregation (view = by-dst, a = src, b = rel, post-scale nnorm[seg]^2)
+// and for d/dh (view = by-src, a = dst, b = rel, per-edge scale nnorm[dst]^2, transposed blocks).
+template <int S, int MODE, bool W_LDS>
+__global__ void __launch_bounds__(1024) k_rgcn_agg(TempEdgeView v, const float* __restrict__ feat, int ldf,
+                                                   const int32_t* __restrict__ feat_ids, const float* __restrict__ W,
+                                                   int n_rel_rows, const float* __restrict__ nnorm, int D, int lpr,
+                                                   float* __restrict__ out, float* __restrict__ partial) {
+  extern __shared__ float4 Ws4[];
+  const int D4 = D >> 2;
+  if (W_LDS) {
+    stage_weights<S>(Ws4, W, n_rel_rows, D4);
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lr = lane & (lpr - 1), gi = lane / lpr, epw = 64 / lpr;
+  const int f = lr << 2;
+  const bool active = f < D;
+  ItemRange it = xcd_items(v.n_chunks, wpb);
+  for (int c = it.beg + wave; c < it.end; c += it.stride) {
+    const int seg = v.chunk_seg[c], beg = v.chunk_beg[c], cnt = v.chunk_end[c] - beg, slot = v.chunk_slot[c];
+    int a_l = 0, b_l = 0;
+    float s_l = 1.f;
+    if (lane < cnt) {
+      a_l = v.a[beg + lane];
+      b_l = v.b[beg + lane];
+      if (MODE == MODE_DX) { const float nn = nnorm[a_l]; s_l = nn * nn; }
+      if (feat_ids) a_l = feat_ids[a_l];
+    }
+    float4 acc = zero4();
+    constexpr int U = 4;
+    for (int e0 = 0; e0 < cnt; e0 += epw * U) {
+      float4 xv[U];
+      int rr[U];
+      float sc[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * epw + gi;
+        ok[u] = (e < cnt) && active;
+        const int row = __shfl(a_l, e & 63);
+        rr[u] = __shfl(b_l, e & 63);
+        sc[u] = __shfl(s_l, e & 63);
+        xv[u] = ok[u] ? ld4(feat + (size_t)row * ldf + f) : zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          float4 w[S];
+          if (W_LDS) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) w[j] = Ws4[(rr[u] * S + j) * D4 + lr];
+          } else {
+            const float* wr = W + (size_t)rr[u] * (D * S) + f * S;
+#pragma unroll
+            for (int j = 0; j < S; ++j) w[j] = ld4(wr + 4 * j);
+          }
+          block_mac<S, MODE>(acc, xv[u], w, sc[u]);
+        }
+      }
+    }
+    for (int off = lpr; off < 64; off <<= 1) acc = add4(acc, shfl_xor4(acc, off));
+    if (gi == 0 && active) {
+      if (MODE == MODE_FWD) { const float nn = nnorm[seg]; acc = scale4(acc, nn * nn); }
+      float* dst = (slot < 0) ? out + (size_t)seg * D + f : partial + (size_t)slot * D + f;
+      st4(dst, acc);
+    }
+  }
+}
+
+// Generic (any si, so) scalar-lane variant; slow, for shapes outside the fast path.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rgcn_agg_generic(TempEdgeView v, const float* __restrict__ feat, int ldf,
+                                                          const int32_t* __restrict__ feat_ids, const float* __restrict__ W,
+                                                          const float* __restrict__ nnorm, int d_in, int d_out, int si, int so,
+                                                          float* __restrict__ out, float* __restrict__ partial) {
+  // MODE_FWD: result width d_out, input width d_in.  MODE_DX: result width d_in, input (grad) width d_out.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int wres = (MODE == MODE_FWD) ? d_out : d_in;
+  const int wrow = (d_in / si) * si * so;
+  for (int c = blockIdx.x * wpb + wave; c < v.n_chunks; c += gridDim.x * wpb) {
+    const int seg = v.chunk_seg[c], beg = v.chunk_beg[c], end = v.chunk_end[c], slot = v.chunk_slot[c];
+    for (int o = lane; o < wres; o += 64) {
+      float acc = 0.f;
+      for (int e = beg; e < end; ++e) {
+        int row = v.a[e];
+        const int r = v.b[e];
+        float c2 = 1.f;
+        if (MODE == MODE_DX) { const float nn = nnorm[row]; c2 = nn * nn; }
+        if (feat_ids) row = feat_ids[row];
+        const float* x = feat + (size_t)row * ldf;
+        const float* w = W + (size_t)r * wrow;
+        if (MODE == MODE_FWD) {
+          const int b = o / so, oo = o - b * so;
+          for (int i = 0; i < si; ++i) acc = fmaf(x[b * si + i], w[b * si * so + i * so + oo], acc);
+        } else {
+          const int b = o / si, ii = o - b * si;
+          float t = 0.f;
+          for (int q = 0; q < so; ++q) t = fmaf(x[b * so + q], w[b * si * so + ii * so + q], t);
+          acc = fmaf(c2, t, acc);
+        }
+      }
+      if (MODE == MODE_FWD) { const float nn = nnorm[seg]; acc *= nn * nn; }
+      float* dst = (slot < 0) ? out + (size_t)seg * wres : partial + (size_t)slot * wres;
+      dst[o] = acc;
+    }
+  }
+}
+
+// out[seg] = sum of its partial slots, in slot order (deterministic).  One wave per fix entry.
+__global__ void __launch_bounds__(256) k_fixup(int n_fix, const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ fix_slot,
+                                               const int32_t* __restrict__ fix_cnt, const float* __restrict__ partial, int width,
+                                               float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  for (int i = blockIdx.x * wpb + wave; i < n_fix; i += gridDim.x * wpb) {
+    const int seg = fix_seg[i], s0 = fix_slot[i], cnt = fix_cnt[i];
+    for (int f = lane; f < width; f += 64) {
+      float acc = 0.f;
+      for (int s = 0; s < cnt; ++s) acc += partial[(size_t)(s0 + s) * width + f];
+      out[(size_t)seg * width + f] = acc;
+    }
+  }
+}
+
+// d/dweight: view = by-rel (a = src node, b = dst node).  Per edge the lane takes its 4 features of
+// x[src] and of c*dz[dst] and accumulates the S x S outer products of its blocks in registers.
+template <int S>
+__global__ void __launch_bounds__(256) k_rgcn_dw(TempEdgeView v, const float* __restrict__ x, const float* __restrict__ dz,
+                                                 const float* __restrict__ nnorm, int D, int lpr,
+                                                 float* __restrict__ dW, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lr = lane & (lpr - 1), gi = lane / lpr, epw = 64 / lpr;
+  const int f = lr << 2;
+  const bool active = f < D;
+  const int wrow = D * S;
+  ItemRange it = xcd_items(v.n_chunks, wpb);
+  for (int c = it.beg + wave; c < it.end; c += it.stride) {
+    const int seg = v.chunk_seg[c], beg = v.chunk_beg[c], cnt = v.chunk_end[c] - beg, slot = v.chunk_slot[c];
+    int a_l = 0, b_l = 0;
+    float s_l = 0.f;
+    if (lane < cnt) {
+      a_l = v.a[beg + lane];
+      b_l = v.b[beg + lane];
+      const float nn = nnorm[b_l];
+      s_l = nn * nn;
+    }
+    float4 acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = zero4();
+    constexpr int U = 2;
+    for (int e0 = 0; e0 < cnt; e0 += epw * U) {
+      float4 xv[U], gv[U];
+      float sc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * epw + gi;
+        const bool ok = (e < cnt) && active;
+        const int src = __shfl(a_l, e & 63), dst = __shfl(b_l, e & 63);
+        sc[u] = __shfl(s_l, e & 63);
+        xv[u] = ok ? ld4(x + (size_t)src * D + f) : zero4();
+        gv[u] = ok ? ld4(dz + (size_t)dst * D + f) : zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float4 g = scale4(gv[u], sc[u]);
+        const float4 xx = xv[u];
+        if (S == 1) {
+          acc[0].x = fmaf(xx.x, g.x, acc[0].x);
+          acc[0].y = fmaf(xx.y, g.y, acc[0].y);
+          acc[0].z = fmaf(xx.z, g.z, acc[0].z);
+          acc[0].w = fmaf(xx.w, g.w, acc[0].w);
+        } else if (S == 2) {
+          acc[0].x = fmaf(xx.x, g.x, acc[0].x);  // blk0 w00
+          acc[0].y = fmaf(xx.x, g.y, acc[0].y);  //      w01
+          acc[0].z = fmaf(xx.y, g.x, acc[0].z);  //      w10
+          acc[0].w = fmaf(xx.y, g.y, acc[0].w);  //      w11
+          acc[1].x = fmaf(xx.z, g.z, acc[1].x);  // blk1
+          acc[1].y = fmaf(xx.z, g.w, acc[1].y);
+          acc[1].z = fmaf(xx.w, g.z, acc[1].z);
+          acc[1].w = fmaf(xx.w, g.w, acc[1].w);
+        } else {
+          acc[0] = fma4(xx.x, g, acc[0]);
+          acc[1] = fma4(xx.y, g, acc[1]);
+          acc[2] = fma4(xx.z, g, acc[2]);
+          acc[3] = fma4(xx.w, g, acc[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+      for (int off = lpr; off < 64; off <<= 1) acc[j] = add4(acc[j], shfl_xor4(acc[j], off));
+    if (gi == 0 && active) {
+      float* dst = ((slot < 0) ? dW + (size_t)seg * wrow : partial + (size_t)slot * wrow) + f * S;
+#pragma unroll
+      for (int j = 0; j < S; ++j) st4(dst + 4 * j, acc[j]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rgcn_dw_generic(TempEdgeView v, const float* __restrict__ x, const float* __restrict__ dz,
+                                                         const float* __restrict__ nnorm, int d_in, int d_out, int si, int so,
+                                                         float* __restrict__ dW, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int wrow = (d_in / si) * si * so;
+  for (int c = blockIdx.x * wpb + wave; c < v.n_chunks; c += gridDim.x * wpb) {
+    const int seg = v.chunk_seg[c], beg = v.chunk_beg[c], end = v.chunk_end[c], slot = v.chunk_slot[c];
+    for (int q = lane; q < wrow; q += 64) {
+      const int b = q / (si * so), rem = q - b * si * so, i = rem / so, o = rem - i * so;
+      float acc = 0.f;
+      for (int e = beg; e < end; ++e) {
+        const int src = v.a[e], dst = v.b[e];
+        const float nn = nnorm[dst];
+        acc = fmaf(x[(size_t)src * d_in + b * si + i], nn * nn * dz[(size_t)dst * d_out + b * so + o], acc);
+      }
+      float* d = (slot < 0) ? dW + (size_t)seg * wrow : partial + (size_t)slot * wrow;
+      d[q] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int pick_lpr(int D) {
+  int q = D / 4, l = 1;
+  while (l < q) l <<= 1;
+  return l;
+}
+static bool fast_shape(int d_in, int d_out, int num_bases, int* S) {
+  if (d_in != d_out || d_in % 4 != 0 || d_in > 256 || num_bases <= 0 || d_in % num_bases != 0) return false;
+  const int s = d_in / num_bases;
+  if (s != 1 && s != 2 && s != 4) return false;
+  *S = s;
+  return true;
+}
+static bool view_ok(const TempEdgeView& v) {
+  if (v.n_chunks < 0 || v.n_edges < 0 || v.n_partial < 0 || v.n_fix < 0) return false;
+  if (v.n_chunks > 0 && (!v.a || !v.b || !v.chunk_seg || !v.chunk_beg || !v.chunk_end || !v.chunk_slot)) return false;
+  if (v.n_fix > 0 && (!v.fix_seg || !v.fix_slot || !v.fix_cnt)) return false;
+  return true;
+}
+
+template <int S, int MODE>
+static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
+                       const float* nnorm, int D, float* out, float* partial, hipStream_t st) {
+  const int lpr = pick_lpr(D);
+  const size_t wbytes = (size_t)n_rel_rows * D * S * sizeof(float);
+  if (wbytes <= 65536 && v.n_chunks >= 4096) {
+    // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
+    const int grid = 512;
+    hipLaunchKernelGGL((k_rgcn_agg<S, MODE, true>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
+                       lpr, out, partial);
+  } else {
+    int grid = (v.n_chunks + 3) / 4;
+    grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
+    hipLaunchKernelGGL((k_rgcn_agg<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D, lpr,
+                       out, partial);
+  }
+}
+
+static void launch_fixup(const TempEdgeView& v, const float* partial, int width, float* out, hipStream_t st) {
+  if (v.n_fix <= 0) return;
+  int grid = (v.n_fix + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_fixup, dim3(grid), dim3(256), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
+}
+
+// forward / dx aggregation into `out` rows of segments that have edges (others untouched)
+static int run_agg(int mode, const TempEdgeView& v, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
+                   const float* nnorm, int d_in, int d_out, int num_bases, float* out, float* partial, hipStream_t st) {
+  if (v.n_chunks == 0) return TEMP_OK;
+  int S = 0;
+  const int wres = (mode == MODE_FWD) ? d_out : d_in;
+  if (fast_shape(d_in, d_out, num_bases, &S)) {
+#define TEMP_AGG(SS)                                                                                   \
+  if (mode == MODE_FWD) launch_agg<SS, MODE_FWD>(v, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st); \
+  else launch_agg<SS, MODE_DX>(v, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st);
+    if (S == 1) { TEMP_AGG(1) } else if (S == 2) { TEMP_AGG(2) } else { TEMP_AGG(4) }
+#undef TEMP_AGG
+  } else {
+    const int si = d_in / num_bases, so = d_out / num_bases;
+    int grid = (v.n_chunks + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    if (mode == MODE_FWD)
+      hipLaunchKernelGGL((k_rgcn_agg_generic<MODE_FWD>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, nnorm, d_in, d_out, si, so,
+                         out, partial);
+    else
+      hipLaunchKernelGGL((k_rgcn_agg_generic<MODE_DX>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, nnorm, d_in, d_out, si, so,
+                         out, partial);
+  }
+  launch_fixup(v, partial, wres, out, st);
+  return launch_status();
+}
+
+static int run_dw(const TempEdgeView& v, const float* x, const float* dz, const float* nnorm, int d_in, int d_out, int num_bases,
+                  int n_rel_rows, float* dW, float* partial, hipStream_t st) {
+  const int si = d_in / num_bases, so = d_out / num_bases;
+  const size_t wrow = (size_t)num_bases * si * so;
+  if (hipMemsetAsync(dW, 0, (size_t)n_rel_rows * wrow * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+  if (v.n_chunks == 0) return TEMP_OK;
+  int S = 0;
+  if (fast_shape(d_in, d_out, num_bases, &S)) {
+    const int lpr = pick_lpr(d_in);
+    int grid = (v.n_chunks + 3) / 4;
+    grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
+    if (S == 1) hipLaunchKernelGGL((k_rgcn_dw<1>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
+    else if (S == 2) hipLaunchKernelGGL((k_rgcn_dw<2>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
+    else hipLaunchKernelGGL((k_rgcn_dw<4>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
+  } else {
+    int grid = (v.n_chunks + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_rgcn_dw_generic, dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, d_out, si, so, dW, partial);
+  }
+  launch_fixup(v, partial, (int)wrow, dW, st);
+  return launch_status();
+}
+
+}  // namespace temp
+
+using namespace temp;
+
+extern "C" {
+
+size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out) {
+  if (!g) return 0;
+  return align_up((size_t)g->by_dst.n_partial * d_out * sizeof(float), 256) + 256;
+}
+
+int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids, int d_in, int d_out, int num_bases, int n_rel_rows,
+                  const float* weight, const float* loop_w, const float* bias, int act, float* out, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  if (!g || !h || !weight || !loop_w || !out || d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
+  if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
+  if (g->n_nodes < 0 || !view_ok(g->by_dst) || (g->n_nodes > 0 && (!g->nnorm || !g->in_deg))) return TEMP_E_BADARG;
+  if (act != TEMP_ACT_NONE && act != TEMP_ACT_RELU) return TEMP_E_BADARG;
+  if (workspace_bytes < temp_rgcn_fwd_workspace(g, d_out) || (!workspace && g->by_dst.n_partial > 0)) return TEMP_E_WORKSPACE;
+  if (g->n_nodes == 0) return TEMP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  int rc = run_agg(MODE_FWD, g->by_dst, h, d_in, h_ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
+  if (rc) return rc;
+  // out = act( (in_deg>0 ? out : 0) + bias + h . loop_w )       (MFMA fp32 GEMM, fused epilogue)
+  return gemm_add_bias_act(g->n_nodes, d_out, d_in, h, d_in, h_ids, loop_w, d_out, 0, out, d_out, g->in_deg, bias, act, out, d_out, st);
+}
+
+struct BwdWs {
+  float* dz;        // [n, d_out]  (only when act == relu)
+  float* part_dx;   // by_src partial slots [n_partial, d_in]
+  float* part_dw;   // by_rel partial slots [n_partial, wrow]
+  void* tn;         // gemm_tn workspace
+  size_t tn_bytes;
+  void* cs;         // colsum workspace
+  size_t cs_bytes;
+  size_t total;
+};
+static BwdWs carve_bwd(const TempGraph* g, int d_in, int d_out, int num_bases, char* base) {
+  BwdWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+  const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
+  w.dz = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
+  w.part_dx = (float*)take((size_t)g->by_src.n_partial * d_in * sizeof(float));
+  w.part_dw = (float*)take((size_t)g->by_rel.n_partial * wrow * sizeof(float));
+  w.tn_bytes = gemm_tn_workspace(g->n_nodes, d_in, d_out);
+  w.tn = take(w.tn_bytes);
+  w.cs_bytes = colsum_workspace(g->n_nodes, d_out);
+  w.cs = take(w.cs_bytes);
+  w.total = off + 256;
+  return w;
+}
+
+size_t temp_rgcn_bwd_workspace(const TempGraph* g, int d_in, int d_out, int num_bases, int n_rel_rows) {
+  (void)n_rel_rows;
+  if (!g || num_bases <= 0 || d_in <= 0 || d_out <= 0) return 0;
+  return carve_bwd(g, d_in, d_out, num_bases, nullptr).total;
+}
+
+int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const float* d_out_grad, int d_in, int d_out, int num_bases,
+                  int n_rel_rows, const float* weight, const float* loop_w, int has_bias, int act, float* d_h, float* d_weight,
+                  float* d_loop_w, float* d_bias, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !h || !d_out_grad || !weight || !loop_w || !d_h || !d_weight || !d_loop_w) return TEMP_E_BADARG;
+  if (d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
+  if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
+  if (act == TEMP_ACT_RELU && !out) return TEMP_E_BADARG;
+  if (has_bias && !d_bias) return TEMP_E_BADARG;
+  if (!view_ok(g->by_src) || !view_ok(g->by_rel) || (g->n_nodes > 0 && (!g->nnorm || !g->out_deg))) return TEMP_E_BADARG;
+  if (g->by_rel.n_seg != n_rel_rows) return TEMP_E_BADARG;
+  if (!workspace || workspace_bytes < temp_rgcn_bwd_workspace(g, d_in, d_out, num_bases, n_rel_rows)) return TEMP_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
+  if (g->n_nodes == 0) {
+    if (hipMemsetAsync(d_weight, 0, (size_t)n_rel_rows * wrow * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    if (hipMemsetAsync(d_loop_w, 0, (size_t)d_in * d_out * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    if (has_bias && hipMemsetAsync(d_bias, 0, (size_t)d_out * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    return TEMP_OK;
+  }
+  BwdWs w = carve_bwd(g, d_in, d_out, num_bases, (char*)workspace);
+  const float* dz = d_out_grad;
+  int rc;
+  if (act == TEMP_ACT_RELU) {
+    rc = relu_bwd((size_t)g->n_nodes * d_out, out, d_out_grad, w.dz, st);
+    if (rc) return rc;
+    dz = w.dz;
+  }
+  // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
+  rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
+  if (rc) return rc;
+  rc = gemm_add_bias_act(g->n_nodes, d_in, d_out, dz, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
+                         d_h, d_in, st);
+  if (rc) return rc;
+  rc = run_dw(g->by_rel, h, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+  if (rc) return rc;
+  rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
+  if (rc) return rc;
+  if (has_bias) {
+    rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
+    if (rc) return rc;
+  }
+  return TEMP_OK;
+}
+
+}  // extern "C"

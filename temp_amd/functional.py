@@ -1,0 +1,115 @@
+"""torch.autograd wrappers around the HIP kernels (through temp_amd.backend).
+
+Each Function is one reference op with its hand-written backward:
+  rgcn_layer      RGCNLayer.forward            models/RGCN.py:53-104
+  rgcn_isolated   RGCNLayer.forward_isolated   models/RGCN.py:78-89
+  gru_step        decay + single GRU step      models/RRGCN.py:79-85, models/GRU_cell.py:18-30
+  gather_rows     ent_embeds[id] / history gather   models/DynamicRGCN.py:41-43,93
+"""
+import torch
+
+from . import _lib
+from .backend import get_backend
+
+ACTS = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU}
+
+
+class _RGCNLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, weight, loop_w, bias, dg, num_bases, act):
+        be = get_backend()
+        out = be.rgcn_fwd(dg, h, None, weight, loop_w, bias, num_bases, act)
+        ctx.save_for_backward(h, weight, loop_w, out)
+        ctx.dg, ctx.num_bases, ctx.act, ctx.has_bias = dg, num_bases, act, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        h, weight, loop_w, out = ctx.saved_tensors
+        d_h, d_w, d_loop, d_bias = get_backend().rgcn_bwd(ctx.dg, h, out, d_out.contiguous(), weight, loop_w, ctx.has_bias,
+                                                          ctx.num_bases, ctx.act)
+        return d_h, d_w, d_loop, d_bias, None, None, None
+
+
+def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None):
+    """out = act(nnorm^2 * sum_in h_u BD(W_r) [+bias] + h W_loop) on a device graph `dg`."""
+    return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act])
+
+
+class _RGCNIsolatedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, loop_w, bias, act):
+        out = get_backend().rgcn_isolated_fwd(e, loop_w, bias, act)
+        ctx.save_for_backward(e, loop_w, out)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        e, loop_w, out = ctx.saved_tensors
+        d_e, d_loop, d_bias = get_backend().rgcn_isolated_bwd(e, out, d_out.contiguous(), loop_w, ctx.has_bias, ctx.act)
+        return d_e, d_loop, d_bias, None
+
+
+def rgcn_isolated(e, loop_w, bias, act=None):
+    """out = act(e + e W_loop [+bias])."""
+    return _RGCNIsolatedFn.apply(e, loop_w, bias, ACTS[act])
+
+
+class _GRUStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, prev, dt, w_ih, w_hh, b_ih, b_hh, decay_w, decay_b, prev_idx, lam, variant):
+        be = get_backend()
+        wb = None
+        if decay_w is not None:
+            wb = torch.cat([decay_w.detach().reshape(1), decay_b.detach().reshape(1)]).contiguous()
+        dt = dt.reshape(-1).contiguous()
+        h_out, saved = be.gru_fwd(x, prev, prev_idx, dt, lam, wb, w_ih, w_hh, b_ih, b_hh, variant)
+        ctx.save_for_backward(x, prev, dt, w_ih, w_hh, saved, wb if wb is not None else x.new_zeros(0))
+        ctx.prev_idx, ctx.lam, ctx.variant, ctx.learn = prev_idx, lam, variant, wb is not None
+        ctx.wshape = decay_w.shape if decay_w is not None else None
+        ctx.bshape = decay_b.shape if decay_b is not None else None
+        return h_out
+
+    @staticmethod
+    def backward(ctx, d_h):
+        x, prev, dt, w_ih, w_hh, saved, wb = ctx.saved_tensors
+        be = get_backend()
+        d_x, d_prev_rows, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_wb = be.gru_bwd(
+            x, prev, ctx.prev_idx, dt, ctx.lam, wb if ctx.learn else None, w_ih, w_hh, saved, d_h.contiguous(), ctx.variant)
+        if ctx.prev_idx is None:
+            d_prev = d_prev_rows
+        else:
+            d_prev = torch.zeros_like(prev)
+            be.scatter_add_rows(d_prev_rows, ctx.prev_idx, d_prev)
+        d_dw = d_wb[0].reshape(ctx.wshape) if ctx.learn else None
+        d_db = d_wb[1].reshape(ctx.bshape) if ctx.learn else None
+        return d_x, d_prev, None, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_dw, d_db, None, None, None
+
+
+def gru_step(x, prev, dt, w_ih, w_hh, b_ih, b_hh, lam, decay=None, prev_idx=None, type1=False):
+    """h' = GRU(x, prev[prev_idx] * exp(-lam*dt))  (learnable decay when `decay` = (weight, bias)).
+    prev_idx: optional int32 tensor, -1 => zero previous state."""
+    dw, db = decay if decay is not None else (None, None)
+    return _GRUStepFn.apply(x, prev, dt, w_ih, w_hh, b_ih, b_hh, dw, db, prev_idx, float(lam),
+                            _lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH)
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = table.shape[0]
+        return get_backend().gather_rows(table, idx)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (idx,) = ctx.saved_tensors
+        d_table = torch.zeros(ctx.rows, d_out.shape[1], dtype=d_out.dtype, device=d_out.device)
+        get_backend().scatter_add_rows(d_out.contiguous(), idx, d_table)
+        return d_table, None
+
+
+def gather_rows(table, idx):
+    """out[i] = table[idx[i]] (idx int32, -1 => zero row); backward scatter-adds."""
+    return _GatherRowsFn.apply(table, idx)

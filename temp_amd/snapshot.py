@@ -1,0 +1,183 @@
+"""Snapshot graphs: the DGL-graph field contract of the TeMP reference as plain arrays, plus the
+sorted/chunked edge views the HIP kernels consume (include/temp_amd.h, TempEdgeView/TempGraph).
+
+Reference contract being mirrored (utils/dataset.py:210-231, models/DynamicRGCN.py:86-93):
+    g.ndata['id'] (n,1) int64 global entity id      g.ndata['norm'] (n,1) f32 = 1/in_deg (inf -> 0)
+    g.edata['type_s'] (E,) int64                    g.edata['norm'] (E,1) f32 = norm of the dst node
+    g.edges() -> (src, dst) local ids               g.ids {local -> global}
+    g.ndata['h'] (n,D) f32 set by the caller before the encoder runs
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def comp_deg_norm(n, dst):
+    """utils/utils.py:74-79: 1/in_degree in fp32, inf -> 0."""
+    in_deg = np.bincount(np.asarray(dst, dtype=np.int64), minlength=n).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        norm = (np.float32(1.0) / in_deg).astype(np.float32)
+    norm[np.isinf(norm)] = 0
+    return norm
+
+
+class Snapshot:
+    """One per-timestamp graph (or a batch of them).  Host-side arrays are numpy; `ndata`/`edata`
+    dictionaries expose the reference's tensor views lazily."""
+
+    def __init__(self, n, src, dst, rel, ids, nnorm=None):
+        self.n = int(n)
+        self.src = np.ascontiguousarray(src, dtype=np.int64).reshape(-1)
+        self.dst = np.ascontiguousarray(dst, dtype=np.int64).reshape(-1)
+        self.rel = np.ascontiguousarray(rel, dtype=np.int64).reshape(-1)
+        self.gids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        assert self.gids.shape[0] == self.n and self.src.shape == self.dst.shape == self.rel.shape
+        self.nnorm = comp_deg_norm(self.n, self.dst) if nnorm is None else np.ascontiguousarray(nnorm, np.float32).reshape(-1)
+        self.ndata = {}          # 'h' is put here by the caller, as in the reference
+        self._dev = {}           # device -> _DeviceGraph
+        self._ids_dict = None
+
+    # ---- reference-style accessors --------------------------------------------------------
+    @property
+    def ids(self):
+        """g.ids: {local index -> global entity id} (utils/dataset.py:225-231)."""
+        if self._ids_dict is None:
+            self._ids_dict = {i: int(v) for i, v in enumerate(self.gids)}
+        return self._ids_dict
+
+    def edges(self):
+        return torch.from_numpy(self.src), torch.from_numpy(self.dst)
+
+    def nodes(self):
+        return torch.arange(self.n)
+
+    def number_of_nodes(self):
+        return self.n
+
+    def number_of_edges(self):
+        return int(self.src.shape[0])
+
+    def local_var(self):
+        """Shallow copy sharing topology and device views (DGL's local_var)."""
+        g = Snapshot.__new__(Snapshot)
+        g.__dict__.update(self.__dict__)
+        g.ndata = dict(self.ndata)
+        return g
+
+    def edge_subgraph(self, idx):
+        """models/DynamicRGCN.py:80-90: keep edges `idx` (that order), same nodes, norms recomputed
+        from the subgraph's in-degrees."""
+        idx = np.asarray(idx, dtype=np.int64)
+        return Snapshot(self.n, self.src[idx], self.dst[idx], self.rel[idx], self.gids)
+
+    # ---- device views -----------------------------------------------------------------------
+    def device_graph(self, device, n_rel_rows):
+        key = (str(device), int(n_rel_rows))
+        dg = self._dev.get(key)
+        if dg is None:
+            dg = _DeviceGraph(self, device, n_rel_rows)
+            self._dev[key] = dg
+        return dg
+
+
+def batch(snapshots):
+    """dgl.batch as used at models/DynamicRGCN.py:92: disjoint union with node-id offsets."""
+    off, src, dst, rel, ids, nn_ = 0, [], [], [], [], []
+    for g in snapshots:
+        src.append(g.src + off)
+        dst.append(g.dst + off)
+        rel.append(g.rel)
+        ids.append(g.gids)
+        nn_.append(g.nnorm)
+        off += g.n
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
+    out = Snapshot(off, cat(src, np.int64), cat(dst, np.int64), cat(rel, np.int64), cat(ids, np.int64), cat(nn_, np.float32))
+    out.node_sizes = [g.n for g in snapshots]
+    return out
+
+
+def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK):
+    """Sort edges by `seg` (stable) and cut every segment into chunks of <= `chunk` edges.
+    Returns a dict of int32 numpy arrays + counts (layout of TempEdgeView)."""
+    seg = np.asarray(seg, dtype=np.int64)
+    order = np.argsort(seg, kind="stable")
+    seg_s = seg[order]
+    counts = np.bincount(seg_s, minlength=n_seg).astype(np.int64)
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    nch = (counts + chunk - 1) // chunk
+    total = int(nch.sum())
+    chunk_seg = np.repeat(np.arange(n_seg, dtype=np.int64), nch)
+    first = np.cumsum(nch) - nch
+    k = np.arange(total, dtype=np.int64) - first[chunk_seg]
+    chunk_beg = ptr[chunk_seg] + k * chunk
+    chunk_end = np.minimum(chunk_beg + chunk, ptr[chunk_seg + 1])
+    multi = nch > 1
+    is_multi = multi[chunk_seg]
+    slot = np.where(is_multi, np.cumsum(is_multi) - 1, -1)
+    fix_seg = np.nonzero(multi)[0]
+    fix_cnt = nch[fix_seg]
+    fix_slot = np.cumsum(fix_cnt) - fix_cnt
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+    return dict(n_seg=int(n_seg), n_edges=int(seg.shape[0]), a=i32(np.asarray(a)[order]), b=i32(np.asarray(b)[order]),
+                n_chunks=total, chunk_seg=i32(chunk_seg), chunk_beg=i32(chunk_beg), chunk_end=i32(chunk_end),
+                chunk_slot=i32(slot), n_partial=int(is_multi.sum()), n_fix=int(fix_seg.shape[0]),
+                fix_seg=i32(fix_seg), fix_slot=i32(fix_slot), fix_cnt=i32(fix_cnt), order=order)
+
+
+_VIEW_ARRAYS = ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")
+
+
+class _DeviceGraph:
+    """Device-resident TempGraph: one packed int32 buffer + nnorm, and the ctypes struct whose
+    pointers refer into them (kept alive by this object)."""
+
+    def __init__(self, snap, device, n_rel_rows):
+        n, E = snap.n, snap.number_of_edges()
+        views = dict(by_dst=build_view(snap.dst, snap.src, snap.rel, n),
+                     by_src=build_view(snap.src, snap.dst, snap.rel, n),
+                     by_rel=build_view(snap.rel, snap.src, snap.dst, n_rel_rows))
+        if E and (snap.rel.min() < 0 or snap.rel.max() >= n_rel_rows):
+            raise ValueError("relation id outside [0, %d)" % n_rel_rows)
+        in_deg = np.bincount(snap.dst, minlength=n).astype(np.int32)
+        out_deg = np.bincount(snap.src, minlength=n).astype(np.int32)
+        parts, offs, off = [in_deg, out_deg], {}, 2 * n
+        for vn, v in views.items():
+            for an in _VIEW_ARRAYS:
+                offs[(vn, an)] = off
+                parts.append(v[an])
+                off += v[an].shape[0]
+        packed = np.concatenate(parts) if parts else np.zeros(0, np.int32)
+        if packed.shape[0] == 0:
+            packed = np.zeros(1, np.int32)
+        self.ints = torch.from_numpy(packed).to(device)
+        self.nnorm = torch.from_numpy(snap.nnorm if n else np.zeros(1, np.float32)).to(device)
+        self.in_deg = self.ints[0:n]
+        self.out_deg = self.ints[n:2 * n]
+        self.views = views
+        self.n_nodes, self.n_edges, self.n_rel_rows = n, E, n_rel_rows
+        self.device = self.ints.device
+        base = self.ints.data_ptr()
+        g = _lib.TempGraph()
+        g.n_nodes, g.n_edges = n, E
+        g.nnorm = self.nnorm.data_ptr()
+        g.in_deg = base
+        g.out_deg = base + 4 * n
+        for vn, v in views.items():
+            ev = getattr(g, vn)
+            for fld in ("n_seg", "n_edges", "n_chunks", "n_partial", "n_fix"):
+                setattr(ev, fld, v[fld])
+            for an in _VIEW_ARRAYS:
+                setattr(ev, an, base + 4 * offs[(vn, an)])
+        self.c = g
+        self.offs = offs
+
+    def view_tensor(self, view, name):
+        """Device int32 tensor of one view array (used by tests and the CPU test backend)."""
+        o = self.offs[(view, name)]
+        return self.ints[o:o + self.views[view][name].shape[0]]
+
+    def ref(self):
+        return ctypes.byref(self.c)

@@ -1,0 +1,166 @@
+"""TEST-ONLY stand-in for temp_amd.backend.HipBackend so host logic (graph views, autograd wiring,
+window scheduling, sharding) can be exercised on a machine without a GPU.
+
+It follows the C-ABI contract of include/temp_amd.h *through the same sorted/chunked edge views
+the kernels read* (so a wrong view shows up here), using torch CPU ops and the oracle's GRU
+equations.  It lives under tests/ and is never imported by the product package.
+"""
+import torch
+
+from oracle import temp_oracle as O
+from temp_amd import _lib
+
+
+def _view(dg, name):
+    v = dg.views[name]
+    t = lambda k: torch.from_numpy(v[k]).long()
+    return v, t
+
+
+def _chunk_reduce(dg, name, per_edge_fn, width, n_out, dtype):
+    """Run `per_edge_fn(a, b) -> (E, width)` over the edges of a view in sorted order and reduce
+    exactly like the kernels: per chunk, then ordered partial slots -> fix-up."""
+    v, t = _view(dg, name)
+    out = torch.full((n_out, width), float('nan'), dtype=dtype)      # untouched rows stay NaN (kernel leaves them)
+    if v['n_chunks'] == 0:
+        return out
+    beg, end, seg, slot = t('chunk_beg'), t('chunk_end'), t('chunk_seg'), t('chunk_slot')
+    cnt = end - beg
+    assert int(cnt.min()) >= 1 and int(cnt.max()) <= _lib.CHUNK
+    assert int(cnt.sum()) == v['n_edges'] and torch.equal(beg[1:], end[:-1]) and int(beg[0]) == 0
+    cid = torch.repeat_interleave(torch.arange(v['n_chunks']), cnt)
+    vals = per_edge_fn(t('a'), t('b'))
+    sums = torch.zeros(v['n_chunks'], width, dtype=dtype).index_add(0, cid, vals)
+    direct = slot < 0
+    out[seg[direct]] = sums[direct]
+    partial = torch.zeros(max(v['n_partial'], 1), width, dtype=dtype)
+    partial[slot[~direct]] = sums[~direct]
+    for fs, f0, fc in zip(v['fix_seg'], v['fix_slot'], v['fix_cnt']):
+        acc = torch.zeros(width, dtype=dtype)
+        for s in range(int(fc)):
+            acc = acc + partial[int(f0) + s]
+        out[int(fs)] = acc
+    return out
+
+
+def _blocks(weight, rel, B):
+    return weight.index_select(0, rel).view(rel.shape[0], B, -1)
+
+
+class CpuTestBackend:
+    name = "cpu-test"
+
+    # ---- RGCN ---------------------------------------------------------------------------------
+    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act):
+        h, weight, loop_w = h.detach(), weight.detach(), loop_w.detach()
+        d_in, d_out = loop_w.shape
+        si, so = d_in // num_bases, d_out // num_bases
+        nn = dg.nnorm.cpu()[:dg.n_nodes]
+        rows = (lambda idx: h[h_ids.long()[idx]]) if h_ids is not None else (lambda idx: h[idx])
+
+        def msg(a, b):
+            w = weight.index_select(0, b).view(-1, si, so)
+            return torch.bmm(rows(a).view(-1, 1, si), w).view(-1, d_out)
+
+        agg = _chunk_reduce(dg, 'by_dst', msg, d_out, dg.n_nodes, h.dtype)
+        agg = agg * (nn * nn).view(-1, 1)
+        has_in = dg.in_deg.cpu().long() > 0
+        agg = torch.where(has_in.view(-1, 1), agg, torch.zeros_like(agg))
+        x = rows(torch.arange(dg.n_nodes))
+        out = agg + torch.mm(x, loop_w)
+        if bias is not None:
+            out = out + bias.detach()
+        if act == _lib.ACT_RELU:
+            out = torch.relu(out)
+        return out
+
+    def rgcn_bwd(self, dg, h, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
+        h, weight, loop_w = h.detach(), weight.detach(), loop_w.detach()
+        d_in, d_out = loop_w.shape
+        si, so = d_in // num_bases, d_out // num_bases
+        nn = dg.nnorm.cpu()[:dg.n_nodes]
+        dz = d_out_grad.detach()
+        if act == _lib.ACT_RELU:
+            dz = torch.where(out.detach() > 0, dz, torch.zeros_like(dz))
+
+        def dx_edge(dst, rel):
+            w = weight.index_select(0, rel).view(-1, si, so)
+            g = (dz[dst] * (nn[dst] ** 2).view(-1, 1)).view(-1, so, 1)
+            return torch.bmm(w, g).view(-1, d_in)
+
+        d_h = _chunk_reduce(dg, 'by_src', dx_edge, d_in, dg.n_nodes, h.dtype)
+        has_out = dg.out_deg.cpu().long() > 0
+        d_h = torch.where(has_out.view(-1, 1), d_h, torch.zeros_like(d_h)) + torch.mm(dz, loop_w.t())
+
+        def dw_edge(src, dst):
+            g = (dz[dst] * (nn[dst] ** 2).view(-1, 1)).view(-1, num_bases, 1, so)
+            x = h[src].view(-1, num_bases, si, 1)
+            return (x * g).reshape(src.shape[0], -1)
+
+        wrow = num_bases * si * so
+        d_w = _chunk_reduce(dg, 'by_rel', dw_edge, wrow, weight.shape[0], h.dtype)
+        d_w = torch.where(torch.isnan(d_w), torch.zeros_like(d_w), d_w)      # kernel memsets dW first
+        d_loop = torch.mm(h.t(), dz)
+        d_bias = dz.sum(0) if has_bias else None
+        return d_h, d_w, d_loop, d_bias
+
+    def rgcn_isolated_fwd(self, e, loop_w, bias, act):
+        out = e.detach() + torch.mm(e.detach(), loop_w.detach())
+        if bias is not None:
+            out = out + bias.detach()
+        return torch.relu(out) if act == _lib.ACT_RELU else out
+
+    def rgcn_isolated_bwd(self, e, out, d_out_grad, loop_w, has_bias, act):
+        dz = d_out_grad.detach()
+        if act == _lib.ACT_RELU:
+            dz = torch.where(out.detach() > 0, dz, torch.zeros_like(dz))
+        d_e = dz + torch.mm(dz, loop_w.detach().t())
+        return d_e, torch.mm(e.detach().t(), dz), (dz.sum(0) if has_bias else None)
+
+    # ---- decay + GRU ----------------------------------------------------------------------------
+    @staticmethod
+    def _gru_forward(x, prev, prev_idx, dt, lam, wb, w_ih, w_hh, b_ih, b_hh, variant):
+        if prev_idx is not None:
+            idx = prev_idx.long()
+            rows = prev[idx.clamp(min=0)] * (idx >= 0).to(prev.dtype).view(-1, 1)
+        else:
+            rows = prev
+        dt = dt.view(-1, 1)
+        dec = torch.exp(-torch.clamp(dt * wb[0] + wb[1], min=0)) if wb is not None else torch.exp(-dt * lam)
+        hdec = rows * dec
+        fn = O.gru_type1 if variant == _lib.GRU_TYPE1 else O.gru_torch
+        return fn(x, hdec, w_ih, w_hh, b_ih, b_hh), hdec
+
+    def gru_fwd(self, x, prev, prev_idx, dt, lam, decay_wb, w_ih, w_hh, b_ih, b_hh, variant):
+        args = [t.detach() if t is not None else None for t in (x, prev, None, dt, None, decay_wb, w_ih, w_hh, b_ih, b_hh)]
+        h, hdec = self._gru_forward(args[0], args[1], prev_idx, args[3], lam, args[5], args[6], args[7], args[8], args[9], variant)
+        # `saved` is opaque to callers; this backend only needs the biases back in gru_bwd
+        return h, torch.cat([b_ih.detach().reshape(-1), b_hh.detach().reshape(-1)])
+
+    def gru_bwd(self, x, prev, prev_idx, dt, lam, decay_wb, w_ih, w_hh, saved, d_h, variant):
+        leaf = lambda t: t.detach().clone().requires_grad_(True)
+        xs, ps, wi, wh = leaf(x), leaf(prev), leaf(w_ih), leaf(w_hh)
+        bi, bh = leaf(saved[:w_ih.shape[0]]), leaf(saved[w_ih.shape[0]:])
+        wb = leaf(decay_wb) if decay_wb is not None else None
+        # gradient w.r.t. the GATHERED previous rows (the ABI returns d_prev in x's row order)
+        if prev_idx is not None:
+            idx = prev_idx.long()
+            rows = (ps.detach()[idx.clamp(min=0)] * (idx >= 0).to(ps.dtype).view(-1, 1)).clone().requires_grad_(True)
+        else:
+            rows = ps
+        with torch.enable_grad():            # we are called from inside an autograd backward
+            h, _ = self._gru_forward(xs, rows, None, dt.detach(), lam, wb, wi, wh, bi, bh, variant)
+            h.backward(d_h.detach())
+        z = lambda t, like: t.grad if t.grad is not None else torch.zeros_like(like)
+        return (z(xs, xs), z(rows, rows), z(wi, wi), z(wh, wh), z(bi, bi), z(bh, bh), (z(wb, wb) if wb is not None else None))
+
+    # ---- rows -----------------------------------------------------------------------------------
+    def gather_rows(self, table, idx):
+        i = idx.long()
+        return table.detach()[i.clamp(min=0)] * (i >= 0).to(table.dtype).view(-1, 1)
+
+    def scatter_add_rows(self, src, idx, table):
+        i = idx.long()
+        keep = i >= 0
+        table.index_add_(0, i[keep], src.detach()[keep])
+        return table

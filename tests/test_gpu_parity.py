@@ -1,0 +1,209 @@
+"""GPU parity tests proper (-m gpu): the hand-written HIP kernels, called through the C ABI
+(ctypes -> libtemp_amd.so), against (a) golden vectors recorded from the TeMP reference and
+(b) the CPU oracle on seeded random inputs, including the edge cases the domain has: empty graph,
+zero-in-degree nodes, hub nodes whose segment spans many chunks, duplicate edges, every block
+shape (si=so=1,2,4 and a generic one), inactive previous rows (prev_idx = -1).
+Tolerance: 1e-5 relative fp32 (+ absolute floor), as BASELINE.md states."""
+import numpy as np
+import pytest
+import torch
+
+from temp_amd import _lib
+from temp_amd import backend as TB
+from temp_amd.snapshot import Snapshot
+from tests.cpu_backend import CpuTestBackend
+from tests.encoder_cases import check_G2, check_G4, check_G6, check_G7
+from tests.golden_util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def hip_backend():
+    TB.set_backend(None)
+    be = TB.get_backend()
+    assert be.name == "hip"
+    yield be
+
+
+def test_library_loaded_is_in_tree():
+    lib = _lib.load()
+    assert lib.temp_abi_version() == 1
+    assert _lib.LIB_PATH.endswith("temp_amd/libtemp_amd.so")
+
+
+def test_G2_layer_golden():
+    check_G2(DEV)
+
+
+def test_G4_grrgcn_layer_golden():
+    check_G4(DEV)
+
+
+def test_G6_rrgcn_golden():
+    check_G6(DEV)
+
+
+def test_G7_birrgcn_golden():
+    check_G7(DEV)
+
+
+# ---------------------------------------------------------------------------------------------
+def rand_graph(rng, n, E, R2, hub=False, dup=False):
+    if E == 0:
+        z = np.zeros(0, np.int64)
+        return Snapshot(n, z, z, z, np.arange(n))
+    src = rng.integers(0, n, E)
+    dst = rng.integers(0, n, E)
+    if hub:                               # a few destinations / sources with degree >> 64 (multi-chunk segments)
+        dst[: E // 2] = rng.integers(0, 3, E // 2)
+        src[E // 4: E // 2 + E // 4] = rng.integers(n - 2, n, E // 2)
+    rel = rng.integers(0, R2, E)
+    if dup:
+        src[1::2], dst[1::2], rel[1::2] = src[0::2][: len(src[1::2])], dst[0::2][: len(src[1::2])], rel[0::2][: len(src[1::2])]
+    # leave the upper part of the node range without in-edges sometimes: zero-in-degree rows
+    return Snapshot(n, src, dst, rel, np.arange(n))
+
+
+CASES = [
+    # n, E, D, B, R2, hub, dup, bias, act
+    (50, 0, 16, 8, 6, False, False, False, 0),          # empty graph
+    (1, 1, 8, 2, 4, False, False, True, 1),             # single self edge, S=4
+    (300, 900, 200, 100, 40, False, False, False, 0),   # BASELINE shape (2x2 blocks), LDS-resident table size
+    (300, 5000, 200, 100, 460, True, False, True, 1),   # hubs -> multi-chunk + fix-up, big relation table
+    (257, 2000, 128, 128, 24, True, True, False, 1),    # S=1 (shipped grid configs), duplicates
+    (130, 700, 32, 8, 10, False, False, True, 0),       # S=4
+    (90, 400, 24, 4, 10, True, False, True, 1),         # S=6 -> generic path
+    (4000, 60000, 200, 100, 40, True, False, False, 0), # enough chunks for the persistent LDS-table variant
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rgcn_layer_vs_oracle(case, hip_backend):
+    n, E, D, B, R2, hub, dup, bias, act = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    g = rand_graph(rng, n, E, R2, hub, dup)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    S = D // B
+    h, w, lw = f(n, D), f(R2, B * S * S) * 0.5, f(D, D) * 0.2
+    b = f(D) if bias else None
+    gy = f(n, D)
+    cpu = CpuTestBackend()
+    dg_c = g.device_graph(torch.device("cpu"), R2)
+    want = cpu.rgcn_fwd(dg_c, h, None, w, lw, b, B, act)
+    dg = g.device_graph(DEV, R2)
+    cu = lambda t: t.to(DEV) if t is not None else None
+    got = hip_backend.rgcn_fwd(dg, cu(h), None, cu(w), cu(lw), cu(b), B, act)
+    assert_close(got, want, 1e-5, 5e-6, "rgcn_fwd %s" % (case,))
+    wd = cpu.rgcn_bwd(dg_c, h, want, gy, w, lw, bias, B, act)
+    gd = hip_backend.rgcn_bwd(dg, cu(h), got, cu(gy), cu(w), cu(lw), bias, B, act)
+    scale = max(1.0, float(n) ** 0.5)
+    assert_close(gd[0], wd[0], 1e-5, 5e-6, "d_h %s" % (case,))
+    assert_close(gd[1], wd[1], 2e-5, 1e-5 * scale, "d_weight %s" % (case,))
+    assert_close(gd[2], wd[2], 2e-5, 1e-5 * scale, "d_loop %s" % (case,))
+    if bias:
+        assert_close(gd[3], wd[3], 2e-5, 1e-5 * scale, "d_bias %s" % (case,))
+
+
+def test_rgcn_fused_gather_ids(hip_backend):
+    rng = np.random.default_rng(5)
+    n, E, D, B, R2, N = 200, 1500, 200, 100, 40, 1000
+    g = rand_graph(rng, n, E, R2, hub=True)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    table, w, lw = f(N, D), f(R2, 2 * D) * 0.5, f(D, D) * 0.2
+    ids = torch.from_numpy(rng.integers(0, N, n).astype(np.int32))
+    dg = g.device_graph(DEV, R2)
+    got = hip_backend.rgcn_fwd(dg, table.to(DEV), ids.to(DEV), w.to(DEV), lw.to(DEV), None, B, 0)
+    want = hip_backend.rgcn_fwd(dg, table[ids.long()].to(DEV), None, w.to(DEV), lw.to(DEV), None, B, 0)
+    assert torch.equal(got, want)            # same arithmetic, only the addressing differs
+
+
+@pytest.mark.parametrize("n,D,act,bias", [(0, 16, 0, False), (1, 8, 1, True), (777, 200, 1, True), (5000, 128, 0, False)])
+def test_rgcn_isolated_vs_oracle(n, D, act, bias, hip_backend):
+    rng = np.random.default_rng(n + D)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    e, lw, gy = f(n, D), f(D, D) * 0.2, f(n, D)
+    b = f(D) if bias else None
+    cpu = CpuTestBackend()
+    want = cpu.rgcn_isolated_fwd(e, lw, b, act)
+    cu = lambda t: t.to(DEV) if t is not None else None
+    got = hip_backend.rgcn_isolated_fwd(cu(e), cu(lw), cu(b), act)
+    assert_close(got, want, 1e-5, 5e-6, "iso fwd")
+    wd = cpu.rgcn_isolated_bwd(e, want, gy, lw, bias, act)
+    gd = hip_backend.rgcn_isolated_bwd(cu(e), got, cu(gy), cu(lw), bias, act)
+    scale = max(1.0, float(n) ** 0.5)
+    assert_close(gd[0], wd[0], 1e-5, 5e-6, "iso d_e")
+    assert_close(gd[1], wd[1], 2e-5, 1e-5 * scale, "iso d_loop")
+    if bias:
+        assert_close(gd[2], wd[2], 2e-5, 1e-5 * scale, "iso d_bias")
+
+
+@pytest.mark.parametrize("n,D,variant,learn,use_idx", [
+    (0, 16, 0, False, False), (1, 8, 0, False, False), (333, 200, 0, False, True), (4000, 200, 0, False, True),
+    (500, 128, 1, False, False), (260, 32, 0, True, True), (129, 24, 1, True, True)])
+def test_gru_step_vs_oracle(n, D, variant, learn, use_idx, hip_backend):
+    rng = np.random.default_rng(n * 7 + D + variant)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    k = 1.0 / np.sqrt(D)
+    gi_w = D if variant == 1 else 3 * D
+    x, w_ih, w_hh, b_ih, b_hh = f(n, D), f(gi_w, D) * k, f(3 * D, D) * k, f(gi_w) * k, f(3 * D) * k
+    n_prev = max(n + 13, 1)
+    prev = f(n_prev, D) if use_idx else f(n, D)
+    idx = None
+    if use_idx:
+        perm = rng.permutation(n_prev)[:n].astype(np.int32)
+        perm[rng.random(n) < 0.3] = -1                      # inactive at the previous window position (F8)
+        idx = torch.from_numpy(perm)
+    dt = torch.from_numpy(rng.integers(0, 9, n).astype(np.float32))
+    wb = torch.tensor([0.3, -0.4]) if learn else None
+    gy = f(n, D)
+    cpu = CpuTestBackend()
+    cu = lambda t: t.to(DEV) if t is not None else None
+    want, saved_c = cpu.gru_fwd(x, prev, idx, dt, 0.1, wb, w_ih, w_hh, b_ih, b_hh, variant)
+    got, saved = hip_backend.gru_fwd(cu(x), cu(prev), cu(idx), cu(dt), 0.1, cu(wb), cu(w_ih), cu(w_hh), cu(b_ih), cu(b_hh), variant)
+    assert_close(got, want, 1e-5, 2e-6, "gru fwd")
+    wd = cpu.gru_bwd(x, prev, idx, dt, 0.1, wb, w_ih, w_hh, saved_c, gy, variant)
+    gd = hip_backend.gru_bwd(cu(x), cu(prev), cu(idx), cu(dt), 0.1, cu(wb), cu(w_ih), cu(w_hh), saved, cu(gy), variant)
+    scale = max(1.0, float(n) ** 0.5)
+    assert_close(gd[0], wd[0], 2e-5, 2e-6, "gru d_x")
+    d_prev_got, d_prev_want = gd[1], wd[1]
+    if idx is not None:                                      # rows with idx == -1 carry no gradient
+        keep = (idx >= 0)
+        d_prev_got, d_prev_want = gd[1][keep.to(DEV)], wd[1][keep]
+    assert_close(d_prev_got, d_prev_want, 2e-5, 2e-6, "gru d_prev")
+    for i, nm in ((2, "d_w_ih"), (3, "d_w_hh"), (4, "d_b_ih"), (5, "d_b_hh")):
+        assert_close(gd[i], wd[i], 3e-5, 1e-5 * scale, "gru " + nm)
+    if learn:
+        assert_close(gd[6], wd[6], 1e-4, 1e-4 * scale, "gru d_decay")
+
+
+def test_gather_scatter_rows(hip_backend):
+    rng = np.random.default_rng(3)
+    table = torch.from_numpy(rng.standard_normal((100, 200)).astype(np.float32)).to(DEV)
+    idx = torch.from_numpy(rng.integers(-1, 100, 5000).astype(np.int32)).to(DEV)
+    out = hip_backend.gather_rows(table, idx)
+    i = idx.long()
+    want = table[i.clamp(min=0)] * (i >= 0).float().view(-1, 1)
+    assert torch.equal(out, want)
+    src = torch.from_numpy(rng.integers(-8, 8, (5000, 200)).astype(np.float32)).to(DEV)   # integers: order-independent sum
+    acc = torch.zeros(100, 200, device=DEV)
+    hip_backend.scatter_add_rows(src, idx, acc)
+    ref = torch.zeros(100, 200, device=DEV).index_add_(0, i[i >= 0], src[i >= 0])
+    assert torch.equal(acc, ref)
+
+
+def test_determinism_bitwise(hip_backend):
+    """No atomics in the encoder kernels: two runs give identical bits."""
+    rng = np.random.default_rng(9)
+    g = rand_graph(rng, 500, 20000, 40, hub=True)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(DEV)
+    h, w, lw, gy = f(500, 200), f(40, 400), f(200, 200), f(500, 200)
+    dg = g.device_graph(DEV, 40)
+    a = hip_backend.rgcn_fwd(dg, h, None, w, lw, None, 100, 1)
+    b = hip_backend.rgcn_fwd(dg, h, None, w, lw, None, 100, 1)
+    assert torch.equal(a, b)
+    ga = hip_backend.rgcn_bwd(dg, h, a, gy, w, lw, False, 100, 1)
+    gb = hip_backend.rgcn_bwd(dg, h, a, gy, w, lw, False, 100, 1)
+    for u, v in zip(ga[:3], gb[:3]):
+        assert torch.equal(u, v)
