@@ -1,0 +1,149 @@
+"""BiDynamicRGCN -- the bi-directional window model with the reference's interface
+(models/BiDynamicRGCN.py:10-208).  A forward chain over [t-L+1 .. t-1] (forward_rnn) and a backward
+chain over [t+L-1 .. t+1] (backward_rnn) feed the centre step
+    H = GRU_f(Y2, dec(S_f)) + GRU_b(Y2, dec(S_b))            (models/BiRRGCN.py:27-47).
+The batched path runs the 2 RGCN layers of all 2(L-1)+1 positions x bsz windows as one launch
+each; only the GRU cells walk the two chains.
+"""
+import numpy as np
+import torch
+
+from . import functional as TF
+from .birrgcn import BiGRRGCNLayer, BiRRGCN
+from .dynamic_rgcn import DynamicRGCN
+from .rrgcn import run_rnn
+from .window import ChainPlan, Step, concat_steps, window_times
+
+
+class BiDynamicRGCN(DynamicRGCN):
+    def build_model(self):
+        self.ent_encoder = BiRRGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
+
+    def _can_batch(self):
+        enc = self.ent_encoder
+        return (self.use_batched_path and enc.rec_only_last_layer and isinstance(enc.layer_2, BiGRRGCNLayer)
+                and not (enc.layer_2.post_aggregation or enc.layer_2.post_ensemble or enc.layer_2.impute))
+
+    @staticmethod
+    def get_batch_graph_list(t_list, seq_len, graph_dict):
+        """models/BiDynamicRGCN.py:17-49 -> (g_fwd[p][b], t_fwd[p][b], g_bwd[p][b], t_bwd[p][b])."""
+        times = list(graph_dict.keys())
+        out = []
+        for asc in (False, True):
+            rows = window_times(t_list, seq_len, times, ascending=asc)
+            tb = [list(x) for x in zip(*rows)]
+            gb = [[graph_dict[t] if t is not None else None for t in col] for col in tb]
+            out += [gb, tb]
+        return tuple(out)
+
+    # -- reference-granular path ------------------------------------------------------------------------
+    def _encode_step_one_direction(self, st, prev_first, prev_second, forward):
+        dev = self._device()
+        ids, pidx, dt = st.tensors(dev)
+        g = st.batched()
+        g.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+        fp = self._gather_prev(prev_first, pidx, st.n_rows)
+        sp = self._gather_prev(prev_second, pidx, st.n_rows)
+        return self.ent_encoder.forward_one_direction(g, fp, sp, dt, st.times, st.sizes, forward)
+
+    def pre_forward(self, plan, forward=True):
+        first = second = None
+        for st in plan.steps:
+            first, second = self._encode_step_one_direction(st, first, second, forward)
+        return first, second
+
+    def _bi_target(self, plan_f, plan_b, rows, graphs):
+        L = plan_f.seq_len
+        st = self._target_step(plan_f, rows, graphs)
+        pidx, dts = [], []
+        for b, g in enumerate(graphs):
+            a, d = plan_b.final_prev(b, g.gids, L - 1)
+            pidx.append(a)
+            dts.append(d)
+        st_b = Step(L - 1, st.windows, graphs, st.times)
+        st_b.prev_idx = np.concatenate(pidx) if pidx else np.zeros(0, np.int64)
+        st_b.dt = np.concatenate(dts) if dts else np.zeros(0, np.float32)
+        st_b.graph = None
+        return st, st_b
+
+    def _encode_generic_bi(self, plan_f, plan_b, tf, tb):
+        dev = self._device()
+        hf = self.pre_forward(plan_f, True)
+        hb = self.pre_forward(plan_b, False)
+        ids, pf, dtf = tf.tensors(dev)
+        _, pb, dtb = tb.tensors(dev)
+        g = tf.batched()
+        g.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+        n = tf.n_rows
+        out = self.ent_encoder(g, self._gather_prev(hf[0], pf, n), self._gather_prev(hf[1], pf, n), dtf,
+                               self._gather_prev(hb[0], pb, n), self._gather_prev(hb[1], pb, n), dtb, tf.times, tf.sizes)
+        return out, hf, hb
+
+    # -- batched path --------------------------------------------------------------------------------------
+    def _encode_batched_bi(self, plan_f, plan_b, tf, tb):
+        enc, dev = self.ent_encoder, self._device()
+        steps = plan_f.steps + plan_b.steps + [tf]
+        g_all, total = concat_steps(steps)
+        ids_all = torch.from_numpy(g_all.gids.astype(np.int32)).to(dev)
+        h0 = TF.gather_rows(self.ent_embeds, ids_all)
+        y1 = enc.layer_1.conv(g_all, h0)
+        y2 = enc.layer_2.conv(g_all, y1)                      # ReLU fused (models/BiRRGCN.py:202-203)
+        l2 = enc.layer_2
+        lam, dec = l2.inv_temperature, l2.decay_spec()
+
+        def chain(plan, rnn):
+            H = None
+            for st in plan.steps:
+                _, pidx, dt = st.tensors(dev)
+                x = y2[st.row0:st.row0 + st.n_rows]
+                prev = H if H is not None else x.new_zeros(1, x.shape[1])
+                H = run_rnn(rnn, x, prev, dt, lam, dec, pidx)
+                if enc.use_time_embedding:
+                    H = H + l2.get_time_embedding(st.times, st.sizes)
+            return H
+
+        Hf = chain(plan_f, l2.forward_rnn)
+        Hb = chain(plan_b, l2.backward_rnn)
+        x = y2[tf.row0:tf.row0 + tf.n_rows]
+        _, pf, dtf = tf.tensors(dev)
+        _, pb, dtb = tb.tensors(dev)
+        zero = x.new_zeros(1, x.shape[1])
+        out = run_rnn(l2.forward_rnn, x, Hf if Hf is not None else zero, dtf, lam, dec, pf) + \
+            run_rnn(l2.backward_rnn, x, Hb if Hb is not None else zero, dtb, lam, dec, pb)
+        if enc.use_time_embedding:
+            out = out + l2.get_time_embedding(tf.times, tf.sizes)
+        return out, (Hf, Hf), (Hb, Hb)
+
+    # ---------------------------------------------------------------------------------------------
+    def encode(self, t_list, seq_len, train=True, target_edge_ids=None):
+        rows_f = window_times(t_list, seq_len, self.total_time)
+        rows_b = window_times(t_list, seq_len, self.total_time, ascending=True)
+        plan_f = ChainPlan(rows_f, self.graph_dict_train, self.num_ents, seq_len)
+        plan_b = ChainPlan(rows_b, self.graph_dict_train, self.num_ents, seq_len).flipped()
+        graphs = [self.graph_dict_train[r[-1]] for r in rows_f]
+        tgt = self.sample_target_graphs(graphs, 0.5, target_edge_ids) if train else graphs
+        tf, tb = self._bi_target(plan_f, plan_b, rows_f, tgt)
+        fn = self._encode_batched_bi if self._can_batch() else self._encode_generic_bi
+        out, hf, hb = fn(plan_f, plan_b, tf, tb)
+        return list(out.split(tf.sizes)), (plan_f, plan_b), rows_f, graphs, (hf, hb)
+
+    def get_all_embeds_Gt(self, convoluted_embeds, g, t, plans, b, hist):
+        """models/BiDynamicRGCN.py:102-112."""
+        dev = self._device()
+        plan_f, plan_b = plans
+        hf, hb = hist
+        L = plan_f.seq_len
+        if getattr(self.args, "use_embed_for_non_active", False):
+            all_embeds = self.ent_embeds
+        else:
+            def prevs(plan, h):
+                row_of, dt = plan.final_all(b, L - 1)
+                idx = torch.from_numpy(row_of.astype(np.int32)).to(dev)
+                p1 = self._gather_prev(h[0], idx, self.num_ents)
+                p2 = p1 if h[1] is h[0] else self._gather_prev(h[1], idx, self.num_ents)
+                return p1, p2, torch.from_numpy(dt).view(-1, 1).to(dev)
+            f1, f2, dtf = prevs(plan_f, hf)
+            b1, b2, dtb = prevs(plan_b, hb)
+            all_embeds = self.ent_encoder.forward_isolated(self.ent_embeds, f1, f2, dtf, b1, b2, dtb, t)
+        gid = torch.from_numpy(g.gids).to(dev)
+        return all_embeds.index_copy(0, gid, convoluted_embeds)

@@ -1,0 +1,177 @@
+"""DynamicRGCN -- the uni-directional window model with the reference's interface
+(models/DynamicRGCN.py:14-220): `DynamicRGCN(args, num_ents, num_rels, graph_dict_train,
+graph_dict_val, graph_dict_test)`, `.forward(t_list) -> loss`, same parameter / state_dict names.
+
+Two execution paths, same results:
+  * reference-granular: one encoder call per window position through the drop-in `RRGCN` API,
+    previous states fetched by row-gather from the previous position's output (window.ChainPlan)
+    instead of the reference's dense re-zeroed history;
+  * batched (GRU module + --rec-only-last-layer, the paper's recommended mode): the two RGCN layers
+    of EVERY visit of the step run as ONE launch each over a block-diagonal union of all visited
+    snapshots, and only the fused decay+GRU kernel walks the window positions, reading its
+    previous state through `prev_idx`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as TF
+from . import snapshot as S
+from .rrgcn import RRGCN, GRRGCNLayer, run_rnn
+from .tkg_module import TKG_Module
+from .window import ChainPlan, Step, concat_steps, window_times
+
+
+class DynamicRGCN(TKG_Module):
+    def __init__(self, args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type=None):
+        self.num_layers = args.num_layers
+        self.train_seq_len = args.train_seq_len
+        self.test_seq_len = args.train_seq_len            # --test-seq-len is ignored by the reference too (F10)
+        super().__init__(args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type)
+        self.ent_embeds = nn.Parameter(torch.Tensor(self.num_ents, self.embed_size))
+        self.rel_embeds = nn.Parameter(torch.Tensor(self.num_rels * 2, self.embed_size))
+        self.edge_dropout = getattr(args, "edge_dropout", False)
+        self.post_aggregation = getattr(args, "post_aggregation", False)
+        if self.edge_dropout:
+            raise NotImplementedError("--edge-dropout (utils/DropEdge.py) is outside the hot-path scope (SURVEY section 2)")
+        nn.init.xavier_uniform_(self.ent_embeds, gain=nn.init.calculate_gain('relu'))
+        nn.init.xavier_uniform_(self.rel_embeds, gain=nn.init.calculate_gain('relu'))
+        self.sample_rng = np.random.default_rng(getattr(args, "seed", None))
+        self.use_batched_path = True
+
+    def build_model(self):
+        self.ent_encoder = RRGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
+
+    # ---------------------------------------------------------------------------------------------
+    # shared helpers
+    # ---------------------------------------------------------------------------------------------
+    def _device(self):
+        return self.ent_embeds.device
+
+    def _can_batch(self):
+        enc = self.ent_encoder
+        return (self.use_batched_path and enc.rec_only_last_layer and isinstance(enc.layer_2, GRRGCNLayer)
+                and not (enc.layer_2.post_aggregation or enc.layer_2.post_ensemble or enc.layer_2.impute))
+
+    def _gather_prev(self, prev_out, idx_t, n):
+        if prev_out is None:
+            return self.ent_embeds.new_zeros(n, self.embed_size)
+        return TF.gather_rows(prev_out, idx_t)
+
+    def sample_target_graphs(self, graphs, rate=0.5, edge_ids=None):
+        """Random edge subsample of the target snapshots with recomputed norms
+        (get_batch_graph_embeds(full=False), models/DynamicRGCN.py:76-90).  `edge_ids`
+        injects the kept edge ids (tests replay the reference's recorded draws)."""
+        out = []
+        for i, g in enumerate(graphs):
+            E = g.number_of_edges()
+            idx = edge_ids[i] if edge_ids is not None else self.sample_rng.choice(np.arange(E), size=int(rate * E), replace=False)
+            out.append(g.edge_subgraph(idx))
+        return out
+
+    def _target_step(self, plan, rows, graphs):
+        L = plan.seq_len
+        st = Step(L - 1, list(range(len(graphs))), graphs, [r[-1] for r in rows])
+        pidx, dts = [], []
+        for b, g in enumerate(graphs):
+            a, d = plan.final_prev(b, g.gids, L - 1)
+            pidx.append(a)
+            dts.append(d)
+        st.prev_idx = np.concatenate(pidx) if pidx else np.zeros(0, np.int64)
+        st.dt = np.concatenate(dts) if dts else np.zeros(0, np.float32)
+        return st
+
+    # ---------------------------------------------------------------------------------------------
+    # reference-granular path
+    # ---------------------------------------------------------------------------------------------
+    def _encode_step(self, st, prev_first, prev_second):
+        dev = self._device()
+        ids, pidx, dt = st.tensors(dev)
+        g = st.batched()
+        g.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+        fp = self._gather_prev(prev_first, pidx, st.n_rows)
+        sp = self._gather_prev(prev_second, pidx, st.n_rows)
+        return self.ent_encoder(g, fp, sp, dt, st.times, st.sizes)
+
+    def pre_forward(self, plan):
+        """History positions 0..L-2 (models/DynamicRGCN.py:156-174) -> outputs of the last executed one."""
+        first = second = None
+        for st in plan.steps:
+            first, second = self._encode_step(st, first, second)
+        return first, second
+
+    def _encode_generic(self, plan, target):
+        first, second = self.pre_forward(plan)
+        _, out = self._encode_step(target, first, second)
+        return out, (first, second)
+
+    # ---------------------------------------------------------------------------------------------
+    # batched path
+    # ---------------------------------------------------------------------------------------------
+    def _encode_batched(self, plan, target):
+        enc, dev = self.ent_encoder, self._device()
+        steps = plan.steps + [target]
+        g_all, total = concat_steps(steps)
+        ids_all = torch.from_numpy(g_all.gids.astype(np.int32)).to(dev)
+        h0 = TF.gather_rows(self.ent_embeds, ids_all)
+        y1 = enc.layer_1.conv(g_all, h0)
+        y2 = enc.layer_2.conv(g_all, y1)
+        l2 = enc.layer_2
+        H, hist = None, None
+        for st in steps:
+            _, pidx, dt = st.tensors(dev)
+            x = y2[st.row0:st.row0 + st.n_rows]
+            prev = H if H is not None else x.new_zeros(1, x.shape[1])
+            H = run_rnn(l2.rnn, x, prev, dt, l2.inv_temperature, l2.decay_spec(), pidx)
+            if enc.use_time_embedding:
+                H = H + l2.get_time_embedding(st.times, st.sizes)
+            if st is not target:
+                hist = H
+        return H, (hist, hist)
+
+    # ---------------------------------------------------------------------------------------------
+    def encode(self, t_list, seq_len, train=True, target_edge_ids=None):
+        """Window encoder: -> (per-window target embeddings, plan, rows, target graphs, final history)."""
+        rows = window_times(t_list, seq_len, self.total_time)
+        plan = ChainPlan(rows, self.graph_dict_train, self.num_ents, seq_len)
+        graphs = [self.graph_dict_train[r[-1]] for r in rows]
+        tgt = self.sample_target_graphs(graphs, 0.5, target_edge_ids) if train else graphs
+        target = self._target_step(plan, rows, tgt)
+        out, hist = (self._encode_batched if self._can_batch() else self._encode_generic)(plan, target)
+        return list(out.split(target.sizes)), plan, rows, graphs, hist
+
+    def get_all_embeds_Gt(self, convoluted_embeds, g, t, plan, b, hist):
+        """Isolated pass over ALL entities, then the active rows overwritten
+        (models/DynamicRGCN.py:56-64).  Previous states come from the last history output by row map."""
+        dev = self._device()
+        L = plan.seq_len
+        if getattr(self.args, "use_embed_for_non_active", False):
+            all_embeds = self.ent_embeds
+        else:
+            row_of, dt = plan.final_all(b, L - 1)
+            idx = torch.from_numpy(row_of.astype(np.int32)).to(dev)
+            dt_t = torch.from_numpy(dt).view(-1, 1).to(dev)
+            p1 = self._gather_prev(hist[0], idx, self.num_ents)
+            p2 = p1 if hist[1] is hist[0] else self._gather_prev(hist[1], idx, self.num_ents)
+            all_embeds = self.ent_encoder.forward_isolated(self.ent_embeds, p1, p2, dt_t, t)
+        gid = torch.from_numpy(g.gids).to(dev)
+        return all_embeds.index_copy(0, gid, convoluted_embeds)
+
+    def forward(self, t_list, reverse=False, target_edge_ids=None, samples=None):
+        """models/DynamicRGCN.py:176-194.  `target_edge_ids` / `samples` inject the random draws
+        (SURVEY F11); by default they are sampled here."""
+        dev = self._device()
+        per_graph, plan, rows, graphs, hist = self.encode(t_list, self.train_seq_len, True, target_edge_ids)
+        loss = 0
+        for i, (g, ent_embed) in enumerate(zip(graphs, per_graph)):
+            t = rows[i][-1]
+            if samples is not None:
+                triplets, neg_tail, neg_head = samples[i]
+                labels = torch.zeros(triplets.shape[0], dtype=torch.int64)
+            else:
+                triplets, neg_tail, neg_head, labels = self.corrupter.single_graph_negative_sampling(t, g, self.num_ents)
+            triplets, neg_tail, neg_head, labels = triplets.to(dev), neg_tail.to(dev), neg_head.to(dev), labels.to(dev)
+            all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, plan, i, hist)
+            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
+            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False)
+        return loss

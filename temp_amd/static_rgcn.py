@@ -1,0 +1,71 @@
+"""StaticRGCN -- the non-recurrent baseline (BASELINE config 1) with the reference's interface
+(baselines/StaticRGCN.py:10-113, baselines/TKG_Non_Recurrent.py): per-timestamp 2-layer RGCN on a
+50 % edge subsample of each target snapshot, no history."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as TF
+from . import snapshot as S
+from .rgcn import RGCN
+from .tkg_module import TKG_Module
+
+
+class StaticRGCN(TKG_Module):
+    def __init__(self, args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type=None):
+        super().__init__(args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type)
+        self.ent_embeds = nn.Parameter(torch.Tensor(self.num_ents, self.embed_size))
+        self.rel_embeds = nn.Parameter(torch.Tensor(self.num_rels * 2, self.embed_size))
+        nn.init.xavier_uniform_(self.ent_embeds, gain=nn.init.calculate_gain('relu'))
+        nn.init.xavier_uniform_(self.rel_embeds, gain=nn.init.calculate_gain('relu'))
+        self.sample_rng = np.random.default_rng(getattr(args, "seed", None))
+
+    def build_model(self):
+        self.train_seq_len = self.args.train_seq_len
+        self.test_seq_len = self.args.train_seq_len
+        self.ent_encoder = RGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
+
+    def get_per_graph_ent_embeds(self, t_list, graph_train_list, val=False, edge_ids=None):
+        """baselines/StaticRGCN.py:60-89."""
+        if val:
+            graphs = graph_train_list
+        else:
+            graphs = []
+            for i, g in enumerate(graph_train_list):
+                E = g.number_of_edges()
+                idx = edge_ids[i] if edge_ids is not None else self.sample_rng.choice(np.arange(E), size=int(0.5 * E), replace=False)
+                graphs.append(g.edge_subgraph(idx))
+        bg = S.batch(graphs)
+        ids = torch.from_numpy(bg.gids.astype(np.int32)).to(self.ent_embeds.device)
+        bg.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+        sizes = [g.n for g in graph_train_list]
+        out = self.ent_encoder(bg, [int(t) for t in t_list], sizes)
+        return out.ndata['h'].split(sizes)
+
+    def get_all_embeds_Gt(self, t, g, convoluted_embeds):
+        """baselines/StaticRGCN.py:48-58."""
+        if getattr(self.args, "use_embed_for_non_active", False):
+            all_embeds = self.ent_embeds
+        else:
+            all_embeds = self.ent_encoder.forward_isolated(self.ent_embeds, int(t))
+        gid = torch.from_numpy(g.gids).to(self.ent_embeds.device)
+        return all_embeds.index_copy(0, gid, convoluted_embeds)
+
+    def forward(self, t_list, target_edge_ids=None, samples=None):
+        """baselines/StaticRGCN.py:36-46."""
+        dev = self.ent_embeds.device
+        ts = [int(t) for t in t_list]
+        g_list = [self.graph_dict_train[t] for t in ts]
+        per_graph = self.get_per_graph_ent_embeds(ts, g_list, edge_ids=target_edge_ids)
+        loss = 0
+        for i, (t, g, ent_embed) in enumerate(zip(ts, g_list, per_graph)):
+            if samples is not None:
+                triplets, neg_tail, neg_head = samples[i]
+                labels = torch.zeros(triplets.shape[0], dtype=torch.int64)
+            else:
+                triplets, neg_tail, neg_head, labels = self.corrupter.single_graph_negative_sampling(t, g, self.num_ents)
+            triplets, neg_tail, neg_head, labels = triplets.to(dev), neg_tail.to(dev), neg_head.to(dev), labels.to(dev)
+            all_embeds_g = self.get_all_embeds_Gt(t, g, ent_embed)
+            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
+            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False)
+        return loss

@@ -1,0 +1,75 @@
+"""TKG_Module -- the task base class with the reference's constructor / method surface
+(models/TKG_Module.py:20-274) minus the pytorch_lightning plumbing (Lightning 0.5.2 is a training
+harness, not part of the hot path; the hooks a harness calls -- training_step, validation_step,
+configure_optimizers -- are kept and need no Lightning import).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import scores
+from .sampling import CorruptTriples
+
+
+class TKG_Module(nn.Module):
+    def __init__(self, args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type=None):
+        super().__init__()
+        self.args = self.hparams = args
+        self.graph_dict_train = graph_dict_train
+        self.graph_dict_val = graph_dict_val
+        self.graph_dict_test = graph_dict_test
+        self.total_time = np.array(list(graph_dict_train.keys()))
+        self.num_rels = num_rels
+        self.num_ents = num_ents
+        self.embed_size = args.embed_size
+        self.hidden_size = args.hidden_size
+        self.use_cuda = getattr(args, "use_cuda", False)
+        self.num_pos_facts = args.num_pos_facts
+        self.negative_rate = args.negative_rate
+        self.calc_score = {'distmult': scores.distmult, 'complex': scores.complex, 'transE': scores.transE}[args.score_function]
+        self.build_model()
+        if not getattr(args, "debug", False):
+            self.corrupter = CorruptTriples(self.args, graph_dict_train)
+            if evaluater_type is not None:
+                self.evaluater = evaluater_type(args, self.calc_score, graph_dict_train, graph_dict_val, graph_dict_test)
+
+    def build_model(self):
+        raise NotImplementedError
+
+    # -- harness hooks (models/TKG_Module.py:43-160) ------------------------------------------------
+    def training_step(self, batch_time, batch_idx=0):
+        loss = self.forward(batch_time)
+        return {'loss': loss, 'progress_bar': {'train_loss': loss}, 'log': {'train_loss': loss}}
+
+    def validation_step(self, batch_time, batch_idx=0):
+        ranks, loss = self.evaluate(batch_time)
+        return {'ranks': ranks, 'val_loss': loss}
+
+    def get_metrics(self, ranks):
+        r = ranks.float()
+        return torch.mean(1.0 / r), torch.mean((ranks <= 1).float()), torch.mean((ranks <= 3).float()), torch.mean((ranks <= 10).float())
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.args.lr, weight_decay=0.0001)
+
+    # -- loss (models/TKG_Module.py:202-221) ----------------------------------------------------------
+    def train_link_prediction(self, ent_embed, triplets, neg_samples, labels, all_embeds_g, corrupt_tail=True):
+        r = self.rel_embeds[triplets[:, 1]]
+        if corrupt_tail:
+            score = self.calc_score(ent_embed[triplets[:, 0]], r, all_embeds_g[neg_samples], mode='tail')
+        else:
+            score = self.calc_score(all_embeds_g[neg_samples], r, ent_embed[triplets[:, 2]], mode='head')
+        return F.cross_entropy(score, labels)
+
+    def link_classification_loss(self, ent_embed, rel_embeds, triplets, labels):
+        score = self.calc_score(ent_embed[triplets[:, 0]], rel_embeds[triplets[:, 1]], ent_embed[triplets[:, 2]])
+        return F.binary_cross_entropy_with_logits(score, labels)
+
+    # -- window construction (models/TKG_Module.py:232-250) --------------------------------------------
+    def get_batch_graph_list(self, t_list, seq_len, graph_dict):
+        from .window import window_times
+        rows = window_times(t_list, seq_len, list(graph_dict.keys()))
+        t_batched = [list(x) for x in zip(*rows)]
+        g_batched = [[graph_dict[t] if t is not None else None for t in col] for col in t_batched]
+        return g_batched, t_batched

@@ -1,0 +1,137 @@
+"""Window scheduling for the recurrent snapshot encoder: which snapshot is visited at which window
+position, where each node's previous state lives, and how long ago the node was last active.
+
+This replaces the reference's dense per-step bookkeeping -- `hist_embeddings (bsz,2,N_ents,D)`
+re-allocated and zero-filled at EVERY window position plus `start_time_tensor (bsz,N_ents)`
+(models/DynamicRGCN.py:35-54,156-174; 91 MB of zero-fill per step on ICEWS14) -- by a
+host-side *plan* of int32 row maps, with identical semantics:
+
+    prev(v) at position p = output row of v at position p-1 if v was active there, else 0
+    dt(v)   at position p = p - last_active(v)          (last_active starts at 0)
+
+Because snapshot membership is static, the plan is pure integer work on the host; the device only
+sees `prev_idx` (row into the previous position's output, -1 => zero) and `dt`.
+"""
+import numpy as np
+import torch
+
+from . import snapshot as S
+
+
+def window_times(t_list, seq_len, times, ascending=False):
+    """Window construction of TKG_Module.get_batch_graph_list (models/TKG_Module.py:232-250) and of
+    the backward half of BiDynamicRGCN.get_batch_graph_list (models/BiDynamicRGCN.py:17-49).
+
+    Returns rows[b][p] (left-padded with None).  Forward: targets sorted DESCENDING, window
+    [t-L+1 .. t].  Backward (`ascending=True`): targets sorted ASCENDING, window [t .. t+L-1]
+    reversed so the target is last."""
+    times = [int(t) for t in times]
+    index = {t: i for i, t in enumerate(times)}
+    ts = sorted([int(t) for t in t_list], reverse=not ascending)
+    rows = []
+    for tim in ts:
+        k = index[tim]
+        if not ascending:
+            seq = times[max(0, k + 1 - seq_len):k + 1]
+        else:
+            seq = times[k:k + seq_len][::-1]
+        rows.append([None] * (seq_len - len(seq)) + seq)
+    return rows
+
+
+class Step:
+    """One executed window position: the graphs of the windows active there, batched."""
+    __slots__ = ("p", "windows", "graphs", "times", "sizes", "offsets", "n_rows", "ids", "prev_idx", "dt", "graph",
+                 "row0", "dev")
+
+    def __init__(self, p, windows, graphs, times):
+        self.p, self.windows, self.graphs, self.times = p, windows, graphs, times
+        self.sizes = [g.n for g in graphs]
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        self.n_rows = int(self.offsets[-1])
+        self.ids = np.concatenate([g.gids for g in graphs]) if graphs else np.zeros(0, np.int64)
+        self.prev_idx = None
+        self.dt = None
+        self.graph = None            # batched Snapshot (built lazily)
+        self.row0 = 0                # first row inside an all-visits batch (fast path)
+        self.dev = {}
+
+    def batched(self):
+        if self.graph is None:
+            self.graph = S.batch(self.graphs)
+        return self.graph
+
+    def tensors(self, device):
+        """(ids int32, prev_idx int32, dt float32 (n,1)) on `device`, cached."""
+        key = str(device)
+        t = self.dev.get(key)
+        if t is None:
+            t = (torch.from_numpy(self.ids.astype(np.int32)).to(device),
+                 torch.from_numpy(self.prev_idx.astype(np.int32)).to(device),
+                 torch.from_numpy(self.dt.astype(np.float32)).view(-1, 1).to(device))
+            self.dev[key] = t
+        return t
+
+
+class ChainPlan:
+    """History positions 0..L-2 of one direction, plus the maps the consumers of the final history
+    need (target position, all-entity pass)."""
+
+    def __init__(self, rows, graph_dict, num_ents, seq_len):
+        self.bsz = len(rows)
+        self.seq_len = seq_len
+        self.num_ents = num_ents
+        self.rows = rows
+        row_of = np.full((self.bsz, num_ents), -1, dtype=np.int64)     # row in the previous executed step's output
+        last = np.zeros((self.bsz, num_ents), dtype=np.float32)        # start_time_tensor
+        set_ids = [np.zeros(0, np.int64) for _ in range(self.bsz)]
+        self.steps = []
+        for p in range(seq_len - 1):
+            win = [b for b in range(self.bsz) if rows[b][p] is not None]
+            if not win:
+                continue
+            assert win == list(range(len(win))), "padded windows must form a suffix of the batch"
+            st = Step(p, win, [graph_dict[rows[b][p]] for b in win], [rows[b][p] for b in win])
+            pidx, dts = [], []
+            for j, b in enumerate(win):
+                ids = st.graphs[j].gids
+                pidx.append(row_of[b][ids])
+                dts.append(p - last[b][ids])
+            st.prev_idx = np.concatenate(pidx) if pidx else np.zeros(0, np.int64)
+            st.dt = np.concatenate(dts) if dts else np.zeros(0, np.float32)
+            for j, b in enumerate(win):                                # F8: history holds ONLY this step's nodes
+                ids = st.graphs[j].gids
+                row_of[b][set_ids[b]] = -1
+                row_of[b][ids] = st.offsets[j] + np.arange(len(ids))
+                set_ids[b] = ids
+                last[b][ids] = p
+            self.steps.append(st)
+        self.row_of, self.last = row_of, last
+
+    def flipped(self):
+        """torch.flip(hist, [0]) / flip(start_time) of models/BiDynamicRGCN.py:97-99: re-index the
+        final maps by the forward batch order."""
+        self.row_of = self.row_of[::-1].copy()
+        self.last = self.last[::-1].copy()
+        return self
+
+    def final_prev(self, b, ids, cur_t):
+        """prev_idx / dt of nodes `ids` of window b as get_prev_embeddings (models/DynamicRGCN.py:35-45)
+        would compute them after the last history position."""
+        return self.row_of[b][ids], (cur_t - self.last[b][ids]).astype(np.float32)
+
+    def final_all(self, b, cur_t):
+        """Same for ALL entities (the isolated pass of get_all_embeds_Gt, models/DynamicRGCN.py:56-64)."""
+        return self.row_of[b], (cur_t - self.last[b]).astype(np.float32)
+
+
+def concat_steps(steps):
+    """All visits of several steps as ONE batched graph (fast path: the RGCN stack of every visit is
+    independent of history when only the last layer is recurrent, models/RRGCN.py:182-187), with
+    each step's first row recorded in `step.row0`."""
+    graphs, off = [], 0
+    for st in steps:
+        st.row0 = off
+        graphs.extend(st.graphs)
+        off += st.n_rows
+    return S.batch(graphs), off

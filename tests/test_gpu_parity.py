@@ -207,3 +207,24 @@ def test_determinism_bitwise(hip_backend):
     gb = hip_backend.rgcn_bwd(dg, h, a, gy, w, lw, False, 100, 1)
     for u, v in zip(ga[:3], gb[:3]):
         assert torch.equal(u, v)
+
+
+# ---------------------------------------------------------------------------------------------
+# window level: DynamicRGCN / BiDynamicRGCN / StaticRGCN .forward on the ICEWS14 slice (G10, G12)
+# ---------------------------------------------------------------------------------------------
+from tests.window_cases import check_batched_equals_generic, check_static, check_window  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["G10_uni_grrgcn", "G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol", "G10_bi_grrgcn",
+                                  "G10_uni_grrgcn_d200"])
+def test_window_loss_and_grads_golden_gpu(name):
+    check_window(name, DEV)
+
+
+@pytest.mark.parametrize("name", ["G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol"])
+def test_batched_equals_generic_gpu(name):
+    check_batched_equals_generic(name, DEV)
+
+
+def test_static_rgcn_golden_gpu():
+    check_static(DEV)

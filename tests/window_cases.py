@@ -1,0 +1,145 @@
+"""Window-level parity cases shared by CPU (test backend) and GPU (HIP) runs: drive
+DynamicRGCN / BiDynamicRGCN / StaticRGCN.forward on the committed ICEWS14 slice with the reference's
+recorded random draws and compare loss + gradients with the golden vectors (G10, G12)."""
+import argparse
+
+import numpy as np
+import torch
+
+from oracle import temp_oracle as O
+from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
+from temp_amd.dataset import build_interpolation_snapshots
+from temp_amd.dynamic_rgcn import DynamicRGCN
+from temp_amd.static_rgcn import StaticRGCN
+from tests.golden_util import T, assert_close, checksum, load
+
+_SLICE = {}
+
+
+def slice_snapshots():
+    if not _SLICE:
+        z = load("icews14_slice")
+        tr, va, te = build_interpolation_snapshots(z["train"], z["valid"], z["test"], z["times"])
+        _SLICE.update(num_e=int(z["num_ents"]), num_r=int(z["num_rels"]), times=[int(t) for t in z["times"]], tr=tr, va=va, te=te)
+    return _SLICE
+
+
+def make_args(**over):
+    d = dict(n_bases=16, dropout=0.0, inv_temperature=0.1, learnable_lambda=False, impute=False, post_aggregation=False,
+             post_ensemble=False, num_layers=1, type1=False, rec_only_last_layer=False, use_time_embedding=False,
+             module='GRRGCN', embed_size=32, hidden_size=32, num_pos_facts=3000, negative_rate=20, score_function='complex',
+             train_seq_len=8, test_seq_len=8, use_cuda=False, debug=False, edge_dropout=False, random_dropout=False,
+             use_embed_for_non_active=False, lr=1e-3, seed=0, batch_size=4)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def state_dict_from_oracle(model):
+    """oracle parameter dict -> the REFERENCE's state_dict key names."""
+    sd = {'ent_embeds': model['ent_embeds'], 'rel_embeds': model['rel_embeds']}
+    for ln, d in model['ent_encoder'].items():
+        p = 'ent_encoder.%s.' % ln
+        for k in ('weight', 'loop_weight', 'time_embed', 'time_weight', 'time_weight_forward', 'time_weight_backward', 'h_bias'):
+            if d.get(k) is not None:
+                sd[p + k] = d[k]
+        for name in ('rnn', 'forward_rnn', 'backward_rnn'):
+            if name in d:
+                for li, q in enumerate(d[name]):
+                    for a, b in (('w_ih', 'weight_ih'), ('w_hh', 'weight_hh'), ('b_ih', 'bias_ih'), ('b_hh', 'bias_hh')):
+                        sd['%s%s.%s_l%d' % (p, name, b, li)] = q[a]
+    return sd
+
+
+def build_window_model(z, device, batched=True):
+    s = slice_snapshots()
+    module, rec_only, D, B, L = str(z["module"]), bool(z["rec_only"]), int(z["D"]), int(z["B"]), int(z["L"])
+    cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=bool(z["te"]))
+    model = O.init_model(cfg, s["num_e"], s["num_r"], len(s["times"]), D, seed=int(z["seed"]))
+    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6
+    args = make_args(module=module, rec_only_last_layer=rec_only, embed_size=D, hidden_size=D, n_bases=B, train_seq_len=L,
+                     test_seq_len=L, negative_rate=int(z["neg"]), use_time_embedding=bool(z["te"]))
+    cls = BiDynamicRGCN if module.startswith("Bi") else DynamicRGCN
+    m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
+    m.load_state_dict(state_dict_from_oracle(model), strict=True)
+    m.use_batched_path = batched
+    return m.to(device)
+
+
+def window_inputs(z):
+    n = int(z["n_choices"])
+    edge_ids = [z["choice_%d" % i] for i in range(n)]
+    samples = [(T(z["trip_%d" % i]).long(), T(z["negtail_%d" % i]).long(), T(z["neghead_%d" % i]).long()) for i in range(n)]
+    return edge_ids, samples
+
+
+def check_window(name, device, batched=True):
+    z = load(name)
+    m = build_window_model(z, device, batched)
+    edge_ids, samples = window_inputs(z)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    loss = m(t_list, target_edge_ids=edge_ids, samples=samples)
+    want = float(z["loss"])
+    assert abs(loss.item() - want) < 3e-5 * abs(want), (name, loss.item(), want)
+    loss.backward()
+    eg = m.ent_embeds.grad
+    rows = T(z["d_ent_nz_rows"]).long().to(device)
+    assert_close(eg[rows], z["d_ent_nz_vals"], 1e-4, 3e-6, name + " d_ent")
+    mask = torch.ones(eg.shape[0], dtype=torch.bool, device=device)
+    mask[rows] = False
+    assert float(eg[mask].abs().max()) < 1e-7
+    assert_close(m.rel_embeds.grad, z["d_rel"], 1e-4, 3e-6, name + " d_rel")
+    checked = 0
+    for k, v in m.named_parameters():
+        gk = "gabs_" + k
+        if gk in z.files and v.grad is not None:
+            want = float(z[gk])
+            got = v.grad.double().abs().sum().item()
+            assert abs(got - want) < 3e-4 * max(want, 1e-3), (name, k, got, want)
+            checked += 1
+    assert checked >= 5
+    return m
+
+
+def check_batched_equals_generic(name, device):
+    """The batched path (one RGCN launch per layer over all visits + GRU chain through prev_idx)
+    must reproduce the reference-granular path."""
+    z = load(name)
+    edge_ids, samples = window_inputs(z)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    outs = []
+    for batched in (False, True):
+        m = build_window_model(z, device, batched)
+        assert m._can_batch() == batched
+        per_graph, *_ = m.encode(t_list, int(z["L"]), True, edge_ids)
+        s = sum((e * (i + 1)).sum() for i, e in enumerate(per_graph))
+        s.backward()
+        outs.append((per_graph, m.ent_embeds.grad.clone(), m.ent_encoder.layer_2.weight.grad.clone()))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert_close(a, b, 1e-5, 2e-6, name + " batched vs generic")
+    assert_close(outs[0][1], outs[1][1], 5e-5, 3e-6, name + " d_ent batched vs generic")
+    assert_close(outs[0][2], outs[1][2], 5e-5, 3e-6, name + " d_weight batched vs generic")
+
+
+def check_static(device):
+    z = load("G12_static_rgcn")
+    s = slice_snapshots()
+    D, B, seed = int(z["D"]), int(z["B"]), int(z["seed"])
+    cfg = dict(module="SRGCN", n_bases=B, inv_temperature=0.1, rec_only_last_layer=False, use_time_embedding=False)
+    model = O.init_model(cfg, s["num_e"], s["num_r"], len(s["times"]), D, seed=seed, bias=True)
+    rng = np.random.default_rng(seed + 1)
+    for ln in ("layer_1", "layer_2"):
+        model["ent_encoder"][ln]["h_bias"] = T(rng.uniform(-0.3, 0.3, D).astype(np.float32))
+    args = make_args(module="SRGCN", embed_size=D, hidden_size=D, n_bases=B)
+    m = StaticRGCN(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
+    m.load_state_dict(state_dict_from_oracle(model), strict=True)
+    m.to(device)
+    tl = [int(t) for t in z["t_list"]]
+    with torch.no_grad():
+        embeds = m.get_per_graph_ent_embeds(tl, [s["tr"][t] for t in tl], val=True)
+        iso = m.ent_encoder.forward_isolated(m.ent_embeds[:200], tl[0])
+    for i, e in enumerate(embeds):
+        assert_close(e, z["emb_%d" % i], 1e-5, 2e-6, "G12 emb %d" % i)
+    assert_close(iso, z["iso"], 1e-5, 2e-6, "G12 iso")
+    loss = m(torch.tensor(tl))            # end-to-end with its own sampler: finite, differentiable
+    loss.backward()
+    assert torch.isfinite(loss) and m.ent_embeds.grad.abs().sum() > 0
