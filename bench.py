@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Headline benchmark: edges/sec of a train-seq-len=15 RGCN+GRU window encoder, forward+backward.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S-gdelt]
+
+One "step" = one forward+backward pass of the snapshot encoder (2 RGCN layers + GRU/BiGRU chain,
+BiGRRGCN with --rec-only-last-layer) over one batch of bsz windows of synthetic GDELT-shaped
+snapshots (temp_amd/synthetic.py; the real GDELT files are not shipped with the reference), with
+the upstream gradient = ones on the target-position output.  A unit of work is one
+snapshot-edge visit; `value` = edge visits processed by all ranks / wall time, inputs (parameters,
+snapshot edge views, window row maps) already resident in HBM.
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): every rank encodes its own bsz
+windows (weak scaling, the reference's DDP axis) and the parameter gradients are all-reduced in
+one bucket after backward.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (largest share of traced kernel time): algorithmic bytes (or
+                flops) per step / its HIP-event time per step, against 8 TB/s HBM (or the 157.3
+                TFLOP/s fp32 MFMA peak).  Events are recorded by libtemp_amd around every launch
+                on the launch stream (temp_trace_begin/end) during extra traced steps run right
+                after the timed region, so the headline number is not perturbed.
+  cpu_baseline  the CPU oracle (torch restatement of the reference's op sequence, kind "port")
+                timed on the host cores on ONE window of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak, same guide
+
+
+def make_args(w, module):
+    return argparse.Namespace(
+        n_bases=w["B"], dropout=0.0, inv_temperature=0.1, learnable_lambda=False, impute=False, post_aggregation=False,
+        post_ensemble=False, num_layers=1, type1=False, rec_only_last_layer=True, use_time_embedding=False, module=module,
+        embed_size=w["D"], hidden_size=w["D"], num_pos_facts=3000, negative_rate=500, score_function="complex",
+        train_seq_len=w["L"], test_seq_len=w["L"], use_cuda=True, debug=True, edge_dropout=False, random_dropout=False,
+        use_embed_for_non_active=False, lr=1e-3, seed=0, batch_size=w["bsz"])
+
+
+def build_model(w, device):
+    from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
+    from temp_amd.dynamic_rgcn import DynamicRGCN
+    torch.manual_seed(1)
+    cls = BiDynamicRGCN if w["module"].startswith("Bi") else DynamicRGCN
+    snaps = w["snapshots"]
+    m = cls(make_args(w, w["module"]), w["num_ents"], w["num_rels"], snaps, snaps, snaps)
+    return m.to(device)
+
+
+def algorithmic_costs(wb, D, bi, S=2):
+    """Per-step ALGORITHMIC bytes / flops of every kernel family of the batched path (fp32, int32
+    ids).  n = node visits, E = edge visits of the step; the GRU runs once per node visit (twice on
+    the target position of the bi model)."""
+    n, E = wb.n_node_visits, wb.n_edge_visits
+    n_gru = n + (wb.target.n_rows if bi else 0)
+    row = 4 * D
+    c = {}
+    c["k_gather_rows"] = dict(bytes=n * (4 + 2 * row), flops=0)
+    c["k_scatter_add_rows"] = dict(bytes=n * (4 + 3 * row), flops=0)
+    c["k_rgcn_agg<fwd>"] = dict(bytes=2 * (E * (row + 8) + n * row), flops=2 * E * 2 * D * S)
+    c["k_rgcn_agg<dx>"] = dict(bytes=2 * (E * (row + 12) + n * row), flops=2 * E * 2 * D * S)
+    c["k_rgcn_dw"] = dict(bytes=2 * (E * (2 * row + 12)), flops=2 * E * 2 * D * S)
+    c["k_gemm_panel<loop_fwd>"] = dict(bytes=2 * n * 3 * row, flops=2 * 2 * n * D * D)
+    c["k_gemm_panel<loop_dx>"] = dict(bytes=2 * n * 3 * row, flops=2 * 2 * n * D * D)
+    c["k_gemm_tn"] = dict(bytes=2 * n * 2 * row + n_gru * (2 * row + 6 * row), flops=2 * 2 * n * D * D + 2 * 2 * n_gru * 3 * D * D)
+    c["k_relu_bwd"] = dict(bytes=n * 3 * row, flops=0)
+    c["k_gru_fwd"] = dict(bytes=n_gru * (3 * row + 5 * row + 8), flops=12 * n_gru * D * D)
+    c["k_gru_bwd_gates"] = dict(bytes=n_gru * (6 * row + 6 * row), flops=0)
+    c["k_gemm_panel<gru_dx>"] = dict(bytes=n_gru * (3 * row + row), flops=2 * n_gru * 3 * D * D)
+    c["k_gemm_panel<gru_dprev>"] = dict(bytes=n_gru * (3 * row + 3 * row), flops=2 * n_gru * 3 * D * D)
+    c["k_colsum_part"] = dict(bytes=n_gru * 6 * row, flops=0)
+    return c
+
+
+MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd")
+
+
+def traced_steps(step_fn, n_steps, lib):
+    cap = 20000
+    from temp_amd import _lib
+    _lib.check(lib.temp_trace_begin(cap), "temp_trace_begin")
+    for _ in range(n_steps):
+        step_fn()
+    ids = (ctypes.c_int32 * cap)()
+    ms = (ctypes.c_float * cap)()
+    n = ctypes.c_int32(0)
+    _lib.check(lib.temp_trace_end(ids, ms, cap, ctypes.byref(n)), "temp_trace_end")
+    agg = {}
+    for i in range(n.value):
+        name = lib.temp_trace_kernel_name(ids[i]).decode()
+        a = agg.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += ms[i]
+    return {k: dict(launches_per_step=v[0] / n_steps, ms_per_step=v[1] / n_steps, avg_ms=v[1] / v[0]) for k, v in agg.items()}
+
+
+def cpu_baseline(model, w, device_targets):
+    """The oracle (port of the reference's op sequence, dense history kept) on ONE window, host cores."""
+    from oracle import temp_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    bi = w["module"].startswith("Bi")
+    cfg = dict(module=w["module"], n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+    om = O.model_from_state_dict(sd, cfg)
+    gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
+    times = sorted(gd.keys())
+    tl = [device_targets[0]]
+    L = w["L"]
+    for v in O.leaf_tensors(om).values():
+        v.requires_grad_(True)
+
+    def run():
+        if bi:
+            tf, tb = O.get_batch_graph_list_bi(tl, L, times)
+            Hf = O.bi_pre_forward(om, cfg, gd, tf, L, True)
+            Hb = O.bi_pre_forward(om, cfg, gd, tb, L, False)
+            out = O.bi_target_embeds(om, cfg, Hf, Hb, [gd[tl[0]]], tf[-1], L)
+            visits = [t for col in tf[:-1] + tb[:-1] for t in col if t is not None] + tl
+        else:
+            tf = O.get_batch_graph_list(tl, L, times)
+            H = O.uni_pre_forward(om, cfg, gd, tf, L)
+            out = O.uni_target_embeds(om, cfg, H, [gd[tl[0]]], tf[-1], L)
+            visits = [t for col in tf for t in col if t is not None]
+        sum(o.sum() for o in out).backward()
+        return sum(gd[t].num_edges for t in visits)
+
+    t0 = time.perf_counter()
+    edges = run()
+    dt = time.perf_counter() - t0
+    return dict(value=edges / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 window (bsz=1) of %s: %d snapshot visits, %d edge visits, full target graph, fwd+bwd, %.1f s"
+                       % (w["name"], len(tl) * (2 * L - 1 if bi else L), edges, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="S-gdelt")
+    ap.add_argument("--trace-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel trace table to stderr")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from temp_amd import _lib, synthetic
+    from temp_amd import backend as TB
+    lib = _lib.load()
+    assert TB.get_backend().name == "hip"
+
+    w = synthetic.workload(a.workload, seed=0)
+    model = build_model(w, device)
+    bi = w["module"].startswith("Bi")
+    targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rank)
+    model.sample_rng = np.random.default_rng(2 + rank)
+    t0 = time.perf_counter()
+    wb = model.prepare(targets, w["L"], train=True)
+    torch.cuda.synchronize()
+    prepare_s = time.perf_counter() - t0
+    params = [p for p in model.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        out, _ = model.run(wb)
+        out.sum().backward()
+        if dist is not None:
+            grads = [p.grad for p in params if p.grad is not None]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat)
+            flat.div_(world)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+
+    for _ in range(a.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    edges = float(wb.n_edge_visits)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        e = torch.tensor([edges], device=device, dtype=torch.float64)
+        dist.all_reduce(e)
+        edges = float(e.item())
+    value = edges * a.steps / elapsed
+
+    roof = None
+    cpu = None
+    if rank == 0:
+        tr = traced_steps(step, a.trace_steps, lib)
+        costs = algorithmic_costs(wb, w["D"], bi, w["D"] // w["B"])
+        total_ms = sum(v["ms_per_step"] for v in tr.values())
+        dom = max(tr, key=lambda k: tr[k]["ms_per_step"])
+        if a.kernel_table:
+            for k in sorted(tr, key=lambda k: -tr[k]["ms_per_step"]):
+                v = tr[k]
+                cst = costs.get(k, {})
+                gbs = cst.get("bytes", 0) / (v["ms_per_step"] * 1e-3) / 1e9 if v["ms_per_step"] else 0
+                tfs = cst.get("flops", 0) / (v["ms_per_step"] * 1e-3) / 1e12 if v["ms_per_step"] else 0
+                print("%-28s launches/step %6.1f  ms/step %8.3f (%4.1f%%)  avg %8.4f ms  alg %7.1f GB/s %6.1f TF/s"
+                      % (k, v["launches_per_step"], v["ms_per_step"], 100 * v["ms_per_step"] / total_ms, v["avg_ms"], gbs, tfs),
+                      file=sys.stderr)
+        cst = costs.get(dom, dict(bytes=0, flops=0))
+        sec = tr[dom]["ms_per_step"] * 1e-3
+        if dom.startswith(MFMA_KERNELS) and cst["flops"]:
+            ach = cst["flops"] / sec / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None)
+        else:
+            ach = cst["bytes"] / sec / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
+        roof.update(avg_launch_ms=tr[dom]["avg_ms"], launches_per_step=tr[dom]["launches_per_step"],
+                    share_of_kernel_time=tr[dom]["ms_per_step"] / total_ms, traced_kernel_ms_per_step=total_ms)
+        # whole-step view against the HBM roofline with SURVEY 8d's per-edge-visit byte model
+        n_over_e = wb.n_node_visits / max(wb.n_edge_visits, 1)
+        D = w["D"]
+        bytes_per_edge = 2 * (12 * D + 24) + n_over_e * (2 * (20 * D + 16) + 32 * D + 4)
+        roof["step_bytes_per_edge_visit"] = bytes_per_edge
+        roof["step_frac_of_hbm"] = (wb.n_edge_visits * a.steps / elapsed if world == 1 else value / world) * bytes_per_edge / (HBM_PEAK_GBS * 1e9)
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline(model, w, targets)
+
+    if rank == 0:
+        out = dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=%d" % w["L"], value=value, unit="edges/s", n_gpus=world,
+                   steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=w["name"], encoder=w["module"], rec_only_last_layer=True, seq_len=w["L"],
+                               windows_per_gpu=w["bsz"], embed=w["D"], n_bases=w["B"], entities=w["num_ents"],
+                               relations=w["num_rels"], edges_per_snapshot=w["edges_per_snap"],
+                               edge_visits_per_step_per_gpu=wb.n_edge_visits, node_visits_per_step_per_gpu=wb.n_node_visits,
+                               parallelism="dp%d(windows)+grad-allreduce" % world, host_prepare_s=prepare_s),
+                   roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

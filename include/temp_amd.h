@@ -191,6 +191,16 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
  * (float4 copy of `bytes` bytes, dst and src must not overlap). */
 int temp_copy_probe(const void* src, void* dst, size_t bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-kernel timing for bench.py's roofline (not used by the product path).  Between begin and end
+ * every kernel launch of this library is bracketed by HIP events on its launch stream.
+ * temp_trace_end() synchronises the device, returns up to `capacity` (kernel id, milliseconds)
+ * records in launch order and releases the events.  One trace at a time.
+ * ---------------------------------------------------------------------------------------------- */
+int temp_trace_begin(int capacity);
+int temp_trace_end(int* kernel_ids /*host*/, float* ms /*host*/, int capacity, int* n_out /*host*/);
+const char* temp_trace_kernel_name(int kernel_id);
+
 #ifdef __cplusplus
 }
 #endif

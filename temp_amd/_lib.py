@@ -50,6 +50,9 @@ SYMBOLS = {
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_copy_probe": (_I, [c_vp, c_vp, _SZ, c_vp]),
+    "temp_trace_begin": (_I, [_I]),
+    "temp_trace_end": (_I, [c_i32p, c_f32p, _I, c_i32p]),
+    "temp_trace_kernel_name": (ctypes.c_char_p, [_I]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ import torch
 
 from . import functional as TF
 from .birrgcn import BiGRRGCNLayer, BiRRGCN
-from .dynamic_rgcn import DynamicRGCN
+from .dynamic_rgcn import DynamicRGCN, WindowBatch
 from .rrgcn import run_rnn
 from .window import ChainPlan, Step, concat_steps, window_times
 
@@ -66,8 +66,10 @@ class BiDynamicRGCN(DynamicRGCN):
         st_b.graph = None
         return st, st_b
 
-    def _encode_generic_bi(self, plan_f, plan_b, tf, tb):
+    def _run_generic(self, wb):
         dev = self._device()
+        plan_f, plan_b = wb.plan
+        tf, tb = wb.target, wb.target_b
         hf = self.pre_forward(plan_f, True)
         hb = self.pre_forward(plan_b, False)
         ids, pf, dtf = tf.tensors(dev)
@@ -77,17 +79,16 @@ class BiDynamicRGCN(DynamicRGCN):
         n = tf.n_rows
         out = self.ent_encoder(g, self._gather_prev(hf[0], pf, n), self._gather_prev(hf[1], pf, n), dtf,
                                self._gather_prev(hb[0], pb, n), self._gather_prev(hb[1], pb, n), dtb, tf.times, tf.sizes)
-        return out, hf, hb
+        return out, (hf, hb)
 
     # -- batched path --------------------------------------------------------------------------------------
-    def _encode_batched_bi(self, plan_f, plan_b, tf, tb):
+    def _run_batched(self, wb):
         enc, dev = self.ent_encoder, self._device()
-        steps = plan_f.steps + plan_b.steps + [tf]
-        g_all, total = concat_steps(steps)
-        ids_all = torch.from_numpy(g_all.gids.astype(np.int32)).to(dev)
-        h0 = TF.gather_rows(self.ent_embeds, ids_all)
-        y1 = enc.layer_1.conv(g_all, h0)
-        y2 = enc.layer_2.conv(g_all, y1)                      # ReLU fused (models/BiRRGCN.py:202-203)
+        plan_f, plan_b = wb.plan
+        tf, tb = wb.target, wb.target_b
+        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
+        y1 = enc.layer_1.conv(wb.g_all, h0)
+        y2 = enc.layer_2.conv(wb.g_all, y1)                   # ReLU fused (models/BiRRGCN.py:202-203)
         l2 = enc.layer_2
         lam, dec = l2.inv_temperature, l2.decay_spec()
 
@@ -112,20 +113,30 @@ class BiDynamicRGCN(DynamicRGCN):
             run_rnn(l2.backward_rnn, x, Hb if Hb is not None else zero, dtb, lam, dec, pb)
         if enc.use_time_embedding:
             out = out + l2.get_time_embedding(tf.times, tf.sizes)
-        return out, (Hf, Hf), (Hb, Hb)
+        return out, ((Hf, Hf), (Hb, Hb))
 
     # ---------------------------------------------------------------------------------------------
-    def encode(self, t_list, seq_len, train=True, target_edge_ids=None):
-        rows_f = window_times(t_list, seq_len, self.total_time)
+    def prepare(self, t_list, seq_len, train=True, target_edge_ids=None):
+        dev = self._device()
+        wb = WindowBatch()
+        wb.rows = window_times(t_list, seq_len, self.total_time)
         rows_b = window_times(t_list, seq_len, self.total_time, ascending=True)
-        plan_f = ChainPlan(rows_f, self.graph_dict_train, self.num_ents, seq_len)
+        plan_f = ChainPlan(wb.rows, self.graph_dict_train, self.num_ents, seq_len)
         plan_b = ChainPlan(rows_b, self.graph_dict_train, self.num_ents, seq_len).flipped()
-        graphs = [self.graph_dict_train[r[-1]] for r in rows_f]
-        tgt = self.sample_target_graphs(graphs, 0.5, target_edge_ids) if train else graphs
-        tf, tb = self._bi_target(plan_f, plan_b, rows_f, tgt)
-        fn = self._encode_batched_bi if self._can_batch() else self._encode_generic_bi
-        out, hf, hb = fn(plan_f, plan_b, tf, tb)
-        return list(out.split(tf.sizes)), (plan_f, plan_b), rows_f, graphs, (hf, hb)
+        wb.plan = (plan_f, plan_b)
+        wb.graphs = [self.graph_dict_train[r[-1]] for r in wb.rows]
+        tgt = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
+        wb.target, wb.target_b = self._bi_target(plan_f, plan_b, wb.rows, tgt)
+        wb.batched = self._can_batch()
+        wb.steps = plan_f.steps + plan_b.steps + [wb.target]
+        self._upload(wb, dev)
+        wb.target_b.tensors(dev)
+        return wb
+
+    def encode(self, t_list, seq_len, train=True, target_edge_ids=None):
+        wb = self.prepare(t_list, seq_len, train, target_edge_ids)
+        out, hist = self.run(wb)
+        return list(out.split(wb.target.sizes)), wb.plan, wb.rows, wb.graphs, hist
 
     def get_all_embeds_Gt(self, convoluted_embeds, g, t, plans, b, hist):
         """models/BiDynamicRGCN.py:102-112."""

@@ -48,6 +48,23 @@ __device__ __forceinline__ ItemRange xcd_items(int n_items, int per_block) {
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- optional per-kernel timing (bench only): HIP events recorded on the launch stream around
+// every kernel launch between temp_trace_begin() and temp_trace_end().  Off by default; the only
+// mutable global of the library, with an explicit caller-driven lifecycle.
+enum KernelId {
+  K_RGCN_AGG_FWD = 0, K_RGCN_AGG_DX, K_RGCN_DW, K_FIXUP, K_GEMM_LOOP_FWD, K_GEMM_LOOP_DX, K_GEMM_TN, K_REDUCE_SLICES, K_COLSUM,
+  K_RELU_BWD, K_GRU_FWD, K_GRU_BWD_GATES, K_GEMM_GRU_DX, K_GEMM_GRU_DPREV, K_GATHER_ROWS, K_SCATTER_ADD, K_DECAY_GRAD, K_COPY,
+  K_GEMM_ISO, K_COUNT
+};
+int trace_open(int kernel_id, hipStream_t st);       // -> slot or -1
+void trace_close(int slot, hipStream_t st);
+#define TEMP_LAUNCH(KID, kernel, grid, block, shmem, st, ...)            \
+  do {                                                                   \
+    const int _slot = ::temp::trace_open((KID), (st));                   \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);     \
+    ::temp::trace_close(_slot, (st));                                    \
+  } while (0)
+
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? TEMP_OK : TEMP_E_LAUNCH;
@@ -59,7 +76,7 @@ struct EpiAddBiasAct;   // gemm_kernels.hip
 // C[M,N] = act( (row_mask==NULL || row_mask[m] > 0 ? addend[m,n] : 0) + bias[n] + A[M,K] . B )
 //   A: row-major, lda; a_idx nullable row gather.  B: [K,N] row-major (ldb) or, if trans_b,
 //   stored as [N,K] row-major (ldb).  addend/bias/row_mask nullable.  out may alias addend.
-int gemm_add_bias_act(int M, int N, int K, const float* A, int lda, const int32_t* a_idx,
+int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx,
                       const float* B, int ldb, int trans_b,
                       const float* addend, int ld_add, const int32_t* row_mask, const float* bias, int act,
                       float* out, int ldo, hipStream_t st);

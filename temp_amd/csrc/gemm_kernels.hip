@@ -30,11 +30,11 @@ struct EpiAddBiasAct {
   }
 };
 
-int gemm_add_bias_act(int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
+int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
                       const float* addend, int ld_add, const int32_t* row_mask, const float* bias, int act, float* out, int ldo,
                       hipStream_t st) {
   EpiAddBiasAct epi{addend, ld_add, row_mask, bias, act, out, ldo};
-  return launch_gemm_panel(M, N, K, A, lda, a_idx, B, ldb, trans_b, epi, st);
+  return launch_gemm_panel(kid, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -128,11 +128,11 @@ int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int 
   int rps = ceil_div(M > 0 ? M : 1, S);
   rps = (rps + 7) / 8 * 8;
   dim3 grid(ceil_div(ceil_div(Ka, 32), 4), ceil_div(Nb, TN_NT * 32), S);
-  hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, (float*)ws);
+  TEMP_LAUNCH(K_GEMM_TN, k_gemm_tn, grid, dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, (float*)ws);
   const size_t elems = (size_t)Ka * Nb;
   int rg = ceil_div((long long)elems, 256);
   if (rg > 2048) rg = 2048;
-  hipLaunchKernelGGL(k_reduce_slices, dim3(rg), dim3(256), 0, st, S, elems, Nb, (const float*)ws, out, ldo);
+  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, S, elems, Nb, (const float*)ws, out, ldo);
   return launch_status();
 }
 
@@ -160,8 +160,8 @@ int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, si
   if (cols <= 0) return TEMP_OK;
   const int nb = ceil_div(rows > 0 ? rows : 1, CS_RPB);
   if (!ws || ws_bytes < (size_t)nb * cols * sizeof(float)) return TEMP_E_WORKSPACE;
-  hipLaunchKernelGGL(k_colsum_part, dim3(ceil_div(cols, 64), nb), dim3(256), 0, st, rows, cols, X, ldx, (float*)ws);
-  hipLaunchKernelGGL(k_reduce_slices, dim3(ceil_div(cols, 256)), dim3(256), 0, st, nb, (size_t)cols, cols, (const float*)ws, out, cols);
+  TEMP_LAUNCH(K_COLSUM, k_colsum_part, dim3(ceil_div(cols, 64), nb), dim3(256), 0, st, rows, cols, X, ldx, (float*)ws);
+  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(ceil_div(cols, 256)), dim3(256), 0, st, nb, (size_t)cols, cols, (const float*)ws, out, cols);
   return launch_status();
 }
 
@@ -179,7 +179,7 @@ int relu_bwd(size_t n, const float* y, const float* dy, float* dz, hipStream_t s
   const size_t n4 = n / 4;
   int grid = ceil_div((long long)n4, 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_relu_bwd, dim3(grid), dim3(256), 0, st, n4, (const float4*)y, (const float4*)dy, (float4*)dz);
+  TEMP_LAUNCH(K_RELU_BWD, k_relu_bwd, dim3(grid), dim3(256), 0, st, n4, (const float4*)y, (const float4*)dy, (float4*)dz);
   return launch_status();
 }
 
@@ -207,11 +207,72 @@ __global__ void __launch_bounds__(256) k_copy(size_t n16, const float4* __restri
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// ---- trace state -------------------------------------------------------------------------------
+struct TraceState { hipEvent_t* ev; int* ids; int cap; int n; };
+static TraceState* g_trace = nullptr;
+
+int trace_open(int kernel_id, hipStream_t st) {
+  TraceState* t = g_trace;
+  if (!t) return -1;
+  const int slot = __atomic_fetch_add(&t->n, 1, __ATOMIC_RELAXED);
+  if (slot >= t->cap) return -1;
+  t->ids[slot] = kernel_id;
+  hipEventRecord(t->ev[2 * slot], st);
+  return slot;
+}
+void trace_close(int slot, hipStream_t st) {
+  TraceState* t = g_trace;
+  if (!t || slot < 0) return;
+  hipEventRecord(t->ev[2 * slot + 1], st);
+}
+
 }  // namespace temp
 
 using namespace temp;
 
 extern "C" {
+
+int temp_trace_begin(int capacity) {
+  if (capacity <= 0 || g_trace) return TEMP_E_BADARG;
+  TraceState* t = new TraceState();
+  t->cap = capacity;
+  t->n = 0;
+  t->ids = new int[capacity];
+  t->ev = new hipEvent_t[2 * (size_t)capacity];
+  for (int i = 0; i < 2 * capacity; ++i)
+    if (hipEventCreate(&t->ev[i]) != hipSuccess) return TEMP_E_LAUNCH;
+  g_trace = t;
+  return TEMP_OK;
+}
+
+int temp_trace_end(int* kernel_ids, float* ms, int capacity, int* n_out) {
+  TraceState* t = g_trace;
+  if (!t || !n_out) return TEMP_E_BADARG;
+  g_trace = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess) return TEMP_E_LAUNCH;
+  int n = t->n < t->cap ? t->n : t->cap;
+  if (n > capacity) n = capacity;
+  for (int i = 0; i < n; ++i) {
+    float v = 0.f;
+    hipEventElapsedTime(&v, t->ev[2 * i], t->ev[2 * i + 1]);
+    if (kernel_ids) kernel_ids[i] = t->ids[i];
+    if (ms) ms[i] = v;
+  }
+  *n_out = n;
+  for (int i = 0; i < 2 * t->cap; ++i) hipEventDestroy(t->ev[i]);
+  delete[] t->ev;
+  delete[] t->ids;
+  delete t;
+  return TEMP_OK;
+}
+
+const char* temp_trace_kernel_name(int id) {
+  static const char* names[] = {"k_rgcn_agg<fwd>", "k_rgcn_agg<dx>", "k_rgcn_dw", "k_fixup", "k_gemm_panel<loop_fwd>",
+                                "k_gemm_panel<loop_dx>", "k_gemm_tn", "k_reduce_slices", "k_colsum_part", "k_relu_bwd", "k_gru_fwd",
+                                "k_gru_bwd_gates", "k_gemm_panel<gru_dx>", "k_gemm_panel<gru_dprev>", "k_gather_rows",
+                                "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>"};
+  return (id >= 0 && id < K_COUNT) ? names[id] : "?";
+}
 
 int temp_abi_version(void) { return TEMP_ABI_VERSION; }
 
@@ -229,7 +290,7 @@ const char* temp_error_string(int code) {
 int temp_rgcn_isolated_fwd(int n, int d, const float* e, const float* loop_w, const float* bias, int act, float* out, void* stream) {
   if (n < 0 || d <= 0 || !loop_w || (n > 0 && (!e || !out))) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
-  return gemm_add_bias_act(n, d, d, e, d, nullptr, loop_w, d, 0, e, d, nullptr, bias, act, out, d, (hipStream_t)stream);
+  return gemm_add_bias_act(K_GEMM_ISO, n, d, d, e, d, nullptr, loop_w, d, 0, e, d, nullptr, bias, act, out, d, (hipStream_t)stream);
 }
 
 size_t temp_rgcn_isolated_bwd_workspace(int n, int d) {
@@ -261,7 +322,7 @@ int temp_rgcn_isolated_bwd(int n, int d, const float* e, const float* out, const
     dz = dzbuf;
   }
   // d_e = dz + dz . loop_w^T
-  rc = gemm_add_bias_act(n, d, d, dz, d, nullptr, loop_w, d, 1, dz, d, nullptr, nullptr, TEMP_ACT_NONE, d_e, d, st);
+  rc = gemm_add_bias_act(K_GEMM_ISO, n, d, d, dz, d, nullptr, loop_w, d, 1, dz, d, nullptr, nullptr, TEMP_ACT_NONE, d_e, d, st);
   if (rc) return rc;
   rc = gemm_tn(n, d, d, e, d, dz, d, d_loop_w, d, tn, tnb, st);
   if (rc) return rc;
@@ -275,7 +336,7 @@ int temp_gather_rows(int n, int d, const float* table, const int32_t* idx, float
   if (n == 0) return TEMP_OK;
   int grid = ceil_div((long long)n * (d / 4), 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, d / 4, (const float4*)table, idx, (float4*)out);
+  TEMP_LAUNCH(K_GATHER_ROWS, k_gather_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, d / 4, (const float4*)table, idx, (float4*)out);
   return launch_status();
 }
 
@@ -284,14 +345,14 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
   if (n == 0) return TEMP_OK;
   int grid = ceil_div((long long)n * d, 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, d, src, idx, table);
+  TEMP_LAUNCH(K_SCATTER_ADD, k_scatter_add_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, d, src, idx, table);
   return launch_status();
 }
 
 int temp_copy_probe(const void* src, void* dst, size_t bytes, void* stream) {
   if (!src || !dst || bytes % 16) return TEMP_E_BADARG;
   if (bytes == 0) return TEMP_OK;
-  hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, (hipStream_t)stream, bytes / 16, (const float4*)src, (float4*)dst);
+  TEMP_LAUNCH(K_COPY, k_copy, dim3(2048), dim3(256), 0, (hipStream_t)stream, bytes / 16, (const float4*)src, (float4*)dst);
   return launch_status();
 }
 

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
 }
 
 template <class Epi>
-int launch_gemm_panel(int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
+int launch_gemm_panel(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
                       const Epi& epi, hipStream_t st) {
   if (M <= 0 || N <= 0) return TEMP_OK;
   if (K % 4 != 0 || lda % 4 != 0) return TEMP_E_UNSUPPORTED;
@@ -97,10 +97,10 @@ int launch_gemm_panel(int M, int N, int K, const float* A, int lda, const int32_
   while (nt > 1 && (long long)row_blocks * ceil_div(ntiles, nt) < 512) nt = (nt == 7) ? 4 : nt / 2;
   dim3 grid(row_blocks, ceil_div(ntiles, nt));
   switch (nt) {
-    case 7: hipLaunchKernelGGL((k_gemm_panel<7, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
-    case 4: hipLaunchKernelGGL((k_gemm_panel<4, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
-    case 2: hipLaunchKernelGGL((k_gemm_panel<2, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
-    default: hipLaunchKernelGGL((k_gemm_panel<1, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
+    case 7: TEMP_LAUNCH(kid, (k_gemm_panel<7, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
+    case 4: TEMP_LAUNCH(kid, (k_gemm_panel<4, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
+    case 2: TEMP_LAUNCH(kid, (k_gemm_panel<2, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
+    default: TEMP_LAUNCH(kid, (k_gemm_panel<1, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
   }
   return launch_status();
 }

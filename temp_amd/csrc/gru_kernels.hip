@@ -241,10 +241,10 @@ int temp_gru_fwd(int n, int d, int variant, const float* x, const float* prev, c
   if (n == 0) return TEMP_OK;
   dim3 grid(ceil_div(n, 128), ceil_div(d, 32));
   if (variant == TEMP_GRU_TORCH)
-    hipLaunchKernelGGL((k_gru_fwd<TEMP_GRU_TORCH>), grid, dim3(256), 0, (hipStream_t)stream, n, d, x, prev, prev_idx, dt, lambda, decay_wb,
+    TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<TEMP_GRU_TORCH>), grid, dim3(256), 0, (hipStream_t)stream, n, d, x, prev, prev_idx, dt, lambda, decay_wb,
                        w_ih, w_hh, b_ih, b_hh, h_out, saved);
   else
-    hipLaunchKernelGGL((k_gru_fwd<TEMP_GRU_TYPE1>), grid, dim3(256), 0, (hipStream_t)stream, n, d, x, prev, prev_idx, dt, lambda, decay_wb,
+    TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<TEMP_GRU_TYPE1>), grid, dim3(256), 0, (hipStream_t)stream, n, d, x, prev, prev_idx, dt, lambda, decay_wb,
                        w_ih, w_hh, b_ih, b_hh, h_out, saved);
   return launch_status();
 }
@@ -279,18 +279,18 @@ int temp_gru_bwd(int n, int d, int variant, const float* x, const float* prev, c
   int grid = ceil_div((long long)nd, 256);
   if (grid > 4096) grid = 4096;
   if (variant == TEMP_GRU_TORCH)
-    hipLaunchKernelGGL((k_gru_bwd_gates<TEMP_GRU_TORCH>), dim3(grid), dim3(256), 0, st, n, d, saved, d_h_out, dt, lambda, decay_wb, w.dgi,
+    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TORCH>), dim3(grid), dim3(256), 0, st, n, d, saved, d_h_out, dt, lambda, decay_wb, w.dgi,
                        w.dgh, w.decv);
   else
-    hipLaunchKernelGGL((k_gru_bwd_gates<TEMP_GRU_TYPE1>), dim3(grid), dim3(256), 0, st, n, d, saved, d_h_out, dt, lambda, decay_wb, w.dgi,
+    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TYPE1>), dim3(grid), dim3(256), 0, st, n, d, saved, d_h_out, dt, lambda, decay_wb, w.dgi,
                        w.dgh, w.decv);
   int rc = launch_status();
   if (rc) return rc;
   // d_x = dgi . W_ih            (W_ih is [gi_w, d] row-major == [K, N])
-  rc = launch_gemm_panel(n, d, gi_w, w.dgi, gi_w, nullptr, w_ih, d, 0, EpiStore{d_x, d}, st);
+  rc = launch_gemm_panel(K_GEMM_GRU_DX, n, d, gi_w, w.dgi, gi_w, nullptr, w_ih, d, 0, EpiStore{d_x, d}, st);
   if (rc) return rc;
   // d_prev = (dgh . W_hh + dh * z) * decay
-  rc = launch_gemm_panel(n, d, 3 * d, w.dgh, 3 * d, nullptr, w_hh, d, 0, EpiGruDprev{d_h_out, saved + nd, w.decv, d_prev, d}, st);
+  rc = launch_gemm_panel(K_GEMM_GRU_DPREV, n, d, 3 * d, w.dgh, 3 * d, nullptr, w_hh, d, 0, EpiGruDprev{d_h_out, saved + nd, w.decv, d_prev, d}, st);
   if (rc) return rc;
   // weight / bias gradients
   rc = gemm_tn(n, gi_w, d, w.dgi, gi_w, x, d, d_w_ih, d, w.tn, w.tn_bytes, st);
@@ -302,7 +302,7 @@ int temp_gru_bwd(int n, int d, int variant, const float* x, const float* prev, c
   rc = colsum(n, 3 * d, w.dgh, 3 * d, d_b_hh, w.cs, w.cs_bytes, st);
   if (rc) return rc;
   if (decay_wb) {
-    hipLaunchKernelGGL(k_decay_grad, dim3(1), dim3(256), 0, st, n, d, d_prev, prev, prev_idx, dt, decay_wb, d_decay_wb);
+    TEMP_LAUNCH(K_DECAY_GRAD, k_decay_grad, dim3(1), dim3(256), 0, st, n, d, d_prev, prev, prev_idx, dt, decay_wb, d_decay_wb);
     rc = launch_status();
   }
   return rc;

@@ -314,12 +314,12 @@ static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const 
   if (wbytes <= 65536 && v.n_chunks >= 4096) {
     // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
     const int grid = 512;
-    hipLaunchKernelGGL((k_rgcn_agg<S, MODE, true>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
+    TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, true>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
                        lpr, out, partial);
   } else {
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
-    hipLaunchKernelGGL((k_rgcn_agg<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D, lpr,
+    TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D, lpr,
                        out, partial);
   }
 }
@@ -328,7 +328,7 @@ static void launch_fixup(const TempEdgeView& v, const float* partial, int width,
   if (v.n_fix <= 0) return;
   int grid = (v.n_fix + 3) / 4;
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(k_fixup, dim3(grid), dim3(256), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
+  TEMP_LAUNCH(K_FIXUP, k_fixup, dim3(grid), dim3(256), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
 }
 
 // forward / dx aggregation into `out` rows of segments that have edges (others untouched)
@@ -348,10 +348,10 @@ static int run_agg(int mode, const TempEdgeView& v, const float* feat, int ldf, 
     int grid = (v.n_chunks + 3) / 4;
     if (grid > 4096) grid = 4096;
     if (mode == MODE_FWD)
-      hipLaunchKernelGGL((k_rgcn_agg_generic<MODE_FWD>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, nnorm, d_in, d_out, si, so,
+      TEMP_LAUNCH(K_RGCN_AGG_FWD, (k_rgcn_agg_generic<MODE_FWD>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, nnorm, d_in, d_out, si, so,
                          out, partial);
     else
-      hipLaunchKernelGGL((k_rgcn_agg_generic<MODE_DX>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, nnorm, d_in, d_out, si, so,
+      TEMP_LAUNCH(K_RGCN_AGG_DX, (k_rgcn_agg_generic<MODE_DX>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, nnorm, d_in, d_out, si, so,
                          out, partial);
   }
   launch_fixup(v, partial, wres, out, st);
@@ -369,13 +369,13 @@ static int run_dw(const TempEdgeView& v, const float* x, const float* dz, const 
     const int lpr = pick_lpr(d_in);
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
-    if (S == 1) hipLaunchKernelGGL((k_rgcn_dw<1>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
-    else if (S == 2) hipLaunchKernelGGL((k_rgcn_dw<2>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
-    else hipLaunchKernelGGL((k_rgcn_dw<4>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
+    if (S == 1) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<1>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
+    else if (S == 2) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<2>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
+    else TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<4>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
   } else {
     int grid = (v.n_chunks + 3) / 4;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_rgcn_dw_generic, dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, d_out, si, so, dW, partial);
+    TEMP_LAUNCH(K_RGCN_DW, k_rgcn_dw_generic, dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, d_out, si, so, dW, partial);
   }
   launch_fixup(v, partial, (int)wrow, dW, st);
   return launch_status();
@@ -406,7 +406,7 @@ int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids, int 
   int rc = run_agg(MODE_FWD, g->by_dst, h, d_in, h_ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
   if (rc) return rc;
   // out = act( (in_deg>0 ? out : 0) + bias + h . loop_w )       (MFMA fp32 GEMM, fused epilogue)
-  return gemm_add_bias_act(g->n_nodes, d_out, d_in, h, d_in, h_ids, loop_w, d_out, 0, out, d_out, g->in_deg, bias, act, out, d_out, st);
+  return gemm_add_bias_act(K_GEMM_LOOP_FWD, g->n_nodes, d_out, d_in, h, d_in, h_ids, loop_w, d_out, 0, out, d_out, g->in_deg, bias, act, out, d_out, st);
 }
 
 struct BwdWs {
@@ -471,7 +471,7 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
   // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
   rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
   if (rc) return rc;
-  rc = gemm_add_bias_act(g->n_nodes, d_in, d_out, dz, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
+  rc = gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dz, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
                          d_h, d_in, st);
   if (rc) return rc;
   rc = run_dw(g->by_rel, h, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);

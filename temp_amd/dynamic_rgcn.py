@@ -22,6 +22,11 @@ from .tkg_module import TKG_Module
 from .window import ChainPlan, Step, concat_steps, window_times
 
 
+class WindowBatch:
+    """Everything `run` needs for one batch of windows (plans, batched graphs, device index tensors)."""
+    pass
+
+
 class DynamicRGCN(TKG_Module):
     def __init__(self, args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type=None):
         self.num_layers = args.num_layers
@@ -100,45 +105,71 @@ class DynamicRGCN(TKG_Module):
             first, second = self._encode_step(st, first, second)
         return first, second
 
-    def _encode_generic(self, plan, target):
-        first, second = self.pre_forward(plan)
-        _, out = self._encode_step(target, first, second)
+    def _run_generic(self, wb):
+        first, second = self.pre_forward(wb.plan)
+        _, out = self._encode_step(wb.target, first, second)
         return out, (first, second)
 
     # ---------------------------------------------------------------------------------------------
     # batched path
     # ---------------------------------------------------------------------------------------------
-    def _encode_batched(self, plan, target):
+    def _run_batched(self, wb):
         enc, dev = self.ent_encoder, self._device()
-        steps = plan.steps + [target]
-        g_all, total = concat_steps(steps)
-        ids_all = torch.from_numpy(g_all.gids.astype(np.int32)).to(dev)
-        h0 = TF.gather_rows(self.ent_embeds, ids_all)
-        y1 = enc.layer_1.conv(g_all, h0)
-        y2 = enc.layer_2.conv(g_all, y1)
+        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
+        y1 = enc.layer_1.conv(wb.g_all, h0)
+        y2 = enc.layer_2.conv(wb.g_all, y1)
         l2 = enc.layer_2
         H, hist = None, None
-        for st in steps:
+        for st in wb.steps:
             _, pidx, dt = st.tensors(dev)
             x = y2[st.row0:st.row0 + st.n_rows]
             prev = H if H is not None else x.new_zeros(1, x.shape[1])
             H = run_rnn(l2.rnn, x, prev, dt, l2.inv_temperature, l2.decay_spec(), pidx)
             if enc.use_time_embedding:
                 H = H + l2.get_time_embedding(st.times, st.sizes)
-            if st is not target:
+            if st is not wb.target:
                 hist = H
         return H, (hist, hist)
 
     # ---------------------------------------------------------------------------------------------
+    def prepare(self, t_list, seq_len, train=True, target_edge_ids=None):
+        """Host-side planning + upload of everything that depends only on which snapshots are
+        visited (window layout, row maps, sorted/chunked edge views).  Returns a WindowBatch that
+        `run` can execute any number of times."""
+        dev = self._device()
+        wb = WindowBatch()
+        wb.rows = window_times(t_list, seq_len, self.total_time)
+        wb.plan = ChainPlan(wb.rows, self.graph_dict_train, self.num_ents, seq_len)
+        wb.graphs = [self.graph_dict_train[r[-1]] for r in wb.rows]
+        tgt = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
+        wb.target = self._target_step(wb.plan, wb.rows, tgt)
+        wb.batched = self._can_batch()
+        wb.steps = wb.plan.steps + [wb.target]
+        self._upload(wb, dev)
+        return wb
+
+    def _upload(self, wb, dev):
+        for st in wb.steps:
+            st.tensors(dev)
+        if wb.batched:
+            wb.g_all, wb.total_rows = concat_steps(wb.steps)
+            wb.ids_all = torch.from_numpy(wb.g_all.gids.astype(np.int32)).to(dev)
+            wb.g_all.device_graph(dev, 2 * self.num_rels)
+        else:
+            for st in wb.steps:
+                st.batched().device_graph(dev, 2 * self.num_rels)
+        wb.n_edge_visits = int(sum(g.number_of_edges() for st in wb.steps for g in st.graphs))
+        wb.n_node_visits = int(sum(st.n_rows for st in wb.steps))
+
+    def run(self, wb):
+        """Device work of one encoder pass -> (target rows (sum n_b, D), final history outputs)."""
+        return (self._run_batched if wb.batched else self._run_generic)(wb)
+
     def encode(self, t_list, seq_len, train=True, target_edge_ids=None):
         """Window encoder: -> (per-window target embeddings, plan, rows, target graphs, final history)."""
-        rows = window_times(t_list, seq_len, self.total_time)
-        plan = ChainPlan(rows, self.graph_dict_train, self.num_ents, seq_len)
-        graphs = [self.graph_dict_train[r[-1]] for r in rows]
-        tgt = self.sample_target_graphs(graphs, 0.5, target_edge_ids) if train else graphs
-        target = self._target_step(plan, rows, tgt)
-        out, hist = (self._encode_batched if self._can_batch() else self._encode_generic)(plan, target)
-        return list(out.split(target.sizes)), plan, rows, graphs, hist
+        wb = self.prepare(t_list, seq_len, train, target_edge_ids)
+        out, hist = self.run(wb)
+        return list(out.split(wb.target.sizes)), wb.plan, wb.rows, wb.graphs, hist
 
     def get_all_embeds_Gt(self, convoluted_embeds, g, t, plan, b, hist):
         """Isolated pass over ALL entities, then the active rows overwritten
