@@ -109,7 +109,7 @@ def traced_steps(step_fn, n_steps, lib):
 def cpu_baseline(model, w, device_targets):
     """The oracle (port of the reference's op sequence, dense history kept) on ONE window, host cores."""
     from oracle import temp_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))     # more threads only add OpenMP overhead on these small ops
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     bi = w["module"].startswith("Bi")
     cfg = dict(module=w["module"], n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)

@@ -49,7 +49,8 @@ const char* temp_error_string(int code);
 /* ------------------------------------------------------------------------------------------------
  * Segmented edge lists.  One batched snapshot graph (the disjoint union `dgl.batch` builds at
  * models/DynamicRGCN.py:92) is handed over as three sorted views of the same E edges, each cut
- * into chunks of at most TEMP_CHUNK edges that never straddle a segment:
+ * into chunks of at most TEMP_CHUNK edges (TEMP_CHUNK_REL for the by-relation view, whose segments
+ * are few and long) that never straddle a segment:
  *
  *   by destination  (forward aggregation,  RGCNLayer.propagate  models/RGCN.py:100-104)
  *   by source       (d/dh of the aggregation)
@@ -63,6 +64,7 @@ const char* temp_error_string(int code);
  *                one segment are consecutive and are summed in order => deterministic).
  * ---------------------------------------------------------------------------------------------- */
 #define TEMP_CHUNK 64
+#define TEMP_CHUNK_REL 1024
 
 typedef struct TempEdgeView {
   int32_t n_seg;            /* number of segments (nodes, or relation rows)                        */
@@ -176,6 +178,37 @@ int temp_gru_bwd(int n, int d, int variant,
                  float* d_x, float* d_prev, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh,
                  float* d_decay_wb /*nullable*/,
                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Window-batched recurrence.  When only the last layer is recurrent (--rec-only-last-layer,
+ * models/RRGCN.py:182-187) the GRU input x of EVERY window position is known before the chain
+ * starts, so everything that is not truly sequential is hoisted out of the per-position loop:
+ *
+ *   temp_gru_input_gates   gi = x . W_ih^T + b_ih for all positions at once  (one MFMA GEMM)
+ *   temp_gru_cell_fwd      per position: hdec . W_hh^T on MFMA + gates + blend (reads its gi rows)
+ *   temp_gru_cell_bwd      per position: gate gradients + d_prev = (dgh . W_hh + dh*z) * decay;
+ *                          the gradient arriving from the NEXT position is gathered through the
+ *                          inverse row map `next_idx` (-1 = none) and added to `dh_up` (nullable)
+ *   temp_gru_weight_grads  after the chain: d_x = dgi . W_ih, d_W_ih = dgi^T x, d_W_hh = dgh^T hdec,
+ *                          bias column sums -- over ALL rows that share one set of GRU weights
+ *
+ * `saved` planes (r, z, n, W_hn hdec + b_hn, hdec) are `saved_plane` floats apart so that every
+ * position writes its rows into one [5, N_total, d] buffer and `hdec` (plane 4) is contiguous for
+ * the batched weight gradient.  gi/dgi: [n, 3d] (torch) or [n, d] (type-1); dgh: [n, 3d]; decv: [n].
+ * Fixed decay only (learnable decay uses temp_gru_fwd / temp_gru_bwd).
+ * ---------------------------------------------------------------------------------------------- */
+int temp_gru_input_gates(int n, int d, int variant, const float* x, const float* w_ih, const float* b_ih, float* gi, void* stream);
+int temp_gru_cell_fwd(int n, int d, int variant, const float* gi, const float* prev, const int32_t* prev_idx /*nullable*/,
+                      const float* dt, float lambda, const float* w_hh, const float* b_hh,
+                      float* h_out, float* saved, size_t saved_plane, void* stream);
+int temp_gru_cell_bwd(int n, int d, int variant, const float* saved, size_t saved_plane,
+                      const float* dh_up /*nullable*/, const float* d_prev_next /*nullable*/, const int32_t* next_idx /*nullable*/,
+                      const float* dt, float lambda, const float* w_hh,
+                      float* dgi, float* dgh, float* decv, float* d_prev, void* stream);
+size_t temp_gru_weight_grads_workspace(int n, int d, int variant);
+int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float* hdec, const float* dgi, const float* dgh,
+                          const float* w_ih, float* d_x /*nullable*/, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row gather / scatter helpers of the window loop

@@ -16,6 +16,7 @@ c_vp = ctypes.c_void_p
 ACT_NONE, ACT_RELU = 0, 1
 GRU_TORCH, GRU_TYPE1 = 0, 1
 CHUNK = 64
+CHUNK_REL = 1024
 
 
 class TempEdgeView(ctypes.Structure):
@@ -47,6 +48,11 @@ SYMBOLS = {
     "temp_gru_bwd_workspace": (_SZ, [_I, _I, _I]),
     "temp_gru_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp,
                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_gru_input_gates": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_cell_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_gru_cell_bwd": (_I, [_I, _I, _I, c_vp, _SZ, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_weight_grads_workspace": (_SZ, [_I, _I, _I]),
+    "temp_gru_weight_grads": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_copy_probe": (_I, [c_vp, c_vp, _SZ, c_vp]),

@@ -143,6 +143,46 @@ class HipBackend:
         _lib.check(rc, "temp_gru_bwd")
         return d_x, d_prev, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_wb
 
+    # ---- window-batched recurrence (hoisted input gates, per-position cell, batched weight grads) ---
+    def gru_input_gates(self, x, w_ih, b_ih, variant, out):
+        x, w_ih, b_ih = _f32(x, "x"), _f32(w_ih, "w_ih"), _f32(b_ih, "b_ih")
+        assert out.is_contiguous() and out.shape == (x.shape[0], w_ih.shape[0])
+        rc = self.lib.temp_gru_input_gates(x.shape[0], x.shape[1], variant, _ptr(x), _ptr(w_ih), _ptr(b_ih), _ptr(out), _stream())
+        _lib.check(rc, "temp_gru_input_gates")
+
+    def gru_cell_fwd(self, gi, prev, prev_idx, dt, lam, w_hh, b_hh, variant, h_out, saved_all, row0):
+        """h_out (n,d) and rows [row0, row0+n) of every plane of saved_all (5, N, d) are written."""
+        n, d = h_out.shape
+        plane = saved_all.shape[1] * d
+        sp = ctypes.c_void_p(saved_all.data_ptr() + 4 * row0 * d)
+        rc = self.lib.temp_gru_cell_fwd(n, d, variant, _ptr(gi), _ptr(_f32(prev, "prev")), _ptr(_i32(prev_idx, "prev_idx")),
+                                        _ptr(_f32(dt, "dt")), float(lam), _ptr(_f32(w_hh, "w_hh")), _ptr(_f32(b_hh, "b_hh")),
+                                        _ptr(h_out), sp, plane, _stream())
+        _lib.check(rc, "temp_gru_cell_fwd")
+
+    def gru_cell_bwd(self, saved_all, row0, n, dh_up, d_prev_next, next_idx, dt, lam, w_hh, variant, dgi, dgh, decv, d_prev):
+        d = saved_all.shape[2]
+        plane = saved_all.shape[1] * d
+        sp = ctypes.c_void_p(saved_all.data_ptr() + 4 * row0 * d)
+        rc = self.lib.temp_gru_cell_bwd(n, d, variant, sp, plane, _ptr(dh_up), _ptr(d_prev_next), _ptr(_i32(next_idx, "next_idx")),
+                                        _ptr(_f32(dt, "dt")), float(lam), _ptr(_f32(w_hh, "w_hh")), _ptr(dgi), _ptr(dgh), _ptr(decv),
+                                        _ptr(d_prev), _stream())
+        _lib.check(rc, "temp_gru_cell_bwd")
+
+    def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
+        n, d = x.shape
+        w_ih = _f32(w_ih, "w_ih")
+        dev = x.device
+        d_w_ih = torch.empty_like(w_ih)
+        d_w_hh = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
+        d_b_ih = torch.empty(w_ih.shape[0], dtype=torch.float32, device=dev)
+        d_b_hh = torch.empty(3 * d, dtype=torch.float32, device=dev)
+        ws = self._ws(self.lib.temp_gru_weight_grads_workspace(n, d, variant), dev)
+        rc = self.lib.temp_gru_weight_grads(n, d, variant, _ptr(x), _ptr(hdec), _ptr(dgi), _ptr(dgh), _ptr(w_ih), _ptr(d_x),
+                                            _ptr(d_w_ih), _ptr(d_w_hh), _ptr(d_b_ih), _ptr(d_b_hh), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_gru_weight_grads")
+        return d_w_ih, d_w_hh, d_b_ih, d_b_hh
+
     # ---- row gather / scatter ---------------------------------------------------------------------
     def gather_rows(self, table, idx):
         table, idx = _f32(table, "table"), _i32(idx, "idx")

@@ -11,6 +11,8 @@ import torch
 from . import functional as TF
 from .birrgcn import BiGRRGCNLayer, BiRRGCN
 from .dynamic_rgcn import DynamicRGCN, WindowBatch
+from .gru_cell import GRUCell
+from .gru_chain import GruInstance, GruProgram, gru_chain
 from .rrgcn import run_rnn
 from .window import ChainPlan, Step, concat_steps, window_times
 
@@ -91,6 +93,13 @@ class BiDynamicRGCN(DynamicRGCN):
         y2 = enc.layer_2.conv(wb.g_all, y1)                   # ReLU fused (models/BiRRGCN.py:202-203)
         l2 = enc.layer_2
         lam, dec = l2.inv_temperature, l2.decay_spec()
+        if wb.program is not None:
+            prog = wb.program
+            H_all = gru_chain(y2, prog, [l2.forward_rnn, l2.backward_rnn], lam, isinstance(l2.forward_rnn, GRUCell))
+            rows = lambda i: H_all[prog.inst[i].h0:prog.inst[i].h0 + prog.inst[i].n] if i >= 0 else None
+            out = rows(wb.out_inst[0]) + rows(wb.out_inst[1])
+            Hf, Hb = rows(wb.hist_inst[0]), rows(wb.hist_inst[1])
+            return out, ((Hf, Hf), (Hb, Hb))
 
         def chain(plan, rnn):
             H = None
@@ -114,6 +123,21 @@ class BiDynamicRGCN(DynamicRGCN):
         if enc.use_time_embedding:
             out = out + l2.get_time_embedding(tf.times, tf.sizes)
         return out, ((Hf, Hf), (Hb, Hb))
+
+    def _build_program(self, wb):
+        plan_f, plan_b = wb.plan
+        inst = []
+        last = [-1, -1]
+        for rnn, plan in ((0, plan_f), (1, plan_b)):
+            for st in plan.steps:
+                inst.append(GruInstance(st.n_rows, st.row0, rnn, last[rnn], st.prev_idx, st.dt))
+                last[rnn] = len(inst) - 1
+        tf, tb = wb.target, wb.target_b
+        inst.append(GruInstance(tf.n_rows, tf.row0, 0, last[0], tf.prev_idx, tf.dt))
+        inst.append(GruInstance(tf.n_rows, tf.row0, 1, last[1], tb.prev_idx, tb.dt))
+        wb.program = GruProgram(inst)
+        wb.out_inst = [len(inst) - 2, len(inst) - 1]
+        wb.hist_inst = last
 
     # ---------------------------------------------------------------------------------------------
     def prepare(self, t_list, seq_len, train=True, target_edge_ids=None):

@@ -70,15 +70,20 @@ __global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const fl
     for (int u = 0; u < U; ++u) {
       const int row = m + 2 * u + hh;
       const bool rok = row < mend;
-      av[u] = (rok && a_ok) ? A[(size_t)row * lda + ka0 + li] : 0.f;
+      const int rs = rok ? row : mbeg;                      // clamped address + select: no branches in the loop
+      const float a_raw = A[(size_t)rs * lda + (a_ok ? ka0 + li : 0)];
+      av[u] = (rok && a_ok) ? a_raw : 0.f;
 #pragma unroll
-      for (int t = 0; t < TN_NT; ++t) bv[u][t] = (rok && b_ok[t] && t < ntv) ? B[(size_t)row * ldb + nb0 + t * 32 + li] : 0.f;
+      for (int t = 0; t < TN_NT; ++t) {
+        const float b_raw = B[(size_t)rs * ldb + (b_ok[t] ? nb0 + t * 32 + li : 0)];
+        bv[u][t] = (rok && b_ok[t]) ? b_raw : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < TN_NT; ++t)
-        if (t < ntv) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
   }
   float* p = part + (size_t)slice * Ka * Nb;
 #pragma unroll
@@ -217,13 +222,13 @@ int trace_open(int kernel_id, hipStream_t st) {
   const int slot = __atomic_fetch_add(&t->n, 1, __ATOMIC_RELAXED);
   if (slot >= t->cap) return -1;
   t->ids[slot] = kernel_id;
-  hipEventRecord(t->ev[2 * slot], st);
+  (void)hipEventRecord(t->ev[2 * slot], st);
   return slot;
 }
 void trace_close(int slot, hipStream_t st) {
   TraceState* t = g_trace;
   if (!t || slot < 0) return;
-  hipEventRecord(t->ev[2 * slot + 1], st);
+  (void)hipEventRecord(t->ev[2 * slot + 1], st);
 }
 
 }  // namespace temp
@@ -254,12 +259,12 @@ int temp_trace_end(int* kernel_ids, float* ms, int capacity, int* n_out) {
   if (n > capacity) n = capacity;
   for (int i = 0; i < n; ++i) {
     float v = 0.f;
-    hipEventElapsedTime(&v, t->ev[2 * i], t->ev[2 * i + 1]);
+    (void)hipEventElapsedTime(&v, t->ev[2 * i], t->ev[2 * i + 1]);
     if (kernel_ids) kernel_ids[i] = t->ids[i];
     if (ms) ms[i] = v;
   }
   *n_out = n;
-  for (int i = 0; i < 2 * t->cap; ++i) hipEventDestroy(t->ev[i]);
+  for (int i = 0; i < 2 * t->cap; ++i) (void)hipEventDestroy(t->ev[i]);
   delete[] t->ev;
   delete[] t->ids;
   delete t;
@@ -270,7 +275,7 @@ const char* temp_trace_kernel_name(int id) {
   static const char* names[] = {"k_rgcn_agg<fwd>", "k_rgcn_agg<dx>", "k_rgcn_dw", "k_fixup", "k_gemm_panel<loop_fwd>",
                                 "k_gemm_panel<loop_dx>", "k_gemm_tn", "k_reduce_slices", "k_colsum_part", "k_relu_bwd", "k_gru_fwd",
                                 "k_gru_bwd_gates", "k_gemm_panel<gru_dx>", "k_gemm_panel<gru_dprev>", "k_gather_rows",
-                                "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>"};
+                                "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>", "k_gemm_panel<gru_gi>"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 

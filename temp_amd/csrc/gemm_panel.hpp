@@ -22,64 +22,59 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
   const int m0 = (blockIdx.x * 4 + wave) * 32;
   const int n0 = blockIdx.y * BN;
   const int arow = m0 + li;
-  const bool arow_ok = arow < M;
-  const float* aptr = nullptr;
-  if (arow_ok) {
-    const long r = a_idx ? (long)a_idx[arow] : (long)arow;
-    aptr = (r >= 0) ? A + (size_t)r * lda : nullptr;
-  }
+  // Branch-free inner loop: an invalid row reads row 0 (always mapped when M > 0) and is zeroed by a select.
+  long arow_src = -1;
+  if (arow < M) arow_src = a_idx ? (long)a_idx[arow] : (long)arow;
+  const bool arow_ok = arow_src >= 0;
+  const float* aptr = A + (size_t)(arow_ok ? arow_src : 0) * lda + 4 * hh;
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  int ntv = (N - n0 + 31) / 32;
-  if (ntv > NT) ntv = NT;
 
   for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
     const int kc = min(GEMM_KC, K - k0);
     __syncthreads();
+    // stage B[k0 .. k0+KC) x [n0 .. n0+BN); rows >= kc and columns >= N are zero so the MFMA loop needs no guards
     if (!trans_b) {
-      for (int idx = threadIdx.x; idx < kc * BN; idx += 256) {
+      for (int idx = threadIdx.x; idx < GEMM_KC * BN; idx += 256) {
         const int k = idx / BN, j = idx - k * BN;
-        Bs[k * LDS_B + j] = (n0 + j < N) ? B[(size_t)(k0 + k) * ldb + n0 + j] : 0.f;
+        Bs[k * LDS_B + j] = (k < kc && n0 + j < N) ? B[(size_t)(k0 + k) * ldb + n0 + j] : 0.f;
       }
     } else {
-      for (int idx = threadIdx.x; idx < kc * BN; idx += 256) {
-        const int j = idx / kc, k = idx - j * kc;
-        Bs[k * LDS_B + j] = (n0 + j < N) ? B[(size_t)(n0 + j) * ldb + k0 + k] : 0.f;
+      for (int idx = threadIdx.x; idx < GEMM_KC * BN; idx += 256) {
+        const int j = idx / GEMM_KC, k = idx - j * GEMM_KC;
+        Bs[k * LDS_B + j] = (k < kc && n0 + j < N) ? B[(size_t)(n0 + j) * ldb + k0 + k] : 0.f;
       }
     }
     __syncthreads();
-    for (int kk = 0; kk < kc; kk += 8) {
-      const int kb = kk + 4 * hh;          // this lane's 4 k values inside the chunk
-      float4 a = zero4();
-      if (aptr && kb < kc) a = ld4(aptr + k0 + kb);
-      const float av[4] = {a.x, a.y, a.z, a.w};
+    float4 av[GEMM_KC / 8];
+#pragma unroll
+    for (int q = 0; q < GEMM_KC / 8; ++q) {          // all A loads of the chunk issued up front
+      const bool ok = arow_ok && (q * 8 + 4 * hh < kc);
+      const float4 v = ld4(aptr + (ok ? k0 + q * 8 : -4 * hh));     // !ok: re-read k=0..3 of the row (in bounds)
+      av[q] = ok ? v : zero4();
+    }
+#pragma unroll
+    for (int q = 0; q < GEMM_KC / 8; ++q) {
+      const float as[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int krow = kb + s;
-        const bool kok = krow < kc;
+        const float* brow = Bs + (q * 8 + 4 * hh + s) * LDS_B + li;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (t < ntv) {
-            const float b = kok ? Bs[krow * LDS_B + t * 32 + li] : 0.f;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc[t], 0, 0, 0);
-          }
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], brow[t * 32], acc[t], 0, 0, 0);
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (t < ntv) {
-      const int col = n0 + t * 32 + li;
-      if (col < N) {
+    const int col = n0 + t * 32 + li;
+    if (col < N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (row < M) epi(row, col, acc[t][r]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < M) epi(row, col, acc[t][r]);
       }
     }
   }

@@ -20,12 +20,19 @@ __device__ __forceinline__ float decay_factor(float dt, float lambda, const floa
   return expf(-dt * lambda);
 }
 
-template <int VARIANT>
-__global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __restrict__ x, const float* __restrict__ prev,
-                                                 const int32_t* __restrict__ prev_idx, const float* __restrict__ dt, float lambda,
-                                                 const float* __restrict__ decay_wb, const float* __restrict__ w_ih,
-                                                 const float* __restrict__ w_hh, const float* __restrict__ b_ih,
-                                                 const float* __restrict__ b_hh, float* __restrict__ h_out, float* __restrict__ saved) {
+// One kernel, two modes:
+//   GI == nullptr : fused -- phase X (x . W_ih^T) and phase H (hdec . W_hh^T) both on MFMA;
+//   GI != nullptr : the input-side gates were hoisted out of the recurrence (one big GEMM over all
+//                   window positions, temp_gru_input_gates) and only phase H runs here.
+// The MFMA loops are branch-free: B rows/columns outside the problem are staged as zeros and
+// invalid A rows are zeroed by a select, so all loads of a K chunk issue before its MFMAs.
+template <int VARIANT, bool HOISTED>
+__global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __restrict__ x, const float* __restrict__ gi,
+                                                 const float* __restrict__ prev, const int32_t* __restrict__ prev_idx,
+                                                 const float* __restrict__ dt, float lambda, const float* __restrict__ decay_wb,
+                                                 const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                 float* __restrict__ h_out, float* __restrict__ saved, size_t plane) {
   __shared__ float Bs[3][GRU_KC * GRU_LDB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
@@ -44,76 +51,89 @@ __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __re
   for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; }
 
   // ---- phase X: x . W_ih^T (torch: gates r,z,n; type-1: new gate only) ------------------------
-  const float* xa = arow_ok ? x + (size_t)arow * D : nullptr;
-  for (int k0 = 0; k0 < D; k0 += GRU_KC) {
-    const int kc = min(GRU_KC, D - k0);
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 3 * kc * 32; idx += 256) {
-      const int g = idx / (kc * 32), rem = idx - g * (kc * 32);
-      const int j = rem / kc, k = rem - j * kc;
-      float v = 0.f;
-      if (j0 + j < D) {
-        if (VARIANT == TEMP_GRU_TORCH) v = w_ih[(size_t)(g * D + j0 + j) * D + k0 + k];
-        else if (g == 2) v = w_ih[(size_t)(j0 + j) * D + k0 + k];
-      }
-      Bs[g][k * GRU_LDB + j] = v;
-    }
-    __syncthreads();
-    for (int kk = 0; kk < kc; kk += 8) {
-      const int kb = kk + 4 * hh;
-      float4 a = zero4();
-      if (xa && kb < kc) a = ld4(xa + k0 + kb);
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int krow = kb + s;
-        const bool kok = krow < kc;
-        const int off = krow * GRU_LDB + li;
-        if (VARIANT == TEMP_GRU_TORCH) {
-          acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], kok ? Bs[0][off] : 0.f, acc_r, 0, 0, 0);
-          acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], kok ? Bs[1][off] : 0.f, acc_z, 0, 0, 0);
+  if (!HOISTED) {
+    const float* xa = x + (size_t)(arow_ok ? arow : 0) * D + 4 * hh;
+    for (int k0 = 0; k0 < D; k0 += GRU_KC) {
+      const int kc = min(GRU_KC, D - k0);
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 3 * GRU_KC * 32; idx += 256) {
+        const int g = idx / (GRU_KC * 32), rem = idx - g * (GRU_KC * 32);
+        const int j = rem / GRU_KC, k = rem - j * GRU_KC;
+        float v = 0.f;
+        if (k < kc && j0 + j < D) {
+          if (VARIANT == TEMP_GRU_TORCH) v = w_ih[(size_t)(g * D + j0 + j) * D + k0 + k];
+          else if (g == 2) v = w_ih[(size_t)(j0 + j) * D + k0 + k];
         }
-        acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], kok ? Bs[2][off] : 0.f, acc_in, 0, 0, 0);
+        Bs[g][k * GRU_LDB + j] = v;
+      }
+      __syncthreads();
+      float4 av[GRU_KC / 8];
+#pragma unroll
+      for (int q = 0; q < GRU_KC / 8; ++q) {
+        const bool ok = arow_ok && (q * 8 + 4 * hh < kc);
+        const float4 v = ld4(xa + (ok ? k0 + q * 8 : -4 * hh));
+        av[q] = ok ? v : zero4();
+      }
+#pragma unroll
+      for (int q = 0; q < GRU_KC / 8; ++q) {
+        const float as[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int off = (q * 8 + 4 * hh + s) * GRU_LDB + li;
+          if (VARIANT == TEMP_GRU_TORCH) {
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[0][off], acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[1][off], acc_z, 0, 0, 0);
+          }
+          acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[2][off], acc_in, 0, 0, 0);
+        }
       }
     }
   }
   // ---- phase H: hdec . W_hh^T -------------------------------------------------------------------
-  const float* ha = (arow_ok && prow >= 0) ? prev + (size_t)prow * D : nullptr;
-  for (int k0 = 0; k0 < D; k0 += GRU_KC) {
-    const int kc = min(GRU_KC, D - k0);
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 3 * kc * 32; idx += 256) {
-      const int g = idx / (kc * 32), rem = idx - g * (kc * 32);
-      const int j = rem / kc, k = rem - j * kc;
-      Bs[g][k * GRU_LDB + j] = (j0 + j < D) ? w_hh[(size_t)(g * D + j0 + j) * D + k0 + k] : 0.f;
-    }
-    __syncthreads();
-    for (int kk = 0; kk < kc; kk += 8) {
-      const int kb = kk + 4 * hh;
-      float4 a = zero4();
-      if (ha && kb < kc) a = scale4(ld4(ha + k0 + kb), dec);
-      const float av[4] = {a.x, a.y, a.z, a.w};
+  {
+    const bool h_ok = arow_ok && prow >= 0;
+    const float* ha = prev + (size_t)(h_ok ? prow : 0) * D + 4 * hh;
+    for (int k0 = 0; k0 < D; k0 += GRU_KC) {
+      const int kc = min(GRU_KC, D - k0);
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 3 * GRU_KC * 32; idx += 256) {
+        const int g = idx / (GRU_KC * 32), rem = idx - g * (GRU_KC * 32);
+        const int j = rem / GRU_KC, k = rem - j * GRU_KC;
+        Bs[g][k * GRU_LDB + j] = (k < kc && j0 + j < D) ? w_hh[(size_t)(g * D + j0 + j) * D + k0 + k] : 0.f;
+      }
+      __syncthreads();
+      float4 av[GRU_KC / 8];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int krow = kb + s;
-        const bool kok = krow < kc;
-        const int off = krow * GRU_LDB + li;
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], kok ? Bs[0][off] : 0.f, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], kok ? Bs[1][off] : 0.f, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], kok ? Bs[2][off] : 0.f, acc_hn, 0, 0, 0);
+      for (int q = 0; q < GRU_KC / 8; ++q) {
+        const bool ok = h_ok && (q * 8 + 4 * hh < kc);
+        const float4 v = ld4(ha + (ok ? k0 + q * 8 : -4 * hh));
+        av[q] = ok ? scale4(v, dec) : zero4();
+      }
+#pragma unroll
+      for (int q = 0; q < GRU_KC / 8; ++q) {
+        const float as[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int off = (q * 8 + 4 * hh + s) * GRU_LDB + li;
+          acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[0][off], acc_r, 0, 0, 0);
+          acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[1][off], acc_z, 0, 0, 0);
+          acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[2][off], acc_hn, 0, 0, 0);
+        }
       }
     }
   }
   // ---- epilogue -----------------------------------------------------------------------------------
   const int col = j0 + li;
   const bool col_ok = col < D;
+  const int G = (VARIANT == TEMP_GRU_TORCH) ? 3 * D : D;
   float bir = 0.f, biz = 0.f, bin = 0.f, bhr = 0.f, bhz = 0.f, bhn = 0.f;
   if (col_ok) {
-    if (VARIANT == TEMP_GRU_TORCH) { bir = b_ih[col]; biz = b_ih[D + col]; bin = b_ih[2 * D + col]; }
-    else bin = b_ih[col];
+    if (!HOISTED) {                                     // hoisted gi already carries b_ih
+      if (VARIANT == TEMP_GRU_TORCH) { bir = b_ih[col]; biz = b_ih[D + col]; bin = b_ih[2 * D + col]; }
+      else bin = b_ih[col];
+    }
     bhr = b_hh[col]; bhz = b_hh[D + col]; bhn = b_hh[2 * D + col];
   }
-  const size_t nd = (size_t)n * D;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;   // row inside the tile == the lane that loaded it
@@ -121,33 +141,48 @@ __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __re
     const float dec_r = __shfl(dec, rl);
     const int row = m0 + rl;
     if (row < n && col_ok) {
+      float xr = acc_r[r], xz = acc_z[r], xn = acc_in[r];
+      if (HOISTED) {
+        const float* g = gi + (size_t)row * G;
+        if (VARIANT == TEMP_GRU_TORCH) { xr += g[col]; xz += g[D + col]; xn = g[2 * D + col]; }
+        else xn = g[col];
+      }
       const float hd = (prow_r >= 0) ? prev[(size_t)prow_r * D + col] * dec_r : 0.f;
-      const float rg = 1.f / (1.f + expf(-(acc_r[r] + bir + bhr)));
-      const float zg = 1.f / (1.f + expf(-(acc_z[r] + biz + bhz)));
+      const float rg = 1.f / (1.f + expf(-(xr + bir + bhr)));
+      const float zg = 1.f / (1.f + expf(-(xz + biz + bhz)));
       const float hn = acc_hn[r] + bhn;
-      const float ng = tanhf(acc_in[r] + bin + rg * hn);
+      const float ng = tanhf(xn + bin + rg * hn);
       const float hy = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg) * ng + zg * hd) : (ng + zg * (hd - ng));
       const size_t o = (size_t)row * D + col;
       h_out[o] = hy;
       saved[o] = rg;
-      saved[nd + o] = zg;
-      saved[2 * nd + o] = ng;
-      saved[3 * nd + o] = hn;
-      saved[4 * nd + o] = hd;
+      saved[plane + o] = zg;
+      saved[2 * plane + o] = ng;
+      saved[3 * plane + o] = hn;
+      saved[4 * plane + o] = hd;
     }
   }
 }
 
 // Gate gradients (pointwise).  dgi: [n, 3D] (torch) or [n, D] (type-1); dgh: [n, 3D]; decv: [n].
+// d_h = dh_up (nullable) + d_prev_next[next_idx[row]] (nullable; the gradient flowing back from the
+// next window position, gathered through the inverse row map, -1 = none).  dhz (= d_h * z) seeds the
+// d_prev GEMM epilogue.
 template <int VARIANT>
-__global__ void __launch_bounds__(256) k_gru_bwd_gates(int n, int D, const float* __restrict__ saved, const float* __restrict__ dh,
-                                                       const float* __restrict__ dt, float lambda, const float* __restrict__ decay_wb,
-                                                       float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ decv) {
+__global__ void __launch_bounds__(256) k_gru_bwd_gates(int n, int D, const float* __restrict__ saved, size_t plane,
+                                                       const float* __restrict__ dh_up, const float* __restrict__ d_prev_next,
+                                                       const int32_t* __restrict__ next_idx, const float* __restrict__ dt, float lambda,
+                                                       const float* __restrict__ decay_wb, float* __restrict__ dgi, float* __restrict__ dgh,
+                                                       float* __restrict__ decv, float* __restrict__ dhz) {
   const size_t nd = (size_t)n * D;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / D), col = (int)(i - (size_t)row * D);
-    const float rg = saved[i], zg = saved[nd + i], ng = saved[2 * nd + i], hn = saved[3 * nd + i], hd = saved[4 * nd + i];
-    const float g = dh[i];
+    const float rg = saved[i], zg = saved[plane + i], ng = saved[2 * plane + i], hn = saved[3 * plane + i], hd = saved[4 * plane + i];
+    float g = dh_up ? dh_up[i] : 0.f;
+    if (next_idx) {
+      const int nx = next_idx[row];
+      if (nx >= 0) g += d_prev_next[(size_t)nx * D + col];
+    }
     const float dn = g * (1.f - zg);
     const float dz = g * (hd - ng);
     const float dn_pre = dn * (1.f - ng * ng);
@@ -164,16 +199,17 @@ __global__ void __launch_bounds__(256) k_gru_bwd_gates(int n, int D, const float
     dgh[b3] = dr_pre;
     dgh[b3 + D] = dz_pre;
     dgh[b3 + 2 * D] = dn_pre * rg;
+    dhz[i] = g * zg;
     if (col == 0) decv[row] = decay_factor(dt[row], lambda, decay_wb);
   }
 }
 
-// d_prev = (dgh . W_hh + dh * z) * decay[row]
+// d_prev = (dgh . W_hh + dh * z) * decay[row]; dh*z was left in `io` by the gates kernel
 struct EpiGruDprev {
-  const float* dh; const float* z; const float* decv; float* out; int D;
+  const float* decv; float* io; int D;
   __device__ __forceinline__ void operator()(int row, int col, float acc) const {
     const size_t o = (size_t)row * D + col;
-    out[o] = (acc + dh[o] * z[o]) * decv[row];
+    io[o] = (acc + io[o]) * decv[row];
   }
 };
 struct EpiStore {
@@ -231,6 +267,33 @@ using namespace temp;
 
 extern "C" {
 
+static int launch_gru_fwd(int n, int d, int variant, const float* x, const float* gi, const float* prev, const int32_t* prev_idx,
+                          const float* dt, float lambda, const float* decay_wb, const float* w_ih, const float* w_hh,
+                          const float* b_ih, const float* b_hh, float* h_out, float* saved, size_t plane, hipStream_t st) {
+  dim3 grid(ceil_div(n, 128), ceil_div(d, 32));
+#define TEMP_GRU_FWD(V, H)                                                                                              \
+  TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<V, H>), grid, dim3(256), 0, st, n, d, x, gi, prev, prev_idx, dt, lambda, decay_wb, \
+              w_ih, w_hh, b_ih, b_hh, h_out, saved, plane)
+  if (variant == TEMP_GRU_TORCH) { if (gi) TEMP_GRU_FWD(TEMP_GRU_TORCH, true); else TEMP_GRU_FWD(TEMP_GRU_TORCH, false); }
+  else { if (gi) TEMP_GRU_FWD(TEMP_GRU_TYPE1, true); else TEMP_GRU_FWD(TEMP_GRU_TYPE1, false); }
+#undef TEMP_GRU_FWD
+  return launch_status();
+}
+
+static int launch_gru_gates(int n, int d, int variant, const float* saved, size_t plane, const float* dh_up, const float* d_prev_next,
+                            const int32_t* next_idx, const float* dt, float lambda, const float* decay_wb, float* dgi, float* dgh,
+                            float* decv, float* dhz, hipStream_t st) {
+  int grid = ceil_div((long long)n * d, 256);
+  if (grid > 4096) grid = 4096;
+  if (variant == TEMP_GRU_TORCH)
+    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TORCH>), dim3(grid), dim3(256), 0, st, n, d, saved, plane, dh_up, d_prev_next,
+                next_idx, dt, lambda, decay_wb, dgi, dgh, decv, dhz);
+  else
+    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TYPE1>), dim3(grid), dim3(256), 0, st, n, d, saved, plane, dh_up, d_prev_next,
+                next_idx, dt, lambda, decay_wb, dgi, dgh, decv, dhz);
+  return launch_status();
+}
+
 int temp_gru_fwd(int n, int d, int variant, const float* x, const float* prev, const int32_t* prev_idx, const float* dt, float lambda,
                  const float* decay_wb, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* h_out,
                  float* saved, void* stream) {
@@ -239,19 +302,31 @@ int temp_gru_fwd(int n, int d, int variant, const float* x, const float* prev, c
   if (n > 0 && (!x || !prev || !dt || !h_out || !saved)) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
   if (n == 0) return TEMP_OK;
-  dim3 grid(ceil_div(n, 128), ceil_div(d, 32));
-  if (variant == TEMP_GRU_TORCH)
-    TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<TEMP_GRU_TORCH>), grid, dim3(256), 0, (hipStream_t)stream, n, d, x, prev, prev_idx, dt, lambda, decay_wb,
-                       w_ih, w_hh, b_ih, b_hh, h_out, saved);
-  else
-    TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<TEMP_GRU_TYPE1>), grid, dim3(256), 0, (hipStream_t)stream, n, d, x, prev, prev_idx, dt, lambda, decay_wb,
-                       w_ih, w_hh, b_ih, b_hh, h_out, saved);
-  return launch_status();
+  return launch_gru_fwd(n, d, variant, x, nullptr, prev, prev_idx, dt, lambda, decay_wb, w_ih, w_hh, b_ih, b_hh, h_out, saved,
+                        (size_t)n * d, (hipStream_t)stream);
 }
 
 size_t temp_gru_bwd_workspace(int n, int d, int variant) {
   if (n < 0 || d <= 0) return 0;
   return carve_gru(n, d, variant, nullptr).total;
+}
+
+static int gru_weight_grads(int n, int d, int variant, const float* x, const float* hdec, const float* dgi, const float* dgh,
+                            const float* w_ih, float* d_x, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh, void* tn,
+                            size_t tn_bytes, void* cs, size_t cs_bytes, hipStream_t st) {
+  const int gi_w = (variant == TEMP_GRU_TORCH) ? 3 * d : d;
+  int rc = TEMP_OK;
+  if (d_x) {                       // d_x = dgi . W_ih            (W_ih is [gi_w, d] row-major == [K, N])
+    rc = launch_gemm_panel(K_GEMM_GRU_DX, n, d, gi_w, dgi, gi_w, nullptr, w_ih, d, 0, EpiStore{d_x, d}, st);
+    if (rc) return rc;
+  }
+  rc = gemm_tn(n, gi_w, d, dgi, gi_w, x, d, d_w_ih, d, tn, tn_bytes, st);
+  if (rc) return rc;
+  rc = gemm_tn(n, 3 * d, d, dgh, 3 * d, hdec, d, d_w_hh, d, tn, tn_bytes, st);
+  if (rc) return rc;
+  rc = colsum(n, gi_w, dgi, gi_w, d_b_ih, cs, cs_bytes, st);
+  if (rc) return rc;
+  return colsum(n, 3 * d, dgh, 3 * d, d_b_hh, cs, cs_bytes, st);
 }
 
 int temp_gru_bwd(int n, int d, int variant, const float* x, const float* prev, const int32_t* prev_idx, const float* dt, float lambda,
@@ -276,36 +351,79 @@ int temp_gru_bwd(int n, int d, int variant, const float* x, const float* prev, c
   }
   GruBwdWs w = carve_gru(n, d, variant, (char*)workspace);
   const size_t nd = (size_t)n * d;
-  int grid = ceil_div((long long)nd, 256);
-  if (grid > 4096) grid = 4096;
-  if (variant == TEMP_GRU_TORCH)
-    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TORCH>), dim3(grid), dim3(256), 0, st, n, d, saved, d_h_out, dt, lambda, decay_wb, w.dgi,
-                       w.dgh, w.decv);
-  else
-    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TYPE1>), dim3(grid), dim3(256), 0, st, n, d, saved, d_h_out, dt, lambda, decay_wb, w.dgi,
-                       w.dgh, w.decv);
-  int rc = launch_status();
+  int rc = launch_gru_gates(n, d, variant, saved, nd, d_h_out, nullptr, nullptr, dt, lambda, decay_wb, w.dgi, w.dgh, w.decv, d_prev, st);
   if (rc) return rc;
-  // d_x = dgi . W_ih            (W_ih is [gi_w, d] row-major == [K, N])
-  rc = launch_gemm_panel(K_GEMM_GRU_DX, n, d, gi_w, w.dgi, gi_w, nullptr, w_ih, d, 0, EpiStore{d_x, d}, st);
+  rc = launch_gemm_panel(K_GEMM_GRU_DPREV, n, d, 3 * d, w.dgh, 3 * d, nullptr, w_hh, d, 0, EpiGruDprev{w.decv, d_prev, d}, st);
   if (rc) return rc;
-  // d_prev = (dgh . W_hh + dh * z) * decay
-  rc = launch_gemm_panel(K_GEMM_GRU_DPREV, n, d, 3 * d, w.dgh, 3 * d, nullptr, w_hh, d, 0, EpiGruDprev{d_h_out, saved + nd, w.decv, d_prev, d}, st);
-  if (rc) return rc;
-  // weight / bias gradients
-  rc = gemm_tn(n, gi_w, d, w.dgi, gi_w, x, d, d_w_ih, d, w.tn, w.tn_bytes, st);
-  if (rc) return rc;
-  rc = gemm_tn(n, 3 * d, d, w.dgh, 3 * d, saved + 4 * nd, d, d_w_hh, d, w.tn, w.tn_bytes, st);
-  if (rc) return rc;
-  rc = colsum(n, gi_w, w.dgi, gi_w, d_b_ih, w.cs, w.cs_bytes, st);
-  if (rc) return rc;
-  rc = colsum(n, 3 * d, w.dgh, 3 * d, d_b_hh, w.cs, w.cs_bytes, st);
+  rc = gru_weight_grads(n, d, variant, x, saved + 4 * nd, w.dgi, w.dgh, w_ih, d_x, d_w_ih, d_w_hh, d_b_ih, d_b_hh, w.tn, w.tn_bytes, w.cs,
+                        w.cs_bytes, st);
   if (rc) return rc;
   if (decay_wb) {
     TEMP_LAUNCH(K_DECAY_GRAD, k_decay_grad, dim3(1), dim3(256), 0, st, n, d, d_prev, prev, prev_idx, dt, decay_wb, d_decay_wb);
     rc = launch_status();
   }
   return rc;
+}
+
+/* ---- window-batched recurrence (see include/temp_amd.h) ---------------------------------------- */
+int temp_gru_input_gates(int n, int d, int variant, const float* x, const float* w_ih, const float* b_ih, float* gi, void* stream) {
+  if (n < 0 || d <= 0 || !w_ih || !b_ih || (n > 0 && (!x || !gi))) return TEMP_E_BADARG;
+  if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  const int gi_w = (variant == TEMP_GRU_TORCH) ? 3 * d : d;
+  // gi = x . W_ih^T + b_ih       (W_ih stored [gi_w, d] => transposed B)
+  return gemm_add_bias_act(K_GEMM_GRU_GI, n, gi_w, d, x, d, nullptr, w_ih, d, 1, nullptr, 0, nullptr, b_ih, TEMP_ACT_NONE, gi, gi_w,
+                           (hipStream_t)stream);
+}
+
+int temp_gru_cell_fwd(int n, int d, int variant, const float* gi, const float* prev, const int32_t* prev_idx, const float* dt, float lambda,
+                      const float* w_hh, const float* b_hh, float* h_out, float* saved, size_t saved_plane, void* stream) {
+  if (n < 0 || d <= 0 || !w_hh || !b_hh) return TEMP_E_BADARG;
+  if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
+  if (n > 0 && (!gi || !prev || !dt || !h_out || !saved || saved_plane < (size_t)n * d)) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (n == 0) return TEMP_OK;
+  return launch_gru_fwd(n, d, variant, nullptr, gi, prev, prev_idx, dt, lambda, nullptr, nullptr, w_hh, nullptr, b_hh, h_out, saved,
+                        saved_plane, (hipStream_t)stream);
+}
+
+int temp_gru_cell_bwd(int n, int d, int variant, const float* saved, size_t saved_plane, const float* dh_up, const float* d_prev_next,
+                      const int32_t* next_idx, const float* dt, float lambda, const float* w_hh, float* dgi, float* dgh, float* decv,
+                      float* d_prev, void* stream) {
+  if (n < 0 || d <= 0 || !w_hh) return TEMP_E_BADARG;
+  if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
+  if (n > 0 && (!saved || !dt || !dgi || !dgh || !decv || !d_prev)) return TEMP_E_BADARG;
+  if (next_idx && !d_prev_next) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (n == 0) return TEMP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_gru_gates(n, d, variant, saved, saved_plane, dh_up, d_prev_next, next_idx, dt, lambda, nullptr, dgi, dgh, decv, d_prev, st);
+  if (rc) return rc;
+  return launch_gemm_panel(K_GEMM_GRU_DPREV, n, d, 3 * d, dgh, 3 * d, nullptr, w_hh, d, 0, EpiGruDprev{decv, d_prev, d}, st);
+}
+
+size_t temp_gru_weight_grads_workspace(int n, int d, int variant) {
+  if (n < 0 || d <= 0) return 0;
+  const int gi_w = (variant == TEMP_GRU_TORCH) ? 3 * d : d;
+  size_t tn = gemm_tn_workspace(n, 3 * d, d);
+  if (gemm_tn_workspace(n, gi_w, d) > tn) tn = gemm_tn_workspace(n, gi_w, d);
+  return tn + colsum_workspace(n, 3 * d) + 512;
+}
+
+int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float* hdec, const float* dgi, const float* dgh,
+                          const float* w_ih, float* d_x, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (n < 0 || d <= 0 || !w_ih || !d_w_ih || !d_w_hh || !d_b_ih || !d_b_hh) return TEMP_E_BADARG;
+  if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
+  if (n > 0 && (!x || !hdec || !dgi || !dgh)) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (!workspace || workspace_bytes < temp_gru_weight_grads_workspace(n, d, variant)) return TEMP_E_WORKSPACE;
+  const int gi_w = (variant == TEMP_GRU_TORCH) ? 3 * d : d;
+  size_t tn = gemm_tn_workspace(n, 3 * d, d);
+  if (gemm_tn_workspace(n, gi_w, d) > tn) tn = gemm_tn_workspace(n, gi_w, d);
+  char* base = (char*)workspace;
+  return gru_weight_grads(n, d, variant, x, hdec, dgi, dgh, w_ih, d_x, d_w_ih, d_w_hh, d_b_ih, d_b_hh, base, tn, base + tn,
+                          colsum_workspace(n, 3 * d), (hipStream_t)stream);
 }
 
 }  // extern "C"

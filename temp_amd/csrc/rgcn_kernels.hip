@@ -173,18 +173,31 @@ __global__ void __launch_bounds__(256) k_rgcn_agg_generic(TempEdgeView v, const 
   }
 }
 
-// out[seg] = sum of its partial slots, in slot order (deterministic).  One wave per fix entry.
+// out[seg] = sum of its partial slots, in slot order (deterministic).  One wave per (fix entry,
+// 256-float column block); lanes own float4s; the slot walk is unrolled for memory-level parallelism.
 __global__ void __launch_bounds__(256) k_fixup(int n_fix, const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ fix_slot,
                                                const int32_t* __restrict__ fix_cnt, const float* __restrict__ partial, int width,
                                                float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  for (int i = blockIdx.x * wpb + wave; i < n_fix; i += gridDim.x * wpb) {
+  const int cblocks = (width + 255) >> 8;
+  const long long items = (long long)n_fix * cblocks;
+  for (long long it = (long long)blockIdx.x * wpb + wave; it < items; it += (long long)gridDim.x * wpb) {
+    const int i = (int)(it / cblocks), cb = (int)(it - (long long)i * cblocks);
+    const int f = (cb << 8) + (lane << 2);
+    if (f >= width) continue;
     const int seg = fix_seg[i], s0 = fix_slot[i], cnt = fix_cnt[i];
-    for (int f = lane; f < width; f += 64) {
-      float acc = 0.f;
-      for (int s = 0; s < cnt; ++s) acc += partial[(size_t)(s0 + s) * width + f];
-      out[(size_t)seg * width + f] = acc;
+    const float* p = partial + (size_t)s0 * width + f;
+    float4 acc = zero4();
+    int s = 0;
+    for (; s + 8 <= cnt; s += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4(p + (size_t)(s + u) * width);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
     }
+    for (; s < cnt; ++s) acc = add4(acc, ld4(p + (size_t)s * width));
+    st4(out + (size_t)seg * width + f, acc);
   }
 }
 
@@ -201,54 +214,58 @@ __global__ void __launch_bounds__(256) k_rgcn_dw(TempEdgeView v, const float* __
   const int wrow = D * S;
   ItemRange it = xcd_items(v.n_chunks, wpb);
   for (int c = it.beg + wave; c < it.end; c += it.stride) {
-    const int seg = v.chunk_seg[c], beg = v.chunk_beg[c], cnt = v.chunk_end[c] - beg, slot = v.chunk_slot[c];
-    int a_l = 0, b_l = 0;
-    float s_l = 0.f;
-    if (lane < cnt) {
-      a_l = v.a[beg + lane];
-      b_l = v.b[beg + lane];
-      const float nn = nnorm[b_l];
-      s_l = nn * nn;
-    }
+    const int seg = v.chunk_seg[c], cbeg = v.chunk_beg[c], cend = v.chunk_end[c], slot = v.chunk_slot[c];
     float4 acc[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) acc[j] = zero4();
-    constexpr int U = 2;
-    for (int e0 = 0; e0 < cnt; e0 += epw * U) {
-      float4 xv[U], gv[U];
-      float sc[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * epw + gi;
-        const bool ok = (e < cnt) && active;
-        const int src = __shfl(a_l, e & 63), dst = __shfl(b_l, e & 63);
-        sc[u] = __shfl(s_l, e & 63);
-        xv[u] = ok ? ld4(x + (size_t)src * D + f) : zero4();
-        gv[u] = ok ? ld4(dz + (size_t)dst * D + f) : zero4();
+    // a relation chunk holds up to TEMP_CHUNK_REL edges; walk it 64 edges (one per lane) at a time
+    for (int beg = cbeg; beg < cend; beg += 64) {
+      const int cnt = min(64, cend - beg);
+      int a_l = 0, b_l = 0;
+      float s_l = 0.f;
+      if (lane < cnt) {
+        a_l = v.a[beg + lane];
+        b_l = v.b[beg + lane];
+        const float nn = nnorm[b_l];
+        s_l = nn * nn;
       }
+      constexpr int U = 4;
+      for (int e0 = 0; e0 < cnt; e0 += epw * U) {
+        float4 xv[U], gv[U];
+        float sc[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float4 g = scale4(gv[u], sc[u]);
-        const float4 xx = xv[u];
-        if (S == 1) {
-          acc[0].x = fmaf(xx.x, g.x, acc[0].x);
-          acc[0].y = fmaf(xx.y, g.y, acc[0].y);
-          acc[0].z = fmaf(xx.z, g.z, acc[0].z);
-          acc[0].w = fmaf(xx.w, g.w, acc[0].w);
-        } else if (S == 2) {
-          acc[0].x = fmaf(xx.x, g.x, acc[0].x);  // blk0 w00
-          acc[0].y = fmaf(xx.x, g.y, acc[0].y);  //      w01
-          acc[0].z = fmaf(xx.y, g.x, acc[0].z);  //      w10
-          acc[0].w = fmaf(xx.y, g.y, acc[0].w);  //      w11
-          acc[1].x = fmaf(xx.z, g.z, acc[1].x);  // blk1
-          acc[1].y = fmaf(xx.z, g.w, acc[1].y);
-          acc[1].z = fmaf(xx.w, g.z, acc[1].z);
-          acc[1].w = fmaf(xx.w, g.w, acc[1].w);
-        } else {
-          acc[0] = fma4(xx.x, g, acc[0]);
-          acc[1] = fma4(xx.y, g, acc[1]);
-          acc[2] = fma4(xx.z, g, acc[2]);
-          acc[3] = fma4(xx.w, g, acc[3]);
+        for (int u = 0; u < U; ++u) {
+          const int e = e0 + u * epw + gi;
+          const bool ok = (e < cnt) && active;
+          const int src = __shfl(a_l, e & 63), dst = __shfl(b_l, e & 63);
+          sc[u] = __shfl(s_l, e & 63);
+          xv[u] = ok ? ld4(x + (size_t)src * D + f) : zero4();
+          gv[u] = ok ? ld4(dz + (size_t)dst * D + f) : zero4();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float4 g = scale4(gv[u], sc[u]);
+          const float4 xx = xv[u];
+          if (S == 1) {
+            acc[0].x = fmaf(xx.x, g.x, acc[0].x);
+            acc[0].y = fmaf(xx.y, g.y, acc[0].y);
+            acc[0].z = fmaf(xx.z, g.z, acc[0].z);
+            acc[0].w = fmaf(xx.w, g.w, acc[0].w);
+          } else if (S == 2) {
+            acc[0].x = fmaf(xx.x, g.x, acc[0].x);  // blk0 w00
+            acc[0].y = fmaf(xx.x, g.y, acc[0].y);  //      w01
+            acc[0].z = fmaf(xx.y, g.x, acc[0].z);  //      w10
+            acc[0].w = fmaf(xx.y, g.y, acc[0].w);  //      w11
+            acc[1].x = fmaf(xx.z, g.z, acc[1].x);  // blk1
+            acc[1].y = fmaf(xx.z, g.w, acc[1].y);
+            acc[1].z = fmaf(xx.w, g.z, acc[1].z);
+            acc[1].w = fmaf(xx.w, g.w, acc[1].w);
+          } else {
+            acc[0] = fma4(xx.x, g, acc[0]);
+            acc[1] = fma4(xx.y, g, acc[1]);
+            acc[2] = fma4(xx.z, g, acc[2]);
+            acc[3] = fma4(xx.w, g, acc[3]);
+          }
         }
       }
     }
@@ -326,8 +343,8 @@ static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const 
 
 static void launch_fixup(const TempEdgeView& v, const float* partial, int width, float* out, hipStream_t st) {
   if (v.n_fix <= 0) return;
-  int grid = (v.n_fix + 3) / 4;
-  if (grid > 2048) grid = 2048;
+  long long items = (long long)v.n_fix * ((width + 255) / 256);
+  int grid = (int)((items + 3) / 4 > 4096 ? 4096 : (items + 3) / 4);
   TEMP_LAUNCH(K_FIXUP, k_fixup, dim3(grid), dim3(256), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
 }
 

@@ -19,6 +19,8 @@ from . import functional as TF
 from . import snapshot as S
 from .rrgcn import RRGCN, GRRGCNLayer, run_rnn
 from .tkg_module import TKG_Module
+from .gru_chain import GruInstance, GruProgram, gru_chain
+from .gru_cell import GRUCell
 from .window import ChainPlan, Step, concat_steps, window_times
 
 
@@ -43,6 +45,7 @@ class DynamicRGCN(TKG_Module):
         nn.init.xavier_uniform_(self.rel_embeds, gain=nn.init.calculate_gain('relu'))
         self.sample_rng = np.random.default_rng(getattr(args, "seed", None))
         self.use_batched_path = True
+        self.use_gru_chain = True
 
     def build_model(self):
         self.ent_encoder = RRGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
@@ -113,12 +116,33 @@ class DynamicRGCN(TKG_Module):
     # ---------------------------------------------------------------------------------------------
     # batched path
     # ---------------------------------------------------------------------------------------------
+    def _can_chain(self):
+        """The whole recurrence as one autograd node (gru_chain): fixed decay, single GRU layer,
+        no per-position time embedding."""
+        enc = self.ent_encoder
+        l2 = enc.layer_2
+        return (self.use_gru_chain and l2.decay_spec() is None and not enc.use_time_embedding and getattr(l2, "num_layers", 1) == 1)
+
+    def _build_program(self, wb):
+        inst = []
+        for k, st in enumerate(wb.steps):
+            has_prev = k > 0
+            inst.append(GruInstance(st.n_rows, st.row0, 0, k - 1 if has_prev else -1, st.prev_idx, st.dt))
+        wb.program = GruProgram(inst)
+        wb.out_inst = [len(inst) - 1]
+        wb.hist_inst = len(inst) - 2 if len(inst) > 1 else -1
+
     def _run_batched(self, wb):
         enc, dev = self.ent_encoder, self._device()
         h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
         y1 = enc.layer_1.conv(wb.g_all, h0)
         y2 = enc.layer_2.conv(wb.g_all, y1)
         l2 = enc.layer_2
+        if wb.program is not None:
+            H_all = gru_chain(y2, wb.program, [l2.rnn], l2.inv_temperature, isinstance(l2.rnn, GRUCell))
+            rows = lambda i: H_all[wb.program.inst[i].h0:wb.program.inst[i].h0 + wb.program.inst[i].n]
+            hist = rows(wb.hist_inst) if wb.hist_inst >= 0 else None
+            return rows(wb.out_inst[0]), (hist, hist)
         H, hist = None, None
         for st in wb.steps:
             _, pidx, dt = st.tensors(dev)
@@ -151,10 +175,14 @@ class DynamicRGCN(TKG_Module):
     def _upload(self, wb, dev):
         for st in wb.steps:
             st.tensors(dev)
+        wb.program = None
         if wb.batched:
             wb.g_all, wb.total_rows = concat_steps(wb.steps)
             wb.ids_all = torch.from_numpy(wb.g_all.gids.astype(np.int32)).to(dev)
             wb.g_all.device_graph(dev, 2 * self.num_rels)
+            if self._can_chain():
+                self._build_program(wb)
+                wb.program.upload(dev)
         else:
             for st in wb.steps:
                 st.batched().device_graph(dev, 2 * self.num_rels)

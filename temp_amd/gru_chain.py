@@ -1,0 +1,163 @@
+"""Window-batched GRU recurrence: one autograd node for the whole chain of window positions.
+
+With --rec-only-last-layer the GRU input of every position is known before the recurrence starts
+(models/RRGCN.py:182-187: layer 1 is a plain RGCNLayer), so the per-position work shrinks to what is
+truly sequential -- hdec . W_hh^T + gates forward, gate gradients + d_prev backward -- and the
+input-side GEMM, d_x, and all weight / bias gradients run once over all rows (temp_gru_input_gates,
+temp_gru_weight_grads).  Previous states and their gradients move between positions through the
+plan's row maps (`prev_idx` forward, its inverse `next_idx` backward), never through a dense
+(bsz, N_ents, D) history (SURVEY F8 semantics kept: -1 => zero state).
+
+A `GruProgram` is a small static DAG of *instances*; instance i applies GRU weights `rnn[i]` to
+x rows [x0, x0+n) with previous state = output of instance `prev` (or none) and writes H rows
+[h0, h0+n).  The bi-directional centre position is two instances over the same x rows whose
+outputs the caller adds (models/BiRRGCN.py:45).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .backend import get_backend
+
+
+class GruInstance:
+    __slots__ = ("n", "x0", "h0", "rnn", "prev", "next", "prev_idx", "next_idx", "dt", "group")
+
+    def __init__(self, n, x0, rnn, prev, prev_idx_np, dt_np):
+        self.n, self.x0, self.rnn, self.prev = int(n), int(x0), rnn, prev
+        self.h0 = 0
+        self.next = -1
+        self.prev_idx = prev_idx_np
+        self.next_idx = None
+        self.dt = dt_np
+        self.group = -1
+
+
+class GruProgram:
+    def __init__(self, instances):
+        self.inst = instances
+        off = 0
+        for it in instances:
+            it.h0 = off
+            off += it.n
+        self.n_total = off
+        # inverse row maps: which row of the NEXT instance consumes each row of this one
+        for i, it in enumerate(instances):
+            if it.prev >= 0:
+                p = instances[it.prev]
+                assert p.next == -1, "an instance feeds at most one successor"
+                p.next = i
+                inv = np.full(p.n, -1, dtype=np.int32)
+                ok = it.prev_idx >= 0
+                inv[it.prev_idx[ok]] = np.nonzero(ok)[0].astype(np.int32)
+                p.next_idx = inv
+        # groups: maximal runs of instances with the same weights and contiguous x and h rows
+        self.groups = []
+        for i, it in enumerate(instances):
+            g = self.groups[-1] if self.groups else None
+            if g is not None and g["rnn"] == it.rnn and g["x1"] == it.x0 and g["h1"] == it.h0:
+                g["x1"] += it.n
+                g["h1"] += it.n
+            else:
+                self.groups.append(dict(rnn=it.rnn, x0=it.x0, x1=it.x0 + it.n, h0=it.h0, h1=it.h0 + it.n))
+            it.group = len(self.groups) - 1
+        self.dev = None
+
+    def upload(self, device):
+        if self.dev is not None and self.dev[0] == str(device):
+            return self.dev[1]
+        t = []
+        for it in self.inst:
+            pi = torch.from_numpy(it.prev_idx.astype(np.int32)).to(device) if it.prev >= 0 else None
+            ni = torch.from_numpy(it.next_idx).to(device) if it.next_idx is not None else None
+            t.append((pi, ni, torch.from_numpy(it.dt.astype(np.float32)).to(device)))
+        self.dev = (str(device), t)
+        return t
+
+
+class _GruChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_all, prog, lam, variant, n_rnn, *weights):
+        be = get_backend()
+        dev = x_all.device
+        d = x_all.shape[1]
+        G = weights[0].shape[0]                      # 3d (torch) or d (type-1)
+        N = prog.n_total
+        x_all = x_all.detach().contiguous()
+        W = [tuple(w.detach().contiguous() for w in weights[4 * r:4 * r + 4]) for r in range(n_rnn)]   # (w_ih, w_hh, b_ih, b_hh)
+        tens = prog.upload(dev)
+        gi = torch.empty(N, G, dtype=torch.float32, device=dev)
+        for g in prog.groups:
+            w_ih, _, b_ih, _ = W[g["rnn"]]
+            be.gru_input_gates(x_all[g["x0"]:g["x1"]], w_ih, b_ih, variant, gi[g["h0"]:g["h1"]])
+        H = torch.empty(N, d, dtype=torch.float32, device=dev)
+        saved = torch.empty(5, N, d, dtype=torch.float32, device=dev)
+        zero = torch.zeros(1, d, dtype=torch.float32, device=dev)
+        for it, (pi, _, dt) in zip(prog.inst, tens):
+            if it.n == 0:
+                continue
+            _, w_hh, _, b_hh = W[it.rnn]
+            if it.prev >= 0:
+                p = prog.inst[it.prev]
+                prev, pidx = H[p.h0:p.h0 + p.n], pi
+            else:                                     # no history yet: every previous state is zero
+                prev, pidx = zero, torch.full((it.n,), -1, dtype=torch.int32, device=dev)
+            be.gru_cell_fwd(gi[it.h0:it.h0 + it.n], prev, pidx, dt, lam, w_hh, b_hh, variant, H[it.h0:it.h0 + it.n], saved, it.h0)
+        ctx.save_for_backward(x_all, saved, *[w for ws in W for w in ws])
+        ctx.prog, ctx.lam, ctx.variant, ctx.n_rnn, ctx.G = prog, lam, variant, n_rnn, G
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        be = get_backend()
+        x_all, saved = ctx.saved_tensors[:2]
+        flat = ctx.saved_tensors[2:]
+        W = [flat[4 * r:4 * r + 4] for r in range(ctx.n_rnn)]
+        prog, lam, variant, G = ctx.prog, ctx.lam, ctx.variant, ctx.G
+        dev, d, N = x_all.device, x_all.shape[1], prog.n_total
+        dH = dH.contiguous()
+        tens = prog.upload(dev)
+        dgi = torch.empty(N, G, dtype=torch.float32, device=dev)
+        dgh = torch.empty(N, 3 * d, dtype=torch.float32, device=dev)
+        decv = torch.empty(N, dtype=torch.float32, device=dev)
+        d_prev = torch.empty(N, d, dtype=torch.float32, device=dev)
+        for i in range(len(prog.inst) - 1, -1, -1):
+            it = prog.inst[i]
+            if it.n == 0:
+                continue
+            _, ni, dt = tens[i]
+            nxt = prog.inst[it.next] if it.next >= 0 else None
+            be.gru_cell_bwd(saved, it.h0, it.n, dH[it.h0:it.h0 + it.n],
+                            d_prev[nxt.h0:nxt.h0 + nxt.n] if nxt is not None else None, ni if nxt is not None else None,
+                            dt, lam, W[it.rnn][1], variant, dgi[it.h0:it.h0 + it.n], dgh[it.h0:it.h0 + it.n],
+                            decv[it.h0:it.h0 + it.n], d_prev[it.h0:it.h0 + it.n])
+        d_x_all = torch.empty_like(x_all)
+        written = np.zeros(x_all.shape[0], dtype=bool)
+        grads = [None] * (4 * ctx.n_rnn)
+        for g in prog.groups:
+            xs, hs = slice(g["x0"], g["x1"]), slice(g["h0"], g["h1"])
+            first = not written[xs].any()
+            assert first or written[xs].all()
+            tgt = d_x_all[xs] if first else torch.empty(g["x1"] - g["x0"], d, dtype=torch.float32, device=dev)
+            gw = be.gru_weight_grads(x_all[xs], saved[4, hs], dgi[hs], dgh[hs], W[g["rnn"]][0], variant, tgt)
+            if not first:
+                d_x_all[xs] += tgt
+            written[xs] = True
+            for k in range(4):                         # (d_w_ih, d_w_hh, d_b_ih, d_b_hh) -> weight order (w_ih, w_hh, b_ih, b_hh)
+                j = 4 * g["rnn"] + k
+                grads[j] = gw[k] if grads[j] is None else grads[j] + gw[k]
+        if not written.all():
+            d_x_all[torch.from_numpy(~written).to(dev)] = 0
+        return (d_x_all, None, None, None, None) + tuple(grads)
+
+
+def gru_chain(x_all, prog, rnns, lam, type1=False):
+    """Run a GruProgram.  `rnns`: list of modules holding (weight_ih, weight_hh, bias_ih, bias_hh)
+    (nn.GRU layer 0 or the type-1 GRUCell).  Returns H_all (prog.n_total, d)."""
+    ws = []
+    for r in rnns:
+        if type1:
+            ws += [r.weight_ih, r.weight_hh, r.bias_ih, r.bias_hh]
+        else:
+            ws += [r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0]
+    return _GruChainFn.apply(x_all, prog, float(lam), _lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH, len(rnns), *ws)

@@ -138,7 +138,7 @@ class _DeviceGraph:
         n, E = snap.n, snap.number_of_edges()
         views = dict(by_dst=build_view(snap.dst, snap.src, snap.rel, n),
                      by_src=build_view(snap.src, snap.dst, snap.rel, n),
-                     by_rel=build_view(snap.rel, snap.src, snap.dst, n_rel_rows))
+                     by_rel=build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL))
         if E and (snap.rel.min() < 0 or snap.rel.max() >= n_rel_rows):
             raise ValueError("relation id outside [0, %d)" % n_rel_rows)
         in_deg = np.bincount(snap.dst, minlength=n).astype(np.int32)

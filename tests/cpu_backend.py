@@ -26,7 +26,7 @@ def _chunk_reduce(dg, name, per_edge_fn, width, n_out, dtype):
         return out
     beg, end, seg, slot = t('chunk_beg'), t('chunk_end'), t('chunk_seg'), t('chunk_slot')
     cnt = end - beg
-    assert int(cnt.min()) >= 1 and int(cnt.max()) <= _lib.CHUNK
+    assert int(cnt.min()) >= 1 and int(cnt.max()) <= (_lib.CHUNK_REL if name == 'by_rel' else _lib.CHUNK)
     assert int(cnt.sum()) == v['n_edges'] and torch.equal(beg[1:], end[:-1]) and int(beg[0]) == 0
     cid = torch.repeat_interleave(torch.arange(v['n_chunks']), cnt)
     vals = per_edge_fn(t('a'), t('b'))
@@ -153,6 +153,55 @@ class CpuTestBackend:
             h.backward(d_h.detach())
         z = lambda t, like: t.grad if t.grad is not None else torch.zeros_like(like)
         return (z(xs, xs), z(rows, rows), z(wi, wi), z(wh, wh), z(bi, bi), z(bh, bh), (z(wb, wb) if wb is not None else None))
+
+    # ---- window-batched recurrence (same contract as the HIP entry points) ---------------------
+    def gru_input_gates(self, x, w_ih, b_ih, variant, out):
+        out.copy_(torch.mm(x.detach(), w_ih.detach().t()) + b_ih.detach())
+
+    def gru_cell_fwd(self, gi, prev, prev_idx, dt, lam, w_hh, b_hh, variant, h_out, saved_all, row0):
+        n, d = h_out.shape
+        prev, w_hh, b_hh = prev.detach(), w_hh.detach(), b_hh.detach()
+        if prev_idx is not None:
+            idx = prev_idx.long()
+            rows = prev[idx.clamp(min=0)] * (idx >= 0).to(prev.dtype).view(-1, 1)
+        else:
+            rows = prev
+        hd = rows * torch.exp(-dt.view(-1, 1) * lam)
+        gh = torch.mm(hd, w_hh.t()) + b_hh
+        h_r, h_z, h_n = gh.chunk(3, 1)
+        if variant == _lib.GRU_TORCH:
+            i_r, i_z, i_n = gi.chunk(3, 1)
+            r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+        else:
+            i_n = gi
+            r, z = torch.sigmoid(h_r), torch.sigmoid(h_z)
+        nn_ = torch.tanh(i_n + r * h_n)
+        h_out.copy_((1 - z) * nn_ + z * hd)
+        for k, v in enumerate((r, z, nn_, h_n, hd)):
+            saved_all[k, row0:row0 + n] = v
+
+    def gru_cell_bwd(self, saved_all, row0, n, dh_up, d_prev_next, next_idx, dt, lam, w_hh, variant, dgi, dgh, decv, d_prev):
+        r, z, nn_, hn, hd = (saved_all[k, row0:row0 + n] for k in range(5))
+        g = dh_up.detach().clone() if dh_up is not None else torch.zeros_like(r)
+        if next_idx is not None:
+            i = next_idx.long()
+            g = g + d_prev_next[i.clamp(min=0)] * (i >= 0).to(g.dtype).view(-1, 1)
+        dn_pre = g * (1 - z) * (1 - nn_ * nn_)
+        dz_pre = g * (hd - nn_) * z * (1 - z)
+        dr_pre = dn_pre * hn * r * (1 - r)
+        if variant == _lib.GRU_TORCH:
+            dgi.copy_(torch.cat([dr_pre, dz_pre, dn_pre], 1))
+        else:
+            dgi.copy_(dn_pre)
+        dgh.copy_(torch.cat([dr_pre, dz_pre, dn_pre * r], 1))
+        dec = torch.exp(-dt.view(-1) * lam)
+        decv.copy_(dec)
+        d_prev.copy_((torch.mm(dgh, w_hh.detach()) + g * z) * dec.view(-1, 1))
+
+    def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
+        if d_x is not None:
+            d_x.copy_(torch.mm(dgi, w_ih.detach()))
+        return torch.mm(dgi.t(), x.detach()), torch.mm(dgh.t(), hdec), dgi.sum(0), dgh.sum(0)
 
     # ---- rows -----------------------------------------------------------------------------------
     def gather_rows(self, table, idx):

@@ -50,7 +50,7 @@ def state_dict_from_oracle(model):
     return sd
 
 
-def build_window_model(z, device, batched=True):
+def build_window_model(z, device, batched=True, chain=True):
     s = slice_snapshots()
     module, rec_only, D, B, L = str(z["module"]), bool(z["rec_only"]), int(z["D"]), int(z["B"]), int(z["L"])
     cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=bool(z["te"]))
@@ -62,6 +62,7 @@ def build_window_model(z, device, batched=True):
     m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
     m.load_state_dict(state_dict_from_oracle(model), strict=True)
     m.use_batched_path = batched
+    m.use_gru_chain = chain
     return m.to(device)
 
 
@@ -107,17 +108,20 @@ def check_batched_equals_generic(name, device):
     edge_ids, samples = window_inputs(z)
     t_list = torch.tensor([int(t) for t in z["t_list"]])
     outs = []
-    for batched in (False, True):
-        m = build_window_model(z, device, batched)
-        assert m._can_batch() == batched
+    for batched, chain in ((False, False), (True, False), (True, True)):
+        m = build_window_model(z, device, batched, chain)
+        assert m._can_batch() == batched and m._can_chain() == chain
+        wb = m.prepare(t_list, int(z["L"]), True, edge_ids)
+        assert (wb.program is not None) == (batched and chain)
         per_graph, *_ = m.encode(t_list, int(z["L"]), True, edge_ids)
         s = sum((e * (i + 1)).sum() for i, e in enumerate(per_graph))
         s.backward()
         outs.append((per_graph, m.ent_embeds.grad.clone(), m.ent_encoder.layer_2.weight.grad.clone()))
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert_close(a, b, 1e-5, 2e-6, name + " batched vs generic")
-    assert_close(outs[0][1], outs[1][1], 5e-5, 3e-6, name + " d_ent batched vs generic")
-    assert_close(outs[0][2], outs[1][2], 5e-5, 3e-6, name + " d_weight batched vs generic")
+    for other in outs[1:]:
+        for a, b in zip(outs[0][0], other[0]):
+            assert_close(a, b, 1e-5, 2e-6, name + " batched vs generic")
+        assert_close(outs[0][1], other[1], 5e-5, 3e-6, name + " d_ent batched vs generic")
+        assert_close(outs[0][2], other[2], 5e-5, 3e-6, name + " d_weight batched vs generic")
 
 
 def check_static(device):
