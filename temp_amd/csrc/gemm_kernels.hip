@@ -38,64 +38,98 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// TN split-K: out[Ka,Nb] = sum_m A[m,ka] * B[m,nb].  A wave owns a 32 x (NT*32) output tile over
-// one slice of m; both operands are read row-wise (coalesced 128 B per half wave), no LDS.
-// Slices are written to a workspace and summed in slice order by k_reduce_slices.
+// TN split-K: out[Ka,Nb] = sum_m A[m,ka] * B[m,nb]  (every weight gradient).
+// A block owns a 128(ka) x NT*32(nb) output tile over one slice of m; wave w owns ka rows
+// [32w, 32w+32).  Chunks of TN_MC rows of A and B are staged in LDS (coalesced float4 row reads,
+// register-prefetched one chunk ahead, double-buffered); for the row pair (m, m+1) lane (li, hh)
+// reads As[m+hh][32w+li] and Bs[m+hh][32t+li] -- conflict-free b32 reads.  Slices are written to a
+// workspace and summed in slice order by k_reduce_slices (deterministic).
 // ---------------------------------------------------------------------------------------------
-#define TN_NT 4
+#define TN_MC 16
+template <int NT>
 __global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
-                                                 const float* __restrict__ B, int ldb, int rows_per_slice, float* __restrict__ part) {
+                                                 const float* __restrict__ B, int ldb, int rows_per_slice, int nb_base,
+                                                 float* __restrict__ part) {
+  constexpr int BN = NT * 32;
+  constexpr int NVA = TN_MC * 128 / 4 / 256;                 // = 2 float4 per thread
+  constexpr int NVB = (TN_MC * BN / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float As[2][TN_MC * 128];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TN_MC * BN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
-  const int ka0 = (blockIdx.x * 4 + wave) * 32;
-  const int nb0 = blockIdx.y * (TN_NT * 32);
+  const int ka_blk = blockIdx.x * 128;
+  const int ka0 = ka_blk + wave * 32;
+  const int nb0 = nb_base + blockIdx.y * BN;
   const int slice = blockIdx.z;
-  if (ka0 >= Ka) return;
   const int mbeg = slice * rows_per_slice, mend = min(M, mbeg + rows_per_slice);
-  f32x16 acc[TN_NT];
+  const bool wave_on = ka0 < Ka;
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < TN_NT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const bool a_ok = ka0 + li < Ka;
-  bool b_ok[TN_NT];
+
+  float4 ra[NVA], rb[NVB];
+  auto fetch = [&](int m0) {
 #pragma unroll
-  for (int t = 0; t < TN_NT; ++t) b_ok[t] = nb0 + t * 32 + li < Nb;
-  int ntv = (Nb - nb0 + 31) / 32;
-  if (ntv > TN_NT) ntv = TN_NT;
-  constexpr int U = 4;
-  for (int m = mbeg; m < mend; m += 2 * U) {
-    float av[U], bv[U][TN_NT];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int row = m + 2 * u + hh;
-      const bool rok = row < mend;
-      const int rs = rok ? row : mbeg;                      // clamped address + select: no branches in the loop
-      const float a_raw = A[(size_t)rs * lda + (a_ok ? ka0 + li : 0)];
-      av[u] = (rok && a_ok) ? a_raw : 0.f;
-#pragma unroll
-      for (int t = 0; t < TN_NT; ++t) {
-        const float b_raw = B[(size_t)rs * ldb + (b_ok[t] ? nb0 + t * 32 + li : 0)];
-        bv[u][t] = (rok && b_ok[t]) ? b_raw : 0.f;
-      }
+    for (int i = 0; i < NVA; ++i) {
+      const int p = threadIdx.x + i * 256;
+      const int r = p >> 5, c = (p & 31) << 2;
+      const bool ok = (m0 + r < mend) && (ka_blk + c < Ka);
+      const float4 v = ld4(A + (ok ? (size_t)(m0 + r) * lda + ka_blk + c : 0));
+      ra[i] = ok ? v : zero4();
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int i = 0; i < NVB; ++i) {
+      const int p = threadIdx.x + i * 256;
+      const int r = p / (BN / 4), c = (p - r * (BN / 4)) << 2;
+      const bool ok = (p < TN_MC * BN / 4) && (m0 + r < mend) && (nb0 + c < Nb);
+      const float4 v = ld4(B + (ok ? (size_t)(m0 + r) * ldb + nb0 + c : 0));
+      rb[i] = ok ? v : zero4();
+    }
+  };
+  auto store = [&](int buf) {
 #pragma unroll
-      for (int t = 0; t < TN_NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+    for (int i = 0; i < NVA; ++i) st4(&As[buf][(threadIdx.x + i * 256) << 2], ra[i]);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int p = threadIdx.x + i * 256;
+      if (p < TN_MC * BN / 4) st4(&Bs[buf][p << 2], rb[i]);
+    }
+  };
+
+  const int nchunks = (mend > mbeg) ? (mend - mbeg + TN_MC - 1) / TN_MC : 0;
+  if (nchunks > 0) {
+    fetch(mbeg);
+    store(0);
   }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) fetch(mbeg + (c + 1) * TN_MC);
+    if (wave_on) {
+      const float* as = As[c & 1] + wave * 32 + li;
+      const float* bs = Bs[c & 1] + li;
+#pragma unroll
+      for (int mp = 0; mp < TN_MC; mp += 2) {
+        const float a = as[(mp + hh) * 128];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[(mp + hh) * BN + t * 32], acc[t], 0, 0, 0);
+      }
+    }
+    if (more) store((c + 1) & 1);
+    __syncthreads();
+  }
+  if (!wave_on) return;
   float* p = part + (size_t)slice * Ka * Nb;
 #pragma unroll
-  for (int t = 0; t < TN_NT; ++t) {
-    if (t < ntv) {
-      const int col = nb0 + t * 32 + li;
-      if (col < Nb) {
+  for (int t = 0; t < NT; ++t) {
+    const int col = nb0 + t * 32 + li;
+    if (col < Nb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = ka0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (row < Ka) p[(size_t)row * Nb + col] = acc[t][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = ka0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < Ka) p[(size_t)row * Nb + col] = acc[t][r];
       }
     }
   }
@@ -112,10 +146,9 @@ __global__ void __launch_bounds__(256) k_reduce_slices(int n_slices, size_t elem
 }
 
 static int tn_slices(int M, int Ka, int Nb) {
-  const long long tiles = (long long)ceil_div(ceil_div(Ka, 32), 4) * ceil_div(Nb, TN_NT * 32);
+  const long long tiles = (long long)ceil_div(Ka, 128) * ceil_div(Nb, 128);
   long long s = 1024 / (tiles > 0 ? tiles : 1);
-  if (s < 1) s = 1;
-  const long long max_s = (M + 63) / 64;      // at least 64 rows per slice
+  const long long max_s = (M + 127) / 128;    // at least 128 rows per slice
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   return (int)s;
@@ -128,12 +161,18 @@ size_t gemm_tn_workspace(int M, int Ka, int Nb) {
 int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo, void* ws, size_t ws_bytes,
             hipStream_t st) {
   if (Ka <= 0 || Nb <= 0) return TEMP_OK;
+  if (Ka % 4 || Nb % 4 || lda % 4 || ldb % 4) return TEMP_E_UNSUPPORTED;
   const int S = tn_slices(M, Ka, Nb);
   if (ws_bytes < (size_t)S * Ka * Nb * sizeof(float) || !ws) return TEMP_E_WORKSPACE;
   int rps = ceil_div(M > 0 ? M : 1, S);
-  rps = (rps + 7) / 8 * 8;
-  dim3 grid(ceil_div(ceil_div(Ka, 32), 4), ceil_div(Nb, TN_NT * 32), S);
-  TEMP_LAUNCH(K_GEMM_TN, k_gemm_tn, grid, dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, (float*)ws);
+  rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
+  const int ntiles = ceil_div(Nb, 32), full = ntiles / 4, rem = ntiles - full * 4;
+  const int kab = ceil_div(Ka, 128);
+  float* part = (float*)ws;
+  if (full > 0) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<4>), dim3(kab, full, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part);
+  if (rem == 3) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<3>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part);
+  else if (rem == 2) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<2>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part);
+  else if (rem == 1) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<1>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part);
   const size_t elems = (size_t)Ka * Nb;
   int rg = ceil_div((long long)elems, 256);
   if (rg > 2048) rg = 2048;

@@ -1,9 +1,17 @@
 // Row-panel fp32 MFMA GEMM template shared by gemm_kernels.hip and gru_kernels.hip.
+//
+//   C[M, n0 .. n0+NT*32) = epi( A[M,K] . B[K, ...] )
+//
 // A wave owns 32 rows x (NT*32) columns; the 4 waves of a block own 4 consecutive row tiles and
-// share the B chunk staged in LDS.  A is read straight from global memory: the MFMA sums over k in
-// any order, so lane (row i, half hh) loads ONE float4 holding k = k0 + 4*hh .. +3 and feeds its 4
-// components to 4 consecutive MFMAs whose B operand uses the same k -- a 16-byte load per lane per
-// 4 MFMAs and no LDS traffic for A.
+// share the B chunk (KC x NT*32) staged in LDS.  A is read straight from global memory: the MFMA
+// sums over k in any order, so lane (row i, half hh) loads ONE float4 holding k = k0 + 4*hh .. +3
+// and feeds its 4 components to 4 consecutive MFMAs whose B operand uses the same k -- a 16-byte
+// load per lane per 4 MFMAs and no LDS traffic for A.
+//
+// Software pipeline: the B chunk c+1 (float4 global loads, all issued back to back, branch-free:
+// out-of-range pieces read a clamped address and are zeroed by a select) and the A fragments of
+// chunk c+1 are fetched into registers while the MFMAs of chunk c run out of LDS buffer c&1; the
+// registers are then written to buffer (c+1)&1 -- one barrier per chunk, no load on the MFMA path.
 #pragma once
 #include "common.hpp"
 
@@ -11,21 +19,71 @@ namespace temp {
 
 #define GEMM_KC 40
 
+template <int NT>
+struct PanelCfg {
+  static constexpr int BN = NT * 32;
+  static constexpr int LDS_B = BN + 1;                       // odd row stride: conflict-free b32 reads and transposed writes
+  static constexpr int NV = (GEMM_KC * BN / 4 + 255) / 256;  // float4 pieces of a B chunk per thread
+};
+
+// Fetch the float4 pieces of B chunk [k0, k0+KC) x [n0, n0+BN) owned by this thread.
+template <int NT>
+__device__ __forceinline__ void panel_fetch_b(float4 (&reg)[PanelCfg<NT>::NV], const float* __restrict__ B, int ldb, int trans_b,
+                                              int k0, int K, int n0, int N) {
+  constexpr int BN = PanelCfg<NT>::BN;
+#pragma unroll
+  for (int i = 0; i < PanelCfg<NT>::NV; ++i) {
+    const int p = threadIdx.x + i * 256;
+    size_t off;
+    bool ok;
+    if (!trans_b) {                                          // B[k][n]: pieces run along n
+      const int k = p / (BN / 4), j = (p - k * (BN / 4)) * 4;
+      ok = (p < GEMM_KC * BN / 4) && (k0 + k < K) && (n0 + j < N);
+      off = (size_t)(k0 + k) * ldb + n0 + j;
+    } else {                                                 // B stored [n][k]: pieces run along k
+      const int j = p / (GEMM_KC / 4), k = (p - j * (GEMM_KC / 4)) * 4;
+      ok = (p < GEMM_KC * BN / 4) && (k0 + k < K) && (n0 + j < N);
+      off = (size_t)(n0 + j) * ldb + k0 + k;
+    }
+    const float4 v = ld4(B + (ok ? off : 0));
+    reg[i] = ok ? v : zero4();
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void panel_store_b(const float4 (&reg)[PanelCfg<NT>::NV], float* __restrict__ Bs, int trans_b) {
+  constexpr int BN = PanelCfg<NT>::BN, LDS_B = PanelCfg<NT>::LDS_B;
+#pragma unroll
+  for (int i = 0; i < PanelCfg<NT>::NV; ++i) {
+    const int p = threadIdx.x + i * 256;
+    if (p < GEMM_KC * BN / 4) {
+      if (!trans_b) {
+        const int k = p / (BN / 4), j = (p - k * (BN / 4)) * 4;
+        float* d = Bs + k * LDS_B + j;
+        d[0] = reg[i].x; d[1] = reg[i].y; d[2] = reg[i].z; d[3] = reg[i].w;
+      } else {
+        const int j = p / (GEMM_KC / 4), k = (p - j * (GEMM_KC / 4)) * 4;
+        float* d = Bs + k * LDS_B + j;
+        d[0] = reg[i].x; d[LDS_B] = reg[i].y; d[2 * LDS_B] = reg[i].z; d[3 * LDS_B] = reg[i].w;
+      }
+    }
+  }
+}
+
 template <int NT, class Epi>
 __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                     const int32_t* __restrict__ a_idx, const float* __restrict__ B, int ldb,
-                                                    int trans_b, Epi epi) {
-  constexpr int BN = NT * 32, LDS_B = BN + 1;
-  __shared__ float Bs[GEMM_KC * LDS_B];
+                                                    int trans_b, int n_base, Epi epi) {
+  constexpr int LDS_B = PanelCfg<NT>::LDS_B, NV = PanelCfg<NT>::NV, NQ = GEMM_KC / 8;
+  __shared__ float Bs[2][GEMM_KC * LDS_B];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
   const int m0 = (blockIdx.x * 4 + wave) * 32;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = n_base + blockIdx.y * PanelCfg<NT>::BN;
   const int arow = m0 + li;
-  // Branch-free inner loop: an invalid row reads row 0 (always mapped when M > 0) and is zeroed by a select.
   long arow_src = -1;
   if (arow < M) arow_src = a_idx ? (long)a_idx[arow] : (long)arow;
-  const bool arow_ok = arow_src >= 0;
+  const bool arow_ok = arow_src >= 0;                         // invalid row: read row 0, zero by select
   const float* aptr = A + (size_t)(arow_ok ? arow_src : 0) * lda + 4 * hh;
   f32x16 acc[NT];
 #pragma unroll
@@ -33,39 +91,44 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
-    const int kc = min(GEMM_KC, K - k0);
-    __syncthreads();
-    // stage B[k0 .. k0+KC) x [n0 .. n0+BN); rows >= kc and columns >= N are zero so the MFMA loop needs no guards
-    if (!trans_b) {
-      for (int idx = threadIdx.x; idx < GEMM_KC * BN; idx += 256) {
-        const int k = idx / BN, j = idx - k * BN;
-        Bs[k * LDS_B + j] = (k < kc && n0 + j < N) ? B[(size_t)(k0 + k) * ldb + n0 + j] : 0.f;
-      }
-    } else {
-      for (int idx = threadIdx.x; idx < GEMM_KC * BN; idx += 256) {
-        const int j = idx / GEMM_KC, k = idx - j * GEMM_KC;
-        Bs[k * LDS_B + j] = (k < kc && n0 + j < N) ? B[(size_t)(n0 + j) * ldb + k0 + k] : 0.f;
-      }
-    }
-    __syncthreads();
-    float4 av[GEMM_KC / 8];
+  auto fetch_a = [&](float4 (&av)[NQ], int k0) {
 #pragma unroll
-    for (int q = 0; q < GEMM_KC / 8; ++q) {          // all A loads of the chunk issued up front
-      const bool ok = arow_ok && (q * 8 + 4 * hh < kc);
-      const float4 v = ld4(aptr + (ok ? k0 + q * 8 : -4 * hh));     // !ok: re-read k=0..3 of the row (in bounds)
+    for (int q = 0; q < NQ; ++q) {
+      const bool ok = arow_ok && (k0 + q * 8 + 4 * hh < K);
+      const float4 v = ld4(aptr + (ok ? k0 + q * 8 : -4 * hh));    // !ok: re-read k = 0..3 of the row (in bounds)
       av[q] = ok ? v : zero4();
     }
+  };
+
+  float4 breg[NV], av[NQ], av_next[NQ];
+  panel_fetch_b<NT>(breg, B, ldb, trans_b, 0, K, n0, N);
+  fetch_a(av, 0);
+  panel_store_b<NT>(breg, Bs[0], trans_b);
+  __syncthreads();
+  const int nchunks = (K + GEMM_KC - 1) / GEMM_KC;
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) {
+      panel_fetch_b<NT>(breg, B, ldb, trans_b, (c + 1) * GEMM_KC, K, n0, N);
+      fetch_a(av_next, (c + 1) * GEMM_KC);
+    }
+    const float* bs = Bs[c & 1];
 #pragma unroll
-    for (int q = 0; q < GEMM_KC / 8; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const float as[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float* brow = Bs + (q * 8 + 4 * hh + s) * LDS_B + li;
+        const float* brow = bs + (q * 8 + 4 * hh + s) * LDS_B + li;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], brow[t * 32], acc[t], 0, 0, 0);
       }
     }
+    if (more) {
+      panel_store_b<NT>(breg, Bs[(c + 1) & 1], trans_b);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) av[q] = av_next[q];
+    }
+    __syncthreads();
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -80,25 +143,35 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
   }
 }
 
+template <int NT, class Epi>
+static inline void launch_panel_nt(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb,
+                                   int trans_b, int n_base, int col_blocks, const Epi& epi, hipStream_t st) {
+  dim3 grid(ceil_div(M, 128), col_blocks);
+  TEMP_LAUNCH(kid, (k_gemm_panel<NT, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, n_base, epi);
+}
+
 template <class Epi>
 int launch_gemm_panel(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
                       const Epi& epi, hipStream_t st) {
   if (M <= 0 || N <= 0) return TEMP_OK;
-  if (K % 4 != 0 || lda % 4 != 0) return TEMP_E_UNSUPPORTED;
+  if (K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0 || N % 4 != 0) return TEMP_E_UNSUPPORTED;
   const int row_blocks = ceil_div(M, 128);
   const int ntiles = ceil_div(N, 32);
-  // widest column block that still leaves >= ~2 blocks per CU; narrow blocks re-read A from L2.
-  int nt = 7;
-  while (nt > 1 && (long long)row_blocks * ceil_div(ntiles, nt) < 512) nt = (nt == 7) ? 4 : nt / 2;
-  dim3 grid(row_blocks, ceil_div(ntiles, nt));
-  switch (nt) {
-    case 7: TEMP_LAUNCH(kid, (k_gemm_panel<7, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
-    case 4: TEMP_LAUNCH(kid, (k_gemm_panel<4, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
-    case 2: TEMP_LAUNCH(kid, (k_gemm_panel<2, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
-    default: TEMP_LAUNCH(kid, (k_gemm_panel<1, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi); break;
+  // column-block width: 4 tiles when the grid still fills the chip (re-reads of A come from L2),
+  // narrower blocks for short panels (the per-position GEMMs of the GRU chain) to get more waves.
+  int nt = 4;
+  while (nt > 1 && (long long)row_blocks * ceil_div(ntiles, nt) < 384) nt >>= 1;
+  const int full = ntiles / nt, rem = ntiles - full * nt;
+#define TEMP_PANEL(NT_, BASE, CB) launch_panel_nt<NT_, Epi>(kid, M, N, K, A, lda, a_idx, B, ldb, trans_b, (BASE), (CB), epi, st)
+  if (full > 0) {
+    if (nt == 4) TEMP_PANEL(4, 0, full); else if (nt == 2) TEMP_PANEL(2, 0, full); else TEMP_PANEL(1, 0, full);
   }
+  if (rem > 0) {
+    const int base = full * nt * 32;
+    if (rem == 3) TEMP_PANEL(3, base, 1); else if (rem == 2) TEMP_PANEL(2, base, 1); else TEMP_PANEL(1, base, 1);
+  }
+#undef TEMP_PANEL
   return launch_status();
 }
-
 
 }  // namespace temp

@@ -24,8 +24,92 @@ __device__ __forceinline__ float decay_factor(float dt, float lambda, const floa
 //   GI == nullptr : fused -- phase X (x . W_ih^T) and phase H (hdec . W_hh^T) both on MFMA;
 //   GI != nullptr : the input-side gates were hoisted out of the recurrence (one big GEMM over all
 //                   window positions, temp_gru_input_gates) and only phase H runs here.
-// The MFMA loops are branch-free: B rows/columns outside the problem are staged as zeros and
-// invalid A rows are zeroed by a select, so all loads of a K chunk issue before its MFMAs.
+// Each phase is a software-pipelined K loop: the three 32-column gate slices of the (transposed)
+// weight chunk c+1 and the A fragments of chunk c+1 are fetched into registers (branch-free float4
+// loads: out-of-range pieces read a clamped address and are zeroed by a select) while the MFMAs of
+// chunk c run out of LDS buffer c&1.
+#define GRU_NVB ((3 * GRU_KC * 32 / 4 + 255) / 256)     // float4 weight pieces per thread per chunk (= 4)
+#define GRU_NQ (GRU_KC / 8)
+
+// W: [rows, D] row-major; gate g's slice = rows row_base[g] + j0 .. +32 (row_base[g] < 0: gate unused)
+struct GruPhase {
+  const float* W; int row_base[3]; int D; int j0;
+};
+
+__device__ __forceinline__ void gru_fetch_w(float4 (&reg)[GRU_NVB], const GruPhase& ph, int k0) {
+#pragma unroll
+  for (int i = 0; i < GRU_NVB; ++i) {
+    const int p = threadIdx.x + i * 256;
+    const int g = p / (32 * GRU_KC / 4), rem = p - g * (32 * GRU_KC / 4);
+    const int j = rem / (GRU_KC / 4), k = (rem - j * (GRU_KC / 4)) * 4;
+    const int rb = (g == 0) ? ph.row_base[0] : (g == 1 ? ph.row_base[1] : ph.row_base[2]);
+    const bool ok = (p < 3 * 32 * GRU_KC / 4) && rb >= 0 && (ph.j0 + j < ph.D) && (k0 + k < ph.D);
+    const float4 v = ld4(ph.W + (ok ? (size_t)(rb + ph.j0 + j) * ph.D + k0 + k : 0));
+    reg[i] = ok ? v : zero4();
+  }
+}
+__device__ __forceinline__ void gru_store_w(const float4 (&reg)[GRU_NVB], float (*Bs)[GRU_KC * GRU_LDB]) {
+#pragma unroll
+  for (int i = 0; i < GRU_NVB; ++i) {
+    const int p = threadIdx.x + i * 256;
+    if (p < 3 * 32 * GRU_KC / 4) {
+      const int g = p / (32 * GRU_KC / 4), rem = p - g * (32 * GRU_KC / 4);
+      const int j = rem / (GRU_KC / 4), k = (rem - j * (GRU_KC / 4)) * 4;
+      float* d = Bs[g] + k * GRU_LDB + j;
+      d[0] = reg[i].x; d[GRU_LDB] = reg[i].y; d[2 * GRU_LDB] = reg[i].z; d[3 * GRU_LDB] = reg[i].w;
+    }
+  }
+}
+
+// acc0 += A . W_g0^T, acc1 += A . W_g1^T (if G01), acc2 += A . W_g2^T ; A rows scaled by `scale`
+template <bool G01>
+__device__ __forceinline__ void gru_phase(const GruPhase& ph, const float* __restrict__ arow_ptr, bool a_ok, float scale, int hh, int li,
+                                          float (*Bs)[3][GRU_KC * GRU_LDB], f32x16& acc0, f32x16& acc1, f32x16& acc2) {
+  const int D = ph.D;
+  float4 breg[GRU_NVB], av[GRU_NQ], av_next[GRU_NQ];
+  auto fetch_a = [&](float4 (&dst)[GRU_NQ], int k0) {
+#pragma unroll
+    for (int q = 0; q < GRU_NQ; ++q) {
+      const bool ok = a_ok && (k0 + q * 8 + 4 * hh < D);
+      const float4 v = ld4(arow_ptr + (ok ? k0 + q * 8 : -4 * hh));
+      dst[q] = ok ? scale4(v, scale) : zero4();
+    }
+  };
+  __syncthreads();                          // previous phase done with both LDS buffers
+  gru_fetch_w(breg, ph, 0);
+  fetch_a(av, 0);
+  gru_store_w(breg, Bs[0]);
+  __syncthreads();
+  const int nchunks = (D + GRU_KC - 1) / GRU_KC;
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) {
+      gru_fetch_w(breg, ph, (c + 1) * GRU_KC);
+      fetch_a(av_next, (c + 1) * GRU_KC);
+    }
+    float (*bs)[GRU_KC * GRU_LDB] = Bs[c & 1];
+#pragma unroll
+    for (int q = 0; q < GRU_NQ; ++q) {
+      const float as[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int off = (q * 8 + 4 * hh + s) * GRU_LDB + li;
+        if (G01) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], bs[0][off], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], bs[1][off], acc1, 0, 0, 0);
+        }
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], bs[2][off], acc2, 0, 0, 0);
+      }
+    }
+    if (more) {
+      gru_store_w(breg, Bs[(c + 1) & 1]);
+#pragma unroll
+      for (int q = 0; q < GRU_NQ; ++q) av[q] = av_next[q];
+    }
+    __syncthreads();
+  }
+}
+
 template <int VARIANT, bool HOISTED>
 __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __restrict__ x, const float* __restrict__ gi,
                                                  const float* __restrict__ prev, const int32_t* __restrict__ prev_idx,
@@ -33,7 +117,7 @@ __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __re
                                                  const float* __restrict__ w_ih, const float* __restrict__ w_hh,
                                                  const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                  float* __restrict__ h_out, float* __restrict__ saved, size_t plane) {
-  __shared__ float Bs[3][GRU_KC * GRU_LDB];
+  __shared__ float Bs[2][3][GRU_KC * GRU_LDB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
   const int m0 = (blockIdx.x * 4 + wave) * 32;
@@ -50,77 +134,22 @@ __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __re
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; }
 
-  // ---- phase X: x . W_ih^T (torch: gates r,z,n; type-1: new gate only) ------------------------
-  if (!HOISTED) {
+  if (!HOISTED) {                       // phase X: x . W_ih^T (torch: gates r,z,n; type-1: new gate only)
+    GruPhase ph;
+    ph.W = w_ih; ph.D = D; ph.j0 = j0;
+    if (VARIANT == TEMP_GRU_TORCH) { ph.row_base[0] = 0; ph.row_base[1] = D; ph.row_base[2] = 2 * D; }
+    else { ph.row_base[0] = -1; ph.row_base[1] = -1; ph.row_base[2] = 0; }
     const float* xa = x + (size_t)(arow_ok ? arow : 0) * D + 4 * hh;
-    for (int k0 = 0; k0 < D; k0 += GRU_KC) {
-      const int kc = min(GRU_KC, D - k0);
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < 3 * GRU_KC * 32; idx += 256) {
-        const int g = idx / (GRU_KC * 32), rem = idx - g * (GRU_KC * 32);
-        const int j = rem / GRU_KC, k = rem - j * GRU_KC;
-        float v = 0.f;
-        if (k < kc && j0 + j < D) {
-          if (VARIANT == TEMP_GRU_TORCH) v = w_ih[(size_t)(g * D + j0 + j) * D + k0 + k];
-          else if (g == 2) v = w_ih[(size_t)(j0 + j) * D + k0 + k];
-        }
-        Bs[g][k * GRU_LDB + j] = v;
-      }
-      __syncthreads();
-      float4 av[GRU_KC / 8];
-#pragma unroll
-      for (int q = 0; q < GRU_KC / 8; ++q) {
-        const bool ok = arow_ok && (q * 8 + 4 * hh < kc);
-        const float4 v = ld4(xa + (ok ? k0 + q * 8 : -4 * hh));
-        av[q] = ok ? v : zero4();
-      }
-#pragma unroll
-      for (int q = 0; q < GRU_KC / 8; ++q) {
-        const float as[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int off = (q * 8 + 4 * hh + s) * GRU_LDB + li;
-          if (VARIANT == TEMP_GRU_TORCH) {
-            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[0][off], acc_r, 0, 0, 0);
-            acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[1][off], acc_z, 0, 0, 0);
-          }
-          acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[2][off], acc_in, 0, 0, 0);
-        }
-      }
-    }
+    if (VARIANT == TEMP_GRU_TORCH) gru_phase<true>(ph, xa, arow_ok, 1.f, hh, li, Bs, acc_r, acc_z, acc_in);
+    else gru_phase<false>(ph, xa, arow_ok, 1.f, hh, li, Bs, acc_r, acc_z, acc_in);
   }
-  // ---- phase H: hdec . W_hh^T -------------------------------------------------------------------
-  {
+  {                                     // phase H: hdec . W_hh^T
+    GruPhase ph;
+    ph.W = w_hh; ph.D = D; ph.j0 = j0;
+    ph.row_base[0] = 0; ph.row_base[1] = D; ph.row_base[2] = 2 * D;
     const bool h_ok = arow_ok && prow >= 0;
     const float* ha = prev + (size_t)(h_ok ? prow : 0) * D + 4 * hh;
-    for (int k0 = 0; k0 < D; k0 += GRU_KC) {
-      const int kc = min(GRU_KC, D - k0);
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < 3 * GRU_KC * 32; idx += 256) {
-        const int g = idx / (GRU_KC * 32), rem = idx - g * (GRU_KC * 32);
-        const int j = rem / GRU_KC, k = rem - j * GRU_KC;
-        Bs[g][k * GRU_LDB + j] = (k < kc && j0 + j < D) ? w_hh[(size_t)(g * D + j0 + j) * D + k0 + k] : 0.f;
-      }
-      __syncthreads();
-      float4 av[GRU_KC / 8];
-#pragma unroll
-      for (int q = 0; q < GRU_KC / 8; ++q) {
-        const bool ok = h_ok && (q * 8 + 4 * hh < kc);
-        const float4 v = ld4(ha + (ok ? k0 + q * 8 : -4 * hh));
-        av[q] = ok ? scale4(v, dec) : zero4();
-      }
-#pragma unroll
-      for (int q = 0; q < GRU_KC / 8; ++q) {
-        const float as[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int off = (q * 8 + 4 * hh + s) * GRU_LDB + li;
-          acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[0][off], acc_r, 0, 0, 0);
-          acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[1][off], acc_z, 0, 0, 0);
-          acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], Bs[2][off], acc_hn, 0, 0, 0);
-        }
-      }
-    }
+    gru_phase<true>(ph, ha, h_ok, dec, hh, li, Bs, acc_r, acc_z, acc_hn);
   }
   // ---- epilogue -----------------------------------------------------------------------------------
   const int col = j0 + li;
