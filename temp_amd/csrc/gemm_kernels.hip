@@ -21,10 +21,18 @@ namespace temp {
 // ---------------------------------------------------------------------------------------------
 struct EpiAddBiasAct {
   const float* addend; int ld_add; const int32_t* row_mask; const float* bias; int act; float* out; int ldo;
-  __device__ __forceinline__ void operator()(int row, int col, float acc) const {
-    float v = acc;
-    if (addend && (!row_mask || row_mask[row] > 0)) v += addend[(size_t)row * ld_add + col];
-    if (bias) v += bias[col];
+  // pre(): branch-free loads (row/col are clamped by the caller); fin(): arithmetic + store
+  __device__ __forceinline__ float pre(int row, int col) const {
+    float a = 0.f;
+    if (addend) {                                   // kernel-uniform
+      a = addend[(size_t)row * ld_add + col];
+      if (row_mask) a = (row_mask[row] > 0) ? a : 0.f;
+    }
+    if (bias) a += bias[col];
+    return a;
+  }
+  __device__ __forceinline__ void fin(int row, int col, float acc, float p) const {
+    float v = acc + p;
     if (act == TEMP_ACT_RELU) v = fmaxf(v, 0.f);
     out[(size_t)row * ldo + col] = v;
   }

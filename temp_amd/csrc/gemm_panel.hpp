@@ -130,15 +130,23 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
     }
     __syncthreads();
   }
+  // Epilogue in two passes per tile so that the 16 loads a lane needs (addend / mask / ...) are all
+  // in flight together instead of 16 dependent load->branch->store round trips.
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = n0 + t * 32 + li;
-    if (col < N) {
+    const bool col_ok = col < N;
+    float pre[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < M) epi(row, col, acc[t][r]);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const bool ok = col_ok && row < M;
+      pre[r] = epi.pre(ok ? row : 0, ok ? col : 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (col_ok && row < M) epi.fin(row, col, acc[t][r], pre[r]);
     }
   }
 }

@@ -163,20 +163,36 @@ __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __re
     }
     bhr = b_hh[col]; bhz = b_hh[D + col]; bhn = b_hh[2 * D + col];
   }
+  // pass 1: every load of the 16 result rows in flight together (clamped addresses, no branches)
+  float hd_[16], g0_[16], g1_[16], g2_[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;   // row inside the tile == the lane that loaded it
     const int prow_r = __shfl(prow, rl);
     const float dec_r = __shfl(dec, rl);
     const int row = m0 + rl;
+    const bool ok = row < n && col_ok;
+    const float pv = prev[(size_t)((ok && prow_r >= 0) ? prow_r : 0) * D + (ok ? col : 0)];
+    hd_[r] = (ok && prow_r >= 0) ? pv * dec_r : 0.f;
+    g0_[r] = 0.f; g1_[r] = 0.f; g2_[r] = 0.f;
+    if (HOISTED) {
+      const float* g = gi + (size_t)(ok ? row : 0) * G + (ok ? col : 0);
+      if (VARIANT == TEMP_GRU_TORCH) { g0_[r] = g[0]; g1_[r] = g[D]; g2_[r] = g[2 * D]; }
+      else g2_[r] = g[0];
+    }
+  }
+  // pass 2: gates, blend, stores
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const int row = m0 + rl;
     if (row < n && col_ok) {
       float xr = acc_r[r], xz = acc_z[r], xn = acc_in[r];
       if (HOISTED) {
-        const float* g = gi + (size_t)row * G;
-        if (VARIANT == TEMP_GRU_TORCH) { xr += g[col]; xz += g[D + col]; xn = g[2 * D + col]; }
-        else xn = g[col];
+        if (VARIANT == TEMP_GRU_TORCH) { xr += g0_[r]; xz += g1_[r]; }
+        xn = g2_[r];
       }
-      const float hd = (prow_r >= 0) ? prev[(size_t)prow_r * D + col] * dec_r : 0.f;
+      const float hd = hd_[r];
       const float rg = 1.f / (1.f + expf(-(xr + bir + bhr)));
       const float zg = 1.f / (1.f + expf(-(xz + biz + bhz)));
       const float hn = acc_hn[r] + bhn;
@@ -236,14 +252,13 @@ __global__ void __launch_bounds__(256) k_gru_bwd_gates(int n, int D, const float
 // d_prev = (dgh . W_hh + dh * z) * decay[row]; dh*z was left in `io` by the gates kernel
 struct EpiGruDprev {
   const float* decv; float* io; int D;
-  __device__ __forceinline__ void operator()(int row, int col, float acc) const {
-    const size_t o = (size_t)row * D + col;
-    io[o] = (acc + io[o]) * decv[row];
-  }
+  __device__ __forceinline__ float pre(int row, int col) const { return io[(size_t)row * D + col]; }
+  __device__ __forceinline__ void fin(int row, int col, float acc, float p) const { io[(size_t)row * D + col] = (acc + p) * decv[row]; }
 };
 struct EpiStore {
   float* out; int ldo;
-  __device__ __forceinline__ void operator()(int row, int col, float acc) const { out[(size_t)row * ldo + col] = acc; }
+  __device__ __forceinline__ float pre(int, int) const { return 0.f; }
+  __device__ __forceinline__ void fin(int row, int col, float acc, float) const { out[(size_t)row * ldo + col] = acc; }
 };
 
 // Learnable decay exp(-max(0, w*dt+b)): d/dw = -sum_rows dt*ind*s_row, d/db = -sum_rows ind*s_row with
