@@ -106,42 +106,53 @@ def traced_steps(step_fn, n_steps, lib):
     return {k: dict(launches_per_step=v[0] / n_steps, ms_per_step=v[1] / n_steps, avg_ms=v[1] / v[0]) for k, v in agg.items()}
 
 
-def cpu_baseline(model, w, device_targets):
-    """The oracle (port of the reference's op sequence, dense history kept) on ONE window, host cores."""
+def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
+    """The oracle (port of the reference's op sequence, dense re-zeroed history kept) on the host
+    cores: one window (bsz=1) at a time, fwd+bwd, repeated over the rank-0 targets until at least
+    `min_seconds` of CPU work has been timed."""
     from oracle import temp_oracle as O
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))     # more threads only add OpenMP overhead on these small ops
+    nthreads = min(os.cpu_count() or 1, 16)        # more threads only add OpenMP overhead on these small ops
+    torch.set_num_threads(nthreads)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     bi = w["module"].startswith("Bi")
     cfg = dict(module=w["module"], n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
     om = O.model_from_state_dict(sd, cfg)
     gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
     times = sorted(gd.keys())
-    tl = [device_targets[0]]
     L = w["L"]
-    for v in O.leaf_tensors(om).values():
+    leaves = list(O.leaf_tensors(om).values())
+    for v in leaves:
         v.requires_grad_(True)
 
-    def run():
+    def run(t):
+        for v in leaves:
+            v.grad = None
         if bi:
-            tf, tb = O.get_batch_graph_list_bi(tl, L, times)
+            tf, tb = O.get_batch_graph_list_bi([t], L, times)
             Hf = O.bi_pre_forward(om, cfg, gd, tf, L, True)
             Hb = O.bi_pre_forward(om, cfg, gd, tb, L, False)
-            out = O.bi_target_embeds(om, cfg, Hf, Hb, [gd[tl[0]]], tf[-1], L)
-            visits = [t for col in tf[:-1] + tb[:-1] for t in col if t is not None] + tl
+            out = O.bi_target_embeds(om, cfg, Hf, Hb, [gd[t]], tf[-1], L)
+            visits = [x for col in tf[:-1] + tb[:-1] for x in col if x is not None] + [t]
         else:
-            tf = O.get_batch_graph_list(tl, L, times)
+            tf = O.get_batch_graph_list([t], L, times)
             H = O.uni_pre_forward(om, cfg, gd, tf, L)
-            out = O.uni_target_embeds(om, cfg, H, [gd[tl[0]]], tf[-1], L)
-            visits = [t for col in tf for t in col if t is not None]
+            out = O.uni_target_embeds(om, cfg, H, [gd[t]], tf[-1], L)
+            visits = [x for col in tf for x in col if x is not None]
         sum(o.sum() for o in out).backward()
-        return sum(gd[t].num_edges for t in visits)
+        return sum(gd[x].num_edges for x in visits), len(visits)
 
+    run(device_targets[0])                          # warm-up (allocator, thread pool)
+    edges = visits = nwin = 0
     t0 = time.perf_counter()
-    edges = run()
-    dt = time.perf_counter() - t0
-    return dict(value=edges / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
-                sample="1 window (bsz=1) of %s: %d snapshot visits, %d edge visits, full target graph, fwd+bwd, %.1f s"
-                       % (w["name"], len(tl) * (2 * L - 1 if bi else L), edges, dt))
+    while True:
+        e, v = run(device_targets[nwin % len(device_targets)])
+        edges, visits, nwin = edges + e, visits + v, nwin + 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or nwin >= max_windows:
+            break
+    return dict(value=edges / dt, unit="edges/s", cores=nthreads, kind="port",
+                sample="%d windows (bsz=1 each) of %s: %d snapshot visits, %d edge visits, full target graphs, fwd+bwd, %.1f s"
+                       % (nwin, w["name"], visits, edges, dt))
 
 
 def main():
@@ -151,6 +162,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="S-gdelt")
     ap.add_argument("--trace-steps", type=int, default=3)
+    ap.add_argument("--shard", choices=("windows", "snapshots"), default="windows",
+                    help="N>1: 'windows' = each rank encodes its own windows (+ gradient all-reduce); 'snapshots' = snapshot "
+                         "visits of a global batch of bsz*N windows sharded across ranks with an all-gather of per-snapshot "
+                         "node states before the recurrent chain (north_star variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel trace table to stderr")
     a = ap.parse_args()
@@ -178,28 +193,33 @@ def main():
     w = synthetic.workload(a.workload, seed=0)
     model = build_model(w, device)
     bi = w["module"].startswith("Bi")
+    from temp_amd.dist import SnapshotShardedEncoder, allreduce_gradients
+    sharded = dist is not None and a.shard == "snapshots"
     targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rank)
-    model.sample_rng = np.random.default_rng(2 + rank)
+    params = [p for p in model.parameters()]
     t0 = time.perf_counter()
-    wb = model.prepare(targets, w["L"], train=True)
+    if sharded:
+        # one global batch of bsz*world windows, identical on every rank (same seed => same target subsample)
+        all_targets = [t for r in range(world) for t in synthetic.default_targets(w["num_times"], w["L"], w["bsz"], r)]
+        model.sample_rng = np.random.default_rng(2)
+        enc = SnapshotShardedEncoder(model)
+        wb = enc.prepare(all_targets, w["L"], train=True)
+        wb.n_edge_visits = wb.n_edge_visits_global / world       # per-rank share of the global step
+        wb.n_node_visits = 0
+        run = lambda: enc.run(wb)
+    else:
+        model.sample_rng = np.random.default_rng(2 + rank)
+        wb = model.prepare(targets, w["L"], train=True)
+        run = lambda: model.run(wb)[0]
     torch.cuda.synchronize()
     prepare_s = time.perf_counter() - t0
-    params = [p for p in model.parameters()]
 
     def step():
         for p in params:
             p.grad = None
-        out, _ = model.run(wb)
-        out.sum().backward()
+        run().sum().backward()
         if dist is not None:
-            grads = [p.grad for p in params if p.grad is not None]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            dist.all_reduce(flat)
-            flat.div_(world)
-            off = 0
-            for g in grads:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+            allreduce_gradients(params, world, average=not sharded)
 
     for _ in range(a.warmup):
         step()
@@ -225,7 +245,7 @@ def main():
 
     roof = None
     cpu = None
-    if rank == 0:
+    if rank == 0 and a.trace_steps > 0 and not sharded:
         tr = traced_steps(step, a.trace_steps, lib)
         costs = algorithmic_costs(wb, w["D"], bi, w["D"] // w["B"])
         total_ms = sum(v["ms_per_step"] for v in tr.values())
@@ -256,8 +276,8 @@ def main():
         bytes_per_edge = 2 * (12 * D + 24) + n_over_e * (2 * (20 * D + 16) + 32 * D + 4)
         roof["step_bytes_per_edge_visit"] = bytes_per_edge
         roof["step_frac_of_hbm"] = (wb.n_edge_visits * a.steps / elapsed if world == 1 else value / world) * bytes_per_edge / (HBM_PEAK_GBS * 1e9)
-        if not a.no_cpu_baseline:
-            cpu = cpu_baseline(model, w, targets)
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(model, w, targets)
 
     if rank == 0:
         out = dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=%d" % w["L"], value=value, unit="edges/s", n_gpus=world,
@@ -267,7 +287,8 @@ def main():
                                windows_per_gpu=w["bsz"], embed=w["D"], n_bases=w["B"], entities=w["num_ents"],
                                relations=w["num_rels"], edges_per_snapshot=w["edges_per_snap"],
                                edge_visits_per_step_per_gpu=wb.n_edge_visits, node_visits_per_step_per_gpu=wb.n_node_visits,
-                               parallelism="dp%d(windows)+grad-allreduce" % world, host_prepare_s=prepare_s),
+                               parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
+                               else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out))
     if dist is not None:

@@ -1,0 +1,235 @@
+"""Multi-GPU execution of the window encoder: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Two ways the path shards:
+
+1. windows -> ranks (the reference's DDP axis, models/TKG_Module.py:166-168): every rank encodes its
+   own windows, no data-path collective; the only exchange is ONE bucketed all-reduce of the
+   parameter gradients after backward (`allreduce_gradients`).
+
+2. snapshot visits -> ranks (BASELINE north_star; needs --rec-only-last-layer): all ranks share the
+   same batch of windows; the (position, window) snapshot visits are cut into `world` contiguous
+   ranges balanced by edge count; each rank runs the two RGCN layers on ITS visits only, then ONE
+   all-gather of the per-snapshot node states (padded to the largest shard) gives every rank the GRU
+   inputs of all visits; the recurrent chain itself is sharded by window (rank = window index mod
+   world).  Backward mirrors it: the adjoint of the all-gather is a reduce-scatter that returns to
+   each rank the summed gradient of its own visits' node states; parameter gradients are partial
+   sums on every rank and are all-reduced like in (1).  (`SnapshotShardedEncoder`)
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import functional as TF
+from .gru_cell import GRUCell
+from .gru_chain import GruInstance, GruProgram, gru_chain
+from .window import ChainPlan, Step, concat_steps, window_times
+
+
+def allreduce_gradients(params, world=None, average=True, group=None):
+    """One flat bucket for all parameter gradients (about 2.5 M floats at D=200 on ICEWS14)."""
+    if world is None:
+        world = dist.get_world_size(group)
+    if world == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    if average:
+        flat.div_(world)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """forward : all-gather of equally padded row blocks -> rows re-ordered to the canonical layout
+    backward: scatter to the padded layout, reduce-scatter (sum) -> this rank's rows."""
+
+    @staticmethod
+    def forward(ctx, local, n_max, canon_index, world, rank, group):
+        d = local.shape[1]
+        pad = local.new_zeros(n_max, d)
+        pad[:local.shape[0]] = local
+        gathered = local.new_empty(world * n_max, d)
+        dist.all_gather_into_tensor(gathered, pad, group=group)
+        ctx.save_for_backward(canon_index)
+        ctx.meta = (local.shape[0], n_max, world, rank, group)
+        return gathered.index_select(0, canon_index)
+
+    @staticmethod
+    def backward(ctx, d_all):
+        (canon_index,) = ctx.saved_tensors
+        n_local, n_max, world, rank, group = ctx.meta
+        d = d_all.shape[1]
+        padded = d_all.new_zeros(world * n_max, d)
+        padded.index_copy_(0, canon_index, d_all.contiguous())
+        mine = d_all.new_empty(n_max, d)
+        try:
+            dist.reduce_scatter_tensor(mine, padded, group=group)
+        except (RuntimeError, NotImplementedError):          # gloo has no reduce_scatter: all-reduce + slice
+            dist.all_reduce(padded, group=group)
+            mine = padded[rank * n_max:(rank + 1) * n_max]
+        return mine[:n_local].contiguous(), None, None, None, None, None
+
+
+def split_visits_by_edges(edge_counts, world):
+    """Cut the visit list into `world` contiguous ranges with about equal edge totals."""
+    csum = np.cumsum(np.asarray(edge_counts, dtype=np.float64))
+    total = csum[-1] if len(csum) else 0.0
+    bounds = [0]
+    for r in range(1, world):
+        bounds.append(int(np.searchsorted(csum, total * r / world, side="left")))
+    bounds.append(len(edge_counts))
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+class SnapshotShardedEncoder:
+    """Snapshot-visit sharding of a (Bi)DynamicRGCN batched encoder pass across ranks."""
+
+    def __init__(self, model, group=None):
+        self.model = model
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        assert model._can_batch() and model._can_chain(), "snapshot sharding needs the batched GRU + rec-only-last-layer path"
+
+    # ---------------------------------------------------------------------------------------------
+    def prepare(self, t_list, seq_len, train=True, target_edge_ids=None):
+        m, dev = self.model, self.model._device()
+        W, R = self.world, self.rank
+        bi = hasattr(m.ent_encoder.layer_2, "forward_rnn")
+        times = m.total_time
+        rows_f = window_times(t_list, seq_len, times)
+        bsz = len(rows_f)
+        graphs = [m.graph_dict_train[r[-1]] for r in rows_f]
+        tgt = m.sample_target_graphs(graphs, 0.5, target_edge_ids) if train else graphs
+        # ---- global visit list (every rank builds the same one: it is pure host integer work) ------
+        plan_f = ChainPlan(rows_f, m.graph_dict_train, m.num_ents, seq_len)
+        plans = [plan_f]
+        if bi:
+            rows_b = window_times(t_list, seq_len, times, ascending=True)
+            plans.append(ChainPlan(rows_b, m.graph_dict_train, m.num_ents, seq_len))
+        target = Step(seq_len - 1, list(range(bsz)), tgt, [r[-1] for r in rows_f])
+        steps = [st for p in plans for st in p.steps] + [target]
+        visits = []                                   # (step index, j in step, graph)
+        for si, st in enumerate(steps):
+            for j, g in enumerate(st.graphs):
+                visits.append((si, j, g))
+        bounds = split_visits_by_edges([g.number_of_edges() for _, _, g in visits], W)
+        sizes = np.array([g.n for _, _, g in visits], dtype=np.int64)
+        canon_off = np.concatenate([[0], np.cumsum(sizes)])
+        shard_rows = [int(sizes[bounds[r]:bounds[r + 1]].sum()) for r in range(W)]
+        n_max = max(max(shard_rows), 1)
+        canon_index = np.empty(int(canon_off[-1]), dtype=np.int64)      # canonical row -> row in the padded gather
+        for r in range(W):
+            lo, hi = bounds[r], bounds[r + 1]
+            n_r = int(canon_off[hi] - canon_off[lo])
+            canon_index[canon_off[lo]:canon_off[hi]] = r * n_max + np.arange(n_r)
+        # ---- this rank's RGCN shard ------------------------------------------------------------------
+        from . import snapshot as S
+        mine = [g for _, _, g in visits[bounds[R]:bounds[R + 1]]]
+        g_local = S.batch(mine)
+        g_local.device_graph(dev, 2 * m.num_rels)
+        # ---- this rank's windows of the recurrence ---------------------------------------------------
+        def local_windows(nwin):
+            return [b for b in range(nwin) if b % W == R]
+        # canonical first row of (step si, window slot j)
+        first_row = {}
+        k = 0
+        for si, st in enumerate(steps):
+            for j in range(len(st.graphs)):
+                first_row[(si, j)] = int(canon_off[k])
+                k += 1
+        sb = type("ShardBatch", (), {})()
+        sb.g_local, sb.ids_local = g_local, torch.from_numpy(g_local.gids.astype(np.int32)).to(dev)
+        sb.n_max, sb.canon_index = n_max, torch.from_numpy(canon_index).to(dev)
+        sb.n_edge_visits_local = int(sum(g.number_of_edges() for g in mine))
+        sb.n_edge_visits_global = int(sum(g.number_of_edges() for _, _, g in visits))
+        # local chain program: for every plan, the sub-chain over this rank's windows
+        inst, x_rows, out_sizes = [], [], []
+        x_off = 0
+        last = []
+        step_base = 0
+        for pi, plan in enumerate(plans):
+            nwin = plan.bsz
+            # windows of the backward plan are in ascending-target order; window b of the forward order is
+            # index bsz-1-b there (torch.flip of the reference, models/BiDynamicRGCN.py:97-99)
+            fwd_of = (lambda j: j) if pi == 0 else (lambda j: nwin - 1 - j)
+            keep = [j for j in range(nwin) if fwd_of(j) % W == R]
+            sub_rows = [plan.rows[j] for j in keep]
+            sub = ChainPlan(sub_rows, m.graph_dict_train, m.num_ents, seq_len) if keep else None
+            prev_inst = -1
+            if sub is not None:
+                for st in sub.steps:
+                    gi_step = step_base + [s.p for s in plan.steps].index(st.p)
+                    rows_idx = []
+                    for jj, wj in enumerate(st.windows):
+                        j_global = keep[wj]
+                        gslot = steps[gi_step].windows.index(j_global)
+                        r0 = first_row[(gi_step, gslot)]
+                        rows_idx.append(np.arange(r0, r0 + st.sizes[jj]))
+                    rows_idx = np.concatenate(rows_idx) if rows_idx else np.zeros(0, np.int64)
+                    inst.append(GruInstance(st.n_rows, x_off, pi, prev_inst, st.prev_idx, st.dt))
+                    prev_inst = len(inst) - 1
+                    x_rows.append(rows_idx)
+                    x_off += st.n_rows
+            last.append((prev_inst, sub, keep, fwd_of))
+            step_base += len(plan.steps)
+        # centre / target instances over this rank's windows (forward order)
+        tw = local_windows(bsz)
+        t_rows, t_sizes = [], []
+        ti = len(steps) - 1
+        for b in tw:
+            r0 = first_row[(ti, b)]
+            t_rows.append(np.arange(r0, r0 + tgt[b].n))
+            t_sizes.append(tgt[b].n)
+        t_rows = np.concatenate(t_rows) if t_rows else np.zeros(0, np.int64)
+        n_t = int(sum(t_sizes))
+        out_inst = []
+        for pi, (prev_inst, sub, keep, fwd_of) in enumerate(last):
+            pidx, dts = [], []
+            for b in tw:
+                if sub is not None:
+                    jl = keep.index(b if pi == 0 else bsz - 1 - b)
+                    a, d = sub.final_prev(jl, tgt[b].gids, seq_len - 1)
+                else:
+                    a, d = np.full(tgt[b].n, -1, np.int64), np.full(tgt[b].n, seq_len - 1, np.float32)
+                pidx.append(a)
+                dts.append(d)
+            pidx = np.concatenate(pidx) if pidx else np.zeros(0, np.int64)
+            dts = np.concatenate(dts) if dts else np.zeros(0, np.float32)
+            inst.append(GruInstance(n_t, x_off, pi, prev_inst, pidx, dts))
+            out_inst.append(len(inst) - 1)
+        x_rows.append(t_rows)
+        sb.program = GruProgram(inst)
+        sb.program.upload(dev)
+        sb.x_index = torch.from_numpy(np.concatenate(x_rows) if x_rows else np.zeros(0, np.int64)).to(dev)
+        sb.out_inst, sb.target_sizes, sb.target_windows = out_inst, t_sizes, tw
+        return sb
+
+    # ---------------------------------------------------------------------------------------------
+    def run(self, sb):
+        """-> (target-position embeddings of THIS rank's windows, concatenated, forward order)."""
+        m = self.model
+        enc = m.ent_encoder
+        h0 = TF.gather_rows(m.ent_embeds, sb.ids_local)
+        y1 = enc.layer_1.conv(sb.g_local, h0)
+        y2 = enc.layer_2.conv(sb.g_local, y1)
+        y2_all = _AllGatherRows.apply(y2, sb.n_max, sb.canon_index, self.world, self.rank, self.group)
+        x = y2_all.index_select(0, sb.x_index)
+        l2 = enc.layer_2
+        rnns = [l2.forward_rnn, l2.backward_rnn] if hasattr(l2, "forward_rnn") else [l2.rnn]
+        H = gru_chain(x, sb.program, rnns, l2.inv_temperature, isinstance(rnns[0], GRUCell))
+        prog = sb.program
+        out = None
+        for i in sb.out_inst:
+            it = prog.inst[i]
+            piece = H[it.h0:it.h0 + it.n]
+            out = piece if out is None else out + piece
+        return out

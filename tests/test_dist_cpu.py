@@ -1,0 +1,105 @@
+"""world_size-2 gloo tests (CPU, test-only kernel backend) of both multi-GPU decompositions:
+windows -> ranks with a gradient all-reduce, and snapshot visits -> ranks with the all-gather of
+per-snapshot node states before the recurrent chain.  Both must reproduce the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.golden_util import load
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(name, batched=True):
+    from temp_amd import backend as TB
+    from tests.cpu_backend import CpuTestBackend
+    from tests.window_cases import build_window_model, window_inputs
+    TB.set_backend(CpuTestBackend())
+    z = load(name)
+    m = build_window_model(z, torch.device("cpu"), batched)
+    edge_ids, _ = window_inputs(z)
+    t_list = sorted([int(t) for t in z["t_list"]], reverse=True)
+    return m, z, edge_ids, t_list
+
+
+def _reference(name):
+    m, z, edge_ids, t_list = _build(name)
+    per_graph, *_ = m.encode(torch.tensor(t_list), int(z["L"]), True, edge_ids)
+    loss = sum((e * (i + 1)).sum() for i, e in enumerate(per_graph))
+    loss.backward()
+    return [e.detach() for e in per_graph], {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+
+def _worker(rank, world, port, name, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from temp_amd.dist import SnapshotShardedEncoder, allreduce_gradients
+        m, z, edge_ids, t_list = _build(name)
+        L = int(z["L"])
+        if mode == "snapshots":
+            enc = SnapshotShardedEncoder(m)
+            sb = enc.prepare(torch.tensor(t_list), L, True, edge_ids)
+            out = enc.run(sb)
+            pieces = list(out.split(sb.target_sizes))
+            wins = sb.target_windows
+        else:                                   # windows -> ranks: each rank encodes its own windows
+            wins = [b for b in range(len(t_list)) if b % world == rank]
+            sub_t = [t_list[b] for b in wins]
+            pieces, *_ = m.encode(torch.tensor(sub_t), L, True, [edge_ids[b] for b in wins])
+        loss = sum((e * (b + 1)).sum() for b, e in zip(wins, pieces))
+        if isinstance(loss, torch.Tensor):
+            loss.backward()
+        for p in m.parameters():                # ranks without work still join the collective
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        allreduce_gradients(list(m.parameters()), world, average=False)
+        q.put((rank, wins, [e.detach().numpy() for e in pieces], {k: v.grad.numpy() for k, v in m.named_parameters()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,name", [("windows", "G10_bi_grrgcn_rol"), ("snapshots", "G10_bi_grrgcn_rol"),
+                                       ("snapshots", "G10_uni_grrgcn_rol"), ("windows", "G10_uni_grrgcn")])
+def test_two_ranks_match_single_process(mode, name):
+    ref_out, ref_grads = _reference(name)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = set()
+    for rank, wins, pieces, grads in results:
+        for b, e in zip(wins, pieces):
+            np.testing.assert_allclose(e, ref_out[b].numpy(), rtol=2e-5, atol=2e-6)
+            seen.add(b)
+        for k, g in grads.items():
+            if k in ref_grads:
+                np.testing.assert_allclose(g, ref_grads[k].numpy(), rtol=2e-4, atol=3e-6, err_msg=k)
+    assert seen == set(range(len(ref_out)))
+
+
+def test_split_visits_by_edges():
+    from temp_amd.dist import split_visits_by_edges
+    b = split_visits_by_edges([10, 10, 10, 10, 40, 10, 10], 4)
+    assert b[0] == 0 and b[-1] == 7 and all(x <= y for x, y in zip(b, b[1:]))
+    assert split_visits_by_edges([], 3) == [0, 0, 0, 0]
+    assert split_visits_by_edges([5], 2)[-1] == 1
