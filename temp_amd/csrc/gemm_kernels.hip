@@ -21,20 +21,26 @@ namespace temp {
 // ---------------------------------------------------------------------------------------------
 struct EpiAddBiasAct {
   const float* addend; int ld_add; const int32_t* row_mask; const float* bias; int act; float* out; int ldo;
-  // pre(): branch-free loads (row/col are clamped by the caller); fin(): arithmetic + store
-  __device__ __forceinline__ float pre(int row, int col) const {
-    float a = 0.f;
+  struct RowCtx { bool add; };
+  __device__ __forceinline__ RowCtx row_ctx(int row) const {
+    RowCtx c;
+    c.add = addend && (!row_mask || row_mask[row] > 0);
+    return c;
+  }
+  // pre4(): branch-free float4 loads (row/col clamped by the caller); fin4(): arithmetic + float4 store
+  __device__ __forceinline__ float4 pre4(const RowCtx& c, int row, int col) const {
+    float4 a = zero4();
     if (addend) {                                   // kernel-uniform
-      a = addend[(size_t)row * ld_add + col];
-      if (row_mask) a = (row_mask[row] > 0) ? a : 0.f;
+      const float4 v = ld4(addend + (size_t)row * ld_add + col);
+      a = c.add ? v : zero4();
     }
-    if (bias) a += bias[col];
+    if (bias) a = add4(a, ld4(bias + col));
     return a;
   }
-  __device__ __forceinline__ void fin(int row, int col, float acc, float p) const {
-    float v = acc + p;
-    if (act == TEMP_ACT_RELU) v = fmaxf(v, 0.f);
-    out[(size_t)row * ldo + col] = v;
+  __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4 p) const {
+    float4 v = add4(acc, p);
+    if (act == TEMP_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    st4(out + (size_t)row * ldo + col, v);
   }
 };
 

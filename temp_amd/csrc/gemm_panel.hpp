@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
       for (int s = 0; s < 4; ++s) {
         const float* brow = bs + (q * 8 + 4 * hh + s) * LDS_B + li;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], brow[t * 32], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(brow[t * 32], as[s], acc[t], 0, 0, 0);   // operands swapped: C^T tile
       }
     }
     if (more) {
@@ -130,23 +130,27 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
     }
     __syncthreads();
   }
-  // Epilogue in two passes per tile so that the 16 loads a lane needs (addend / mask / ...) are all
-  // in flight together instead of 16 dependent load->branch->store round trips.
+  // The MFMA operands are swapped (weights as the A operand, activations as B), so the accumulator
+  // tile is C^T: lane (li, hh) holds ONE output row (m0 + li) and, in registers 4q..4q+3, the four
+  // consecutive columns n0 + t*32 + 8q + 4hh .. +3  ->  float4 loads/stores along the row, one row
+  // mask / row scale per lane.  Two passes (all loads, then all stores).
+  const int row = m0 + li;
+  const bool row_ok = row < M;
+  const typename Epi::RowCtx rc = epi.row_ctx(row_ok ? row : 0);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int col = n0 + t * 32 + li;
-    const bool col_ok = col < N;
-    float pre[16];
+    float4 pre[4];
+    bool ok[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const bool ok = col_ok && row < M;
-      pre[r] = epi.pre(ok ? row : 0, ok ? col : 0);
+    for (int q = 0; q < 4; ++q) {
+      const int col = n0 + t * 32 + 8 * q + 4 * hh;
+      ok[q] = row_ok && col < N;
+      pre[q] = epi.pre4(rc, ok[q] ? row : 0, ok[q] ? col : 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (col_ok && row < M) epi.fin(row, col, acc[t][r], pre[r]);
+    for (int q = 0; q < 4; ++q) {
+      const int col = n0 + t * 32 + 8 * q + 4 * hh;
+      if (ok[q]) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), pre[q]);
     }
   }
 }

@@ -95,10 +95,10 @@ __device__ __forceinline__ void gru_phase(const GruPhase& ph, const float* __res
       for (int s = 0; s < 4; ++s) {
         const int off = (q * 8 + 4 * hh + s) * GRU_LDB + li;
         if (G01) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], bs[0][off], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], bs[1][off], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[0][off], as[s], acc0, 0, 0, 0);      // swapped operands: C^T tile,
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[1][off], as[s], acc1, 0, 0, 0);      // one output row per lane
         }
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], bs[2][off], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[2][off], as[s], acc2, 0, 0, 0);
       }
     }
     if (more) {
@@ -151,61 +151,64 @@ __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __re
     const float* ha = prev + (size_t)(h_ok ? prow : 0) * D + 4 * hh;
     gru_phase<true>(ph, ha, h_ok, dec, hh, li, Bs, acc_r, acc_z, acc_hn);
   }
-  // ---- epilogue -----------------------------------------------------------------------------------
-  const int col = j0 + li;
-  const bool col_ok = col < D;
+  // ---- epilogue: lane (li, hh) owns row m0+li (the row whose A fragment it loaded: prow/dec are its
+  // own) and, per q, the 4 consecutive columns j0 + 8q + 4hh .. +3 -> float4 traffic only -----------
   const int G = (VARIANT == TEMP_GRU_TORCH) ? 3 * D : D;
-  float bir = 0.f, biz = 0.f, bin = 0.f, bhr = 0.f, bhz = 0.f, bhn = 0.f;
-  if (col_ok) {
-    if (!HOISTED) {                                     // hoisted gi already carries b_ih
-      if (VARIANT == TEMP_GRU_TORCH) { bir = b_ih[col]; biz = b_ih[D + col]; bin = b_ih[2 * D + col]; }
-      else bin = b_ih[col];
-    }
-    bhr = b_hh[col]; bhz = b_hh[D + col]; bhn = b_hh[2 * D + col];
-  }
-  // pass 1: every load of the 16 result rows in flight together (clamped addresses, no branches)
-  float hd_[16], g0_[16], g1_[16], g2_[16];
+  const int row = arow;
+  float4 hd4[4], g0[4], g1[4], g2[4];
+  bool ok[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;   // row inside the tile == the lane that loaded it
-    const int prow_r = __shfl(prow, rl);
-    const float dec_r = __shfl(dec, rl);
-    const int row = m0 + rl;
-    const bool ok = row < n && col_ok;
-    const float pv = prev[(size_t)((ok && prow_r >= 0) ? prow_r : 0) * D + (ok ? col : 0)];
-    hd_[r] = (ok && prow_r >= 0) ? pv * dec_r : 0.f;
-    g0_[r] = 0.f; g1_[r] = 0.f; g2_[r] = 0.f;
+  for (int q = 0; q < 4; ++q) {                          // pass 1: all loads in flight
+    const int col = j0 + 8 * q + 4 * hh;
+    ok[q] = arow_ok && col < D;
+    const bool hp = ok[q] && prow >= 0;
+    const float4 pv = ld4(prev + (size_t)(hp ? prow : 0) * D + (hp ? col : 0));
+    hd4[q] = hp ? scale4(pv, dec) : zero4();
+    g0[q] = zero4(); g1[q] = zero4(); g2[q] = zero4();
     if (HOISTED) {
-      const float* g = gi + (size_t)(ok ? row : 0) * G + (ok ? col : 0);
-      if (VARIANT == TEMP_GRU_TORCH) { g0_[r] = g[0]; g1_[r] = g[D]; g2_[r] = g[2 * D]; }
-      else g2_[r] = g[0];
+      const float* g = gi + (size_t)(ok[q] ? row : 0) * G + (ok[q] ? col : 0);
+      if (VARIANT == TEMP_GRU_TORCH) { g0[q] = ld4(g); g1[q] = ld4(g + D); g2[q] = ld4(g + 2 * D); }
+      else g2[q] = ld4(g);
     }
   }
-  // pass 2: gates, blend, stores
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
-    const int row = m0 + rl;
-    if (row < n && col_ok) {
+  for (int q = 0; q < 4; ++q) {                          // pass 2: gates, blend, float4 stores
+    if (!ok[q]) continue;
+    const int col = j0 + 8 * q + 4 * hh;
+    float4 bir = zero4(), biz = zero4(), bin = zero4();
+    if (!HOISTED) {                                      // hoisted gi already carries b_ih
+      if (VARIANT == TEMP_GRU_TORCH) { bir = ld4(b_ih + col); biz = ld4(b_ih + D + col); bin = ld4(b_ih + 2 * D + col); }
+      else bin = ld4(b_ih + col);
+    }
+    const float4 bhr = ld4(b_hh + col), bhz = ld4(b_hh + D + col), bhn = ld4(b_hh + 2 * D + col);
+    float o_h[4], o_r[4], o_z[4], o_n[4], o_hn[4];
+    const float hdv[4] = {hd4[q].x, hd4[q].y, hd4[q].z, hd4[q].w};
+    const float g0v[4] = {g0[q].x, g0[q].y, g0[q].z, g0[q].w}, g1v[4] = {g1[q].x, g1[q].y, g1[q].z, g1[q].w};
+    const float g2v[4] = {g2[q].x, g2[q].y, g2[q].z, g2[q].w};
+    const float birv[4] = {bir.x, bir.y, bir.z, bir.w}, bizv[4] = {biz.x, biz.y, biz.z, biz.w}, binv[4] = {bin.x, bin.y, bin.z, bin.w};
+    const float bhrv[4] = {bhr.x, bhr.y, bhr.z, bhr.w}, bhzv[4] = {bhz.x, bhz.y, bhz.z, bhz.w}, bhnv[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
       float xr = acc_r[r], xz = acc_z[r], xn = acc_in[r];
       if (HOISTED) {
-        if (VARIANT == TEMP_GRU_TORCH) { xr += g0_[r]; xz += g1_[r]; }
-        xn = g2_[r];
+        if (VARIANT == TEMP_GRU_TORCH) { xr += g0v[e]; xz += g1v[e]; }
+        xn = g2v[e];
       }
-      const float hd = hd_[r];
-      const float rg = 1.f / (1.f + expf(-(xr + bir + bhr)));
-      const float zg = 1.f / (1.f + expf(-(xz + biz + bhz)));
-      const float hn = acc_hn[r] + bhn;
-      const float ng = tanhf(xn + bin + rg * hn);
-      const float hy = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg) * ng + zg * hd) : (ng + zg * (hd - ng));
-      const size_t o = (size_t)row * D + col;
-      h_out[o] = hy;
-      saved[o] = rg;
-      saved[plane + o] = zg;
-      saved[2 * plane + o] = ng;
-      saved[3 * plane + o] = hn;
-      saved[4 * plane + o] = hd;
+      const float rg = 1.f / (1.f + expf(-(xr + birv[e] + bhrv[e])));
+      const float zg = 1.f / (1.f + expf(-(xz + bizv[e] + bhzv[e])));
+      const float hn = acc_hn[r] + bhnv[e];
+      const float ng = tanhf(xn + binv[e] + rg * hn);
+      o_h[e] = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg) * ng + zg * hdv[e]) : (ng + zg * (hdv[e] - ng));
+      o_r[e] = rg; o_z[e] = zg; o_n[e] = ng; o_hn[e] = hn;
     }
+    const size_t o = (size_t)row * D + col;
+    st4(h_out + o, make_float4(o_h[0], o_h[1], o_h[2], o_h[3]));
+    st4(saved + o, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
+    st4(saved + plane + o, make_float4(o_z[0], o_z[1], o_z[2], o_z[3]));
+    st4(saved + 2 * plane + o, make_float4(o_n[0], o_n[1], o_n[2], o_n[3]));
+    st4(saved + 3 * plane + o, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
+    st4(saved + 4 * plane + o, hd4[q]);
   }
 }
 
@@ -252,13 +255,19 @@ __global__ void __launch_bounds__(256) k_gru_bwd_gates(int n, int D, const float
 // d_prev = (dgh . W_hh + dh * z) * decay[row]; dh*z was left in `io` by the gates kernel
 struct EpiGruDprev {
   const float* decv; float* io; int D;
-  __device__ __forceinline__ float pre(int row, int col) const { return io[(size_t)row * D + col]; }
-  __device__ __forceinline__ void fin(int row, int col, float acc, float p) const { io[(size_t)row * D + col] = (acc + p) * decv[row]; }
+  struct RowCtx { float dec; };
+  __device__ __forceinline__ RowCtx row_ctx(int row) const { RowCtx c; c.dec = decv[row]; return c; }
+  __device__ __forceinline__ float4 pre4(const RowCtx&, int row, int col) const { return ld4(io + (size_t)row * D + col); }
+  __device__ __forceinline__ void fin4(const RowCtx& c, int row, int col, float4 acc, float4 p) const {
+    st4(io + (size_t)row * D + col, scale4(add4(acc, p), c.dec));
+  }
 };
 struct EpiStore {
   float* out; int ldo;
-  __device__ __forceinline__ float pre(int, int) const { return 0.f; }
-  __device__ __forceinline__ void fin(int row, int col, float acc, float) const { out[(size_t)row * ldo + col] = acc; }
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
+  __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
+  __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const { st4(out + (size_t)row * ldo + col, acc); }
 };
 
 // Learnable decay exp(-max(0, w*dt+b)): d/dw = -sum_rows dt*ind*s_row, d/db = -sum_rows ind*s_row with
