@@ -205,6 +205,19 @@ int temp_gru_cell_bwd(int n, int d, int variant, const float* saved, size_t save
                       const float* dh_up /*nullable*/, const float* d_prev_next /*nullable*/, const int32_t* next_idx /*nullable*/,
                       const float* dt, float lambda, const float* w_hh,
                       float* dgi, float* dgh, float* decv, float* d_prev, void* stream);
+/* Several independent cells in ONE launch each (forward chain and backward chain of the bidirectional
+ * window advance position by position together; count <= 4; arrays are HOST arrays of structs). */
+typedef struct TempGruCellFwd {
+  int32_t n; const float* gi; const float* prev; const int32_t* prev_idx /*nullable*/; const float* dt;
+  const float* w_hh; const float* b_hh; float* h_out; float* saved /* first row of the cell inside the [5, N, d] planes */;
+} TempGruCellFwd;
+typedef struct TempGruCellBwd {
+  int32_t n; const float* saved; const float* dh_up /*nullable*/; const float* d_prev_next /*nullable*/;
+  const int32_t* next_idx /*nullable*/; const float* dt; const float* w_hh;
+  float* dgi; float* dgh; float* decv; float* d_prev;
+} TempGruCellBwd;
+int temp_gru_cell_fwd_multi(int count, const TempGruCellFwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream);
+int temp_gru_cell_bwd_multi(int count, const TempGruCellBwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream);
 size_t temp_gru_weight_grads_workspace(int n, int d, int variant);
 int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float* hdec, const float* dgi, const float* dgh,
                           const float* w_ih, float* d_x /*nullable*/, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh,

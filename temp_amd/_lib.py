@@ -31,6 +31,16 @@ class TempGraph(ctypes.Structure):
                 ("out_deg", c_vp), ("by_dst", TempEdgeView), ("by_src", TempEdgeView), ("by_rel", TempEdgeView)]
 
 
+class TempGruCellFwd(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("gi", c_vp), ("prev", c_vp), ("prev_idx", c_vp), ("dt", c_vp), ("w_hh", c_vp),
+                ("b_hh", c_vp), ("h_out", c_vp), ("saved", c_vp)]
+
+
+class TempGruCellBwd(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("saved", c_vp), ("dh_up", c_vp), ("d_prev_next", c_vp), ("next_idx", c_vp), ("dt", c_vp),
+                ("w_hh", c_vp), ("dgi", c_vp), ("dgh", c_vp), ("decv", c_vp), ("d_prev", c_vp)]
+
+
 # name -> (restype, argtypes); mirrors include/temp_amd.h one to one
 _G = ctypes.POINTER(TempGraph)
 _I, _F, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -51,6 +61,8 @@ SYMBOLS = {
     "temp_gru_input_gates": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_cell_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gru_cell_bwd": (_I, [_I, _I, _I, c_vp, _SZ, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_cell_fwd_multi": (_I, [_I, ctypes.POINTER(TempGruCellFwd), _I, _I, _F, _SZ, c_vp]),
+    "temp_gru_cell_bwd_multi": (_I, [_I, ctypes.POINTER(TempGruCellBwd), _I, _I, _F, _SZ, c_vp]),
     "temp_gru_weight_grads_workspace": (_SZ, [_I, _I, _I]),
     "temp_gru_weight_grads": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),

@@ -169,6 +169,39 @@ class HipBackend:
                                         _ptr(d_prev), _stream())
         _lib.check(rc, "temp_gru_cell_bwd")
 
+    def gru_cell_fwd_multi(self, cells, lam, variant, saved_all):
+        """cells: list (<= 4) of dicts(gi, prev, prev_idx, dt, w_hh, b_hh, h_out, row0) -- one launch for all."""
+        d = saved_all.shape[2]
+        arr = (_lib.TempGruCellFwd * len(cells))()
+        keep = []
+        for a, c in zip(arr, cells):
+            prev, pidx, dt = _f32(c["prev"], "prev"), _i32(c["prev_idx"], "prev_idx"), _f32(c["dt"], "dt")
+            w_hh, b_hh = _f32(c["w_hh"], "w_hh"), _f32(c["b_hh"], "b_hh")
+            keep += [prev, pidx, dt, w_hh, b_hh]
+            a.n = c["h_out"].shape[0]
+            a.gi, a.prev, a.prev_idx, a.dt = c["gi"].data_ptr(), prev.data_ptr(), (pidx.data_ptr() if pidx is not None else None), dt.data_ptr()
+            a.w_hh, a.b_hh, a.h_out = w_hh.data_ptr(), b_hh.data_ptr(), c["h_out"].data_ptr()
+            a.saved = saved_all.data_ptr() + 4 * c["row0"] * d
+        rc = self.lib.temp_gru_cell_fwd_multi(len(cells), arr, d, variant, float(lam), saved_all.shape[1] * d, _stream())
+        _lib.check(rc, "temp_gru_cell_fwd_multi")
+
+    def gru_cell_bwd_multi(self, cells, lam, variant, saved_all):
+        """cells: list (<= 4) of dicts(row0, n, dh_up, d_prev_next, next_idx, dt, w_hh, dgi, dgh, decv, d_prev)."""
+        d = saved_all.shape[2]
+        arr = (_lib.TempGruCellBwd * len(cells))()
+        keep = []
+        opt = lambda t: t.data_ptr() if t is not None else None
+        for a, c in zip(arr, cells):
+            dt, w_hh, nidx = _f32(c["dt"], "dt"), _f32(c["w_hh"], "w_hh"), _i32(c["next_idx"], "next_idx")
+            keep += [dt, w_hh, nidx]
+            a.n = c["n"]
+            a.saved = saved_all.data_ptr() + 4 * c["row0"] * d
+            a.dh_up, a.d_prev_next, a.next_idx = opt(c["dh_up"]), opt(c["d_prev_next"]), opt(nidx)
+            a.dt, a.w_hh = dt.data_ptr(), w_hh.data_ptr()
+            a.dgi, a.dgh, a.decv, a.d_prev = c["dgi"].data_ptr(), c["dgh"].data_ptr(), c["decv"].data_ptr(), c["d_prev"].data_ptr()
+        rc = self.lib.temp_gru_cell_bwd_multi(len(cells), arr, d, variant, float(lam), saved_all.shape[1] * d, _stream())
+        _lib.check(rc, "temp_gru_cell_bwd_multi")
+
     def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
         n, d = x.shape
         w_ih = _f32(w_ih, "w_ih")

@@ -70,12 +70,27 @@ __device__ __forceinline__ void panel_store_b(const float4 (&reg)[PanelCfg<NT>::
   }
 }
 
+// Up to PANEL_MAXP independent problems that share N, K, leading dimensions and the transposition
+// flag run as ONE launch (blockIdx.z selects the problem): the forward and backward chains of the
+// bidirectional window walk the same position at the same time, so their per-position GEMMs are
+// launched together to double the waves in flight.
+#define PANEL_MAXP 4
+template <class Epi>
+struct PanelProblem { int M; const float* A; const int32_t* a_idx; const float* B; Epi epi; };
+template <class Epi>
+struct PanelBatch { PanelProblem<Epi> p[PANEL_MAXP]; };
+
 template <int NT, class Epi>
-__global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                    const int32_t* __restrict__ a_idx, const float* __restrict__ B, int ldb,
-                                                    int trans_b, int n_base, Epi epi) {
+__global__ void __launch_bounds__(256) k_gemm_panel(PanelBatch<Epi> batch, int N, int K, int lda, int ldb, int trans_b, int n_base) {
   constexpr int LDS_B = PanelCfg<NT>::LDS_B, NV = PanelCfg<NT>::NV, NQ = GEMM_KC / 8;
   __shared__ float Bs[2][GEMM_KC * LDS_B];
+  const PanelProblem<Epi>& pb = batch.p[blockIdx.z];
+  const int M = pb.M;
+  if ((int)blockIdx.x * 128 >= M) return;                    // whole block out of range (uniform)
+  const float* __restrict__ A = pb.A;
+  const int32_t* __restrict__ a_idx = pb.a_idx;
+  const float* __restrict__ B = pb.B;
+  const Epi& epi = pb.epi;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
   const int m0 = (blockIdx.x * 4 + wave) * 32;
@@ -156,25 +171,30 @@ __global__ void __launch_bounds__(256) k_gemm_panel(int M, int N, int K, const f
 }
 
 template <int NT, class Epi>
-static inline void launch_panel_nt(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb,
-                                   int trans_b, int n_base, int col_blocks, const Epi& epi, hipStream_t st) {
-  dim3 grid(ceil_div(M, 128), col_blocks);
-  TEMP_LAUNCH(kid, (k_gemm_panel<NT, Epi>), grid, dim3(256), 0, st, M, N, K, A, lda, a_idx, B, ldb, trans_b, n_base, epi);
+static inline void launch_panel_nt(int kid, const PanelBatch<Epi>& batch, int count, int max_m, int N, int K, int lda, int ldb, int trans_b,
+                                   int n_base, int col_blocks, hipStream_t st) {
+  dim3 grid(ceil_div(max_m, 128), col_blocks, count);
+  TEMP_LAUNCH(kid, (k_gemm_panel<NT, Epi>), grid, dim3(256), 0, st, batch, N, K, lda, ldb, trans_b, n_base);
 }
 
 template <class Epi>
-int launch_gemm_panel(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
-                      const Epi& epi, hipStream_t st) {
-  if (M <= 0 || N <= 0) return TEMP_OK;
+int launch_gemm_panel_multi(int kid, const PanelBatch<Epi>& batch, int count, int N, int K, int lda, int ldb, int trans_b, hipStream_t st) {
+  if (count <= 0 || count > PANEL_MAXP) return TEMP_E_BADARG;
+  int max_m = 0;
+  long long sum_blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (batch.p[i].M > max_m) max_m = batch.p[i].M;
+    sum_blocks += ceil_div(batch.p[i].M > 0 ? batch.p[i].M : 0, 128);
+  }
+  if (max_m <= 0 || N <= 0) return TEMP_OK;
   if (K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0 || N % 4 != 0) return TEMP_E_UNSUPPORTED;
-  const int row_blocks = ceil_div(M, 128);
   const int ntiles = ceil_div(N, 32);
   // column-block width: 4 tiles when the grid still fills the chip (re-reads of A come from L2),
   // narrower blocks for short panels (the per-position GEMMs of the GRU chain) to get more waves.
   int nt = 4;
-  while (nt > 1 && (long long)row_blocks * ceil_div(ntiles, nt) < 384) nt >>= 1;
+  while (nt > 1 && sum_blocks * ceil_div(ntiles, nt) < 384) nt >>= 1;
   const int full = ntiles / nt, rem = ntiles - full * nt;
-#define TEMP_PANEL(NT_, BASE, CB) launch_panel_nt<NT_, Epi>(kid, M, N, K, A, lda, a_idx, B, ldb, trans_b, (BASE), (CB), epi, st)
+#define TEMP_PANEL(NT_, BASE, CB) launch_panel_nt<NT_, Epi>(kid, batch, count, max_m, N, K, lda, ldb, trans_b, (BASE), (CB), st)
   if (full > 0) {
     if (nt == 4) TEMP_PANEL(4, 0, full); else if (nt == 2) TEMP_PANEL(2, 0, full); else TEMP_PANEL(1, 0, full);
   }
@@ -184,6 +204,16 @@ int launch_gemm_panel(int kid, int M, int N, int K, const float* A, int lda, con
   }
 #undef TEMP_PANEL
   return launch_status();
+}
+
+template <class Epi>
+int launch_gemm_panel(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
+                      const Epi& epi, hipStream_t st) {
+  if (M <= 0 || N <= 0) return TEMP_OK;
+  PanelBatch<Epi> batch;
+  for (int i = 0; i < PANEL_MAXP; ++i) batch.p[i] = PanelProblem<Epi>{0, nullptr, nullptr, nullptr, epi};
+  batch.p[0] = PanelProblem<Epi>{M, A, a_idx, B, epi};
+  return launch_gemm_panel_multi(kid, batch, 1, N, K, lda, ldb, trans_b, st);
 }
 
 }  // namespace temp

@@ -110,14 +110,31 @@ __device__ __forceinline__ void gru_phase(const GruPhase& ph, const float* __res
   }
 }
 
+#define GRU_MAXP 4
+struct GruFwdCell {
+  int n; const float* x; const float* gi; const float* prev; const int32_t* prev_idx; const float* dt;
+  const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh; float* h_out; float* saved;
+};
+struct GruFwdBatch { GruFwdCell c[GRU_MAXP]; };
+
+// blockIdx.z selects the cell: the forward- and backward-direction chains advance together.
 template <int VARIANT, bool HOISTED>
-__global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __restrict__ x, const float* __restrict__ gi,
-                                                 const float* __restrict__ prev, const int32_t* __restrict__ prev_idx,
-                                                 const float* __restrict__ dt, float lambda, const float* __restrict__ decay_wb,
-                                                 const float* __restrict__ w_ih, const float* __restrict__ w_hh,
-                                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh,
-                                                 float* __restrict__ h_out, float* __restrict__ saved, size_t plane) {
+__global__ void __launch_bounds__(256) k_gru_fwd(GruFwdBatch batch, int D, float lambda, const float* __restrict__ decay_wb, size_t plane) {
   __shared__ float Bs[2][3][GRU_KC * GRU_LDB];
+  const GruFwdCell& cell = batch.c[blockIdx.z];
+  const int n = cell.n;
+  if ((int)blockIdx.x * 128 >= n) return;                     // uniform per block
+  const float* __restrict__ x = cell.x;
+  const float* __restrict__ gi = cell.gi;
+  const float* __restrict__ prev = cell.prev;
+  const int32_t* __restrict__ prev_idx = cell.prev_idx;
+  const float* __restrict__ dt = cell.dt;
+  const float* __restrict__ w_ih = cell.w_ih;
+  const float* __restrict__ w_hh = cell.w_hh;
+  const float* __restrict__ b_ih = cell.b_ih;
+  const float* __restrict__ b_hh = cell.b_hh;
+  float* __restrict__ h_out = cell.h_out;
+  float* __restrict__ saved = cell.saved;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
   const int m0 = (blockIdx.x * 4 + wave) * 32;
@@ -216,12 +233,26 @@ __global__ void __launch_bounds__(256) k_gru_fwd(int n, int D, const float* __re
 // d_h = dh_up (nullable) + d_prev_next[next_idx[row]] (nullable; the gradient flowing back from the
 // next window position, gathered through the inverse row map, -1 = none).  dhz (= d_h * z) seeds the
 // d_prev GEMM epilogue.
+struct GruGatesCell {
+  int n; const float* saved; const float* dh_up; const float* d_prev_next; const int32_t* next_idx; const float* dt;
+  float* dgi; float* dgh; float* decv; float* dhz;
+};
+struct GruGatesBatch { GruGatesCell c[GRU_MAXP]; };
+
 template <int VARIANT>
-__global__ void __launch_bounds__(256) k_gru_bwd_gates(int n, int D, const float* __restrict__ saved, size_t plane,
-                                                       const float* __restrict__ dh_up, const float* __restrict__ d_prev_next,
-                                                       const int32_t* __restrict__ next_idx, const float* __restrict__ dt, float lambda,
-                                                       const float* __restrict__ decay_wb, float* __restrict__ dgi, float* __restrict__ dgh,
-                                                       float* __restrict__ decv, float* __restrict__ dhz) {
+__global__ void __launch_bounds__(256) k_gru_bwd_gates(GruGatesBatch batch, int D, size_t plane, float lambda,
+                                                       const float* __restrict__ decay_wb) {
+  const GruGatesCell& cell = batch.c[blockIdx.y];
+  const int n = cell.n;
+  const float* __restrict__ saved = cell.saved;
+  const float* __restrict__ dh_up = cell.dh_up;
+  const float* __restrict__ d_prev_next = cell.d_prev_next;
+  const int32_t* __restrict__ next_idx = cell.next_idx;
+  const float* __restrict__ dt = cell.dt;
+  float* __restrict__ dgi = cell.dgi;
+  float* __restrict__ dgh = cell.dgh;
+  float* __restrict__ decv = cell.decv;
+  float* __restrict__ dhz = cell.dhz;
   const size_t nd = (size_t)n * D;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / D), col = (int)(i - (size_t)row * D);
@@ -320,31 +351,48 @@ using namespace temp;
 
 extern "C" {
 
+static int launch_gru_fwd_batch(const GruFwdBatch& batch, int count, int d, int variant, bool hoisted, float lambda, const float* decay_wb,
+                                size_t plane, hipStream_t st) {
+  int max_n = 0;
+  for (int i = 0; i < count; ++i) if (batch.c[i].n > max_n) max_n = batch.c[i].n;
+  if (max_n <= 0) return TEMP_OK;
+  dim3 grid(ceil_div(max_n, 128), ceil_div(d, 32), count);
+#define TEMP_GRU_FWD(V, H) TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<V, H>), grid, dim3(256), 0, st, batch, d, lambda, decay_wb, plane)
+  if (variant == TEMP_GRU_TORCH) { if (hoisted) TEMP_GRU_FWD(TEMP_GRU_TORCH, true); else TEMP_GRU_FWD(TEMP_GRU_TORCH, false); }
+  else { if (hoisted) TEMP_GRU_FWD(TEMP_GRU_TYPE1, true); else TEMP_GRU_FWD(TEMP_GRU_TYPE1, false); }
+#undef TEMP_GRU_FWD
+  return launch_status();
+}
+
 static int launch_gru_fwd(int n, int d, int variant, const float* x, const float* gi, const float* prev, const int32_t* prev_idx,
                           const float* dt, float lambda, const float* decay_wb, const float* w_ih, const float* w_hh,
                           const float* b_ih, const float* b_hh, float* h_out, float* saved, size_t plane, hipStream_t st) {
-  dim3 grid(ceil_div(n, 128), ceil_div(d, 32));
-#define TEMP_GRU_FWD(V, H)                                                                                              \
-  TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<V, H>), grid, dim3(256), 0, st, n, d, x, gi, prev, prev_idx, dt, lambda, decay_wb, \
-              w_ih, w_hh, b_ih, b_hh, h_out, saved, plane)
-  if (variant == TEMP_GRU_TORCH) { if (gi) TEMP_GRU_FWD(TEMP_GRU_TORCH, true); else TEMP_GRU_FWD(TEMP_GRU_TORCH, false); }
-  else { if (gi) TEMP_GRU_FWD(TEMP_GRU_TYPE1, true); else TEMP_GRU_FWD(TEMP_GRU_TYPE1, false); }
-#undef TEMP_GRU_FWD
+  GruFwdBatch batch = {};
+  batch.c[0] = GruFwdCell{n, x, gi, prev, prev_idx, dt, w_ih, w_hh, b_ih, b_hh, h_out, saved};
+  return launch_gru_fwd_batch(batch, 1, d, variant, gi != nullptr, lambda, decay_wb, plane, st);
+}
+
+static int launch_gru_gates_batch(const GruGatesBatch& batch, int count, int d, int variant, size_t plane, float lambda,
+                                  const float* decay_wb, hipStream_t st) {
+  int max_n = 0;
+  for (int i = 0; i < count; ++i) if (batch.c[i].n > max_n) max_n = batch.c[i].n;
+  if (max_n <= 0) return TEMP_OK;
+  int gx = ceil_div((long long)max_n * d, 256);
+  if (gx > 2048) gx = 2048;
+  dim3 grid(gx, count);
+  if (variant == TEMP_GRU_TORCH)
+    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TORCH>), grid, dim3(256), 0, st, batch, d, plane, lambda, decay_wb);
+  else
+    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TYPE1>), grid, dim3(256), 0, st, batch, d, plane, lambda, decay_wb);
   return launch_status();
 }
 
 static int launch_gru_gates(int n, int d, int variant, const float* saved, size_t plane, const float* dh_up, const float* d_prev_next,
                             const int32_t* next_idx, const float* dt, float lambda, const float* decay_wb, float* dgi, float* dgh,
                             float* decv, float* dhz, hipStream_t st) {
-  int grid = ceil_div((long long)n * d, 256);
-  if (grid > 4096) grid = 4096;
-  if (variant == TEMP_GRU_TORCH)
-    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TORCH>), dim3(grid), dim3(256), 0, st, n, d, saved, plane, dh_up, d_prev_next,
-                next_idx, dt, lambda, decay_wb, dgi, dgh, decv, dhz);
-  else
-    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TYPE1>), dim3(grid), dim3(256), 0, st, n, d, saved, plane, dh_up, d_prev_next,
-                next_idx, dt, lambda, decay_wb, dgi, dgh, decv, dhz);
-  return launch_status();
+  GruGatesBatch batch = {};
+  batch.c[0] = GruGatesCell{n, saved, dh_up, d_prev_next, next_idx, dt, dgi, dgh, decv, dhz};
+  return launch_gru_gates_batch(batch, 1, d, variant, plane, lambda, decay_wb, st);
 }
 
 int temp_gru_fwd(int n, int d, int variant, const float* x, const float* prev, const int32_t* prev_idx, const float* dt, float lambda,
@@ -453,6 +501,41 @@ int temp_gru_cell_bwd(int n, int d, int variant, const float* saved, size_t save
   int rc = launch_gru_gates(n, d, variant, saved, saved_plane, dh_up, d_prev_next, next_idx, dt, lambda, nullptr, dgi, dgh, decv, d_prev, st);
   if (rc) return rc;
   return launch_gemm_panel(K_GEMM_GRU_DPREV, n, d, 3 * d, dgh, 3 * d, nullptr, w_hh, d, 0, EpiGruDprev{decv, d_prev, d}, st);
+}
+
+int temp_gru_cell_fwd_multi(int count, const TempGruCellFwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream) {
+  if (count <= 0 || count > GRU_MAXP || !cells || d <= 0) return TEMP_E_BADARG;
+  if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  GruFwdBatch batch = {};
+  for (int i = 0; i < count; ++i) {
+    const TempGruCellFwd& c = cells[i];
+    if (c.n < 0 || !c.w_hh || !c.b_hh) return TEMP_E_BADARG;
+    if (c.n > 0 && (!c.gi || !c.prev || !c.dt || !c.h_out || !c.saved || saved_plane < (size_t)c.n * d)) return TEMP_E_BADARG;
+    batch.c[i] = GruFwdCell{c.n, nullptr, c.gi, c.prev, c.prev_idx, c.dt, nullptr, c.w_hh, nullptr, c.b_hh, c.h_out, c.saved};
+  }
+  return launch_gru_fwd_batch(batch, count, d, variant, true, lambda, nullptr, saved_plane, (hipStream_t)stream);
+}
+
+int temp_gru_cell_bwd_multi(int count, const TempGruCellBwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream) {
+  if (count <= 0 || count > GRU_MAXP || !cells || d <= 0) return TEMP_E_BADARG;
+  if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  GruGatesBatch gb = {};
+  PanelBatch<EpiGruDprev> pb;
+  for (int i = 0; i < PANEL_MAXP; ++i) pb.p[i] = PanelProblem<EpiGruDprev>{0, nullptr, nullptr, nullptr, EpiGruDprev{nullptr, nullptr, d}};
+  for (int i = 0; i < count; ++i) {
+    const TempGruCellBwd& c = cells[i];
+    if (c.n < 0 || !c.w_hh) return TEMP_E_BADARG;
+    if (c.n > 0 && (!c.saved || !c.dt || !c.dgi || !c.dgh || !c.decv || !c.d_prev)) return TEMP_E_BADARG;
+    if (c.next_idx && !c.d_prev_next) return TEMP_E_BADARG;
+    gb.c[i] = GruGatesCell{c.n, c.saved, c.dh_up, c.d_prev_next, c.next_idx, c.dt, c.dgi, c.dgh, c.decv, c.d_prev};
+    pb.p[i] = PanelProblem<EpiGruDprev>{c.n, c.dgh, nullptr, c.w_hh, EpiGruDprev{c.decv, c.d_prev, d}};
+  }
+  int rc = launch_gru_gates_batch(gb, count, d, variant, saved_plane, lambda, nullptr, st);
+  if (rc) return rc;
+  return launch_gemm_panel_multi(K_GEMM_GRU_DPREV, pb, count, d, 3 * d, 3 * d, d, 0, st);
 }
 
 size_t temp_gru_weight_grads_workspace(int n, int d, int variant) {

@@ -61,6 +61,16 @@ class GruProgram:
             else:
                 self.groups.append(dict(rnn=it.rnn, x0=it.x0, x1=it.x0 + it.n, h0=it.h0, h1=it.h0 + it.n))
             it.group = len(self.groups) - 1
+        # levels: instances at the same distance from their chain start are independent of each other
+        # (forward-direction and backward-direction chains, the two centre cells) -> launched together
+        depth = []
+        for it in instances:
+            depth.append(0 if it.prev < 0 else depth[it.prev] + 1)
+        self.levels = []
+        for lv in range(max(depth) + 1 if depth else 0):
+            idx = [i for i, dp in enumerate(depth) if dp == lv and instances[i].n > 0]
+            for k in range(0, len(idx), 4):
+                self.levels.append(idx[k:k + 4])
         self.dev = None
 
     def upload(self, device):
@@ -93,16 +103,20 @@ class _GruChainFn(torch.autograd.Function):
         H = torch.empty(N, d, dtype=torch.float32, device=dev)
         saved = torch.empty(5, N, d, dtype=torch.float32, device=dev)
         zero = torch.zeros(1, d, dtype=torch.float32, device=dev)
-        for it, (pi, _, dt) in zip(prog.inst, tens):
-            if it.n == 0:
-                continue
-            _, w_hh, _, b_hh = W[it.rnn]
-            if it.prev >= 0:
-                p = prog.inst[it.prev]
-                prev, pidx = H[p.h0:p.h0 + p.n], pi
-            else:                                     # no history yet: every previous state is zero
-                prev, pidx = zero, torch.full((it.n,), -1, dtype=torch.int32, device=dev)
-            be.gru_cell_fwd(gi[it.h0:it.h0 + it.n], prev, pidx, dt, lam, w_hh, b_hh, variant, H[it.h0:it.h0 + it.n], saved, it.h0)
+        for level in prog.levels:
+            cells = []
+            for i in level:
+                it = prog.inst[i]
+                pi, _, dt = tens[i]
+                _, w_hh, _, b_hh = W[it.rnn]
+                if it.prev >= 0:
+                    p = prog.inst[it.prev]
+                    prev, pidx = H[p.h0:p.h0 + p.n], pi
+                else:                                 # no history yet: every previous state is zero
+                    prev, pidx = zero, torch.full((it.n,), -1, dtype=torch.int32, device=dev)
+                cells.append(dict(gi=gi[it.h0:it.h0 + it.n], prev=prev, prev_idx=pidx, dt=dt, w_hh=w_hh, b_hh=b_hh,
+                                  h_out=H[it.h0:it.h0 + it.n], row0=it.h0))
+            be.gru_cell_fwd_multi(cells, lam, variant, saved)
         ctx.save_for_backward(x_all, saved, *[w for ws in W for w in ws])
         ctx.prog, ctx.lam, ctx.variant, ctx.n_rnn, ctx.G = prog, lam, variant, n_rnn, G
         return H
@@ -121,16 +135,17 @@ class _GruChainFn(torch.autograd.Function):
         dgh = torch.empty(N, 3 * d, dtype=torch.float32, device=dev)
         decv = torch.empty(N, dtype=torch.float32, device=dev)
         d_prev = torch.empty(N, d, dtype=torch.float32, device=dev)
-        for i in range(len(prog.inst) - 1, -1, -1):
-            it = prog.inst[i]
-            if it.n == 0:
-                continue
-            _, ni, dt = tens[i]
-            nxt = prog.inst[it.next] if it.next >= 0 else None
-            be.gru_cell_bwd(saved, it.h0, it.n, dH[it.h0:it.h0 + it.n],
-                            d_prev[nxt.h0:nxt.h0 + nxt.n] if nxt is not None else None, ni if nxt is not None else None,
-                            dt, lam, W[it.rnn][1], variant, dgi[it.h0:it.h0 + it.n], dgh[it.h0:it.h0 + it.n],
-                            decv[it.h0:it.h0 + it.n], d_prev[it.h0:it.h0 + it.n])
+        for level in reversed(prog.levels):
+            cells = []
+            for i in level:
+                it = prog.inst[i]
+                _, ni, dt = tens[i]
+                nxt = prog.inst[it.next] if (it.next >= 0 and prog.inst[it.next].n > 0) else None
+                sl = slice(it.h0, it.h0 + it.n)
+                cells.append(dict(row0=it.h0, n=it.n, dh_up=dH[sl], d_prev_next=d_prev[nxt.h0:nxt.h0 + nxt.n] if nxt is not None else None,
+                                  next_idx=ni if nxt is not None else None, dt=dt, w_hh=W[it.rnn][1], dgi=dgi[sl], dgh=dgh[sl],
+                                  decv=decv[sl], d_prev=d_prev[sl]))
+            be.gru_cell_bwd_multi(cells, lam, variant, saved)
         d_x_all = torch.empty_like(x_all)
         written = np.zeros(x_all.shape[0], dtype=bool)
         grads = [None] * (4 * ctx.n_rnn)

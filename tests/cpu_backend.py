@@ -198,6 +198,15 @@ class CpuTestBackend:
         decv.copy_(dec)
         d_prev.copy_((torch.mm(dgh, w_hh.detach()) + g * z) * dec.view(-1, 1))
 
+    def gru_cell_fwd_multi(self, cells, lam, variant, saved_all):
+        for c in cells:
+            self.gru_cell_fwd(c["gi"], c["prev"], c["prev_idx"], c["dt"], lam, c["w_hh"], c["b_hh"], variant, c["h_out"], saved_all, c["row0"])
+
+    def gru_cell_bwd_multi(self, cells, lam, variant, saved_all):
+        for c in cells:
+            self.gru_cell_bwd(saved_all, c["row0"], c["n"], c["dh_up"], c["d_prev_next"], c["next_idx"], c["dt"], lam, c["w_hh"], variant,
+                              c["dgi"], c["dgh"], c["decv"], c["d_prev"])
+
     def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
         if d_x is not None:
             d_x.copy_(torch.mm(dgi, w_ih.detach()))
