@@ -83,8 +83,9 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 
 // out[Ka,Nb] = sum_m A[m,ka] * B[m,nb]   (split over m, deterministic two-pass reduce)
 size_t gemm_tn_workspace(int M, int Ka, int Nb);
+bool gemm_tn_can_fuse_bias(int Nb);
 int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb,
-            float* out, int ldo, void* ws, size_t ws_bytes, hipStream_t st);
+            float* out, int ldo, void* ws, size_t ws_bytes, hipStream_t st, float* bias_out = nullptr);
 
 // out[n_cols] = sum over rows of X[rows, n_cols]
 size_t colsum_workspace(int rows, int cols);

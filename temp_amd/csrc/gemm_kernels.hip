@@ -63,7 +63,7 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 template <int NT>
 __global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
                                                  const float* __restrict__ B, int ldb, int rows_per_slice, int nb_base,
-                                                 float* __restrict__ part) {
+                                                 float* __restrict__ part, float* __restrict__ bias_part) {
   constexpr int BN = NT * 32;
   constexpr int NVA = TN_MC * 128 / 4 / 256;                 // = 2 float4 per thread
   constexpr int NVB = (TN_MC * BN / 4 + 255) / 256;
@@ -100,6 +100,9 @@ __global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const fl
       const bool ok = (p < TN_MC * BN / 4) && (m0 + r < mend) && (nb0 + c < Nb);
       const float4 v = ld4(B + (ok ? (size_t)(m0 + r) * ldb + nb0 + c : 0));
       rb[i] = ok ? v : zero4();
+      // bias gradient for free: the first padding column of B is a column of ones, so output column
+      // Nb is sum_m A[m, ka]
+      if (bias_part && (p < TN_MC * BN / 4) && (m0 + r < mend) && (nb0 + c == Nb)) rb[i].x = 1.f;
     }
   };
   auto store = [&](int buf) {
@@ -145,6 +148,12 @@ __global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const fl
         const int row = ka0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (row < Ka) p[(size_t)row * Nb + col] = acc[t][r];
       }
+    } else if (bias_part && col == Nb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = ka0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < Ka) bias_part[(size_t)slice * Ka + row] = acc[t][r];
+      }
     }
   }
 }
@@ -182,28 +191,36 @@ static int tn_slices(int M, int Ka, int Nb) {
 }
 
 size_t gemm_tn_workspace(int M, int Ka, int Nb) {
-  return align_up((size_t)tn_slices(M, Ka, Nb) * Ka * Nb * sizeof(float), 256);
+  const size_t S = (size_t)tn_slices(M, Ka, Nb);
+  return align_up(S * Ka * Nb * sizeof(float), 256) + align_up(S * Ka * sizeof(float), 256);
 }
 
+// bias_out (nullable): also produce bias_out[ka] = sum_m A[m, ka] (needs Nb % 32 != 0: a padding column exists)
+bool gemm_tn_can_fuse_bias(int Nb) { return (Nb % 32) != 0; }
+
 int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo, void* ws, size_t ws_bytes,
-            hipStream_t st) {
+            hipStream_t st, float* bias_out) {
   if (Ka <= 0 || Nb <= 0) return TEMP_OK;
   if (Ka % 4 || Nb % 4 || lda % 4 || ldb % 4) return TEMP_E_UNSUPPORTED;
+  if (bias_out && !gemm_tn_can_fuse_bias(Nb)) return TEMP_E_UNSUPPORTED;
   const int S = tn_slices(M, Ka, Nb);
-  if (ws_bytes < (size_t)S * Ka * Nb * sizeof(float) || !ws) return TEMP_E_WORKSPACE;
+  if (ws_bytes < gemm_tn_workspace(M, Ka, Nb) || !ws) return TEMP_E_WORKSPACE;
   int rps = ceil_div(M > 0 ? M : 1, S);
   rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
   const int ntiles = ceil_div(Nb, 32), full = ntiles / 4, rem = ntiles - full * 4;
   const int kab = ceil_div(Ka, 128);
   float* part = (float*)ws;
-  if (full > 0) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<4>), dim3(kab, full, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part);
-  if (rem == 3) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<3>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part);
-  else if (rem == 2) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<2>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part);
-  else if (rem == 1) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<1>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part);
+  float* bpart = bias_out ? (float*)((char*)ws + align_up((size_t)S * Ka * Nb * sizeof(float), 256)) : nullptr;
+  if (full > 0) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<4>), dim3(kab, full, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part, bpart);
+  if (rem == 3) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<3>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part, bpart);
+  else if (rem == 2) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<2>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part, bpart);
+  else if (rem == 1) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<1>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part, bpart);
   const size_t elems = (size_t)Ka * Nb;
   int rg = ceil_div((long long)elems / 4, 256);
   if (rg > 2048) rg = 2048;
   TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, S, elems, Nb, (const float*)ws, out, ldo);
+  if (bias_out)
+    TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(ceil_div(Ka / 4, 256)), dim3(256), 0, st, S, (size_t)Ka, Ka, (const float*)bpart, bias_out, Ka);
   return launch_status();
 }
 

@@ -421,10 +421,12 @@ static int gru_weight_grads(int n, int d, int variant, const float* x, const flo
     rc = launch_gemm_panel(K_GEMM_GRU_DX, n, d, gi_w, dgi, gi_w, nullptr, w_ih, d, 0, EpiStore{d_x, d}, st);
     if (rc) return rc;
   }
-  rc = gemm_tn(n, gi_w, d, dgi, gi_w, x, d, d_w_ih, d, tn, tn_bytes, st);
+  const bool fuse = gemm_tn_can_fuse_bias(d);      // bias gradients ride along as a ones column of the TN GEMM
+  rc = gemm_tn(n, gi_w, d, dgi, gi_w, x, d, d_w_ih, d, tn, tn_bytes, st, fuse ? d_b_ih : nullptr);
   if (rc) return rc;
-  rc = gemm_tn(n, 3 * d, d, dgh, 3 * d, hdec, d, d_w_hh, d, tn, tn_bytes, st);
+  rc = gemm_tn(n, 3 * d, d, dgh, 3 * d, hdec, d, d_w_hh, d, tn, tn_bytes, st, fuse ? d_b_hh : nullptr);
   if (rc) return rc;
+  if (fuse) return TEMP_OK;
   rc = colsum(n, gi_w, dgi, gi_w, d_b_ih, cs, cs_bytes, st);
   if (rc) return rc;
   return colsum(n, 3 * d, dgh, 3 * d, d_b_hh, cs, cs_bytes, st);
