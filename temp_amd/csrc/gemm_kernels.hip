@@ -181,13 +181,6 @@ __global__ void __launch_bounds__(256) k_reduce_slices(int n_slices, size_t elem
   }
 }
 
-void reduce_slices(int n_slices, size_t elems, int width, const float* part, float* out, int ldo, hipStream_t st) {
-  int rg = ceil_div((long long)elems / 4, 256);
-  if (rg > 2048) rg = 2048;
-  if (rg < 1) rg = 1;
-  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, n_slices, elems, width, part, out, ldo);
-}
-
 static int tn_slices(int M, int Ka, int Nb) {
   const long long tiles = (long long)ceil_div(Ka, 128) * ceil_div(Nb, 128);
   long long s = 1024 / (tiles > 0 ? tiles : 1);

@@ -134,104 +134,6 @@ __global__ void __launch_bounds__(1024) k_rgcn_agg(TempEdgeView v, const float* 
   }
 }
 
-// Fused d/dh + d/dweight over the by-src view (edges of a source node sorted by relation).
-// Per source u the lane keeps its 4 features of x[u]; per edge it gathers c*dz[dst] (the ONLY row
-// gather of the backward aggregation); per run of equal relation it accumulates g = sum c*dz in
-// registers and, when the relation changes, (a) adds g . BD(W_r)^T to the d/dh accumulator and
-// (b) adds the S x S outer products x[u] (x) g into a per-workgroup LDS copy of d/dW with LDS
-// float atomics.  The LDS tables are flushed to per-block partials and summed in block order.
-// Only d/dW's within-block accumulation order is non-deterministic (fp32 atomics); it is used when
-// the table fits LDS (<= 64 KB), otherwise the deterministic by-relation kernel below runs.
-template <int S>
-__global__ void __launch_bounds__(1024) k_rgcn_dxw(TempEdgeView v, const float* __restrict__ dz, const float* __restrict__ x,
-                                                   const float* __restrict__ W, int n_rel_rows, const float* __restrict__ nnorm, int D,
-                                                   int lpr, float* __restrict__ dx_out, float* __restrict__ dx_partial,
-                                                   float* __restrict__ dw_partial) {
-  extern __shared__ float dWs[];                    // [n_rel_rows][D*S], natural weight layout
-  const int wrow = D * S;
-  const int table = n_rel_rows * wrow;
-  for (int i = threadIdx.x; i < table; i += blockDim.x) dWs[i] = 0.f;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  const int lr = lane & (lpr - 1), gi = lane / lpr, epw = 64 / lpr;
-  const int f = lr << 2;
-  const bool active = f < D;
-  ItemRange it = xcd_items(v.n_chunks, wpb);
-  for (int c = it.beg + wave; c < it.end; c += it.stride) {
-    const int seg = v.chunk_seg[c], beg = v.chunk_beg[c], cnt = v.chunk_end[c] - beg, slot = v.chunk_slot[c];
-    int a_l = 0, b_l = 0;
-    float s_l = 0.f;
-    if (lane < cnt) {
-      a_l = v.a[beg + lane];
-      b_l = v.b[beg + lane];
-      const float nn = nnorm[a_l];
-      s_l = nn * nn;
-    }
-    const float4 xu = active ? ld4(x + (size_t)seg * D + f) : zero4();
-    float4 acc = zero4(), gs = zero4();
-    int cur_r = -1;
-    auto flush = [&]() {
-      if (cur_r >= 0 && active) {
-        const float* wr = W + (size_t)cur_r * wrow + f * S;
-        float4 w[S];
-#pragma unroll
-        for (int j = 0; j < S; ++j) w[j] = ld4(wr + 4 * j);
-        block_mac<S, MODE_DX>(acc, gs, w, 1.f);
-        float* d = dWs + cur_r * wrow + f * S;
-        if (S == 1) {
-          atomicAdd(d + 0, xu.x * gs.x); atomicAdd(d + 1, xu.y * gs.y); atomicAdd(d + 2, xu.z * gs.z); atomicAdd(d + 3, xu.w * gs.w);
-        } else if (S == 2) {
-          atomicAdd(d + 0, xu.x * gs.x); atomicAdd(d + 1, xu.x * gs.y); atomicAdd(d + 2, xu.y * gs.x); atomicAdd(d + 3, xu.y * gs.y);
-          atomicAdd(d + 4, xu.z * gs.z); atomicAdd(d + 5, xu.z * gs.w); atomicAdd(d + 6, xu.w * gs.z); atomicAdd(d + 7, xu.w * gs.w);
-        } else {
-          const float xs[4] = {xu.x, xu.y, xu.z, xu.w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            atomicAdd(d + 4 * i + 0, xs[i] * gs.x); atomicAdd(d + 4 * i + 1, xs[i] * gs.y);
-            atomicAdd(d + 4 * i + 2, xs[i] * gs.z); atomicAdd(d + 4 * i + 3, xs[i] * gs.w);
-          }
-        }
-      }
-    };
-    constexpr int U = 4;
-    for (int e0 = 0; e0 < cnt; e0 += epw * U) {
-      float4 gv[U];
-      int rr[U];
-      float sc[U];
-      bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * epw + gi;
-        ok[u] = e < cnt;
-        const int row = __shfl(a_l, e & 63);
-        rr[u] = __shfl(b_l, e & 63);
-        sc[u] = __shfl(s_l, e & 63);
-        gv[u] = (ok[u] && active) ? ld4(dz + (size_t)row * D + f) : zero4();
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (ok[u]) {
-          if (rr[u] != cur_r) {
-            flush();
-            cur_r = rr[u];
-            gs = zero4();
-          }
-          gs = fma4(sc[u], gv[u], gs);
-        }
-      }
-    }
-    flush();
-    for (int off = lpr; off < 64; off <<= 1) acc = add4(acc, shfl_xor4(acc, off));
-    if (gi == 0 && active) {
-      float* dst = (slot < 0) ? dx_out + (size_t)seg * D + f : dx_partial + (size_t)slot * D + f;
-      st4(dst, acc);
-    }
-  }
-  __syncthreads();
-  float* p = dw_partial + (size_t)blockIdx.x * table;
-  for (int i = threadIdx.x; i < table; i += blockDim.x) p[i] = dWs[i];
-}
-
 // Generic (any si, so) scalar-lane variant; slow, for shapes outside the fast path.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rgcn_agg_generic(TempEdgeView v, const float* __restrict__ feat, int ldf,
@@ -524,13 +426,6 @@ int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids, int 
   return gemm_add_bias_act(K_GEMM_LOOP_FWD, g->n_nodes, d_out, d_in, h, d_in, h_ids, loop_w, d_out, 0, out, d_out, g->in_deg, bias, act, out, d_out, st);
 }
 
-#define DXW_BLOCKS 512
-static bool can_fuse_dxw(int d_in, int d_out, int num_bases, int n_rel_rows, int n_chunks) {
-  int S = 0;
-  if (!fast_shape(d_in, d_out, num_bases, &S)) return false;
-  return (size_t)n_rel_rows * d_in * S * sizeof(float) <= 65536 && n_chunks >= 4096;
-}
-
 struct BwdWs {
   float* dz;        // [n, d_out]  (only when act == relu)
   float* part_dx;   // by_src partial slots [n_partial, d_in]
@@ -548,12 +443,7 @@ static BwdWs carve_bwd(const TempGraph* g, int d_in, int d_out, int num_bases, c
   const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
   w.dz = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
   w.part_dx = (float*)take((size_t)g->by_src.n_partial * d_in * sizeof(float));
-  size_t dw_part = (size_t)g->by_rel.n_partial * wrow * sizeof(float);
-  if (can_fuse_dxw(d_in, d_out, num_bases, g->by_rel.n_seg, g->by_src.n_chunks)) {
-    const size_t fused = (size_t)DXW_BLOCKS * g->by_rel.n_seg * wrow * sizeof(float);
-    if (fused > dw_part) dw_part = fused;
-  }
-  w.part_dw = (float*)take(dw_part);
+  w.part_dw = (float*)take((size_t)g->by_rel.n_partial * wrow * sizeof(float));
   w.tn_bytes = gemm_tn_workspace(g->n_nodes, d_in, d_out);
   w.tn = take(w.tn_bytes);
   w.cs_bytes = colsum_workspace(g->n_nodes, d_out);
@@ -596,33 +486,13 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
     dz = w.dz;
   }
   // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
-  const bool fused = can_fuse_dxw(d_in, d_out, num_bases, n_rel_rows, g->by_src.n_chunks);
-  if (fused) {
-    int S = 0;
-    fast_shape(d_in, d_out, num_bases, &S);
-    const int lpr = pick_lpr(d_in);
-    const size_t lds = (size_t)n_rel_rows * d_in * S * sizeof(float);
-#define TEMP_DXW(SS) TEMP_LAUNCH(K_RGCN_AGG_DX, (k_rgcn_dxw<SS>), dim3(DXW_BLOCKS), dim3(1024), lds, st, g->by_src, dz, h, weight, n_rel_rows, \
-                                 g->nnorm, d_in, lpr, d_h, w.part_dx, w.part_dw)
-    if (S == 1) TEMP_DXW(1); else if (S == 2) TEMP_DXW(2); else TEMP_DXW(4);
-#undef TEMP_DXW
-    launch_fixup(g->by_src, w.part_dx, d_in, d_h, st);
-    // d_weight = sum over blocks of the per-block tables, in block order
-    const size_t elems = (size_t)n_rel_rows * wrow;
-    reduce_slices(DXW_BLOCKS, elems, (int)wrow, w.part_dw, d_weight, (int)wrow, st);
-    rc = launch_status();
-    if (rc) return rc;
-  } else {
-    rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
-    if (rc) return rc;
-  }
+  rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
+  if (rc) return rc;
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dz, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
                          d_h, d_in, st);
   if (rc) return rc;
-  if (!fused) {
-    rc = run_dw(g->by_rel, h, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
-    if (rc) return rc;
-  }
+  rc = run_dw(g->by_rel, h, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+  if (rc) return rc;
   rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
   if (rc) return rc;
   if (has_bias) {

@@ -99,11 +99,11 @@ def batch(snapshots):
     return out
 
 
-def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK, secondary=None):
-    """Sort edges by `seg` (stable; ties broken by `secondary` when given) and cut every segment
-    into chunks of <= `chunk` edges.  Returns a dict of int32 numpy arrays + counts (TempEdgeView)."""
+def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK):
+    """Sort edges by `seg` (stable) and cut every segment into chunks of <= `chunk` edges.
+    Returns a dict of int32 numpy arrays + counts (layout of TempEdgeView)."""
     seg = np.asarray(seg, dtype=np.int64)
-    order = np.argsort(seg, kind="stable") if secondary is None else np.lexsort((np.asarray(secondary), seg))
+    order = np.argsort(seg, kind="stable")
     seg_s = seg[order]
     counts = np.bincount(seg_s, minlength=n_seg).astype(np.int64)
     ptr = np.concatenate([[0], np.cumsum(counts)])
@@ -137,7 +137,7 @@ class _DeviceGraph:
     def __init__(self, snap, device, n_rel_rows):
         n, E = snap.n, snap.number_of_edges()
         views = dict(by_dst=build_view(snap.dst, snap.src, snap.rel, n),
-                     by_src=build_view(snap.src, snap.dst, snap.rel, n, secondary=snap.rel),   # runs of equal relation per source
+                     by_src=build_view(snap.src, snap.dst, snap.rel, n),
                      by_rel=build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL))
         if E and (snap.rel.min() < 0 or snap.rel.max() >= n_rel_rows):
             raise ValueError("relation id outside [0, %d)" % n_rel_rows)
