@@ -87,6 +87,9 @@ bool gemm_tn_can_fuse_bias(int Nb);
 int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb,
             float* out, int ldo, void* ws, size_t ws_bytes, hipStream_t st, float* bias_out = nullptr);
 
+// out = sum over n_slices of part[s] (each `elems` floats, elems % 4 == 0), in slice order
+void reduce_slices(int n_slices, size_t elems, int width, const float* part, float* out, int ldo, hipStream_t st);
+
 // out[n_cols] = sum over rows of X[rows, n_cols]
 size_t colsum_workspace(int rows, int cols);
 int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st);

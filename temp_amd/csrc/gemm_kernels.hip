@@ -53,25 +53,29 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 
 // ---------------------------------------------------------------------------------------------
 // TN split-K: out[Ka,Nb] = sum_m A[m,ka] * B[m,nb]  (every weight gradient).
-// A block owns a 128(ka) x NT*32(nb) output tile over one slice of m; wave w owns ka rows
-// [32w, 32w+32).  Chunks of TN_MC rows of A and B are staged in LDS (coalesced float4 row reads,
-// register-prefetched one chunk ahead, double-buffered); for the row pair (m, m+1) lane (li, hh)
-// reads As[m+hh][32w+li] and Bs[m+hh][32t+li] -- conflict-free b32 reads.  Slices are written to a
-// workspace and summed in slice order by k_reduce_slices (deterministic).
+// These GEMMs have a tiny output and two long, thin inputs, so they are bound by how often A and B
+// are re-read: a block therefore owns a (WPB*32) x (NT*32) output tile -- for D = 200 ALL 224 padded
+// columns and 224/256 rows -- over one slice of m, so A is streamed once and B once per 256 rows of
+// Ka.  Wave w owns ka rows [32w, 32w+32) x NT column tiles (NT*16 accumulator registers).  Chunks of
+// TN_MC rows of A and B are staged in LDS (coalesced float4 row reads, register-prefetched one chunk
+// ahead, double-buffered); for the row pair (m, m+1) lane (li, hh) reads As[m+hh][32w+li] and
+// Bs[m+hh][32t+li] -- conflict-free b32 reads.  MFMA operands are swapped so that a lane holds one
+// output row and 4 consecutive columns per register quad (float4 stores).  Slices go to a workspace
+// and are summed in slice order by k_reduce_slices (deterministic).
 // ---------------------------------------------------------------------------------------------
 #define TN_MC 16
-template <int NT>
-__global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
-                                                 const float* __restrict__ B, int ldb, int rows_per_slice, int nb_base,
-                                                 float* __restrict__ part, float* __restrict__ bias_part) {
-  constexpr int BN = NT * 32;
-  constexpr int NVA = TN_MC * 128 / 4 / 256;                 // = 2 float4 per thread
-  constexpr int NVB = (TN_MC * BN / 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float As[2][TN_MC * 128];
+template <int NT, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ B, int ldb, int rows_per_slice, int nb_base,
+                                                      float* __restrict__ part, float* __restrict__ bias_part) {
+  constexpr int T = WPB * 64, BK = WPB * 32, BN = NT * 32;
+  constexpr int NVA = (TN_MC * BK / 4 + T - 1) / T;          // = 2
+  constexpr int NVB = (TN_MC * BN / 4 + T - 1) / T;
+  __shared__ __attribute__((aligned(16))) float As[2][TN_MC * BK];
   __shared__ __attribute__((aligned(16))) float Bs[2][TN_MC * BN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
-  const int ka_blk = blockIdx.x * 128;
+  const int ka_blk = blockIdx.x * BK;
   const int ka0 = ka_blk + wave * 32;
   const int nb0 = nb_base + blockIdx.y * BN;
   const int slice = blockIdx.z;
@@ -87,30 +91,34 @@ __global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const fl
   auto fetch = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
-      const int p = threadIdx.x + i * 256;
-      const int r = p >> 5, c = (p & 31) << 2;
-      const bool ok = (m0 + r < mend) && (ka_blk + c < Ka);
+      const int p = threadIdx.x + i * T;
+      const int r = p / (BK / 4), c = (p - r * (BK / 4)) << 2;
+      const bool ok = (p < TN_MC * BK / 4) && (m0 + r < mend) && (ka_blk + c < Ka);
       const float4 v = ld4(A + (ok ? (size_t)(m0 + r) * lda + ka_blk + c : 0));
       ra[i] = ok ? v : zero4();
     }
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
-      const int p = threadIdx.x + i * 256;
+      const int p = threadIdx.x + i * T;
       const int r = p / (BN / 4), c = (p - r * (BN / 4)) << 2;
-      const bool ok = (p < TN_MC * BN / 4) && (m0 + r < mend) && (nb0 + c < Nb);
+      const bool inr = (p < TN_MC * BN / 4) && (m0 + r < mend);
+      const bool ok = inr && (nb0 + c < Nb);
       const float4 v = ld4(B + (ok ? (size_t)(m0 + r) * ldb + nb0 + c : 0));
       rb[i] = ok ? v : zero4();
       // bias gradient for free: the first padding column of B is a column of ones, so output column
       // Nb is sum_m A[m, ka]
-      if (bias_part && (p < TN_MC * BN / 4) && (m0 + r < mend) && (nb0 + c == Nb)) rb[i].x = 1.f;
+      if (bias_part && inr && (nb0 + c == Nb)) rb[i].x = 1.f;
     }
   };
   auto store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NVA; ++i) st4(&As[buf][(threadIdx.x + i * 256) << 2], ra[i]);
+    for (int i = 0; i < NVA; ++i) {
+      const int p = threadIdx.x + i * T;
+      if (p < TN_MC * BK / 4) st4(&As[buf][p << 2], ra[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
-      const int p = threadIdx.x + i * 256;
+      const int p = threadIdx.x + i * T;
       if (p < TN_MC * BN / 4) st4(&Bs[buf][p << 2], rb[i]);
     }
   };
@@ -129,31 +137,26 @@ __global__ void __launch_bounds__(256) k_gemm_tn(int M, int Ka, int Nb, const fl
       const float* bs = Bs[c & 1] + li;
 #pragma unroll
       for (int mp = 0; mp < TN_MC; mp += 2) {
-        const float a = as[(mp + hh) * 128];
+        const float a = as[(mp + hh) * BK];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[(mp + hh) * BN + t * 32], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[(mp + hh) * BN + t * 32], a, acc[t], 0, 0, 0);
       }
     }
     if (more) store((c + 1) & 1);
     __syncthreads();
   }
-  if (!wave_on) return;
-  float* p = part + (size_t)slice * Ka * Nb;
+  // swapped operands: lane (li, hh) holds output row ka0 + li, register quad q of tile t holds the
+  // four columns nb0 + t*32 + 8q + 4hh .. +3
+  const int row = ka0 + li;
+  if (!wave_on || row >= Ka) return;
+  float* p = part + (size_t)slice * Ka * Nb + (size_t)row * Nb;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int col = nb0 + t * 32 + li;
-    if (col < Nb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = ka0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < Ka) p[(size_t)row * Nb + col] = acc[t][r];
-      }
-    } else if (bias_part && col == Nb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = ka0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < Ka) bias_part[(size_t)slice * Ka + row] = acc[t][r];
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int col = nb0 + t * 32 + 8 * q + 4 * hh;
+      if (col < Nb) st4(p + col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]));
+      else if (bias_part && col == Nb) bias_part[(size_t)slice * Ka + row] = acc[t][4 * q];
     }
   }
 }
@@ -181,46 +184,65 @@ __global__ void __launch_bounds__(256) k_reduce_slices(int n_slices, size_t elem
   }
 }
 
-static int tn_slices(int M, int Ka, int Nb) {
-  const long long tiles = (long long)ceil_div(Ka, 128) * ceil_div(Nb, 128);
-  long long s = 1024 / (tiles > 0 ? tiles : 1);
-  const long long max_s = (M + 127) / 128;    // at least 128 rows per slice
+void reduce_slices(int n_slices, size_t elems, int width, const float* part, float* out, int ldo, hipStream_t st) {
+  int rg = ceil_div((long long)elems / 4, 256);
+  if (rg > 2048) rg = 2048;
+  if (rg < 1) rg = 1;
+  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, n_slices, elems, width, part, out, ldo);
+}
+
+struct TnCfg { int wpb, bk, kab, nt, nbb, slices; };
+static TnCfg tn_cfg(int M, int Ka, int Nb) {
+  TnCfg c;
+  const int ktiles = ceil_div(Ka, 32);
+  c.wpb = (ktiles <= 7) ? 7 : 8;                      // D = 200 -> 7 row tiles: one block owns all of Ka
+  c.bk = c.wpb * 32;
+  c.kab = ceil_div(Ka, c.bk);
+  const int ntiles = ceil_div(Nb, 32);
+  c.nt = ntiles >= 5 ? 7 : (ntiles >= 3 ? 4 : (ntiles == 2 ? 2 : 1));
+  c.nbb = ceil_div(ntiles, c.nt);
+  long long s = 256 / ((long long)c.kab * c.nbb);     // ~ one 7/8-wave block per CU
+  const long long max_s = (M + 127) / 128;            // at least 128 rows per slice
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
-  return (int)s;
+  c.slices = (int)s;
+  return c;
 }
 
 size_t gemm_tn_workspace(int M, int Ka, int Nb) {
-  const size_t S = (size_t)tn_slices(M, Ka, Nb);
+  const size_t S = (size_t)tn_cfg(M, Ka, Nb).slices;
   return align_up(S * Ka * Nb * sizeof(float), 256) + align_up(S * Ka * sizeof(float), 256);
 }
 
 // bias_out (nullable): also produce bias_out[ka] = sum_m A[m, ka] (needs Nb % 32 != 0: a padding column exists)
 bool gemm_tn_can_fuse_bias(int Nb) { return (Nb % 32) != 0; }
 
+template <int NT>
+static void launch_tn(const TnCfg& c, int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, int rps, float* part,
+                      float* bpart, hipStream_t st) {
+  dim3 grid(c.kab, c.nbb, c.slices);
+  if (c.wpb == 7) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<NT, 7>), grid, dim3(7 * 64), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part, bpart);
+  else TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<NT, 8>), grid, dim3(8 * 64), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part, bpart);
+}
+
 int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo, void* ws, size_t ws_bytes,
             hipStream_t st, float* bias_out) {
   if (Ka <= 0 || Nb <= 0) return TEMP_OK;
   if (Ka % 4 || Nb % 4 || lda % 4 || ldb % 4) return TEMP_E_UNSUPPORTED;
   if (bias_out && !gemm_tn_can_fuse_bias(Nb)) return TEMP_E_UNSUPPORTED;
-  const int S = tn_slices(M, Ka, Nb);
+  const TnCfg c = tn_cfg(M, Ka, Nb);
+  const int S = c.slices;
   if (ws_bytes < gemm_tn_workspace(M, Ka, Nb) || !ws) return TEMP_E_WORKSPACE;
   int rps = ceil_div(M > 0 ? M : 1, S);
   rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
-  const int ntiles = ceil_div(Nb, 32), full = ntiles / 4, rem = ntiles - full * 4;
-  const int kab = ceil_div(Ka, 128);
   float* part = (float*)ws;
   float* bpart = bias_out ? (float*)((char*)ws + align_up((size_t)S * Ka * Nb * sizeof(float), 256)) : nullptr;
-  if (full > 0) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<4>), dim3(kab, full, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part, bpart);
-  if (rem == 3) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<3>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part, bpart);
-  else if (rem == 2) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<2>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part, bpart);
-  else if (rem == 1) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<1>), dim3(kab, 1, S), dim3(256), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, full * 128, part, bpart);
-  const size_t elems = (size_t)Ka * Nb;
-  int rg = ceil_div((long long)elems / 4, 256);
-  if (rg > 2048) rg = 2048;
-  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, S, elems, Nb, (const float*)ws, out, ldo);
-  if (bias_out)
-    TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(ceil_div(Ka / 4, 256)), dim3(256), 0, st, S, (size_t)Ka, Ka, (const float*)bpart, bias_out, Ka);
+  if (c.nt == 7) launch_tn<7>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
+  else if (c.nt == 4) launch_tn<4>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
+  else if (c.nt == 2) launch_tn<2>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
+  else launch_tn<1>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
+  reduce_slices(S, (size_t)Ka * Nb, Nb, part, out, ldo, st);
+  if (bias_out) reduce_slices(S, (size_t)Ka, Ka, bpart, bias_out, Ka, st);
   return launch_status();
 }
 
