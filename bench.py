@@ -287,6 +287,7 @@ def main():
                                windows_per_gpu=w["bsz"], embed=w["D"], n_bases=w["B"], entities=w["num_ents"],
                                relations=w["num_rels"], edges_per_snapshot=w["edges_per_snap"],
                                edge_visits_per_step_per_gpu=wb.n_edge_visits, node_visits_per_step_per_gpu=wb.n_node_visits,
+                               distinct_snapshot_edges_per_step=getattr(wb, "n_edges_distinct", None), targets=targets,
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
                                else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s),
                    roofline=roof, cpu_baseline=cpu)

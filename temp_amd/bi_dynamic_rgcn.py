@@ -91,6 +91,8 @@ class BiDynamicRGCN(DynamicRGCN):
         h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
         y1 = enc.layer_1.conv(wb.g_all, h0)
         y2 = enc.layer_2.conv(wb.g_all, y1)                   # ReLU fused (models/BiRRGCN.py:202-203)
+        if wb.visit_rows is not None:                         # distinct-snapshot rows -> visit rows
+            y2 = TF.gather_rows(y2, wb.visit_rows)
         l2 = enc.layer_2
         lam, dec = l2.inv_temperature, l2.decay_spec()
         if wb.program is not None:

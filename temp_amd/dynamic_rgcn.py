@@ -21,7 +21,7 @@ from .rrgcn import RRGCN, GRRGCNLayer, run_rnn
 from .tkg_module import TKG_Module
 from .gru_chain import GruInstance, GruProgram, gru_chain
 from .gru_cell import GRUCell
-from .window import ChainPlan, Step, concat_steps, window_times
+from .window import ChainPlan, Step, concat_steps, concat_steps_dedup, window_times
 
 
 class WindowBatch:
@@ -46,6 +46,7 @@ class DynamicRGCN(TKG_Module):
         self.sample_rng = np.random.default_rng(getattr(args, "seed", None))
         self.use_batched_path = True
         self.use_gru_chain = True
+        self.dedup_snapshots = True
 
     def build_model(self):
         self.ent_encoder = RRGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
@@ -137,6 +138,8 @@ class DynamicRGCN(TKG_Module):
         h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
         y1 = enc.layer_1.conv(wb.g_all, h0)
         y2 = enc.layer_2.conv(wb.g_all, y1)
+        if wb.visit_rows is not None:                 # distinct-snapshot rows -> visit rows
+            y2 = TF.gather_rows(y2, wb.visit_rows)
         l2 = enc.layer_2
         if wb.program is not None:
             H_all = gru_chain(y2, wb.program, [l2.rnn], l2.inv_temperature, isinstance(l2.rnn, GRUCell))
@@ -176,8 +179,13 @@ class DynamicRGCN(TKG_Module):
         for st in wb.steps:
             st.tensors(dev)
         wb.program = None
+        wb.visit_rows = None
         if wb.batched:
-            wb.g_all, wb.total_rows = concat_steps(wb.steps)
+            if self.dedup_snapshots:
+                wb.g_all, vr, wb.total_rows = concat_steps_dedup(wb.steps)
+                wb.visit_rows = torch.from_numpy(vr).to(dev) if vr is not None else None
+            else:
+                wb.g_all, wb.total_rows = concat_steps(wb.steps)
             wb.ids_all = torch.from_numpy(wb.g_all.gids.astype(np.int32)).to(dev)
             wb.g_all.device_graph(dev, 2 * self.num_rels)
             if self._can_chain():
@@ -187,6 +195,8 @@ class DynamicRGCN(TKG_Module):
             for st in wb.steps:
                 st.batched().device_graph(dev, 2 * self.num_rels)
         wb.n_edge_visits = int(sum(g.number_of_edges() for st in wb.steps for g in st.graphs))
+        wb.n_edges_distinct = int(wb.g_all.number_of_edges()) if wb.batched else wb.n_edge_visits
+        wb.n_nodes_distinct = int(wb.g_all.n) if wb.batched else 0
         wb.n_node_visits = int(sum(st.n_rows for st in wb.steps))
 
     def run(self, wb):

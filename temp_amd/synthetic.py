@@ -17,8 +17,8 @@ from .snapshot import Snapshot
 
 WORKLOADS = {
     # name:        N_ents, R,   E/snap, n/snap, T,  D,   B,   L,  bsz, module
-    "S-gdelt":     (500, 20, 7475, 500, 64, 200, 100, 15, 8, "BiGRRGCN"),
-    "S-icews14":   (7128, 230, 200, 227, 64, 200, 100, 8, 8, "GRRGCN"),
+    "S-gdelt":     (500, 20, 7475, 500, 366, 200, 100, 15, 8, "BiGRRGCN"),
+    "S-icews14":   (7128, 230, 200, 227, 365, 200, 100, 8, 8, "GRRGCN"),
     "S-icews0515": (10488, 251, 92, 110, 64, 200, 100, 15, 8, "BiGRRGCN"),
     "S-hbm":       (1 << 20, 230, 1 << 24, 1 << 20, 32, 200, 100, 15, 1, "BiGRRGCN"),
     "S-tiny":      (64, 6, 300, 40, 24, 16, 8, 4, 3, "BiGRRGCN"),
@@ -58,8 +58,14 @@ def workload(name, seed=0):
                 module=module, snapshots=snaps)
 
 
-def default_targets(num_times, L, bsz, rank=0):
-    """bsz target timestamps whose forward AND backward windows are full, distinct per rank."""
+def default_targets(num_times, L, bsz, rank=0, seed=3):
+    """bsz target timestamps drawn uniformly without replacement (seeded, distinct per rank) from the
+    timestamps whose forward AND backward windows are full -- what the reference's shuffled
+    DataLoader over all timestamps produces (models/TKG_Module.py:162-179), so windows overlap as
+    often as they do in real training and no more."""
     lo, hi = L - 1, num_times - L
-    span = max(hi - lo + 1, 1)
-    return [lo + ((rank * bsz + i) * 3) % span for i in range(bsz)]
+    cand = np.arange(lo, max(hi, lo) + 1)
+    rng = np.random.default_rng(seed + 1000 * rank)
+    if len(cand) >= bsz:
+        return [int(t) for t in rng.choice(cand, size=bsz, replace=False)]
+    return [int(cand[i % len(cand)]) for i in range(bsz)]

@@ -125,6 +125,38 @@ class ChainPlan:
         return self.row_of[b], (cur_t - self.last[b]).astype(np.float32)
 
 
+def concat_steps_dedup(steps):
+    """Like concat_steps, but a snapshot that is visited several times in the step -- the same
+    timestamp inside several overlapping windows, or in one window's forward chain and another's
+    backward chain -- enters the batched RGCN graph ONCE: with only the last layer recurrent the RGCN
+    stack of a visit depends on the snapshot alone, so its output rows are shared by all visits
+    (the reference recomputes them per window).  Target snapshots carry a per-window random edge
+    subsample and stay distinct.
+
+    Returns (batched graph over the distinct snapshots, visit_rows, total visit rows): visit_rows is
+    an int32 array mapping every visit row (step.row0 layout) to its row in the distinct layout, or
+    None when nothing is shared."""
+    uniq, first_row, graphs = {}, [], []
+    off_u = 0
+    visit_rows = []
+    off = 0
+    shared = False
+    for st in steps:
+        st.row0 = off
+        for g in st.graphs:
+            key = id(g)
+            if key in uniq:
+                shared = True
+            else:
+                uniq[key] = off_u
+                graphs.append(g)
+                off_u += g.n
+            visit_rows.append(uniq[key] + np.arange(g.n, dtype=np.int64))
+        off += st.n_rows
+    vr = np.concatenate(visit_rows).astype(np.int32) if (shared and visit_rows) else None
+    return S.batch(graphs), vr, off
+
+
 def concat_steps(steps):
     """All visits of several steps as ONE batched graph (fast path: the RGCN stack of every visit is
     independent of history when only the last layer is recurrent, models/RRGCN.py:182-187), with
