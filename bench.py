@@ -63,12 +63,15 @@ def algorithmic_costs(wb, D, bi, S=2):
     """Per-step ALGORITHMIC bytes / flops of every kernel family of the batched path (fp32, int32
     ids).  n = node visits, E = edge visits of the step; the GRU runs once per node visit (twice on
     the target position of the bi model)."""
-    n, E = wb.n_node_visits, wb.n_edge_visits
-    n_gru = n + (wb.target.n_rows if bi else 0)
+    n_gru = wb.n_node_visits + (wb.target.n_rows if bi else 0)     # GRU cells: one per node visit (two on the bi target)
+    # the RGCN layers run once per DISTINCT snapshot of the step (shared between overlapping windows)
+    n = getattr(wb, "n_nodes_distinct", 0) or wb.n_node_visits
+    E = getattr(wb, "n_edges_distinct", 0) or wb.n_edge_visits
     row = 4 * D
     c = {}
-    c["k_gather_rows"] = dict(bytes=n * (4 + 2 * row), flops=0)
-    c["k_scatter_add_rows"] = dict(bytes=n * (4 + 3 * row), flops=0)
+    nv = wb.n_node_visits
+    c["k_gather_rows"] = dict(bytes=(n + nv) * (4 + 2 * row), flops=0)
+    c["k_scatter_add_rows"] = dict(bytes=(n + nv) * (4 + 3 * row), flops=0)
     c["k_rgcn_agg<fwd>"] = dict(bytes=2 * (E * (row + 8) + n * row), flops=2 * E * 2 * D * S)
     c["k_rgcn_agg<dx>"] = dict(bytes=2 * (E * (row + 12) + n * row), flops=2 * E * 2 * D * S)
     c["k_rgcn_dw"] = dict(bytes=2 * (E * (2 * row + 12)), flops=2 * E * 2 * D * S)
@@ -76,7 +79,8 @@ def algorithmic_costs(wb, D, bi, S=2):
     c["k_gemm_panel<loop_dx>"] = dict(bytes=2 * n * 3 * row, flops=2 * 2 * n * D * D)
     c["k_gemm_tn"] = dict(bytes=2 * n * 2 * row + n_gru * (2 * row + 6 * row), flops=2 * 2 * n * D * D + 2 * 2 * n_gru * 3 * D * D)
     c["k_relu_bwd"] = dict(bytes=n * 3 * row, flops=0)
-    c["k_gru_fwd"] = dict(bytes=n_gru * (3 * row + 5 * row + 8), flops=12 * n_gru * D * D)
+    c["k_gru_fwd"] = dict(bytes=n_gru * (row + 3 * row + row + 5 * row + 8), flops=6 * n_gru * D * D)   # hoisted: h-phase only
+    c["k_gemm_panel<gru_gi>"] = dict(bytes=n_gru * (row + 3 * row), flops=2 * n_gru * 3 * D * D)
     c["k_gru_bwd_gates"] = dict(bytes=n_gru * (6 * row + 6 * row), flops=0)
     c["k_gemm_panel<gru_dx>"] = dict(bytes=n_gru * (3 * row + row), flops=2 * n_gru * 3 * D * D)
     c["k_gemm_panel<gru_dprev>"] = dict(bytes=n_gru * (3 * row + 3 * row), flops=2 * n_gru * 3 * D * D)
