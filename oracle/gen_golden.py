@@ -575,7 +575,34 @@ def gen_G12():
     save("G12_static_rgcn", **out)
 
 
-ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12)
+def gen_G13():
+    """evaluate(): filtered ranks + classification loss (models/DynamicRGCN.py:118-144,196-220,
+    models/BiDynamicRGCN.py:146-208, utils/evaluation.py:34-106)."""
+    from models.DynamicRGCN import DynamicRGCN
+    from models.BiDynamicRGCN import BiDynamicRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    for name, cls, module, rec_only, seed, idx in (("G13_eval_uni", DynamicRGCN, 'GRRGCN', True, 701, [14, 8, 2]),
+                                                  ("G13_eval_bi", BiDynamicRGCN, 'BiGRRGCN', True, 702, [21, 12, 6])):
+        D, B, L = 32, 16, 6
+        args = rh.make_args(module=module, rec_only_last_layer=rec_only, hidden_size=D, embed_size=D, n_bases=B,
+                            train_seq_len=L, test_seq_len=L, batch_size=4, negative_rate=20)
+        cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=False)
+        model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
+        m = cls(args, num_e, num_r, tr, va, te_g)
+        m.load_state_dict(to_ref_state_dict(model), strict=True)
+        t_list = [int(times[i]) for i in idx]
+        out = dict(module=module, rec_only=int(rec_only), D=D, B=B, seed=seed, L=L, te=0, neg=20, t_list=np.array(t_list),
+                   param_checksum=checksum(model))
+        with torch.no_grad():
+            for split, val in (("val", True), ("test", False)):
+                ranks, loss = m.evaluate(torch.tensor(t_list), val=val)
+                out["ranks_" + split] = ranks
+                out["loss_" + split] = float(loss)
+        save(name, **out)
+
+
+ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13)
 
 if __name__ == "__main__":
     rh.activate()

@@ -226,6 +226,32 @@ class DynamicRGCN(TKG_Module):
         gid = torch.from_numpy(g.gids).to(dev)
         return all_embeds.index_copy(0, gid, convoluted_embeds)
 
+    def evaluate(self, t_list, val=True):
+        """models/DynamicRGCN.py:118-144,196-220: window encoder on the full train graphs, then filtered
+        ranks of the valid (or test) triples of every target timestamp + their classification loss.
+        (The reference skips graphs without triples WITHOUT advancing its history index; here the index
+        always follows the window.)"""
+        from .evaluation import EvaluationFilter
+        if not hasattr(self, "evaluater"):
+            self.evaluater = EvaluationFilter(self.args, self.calc_score, self.graph_dict_train, self.graph_dict_val, self.graph_dict_test)
+        graph_dict = self.graph_dict_val if val else self.graph_dict_test
+        dev = self._device()
+        with torch.no_grad():
+            per_graph, plan, rows, graphs, hist = self.encode(t_list, self.test_seq_len, train=False)
+            ranks, losses = [], []
+            for i, ent_embed in enumerate(per_graph):
+                t = rows[i][-1]
+                g = graph_dict[t]
+                if g.number_of_edges() == 0:
+                    continue
+                all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, plan, i, hist)
+                index_sample = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(dev)
+                label = torch.ones(index_sample.shape[0], device=dev)
+                ranks.append(self.evaluater.calc_metrics_single_graph(ent_embed, self.rel_embeds, all_embeds_g, index_sample, g, t))
+                losses.append(self.link_classification_loss(ent_embed, self.rel_embeds, index_sample, label).item())
+        ranks = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
+        return ranks, (float(np.mean(losses)) if losses else float("nan"))
+
     def forward(self, t_list, reverse=False, target_edge_ids=None, samples=None):
         """models/DynamicRGCN.py:176-194.  `target_edge_ids` / `samples` inject the random draws
         (SURVEY F11); by default they are sampled here."""

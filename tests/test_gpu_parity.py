@@ -228,3 +228,9 @@ def test_batched_equals_generic_gpu(name):
 
 def test_static_rgcn_golden_gpu():
     check_static(DEV)
+
+
+@pytest.mark.parametrize("name", ["G13_eval_uni", "G13_eval_bi"])
+def test_evaluate_ranks_golden_gpu(name):
+    from tests.window_cases import check_evaluate
+    check_evaluate(name, DEV)

@@ -9,7 +9,7 @@ from temp_amd import backend as TB
 from temp_amd.window import ChainPlan, window_times
 from tests.cpu_backend import CpuTestBackend
 from tests.golden_util import load
-from tests.window_cases import check_batched_equals_generic, check_static, check_window, slice_snapshots
+from tests.window_cases import check_batched_equals_generic, check_evaluate, check_static, check_window, slice_snapshots
 from oracle import temp_oracle as O
 
 
@@ -77,3 +77,8 @@ def test_batched_equals_generic(name):
 
 def test_static_rgcn_golden():
     check_static(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", ["G13_eval_uni", "G13_eval_bi"])
+def test_evaluate_ranks_golden(name):
+    check_evaluate(name, torch.device("cpu"))

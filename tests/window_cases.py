@@ -147,3 +147,22 @@ def check_static(device):
     loss = m(torch.tensor(tl))            # end-to-end with its own sampler: finite, differentiable
     loss.backward()
     assert torch.isfinite(loss) and m.ent_embeds.grad.abs().sum() > 0
+
+
+def check_evaluate(name, device):
+    """evaluate(): ranks and loss against the reference's own evaluate() on the ICEWS14 slice (G13)."""
+    z = load(name)
+    m = build_window_model(z, device)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    for split, val in (("val", True), ("test", False)):
+        ranks, loss = m.evaluate(t_list, val=val)
+        want = T(z["ranks_" + split]).long()
+        assert ranks.shape == want.shape
+        # sigmoid(score) in fp32 has real ties near 0.5; the reference breaks them by the (unstable) order
+        # torch.sort happens to produce, so individual ranks may differ by the size of a tie group
+        got = ranks.cpu()
+        assert (got == want).float().mean().item() > 0.75, (name, split)
+        assert (got - want).abs().max().item() <= 6, (name, split)
+        mrr_g, mrr_w = (1.0 / got.float()).mean().item(), (1.0 / want.float()).mean().item()
+        assert abs(mrr_g - mrr_w) < 2e-3 * mrr_w, (name, split, mrr_g, mrr_w)
+        assert abs(loss - float(z["loss_" + split])) < 2e-5 * max(1.0, abs(float(z["loss_" + split])))
