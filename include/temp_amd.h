@@ -233,6 +233,33 @@ int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float
 int temp_gather_rows(int n, int d, const float* table, const int32_t* idx, float* out, void* stream);
 int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, float* table, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Plain fp32 MFMA GEMMs (the extra (n,D)@(D,D) terms of the linear-recurrence layers,
+ * models/RRGCN.py:141, models/BiRRGCN.py:128-129; the all-entity score matrix below).
+ *   temp_linear    C[M,N] = A[M,K] . B          B is [K,N] (trans_b = 0) or stored as [N,K] (trans_b = 1)
+ *   temp_linear_tn out[Ka,Nb] = A[M,Ka]^T . B[M,Nb]      (deterministic split over M)
+ * K, N, Ka, Nb and all leading dimensions must be multiples of 4.
+ * ---------------------------------------------------------------------------------------------- */
+int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, void* stream);
+size_t temp_linear_tn_workspace(int M, int Ka, int Nb);
+int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Link-prediction loss (TKG_Module.train_link_prediction, models/TKG_Module.py:202-213;
+ * utils/scores.py:4-44).  DistMult and ComplEx are bilinear in (query, candidate), so the scores of
+ * the P positives against ALL N entities are ONE GEMM  scores = query[P,D] . all_embeds[N,D]^T
+ * (temp_linear, trans_b = 1); the reference instead gathers a (P, 1+neg, D) tensor (1.2 GB at
+ * P = 3000, neg = 500).  These two calls do the cross-entropy with label 0 over cand[P,C]
+ * (column 0 = the true entity, global ids):
+ *   fwd: loss_rows[p] = logsumexp_k scores[p, cand[p,k]] - scores[p, cand[p,0]];  lse_rows saved
+ *   bwd: d_scores[P,N] (fully written) = scale[0] * inv_rows * sum_k (softmax_k - [k==0]) e_{cand[p,k]}
+ *        (`scale` is a DEVICE float: the upstream gradient of the mean loss)
+ * ---------------------------------------------------------------------------------------------- */
+int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* cand, float* loss_rows, float* lse_rows, void* stream);
+int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* cand, const float* lse_rows, const float* scale,
+                       float inv_rows, float* d_scores, void* stream);
+
 /* Device-memory bandwidth probe used by bench.py to calibrate the achievable HBM peak
  * (float4 copy of `bytes` bytes, dst and src must not overlap). */
 int temp_copy_probe(const void* src, void* dst, size_t bytes, void* stream);

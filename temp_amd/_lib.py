@@ -67,6 +67,11 @@ SYMBOLS = {
     "temp_gru_weight_grads": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
+    "temp_linear": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, _I, c_vp, _I, c_vp]),
+    "temp_linear_tn_workspace": (_SZ, [_I, _I, _I]),
+    "temp_linear_tn": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, c_vp, _I, c_vp, _SZ, c_vp]),
+    "temp_gather_ce_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_gather_ce_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp]),
     "temp_copy_probe": (_I, [c_vp, c_vp, _SZ, c_vp]),
     "temp_trace_begin": (_I, [_I]),
     "temp_trace_end": (_I, [c_i32p, c_f32p, _I, c_i32p]),

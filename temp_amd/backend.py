@@ -216,6 +216,45 @@ class HipBackend:
         _lib.check(rc, "temp_gru_weight_grads")
         return d_w_ih, d_w_hh, d_b_ih, d_b_hh
 
+    # ---- plain GEMMs + candidate cross-entropy (link-prediction loss) ---------------------------------
+    def linear(self, a, b, trans_b):
+        """a[M,K] . b  (b is [K,N], or [N,K] when trans_b)."""
+        a, b = _f32(a, "a"), _f32(b, "b")
+        M, K = a.shape
+        N = b.shape[0] if trans_b else b.shape[1]
+        c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        rc = self.lib.temp_linear(M, N, K, _ptr(a), K, _ptr(b), b.shape[1], int(trans_b), _ptr(c), N, _stream())
+        _lib.check(rc, "temp_linear")
+        return c
+
+    def linear_tn(self, a, b):
+        """a[M,Ka]^T . b[M,Nb] -> [Ka,Nb]."""
+        a, b = _f32(a, "a"), _f32(b, "b")
+        M, Ka = a.shape
+        Nb = b.shape[1]
+        out = torch.empty(Ka, Nb, dtype=torch.float32, device=a.device)
+        ws = self._ws(self.lib.temp_linear_tn_workspace(M, Ka, Nb), a.device)
+        rc = self.lib.temp_linear_tn(M, Ka, Nb, _ptr(a), Ka, _ptr(b), Nb, _ptr(out), Nb, _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_linear_tn")
+        return out
+
+    def gather_ce_fwd(self, scores, cand):
+        scores, cand = _f32(scores, "scores"), _i32(cand, "cand")
+        P, N = scores.shape
+        loss = torch.empty(P, dtype=torch.float32, device=scores.device)
+        lse = torch.empty(P, dtype=torch.float32, device=scores.device)
+        rc = self.lib.temp_gather_ce_fwd(P, cand.shape[1], N, _ptr(scores), _ptr(cand), _ptr(loss), _ptr(lse), _stream())
+        _lib.check(rc, "temp_gather_ce_fwd")
+        return loss, lse
+
+    def gather_ce_bwd(self, scores, cand, lse, scale, inv_rows):
+        scores, cand, lse, scale = _f32(scores, "scores"), _i32(cand, "cand"), _f32(lse, "lse"), _f32(scale, "scale")
+        P, N = scores.shape
+        d = torch.empty_like(scores)
+        rc = self.lib.temp_gather_ce_bwd(P, cand.shape[1], N, _ptr(scores), _ptr(cand), _ptr(lse), _ptr(scale), float(inv_rows), _ptr(d), _stream())
+        _lib.check(rc, "temp_gather_ce_bwd")
+        return d
+
     # ---- row gather / scatter ---------------------------------------------------------------------
     def gather_rows(self, table, idx):
         table, idx = _f32(table, "table"), _i32(idx, "idx")

@@ -314,6 +314,67 @@ __global__ void __launch_bounds__(256) k_scatter_add_rows(int n, int d, const fl
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Link-prediction loss over candidate lists (TKG_Module.train_link_prediction, models/TKG_Module.py:202-213):
+// the scores of every positive against ALL entities come from one MFMA GEMM (query . all_embeds^T);
+// these kernels pick the 1 + negative_rate candidates of each row out of that matrix and do the
+// cross-entropy with label 0 -- nothing of shape (P, 1+neg, D) is ever materialised.
+// One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_ce_fwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
+                                                       float* __restrict__ loss_rows, float* __restrict__ lse_rows) {
+  __shared__ float red[256];
+  const int p = blockIdx.x;
+  const float* srow = scores + (size_t)p * N;
+  const int32_t* crow = cand + (size_t)p * C;
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < C; k += 256) mx = fmaxf(mx, srow[crow[k]]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int k = threadIdx.x; k < C; k += 256) sum += expf(srow[crow[k]] - mx);
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float lse = mx + logf(red[0]);
+    lse_rows[p] = lse;
+    loss_rows[p] = lse - srow[crow[0]];
+  }
+}
+
+// d_scores[p, :] = scale * sum_k (softmax_k - [k == 0]) e_{cand[p,k]}   (row built in LDS, written once)
+__global__ void __launch_bounds__(256) k_gather_ce_bwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
+                                                       const float* __restrict__ lse_rows, const float* __restrict__ scale_ptr, float inv_rows,
+                                                       float* __restrict__ d_scores) {
+  extern __shared__ float row[];
+  const int p = blockIdx.x;
+  for (int i = threadIdx.x; i < N; i += 256) row[i] = 0.f;
+  __syncthreads();
+  const float* srow = scores + (size_t)p * N;
+  const int32_t* crow = cand + (size_t)p * C;
+  const float lse = lse_rows[p];
+  const float scale = scale_ptr[0] * inv_rows;
+  for (int k = threadIdx.x; k < C; k += 256) {
+    const int e = crow[k];
+    float g = expf(srow[e] - lse);
+    if (k == 0) g -= 1.f;
+    atomicAdd(&row[e], g * scale);
+  }
+  __syncthreads();
+  float* drow = d_scores + (size_t)p * N;
+  for (int i = threadIdx.x; i < N; i += 256) drow[i] = row[i];
+}
+
 __global__ void __launch_bounds__(256) k_copy(size_t n16, const float4* __restrict__ src, float4* __restrict__ dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -381,7 +442,8 @@ const char* temp_trace_kernel_name(int id) {
   static const char* names[] = {"k_rgcn_agg<fwd>", "k_rgcn_agg<dx>", "k_rgcn_dw", "k_fixup", "k_gemm_panel<loop_fwd>",
                                 "k_gemm_panel<loop_dx>", "k_gemm_tn", "k_reduce_slices", "k_colsum_part", "k_relu_bwd", "k_gru_fwd",
                                 "k_gru_bwd_gates", "k_gemm_panel<gru_dx>", "k_gemm_panel<gru_dprev>", "k_gather_rows",
-                                "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>", "k_gemm_panel<gru_gi>"};
+                                "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>", "k_gemm_panel<gru_gi>",
+                                "k_gemm_panel<linear>", "k_gather_ce"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -457,6 +519,49 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
   int grid = ceil_div((long long)n * d, 256);
   if (grid > 4096) grid = 4096;
   TEMP_LAUNCH(K_SCATTER_ADD, k_scatter_add_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, d, src, idx, table);
+  return launch_status();
+}
+
+struct EpiPlainStore {
+  float* out; int ldo;
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
+  __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
+  __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const { st4(out + (size_t)row * ldo + col, acc); }
+};
+
+int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || !B || (M > 0 && (!A || !C))) return TEMP_E_BADARG;
+  if (ldc % 4) return TEMP_E_UNSUPPORTED;
+  return launch_gemm_panel(K_GEMM_LINEAR, M, N, K, A, lda, nullptr, B, ldb, trans_b, EpiPlainStore{C, ldc}, (hipStream_t)stream);
+}
+
+size_t temp_linear_tn_workspace(int M, int Ka, int Nb) { return (M < 0 || Ka <= 0 || Nb <= 0) ? 0 : gemm_tn_workspace(M, Ka, Nb) + 256; }
+
+int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  if (M < 0 || Ka <= 0 || Nb <= 0 || !out || (M > 0 && (!A || !B))) return TEMP_E_BADARG;
+  if (!workspace || workspace_bytes < temp_linear_tn_workspace(M, Ka, Nb)) return TEMP_E_WORKSPACE;
+  return gemm_tn(M, Ka, Nb, A, lda, B, ldb, out, ldo, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* cand, float* loss_rows, float* lse_rows, void* stream) {
+  if (P < 0 || C <= 0 || N <= 0 || (P > 0 && (!scores || !cand || !loss_rows || !lse_rows))) return TEMP_E_BADARG;
+  if (P == 0) return TEMP_OK;
+  TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_fwd, dim3(P), dim3(256), 0, (hipStream_t)stream, C, N, scores, cand, loss_rows, lse_rows);
+  return launch_status();
+}
+
+int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* cand, const float* lse_rows, const float* scale,
+                       float inv_rows, float* d_scores, void* stream) {
+  if (P < 0 || C <= 0 || N <= 0 || !scale || (P > 0 && (!scores || !cand || !lse_rows || !d_scores))) return TEMP_E_BADARG;
+  if ((size_t)N * sizeof(float) > 160 * 1024 - 1024) return TEMP_E_UNSUPPORTED;
+  if (P == 0) return TEMP_OK;
+  const size_t lds = (size_t)N * sizeof(float);
+  if (lds > 65536) {
+    if (hipFuncSetAttribute((const void*)k_gather_ce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEMP_E_LAUNCH;
+  }
+  TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_bwd, dim3(P), dim3(256), lds, (hipStream_t)stream, C, N, scores, cand, lse_rows, scale, inv_rows, d_scores);
   return launch_status();
 }
 

@@ -113,3 +113,31 @@ class _GatherRowsFn(torch.autograd.Function):
 def gather_rows(table, idx):
     """out[i] = table[idx[i]] (idx int32, -1 => zero row); backward scatter-adds."""
     return _GatherRowsFn.apply(table, idx)
+
+
+class _CandidateCEFn(torch.autograd.Function):
+    """mean_p CE(query[p] . all_embeds[cand[p, :]]^T, label 0) without materialising (P, C, D)."""
+
+    @staticmethod
+    def forward(ctx, query, all_embeds, cand):
+        be = get_backend()
+        scores = be.linear(query, all_embeds, True)                  # (P, N): every positive against ALL entities
+        loss_rows, lse = be.gather_ce_fwd(scores, cand)
+        ctx.save_for_backward(query, all_embeds, scores, lse, cand)
+        return loss_rows.mean()
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        query, all_embeds, scores, lse, cand = ctx.saved_tensors
+        be = get_backend()
+        d_scores = be.gather_ce_bwd(scores, cand, lse, d_loss.reshape(1).contiguous(), 1.0 / max(scores.shape[0], 1))
+        d_query = be.linear(d_scores, all_embeds, False)             # (P,N) . (N,D)
+        d_all = be.linear_tn(d_scores, query)                        # (N,P) . (P,D)
+        return d_query, d_all, None
+
+
+def candidate_cross_entropy(query, all_embeds, cand):
+    """F.cross_entropy(score(query, all_embeds[cand]), 0) for scorers that are bilinear in
+    (query, candidate) -- DistMult and ComplEx (utils/scores.py:4-44).  cand: int32 (P, C), column 0
+    is the true entity."""
+    return _CandidateCEFn.apply(query, all_embeds, cand)

@@ -61,3 +61,18 @@ def simple(head, head_inv, rel, rel_inv, tail, tail_inv, mode='tail'):
         a = _dot_candidates(head * rel, tail_inv, mode)
         b = _dot_candidates(head_inv * rel_inv, tail, mode)
     return (a + b) / 2
+
+
+def bilinear_query(name, known, relation, mode):
+    """Fold the known entity and the relation into ONE query vector q such that
+    score(candidate) = <q, candidate>.  `known` is the subject for mode='tail' (candidates are
+    objects) and the object for mode='head'.  Returns None for scorers that are not bilinear (transE)."""
+    if name == "distmult":
+        return known * relation
+    if name == "complex":
+        re_r, im_r = _split(relation)
+        re_k, im_k = _split(known)
+        if mode == "head":
+            return torch.cat([re_r * re_k + im_r * im_k, re_r * im_k - im_r * re_k], dim=-1)
+        return torch.cat([re_k * re_r - im_k * im_r, re_k * im_r + im_k * re_r], dim=-1)
+    return None

@@ -51,6 +51,30 @@ class StaticRGCN(TKG_Module):
         gid = torch.from_numpy(g.gids).to(self.ent_embeds.device)
         return all_embeds.index_copy(0, gid, convoluted_embeds)
 
+    def evaluate(self, t_list, val=True):
+        """baselines/StaticRGCN.py:20-34,91-113: full train graphs -> embeddings, filtered ranks of the
+        valid/test triples + classification loss."""
+        from .evaluation import EvaluationFilter
+        if not hasattr(self, "evaluater"):
+            self.evaluater = EvaluationFilter(self.args, self.calc_score, self.graph_dict_train, self.graph_dict_val, self.graph_dict_test)
+        graph_dict = self.graph_dict_val if val else self.graph_dict_test
+        dev = self.ent_embeds.device
+        ts = [int(t) for t in t_list]
+        with torch.no_grad():
+            per_graph = self.get_per_graph_ent_embeds(ts, [self.graph_dict_train[t] for t in ts], val=True)
+            ranks, losses = [], []
+            for t, ent_embed in zip(ts, per_graph):
+                g = graph_dict[t]
+                if g.number_of_edges() == 0:
+                    continue
+                all_embeds_g = self.get_all_embeds_Gt(t, g, ent_embed)
+                index_sample = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(dev)
+                label = torch.ones(index_sample.shape[0], device=dev)
+                ranks.append(self.evaluater.calc_metrics_single_graph(ent_embed, self.rel_embeds, all_embeds_g, index_sample, g, t))
+                losses.append(self.link_classification_loss(ent_embed, self.rel_embeds, index_sample, label).item())
+        ranks = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
+        return ranks, (float(np.mean(losses)) if losses else float("nan"))
+
     def forward(self, t_list, target_edge_ids=None, samples=None):
         """baselines/StaticRGCN.py:36-46."""
         dev = self.ent_embeds.device

@@ -28,6 +28,7 @@ class TKG_Module(nn.Module):
         self.num_pos_facts = args.num_pos_facts
         self.negative_rate = args.negative_rate
         self.calc_score = {'distmult': scores.distmult, 'complex': scores.complex, 'transE': scores.transE}[args.score_function]
+        self.fused_loss = True
         self.build_model()
         if not getattr(args, "debug", False):
             self.corrupter = CorruptTriples(self.args, graph_dict_train)
@@ -55,7 +56,16 @@ class TKG_Module(nn.Module):
 
     # -- loss (models/TKG_Module.py:202-221) ----------------------------------------------------------
     def train_link_prediction(self, ent_embed, triplets, neg_samples, labels, all_embeds_g, corrupt_tail=True):
+        """models/TKG_Module.py:202-213.  DistMult / ComplEx take the fused path: ONE GEMM of the
+        folded query against all entities + a candidate cross-entropy kernel, instead of gathering
+        a (P, 1+neg, D) tensor; other scorers use the tensor-algebra path."""
         r = self.rel_embeds[triplets[:, 1]]
+        name = self.args.score_function
+        if self.fused_loss and name in ("distmult", "complex") and all_embeds_g.shape[0] % 4 == 0 and triplets.shape[0] > 0:
+            from . import functional as TF
+            known = ent_embed[triplets[:, 0]] if corrupt_tail else ent_embed[triplets[:, 2]]
+            q = scores.bilinear_query(name, known, r, "tail" if corrupt_tail else "head")
+            return TF.candidate_cross_entropy(q.contiguous(), all_embeds_g.contiguous(), neg_samples.to(torch.int32).contiguous())
         if corrupt_tail:
             score = self.calc_score(ent_embed[triplets[:, 0]], r, all_embeds_g[neg_samples], mode='tail')
         else:

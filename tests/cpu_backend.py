@@ -212,6 +212,26 @@ class CpuTestBackend:
             d_x.copy_(torch.mm(dgi, w_ih.detach()))
         return torch.mm(dgi.t(), x.detach()), torch.mm(dgh.t(), hdec), dgi.sum(0), dgh.sum(0)
 
+    # ---- plain GEMMs + candidate cross-entropy ------------------------------------------------
+    def linear(self, a, b, trans_b):
+        return torch.mm(a.detach(), b.detach().t() if trans_b else b.detach())
+
+    def linear_tn(self, a, b):
+        return torch.mm(a.detach().t(), b.detach())
+
+    def gather_ce_fwd(self, scores, cand):
+        logits = scores.detach().gather(1, cand.long())
+        lse = torch.logsumexp(logits, dim=1)
+        return lse - logits[:, 0], lse
+
+    def gather_ce_bwd(self, scores, cand, lse, scale, inv_rows):
+        c = cand.long()
+        g = torch.exp(scores.detach().gather(1, c) - lse.view(-1, 1))
+        g[:, 0] -= 1.0
+        d = torch.zeros_like(scores)
+        d.scatter_add_(1, c, g * (scale.reshape(-1)[0] * inv_rows))
+        return d
+
     # ---- rows -----------------------------------------------------------------------------------
     def gather_rows(self, table, idx):
         i = idx.long()

@@ -234,3 +234,24 @@ def test_static_rgcn_golden_gpu():
 def test_evaluate_ranks_golden_gpu(name):
     from tests.window_cases import check_evaluate
     check_evaluate(name, DEV)
+
+
+@pytest.mark.parametrize("P,C,N,D", [(1, 3, 8, 8), (200, 51, 7128, 32), (3000, 501, 500, 200), (17, 501, 500, 200)])
+def test_candidate_cross_entropy_vs_torch(P, C, N, D, hip_backend):
+    """Fused link-prediction loss (one GEMM against all entities + candidate CE kernel) vs the
+    reference formulation: gather (P, C, D) candidates, DistMult-style dot, F.cross_entropy(label 0)."""
+    import torch.nn.functional as F
+    from temp_amd import functional as TF
+    rng = np.random.default_rng(P + C + N)
+    q = torch.from_numpy(rng.standard_normal((P, D)).astype(np.float32) * 0.5).to(DEV).requires_grad_(True)
+    E = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32) * 0.5).to(DEV).requires_grad_(True)
+    cand = torch.from_numpy(rng.integers(0, N, (P, C)).astype(np.int32)).to(DEV)        # duplicates inside a row happen
+    loss = TF.candidate_cross_entropy(q, E, cand)
+    loss.backward()
+    q2, E2 = q.detach().clone().requires_grad_(True), E.detach().clone().requires_grad_(True)
+    score = (q2.unsqueeze(1) * E2[cand.long()]).sum(-1)
+    want = F.cross_entropy(score, torch.zeros(P, dtype=torch.int64, device=DEV))
+    want.backward()
+    assert abs(loss.item() - want.item()) < 2e-5 * max(1.0, abs(want.item()))
+    assert_close(q.grad, q2.grad, 2e-5, 2e-6, "d_query")
+    assert_close(E.grad, E2.grad, 2e-5, 2e-6, "d_all_embeds")

@@ -147,6 +147,8 @@ def check_static(device):
     loss = m(torch.tensor(tl))            # end-to-end with its own sampler: finite, differentiable
     loss.backward()
     assert torch.isfinite(loss) and m.ent_embeds.grad.abs().sum() > 0
+    ranks, ev_loss = m.evaluate(torch.tensor(tl))
+    assert ranks.numel() > 0 and int(ranks.min()) >= 1 and int(ranks.max()) <= s["num_e"] and np.isfinite(ev_loss)
 
 
 def check_evaluate(name, device):
