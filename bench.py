@@ -171,6 +171,9 @@ def main():
                          "visits of a global batch of bsz*N windows sharded across ranks with an all-gather of per-snapshot "
                          "node states before the recurrent chain (north_star variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-loss", action="store_true",
+                    help="also run the all-entity pass + scorer + cross-entropy (negative_rate 500, fixed negatives) in the step "
+                         "(reported separately from the headline encoder-only metric, SURVEY 8d)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel trace table to stderr")
     a = ap.parse_args()
 
@@ -214,7 +217,13 @@ def main():
     else:
         model.sample_rng = np.random.default_rng(2 + rank)
         wb = model.prepare(targets, w["L"], train=True)
-        run = lambda: model.run(wb)[0]
+        if a.with_loss:
+            from temp_amd.sampling import CorruptTriples
+            model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5 + rank)
+            fixed = [tuple(x.to(device) for x in smp) for smp in model.draw_samples(wb)]
+            run = lambda: model.run_loss(wb, fixed)
+        else:
+            run = lambda: model.run(wb)[0]
     torch.cuda.synchronize()
     prepare_s = time.perf_counter() - t0
 
@@ -284,7 +293,7 @@ def main():
         cpu = cpu_baseline(model, w, targets)
 
     if rank == 0:
-        out = dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=%d" % w["L"], value=value, unit="edges/s", n_gpus=world,
+        out = dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=%d%s" % (w["L"], " + link-prediction loss" if a.with_loss else ""), value=value, unit="edges/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=w["name"], encoder=w["module"], rec_only_last_layer=True, seq_len=w["L"],

@@ -255,18 +255,27 @@ class DynamicRGCN(TKG_Module):
     def forward(self, t_list, reverse=False, target_edge_ids=None, samples=None):
         """models/DynamicRGCN.py:176-194.  `target_edge_ids` / `samples` inject the random draws
         (SURVEY F11); by default they are sampled here."""
+        wb = self.prepare(t_list, self.train_seq_len, True, target_edge_ids)
+        return self.run_loss(wb, samples)
+
+    def draw_samples(self, wb):
+        """Negative samples of every target graph of a prepared batch (host side)."""
+        return [self.corrupter.single_graph_negative_sampling(wb.rows[i][-1], g, self.num_ents)[:3] for i, g in enumerate(wb.graphs)]
+
+    def run_loss(self, wb, samples=None):
+        """Encoder pass + the per-window link-prediction losses (summed, as the reference does)."""
         dev = self._device()
-        per_graph, plan, rows, graphs, hist = self.encode(t_list, self.train_seq_len, True, target_edge_ids)
+        out, hist = self.run(wb)
+        per_graph = list(out.split(wb.target.sizes))
+        if samples is None:
+            samples = self.draw_samples(wb)
         loss = 0
-        for i, (g, ent_embed) in enumerate(zip(graphs, per_graph)):
-            t = rows[i][-1]
-            if samples is not None:
-                triplets, neg_tail, neg_head = samples[i]
-                labels = torch.zeros(triplets.shape[0], dtype=torch.int64)
-            else:
-                triplets, neg_tail, neg_head, labels = self.corrupter.single_graph_negative_sampling(t, g, self.num_ents)
-            triplets, neg_tail, neg_head, labels = triplets.to(dev), neg_tail.to(dev), neg_head.to(dev), labels.to(dev)
-            all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, plan, i, hist)
+        for i, (g, ent_embed) in enumerate(zip(wb.graphs, per_graph)):
+            t = wb.rows[i][-1]
+            triplets, neg_tail, neg_head = samples[i]
+            triplets, neg_tail, neg_head = triplets.to(dev), neg_tail.to(dev), neg_head.to(dev)
+            labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=dev)
+            all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, wb.plan, i, hist)
             loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
             loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False)
         return loss
