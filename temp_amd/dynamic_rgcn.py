@@ -262,6 +262,40 @@ class DynamicRGCN(TKG_Module):
         """Negative samples of every target graph of a prepared batch (host side)."""
         return [self.corrupter.single_graph_negative_sampling(wb.rows[i][-1], g, self.num_ents)[:3] for i, g in enumerate(wb.graphs)]
 
+    def _all_maps(self, wb):
+        """Row maps / time gaps of ALL entities for every window of the batch, concatenated
+        (bsz * N_ents), cached on the batch: inputs of the batched isolated pass."""
+        if getattr(wb, "all_maps", None) is None:
+            dev = self._device()
+            plans = wb.plan if isinstance(wb.plan, tuple) else (wb.plan,)
+            L = plans[0].seq_len
+            maps = []
+            for plan in plans:
+                idx = np.concatenate([plan.final_all(b, L - 1)[0] for b in range(plan.bsz)]).astype(np.int32)
+                dt = np.concatenate([plan.final_all(b, L - 1)[1] for b in range(plan.bsz)]).astype(np.float32)
+                maps.append((torch.from_numpy(idx).to(dev), torch.from_numpy(dt).view(-1, 1).to(dev)))
+            wb.all_maps = maps
+            wb.gid_dev = [torch.from_numpy(g.gids).to(dev) for g in wb.graphs]
+        return wb.all_maps
+
+    def all_embeds_batched(self, wb, per_graph, hist):
+        """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64): with only the last
+        layer recurrent the isolated RGCN trunk e -> Iso2(Iso1(e)) is the same for every window, so it
+        runs ONCE over the N_ents entities; the GRU then runs once over bsz * N_ents rows, each window
+        reading its own previous states through its row map.  Returns a list of (N_ents, D)."""
+        enc = self.ent_encoder
+        l1, l2 = enc.layer_1, enc.layer_2
+        bsz = len(per_graph)
+        (idx, dt), = self._all_maps(wb)
+        y1 = l1.conv_isolated(self.ent_embeds)
+        x = l2.conv_isolated(y1).repeat(bsz, 1)
+        H = hist[1]
+        prev = H if H is not None else x.new_zeros(1, x.shape[1])
+        pidx = idx if H is not None else torch.full_like(idx, -1)
+        allh = run_rnn(l2.rnn, x, prev, dt, l2.inv_temperature, l2.decay_spec(), pidx)
+        N = self.num_ents
+        return [allh[b * N:(b + 1) * N].index_copy(0, wb.gid_dev[b], per_graph[b]) for b in range(bsz)]
+
     def run_loss(self, wb, samples=None):
         """Encoder pass + the per-window link-prediction losses (summed, as the reference does)."""
         dev = self._device()
@@ -269,13 +303,16 @@ class DynamicRGCN(TKG_Module):
         per_graph = list(out.split(wb.target.sizes))
         if samples is None:
             samples = self.draw_samples(wb)
+        batched = (wb.batched and not self.ent_encoder.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
+                   and getattr(self.ent_encoder.layer_2, "num_layers", 1) == 1)
+        all_list = self.all_embeds_batched(wb, per_graph, hist) if batched else None
         loss = 0
         for i, (g, ent_embed) in enumerate(zip(wb.graphs, per_graph)):
             t = wb.rows[i][-1]
             triplets, neg_tail, neg_head = samples[i]
             triplets, neg_tail, neg_head = triplets.to(dev), neg_tail.to(dev), neg_head.to(dev)
             labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=dev)
-            all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, wb.plan, i, hist)
+            all_embeds_g = all_list[i] if batched else self.get_all_embeds_Gt(ent_embed, g, t, wb.plan, i, hist)
             loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
             loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False)
         return loss
