@@ -175,6 +175,7 @@ def main():
                     help="also run the all-entity pass + scorer + cross-entropy (negative_rate 500, fixed negatives) in the step "
                          "(reported separately from the headline encoder-only metric, SURVEY 8d)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel trace table to stderr")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the step as a captured HIP graph")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -227,12 +228,44 @@ def main():
     torch.cuda.synchronize()
     prepare_s = time.perf_counter() - t0
 
-    def step():
+    def step_eager():
         for p in params:
             p.grad = None
         run().sum().backward()
         if dist is not None:
             allreduce_gradients(params, world, average=not sharded)
+
+    # The window batch is static, so the whole forward+backward of a step (~130 launches) is captured
+    # once into a HIP graph and replayed: no host launch overhead between the small per-position kernels.
+    # The gradient all-reduce stays outside the graph.
+    graph = None
+    if not a.no_graph and not sharded:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    for p in params:
+                        p.grad = None
+                    run().sum().backward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for p in params:
+                p.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                run().sum().backward()
+            torch.cuda.synchronize()
+        except Exception as e:                      # capture is an optimisation only
+            print("bench: HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            graph = None
+
+    def step():
+        if graph is None:
+            return step_eager()
+        graph.replay()
+        if dist is not None:
+            allreduce_gradients(params, world, average=True)
 
     for _ in range(a.warmup):
         step()
@@ -259,7 +292,7 @@ def main():
     roof = None
     cpu = None
     if rank == 0 and a.trace_steps > 0 and not sharded:
-        tr = traced_steps(step, a.trace_steps, lib)
+        tr = traced_steps(step_eager, a.trace_steps, lib)        # per-kernel events need eager launches
         costs = algorithmic_costs(wb, w["D"], bi, w["D"] // w["B"])
         total_ms = sum(v["ms_per_step"] for v in tr.values())
         dom = max(tr, key=lambda k: tr[k]["ms_per_step"])
@@ -302,7 +335,7 @@ def main():
                                edge_visits_per_step_per_gpu=wb.n_edge_visits, node_visits_per_step_per_gpu=wb.n_node_visits,
                                distinct_snapshot_edges_per_step=getattr(wb, "n_edges_distinct", None), targets=targets,
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
-                               else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s),
+                               else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager")),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out))
     if dist is not None:
