@@ -59,13 +59,17 @@ class TKG_Module(nn.Module):
         """models/TKG_Module.py:202-213.  DistMult / ComplEx take the fused path: ONE GEMM of the
         folded query against all entities + a candidate cross-entropy kernel, instead of gathering
         a (P, 1+neg, D) tensor; other scorers use the tensor-algebra path."""
-        r = self.rel_embeds[triplets[:, 1]]
         name = self.args.score_function
         if self.fused_loss and name in ("distmult", "complex") and all_embeds_g.shape[0] % 4 == 0 and triplets.shape[0] > 0:
             from . import functional as TF
-            known = ent_embed[triplets[:, 0]] if corrupt_tail else ent_embed[triplets[:, 2]]
+            t32 = triplets.to(torch.int32)
+            # row gathers through the HIP kernel: its backward is one atomic scatter-add instead of
+            # torch's sort-based index_put (the single largest cost of the loss path otherwise)
+            r = TF.gather_rows(self.rel_embeds, t32[:, 1].contiguous())
+            known = TF.gather_rows(ent_embed, (t32[:, 0] if corrupt_tail else t32[:, 2]).contiguous())
             q = scores.bilinear_query(name, known, r, "tail" if corrupt_tail else "head")
             return TF.candidate_cross_entropy(q.contiguous(), all_embeds_g.contiguous(), neg_samples.to(torch.int32).contiguous())
+        r = self.rel_embeds[triplets[:, 1]]
         if corrupt_tail:
             score = self.calc_score(ent_embed[triplets[:, 0]], r, all_embeds_g[neg_samples], mode='tail')
         else:
