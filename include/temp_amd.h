@@ -260,6 +260,34 @@ int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* 
 int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* cand, const float* lse_rows, const float* scale,
                        float inv_rows, float* d_scores, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * History attention of the self-attention encoder (SARGCNLayer.calc_result + attention,
+ * models/SARGCN.py:25-53; callers models/SARGCN.py:39-62, models/SelfAttentionRGCN.py:88-96).
+ * The reference builds a dense (n, T, D) tensor [history ..., current] (zero rows + a -10e9 additive
+ * mask where a node was inactive) and projects all of it; here K / V are projected once per distinct
+ * (snapshot, node) row into a table and every query row lists its active history rows:
+ *   idx[i, t] (t < T-1) = row of the history table or -1 (masked: softmax weight exactly 0)
+ *   position T-1 is the row's own current K / V (kc, vc).
+ *   s[i,h,t] = <q[i,h,:], K[t][h,:]> / sqrt(d_k) + decay[t];  p = softmax_t;  o[i,h,:] = sum_t p V[t][h,:]
+ *   out[i, d * heads + h] = o[i,h,d]      (the reference's transpose after squeeze, SARGCN.py:37)
+ * heads must be 8 (SARGCN.py:21), D % 8 == 0, D <= 512, T <= 64.
+ * fwd saves score [n, heads, T] (raw s, -inf where masked) and lse [n, heads] for bwd.
+ * bwd: d_q / d_kc / d_vc fully written; d_kh / d_vh ACCUMULATED with atomics (zero them first; rows are
+ * shared between query rows); d_decay [T] accumulated when non-NULL.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct TempAttn {
+  int32_t n, D, heads, T;
+  const float* q;  int32_t ldq;                     /* [n, D] query projections */
+  const float* kh; const float* vh; int32_t ldh;    /* history table K / V rows */
+  const float* kc; const float* vc; int32_t ldc;    /* current-position K / V, row i */
+  const int32_t* idx;                               /* [n, T-1] */
+  const float* decay;                               /* [T] additive score bias or NULL */
+} TempAttn;
+int temp_sa_attn_fwd(const TempAttn* p, float* out, float* score, float* lse, void* stream);
+int temp_sa_attn_bwd(const TempAttn* p, const float* out, const float* score, const float* lse, const float* d_out,
+                     float* d_q, int ld_dq, float* d_kh, float* d_vh, int ld_dh, float* d_kc, float* d_vc, int ld_dc,
+                     float* d_decay, void* stream);
+
 /* Device-memory bandwidth probe used by bench.py to calibrate the achievable HBM peak
  * (float4 copy of `bytes` bytes, dst and src must not overlap). */
 int temp_copy_probe(const void* src, void* dst, size_t bytes, void* stream);

@@ -69,6 +69,9 @@ def to_ref_state_dict(model, type1=False):
                 sd[p + k] = d[k]
         if d.get('h_bias') is not None:
             sd[p + 'h_bias'] = d['h_bias']
+        for name in ('q_linear', 'k_linear', 'v_linear'):
+            if name in d:
+                sd[p + name + '.weight'] = d[name]
         for name in ('rnn', 'forward_rnn', 'backward_rnn'):
             if name in d:
                 for li, q in enumerate(d[name]):
@@ -602,7 +605,79 @@ def gen_G13():
         save(name, **out)
 
 
-ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13)
+def gen_G14():
+    """Self-attention models (config 5): SelfAttentionRGCN / BiSelfAttentionRGCN forward loss + grads
+    (models/SelfAttentionRGCN.py:122-140, models/BiSelfAttentionRGCN.py:48-69, models/SARGCN.py)."""
+    from models.SelfAttentionRGCN import SelfAttentionRGCN
+    from models.BiSelfAttentionRGCN import BiSelfAttentionRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    T = lambda idx: [int(times[i]) for i in idx]
+    for name, cls, module, rec_only, learn, seed, idx, L in (
+            ("G14_sa_uni_rol", SelfAttentionRGCN, 'SARGCN', True, False, 801, [18, 11, 3], 6),
+            ("G14_sa_uni", SelfAttentionRGCN, 'SARGCN', False, True, 802, [20, 9, 1], 5),
+            ("G14_sa_bi_rol", BiSelfAttentionRGCN, 'BiSARGCN', True, False, 803, [19, 12, 4], 5)):
+        out = _run_window_sa(cls, module, rec_only, learn, 32, 16, seed, T(idx), L, 20)
+        save(name, **out)
+
+
+def _run_window_sa(cls, module, rec_only, learn, D, B, seed, t_list, L, neg):
+    num_e, num_r, tr, va, te_g = graphs()
+    args = rh.make_args(module=module, rec_only_last_layer=rec_only, hidden_size=D, embed_size=D, n_bases=B, train_seq_len=L,
+                        test_seq_len=L, batch_size=4, negative_rate=neg, learnable_lambda=learn, EMA=False)
+    cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=True, learnable_lambda=learn)
+    model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
+    if learn:
+        for ln in ('layer_1', 'layer_2'):
+            model['ent_encoder'][ln]['exponential_decay'] = (torch.full((1, 1), 0.25), torch.full((1,), -0.1))
+    torch.manual_seed(0)
+    m = cls(args, num_e, num_r, tr, va, te_g)
+    missing = m.load_state_dict(to_ref_state_dict(model), strict=False)
+    assert not missing.unexpected_keys, missing
+    assert all('exponential_decay' in k for k in missing.missing_keys) or not missing.missing_keys, missing
+    np.random.seed(seed)
+    choices, samples = [], []
+    orig_choice = np.random.choice
+
+    def rec_choice(*a, **k):
+        r = orig_choice(*a, **k)
+        choices.append(np.asarray(r).copy())
+        return r
+
+    orig_neg = m.corrupter.single_graph_negative_sampling
+
+    def rec_neg(t, g, n):
+        res = orig_neg(t, g, n)
+        samples.append([x.clone() for x in res[:3]])
+        return res
+
+    m.corrupter.single_graph_negative_sampling = rec_neg
+    np.random.choice = rec_choice
+    try:
+        loss = m(torch.tensor(t_list))
+    finally:
+        np.random.choice = orig_choice
+    loss.backward()
+    times = list(tr.keys())
+    out = dict(module=module, rec_only=int(rec_only), learn=int(learn), D=D, B=B, seed=seed, L=L, neg=neg, te=1,
+               t_list=np.array(t_list), times=np.array(times), loss=loss.item(), param_checksum=checksum(model),
+               n_choices=len(choices), n_samples=len(samples))
+    for i, c in enumerate(choices):
+        out['choice_%d' % i] = c
+    for i, (trip, nt, nh) in enumerate(samples):
+        out['trip_%d' % i], out['negtail_%d' % i], out['neghead_%d' % i] = trip, nt, nh
+    eg = m.ent_embeds.grad
+    nz = torch.nonzero(eg.abs().sum(1)).view(-1)
+    out['d_ent_nz_rows'] = nz
+    out['d_ent_nz_vals'] = eg[nz]
+    out['d_rel'] = m.rel_embeds.grad
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            out['gabs_' + k] = v.grad.double().abs().sum().item()
+    return out
+
+
+ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14)
 
 if __name__ == "__main__":
     rh.activate()

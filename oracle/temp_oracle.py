@@ -747,6 +747,12 @@ def init_model(cfg, num_ents, num_rels, num_times, D, seed=1, bias=False):
             elif mod == 'BiRRGCN':
                 d['time_weight_forward'] = _xavier(rng, D, D)
                 d['time_weight_backward'] = _xavier(rng, D, D)
+            elif mod in ('SARGCN', 'BiSARGCN'):
+                k = 1.0 / math.sqrt(D)
+                for nm in ('q_linear', 'v_linear', 'k_linear'):
+                    d[nm] = torch.from_numpy(rng.uniform(-k, k, size=(D, D)).astype(np.float32))
+        if mod in ('SARGCN', 'BiSARGCN'):
+            d['h_bias'] = torch.from_numpy(rng.uniform(-0.3, 0.3, D).astype(np.float32))
         return d
 
     rec1 = (mod != 'SRGCN') and not cfg.get('rec_only_last_layer', False)
@@ -779,6 +785,9 @@ def model_from_state_dict(sd, cfg):
         for name in ('time_weight', 'time_weight_forward', 'time_weight_backward'):
             if p + name in sd:
                 d[name] = sd[p + name]
+        for name in ('q_linear', 'k_linear', 'v_linear'):
+            if p + name + '.weight' in sd:
+                d[name] = sd[p + name + '.weight']
         if p + 'exponential_decay.weight' in sd:
             d['exponential_decay'] = (sd[p + 'exponential_decay.weight'], sd[p + 'exponential_decay.bias'])
         enc[ln] = d
@@ -808,3 +817,142 @@ def leaf_tensors(model, prefix=''):
         for i, v in enumerate(model):
             out.update(leaf_tensors(v, prefix + str(i) + '.'))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# a23: self-attention encoder (models/SARGCN.py, models/SelfAttentionRGCN.py,
+#      models/BiSelfAttentionRGCN.py) -- config 5
+# Layer dict gains: q_linear, k_linear, v_linear (D,D) (nn.Linear weights, no bias).
+# --------------------------------------------------------------------------------------
+def sa_attention(layer, cfg, cur, prev, time_diff, mask, heads=8):
+    """SARGCNLayer.calc_result + attention, models/SARGCN.py:25-53: q from the current state, K/V
+    from [history..., current] (T positions), `heads` heads of d_k = D // heads,
+    softmax(q.K^T / sqrt(d_k) + mask + decay) . V.   cur (n,D), prev (n,T-1,D), mask (n,T)."""
+    n, D = cur.shape
+    d_k = D // heads
+    if cfg.get('learnable_lambda'):
+        w, b = layer['exponential_decay']
+        decay = -torch.clamp(time_diff.view(-1, 1) * w.view(1, 1) + b.view(1, 1), min=0).view(-1)
+    else:
+        decay = 0
+    all_t = torch.cat([prev, cur.unsqueeze(1)], dim=1)
+    q = torch.mm(cur, layer['q_linear'].t()).view(n, 1, heads, d_k).transpose(1, 2)
+    k = torch.matmul(all_t, layer['k_linear'].t()).view(n, -1, heads, d_k).transpose(1, 2)
+    v = torch.matmul(all_t, layer['v_linear'].t()).view(n, -1, heads, d_k).transpose(1, 2)
+    scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(d_k)                 # (n,h,1,T)
+    p = F.softmax(scores.squeeze(2) + mask.unsqueeze(1) + decay, dim=-1)          # (n,h,T)
+    out = torch.matmul(p.unsqueeze(2), v).squeeze(2)                                # (n,h,d_k)
+    # models/SARGCN.py:37: the squeeze() in `attention` dropped the length-1 query axis, so the
+    # reference's transpose(1, 2) swaps (heads, d_k): output feature index = d * heads + head.
+    return out.transpose(1, 2).contiguous().view(n, D)
+
+
+def sargcn_forward(enc, cfg, g, h0, times, node_sizes):
+    """SARGCN.forward, models/SARGCN.py:103-107: plain 2-layer RGCN (bias, L2 ReLU); the time
+    embeddings are added to the RETURNED states only (layer 2 consumes layer 1's plain output)."""
+    l1, l2 = enc['layer_1'], enc['layer_2']
+    y1 = rgcn_layer(h0, g, l1['weight'], l1['loop_weight'], cfg['n_bases'], l1.get('h_bias'), None)
+    y2 = rgcn_layer(y1, g, l2['weight'], l2['loop_weight'], cfg['n_bases'], l2.get('h_bias'), 'relu')
+    return y1 + time_embedding_rows(l1['time_embed'], times, node_sizes), y2 + time_embedding_rows(l2['time_embed'], times, node_sizes), y1
+
+
+def sargcn_forward_final(enc, cfg, g, h0, prev1, prev2, time_diff, mask, times, node_sizes):
+    """SARGCN.forward_final, models/SARGCN.py:109-117."""
+    l1, l2 = enc['layer_1'], enc['layer_2']
+    f, s, y1 = sargcn_forward(enc, cfg, g, h0, times, node_sizes)
+    second = sa_attention(l2, cfg, s, prev2, time_diff, mask)
+    if cfg['rec_only_last_layer']:
+        return second
+    first = sa_attention(l1, cfg, f, prev1, time_diff, mask)
+    return torch.max(torch.stack([first, second], dim=-1), dim=-1)[0]
+
+
+def sargcn_isolated(enc, cfg, e, prev1, prev2, time_diff, mask, t):
+    """SARGCN.forward_isolated, models/SARGCN.py:119-125 with SARGCNLayer.forward_isolated :55-62."""
+    l1, l2 = enc['layer_1'], enc['layer_2']
+    y1 = rgcn_layer_isolated(e, l1['loop_weight'], l1.get('h_bias'), None)
+    if cfg['rec_only_last_layer']:
+        first = y1
+    else:
+        first = sa_attention(l1, cfg, y1 + l1['time_embed'][int(t)], prev1, time_diff, mask)
+    y2 = rgcn_layer_isolated(first, l2['loop_weight'], l2.get('h_bias'), 'relu')
+    second = sa_attention(l2, cfg, y2 + l2['time_embed'][int(t)], prev2, time_diff, mask)
+    return second if cfg['rec_only_last_layer'] else torch.max(torch.stack([first, second], dim=-1), dim=-1)[0]
+
+
+def sa_pre_forward(model, cfg, graph_dict, time_batched_list, seq_len, with_current):
+    """SelfAttentionRGCN.pre_forward (models/SelfAttentionRGCN.py:97-120) / the Bi variant
+    (models/BiSelfAttentionRGCN.py:25-46): dense hist (L-1,bsz,2,N,D) and additive mask
+    (L or L-1, bsz, N) = -10e9 except where a node was active."""
+    ent = model['ent_embeds']
+    bsz = len(time_batched_list[0])
+    N, D = ent.shape
+    hist = torch.zeros(seq_len - 1, bsz, 2, N, D, dtype=ent.dtype)
+    mask = torch.zeros(seq_len if with_current else seq_len - 1, bsz, N, dtype=ent.dtype) - 10e9
+    if with_current:
+        mask[-1] = 0
+    for cur_t in range(seq_len - 1):
+        ts = _filter_none(time_batched_list[cur_t])
+        if not ts:
+            continue
+        graphs = [graph_dict[t] for t in ts]
+        sizes = [g.n for g in graphs]
+        bg = batch_graphs(graphs)
+        f, s, _ = sargcn_forward(model['ent_encoder'], cfg, bg, ent[bg.ids], ts, sizes)
+        for i, (fi, si) in enumerate(zip(f.split(sizes), s.split(sizes))):
+            idx = graphs[i].ids
+            mask[cur_t][i][idx] = 0
+            hist[cur_t][i][0][idx] = fi
+            hist[cur_t][i][1][idx] = si
+    return hist, mask
+
+
+def sa_encode(model, cfg, graph_dict, t_list, times, seq_len, target_graphs, bi=False):
+    """History passes + the attention over them for the target graphs (the part of
+    SelfAttentionRGCN.forward / BiSelfAttentionRGCN.forward before the losses,
+    models/SelfAttentionRGCN.py:122-129, models/BiSelfAttentionRGCN.py:48-59).
+    -> (per-graph target embeddings, target times, hist, mask, time_diff)."""
+    ent = model['ent_embeds']
+    if not bi:
+        tbl = get_batch_graph_list(t_list, seq_len, times)
+        hist, mask = sa_pre_forward(model, cfg, graph_dict, tbl, seq_len, True)
+        td = torch.arange(seq_len - 1, -1, -1, dtype=ent.dtype)
+        target_times = tbl[-1]
+    else:
+        tf, tb = get_batch_graph_list_bi(t_list, seq_len, times)
+        hf, mf = sa_pre_forward(model, cfg, graph_dict, tf, seq_len, False)
+        hb, mb = sa_pre_forward(model, cfg, graph_dict, tb, seq_len, False)
+        hb, mb = torch.flip(hb, [1]), torch.flip(mb, [1])
+        hist = torch.cat([hf, hb], dim=0)
+        mask = torch.cat([mf, mb, mf.new_zeros(1, *mf.shape[1:])], dim=0)
+        r = list(range(seq_len - 1, 0, -1))
+        td = torch.tensor(r + r + [0.], dtype=ent.dtype)
+        target_times = tf[-1]
+    sizes = [g.n for g in target_graphs]
+    bg = batch_graphs(target_graphs)
+    p1 = torch.cat([hist[:, i, 0][:, g.ids] for i, g in enumerate(target_graphs)], dim=1).transpose(0, 1)
+    p2 = torch.cat([hist[:, i, 1][:, g.ids] for i, g in enumerate(target_graphs)], dim=1).transpose(0, 1)
+    lm = torch.cat([mask[:, i][:, g.ids] for i, g in enumerate(target_graphs)], dim=1).transpose(0, 1)
+    out = sargcn_forward_final(model['ent_encoder'], cfg, bg, ent[bg.ids], p1, p2, td, lm, target_times, sizes)
+    return list(out.split(sizes)), target_times, hist, mask, td
+
+
+def sa_all_embeds(model, cfg, graph_dict, i, t, emb, hist, mask, td):
+    """SelfAttentionRGCN.get_all_embeds_Gt, models/SelfAttentionRGCN.py:28-45."""
+    all_e = sargcn_isolated(model['ent_encoder'], cfg, model['ent_embeds'], hist[:, i, 0].transpose(0, 1),
+                            hist[:, i, 1].transpose(0, 1), td, mask[:, i].transpose(0, 1), t)
+    return all_e.index_copy(0, graph_dict[t].ids, emb)
+
+
+def sa_forward_loss(model, cfg, graph_dict, t_list, times, seq_len, target_graphs, samples, bi=False, score='complex'):
+    """SelfAttentionRGCN.forward / BiSelfAttentionRGCN.forward (models/SelfAttentionRGCN.py:122-140,
+    models/BiSelfAttentionRGCN.py:48-69), targets / negatives injected."""
+    per_graph, target_times, hist, mask, td = sa_encode(model, cfg, graph_dict, t_list, times, seq_len, target_graphs, bi)
+    fn = SCORERS[score]
+    loss = 0
+    for i, (t, emb) in enumerate(zip(target_times, per_graph)):
+        trip, neg_tail, neg_head = samples[i]
+        all_e = sa_all_embeds(model, cfg, graph_dict, i, t, emb, hist, mask, td)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_tail, all_e, True)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_head, all_e, False)
+    return loss, per_graph

@@ -41,6 +41,12 @@ class TempGruCellBwd(ctypes.Structure):
                 ("w_hh", c_vp), ("dgi", c_vp), ("dgh", c_vp), ("decv", c_vp), ("d_prev", c_vp)]
 
 
+class TempAttn(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("D", ctypes.c_int32), ("heads", ctypes.c_int32), ("T", ctypes.c_int32),
+                ("q", c_vp), ("ldq", ctypes.c_int32), ("kh", c_vp), ("vh", c_vp), ("ldh", ctypes.c_int32),
+                ("kc", c_vp), ("vc", c_vp), ("ldc", ctypes.c_int32), ("idx", c_vp), ("decay", c_vp)]
+
+
 # name -> (restype, argtypes); mirrors include/temp_amd.h one to one
 _G = ctypes.POINTER(TempGraph)
 _I, _F, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -72,6 +78,8 @@ SYMBOLS = {
     "temp_linear_tn": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, c_vp, _I, c_vp, _SZ, c_vp]),
     "temp_gather_ce_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gather_ce_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp]),
+    "temp_sa_attn_fwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp]),
+    "temp_sa_attn_bwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp]),
     "temp_copy_probe": (_I, [c_vp, c_vp, _SZ, c_vp]),
     "temp_trace_begin": (_I, [_I]),
     "temp_trace_end": (_I, [c_i32p, c_f32p, _I, c_i32p]),

@@ -255,6 +255,53 @@ class HipBackend:
         _lib.check(rc, "temp_gather_ce_bwd")
         return d
 
+    # ---- history attention (self-attention encoder) ------------------------------------------------------
+    def _attn_desc(self, qkv, kv_hist, idx, decay):
+        n, D3 = qkv.shape
+        D = D3 // 3
+        T = idx.shape[1] + 1
+        if T > 1 and kv_hist.shape[1] != 2 * D:
+            raise _lib.TempAmdError("kv_hist must be [R, 2D]")
+        a = _lib.TempAttn()
+        a.n, a.D, a.heads, a.T = n, D, 8, T
+        base = qkv.data_ptr()
+        a.q, a.ldq = base, D3
+        a.kc, a.vc, a.ldc = base + 4 * D, base + 8 * D, D3
+        if T > 1:
+            hb = kv_hist.data_ptr()
+            a.kh, a.vh, a.ldh = hb, hb + 4 * D, 2 * D
+        a.idx = idx.data_ptr() if T > 1 else None
+        a.decay = decay.data_ptr() if decay is not None else None
+        return a, n, D, T
+
+    def sa_attn_fwd(self, qkv, kv_hist, idx, decay):
+        """qkv [n,3D] = (q | k | v) of the query rows; kv_hist [R,2D] = (k | v) history table;
+        idx [n,T-1] int32 rows of the table (-1 masked); decay [T] or None -> (out, score, lse)."""
+        qkv, kv_hist, idx, decay = _f32(qkv, "qkv"), _f32(kv_hist, "kv_hist"), _i32(idx, "idx"), _f32(decay, "decay")
+        a, n, D, T = self._attn_desc(qkv, kv_hist, idx, decay)
+        out = torch.empty(n, D, dtype=torch.float32, device=qkv.device)
+        score = torch.empty(n, 8, T, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(n, 8, dtype=torch.float32, device=qkv.device)
+        rc = self.lib.temp_sa_attn_fwd(ctypes.byref(a), _ptr(out), _ptr(score), _ptr(lse), _stream())
+        _lib.check(rc, "temp_sa_attn_fwd")
+        return out, score, lse
+
+    def sa_attn_bwd(self, qkv, kv_hist, idx, decay, out, score, lse, d_out):
+        """-> (d_qkv [n,3D], d_kv_hist [R,2D], d_decay [T] or None)."""
+        qkv, kv_hist, idx, decay = _f32(qkv, "qkv"), _f32(kv_hist, "kv_hist"), _i32(idx, "idx"), _f32(decay, "decay")
+        d_out = _f32(d_out, "d_out")
+        a, n, D, T = self._attn_desc(qkv, kv_hist, idx, decay)
+        d_qkv = torch.empty_like(qkv)
+        d_hist = torch.zeros_like(kv_hist)
+        d_decay = torch.zeros(T, dtype=torch.float32, device=qkv.device) if decay is not None else None
+        db, dh = d_qkv.data_ptr(), d_hist.data_ptr()
+        vp = ctypes.c_void_p
+        rc = self.lib.temp_sa_attn_bwd(ctypes.byref(a), _ptr(out), _ptr(score), _ptr(lse), _ptr(d_out),
+                                       vp(db), 3 * D, vp(dh), vp(dh + 4 * D), 2 * D, vp(db + 4 * D), vp(db + 8 * D), 3 * D,
+                                       _ptr(d_decay), _stream())
+        _lib.check(rc, "temp_sa_attn_bwd")
+        return d_qkv, d_hist, d_decay
+
     # ---- row gather / scatter ---------------------------------------------------------------------
     def gather_rows(self, table, idx):
         table, idx = _f32(table, "table"), _i32(idx, "idx")

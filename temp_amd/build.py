@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtemp_amd.so")
-SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip"]
+SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip", "attn_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_panel.hpp"), os.path.join(REPO, "include", "temp_amd.h")]
 
 

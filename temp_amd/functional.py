@@ -5,6 +5,8 @@ Each Function is one reference op with its hand-written backward:
   rgcn_isolated   RGCNLayer.forward_isolated   models/RGCN.py:78-89
   gru_step        decay + single GRU step      models/RRGCN.py:79-85, models/GRU_cell.py:18-30
   gather_rows     ent_embeds[id] / history gather   models/DynamicRGCN.py:41-43,93
+  linear          nn.Linear without bias (q/k/v projections)   models/SARGCN.py:16-18,32-34
+  history_attention   SARGCNLayer.attention over the active history rows   models/SARGCN.py:25-53
 """
 import torch
 
@@ -141,3 +143,50 @@ def candidate_cross_entropy(query, all_embeds, cand):
     (query, candidate) -- DistMult and ComplEx (utils/scores.py:4-44).  cand: int32 (P, C), column 0
     is the true entity."""
     return _CandidateCEFn.apply(query, all_embeds, cand)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x . W^T (W stored (out, in) like nn.Linear.weight) through the MFMA panel GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return get_backend().linear(x, w, True)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, w = ctx.saved_tensors
+        be = get_backend()
+        d_y = d_y.contiguous()
+        d_x = be.linear(d_y, w, False) if ctx.needs_input_grad[0] else None
+        d_w = be.linear_tn(d_y, x) if ctx.needs_input_grad[1] else None
+        return d_x, d_w
+
+
+def linear(x, w):
+    return _LinearFn.apply(x, w)
+
+
+class _HistoryAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, kv_hist, idx, decay):
+        out, score, lse = get_backend().sa_attn_fwd(qkv, kv_hist, idx, decay)
+        ctx.save_for_backward(qkv, kv_hist, idx, decay if decay is not None else qkv.new_zeros(0), out, score, lse)
+        ctx.has_decay = decay is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, kv_hist, idx, decay, out, score, lse = ctx.saved_tensors
+        d_qkv, d_hist, d_decay = get_backend().sa_attn_bwd(qkv, kv_hist, idx, decay if ctx.has_decay else None, out, score, lse,
+                                                           d_out.contiguous())
+        return d_qkv, d_hist, None, d_decay
+
+
+def history_attention(qkv, kv_hist, idx, decay=None):
+    """8-head attention of every query row over its active history rows + itself.
+    qkv (n,3D) = [q | k | v] projections of the query rows' current states; kv_hist (R,2D) = [k | v]
+    projections of the history table; idx (n,T-1) int32 rows of the table, -1 => masked;
+    decay (T,) additive score bias (already negated / clamped) or None.
+    Returns (n,D) in the reference's feature order (d * 8 + head)."""
+    return _HistoryAttentionFn.apply(qkv, kv_hist, idx, decay)

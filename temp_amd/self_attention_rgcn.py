@@ -1,0 +1,198 @@
+"""SelfAttentionRGCN / BiSelfAttentionRGCN -- the attention window models with the reference's
+interface (models/SelfAttentionRGCN.py:13-180, models/BiSelfAttentionRGCN.py:10-95): same
+constructor, `.forward(t_list) -> loss`, `.evaluate(t_list)`, same parameter names.
+
+Reference data flow: every history position of every window runs the 2-layer RGCN again and writes
+its states into a dense (L-1, bsz, 2, N_ents, D) tensor (+ a (L, bsz, N_ents) additive mask); the
+target pass and the all-entity pass then attend over dense (n, T, D) gathers of it.
+
+Here none of the history visits is recurrent, so the whole step is
+  1. ONE 2-layer RGCN pass over the union of the DISTINCT snapshots the windows touch (history
+     snapshots once each, however many windows / directions share them, then the subsampled targets),
+  2. ONE K/V projection GEMM per attention layer over the history rows of that pass (the table),
+  3. the sparse history-attention kernel for the target rows and for the bsz * N_ents all-entity rows,
+     each row listing its active history rows through an int32 map built on the host (membership is
+     static).
+T = L positions (uni: time_diff L-1..0) or 2(L-1)+1 (bi: forward history, backward history, current;
+time_diff L-1..1, L-1..1, 0).
+"""
+import numpy as np
+import torch
+
+from . import functional as TF
+from . import snapshot as S
+from .dynamic_rgcn import DynamicRGCN, WindowBatch
+from .sargcn import SARGCN, jk_max
+from .window import window_times
+
+
+class SelfAttentionRGCN(DynamicRGCN):
+    bidirectional = False
+
+    def __init__(self, args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type=None):
+        super().__init__(args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type)
+        self.EMA = getattr(args, "EMA", False)
+        if self.EMA:
+            raise NotImplementedError("--EMA (models/SARGCN.py:64-81 stops in pdb.set_trace()) is outside the hot-path scope")
+        if getattr(args, "random_dropout", False):
+            raise NotImplementedError("--random-dropout (per-visit edge subsampling of the history) is outside the hot-path scope")
+
+    def build_model(self):
+        self.ent_encoder = SARGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
+        self.register_buffer("time_diff_train", self._time_diff(self.train_seq_len), persistent=False)
+        self.register_buffer("time_diff_test", self._time_diff(self.test_seq_len), persistent=False)
+
+    def _time_diff(self, L):
+        """models/SelfAttentionRGCN.py:22-23 / models/BiSelfAttentionRGCN.py:19-20."""
+        if self.bidirectional:
+            r = list(range(L - 1, 0, -1))
+            return torch.tensor(r + r + [0.], dtype=torch.float32)
+        return torch.arange(L - 1, -1, -1, dtype=torch.float32)
+
+    # ---------------------------------------------------------------------------------------------------
+    def _history_times(self, t_list, seq_len):
+        """rows_f (target last) and, per window, the timestamps (or None) of its history positions in
+        the order the reference concatenates them."""
+        rows_f = window_times(t_list, seq_len, self.total_time)
+        hist = [list(r[:seq_len - 1]) for r in rows_f]
+        if self.bidirectional:
+            rows_b = window_times(t_list, seq_len, self.total_time, ascending=True)[::-1]      # flip -> forward batch order
+            assert [r[-1] for r in rows_b] == [r[-1] for r in rows_f]
+            hist = [h + list(r[:seq_len - 1]) for h, r in zip(hist, rows_b)]
+        return rows_f, hist
+
+    def prepare(self, t_list, seq_len, train=True, target_edge_ids=None):
+        dev = self._device()
+        N = self.num_ents
+        wb = WindowBatch()
+        wb.rows, wb.hist_times = self._history_times(t_list, seq_len)
+        wb.seq_len = seq_len
+        wb.graphs = [self.graph_dict_train[r[-1]] for r in wb.rows]
+        wb.targets = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
+        wb.target_sizes = [g.n for g in wb.targets]
+        wb.target_times = [r[-1] for r in wb.rows]
+        # distinct history snapshots, in first-use order
+        node_row, hist_graphs, hist_ts, off = {}, [], [], 0
+        for times in wb.hist_times:
+            for t in times:
+                if t is not None and t not in node_row:
+                    g = self.graph_dict_train[t]
+                    m = np.full(N, -1, dtype=np.int32)
+                    m[g.gids] = off + np.arange(g.n, dtype=np.int32)
+                    node_row[t] = m
+                    hist_graphs.append(g)
+                    hist_ts.append(t)
+                    off += g.n
+        wb.n_hist_rows = off
+        none_row = np.full(N, -1, dtype=np.int32)
+        idx_all = [np.stack([node_row[t] if t is not None else none_row for t in times], axis=1) if times
+                   else np.zeros((N, 0), np.int32) for times in wb.hist_times]                     # bsz x (N, Th)
+        idx_tgt = [idx_all[b][g.gids] for b, g in enumerate(wb.targets)]
+        all_graphs = hist_graphs + list(wb.targets)
+        wb.g_all = S.batch(all_graphs)
+        wb.g_all.device_graph(dev, 2 * self.num_rels)
+        as_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+        wb.ids_all = as_dev(wb.g_all.gids, np.int32)
+        wb.time_rows = as_dev(np.repeat(np.array(hist_ts + wb.target_times, dtype=np.int64), [g.n for g in all_graphs]), np.int32)
+        wb.idx_tgt = as_dev(np.concatenate(idx_tgt, axis=0), np.int32)
+        wb.idx_all = as_dev(np.concatenate(idx_all, axis=0), np.int32)
+        wb.all_time_rows = as_dev(np.repeat(np.array(wb.target_times, dtype=np.int64), N), np.int32)
+        wb.gid_dev = [torch.from_numpy(g.gids).to(dev) for g in wb.graphs]
+        wb.time_diff = self.time_diff_train if seq_len == self.train_seq_len else self._time_diff(seq_len).to(dev)
+        wb.batched = True
+        wb.n_edge_visits = int(sum(self.graph_dict_train[t].number_of_edges() for times in wb.hist_times for t in times if t is not None)
+                               + sum(g.number_of_edges() for g in wb.targets))
+        wb.n_edges_distinct = int(wb.g_all.number_of_edges())
+        wb.n_nodes_distinct = int(wb.g_all.n)
+        wb.n_node_visits = int(sum(self.graph_dict_train[t].n for times in wb.hist_times for t in times if t is not None)
+                               + sum(wb.target_sizes))
+        return wb
+
+    def run(self, wb):
+        """-> (target rows (sum n_b, D), (layer-1 K/V table or None, layer-2 K/V table))."""
+        enc = self.ent_encoder
+        l1, l2 = enc.layer_1, enc.layer_2
+        R = wb.n_hist_rows
+        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
+        y1 = l1.conv(wb.g_all, h0)
+        y2 = l2.conv(wb.g_all, y1)
+        s = y2 + TF.gather_rows(l2.time_embed, wb.time_rows)
+        kv2 = l2.project_kv(s[:R])
+        second = l2.attend(s[R:], kv2, wb.idx_tgt, wb.time_diff)
+        if enc.rec_only_last_layer:
+            return second, (None, kv2)
+        f = y1 + TF.gather_rows(l1.time_embed, wb.time_rows)
+        kv1 = l1.project_kv(f[:R])
+        first = l1.attend(f[R:], kv1, wb.idx_tgt, wb.time_diff)
+        return jk_max(first, second), (kv1, kv2)
+
+    def all_embeds_batched(self, wb, per_graph, tables):
+        """get_all_embeds_Gt for every window at once (models/SelfAttentionRGCN.py:28-45 with
+        SARGCN.forward_isolated, models/SARGCN.py:119-125) -> list of (N_ents, D)."""
+        enc = self.ent_encoder
+        l1, l2 = enc.layer_1, enc.layer_2
+        N, bsz = self.num_ents, len(per_graph)
+        if getattr(self.args, "use_embed_for_non_active", False):
+            alls = [self.ent_embeds] * bsz
+        else:
+            kv1, kv2 = tables
+            y1 = l1.conv_isolated(self.ent_embeds)
+            if enc.rec_only_last_layer:
+                y2 = l2.conv_isolated(y1).repeat(bsz, 1)
+                first = None
+            else:
+                cur1 = y1.repeat(bsz, 1) + TF.gather_rows(l1.time_embed, wb.all_time_rows)
+                first = l1.attend(cur1, kv1, wb.idx_all, wb.time_diff)
+                y2 = l2.conv_isolated(first)
+            cur2 = y2 + TF.gather_rows(l2.time_embed, wb.all_time_rows)
+            second = l2.attend(cur2, kv2, wb.idx_all, wb.time_diff)
+            allh = second if first is None else jk_max(first, second)
+            alls = [allh[b * N:(b + 1) * N] for b in range(bsz)]
+        return [a.index_copy(0, wb.gid_dev[b], per_graph[b]) for b, a in enumerate(alls)]
+
+    def encode(self, t_list, seq_len, train=True, target_edge_ids=None):
+        wb = self.prepare(t_list, seq_len, train, target_edge_ids)
+        out, tables = self.run(wb)
+        return list(out.split(wb.target_sizes)), wb, tables
+
+    def run_loss(self, wb, samples=None):
+        dev = self._device()
+        out, tables = self.run(wb)
+        per_graph = list(out.split(wb.target_sizes))
+        if samples is None:
+            samples = self.draw_samples(wb)
+        all_list = self.all_embeds_batched(wb, per_graph, tables)
+        loss = 0
+        for i, ent_embed in enumerate(per_graph):
+            triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
+            labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=dev)
+            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_list[i], corrupt_tail=True)
+            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_list[i], corrupt_tail=False)
+        return loss
+
+    def evaluate(self, t_list, val=True):
+        """models/SelfAttentionRGCN.py:142-180 (Bi: models/BiSelfAttentionRGCN.py:71-95)."""
+        from .evaluation import EvaluationFilter
+        if not hasattr(self, "evaluater"):
+            self.evaluater = EvaluationFilter(self.args, self.calc_score, self.graph_dict_train, self.graph_dict_val, self.graph_dict_test)
+        graph_dict = self.graph_dict_val if val else self.graph_dict_test
+        dev = self._device()
+        with torch.no_grad():
+            per_graph, wb, tables = self.encode(t_list, self.test_seq_len, train=False)
+            all_list = self.all_embeds_batched(wb, per_graph, tables)
+            ranks, losses = [], []
+            for i, ent_embed in enumerate(per_graph):
+                t = wb.rows[i][-1]
+                g = graph_dict[t]
+                if g.number_of_edges() == 0:
+                    continue
+                index_sample = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(dev)
+                label = torch.ones(index_sample.shape[0], device=dev)
+                ranks.append(self.evaluater.calc_metrics_single_graph(ent_embed, self.rel_embeds, all_list[i], index_sample, g, t))
+                losses.append(self.link_classification_loss(ent_embed, self.rel_embeds, index_sample, label).item())
+        ranks = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
+        return ranks, (float(np.mean(losses)) if losses else float("nan"))
+
+
+class BiSelfAttentionRGCN(SelfAttentionRGCN):
+    bidirectional = True

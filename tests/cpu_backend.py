@@ -232,6 +232,44 @@ class CpuTestBackend:
         d.scatter_add_(1, c, g * (scale.reshape(-1)[0] * inv_rows))
         return d
 
+    # ---- history attention (same sparse formulation as the kernel, dense torch ops) -------------------
+    @staticmethod
+    def _attn(qkv, kv_hist, idx, decay):
+        n, D = qkv.shape[0], qkv.shape[1] // 3
+        dk, T = D // 8, idx.shape[1] + 1
+        q, kc, vc = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        i = idx.long()
+        live = (i >= 0)
+        if T > 1:
+            g = kv_hist[i.clamp(min=0).reshape(-1)].view(n, T - 1, 2 * D) * live.unsqueeze(-1).to(qkv.dtype)
+            K = torch.cat([g[:, :, :D], kc.unsqueeze(1)], dim=1)
+            V = torch.cat([g[:, :, D:], vc.unsqueeze(1)], dim=1)
+        else:
+            K, V = kc.unsqueeze(1), vc.unsqueeze(1)
+        s = torch.einsum('nhd,nthd->nht', q.reshape(n, 8, dk), K.reshape(n, T, 8, dk)) / (dk ** 0.5)
+        if decay is not None:
+            s = s + decay.view(1, 1, T)
+        mask = torch.cat([live, live.new_ones(n, 1)], dim=1).unsqueeze(1)
+        s = s.masked_fill(~mask, float('-inf'))
+        p = torch.softmax(s, dim=-1)
+        o = torch.einsum('nht,nthd->nhd', p, V.reshape(n, T, 8, dk))
+        return o.transpose(1, 2).reshape(n, D), s, torch.logsumexp(s, dim=-1)
+
+    def sa_attn_fwd(self, qkv, kv_hist, idx, decay):
+        with torch.no_grad():
+            return self._attn(qkv.detach(), kv_hist.detach(), idx, decay.detach() if decay is not None else None)
+
+    def sa_attn_bwd(self, qkv, kv_hist, idx, decay, out, score, lse, d_out):
+        with torch.enable_grad():
+            a = qkv.detach().clone().requires_grad_(True)
+            b = kv_hist.detach().clone().requires_grad_(True)
+            c = decay.detach().clone().requires_grad_(True) if decay is not None else None
+            o, _, _ = self._attn(a, b, idx, c)
+            ins = [a, b] + ([c] if c is not None else [])
+            gs = torch.autograd.grad(o, ins, d_out.detach(), allow_unused=True)
+        d_hist = gs[1] if gs[1] is not None else torch.zeros_like(b)
+        return gs[0], d_hist, (gs[2] if c is not None else None)
+
     # ---- rows -----------------------------------------------------------------------------------
     def gather_rows(self, table, idx):
         i = idx.long()

@@ -255,3 +255,58 @@ def test_candidate_cross_entropy_vs_torch(P, C, N, D, hip_backend):
     assert abs(loss.item() - want.item()) < 2e-5 * max(1.0, abs(want.item()))
     assert_close(q.grad, q2.grad, 2e-5, 2e-6, "d_query")
     assert_close(E.grad, E2.grad, 2e-5, 2e-6, "d_all_embeds")
+
+
+# ---------------------------------------------------------------------------------------------
+# self-attention encoder (SARGCN, config 5): sparse history-attention kernel + window models (G14)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,R,T,D,decay", [(1, 1, 1, 8, False), (37, 50, 6, 32, True), (300, 2000, 15, 200, False),
+                                           (1000, 700, 29, 200, True), (65, 10, 4, 64, True), (33, 9, 3, 512, False)])
+def test_history_attention_kernel_vs_dense(n, R, T, D, decay, hip_backend):
+    """temp_sa_attn_fwd / _bwd against the dense softmax formulation (test backend) on random rows:
+    all-masked rows, repeated history rows, every per-lane column count (d_k = 1 .. 64)."""
+    rng = np.random.default_rng(n * 7 + T)
+    cpu = CpuTestBackend()
+    qkv = torch.from_numpy(rng.standard_normal((n, 3 * D)).astype(np.float32))
+    kvh = torch.from_numpy(rng.standard_normal((R, 2 * D)).astype(np.float32))
+    idx = rng.integers(0, R, (n, T - 1)).astype(np.int32)
+    idx[rng.random((n, T - 1)) < 0.6] = -1
+    if n > 2 and T > 1:
+        idx[0] = -1                                # only the current position is alive
+        idx[1] = 0                                 # every position reads the same history row
+    idx = torch.from_numpy(idx)
+    dec = torch.from_numpy(-rng.random(T).astype(np.float32)) if decay else None
+    d_out = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32))
+    dev = lambda t: t.to(DEV) if t is not None else None
+    out, score, lse = hip_backend.sa_attn_fwd(dev(qkv), dev(kvh), dev(idx), dev(dec))
+    w_out, w_score, w_lse = cpu.sa_attn_fwd(qkv, kvh, idx, dec)
+    assert_close(out, w_out, 1e-5, 2e-6, "attn out")
+    assert_close(lse, w_lse, 1e-5, 2e-6, "attn lse")
+    live = torch.isfinite(w_score)
+    assert torch.equal(torch.isfinite(score).cpu(), live)
+    assert_close(torch.where(live, score.cpu(), torch.zeros(())), torch.where(live, w_score, torch.zeros(())), 1e-5, 2e-6, "attn score")
+    g = hip_backend.sa_attn_bwd(dev(qkv), dev(kvh), dev(idx), dev(dec), out, score, lse, dev(d_out))
+    w = cpu.sa_attn_bwd(qkv, kvh, idx, dec, w_out, w_score, w_lse, d_out)
+    assert_close(g[0], w[0], 2e-5, 3e-6, "d_qkv")
+    assert_close(g[1], w[1], 2e-5, 3e-6, "d_kv_hist")
+    if decay:
+        assert_close(g[2], w[2], 5e-5, 2e-5, "d_decay")
+    else:
+        assert g[2] is None
+
+
+@pytest.mark.parametrize("name", ["G14_sa_uni_rol", "G14_sa_uni", "G14_sa_bi_rol"])
+def test_self_attention_window_golden_gpu(name):
+    from tests.window_cases import check_sa_window
+    check_sa_window(name, DEV)
+
+
+def test_self_attention_dense_api_gpu():
+    from tests.window_cases import check_sa_dense_api
+    check_sa_dense_api(DEV)
+
+
+@pytest.mark.parametrize("name", ["G14_sa_uni", "G14_sa_bi_rol"])
+def test_self_attention_evaluate_gpu(name):
+    from tests.window_cases import check_sa_evaluate
+    check_sa_evaluate(name, DEV)

@@ -318,3 +318,43 @@ def test_G12_static_rgcn():
         assert_close(e, z["emb_%d" % i], RT, AT, "G12 emb %d" % i)
     iso = O.static_rgcn_isolated(model["ent_encoder"], cfg, model["ent_embeds"][:200], tl[0])
     assert_close(iso, z["iso"], RT, AT, "G12 iso")
+
+
+@pytest.mark.parametrize("name", ["G14_sa_uni_rol", "G14_sa_uni", "G14_sa_bi_rol"])
+def test_G14_self_attention_window_loss_and_grads(name):
+    """Config 5 (SARGCN attention over the history window) against the reference's own
+    SelfAttentionRGCN / BiSelfAttentionRGCN forward + backward."""
+    z = load(name)
+    num_e, num_r, times, gd = slice_graphs()
+    cfg = dict(module=str(z["module"]), n_bases=int(z["B"]), inv_temperature=0.1, rec_only_last_layer=bool(z["rec_only"]),
+               use_time_embedding=True, learnable_lambda=bool(z["learn"]))
+    model = O.init_model(cfg, num_e, num_r, len(times), int(z["D"]), seed=int(z["seed"]))
+    if cfg["learnable_lambda"]:
+        for ln in ("layer_1", "layer_2"):
+            model["ent_encoder"][ln]["exponential_decay"] = (torch.full((1, 1), 0.25), torch.full((1,), -0.1))
+    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6
+    leaves = O.leaf_tensors(model)
+    for v in leaves.values():
+        v.requires_grad_(True)
+    tl, targets, samples = window_inputs(z, gd["train"])
+    loss, _ = O.sa_forward_loss(model, cfg, gd["train"], tl, times, int(z["L"]), targets, samples, bi=cfg["module"].startswith("Bi"))
+    assert abs(loss.item() - float(z["loss"])) < 2e-5 * abs(float(z["loss"]))
+    loss.backward()
+    eg = model["ent_embeds"].grad
+    rows = T(z["d_ent_nz_rows"]).long()
+    assert_close(eg[rows], z["d_ent_nz_vals"], 1e-4, 2e-6, name + " d_ent")
+    assert_close(model["rel_embeds"].grad, z["d_rel"], 1e-4, 2e-6, name + " d_rel")
+    checked = 0
+    for k, v in leaves.items():
+        if v.grad is None or not k.startswith("ent_encoder"):
+            continue
+        parts = k.split(".")
+        ref_key = k + ".weight" if parts[-1] in ("q_linear", "k_linear", "v_linear") else k
+        if parts[-2] == "exponential_decay":
+            ref_key = ".".join(parts[:-1] + ["weight" if parts[-1] == "0" else "bias"])
+        gk = "gabs_" + ref_key
+        if gk in z.files:
+            want = float(z[gk])
+            assert abs(v.grad.double().abs().sum().item() - want) < 2e-4 * max(want, 1e-3), (name, k, want)
+            checked += 1
+    assert checked >= 8, checked

@@ -9,7 +9,8 @@ from temp_amd import backend as TB
 from temp_amd.window import ChainPlan, window_times
 from tests.cpu_backend import CpuTestBackend
 from tests.golden_util import load
-from tests.window_cases import check_batched_equals_generic, check_evaluate, check_static, check_window, slice_snapshots
+from tests.window_cases import (check_batched_equals_generic, check_evaluate, check_sa_dense_api, check_sa_evaluate, check_sa_window,
+                                check_static, check_window, slice_snapshots)
 from oracle import temp_oracle as O
 
 
@@ -82,3 +83,17 @@ def test_static_rgcn_golden():
 @pytest.mark.parametrize("name", ["G13_eval_uni", "G13_eval_bi"])
 def test_evaluate_ranks_golden(name):
     check_evaluate(name, torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", ["G14_sa_uni_rol", "G14_sa_uni", "G14_sa_bi_rol"])
+def test_self_attention_window_golden(name):
+    check_sa_window(name, torch.device("cpu"))
+
+
+def test_self_attention_dense_api():
+    check_sa_dense_api(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", ["G14_sa_uni", "G14_sa_bi_rol"])
+def test_self_attention_evaluate(name):
+    check_sa_evaluate(name, torch.device("cpu"))

@@ -10,6 +10,7 @@ from oracle import temp_oracle as O
 from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
 from temp_amd.dataset import build_interpolation_snapshots
 from temp_amd.dynamic_rgcn import DynamicRGCN
+from temp_amd.self_attention_rgcn import BiSelfAttentionRGCN, SelfAttentionRGCN
 from temp_amd.static_rgcn import StaticRGCN
 from tests.golden_util import T, assert_close, checksum, load
 
@@ -42,6 +43,11 @@ def state_dict_from_oracle(model):
         for k in ('weight', 'loop_weight', 'time_embed', 'time_weight', 'time_weight_forward', 'time_weight_backward', 'h_bias'):
             if d.get(k) is not None:
                 sd[p + k] = d[k]
+        for k in ('q_linear', 'k_linear', 'v_linear'):
+            if k in d:
+                sd[p + k + '.weight'] = d[k]
+        if 'exponential_decay' in d:
+            sd[p + 'exponential_decay.weight'], sd[p + 'exponential_decay.bias'] = d['exponential_decay']
         for name in ('rnn', 'forward_rnn', 'backward_rnn'):
             if name in d:
                 for li, q in enumerate(d[name]):
@@ -168,3 +174,94 @@ def check_evaluate(name, device):
         mrr_g, mrr_w = (1.0 / got.float()).mean().item(), (1.0 / want.float()).mean().item()
         assert abs(mrr_g - mrr_w) < 2e-3 * mrr_w, (name, split, mrr_g, mrr_w)
         assert abs(loss - float(z["loss_" + split])) < 2e-5 * max(1.0, abs(float(z["loss_" + split])))
+
+
+def build_sa_model(z, device):
+    s = slice_snapshots()
+    module, rec_only, D, B, L, learn = str(z["module"]), bool(z["rec_only"]), int(z["D"]), int(z["B"]), int(z["L"]), bool(z["learn"])
+    cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=True, learnable_lambda=learn)
+    model = O.init_model(cfg, s["num_e"], s["num_r"], len(s["times"]), D, seed=int(z["seed"]))
+    if learn:
+        for ln in ("layer_1", "layer_2"):
+            model["ent_encoder"][ln]["exponential_decay"] = (torch.full((1, 1), 0.25), torch.full((1,), -0.1))
+    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6
+    args = make_args(module=module, rec_only_last_layer=rec_only, embed_size=D, hidden_size=D, n_bases=B, train_seq_len=L,
+                     test_seq_len=L, negative_rate=int(z["neg"]), learnable_lambda=learn, EMA=False)
+    cls = BiSelfAttentionRGCN if module.startswith("Bi") else SelfAttentionRGCN
+    m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
+    sd = state_dict_from_oracle(model)
+    if learn and rec_only:
+        sd.pop("ent_encoder.layer_1.exponential_decay.weight", None)
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all("exponential_decay" in k for k in missing.missing_keys), missing
+    return m.to(device), model, cfg
+
+
+def check_sa_window(name, device):
+    """SelfAttentionRGCN / BiSelfAttentionRGCN.forward: loss + gradients against the reference (G14)."""
+    z = load(name)
+    m, _, _ = build_sa_model(z, device)
+    edge_ids, samples = window_inputs(z)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    loss = m(t_list, target_edge_ids=edge_ids, samples=samples)
+    want = float(z["loss"])
+    assert abs(loss.item() - want) < 3e-5 * abs(want), (name, loss.item(), want)
+    loss.backward()
+    eg = m.ent_embeds.grad
+    rows = T(z["d_ent_nz_rows"]).long().to(device)
+    assert_close(eg[rows], z["d_ent_nz_vals"], 1e-4, 3e-6, name + " d_ent")
+    assert_close(m.rel_embeds.grad, z["d_rel"], 1e-4, 3e-6, name + " d_rel")
+    checked = 0
+    for k, v in m.named_parameters():
+        gk = "gabs_" + k
+        if gk in z.files and v.grad is not None:
+            want = float(z[gk])
+            got = v.grad.double().abs().sum().item()
+            assert abs(got - want) < 3e-4 * max(want, 1e-3), (name, k, got, want)
+            checked += 1
+    assert checked >= 9, checked
+    return m
+
+
+def check_sa_dense_api(device, seed=5):
+    """SARGCNLayer.calc_result / SARGCN.forward_isolated through the reference's DENSE signature
+    (history tensor + additive mask) against the oracle restatement."""
+    z = load("G14_sa_uni")
+    m, model, cfg = build_sa_model(z, device)
+    g = torch.Generator().manual_seed(seed)
+    n, Th, D = 37, 4, int(z["D"])
+    cur = torch.randn(n, D, generator=g)
+    live = torch.rand(n, Th, generator=g) < 0.4
+    prev = torch.randn(n, Th, D, generator=g) * live.unsqueeze(-1)
+    mask = torch.cat([torch.where(live, 0.0, -10e9), torch.zeros(n, 1)], dim=1)
+    td = torch.arange(Th, -1, -1, dtype=torch.float32)
+    want = O.sa_attention(model["ent_encoder"]["layer_2"], cfg, cur, prev, td, mask)
+    got = m.ent_encoder.layer_2.calc_result(cur.to(device), prev.to(device), td.to(device), mask.to(device))
+    assert_close(got, want, 1e-5, 2e-6, "calc_result dense")
+    e = torch.randn(n, D, generator=g)
+    want = O.sargcn_isolated(model["ent_encoder"], cfg, e, prev, prev * 0.5, td, mask, 3)
+    got = m.ent_encoder.forward_isolated(e.to(device), prev.to(device), (prev * 0.5).to(device), td.to(device), mask.to(device), 3)
+    assert_close(got, want, 1e-5, 2e-6, "forward_isolated dense")
+
+
+def check_sa_evaluate(name, device):
+    """evaluate() of the attention models: ranks in range, and the encoder outputs it ranks with equal
+    the oracle's (full target graphs, no sampling)."""
+    z = load(name)
+    m, model, cfg = build_sa_model(z, device)
+    s = slice_snapshots()
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    ranks, loss = m.evaluate(t_list)
+    assert ranks.numel() > 0 and int(ranks.min()) >= 1 and int(ranks.max()) <= s["num_e"] and np.isfinite(loss)
+    with torch.no_grad():
+        per_graph, wb, tables = m.encode(t_list, int(z["L"]), train=False)
+        all_list = m.all_embeds_batched(wb, per_graph, tables)
+    from tests.test_oracle_golden import slice_graphs
+    _, _, times, gd = slice_graphs()
+    tl = sorted([int(t) for t in z["t_list"]], reverse=True)
+    targets = [gd["train"][t] for t in tl]
+    with torch.no_grad():
+        want, tt, hist, mask, td = O.sa_encode(model, cfg, gd["train"], tl, times, int(z["L"]), targets, bi=cfg["module"].startswith("Bi"))
+        for i, (a, b) in enumerate(zip(per_graph, want)):
+            assert_close(a, b, 1e-5, 2e-6, name + " eval encode")
+            assert_close(all_list[i], O.sa_all_embeds(model, cfg, gd["train"], i, tt[i], b, hist, mask, td), 1e-5, 2e-6, name + " all embeds")
