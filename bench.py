@@ -49,11 +49,16 @@ def make_args(w, module):
         use_embed_for_non_active=False, lr=1e-3, seed=0, batch_size=w["bsz"])
 
 
-def build_model(w, device):
+def build_model(w, device, encoder="gru"):
     from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
     from temp_amd.dynamic_rgcn import DynamicRGCN
+    from temp_amd.self_attention_rgcn import BiSelfAttentionRGCN, SelfAttentionRGCN
     torch.manual_seed(1)
-    cls = BiDynamicRGCN if w["module"].startswith("Bi") else DynamicRGCN
+    bi = w["module"].startswith("Bi")
+    if encoder == "attention":
+        cls = BiSelfAttentionRGCN if bi else SelfAttentionRGCN
+    else:
+        cls = BiDynamicRGCN if bi else DynamicRGCN
     snaps = w["snapshots"]
     m = cls(make_args(w, w["module"]), w["num_ents"], w["num_rels"], snaps, snaps, snaps)
     return m.to(device)
@@ -63,6 +68,8 @@ def algorithmic_costs(wb, D, bi, S=2):
     """Per-step ALGORITHMIC bytes / flops of every kernel family of the batched path (fp32, int32
     ids).  n = node visits, E = edge visits of the step; the GRU runs once per node visit (twice on
     the target position of the bi model)."""
+    if not hasattr(wb, "target"):                 # attention encoder: RGCN rows only (the mixer is reported by the kernel table)
+        bi = False
     n_gru = wb.n_node_visits + (wb.target.n_rows if bi else 0)     # GRU cells: one per node visit (two on the bi target)
     # the RGCN layers run once per DISTINCT snapshot of the step (shared between overlapping windows)
     n = getattr(wb, "n_nodes_distinct", 0) or wb.n_node_visits
@@ -85,6 +92,12 @@ def algorithmic_costs(wb, D, bi, S=2):
     c["k_gemm_panel<gru_dx>"] = dict(bytes=n_gru * (3 * row + row), flops=2 * n_gru * 3 * D * D)
     c["k_gemm_panel<gru_dprev>"] = dict(bytes=n_gru * (3 * row + 3 * row), flops=2 * n_gru * 3 * D * D)
     c["k_colsum_part"] = dict(bytes=n_gru * 6 * row, flops=0)
+    if hasattr(wb, "idx_tgt"):                    # attention mixer over the target rows (encoder-only step)
+        nq, act = int(wb.idx_tgt.shape[0]), int((wb.idx_tgt >= 0).sum().item())
+        c["k_sa_attn_fwd"] = dict(bytes=nq * 4 * row + act * 2 * row, flops=4 * (act + nq) * D)
+        c["k_sa_attn_bwd"] = dict(bytes=nq * 8 * row + act * 6 * row, flops=8 * (act + nq) * D)
+        R = wb.n_hist_rows
+        c["k_gemm_panel<linear>"] = dict(bytes=(R * 3 + nq * 4) * row * 2, flops=2 * (2 * R * 2 + 2 * nq * 3) * D * D)
     return c
 
 
@@ -175,6 +188,9 @@ def main():
                     help="also run the all-entity pass + scorer + cross-entropy (negative_rate 500, fixed negatives) in the step "
                          "(reported separately from the headline encoder-only metric, SURVEY 8d)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel trace table to stderr")
+    ap.add_argument("--encoder", choices=("gru", "attention"), default="gru",
+                    help="gru: the headline RGCN+GRU window models; attention: SelfAttentionRGCN / BiSelfAttentionRGCN (config 5, "
+                         "secondary measurement: no cpu_baseline leg)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the step as a captured HIP graph")
     a = ap.parse_args()
 
@@ -199,7 +215,9 @@ def main():
     assert TB.get_backend().name == "hip"
 
     w = synthetic.workload(a.workload, seed=0)
-    model = build_model(w, device)
+    model = build_model(w, device, a.encoder)
+    if a.encoder == "attention":
+        a.no_cpu_baseline = True
     bi = w["module"].startswith("Bi")
     from temp_amd.dist import SnapshotShardedEncoder, allreduce_gradients
     sharded = dist is not None and a.shard == "snapshots"
@@ -326,10 +344,10 @@ def main():
         cpu = cpu_baseline(model, w, targets)
 
     if rank == 0:
-        out = dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=%d%s" % (w["L"], " + link-prediction loss" if a.with_loss else ""), value=value, unit="edges/s", n_gpus=world,
+        out = dict(metric="edges/sec (fwd+bwd) RGCN+%s seq_len=%d%s" % ("GRU" if a.encoder == "gru" else "self-attention", w["L"], " + link-prediction loss" if a.with_loss else ""), value=value, unit="edges/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=w["name"], encoder=w["module"], rec_only_last_layer=True, seq_len=w["L"],
+                   config=dict(workload=w["name"], encoder=w["module"] if a.encoder == "gru" else ("BiSARGCN" if bi else "SARGCN"), rec_only_last_layer=True, seq_len=w["L"],
                                windows_per_gpu=w["bsz"], embed=w["D"], n_bases=w["B"], entities=w["num_ents"],
                                relations=w["num_rels"], edges_per_snapshot=w["edges_per_snap"],
                                edge_visits_per_step_per_gpu=wb.n_edge_visits, node_visits_per_step_per_gpu=wb.n_node_visits,

@@ -13,7 +13,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtemp_amd.so")
 SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip", "attn_kernels.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_panel.hpp"), os.path.join(REPO, "include", "temp_amd.h")]
+HEADERS = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")] + [os.path.join(REPO, "include", "temp_amd.h")]
 
 
 def _stale():

@@ -8,7 +8,7 @@
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of lane l is
 // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
 #include "common.hpp"
-#include "gemm_panel.hpp"
+#include "gemm_wres.hpp"
 
 namespace temp {
 

@@ -178,7 +178,7 @@ static inline void launch_panel_nt(int kid, const PanelBatch<Epi>& batch, int co
 }
 
 template <class Epi>
-int launch_gemm_panel_multi(int kid, const PanelBatch<Epi>& batch, int count, int N, int K, int lda, int ldb, int trans_b, hipStream_t st) {
+int launch_gemm_stream_multi(int kid, const PanelBatch<Epi>& batch, int count, int N, int K, int lda, int ldb, int trans_b, hipStream_t st) {
   if (count <= 0 || count > PANEL_MAXP) return TEMP_E_BADARG;
   int max_m = 0;
   long long sum_blocks = 0;
@@ -204,16 +204,6 @@ int launch_gemm_panel_multi(int kid, const PanelBatch<Epi>& batch, int count, in
   }
 #undef TEMP_PANEL
   return launch_status();
-}
-
-template <class Epi>
-int launch_gemm_panel(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
-                      const Epi& epi, hipStream_t st) {
-  if (M <= 0 || N <= 0) return TEMP_OK;
-  PanelBatch<Epi> batch;
-  for (int i = 0; i < PANEL_MAXP; ++i) batch.p[i] = PanelProblem<Epi>{0, nullptr, nullptr, nullptr, epi};
-  batch.p[0] = PanelProblem<Epi>{M, A, a_idx, B, epi};
-  return launch_gemm_panel_multi(kid, batch, 1, N, K, lda, ldb, trans_b, st);
 }
 
 }  // namespace temp

@@ -8,7 +8,7 @@
 // A operand is loaded, and sigmoid / tanh / blend run in the epilogue on the accumulators.
 // Backward = one pointwise pass for the gate gradients + MFMA GEMMs (gemm_panel.hpp, gemm_tn).
 #include "common.hpp"
-#include "gemm_panel.hpp"
+#include "gemm_wres.hpp"
 
 namespace temp {
 

@@ -1,6 +1,6 @@
 // Probe: fp32 GEMM through 3-way bf16 splitting on the bf16 MFMA pipe (6 products) vs the fp32 MFMA panel kernel.
 #include "common.hpp"
-#include "gemm_panel.hpp"
+#include "gemm_wres.hpp"
 #include <cstdio>
 #include <vector>
 #include <cmath>

@@ -1,7 +1,7 @@
 // Ablation probe for the row-panel MFMA GEMM (development tool, not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Itemp_amd/csrc tools/gemm_probe.hip -o gpurun_out/gemm_probe
 #include "common.hpp"
-#include "gemm_panel.hpp"
+#include "gemm_wres.hpp"
 #include <cstdio>
 #include <vector>
 using namespace temp;
