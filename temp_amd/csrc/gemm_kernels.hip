@@ -87,62 +87,90 @@ __global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // fetch: raw float4 loads (out-of-range pieces read element 0, a valid address); the zero-fill
+  // select happens in store(), AFTER the MFMAs of the current chunk, so the loads of chunk c+1 stay
+  // in flight behind them instead of being waited for at issue.
   float4 ra[NVA], rb[NVB];
+  auto a_ok = [&](int i, int m0) {
+    const int p = threadIdx.x + i * T;
+    const int r = p / (BK / 4), c = (p - r * (BK / 4)) << 2;
+    return (p < TN_MC * BK / 4) && (m0 + r < mend) && (ka_blk + c < Ka);
+  };
+  auto b_inr = [&](int i, int m0) {
+    const int p = threadIdx.x + i * T;
+    const int r = p / (BN / 4);
+    return (p < TN_MC * BN / 4) && (m0 + r < mend);
+  };
   auto fetch = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int p = threadIdx.x + i * T;
       const int r = p / (BK / 4), c = (p - r * (BK / 4)) << 2;
-      const bool ok = (p < TN_MC * BK / 4) && (m0 + r < mend) && (ka_blk + c < Ka);
-      const float4 v = ld4(A + (ok ? (size_t)(m0 + r) * lda + ka_blk + c : 0));
-      ra[i] = ok ? v : zero4();
+      ra[i] = ld4(A + (a_ok(i, m0) ? (unsigned)((m0 + r) * lda + ka_blk + c) : 0u));
     }
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       const int p = threadIdx.x + i * T;
       const int r = p / (BN / 4), c = (p - r * (BN / 4)) << 2;
-      const bool inr = (p < TN_MC * BN / 4) && (m0 + r < mend);
-      const bool ok = inr && (nb0 + c < Nb);
-      const float4 v = ld4(B + (ok ? (size_t)(m0 + r) * ldb + nb0 + c : 0));
-      rb[i] = ok ? v : zero4();
-      // bias gradient for free: the first padding column of B is a column of ones, so output column
-      // Nb is sum_m A[m, ka]
-      if (bias_part && inr && (nb0 + c == Nb)) rb[i].x = 1.f;
+      const bool ok = b_inr(i, m0) && (nb0 + c < Nb);
+      rb[i] = ld4(B + (ok ? (unsigned)((m0 + r) * ldb + nb0 + c) : 0u));
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, int m0) {
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int p = threadIdx.x + i * T;
-      if (p < TN_MC * BK / 4) st4(&As[buf][p << 2], ra[i]);
+      if (p < TN_MC * BK / 4) st4(&As[buf][p << 2], a_ok(i, m0) ? ra[i] : zero4());
     }
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       const int p = threadIdx.x + i * T;
-      if (p < TN_MC * BN / 4) st4(&Bs[buf][p << 2], rb[i]);
+      const int r = p / (BN / 4), c = (p - r * (BN / 4)) << 2;
+      const bool inr = b_inr(i, m0);
+      float4 v = (inr && (nb0 + c < Nb)) ? rb[i] : zero4();
+      // bias gradient for free: the first padding column of B is a column of ones, so output column
+      // Nb is sum_m A[m, ka]
+      if (bias_part && inr && (nb0 + c == Nb)) v.x = 1.f;
+      if (p < TN_MC * BN / 4) st4(&Bs[buf][p << 2], v);
     }
   };
 
   const int nchunks = (mend > mbeg) ? (mend - mbeg + TN_MC - 1) / TN_MC : 0;
   if (nchunks > 0) {
     fetch(mbeg);
-    store(0);
+    store(0, mbeg);
   }
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
-    if (more) fetch(mbeg + (c + 1) * TN_MC);
+    fetch(mbeg + (c + 1) * TN_MC);           // unconditional (past the end: clamped re-reads) so no value merge forces a wait here
+    __builtin_amdgcn_sched_barrier(0);
     if (wave_on) {
-      const float* as = As[c & 1] + wave * 32 + li;
-      const float* bs = Bs[c & 1] + li;
+      const float* as = As[c & 1] + wave * 32 + li + hh * BK;
+      const float* bs = Bs[c & 1] + li + hh * BN;
+      // LDS operands of row pair mp+2 are read while the MFMAs of row pair mp issue
+      float a_cur = as[0], b_cur[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b_cur[t] = bs[t * 32];
 #pragma unroll
       for (int mp = 0; mp < TN_MC; mp += 2) {
-        const float a = as[(mp + hh) * BK];
+        float a_nxt = 0.f, b_nxt[NT];
+        if (mp + 2 < TN_MC) {
+          a_nxt = as[(mp + 2) * BK];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[(mp + hh) * BN + t * 32], a, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) b_nxt[t] = bs[(mp + 2) * BN + t * 32];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[t], a_cur, acc[t], 0, 0, 0);
+        if (mp + 2 < TN_MC) {
+          a_cur = a_nxt;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) b_cur[t] = b_nxt[t];
+        }
       }
     }
-    if (more) store((c + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store((c + 1) & 1, mbeg + (c + 1) * TN_MC);
     __syncthreads();
   }
   // swapped operands: lane (li, hh) holds output row ka0 + li, register quad q of tile t holds the
@@ -195,7 +223,10 @@ struct TnCfg { int wpb, bk, kab, nt, nbb, slices; };
 static TnCfg tn_cfg(int M, int Ka, int Nb) {
   TnCfg c;
   const int ktiles = ceil_div(Ka, 32);
-  c.wpb = (ktiles <= 7) ? 7 : 8;                      // D = 200 -> 7 row tiles: one block owns all of Ka
+  // 7- or 8-wave blocks (one per CU), whichever pads Ka less: D = 200 -> 7 row tiles, one block owns all
+  // of Ka; 3D = 600 -> 19 tiles = 7 + 7 + 5.  (4-wave blocks, two per CU, measured 20 % slower: B is
+  // staged twice as often.)
+  c.wpb = (ceil_div(ktiles, 7) * 7 - ktiles <= ceil_div(ktiles, 8) * 8 - ktiles) ? 7 : 8;
   c.bk = c.wpb * 32;
   c.kab = ceil_div(Ka, c.bk);
   const int ntiles = ceil_div(Nb, 32);

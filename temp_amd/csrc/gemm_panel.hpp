@@ -26,45 +26,53 @@ struct PanelCfg {
   static constexpr int NV = (GEMM_KC * BN / 4 + 255) / 256;  // float4 pieces of a B chunk per thread
 };
 
-// Fetch the float4 pieces of B chunk [k0, k0+KC) x [n0, n0+BN) owned by this thread.
+// Piece p of B chunk [k0, k0+KC) x [n0, n0+BN) owned by this thread: in range? / global offset.
+template <int NT>
+__device__ __forceinline__ bool panel_b_piece(int i, int trans_b, int k0, int K, int n0, int N, int ldb, size_t* off) {
+  constexpr int BN = PanelCfg<NT>::BN;
+  const int p = threadIdx.x + i * 256;
+  if (!trans_b) {                                            // B[k][n]: pieces run along n
+    const int k = p / (BN / 4), j = (p - k * (BN / 4)) * 4;
+    *off = (size_t)(k0 + k) * ldb + n0 + j;
+    return (p < GEMM_KC * BN / 4) && (k0 + k < K) && (n0 + j < N);
+  }
+  const int j = p / (GEMM_KC / 4), k = (p - j * (GEMM_KC / 4)) * 4;   // B stored [n][k]: pieces run along k
+  *off = (size_t)(n0 + j) * ldb + k0 + k;
+  return (p < GEMM_KC * BN / 4) && (k0 + k < K) && (n0 + j < N);
+}
+
+// Fetch: raw float4 loads (out-of-range pieces read element 0); zero-filled by panel_store_b, i.e.
+// AFTER the MFMAs of the current chunk -- a select at issue would make the wave wait for the load.
 template <int NT>
 __device__ __forceinline__ void panel_fetch_b(float4 (&reg)[PanelCfg<NT>::NV], const float* __restrict__ B, int ldb, int trans_b,
                                               int k0, int K, int n0, int N) {
-  constexpr int BN = PanelCfg<NT>::BN;
 #pragma unroll
   for (int i = 0; i < PanelCfg<NT>::NV; ++i) {
-    const int p = threadIdx.x + i * 256;
     size_t off;
-    bool ok;
-    if (!trans_b) {                                          // B[k][n]: pieces run along n
-      const int k = p / (BN / 4), j = (p - k * (BN / 4)) * 4;
-      ok = (p < GEMM_KC * BN / 4) && (k0 + k < K) && (n0 + j < N);
-      off = (size_t)(k0 + k) * ldb + n0 + j;
-    } else {                                                 // B stored [n][k]: pieces run along k
-      const int j = p / (GEMM_KC / 4), k = (p - j * (GEMM_KC / 4)) * 4;
-      ok = (p < GEMM_KC * BN / 4) && (k0 + k < K) && (n0 + j < N);
-      off = (size_t)(n0 + j) * ldb + k0 + k;
-    }
-    const float4 v = ld4(B + (ok ? off : 0));
-    reg[i] = ok ? v : zero4();
+    const bool ok = panel_b_piece<NT>(i, trans_b, k0, K, n0, N, ldb, &off);
+    reg[i] = ld4(B + (ok ? off : 0));
   }
 }
 
 template <int NT>
-__device__ __forceinline__ void panel_store_b(const float4 (&reg)[PanelCfg<NT>::NV], float* __restrict__ Bs, int trans_b) {
+__device__ __forceinline__ void panel_store_b(const float4 (&reg)[PanelCfg<NT>::NV], float* __restrict__ Bs, int ldb, int trans_b,
+                                              int k0, int K, int n0, int N) {
   constexpr int BN = PanelCfg<NT>::BN, LDS_B = PanelCfg<NT>::LDS_B;
 #pragma unroll
   for (int i = 0; i < PanelCfg<NT>::NV; ++i) {
     const int p = threadIdx.x + i * 256;
+    size_t off;
+    const bool ok = panel_b_piece<NT>(i, trans_b, k0, K, n0, N, ldb, &off);
+    const float4 v = ok ? reg[i] : zero4();
     if (p < GEMM_KC * BN / 4) {
       if (!trans_b) {
         const int k = p / (BN / 4), j = (p - k * (BN / 4)) * 4;
         float* d = Bs + k * LDS_B + j;
-        d[0] = reg[i].x; d[1] = reg[i].y; d[2] = reg[i].z; d[3] = reg[i].w;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       } else {
         const int j = p / (GEMM_KC / 4), k = (p - j * (GEMM_KC / 4)) * 4;
         float* d = Bs + k * LDS_B + j;
-        d[0] = reg[i].x; d[LDS_B] = reg[i].y; d[2 * LDS_B] = reg[i].z; d[3 * LDS_B] = reg[i].w;
+        d[0] = v.x; d[LDS_B] = v.y; d[2 * LDS_B] = v.z; d[3 * LDS_B] = v.w;
       }
     }
   }
@@ -106,27 +114,30 @@ __global__ void __launch_bounds__(256) k_gemm_panel(PanelBatch<Epi> batch, int N
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  auto fetch_a = [&](float4 (&av)[NQ], int k0) {
+  auto fetch_a = [&](float4 (&av)[NQ], int k0) {               // raw loads; select_a zero-fills at first use
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const bool ok = arow_ok && (k0 + q * 8 + 4 * hh < K);
-      const float4 v = ld4(aptr + (ok ? k0 + q * 8 : -4 * hh));    // !ok: re-read k = 0..3 of the row (in bounds)
-      av[q] = ok ? v : zero4();
+      av[q] = ld4(aptr + (ok ? k0 + q * 8 : -4 * hh));           // !ok: re-read k = 0..3 of the row (in bounds)
     }
+  };
+  auto select_a = [&](float4 (&dst)[NQ], const float4 (&src)[NQ], int k0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) dst[q] = (arow_ok && (k0 + q * 8 + 4 * hh < K)) ? src[q] : zero4();
   };
 
   float4 breg[NV], av[NQ], av_next[NQ];
   panel_fetch_b<NT>(breg, B, ldb, trans_b, 0, K, n0, N);
-  fetch_a(av, 0);
-  panel_store_b<NT>(breg, Bs[0], trans_b);
+  fetch_a(av_next, 0);
+  panel_store_b<NT>(breg, Bs[0], ldb, trans_b, 0, K, n0, N);
+  select_a(av, av_next, 0);
   __syncthreads();
   const int nchunks = (K + GEMM_KC - 1) / GEMM_KC;
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
-    if (more) {
-      panel_fetch_b<NT>(breg, B, ldb, trans_b, (c + 1) * GEMM_KC, K, n0, N);
-      fetch_a(av_next, (c + 1) * GEMM_KC);
-    }
+    panel_fetch_b<NT>(breg, B, ldb, trans_b, (c + 1) * GEMM_KC, K, n0, N);   // unconditional: past the end every piece is a
+    fetch_a(av_next, (c + 1) * GEMM_KC);                                     // clamped re-read, and no value merge forces a wait
+    __builtin_amdgcn_sched_barrier(0);
     const float* bs = Bs[c & 1];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -138,10 +149,10 @@ __global__ void __launch_bounds__(256) k_gemm_panel(PanelBatch<Epi> batch, int N
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(brow[t * 32], as[s], acc[t], 0, 0, 0);   // operands swapped: C^T tile
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) {
-      panel_store_b<NT>(breg, Bs[(c + 1) & 1], trans_b);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) av[q] = av_next[q];
+      panel_store_b<NT>(breg, Bs[(c + 1) & 1], ldb, trans_b, (c + 1) * GEMM_KC, K, n0, N);
+      select_a(av, av_next, (c + 1) * GEMM_KC);
     }
     __syncthreads();
   }

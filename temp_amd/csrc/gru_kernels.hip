@@ -36,27 +36,35 @@ struct GruPhase {
   const float* W; int row_base[3]; int D; int j0;
 };
 
+__device__ __forceinline__ bool gru_w_piece(int i, const GruPhase& ph, int k0, size_t* off) {
+  const int p = threadIdx.x + i * 256;
+  const int g = p / (32 * GRU_KC / 4), rem = p - g * (32 * GRU_KC / 4);
+  const int j = rem / (GRU_KC / 4), k = (rem - j * (GRU_KC / 4)) * 4;
+  const int rb = (g == 0) ? ph.row_base[0] : (g == 1 ? ph.row_base[1] : ph.row_base[2]);
+  *off = (size_t)(rb + ph.j0 + j) * ph.D + k0 + k;
+  return (p < 3 * 32 * GRU_KC / 4) && rb >= 0 && (ph.j0 + j < ph.D) && (k0 + k < ph.D);
+}
+// raw loads; the zero-fill select is applied by gru_store_w, after the MFMAs of the current chunk
 __device__ __forceinline__ void gru_fetch_w(float4 (&reg)[GRU_NVB], const GruPhase& ph, int k0) {
 #pragma unroll
   for (int i = 0; i < GRU_NVB; ++i) {
-    const int p = threadIdx.x + i * 256;
-    const int g = p / (32 * GRU_KC / 4), rem = p - g * (32 * GRU_KC / 4);
-    const int j = rem / (GRU_KC / 4), k = (rem - j * (GRU_KC / 4)) * 4;
-    const int rb = (g == 0) ? ph.row_base[0] : (g == 1 ? ph.row_base[1] : ph.row_base[2]);
-    const bool ok = (p < 3 * 32 * GRU_KC / 4) && rb >= 0 && (ph.j0 + j < ph.D) && (k0 + k < ph.D);
-    const float4 v = ld4(ph.W + (ok ? (size_t)(rb + ph.j0 + j) * ph.D + k0 + k : 0));
-    reg[i] = ok ? v : zero4();
+    size_t off;
+    const bool ok = gru_w_piece(i, ph, k0, &off);
+    reg[i] = ld4(ph.W + (ok ? off : 0));
   }
 }
-__device__ __forceinline__ void gru_store_w(const float4 (&reg)[GRU_NVB], float (*Bs)[GRU_KC * GRU_LDB]) {
+__device__ __forceinline__ void gru_store_w(const float4 (&reg)[GRU_NVB], float (*Bs)[GRU_KC * GRU_LDB], const GruPhase& ph, int k0) {
 #pragma unroll
   for (int i = 0; i < GRU_NVB; ++i) {
     const int p = threadIdx.x + i * 256;
+    size_t off;
+    const bool ok = gru_w_piece(i, ph, k0, &off);
+    const float4 v = ok ? reg[i] : zero4();
     if (p < 3 * 32 * GRU_KC / 4) {
       const int g = p / (32 * GRU_KC / 4), rem = p - g * (32 * GRU_KC / 4);
       const int j = rem / (GRU_KC / 4), k = (rem - j * (GRU_KC / 4)) * 4;
       float* d = Bs[g] + k * GRU_LDB + j;
-      d[0] = reg[i].x; d[GRU_LDB] = reg[i].y; d[2 * GRU_LDB] = reg[i].z; d[3 * GRU_LDB] = reg[i].w;
+      d[0] = v.x; d[GRU_LDB] = v.y; d[2 * GRU_LDB] = v.z; d[3 * GRU_LDB] = v.w;
     }
   }
 }
@@ -67,26 +75,29 @@ __device__ __forceinline__ void gru_phase(const GruPhase& ph, const float* __res
                                           float (*Bs)[3][GRU_KC * GRU_LDB], f32x16& acc0, f32x16& acc1, f32x16& acc2) {
   const int D = ph.D;
   float4 breg[GRU_NVB], av[GRU_NQ], av_next[GRU_NQ];
-  auto fetch_a = [&](float4 (&dst)[GRU_NQ], int k0) {
+  auto fetch_a = [&](float4 (&dst)[GRU_NQ], int k0) {      // raw loads; select_a scales / zero-fills at first use
 #pragma unroll
     for (int q = 0; q < GRU_NQ; ++q) {
       const bool ok = a_ok && (k0 + q * 8 + 4 * hh < D);
-      const float4 v = ld4(arow_ptr + (ok ? k0 + q * 8 : -4 * hh));
-      dst[q] = ok ? scale4(v, scale) : zero4();
+      dst[q] = ld4(arow_ptr + (ok ? k0 + q * 8 : -4 * hh));
     }
+  };
+  auto select_a = [&](float4 (&dst)[GRU_NQ], const float4 (&src)[GRU_NQ], int k0) {
+#pragma unroll
+    for (int q = 0; q < GRU_NQ; ++q) dst[q] = (a_ok && (k0 + q * 8 + 4 * hh < D)) ? scale4(src[q], scale) : zero4();
   };
   __syncthreads();                          // previous phase done with both LDS buffers
   gru_fetch_w(breg, ph, 0);
-  fetch_a(av, 0);
-  gru_store_w(breg, Bs[0]);
+  fetch_a(av_next, 0);
+  gru_store_w(breg, Bs[0], ph, 0);
+  select_a(av, av_next, 0);
   __syncthreads();
   const int nchunks = (D + GRU_KC - 1) / GRU_KC;
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
-    if (more) {
-      gru_fetch_w(breg, ph, (c + 1) * GRU_KC);
-      fetch_a(av_next, (c + 1) * GRU_KC);
-    }
+    gru_fetch_w(breg, ph, (c + 1) * GRU_KC);      // unconditional (clamped past the end): no value merge, no early wait
+    fetch_a(av_next, (c + 1) * GRU_KC);
+    __builtin_amdgcn_sched_barrier(0);
     float (*bs)[GRU_KC * GRU_LDB] = Bs[c & 1];
 #pragma unroll
     for (int q = 0; q < GRU_NQ; ++q) {
@@ -101,10 +112,10 @@ __device__ __forceinline__ void gru_phase(const GruPhase& ph, const float* __res
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[2][off], as[s], acc2, 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) {
-      gru_store_w(breg, Bs[(c + 1) & 1]);
-#pragma unroll
-      for (int q = 0; q < GRU_NQ; ++q) av[q] = av_next[q];
+      gru_store_w(breg, Bs[(c + 1) & 1], ph, (c + 1) * GRU_KC);
+      select_a(av, av_next, (c + 1) * GRU_KC);
     }
     __syncthreads();
   }
