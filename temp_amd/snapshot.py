@@ -127,6 +127,61 @@ def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK):
                 fix_seg=i32(fix_seg), fix_slot=i32(fix_slot), fix_cnt=i32(fix_cnt), order=order)
 
 
+def build_view_tiled(seg, a, b, n_seg, tile, chunk=_lib.CHUNK):
+    """Same contract as build_view, but the chunks are ordered TILE-major: `tile[e]` (a coarse bucket of
+    the edge's node range, i.e. of its snapshot) first, `seg` second.  A segment's edges are then spread
+    over one chunk (or a few) per tile, all of which go through partial slots and the fix-up pass --
+    slots of one segment stay contiguous -- while the rows a run of consecutive chunks gathers all lie in
+    one tile's node range (L2-resident) instead of anywhere in the batch."""
+    seg = np.asarray(seg, dtype=np.int64)
+    tile = np.asarray(tile, dtype=np.int64)
+    n_tile = int(tile.max()) + 1 if tile.shape[0] else 1
+    key = tile * n_seg + seg
+    order = np.argsort(key, kind="stable")
+    counts = np.bincount(key, minlength=n_tile * n_seg).astype(np.int64)      # edges per (tile, seg) group
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    nch = (counts + chunk - 1) // chunk
+    total = int(nch.sum())
+    grp = np.repeat(np.arange(n_tile * n_seg, dtype=np.int64), nch)           # group of every chunk, chunk order
+    first = np.cumsum(nch) - nch
+    k = np.arange(total, dtype=np.int64) - first[grp]
+    chunk_beg = ptr[grp] + k * chunk
+    chunk_end = np.minimum(chunk_beg + chunk, ptr[grp + 1])
+    chunk_seg = grp % n_seg
+    per_seg = nch.reshape(n_tile, n_seg).sum(axis=0)                          # chunks per segment over all tiles
+    multi = per_seg > 1
+    fix_seg = np.nonzero(multi)[0]
+    fix_cnt = per_seg[fix_seg]
+    fix_slot = np.cumsum(fix_cnt) - fix_cnt
+    seg_slot0 = np.full(n_seg, -1, dtype=np.int64)
+    seg_slot0[fix_seg] = fix_slot
+    # rank of a chunk among the chunks of its segment (tile order, then position inside the group)
+    by_seg = np.argsort(chunk_seg, kind="stable")
+    rank = np.empty(total, dtype=np.int64)
+    seg_first = np.cumsum(per_seg) - per_seg
+    rank[by_seg] = np.arange(total, dtype=np.int64) - seg_first[chunk_seg[by_seg]]
+    slot = np.where(multi[chunk_seg], seg_slot0[chunk_seg] + rank, -1)
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+    return dict(n_seg=int(n_seg), n_edges=int(seg.shape[0]), a=i32(np.asarray(a)[order]), b=i32(np.asarray(b)[order]),
+                n_chunks=total, chunk_seg=i32(chunk_seg), chunk_beg=i32(chunk_beg), chunk_end=i32(chunk_end),
+                chunk_slot=i32(slot), n_partial=int(multi[chunk_seg].sum()), n_fix=int(fix_seg.shape[0]),
+                fix_seg=i32(fix_seg), fix_slot=i32(fix_slot), fix_cnt=i32(fix_cnt), order=order)
+
+
+REL_GROUP_EDGES = 192        # target edges per (node tile, relation) group of the by-relation view
+
+
+def by_rel_view(snap, n_rel_rows):
+    """Relation-sorted view for the weight gradient.  When a relation has many edges per snapshot
+    (GDELT-like: ~190), the view is tiled by node range so consecutive chunks read one snapshot's rows."""
+    E, n = snap.number_of_edges(), snap.n
+    tiles = E // (REL_GROUP_EDGES * max(n_rel_rows, 1))
+    if tiles <= 1 or n == 0:
+        return build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL)
+    width = -(-n // tiles)
+    return build_view_tiled(snap.rel, snap.src, snap.dst, n_rel_rows, np.asarray(snap.dst, dtype=np.int64) // width, chunk=_lib.CHUNK_REL)
+
+
 _VIEW_ARRAYS = ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")
 
 
@@ -138,7 +193,7 @@ class _DeviceGraph:
         n, E = snap.n, snap.number_of_edges()
         views = dict(by_dst=build_view(snap.dst, snap.src, snap.rel, n),
                      by_src=build_view(snap.src, snap.dst, snap.rel, n),
-                     by_rel=build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL))
+                     by_rel=by_rel_view(snap, n_rel_rows))
         if E and (snap.rel.min() < 0 or snap.rel.max() >= n_rel_rows):
             raise ValueError("relation id outside [0, %d)" % n_rel_rows)
         in_deg = np.bincount(snap.dst, minlength=n).astype(np.int32)
