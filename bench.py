@@ -332,6 +332,16 @@ def main():
         else:
             ach = cst["bytes"] / sec / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
+        # HBM-side bytes per launch of the dominant kernel: measured separately with rocprofv3 --pmc
+        # (FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py) on this same workload and committed
+        # under profiles/ -- counters cannot be collected from inside this process.
+        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path) and a.workload == "S-gdelt" and a.encoder == "gru" and not a.with_loss:
+            fam = json.load(open(pmc_path)).get("families", {}).get(dom.split("<")[0])
+            if fam:
+                roof["traffic"] = fam["traffic_bytes_per_launch"]
+                roof["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)"
+                roof["algorithmic_per_launch"] = cst["flops" if roof["bound"] == "mfma" else "bytes"] / max(tr[dom]["launches_per_step"], 1e-9)
         roof.update(avg_launch_ms=tr[dom]["avg_ms"], launches_per_step=tr[dom]["launches_per_step"],
                     share_of_kernel_time=tr[dom]["ms_per_step"] / total_ms, traced_kernel_ms_per_step=total_ms)
         # whole-step view against the HBM roofline with SURVEY 8d's per-edge-visit byte model
