@@ -8,6 +8,7 @@
 // A operand is loaded, and sigmoid / tanh / blend run in the epilogue on the accumulators.
 // Backward = one pointwise pass for the gate gradients + MFMA GEMMs (gemm_panel.hpp, gemm_tn).
 #include "common.hpp"
+#include <stdlib.h>
 #include "gemm_wres.hpp"
 
 namespace temp {
@@ -128,59 +129,19 @@ struct GruFwdCell {
 };
 struct GruFwdBatch { GruFwdCell c[GRU_MAXP]; };
 
-// blockIdx.z selects the cell: the forward- and backward-direction chains advance together.
+// Cell epilogue shared by the streaming and the weights-resident forward kernels: lane (li, hh) owns row
+// `arow` (the row whose A fragment it loaded: prow / dec are its own) and, per q, the 4 consecutive columns
+// j0 + 8q + 4hh .. +3 of every gate -> float4 traffic only.
 template <int VARIANT, bool HOISTED>
-__global__ void __launch_bounds__(256) k_gru_fwd(GruFwdBatch batch, int D, float lambda, const float* __restrict__ decay_wb, size_t plane) {
-  __shared__ float Bs[2][3][GRU_KC * GRU_LDB];
-  const GruFwdCell& cell = batch.c[blockIdx.z];
-  const int n = cell.n;
-  if ((int)blockIdx.x * 128 >= n) return;                     // uniform per block
-  const float* __restrict__ x = cell.x;
+__device__ __forceinline__ void gru_cell_epilogue(const GruFwdCell& cell, int D, size_t plane, int arow, bool arow_ok, int prow, float dec,
+                                                  int j0, int hh, const f32x16& acc_r, const f32x16& acc_z, const f32x16& acc_in,
+                                                  const f32x16& acc_hn) {
   const float* __restrict__ gi = cell.gi;
   const float* __restrict__ prev = cell.prev;
-  const int32_t* __restrict__ prev_idx = cell.prev_idx;
-  const float* __restrict__ dt = cell.dt;
-  const float* __restrict__ w_ih = cell.w_ih;
-  const float* __restrict__ w_hh = cell.w_hh;
   const float* __restrict__ b_ih = cell.b_ih;
   const float* __restrict__ b_hh = cell.b_hh;
   float* __restrict__ h_out = cell.h_out;
   float* __restrict__ saved = cell.saved;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hh = lane >> 5, li = lane & 31;
-  const int m0 = (blockIdx.x * 4 + wave) * 32;
-  const int j0 = blockIdx.y * 32;
-  const int arow = m0 + li;
-  const bool arow_ok = arow < n;
-  int prow = -1;
-  float dec = 0.f;
-  if (arow_ok) {
-    prow = prev_idx ? prev_idx[arow] : arow;
-    dec = decay_factor(dt[arow], lambda, decay_wb);
-  }
-  f32x16 acc_r, acc_z, acc_in, acc_hn;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; }
-
-  if (!HOISTED) {                       // phase X: x . W_ih^T (torch: gates r,z,n; type-1: new gate only)
-    GruPhase ph;
-    ph.W = w_ih; ph.D = D; ph.j0 = j0;
-    if (VARIANT == TEMP_GRU_TORCH) { ph.row_base[0] = 0; ph.row_base[1] = D; ph.row_base[2] = 2 * D; }
-    else { ph.row_base[0] = -1; ph.row_base[1] = -1; ph.row_base[2] = 0; }
-    const float* xa = x + (size_t)(arow_ok ? arow : 0) * D + 4 * hh;
-    if (VARIANT == TEMP_GRU_TORCH) gru_phase<true>(ph, xa, arow_ok, 1.f, hh, li, Bs, acc_r, acc_z, acc_in);
-    else gru_phase<false>(ph, xa, arow_ok, 1.f, hh, li, Bs, acc_r, acc_z, acc_in);
-  }
-  {                                     // phase H: hdec . W_hh^T
-    GruPhase ph;
-    ph.W = w_hh; ph.D = D; ph.j0 = j0;
-    ph.row_base[0] = 0; ph.row_base[1] = D; ph.row_base[2] = 2 * D;
-    const bool h_ok = arow_ok && prow >= 0;
-    const float* ha = prev + (size_t)(h_ok ? prow : 0) * D + 4 * hh;
-    gru_phase<true>(ph, ha, h_ok, dec, hh, li, Bs, acc_r, acc_z, acc_hn);
-  }
-  // ---- epilogue: lane (li, hh) owns row m0+li (the row whose A fragment it loaded: prow/dec are its
-  // own) and, per q, the 4 consecutive columns j0 + 8q + 4hh .. +3 -> float4 traffic only -----------
   const int G = (VARIANT == TEMP_GRU_TORCH) ? 3 * D : D;
   const int row = arow;
   float4 hd4[4], g0[4], g1[4], g2[4];
@@ -237,6 +198,160 @@ __global__ void __launch_bounds__(256) k_gru_fwd(GruFwdBatch batch, int D, float
     st4(saved + 2 * plane + o, make_float4(o_n[0], o_n[1], o_n[2], o_n[3]));
     st4(saved + 3 * plane + o, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
     st4(saved + 4 * plane + o, hd4[q]);
+  }
+}
+
+// blockIdx.z selects the cell: the forward- and backward-direction chains advance together.
+template <int VARIANT, bool HOISTED>
+__global__ void __launch_bounds__(256) k_gru_fwd(GruFwdBatch batch, int D, float lambda, const float* __restrict__ decay_wb, size_t plane) {
+  __shared__ float Bs[2][3][GRU_KC * GRU_LDB];
+  const GruFwdCell& cell = batch.c[blockIdx.z];
+  const int n = cell.n;
+  if ((int)blockIdx.x * 128 >= n) return;                     // uniform per block
+  const float* __restrict__ x = cell.x;
+  const float* __restrict__ gi = cell.gi;
+  const float* __restrict__ prev = cell.prev;
+  const int32_t* __restrict__ prev_idx = cell.prev_idx;
+  const float* __restrict__ dt = cell.dt;
+  const float* __restrict__ w_ih = cell.w_ih;
+  const float* __restrict__ w_hh = cell.w_hh;
+  const float* __restrict__ b_ih = cell.b_ih;
+  const float* __restrict__ b_hh = cell.b_hh;
+  float* __restrict__ h_out = cell.h_out;
+  float* __restrict__ saved = cell.saved;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  const int j0 = blockIdx.y * 32;
+  const int arow = m0 + li;
+  const bool arow_ok = arow < n;
+  int prow = -1;
+  float dec = 0.f;
+  if (arow_ok) {
+    prow = prev_idx ? prev_idx[arow] : arow;
+    dec = decay_factor(dt[arow], lambda, decay_wb);
+  }
+  f32x16 acc_r, acc_z, acc_in, acc_hn;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; }
+
+  if (!HOISTED) {                       // phase X: x . W_ih^T (torch: gates r,z,n; type-1: new gate only)
+    GruPhase ph;
+    ph.W = w_ih; ph.D = D; ph.j0 = j0;
+    if (VARIANT == TEMP_GRU_TORCH) { ph.row_base[0] = 0; ph.row_base[1] = D; ph.row_base[2] = 2 * D; }
+    else { ph.row_base[0] = -1; ph.row_base[1] = -1; ph.row_base[2] = 0; }
+    const float* xa = x + (size_t)(arow_ok ? arow : 0) * D + 4 * hh;
+    if (VARIANT == TEMP_GRU_TORCH) gru_phase<true>(ph, xa, arow_ok, 1.f, hh, li, Bs, acc_r, acc_z, acc_in);
+    else gru_phase<false>(ph, xa, arow_ok, 1.f, hh, li, Bs, acc_r, acc_z, acc_in);
+  }
+  {                                     // phase H: hdec . W_hh^T
+    GruPhase ph;
+    ph.W = w_hh; ph.D = D; ph.j0 = j0;
+    ph.row_base[0] = 0; ph.row_base[1] = D; ph.row_base[2] = 2 * D;
+    const bool h_ok = arow_ok && prow >= 0;
+    const float* ha = prev + (size_t)(h_ok ? prow : 0) * D + 4 * hh;
+    gru_phase<true>(ph, ha, h_ok, dec, hh, li, Bs, acc_r, acc_z, acc_hn);
+  }
+  gru_cell_epilogue<VARIANT, HOISTED>(cell, D, plane, arow, arow_ok, prow, dec, j0, hh, acc_r, acc_z, acc_in, acc_hn);
+}
+
+// Weights-resident cell kernel (hoisted input gates only): the per-position launches of the window chain have
+// few rows (bsz * n), so the streaming kernel above spends its time re-staging W_hh chunk by chunk behind
+// barriers.  Here block role = (cell, 32-column group j): the block copies the three gate slices of W_hh for
+// its columns (96 x D floats, [col][k], row stride D+4 -> conflict-free ds_read_b128) into LDS ONCE, then
+// its waves take 32-row panels of that cell: the whole decayed A fragment (D/8 float4 per lane) is issued
+// up front, the D/2 x 3 MFMAs run without any barrier, and the gate epilogue follows.  blocks b, b+8, ...
+// share an XCD, so XCD x takes the x-th eighth of each cell's panels for all column groups.
+#define GRUR_MAXQ 32                       // D <= 256
+#define GRUR_LDS_BYTES (96 * (256 + 4) * 4)
+template <int VARIANT>
+__global__ void __launch_bounds__(256, 2) k_gru_fwd_res(GruFwdBatch batch, int count, int D, float lambda, const float* __restrict__ decay_wb,
+                                                         size_t plane, int bpr) {
+  extern __shared__ __attribute__((aligned(16))) float Wr[];
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int role = local / bpr, idx = local - role * bpr;
+  const int ncg = (D + 31) >> 5;
+  const int z = role / ncg, j0 = (role - z * ncg) * 32;
+  if (z >= count) return;
+  const GruFwdCell& cell = batch.c[z];
+  const int n = cell.n;
+  if (n <= 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const int kpad = (D + 7) & ~7, ldk = kpad + (((kpad >> 2) & 1) ? 8 : 4), k4n = kpad >> 2;
+  {                                         // prologue: W_hh rows g*D + j0 + c  ->  Wr[(g*32 + c)][k]
+    const float* __restrict__ W = cell.w_hh;
+    const int total = 96 * k4n;
+    for (int base = threadIdx.x; base < total; base += 256 * 8) {
+      float4 v[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = base + u * 256;
+        const int cg = p / k4n, k = (p - cg * k4n) * 4;
+        const int g = cg >> 5, c = cg & 31;
+        const bool ok = p < total && (j0 + c < D) && (k < D);
+        dst[u] = p < total ? cg * ldk + k : -1;
+        const float4 x = ld4(W + (ok ? (size_t)(g * D + j0 + c) * D + k : 0));
+        v[u] = ok ? x : zero4();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) st4(Wr + dst[u], v[u]);
+    }
+  }
+  __syncthreads();
+  const float* __restrict__ prev = cell.prev;
+  const int32_t* __restrict__ prev_idx = cell.prev_idx;
+  const float* __restrict__ dt = cell.dt;
+  const int panels = (n + 31) >> 5;
+  const int per_xcd = (panels + 7) >> 3;
+  const int p_end = min(panels, (xcd + 1) * per_xcd);
+  const int nq = kpad >> 3;
+  const float* wrow = Wr + (size_t)li * ldk + 4 * hh;
+  for (int panel = xcd * per_xcd + idx * 4 + wave; panel < p_end; panel += bpr * 4) {
+    const int arow = panel * 32 + li;
+    const bool arow_ok = arow < n;
+    int prow = -1;
+    float dec = 0.f;
+    if (arow_ok) {
+      prow = prev_idx ? prev_idx[arow] : arow;
+      dec = decay_factor(dt[arow], lambda, decay_wb);
+    }
+    const bool h_ok = arow_ok && prow >= 0;
+    const float* ha = prev + (size_t)(h_ok ? prow : 0) * D + 4 * hh;
+    float4 av[GRUR_MAXQ];
+#pragma unroll
+    for (int q = 0; q < GRUR_MAXQ; ++q) {
+      const bool ok = h_ok && q < nq && (q * 8 + 4 * hh < D);
+      av[q] = ld4(ha + (ok ? q * 8 : -4 * hh));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc_r, acc_z, acc_hn, acc_in;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_hn[r] = 0.f; acc_in[r] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < GRUR_MAXQ; ++q) {
+      if (q < nq) {
+        const bool ok = h_ok && (q * 8 + 4 * hh < D);
+        const float4 a = ok ? scale4(av[q], dec) : zero4();
+        const float4 w0 = ld4(wrow + q * 8), w1 = ld4(wrow + (size_t)32 * ldk + q * 8), w2 = ld4(wrow + (size_t)64 * ldk + q * 8);
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a.x, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a.x, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.x, a.x, acc_hn, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a.y, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a.y, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.y, a.y, acc_hn, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a.z, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a.z, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.z, a.z, acc_hn, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a.w, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a.w, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.w, a.w, acc_hn, 0, 0, 0);
+      }
+    }
+    gru_cell_epilogue<VARIANT, true>(cell, D, plane, arow, arow_ok, prow, dec, j0, hh, acc_r, acc_z, acc_in, acc_hn);
   }
 }
 
@@ -367,6 +482,28 @@ static int launch_gru_fwd_batch(const GruFwdBatch& batch, int count, int d, int 
   int max_n = 0;
   for (int i = 0; i < count; ++i) if (batch.c[i].n > max_n) max_n = batch.c[i].n;
   if (max_n <= 0) return TEMP_OK;
+  static const bool res_off = [] { const char* e = getenv("TEMP_GRU_STREAM"); return e && e[0] == '1'; }();
+  if (hoisted && d <= 256 && d % 8 == 0 && !res_off) {
+    // weights-resident variant: roles = (cell, 32-column group); 64 block slots per XCD shared by the roles
+    const int roles = count * ceil_div(d, 32);
+    int bpr = 64 / roles;
+    const int need = ceil_div(ceil_div(ceil_div(max_n, 32), 8), 4);        // blocks that still get a panel per XCD
+    if (bpr > need) bpr = need;
+    if (bpr >= 1) {
+      const size_t lds = (size_t)96 * (((d + 7) & ~7) + 8) * 4;
+      static bool attr[2] = {false, false};
+      const int vi = variant == TEMP_GRU_TORCH ? 0 : 1;
+      const void* fn = vi == 0 ? (const void*)k_gru_fwd_res<TEMP_GRU_TORCH> : (const void*)k_gru_fwd_res<TEMP_GRU_TYPE1>;
+      if (!attr[vi]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GRUR_LDS_BYTES) != hipSuccess) return TEMP_E_LAUNCH;
+        attr[vi] = true;
+      }
+      const dim3 g(roles * bpr * 8);
+      if (vi == 0) TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_res<TEMP_GRU_TORCH>), g, dim3(256), lds, st, batch, count, d, lambda, decay_wb, plane, bpr);
+      else TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_res<TEMP_GRU_TYPE1>), g, dim3(256), lds, st, batch, count, d, lambda, decay_wb, plane, bpr);
+      return launch_status();
+    }
+  }
   dim3 grid(ceil_div(max_n, 128), ceil_div(d, 32), count);
 #define TEMP_GRU_FWD(V, H) TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<V, H>), grid, dim3(256), 0, st, batch, d, lambda, decay_wb, plane)
   if (variant == TEMP_GRU_TORCH) { if (hoisted) TEMP_GRU_FWD(TEMP_GRU_TORCH, true); else TEMP_GRU_FWD(TEMP_GRU_TORCH, false); }
