@@ -91,17 +91,17 @@ class BiDynamicRGCN(DynamicRGCN):
         h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
         y1 = enc.layer_1.conv(wb.g_all, h0)
         y2 = enc.layer_2.conv(wb.g_all, y1)                   # ReLU fused (models/BiRRGCN.py:202-203)
-        if wb.visit_rows is not None:                         # distinct-snapshot rows -> visit rows
-            y2 = TF.gather_rows(y2, wb.visit_rows)
         l2 = enc.layer_2
         lam, dec = l2.inv_temperature, l2.decay_spec()
         if wb.program is not None:
             prog = wb.program
-            H_all = gru_chain(y2, prog, [l2.forward_rnn, l2.backward_rnn], lam, isinstance(l2.forward_rnn, GRUCell))
+            H_all = gru_chain(TF.gather_rows(y2, wb.chain_rows), prog, [l2.forward_rnn, l2.backward_rnn], lam, isinstance(l2.forward_rnn, GRUCell))
             rows = lambda i: H_all[prog.inst[i].h0:prog.inst[i].h0 + prog.inst[i].n] if i >= 0 else None
             out = rows(wb.out_inst[0]) + rows(wb.out_inst[1])
             Hf, Hb = rows(wb.hist_inst[0]), rows(wb.hist_inst[1])
             return out, ((Hf, Hf), (Hb, Hb))
+        if wb.visit_rows is not None:                         # distinct-snapshot rows -> visit rows
+            y2 = TF.gather_rows(y2, wb.visit_rows)
 
         def chain(plan, rnn):
             H = None
@@ -127,19 +127,40 @@ class BiDynamicRGCN(DynamicRGCN):
         return out, ((Hf, Hf), (Hb, Hb))
 
     def _build_program(self, wb):
+        """Chain program with ONE contiguous row range per direction: x rows are laid out
+        [forward history | target | backward history | target (second copy)] and the instances follow the
+        same order, so each direction's input-gate GEMM, d_x GEMM and weight-gradient GEMMs run once over
+        all of its 15 positions (the copy costs one row gather; its gradient is summed by the gather's
+        backward)."""
         plan_f, plan_b = wb.plan
-        inst = []
-        last = [-1, -1]
-        for rnn, plan in ((0, plan_f), (1, plan_b)):
-            for st in plan.steps:
-                inst.append(GruInstance(st.n_rows, st.row0, rnn, last[rnn], st.prev_idx, st.dt))
-                last[rnn] = len(inst) - 1
         tf, tb = wb.target, wb.target_b
-        inst.append(GruInstance(tf.n_rows, tf.row0, 0, last[0], tf.prev_idx, tf.dt))
-        inst.append(GruInstance(tf.n_rows, tf.row0, 1, last[1], tb.prev_idx, tb.dt))
+        nf = sum(st.n_rows for st in plan_f.steps)
+        nb = sum(st.n_rows for st in plan_b.steps)
+        nt = tf.n_rows
+        total = nf + nb + nt
+        base = wb.visit_rows.cpu().numpy().astype(np.int64) if wb.visit_rows is not None else np.arange(total, dtype=np.int64)
+        assert base.shape[0] == total and tf.row0 == nf + nb
+        f_rows = base[:nf]
+        b_rows = base[nf:nf + nb]
+        t_rows = base[tf.row0:tf.row0 + nt]
+        wb.chain_rows = torch.from_numpy(np.concatenate([f_rows, t_rows, b_rows, t_rows]).astype(np.int32)).to(self._device())
+        inst = []
+        last = -1
+        for st in plan_f.steps:
+            inst.append(GruInstance(st.n_rows, st.row0, 0, last, st.prev_idx, st.dt))
+            last = len(inst) - 1
+        inst.append(GruInstance(nt, nf, 0, last, tf.prev_idx, tf.dt))
+        hist_f, out_f = last, len(inst) - 1
+        last = -1
+        for st in plan_b.steps:
+            inst.append(GruInstance(st.n_rows, st.row0 + nt, 1, last, st.prev_idx, st.dt))      # backward rows sit after the target copy
+            last = len(inst) - 1
+        inst.append(GruInstance(nt, nf + nt + nb, 1, last, tb.prev_idx, tb.dt))
+        hist_b, out_b = last, len(inst) - 1
         wb.program = GruProgram(inst)
-        wb.out_inst = [len(inst) - 2, len(inst) - 1]
-        wb.hist_inst = last
+        assert len(wb.program.groups) <= 2
+        wb.out_inst = [out_f, out_b]
+        wb.hist_inst = [hist_f, hist_b]
 
     # ---------------------------------------------------------------------------------------------
     def prepare(self, t_list, seq_len, train=True, target_edge_ids=None):
