@@ -16,6 +16,7 @@
 // tile count.
 #pragma once
 #include <stdlib.h>
+#include <type_traits>
 #include "gemm_panel.hpp"
 
 namespace temp {
@@ -33,12 +34,25 @@ struct WresGeom {
   int n_tiles, tps;                      // tps tiles per slice (<= n_tiles)
   int n_slices;                          // the last slice starts at tile n_tiles - tps and stores only its last `tail_store` tiles
   int tail_store;                        // (it overlaps its predecessor when tps does not divide n_tiles)
+  int gate_stride;                       // 0: plain GEMM.  > 0 (= D): GRU mode -- slice j owns columns [32j, 32j+32) of each of the
+                                         // 3 gate blocks of B ([3D][K] stored [n][k]); tile t = gate t at row t*D + 32j of B
+  int split;                             // 1: every block serves ONE problem of the batch (roles = problems x slices)
 };
+
+// An epilogue that needs all tiles of a slice at once (the GRU cell: gates r, z, n of one column) declares
+//   typedef ... GroupPre;  GroupPre pre_group(int row, bool row_ok, long a_src, int j0, int hh) const;   // issue its loads early
+//     (a_src = the A row this output row was computed from: a_idx[row], row itself without a_idx, -1 for a zero row)
+//   void fin_group(const GroupPre&, int row, bool row_ok, int j0, int hh, const f32x16 (&acc)[3]) const;
+template <class Epi, class = void> struct EpiIsGroup { static constexpr bool value = false; };
+template <class Epi> struct EpiIsGroup<Epi, std::void_t<typename Epi::GroupPre>> { static constexpr bool value = true; };
+template <class Epi, bool G = EpiIsGroup<Epi>::value> struct EpiGroupPre { struct type {}; };
+template <class Epi> struct EpiGroupPre<Epi, true> { typedef typename Epi::GroupPre type; };
 
 // Host-side feasibility + geometry.  Returns false when the shape should use the streaming kernel.
 inline bool wres_plan(int N, int K, int lda, int ldb, int trans_b, long long total_rows, WresGeom* g) {
   if (K % 4 || lda % 4 || ldb % 4 || N % 4 || K < 8) return false;
   g->N = N; g->K = K; g->lda = lda; g->ldb = ldb; g->trans_b = trans_b;
+  g->gate_stride = 0; g->split = 0;
   g->kpad = (K + 8 * WRES_QC - 1) / (8 * WRES_QC) * (8 * WRES_QC);
   g->ldk = g->kpad + 4;                  // kpad / 4 is even, so ldk / 4 is odd: conflict-free ds_read_b128 (see header)
   g->n_tiles = ceil_div(N, 32);
@@ -66,60 +80,90 @@ inline bool wres_plan(int N, int K, int lda, int ldb, int trans_b, long long tot
 
 // One launch covers all column slices (NTS tiles each); every XCD runs `bps` blocks per slice.
 // VAR is 0 in the library; tools/wres_probe.hip instantiates ablations (bit0: no A loads, bit1: no epilogue,
-// bit2: no LDS reads of B).
+// bit2: no LDS reads of B, bit3: per-wave s_memtime stamps through epi.stamp()).
 template <int NTS, class Epi, int VAR = 0>
 __global__ void __launch_bounds__(256, 2) k_gemm_wres(PanelBatch<Epi> batch, int count, WresGeom g, int bps) {
   extern __shared__ __attribute__((aligned(16))) float Ws[];
   constexpr int QC = WRES_QC;
+  constexpr bool GROUP = EpiIsGroup<Epi>::value;
+  static_assert(!GROUP || NTS == 3, "grouped epilogues own the three gate tiles of a slice");
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int slice = local / bps, idx = local - slice * bps;
-  const bool tail = slice == g.n_slices - 1;
-  const int n0 = (tail ? g.n_tiles - NTS : slice * NTS) * 32;
+  const int role = local / bps, idx = local - role * bps;
+  const int zsel = g.split ? role / g.n_slices : -1;          // split: this block serves problem zsel only
+  const int slice = g.split ? role - zsel * g.n_slices : role;
+  const bool tail = !GROUP && slice == g.n_slices - 1;
+  const int n0 = GROUP ? slice * 32 : (tail ? g.n_tiles - NTS : slice * NTS) * 32;
   const int t_store = tail ? NTS - g.tail_store : 0;       // first tile of this slice that is stored
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
   const int K = g.K, ldk = g.ldk;
   const int nch = g.kpad / (8 * QC);
 
+  if constexpr (VAR & 8) batch.p[0].epi.stamp(0, __builtin_amdgcn_s_memtime());
   for (int z = 0; z < count; ++z) {
     const PanelProblem<Epi>& pb = batch.p[z];
     const int M = pb.M;
-    if (M <= 0) continue;
-    if (z == 0 || pb.B != batch.p[z - 1].B) {
-      if (z > 0) __syncthreads();
+    if (M <= 0 || (zsel >= 0 && z != zsel)) continue;
+    if (zsel >= 0 || z == 0 || pb.B != batch.p[z - 1].B) {
+      if (zsel < 0 && z > 0) __syncthreads();
       // ---- prologue: this block's slice of B -> LDS as [col][k] (k contiguous), zero padded.
-      // Loads are issued in batches of 8 per thread before the first LDS store of the batch.
+      // Loads are issued in batches of WRES_PRO per thread (a 96 x 200 slice = 19 float4 per thread: ONE batch, i.e. one
+      // memory round trip) before the first LDS store of the batch.
+      // No integer division here: with runtime divisors it cost ~13 k cycles per wave (measured), more than
+      // the copy itself.  Threads are laid out (tx, ty) with power-of-two widths; 8 loads per thread in flight.
       const float* __restrict__ B = pb.B;
-      const int cols = NTS * 32, k4n = g.kpad / 4, total = cols * k4n;
-      for (int base = threadIdx.x; base < total; base += 256 * 8) {
-        float4 v[8];
-        int dst[8];
+      constexpr int COLS = NTS * 32;
+      const int k4n = g.kpad >> 2;
+      auto col_of = [&](int c, bool* ok) {                       // LDS column c -> column of B
+        const int n = GROUP ? (c >> 5) * g.gate_stride + n0 + (c & 31) : n0 + c;
+        *ok = GROUP ? (n0 + (c & 31) < g.gate_stride) : (n < g.N);
+        return n;
+      };
+      if (g.trans_b) {                                           // B stored [n][k]: lanes run along k
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        for (int k4 = tx; k4 < k4n; k4 += 64) {
+          const int k = k4 * 4;
+          for (int c0 = ty; c0 < COLS; c0 += 32) {
+            float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int p = base + u * 256;
-          int c, k4;
-          if (g.trans_b) { c = p / k4n; k4 = p - c * k4n; }          // B stored [n][k]: consecutive threads along k
-          else { k4 = p / cols; c = p - k4 * cols; }                   // B stored [k][n]: consecutive threads along n
-          const int k = k4 * 4, n = n0 + c;
-          const bool ok = p < total && n < g.N && k < K;
-          dst[u] = p < total ? c * ldk + k : -1;
-          if (g.trans_b) {
-            const float4 x = ld4(B + (ok ? (size_t)n * g.ldb + k : 0));
-            v[u] = ok ? x : zero4();
-          } else {
-            const float* b = B + (ok ? (size_t)k * g.ldb + n : 0);
-            const size_t st = ok ? (size_t)g.ldb : 0;
-            const float4 x = make_float4(b[0], b[st], b[2 * st], b[3 * st]);
-            v[u] = ok ? x : zero4();
+            for (int u = 0; u < 8; ++u) {
+              bool okc;
+              const int n = col_of(c0 + 4 * u, &okc);
+              const bool ok = okc && k < K;
+              v[u] = ld4(B + (ok ? (size_t)n * g.ldb + k : 0));
+              if (!ok) v[u] = zero4();
+            }
+            if constexpr (VAR & 8) pb.epi.stamp(7, __builtin_amdgcn_s_memtime());
+#pragma unroll
+            for (int u = 0; u < 8; ++u) st4(Ws + (size_t)(c0 + 4 * u) * ldk + k, v[u]);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+      } else {                                                   // B stored [k][n]: lanes run along n
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int c = tx; c < COLS; c += 32) {
+          bool okc;
+          const int n = col_of(c, &okc);
+          for (int k40 = ty; k40 < k4n; k40 += 64) {
+            float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (dst[u] >= 0) st4(Ws + dst[u], v[u]);
+            for (int u = 0; u < 8; ++u) {
+              const int k = (k40 + 8 * u) * 4;
+              const bool ok = okc && k < K;
+              const float* b = B + (ok ? (size_t)k * g.ldb + n : 0);
+              const size_t st = ok ? (size_t)g.ldb : 0;
+              v[u] = make_float4(b[0], b[st], b[2 * st], b[3 * st]);
+              if (!ok) v[u] = zero4();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (k40 + 8 * u < k4n) st4(Ws + (size_t)c * ldk + (k40 + 8 * u) * 4, v[u]);
+          }
+        }
       }
+      if constexpr (VAR & 8) pb.epi.stamp(5, __builtin_amdgcn_s_memtime());
       __syncthreads();
     }
+    if constexpr (VAR & 8) pb.epi.stamp(1, __builtin_amdgcn_s_memtime());
     const float* __restrict__ A = pb.A;
     const int32_t* __restrict__ a_idx = pb.a_idx;
     const Epi& epi = pb.epi;
@@ -136,15 +180,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wres(PanelBatch<Epi> batch, int
     int ld_panel = panel, ld_chunk = 0;
     const float* ld_ptr = A;
     bool ld_ok = false;
+    long ld_src = -1;
     auto setup_ld = [&]() {
       long src = -1;
       const int r = ld_panel * 32 + li;
       if (ld_panel < p_end && r < M) src = a_idx ? (long)a_idx[r] : (long)r;
+      ld_src = src;
       ld_ok = src >= 0;
       ld_ptr = A + (size_t)(ld_ok ? src : 0) * g.lda + 4 * hh;
     };
-    auto issue = [&](float4 (&buf)[QC], bool& ok_out, int& kc_out) {
+    auto issue = [&](float4 (&buf)[QC], bool& ok_out, int& kc_out, long& src_out) {
       ok_out = ld_ok;
+      src_out = ld_src;
       kc_out = ld_chunk * 8 * QC;
 #pragma unroll
       for (int q = 0; q < QC; ++q) {
@@ -161,8 +208,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wres(PanelBatch<Epi> batch, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     };
-    auto stage = [&](float4 (&cur)[QC], bool cur_ok, int kc, float4 (&nxt)[QC], bool& nxt_ok, int& nxt_kc) {
-      issue(nxt, nxt_ok, nxt_kc);          // unconditional (past the end: a harmless re-read of row 0) so the vmcnt waits stay exact
+    typename EpiGroupPre<Epi>::type gpre;
+    auto stage = [&](float4 (&cur)[QC], bool cur_ok, int kc, long cur_src, float4 (&nxt)[QC], bool& nxt_ok, int& nxt_kc, long& nxt_src) {
+      issue(nxt, nxt_ok, nxt_kc, nxt_src);          // unconditional (past the end: a harmless re-read of row 0) so the vmcnt waits stay exact
+      if constexpr (GROUP) {               // the epilogue's own loads ride behind the MFMAs of the panel's last stage
+        if (chunk == nch - 1) gpre = epi.pre_group(panel * 32 + li, panel * 32 + li < M, cur_src, n0, hh);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < QC; ++q) {
@@ -187,6 +238,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wres(PanelBatch<Epi> batch, int
         // epilogue: lane (li, hh) owns output row; registers 4q..4q+3 of tile t are columns n0 + t*32 + 8q + 4hh .. +3
         const int row = panel * 32 + li;
         const bool row_ok = row < M;
+        if constexpr (VAR & 8) epi.stamp(2, __builtin_amdgcn_s_memtime());
+        if constexpr (GROUP) {
+          epi.fin_group(gpre, row, row_ok, n0, hh, acc);
+        } else {
         const typename Epi::RowCtx rc = epi.row_ctx(row_ok ? row : 0);
 #pragma unroll
         for (int t = 0; t < NTS; ++t) {
@@ -206,6 +261,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wres(PanelBatch<Epi> batch, int
             if (okc[q]) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), pre[q]);
           }
         }
+        }
+        if constexpr (VAR & 8) epi.stamp(3, __builtin_amdgcn_s_memtime());
         zero_acc();
         chunk = 0;
         panel += stride;
@@ -215,31 +272,34 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wres(PanelBatch<Epi> batch, int
       float4 bufA[QC], bufB[QC];
       bool okA = false, okB = false;
       int kcA = 0, kcB = 0;
+      long srcA = -1, srcB = -1;
       setup_ld();
       zero_acc();
-      issue(bufA, okA, kcA);
+      issue(bufA, okA, kcA, srcA);
       while (true) {
-        stage(bufA, okA, kcA, bufB, okB, kcB);
+        stage(bufA, okA, kcA, srcA, bufB, okB, kcB, srcB);
         if (panel >= p_end) break;
-        stage(bufB, okB, kcB, bufA, okA, kcA);
+        stage(bufB, okB, kcB, srcB, bufA, okA, kcA, srcA);
         if (panel >= p_end) break;
       }
     }
+    if constexpr (VAR & 8) epi.stamp(4, __builtin_amdgcn_s_memtime());
   }
 }
 
 template <int NTS, class Epi>
-int launch_wres_one(int kid, const PanelBatch<Epi>& batch, int count, const WresGeom& g, hipStream_t st) {
+int launch_wres_one(int kid, const PanelBatch<Epi>& batch, int count, const WresGeom& g, hipStream_t st, int local_blocks = WRES_LOCAL_BLOCKS) {
   static bool attr_set = false;          // per instantiation; idempotent
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_gemm_wres<NTS, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES) != hipSuccess)
       return TEMP_E_LAUNCH;
     attr_set = true;
   }
-  int bps = WRES_LOCAL_BLOCKS / g.n_slices;
+  const int roles = g.n_slices * (g.split ? count : 1);
+  int bps = local_blocks / roles;
   if (bps < 1) bps = 1;
   const size_t lds = (size_t)NTS * 32 * g.ldk * 4;
-  TEMP_LAUNCH(kid, (k_gemm_wres<NTS, Epi>), dim3(g.n_slices * bps * 8), dim3(256), lds, st, batch, count, g, bps);
+  TEMP_LAUNCH(kid, (k_gemm_wres<NTS, Epi>), dim3(roles * bps * 8), dim3(256), lds, st, batch, count, g, bps);
   return launch_status();
 }
 

@@ -16,6 +16,17 @@ namespace temp {
 #define GRU_KC 40
 #define GRU_LDB 33
 
+// Gate non-linearities on the hardware exp / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  libm's
+// expf / tanhf cost ~150 VALU instructions per element, i.e. ~10 us per position of the window chain.
+// tanh switches to its odd Taylor polynomial below |x| = 0.25, where 1 - 2/(1+e^2x) would cancel.
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float gate_tanh(float x) {
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
+  const float x2 = x * x;
+  const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+  return fabsf(x) < 0.25f ? small : big;
+}
+
 __device__ __forceinline__ float decay_factor(float dt, float lambda, const float* wb) {
   if (wb) return expf(-fmaxf(fmaf(wb[0], dt, wb[1]), 0.f));
   return expf(-dt * lambda);
@@ -184,10 +195,10 @@ __device__ __forceinline__ void gru_cell_epilogue(const GruFwdCell& cell, int D,
         if (VARIANT == TEMP_GRU_TORCH) { xr += g0v[e]; xz += g1v[e]; }
         xn = g2v[e];
       }
-      const float rg = 1.f / (1.f + expf(-(xr + birv[e] + bhrv[e])));
-      const float zg = 1.f / (1.f + expf(-(xz + bizv[e] + bhzv[e])));
+      const float rg = gate_sigmoid(xr + birv[e] + bhrv[e]);
+      const float zg = gate_sigmoid(xz + bizv[e] + bhzv[e]);
       const float hn = acc_hn[r] + bhnv[e];
-      const float ng = tanhf(xn + binv[e] + rg * hn);
+      const float ng = gate_tanh(xn + binv[e] + rg * hn);
       o_h[e] = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg) * ng + zg * hdv[e]) : (ng + zg * (hdv[e] - ng));
       o_r[e] = rg; o_z[e] = zg; o_n[e] = ng; o_hn[e] = hn;
     }
@@ -355,6 +366,185 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_res(GruFwdBatch batch, int c
   }
 }
 
+// Panel-block cell kernel (hoisted input gates only).  One block = ONE 32-row panel of one cell; its
+// ceil(D/32) waves each own a 32-column group of all three gates.  The decayed previous-state rows of the
+// panel (gathered through prev_idx) are built ONCE per block in LDS ([row][k], stride D+4: conflict-free
+// ds_read_b128) instead of once per column group; the W_hh operand needs no staging at all: W_hh is stored
+// [3D][D], so lane (column li, k-half hh) reads one float4 of its own weight row per 4 MFMAs straight from
+// global memory (L2-resident, 480 KB), prefetched GRUP_PF q-steps ahead.  No prologue, one barrier.
+#define GRUP_PF 6
+template <int VARIANT>
+__global__ void __launch_bounds__(512) k_gru_fwd_pb(GruFwdBatch batch, int count, int D, float lambda, const float* __restrict__ decay_wb,
+                                                     size_t plane) {
+  extern __shared__ __attribute__((aligned(16))) float As[];
+  int z = 0, panel = blockIdx.x;
+  for (; z < count; ++z) {
+    const int np = (batch.c[z].n + 31) >> 5;
+    if (panel < np) break;
+    panel -= np;
+  }
+  if (z >= count) return;
+  const GruFwdCell& cell = batch.c[z];
+  const int n = cell.n;
+  const float* __restrict__ prev = cell.prev;
+  const int32_t* __restrict__ prev_idx = cell.prev_idx;
+  const float* __restrict__ dt = cell.dt;
+  const float* __restrict__ W = cell.w_hh;
+  const int kpad = (D + 7) & ~7, ldk = kpad + (((kpad >> 2) & 1) ? 8 : 4), k4n = kpad >> 2;
+  const int m0 = panel * 32;
+  // phase A: As[r][k] = dec(r) * prev[prev_idx[r]][k]  (zero rows for inactive / out-of-range)
+  for (int p = threadIdx.x; p < 32 * k4n; p += blockDim.x) {
+    const int r = p / k4n, k = (p - r * k4n) * 4;
+    const int row = m0 + r;
+    float4 v = zero4();
+    if (row < n && k < D) {
+      const int pr = prev_idx ? prev_idx[row] : row;
+      if (pr >= 0) v = scale4(ld4(prev + (size_t)pr * D + k), decay_factor(dt[row], lambda, decay_wb));
+    }
+    st4(As + (size_t)r * ldk + k, v);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, li = lane & 31;
+  const int j0 = wave * 32;
+  if (j0 >= D) return;
+  const int nq = kpad >> 3;
+  const bool col_ok = j0 + li < D;
+  const float* w0p = W + (size_t)(col_ok ? j0 + li : 0) * D + 4 * hh;
+  const float* w1p = w0p + (size_t)D * D;
+  const float* w2p = w1p + (size_t)D * D;
+  const float* arow_p = As + (size_t)li * ldk + 4 * hh;
+  f32x16 acc_r, acc_z, acc_hn, acc_in;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_hn[r] = 0.f; acc_in[r] = 0.f; }
+  float4 w0[GRUP_PF], w1[GRUP_PF], w2[GRUP_PF];
+  auto kofs = [&](int q) { return (q < nq && (q * 8 + 4 * hh < D)) ? q * 8 : -4 * hh; };   // out of range: re-read k = 0..3, zeroed at use
+#pragma unroll
+  for (int q = 0; q < GRUP_PF; ++q) { const int o = kofs(q); w0[q] = ld4(w0p + o); w1[q] = ld4(w1p + o); w2[q] = ld4(w2p + o); }
+  for (int qb = 0; qb < nq; qb += GRUP_PF) {
+#pragma unroll
+    for (int u = 0; u < GRUP_PF; ++u) {
+      const int q = qb + u;
+      const bool ok = col_ok && q < nq && (q * 8 + 4 * hh < D);
+      const float4 a = ld4(arow_p + (q < nq ? q * 8 : 0));
+      const float4 x0 = ok ? w0[u] : zero4(), x1 = ok ? w1[u] : zero4(), x2 = ok ? w2[u] : zero4();
+      const int o = kofs(q + GRUP_PF);
+      w0[u] = ld4(w0p + o); w1[u] = ld4(w1p + o); w2[u] = ld4(w2p + o);          // refill the slot for q + GRUP_PF
+      if (q < nq) {
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, a.x, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, a.x, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, a.x, acc_hn, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, a.y, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, a.y, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, a.y, acc_hn, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, a.z, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, a.z, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.z, a.z, acc_hn, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, a.w, acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, a.w, acc_z, 0, 0, 0);
+        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.w, a.w, acc_hn, 0, 0, 0);
+      }
+    }
+  }
+  const int arow = m0 + li;
+  const bool arow_ok = arow < n;
+  int prow = -1;
+  float dec = 0.f;
+  if (arow_ok) {
+    prow = prev_idx ? prev_idx[arow] : arow;
+    dec = decay_factor(dt[arow], lambda, decay_wb);
+  }
+  gru_cell_epilogue<VARIANT, true>(cell, D, plane, arow, arow_ok, prow, dec, j0, hh, acc_r, acc_z, acc_in, acc_hn);
+}
+
+// Grouped epilogue of the weights-resident GEMM (gemm_wres.hpp, GRU mode): the recurrent half of a cell,
+//   acc[g] = prev[prev_idx[row]] . W_hh[g]^T   (UNdecayed: the per-row decay commutes with the product),
+// finished into gates / new state exactly like gru_cell_epilogue.  Its own operands (hoisted input gates,
+// previous-state columns, dt) are loaded while the MFMAs of the panel's last K stage run.
+template <int VARIANT>
+struct EpiGruCell {
+  GruFwdCell cell; int D; size_t plane; float lambda; const float* decay_wb;
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
+  __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
+  __device__ __forceinline__ void fin4(const RowCtx&, int, int, float4, float4) const {}
+  struct GroupPre { float4 hd[4], g0[4], g1[4], g2[4]; float dt; long src; };
+  __device__ __forceinline__ GroupPre pre_group(int row, bool row_ok, long a_src, int j0, int hh) const {
+    GroupPre p;
+    const int G = (VARIANT == TEMP_GRU_TORCH) ? 3 * D : D;
+    p.src = row_ok ? a_src : -1;
+    p.dt = cell.dt[row_ok ? row : 0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = j0 + 8 * q + 4 * hh;
+      const bool ok = row_ok && col < D;
+      const bool hp = ok && a_src >= 0;
+      p.hd[q] = ld4(cell.prev + (size_t)(hp ? a_src : 0) * D + (hp ? col : 0));
+      const float* g = cell.gi + (size_t)(ok ? row : 0) * G + (ok ? col : 0);
+      if (VARIANT == TEMP_GRU_TORCH) { p.g0[q] = ld4(g); p.g1[q] = ld4(g + D); p.g2[q] = ld4(g + 2 * D); }
+      else { p.g0[q] = zero4(); p.g1[q] = zero4(); p.g2[q] = ld4(g); }
+    }
+    return p;
+  }
+  __device__ __forceinline__ void fin_group(const GroupPre& p, int row, bool row_ok, int j0, int hh, const f32x16 (&acc)[3]) const {
+    const float dec = decay_factor(p.dt, lambda, decay_wb);
+    float* __restrict__ h_out = cell.h_out;
+    float* __restrict__ saved = cell.saved;
+    const float* __restrict__ b_hh = cell.b_hh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = j0 + 8 * q + 4 * hh;
+      if (!(row_ok && col < D)) continue;
+      const bool hp = p.src >= 0;
+      const float4 hd4 = hp ? scale4(p.hd[q], dec) : zero4();
+      const float4 bhr = ld4(b_hh + col), bhz = ld4(b_hh + D + col), bhn = ld4(b_hh + 2 * D + col);
+      const float hdv[4] = {hd4.x, hd4.y, hd4.z, hd4.w};
+      const float g0v[4] = {p.g0[q].x, p.g0[q].y, p.g0[q].z, p.g0[q].w}, g1v[4] = {p.g1[q].x, p.g1[q].y, p.g1[q].z, p.g1[q].w};
+      const float g2v[4] = {p.g2[q].x, p.g2[q].y, p.g2[q].z, p.g2[q].w};
+      const float bhrv[4] = {bhr.x, bhr.y, bhr.z, bhr.w}, bhzv[4] = {bhz.x, bhz.y, bhz.z, bhz.w}, bhnv[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
+      float o_h[4], o_r[4], o_z[4], o_n[4], o_hn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        float xr = acc[0][r] * dec, xz = acc[1][r] * dec;
+        if (VARIANT == TEMP_GRU_TORCH) { xr += g0v[e]; xz += g1v[e]; }
+        const float rg = gate_sigmoid(xr + bhrv[e]);
+        const float zg = gate_sigmoid(xz + bhzv[e]);
+        const float hn = acc[2][r] * dec + bhnv[e];
+        const float ng = gate_tanh(g2v[e] + rg * hn);
+        o_h[e] = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg) * ng + zg * hdv[e]) : (ng + zg * (hdv[e] - ng));
+        o_r[e] = rg; o_z[e] = zg; o_n[e] = ng; o_hn[e] = hn;
+      }
+      const size_t o = (size_t)row * D + col;
+      st4(h_out + o, make_float4(o_h[0], o_h[1], o_h[2], o_h[3]));
+      st4(saved + o, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
+      st4(saved + plane + o, make_float4(o_z[0], o_z[1], o_z[2], o_z[3]));
+      st4(saved + 2 * plane + o, make_float4(o_n[0], o_n[1], o_n[2], o_n[3]));
+      st4(saved + 3 * plane + o, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
+      st4(saved + 4 * plane + o, hd4);
+    }
+  }
+};
+
+template <int VARIANT>
+static int launch_gru_fwd_wres(const GruFwdBatch& batch, int count, int d, float lambda, const float* decay_wb, size_t plane, hipStream_t st) {
+  typedef EpiGruCell<VARIANT> Epi;
+  PanelBatch<Epi> pb;
+  long long rows = 0;
+  for (int i = 0; i < PANEL_MAXP; ++i) pb.p[i] = PanelProblem<Epi>{0, nullptr, nullptr, nullptr, Epi{batch.c[0], d, plane, lambda, decay_wb}};
+  for (int i = 0; i < count; ++i) {
+    const GruFwdCell& c = batch.c[i];
+    pb.p[i] = PanelProblem<Epi>{c.n, c.prev, c.prev_idx, c.w_hh, Epi{c, d, plane, lambda, decay_wb}};
+    rows += c.n > 0 ? c.n : 0;
+  }
+  WresGeom g;
+  if (!wres_plan(3 * d, d, d, d, 1, 1 << 20, &g)) return TEMP_E_UNSUPPORTED;
+  if ((size_t)96 * g.ldk * 4 > WRES_LDS_BYTES) return TEMP_E_UNSUPPORTED;
+  g.tps = 3; g.n_slices = ceil_div(d, 32); g.tail_store = 3; g.gate_stride = d; g.split = 1;
+  // two blocks per CU: two waves per SIMD interleave, one wave's MFMAs covering the other's loads / epilogue
+  return launch_wres_one<3, Epi>(K_GRU_FWD, pb, count, g, st, 64);
+}
+
 // Gate gradients (pointwise).  dgi: [n, 3D] (torch) or [n, D] (type-1); dgh: [n, 3D]; decv: [n].
 // d_h = dh_up (nullable) + d_prev_next[next_idx[row]] (nullable; the gradient flowing back from the
 // next window position, gathered through the inverse row map, -1 = none).  dhz (= d_h * z) seeds the
@@ -483,12 +673,32 @@ static int launch_gru_fwd_batch(const GruFwdBatch& batch, int count, int d, int 
   for (int i = 0; i < count; ++i) if (batch.c[i].n > max_n) max_n = batch.c[i].n;
   if (max_n <= 0) return TEMP_OK;
   static const bool res_off = [] { const char* e = getenv("TEMP_GRU_STREAM"); return e && e[0] == '1'; }();
+  static const int pb_mode = [] { const char* e = getenv("TEMP_GRU_PB"); return e ? atoi(e) : 2; }();
+  if (hoisted && d % 8 == 0 && !res_off && pb_mode == 2) {
+    int rc = (variant == TEMP_GRU_TORCH) ? launch_gru_fwd_wres<TEMP_GRU_TORCH>(batch, count, d, lambda, decay_wb, plane, st)
+                                         : launch_gru_fwd_wres<TEMP_GRU_TYPE1>(batch, count, d, lambda, decay_wb, plane, st);
+    if (rc != TEMP_E_UNSUPPORTED) return rc;
+  }
+  if (hoisted && d <= 256 && d % 8 == 0 && !res_off && pb_mode == 1) {
+    int panels = 0;
+    for (int i = 0; i < count; ++i) panels += ceil_div(batch.c[i].n > 0 ? batch.c[i].n : 0, 32);
+    const int waves = ceil_div(d, 32);
+    const int kp = (d + 7) & ~7;
+    const size_t lds = (size_t)32 * (kp + 8) * 4;
+    if (variant == TEMP_GRU_TORCH)
+      TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_pb<TEMP_GRU_TORCH>), dim3(panels), dim3(waves * 64), lds, st, batch, count, d, lambda, decay_wb, plane);
+    else
+      TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_pb<TEMP_GRU_TYPE1>), dim3(panels), dim3(waves * 64), lds, st, batch, count, d, lambda, decay_wb, plane);
+    return launch_status();
+  }
   if (hoisted && d <= 256 && d % 8 == 0 && !res_off) {
     // weights-resident variant: roles = (cell, 32-column group); 64 block slots per XCD shared by the roles
     const int roles = count * ceil_div(d, 32);
     int bpr = 64 / roles;
     const int need = ceil_div(ceil_div(ceil_div(max_n, 32), 8), 4);        // blocks that still get a panel per XCD
     if (bpr > need) bpr = need;
+    static const int bpr_force = [] { const char* e = getenv("TEMP_GRU_BPR"); return e ? atoi(e) : 0; }();
+    if (bpr_force > 0) bpr = bpr_force;
     if (bpr >= 1) {
       const size_t lds = (size_t)96 * (((d + 7) & ~7) + 8) * 4;
       static bool attr[2] = {false, false};

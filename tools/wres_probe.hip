@@ -5,12 +5,19 @@
 #include <cstdio>
 #include <vector>
 using namespace temp;
+static unsigned long long* DBG = nullptr;
 
 int temp::trace_open(int, hipStream_t) { return -1; }
 void temp::trace_close(int, hipStream_t) {}
 
 struct EpiP {
   float* out; int ldo;
+  unsigned long long* dbg;      // [waves][8]: first stamp of each kind, plus the last stamp 3 in slot 5
+  __device__ __forceinline__ void stamp(int k, unsigned long long t) const {
+    if ((threadIdx.x & 63) != 0 || !dbg) return;
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    if (d[k] == 0) d[k] = t;
+  }
   struct RowCtx {};
   __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
   __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
@@ -40,8 +47,8 @@ static void run(const char* name, int M, int N, int K, const float* A, const flo
   g.n_slices = (g.n_tiles + NTS - 1) / NTS;
   g.tail_store = g.n_tiles - (g.n_slices - 1) * NTS;
   PanelBatch<EpiP> batch;
-  for (int i = 0; i < PANEL_MAXP; ++i) batch.p[i] = PanelProblem<EpiP>{0, nullptr, nullptr, nullptr, EpiP{C, N}};
-  batch.p[0] = PanelProblem<EpiP>{M, A, nullptr, B, EpiP{C, N}};
+  for (int i = 0; i < PANEL_MAXP; ++i) batch.p[i] = PanelProblem<EpiP>{0, nullptr, nullptr, nullptr, EpiP{C, N, DBG}};
+  batch.p[0] = PanelProblem<EpiP>{M, A, nullptr, B, EpiP{C, N, DBG}};
   hipFuncSetAttribute((const void*)k_gemm_wres<NTS, EpiP, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
   int bps = 32 * blocks_per_cu / g.n_slices;
   if (bps < 1) bps = 1;
@@ -49,6 +56,43 @@ static void run(const char* name, int M, int N, int K, const float* A, const flo
   float ms = time_ms([&] { hipLaunchKernelGGL((k_gemm_wres<NTS, EpiP, VAR>), dim3(g.n_slices * bps * 8), dim3(256), lds, 0, batch, 1, g, bps); });
   const double fl = 2.0 * M * K * (double)N;
   printf("%-30s M=%6d N=%3d K=%3d NTS=%d slices=%d bps=%2d  %.4f ms  %.1f TF/s useful\n", name, M, N, K, NTS, g.n_slices, bps, ms, fl / ms / 1e9);
+}
+
+template <int NTS>
+static void timeline(const char* name, int M, int N, int K, const float* A, const float* B, float* C, int trans_b, int blocks_per_cu) {
+  WresGeom g;
+  wres_plan(N, K, K, trans_b ? K : N, trans_b, 1 << 20, &g);
+  g.tps = NTS; g.n_slices = (g.n_tiles + NTS - 1) / NTS; g.tail_store = g.n_tiles - (g.n_slices - 1) * NTS;
+  int bps = 32 * blocks_per_cu / g.n_slices;
+  const int nblk = g.n_slices * bps * 8, nw = nblk * 4;
+  unsigned long long* d;
+  hipMalloc(&d, (size_t)nw * 64);
+  hipMemset(d, 0, (size_t)nw * 64);
+  DBG = d;
+  PanelBatch<EpiP> batch;
+  for (int i = 0; i < PANEL_MAXP; ++i) batch.p[i] = PanelProblem<EpiP>{0, nullptr, nullptr, nullptr, EpiP{C, N, d}};
+  batch.p[0] = PanelProblem<EpiP>{M, A, nullptr, B, EpiP{C, N, d}};
+  hipFuncSetAttribute((const void*)k_gemm_wres<NTS, EpiP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
+  const size_t lds = (size_t)NTS * 32 * g.ldk * 4;
+  hipLaunchKernelGGL((k_gemm_wres<NTS, EpiP, 0>), dim3(nblk), dim3(256), lds, 0, batch, 1, g, bps);      // warm
+  hipDeviceSynchronize();
+  hipLaunchKernelGGL((k_gemm_wres<NTS, EpiP, 8>), dim3(nblk), dim3(256), lds, 0, batch, 1, g, bps);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h((size_t)nw * 8);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  // per-wave durations (each XCD has its own counter base, so only differences inside a wave are meaningful)
+  const char* lab[7] = {"prologue (start -> W slice in LDS)", "panel 1: A latency + MFMAs", "panel 1: epilogue", "rest (further panels)", "whole wave", "  prologue: start -> loads issued", "  prologue: loads issued -> LDS stores issued"};
+  double sum[7] = {0}, mx[7] = {0};
+  int cnt[7] = {0};
+  auto add = [&](int k, unsigned long long a, unsigned long long b) { if (a && b && b >= a) { const double v = (double)(b - a); sum[k] += v; if (v > mx[k]) mx[k] = v; cnt[k]++; } };
+  for (int w = 0; w < nw; ++w) {
+    const unsigned long long* t = &h[(size_t)w * 8];
+    add(0, t[0], t[1]); add(1, t[1], t[2]); add(2, t[2], t[3]); add(3, t[3], t[4]); add(4, t[0], t[4]); add(5, t[0], t[7]); add(6, t[7], t[5]);
+  }
+  printf("%s M=%d N=%d K=%d NTS=%d blocks=%d: s_memtime ticks per wave (avg / max)\n", name, M, N, K, NTS, nblk);
+  for (int k = 0; k < 7; ++k) printf("   %-40s avg %9.0f  max %9.0f  (n=%d)\n", lab[k], cnt[k] ? sum[k] / cnt[k] : 0.0, mx[k], cnt[k]);
+  DBG = nullptr;
+  hipFree(d);
 }
 
 int main() {
@@ -59,7 +103,10 @@ int main() {
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
   hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)600 * 600 * 4, hipMemcpyHostToDevice);
-  for (int M : {30000, 120000, 8000}) {
+  timeline<3>("gi-shape 2blk/CU", 8000, 600, 200, A, B, C, 1, 2);
+  timeline<3>("gi-shape 1blk/CU", 8000, 600, 200, A, B, C, 1, 1);
+  timeline<3>("gi-shape 2blk/CU", 120000, 600, 200, A, B, C, 1, 2);
+  for (int M : {0}) {
     run<3, 0>("gi K=200 N=600", M, 600, 200, A, B, C, 1);
     run<2, 0>("gi K=200 N=600", M, 600, 200, A, B, C, 1);
     run<2, 0>("gi K=200 N=600 3blk/CU", M, 600, 200, A, B, C, 1, 3);
