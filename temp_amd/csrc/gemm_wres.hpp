@@ -25,6 +25,7 @@ namespace temp {
 #define WRES_LDS_BYTES (80 * 1024)
 #define WRES_LOCAL_BLOCKS 64             // blocks per XCD (2 per CU)
 
+#define WRES_MIN_ROWS 4096
 #define WRES_QC 5                        // q-steps (8 k each) per software-pipeline stage: 40 k, 5 float4 of A per lane
 
 struct WresGeom {
@@ -74,7 +75,7 @@ inline bool wres_plan(int N, int K, int lda, int ldb, int trans_b, long long tot
   g->n_slices = ceil_div(g->n_tiles, best);
   g->tail_store = g->n_tiles - (g->n_slices - 1) * best;
   if (g->n_slices > 16) return false;                  // wide outputs (score matrix): stream B instead
-  if (total_rows < 16384) return false;                // short problems (the per-position GEMMs of the GRU chain): the B prologue dominates
+  if (total_rows < WRES_MIN_ROWS) return false;        // tiny problems: the B prologue dominates
   return true;
 }
 
@@ -324,7 +325,13 @@ int launch_gemm_panel_multi(int kid, const PanelBatch<Epi>& batch, int count, in
   for (int i = 0; i < count; ++i) rows += batch.p[i].M > 0 ? batch.p[i].M : 0;
   if (rows <= 0 || N <= 0) return TEMP_OK;
   WresGeom g;
-  if (!wres_disabled() && wres_plan(N, K, lda, ldb, trans_b, rows, &g)) return launch_gemm_wres(kid, batch, count, g, st);
+  if (!wres_disabled() && wres_plan(N, K, lda, ldb, trans_b, rows, &g)) {
+    // problems with different B matrices: give every problem its own blocks instead of re-staging B per problem
+    bool distinct = count > 1;
+    for (int i = 1; i < count; ++i) distinct = distinct && batch.p[i].B != batch.p[i - 1].B;
+    if (distinct && g.n_slices * count <= WRES_LOCAL_BLOCKS) g.split = 1;
+    return launch_gemm_wres(kid, batch, count, g, st);
+  }
   return launch_gemm_stream_multi(kid, batch, count, N, K, lda, ldb, trans_b, st);
 }
 
