@@ -313,6 +313,5 @@ class DynamicRGCN(TKG_Module):
             triplets, neg_tail, neg_head = triplets.to(dev), neg_tail.to(dev), neg_head.to(dev)
             labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=dev)
             all_embeds_g = all_list[i] if batched else self.get_all_embeds_Gt(ent_embed, g, t, wb.plan, i, hist)
-            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
-            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False)
+            loss = loss + self.train_link_prediction_both(ent_embed, triplets, neg_tail, neg_head, labels, all_embeds_g)
         return loss

@@ -166,8 +166,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         for i, ent_embed in enumerate(per_graph):
             triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
             labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=dev)
-            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_list[i], corrupt_tail=True)
-            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_list[i], corrupt_tail=False)
+            loss = loss + self.train_link_prediction_both(ent_embed, triplets, neg_tail, neg_head, labels, all_list[i])
         return loss
 
     def evaluate(self, t_list, val=True):

@@ -90,6 +90,5 @@ class StaticRGCN(TKG_Module):
                 triplets, neg_tail, neg_head, labels = self.corrupter.single_graph_negative_sampling(t, g, self.num_ents)
             triplets, neg_tail, neg_head, labels = triplets.to(dev), neg_tail.to(dev), neg_head.to(dev), labels.to(dev)
             all_embeds_g = self.get_all_embeds_Gt(t, g, ent_embed)
-            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
-            loss = loss + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False)
+            loss = loss + self.train_link_prediction_both(ent_embed, triplets, neg_tail, neg_head, labels, all_embeds_g)
         return loss

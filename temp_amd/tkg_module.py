@@ -76,6 +76,23 @@ class TKG_Module(nn.Module):
             score = self.calc_score(all_embeds_g[neg_samples], r, ent_embed[triplets[:, 2]], mode='head')
         return F.cross_entropy(score, labels)
 
+    def train_link_prediction_both(self, ent_embed, triplets, neg_tail, neg_head, labels, all_embeds_g):
+        """loss_tail + loss_head of one target graph (models/DynamicRGCN.py:189-192).  On the fused path the
+        two directions share the score GEMM against all entities: their queries are stacked into one (2P, D)
+        operand (both halves have P rows, so the sum of the two means is twice the mean over the stack)."""
+        name = self.args.score_function
+        P = triplets.shape[0]
+        if self.fused_loss and name in ("distmult", "complex") and all_embeds_g.shape[0] % 4 == 0 and P > 0:
+            from . import functional as TF
+            t32 = triplets.to(torch.int32)
+            r = TF.gather_rows(self.rel_embeds, t32[:, 1].contiguous())
+            known = TF.gather_rows(ent_embed, torch.cat([t32[:, 0], t32[:, 2]]).contiguous())
+            q = torch.cat([scores.bilinear_query(name, known[:P], r, "tail"), scores.bilinear_query(name, known[P:], r, "head")], dim=0)
+            cand = torch.cat([neg_tail, neg_head], dim=0).to(torch.int32).contiguous()
+            return 2.0 * TF.candidate_cross_entropy(q.contiguous(), all_embeds_g.contiguous(), cand)
+        return (self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
+                + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False))
+
     def link_classification_loss(self, ent_embed, rel_embeds, triplets, labels):
         score = self.calc_score(ent_embed[triplets[:, 0]], rel_embeds[triplets[:, 1]], ent_embed[triplets[:, 2]])
         return F.binary_cross_entropy_with_logits(score, labels)
