@@ -204,7 +204,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TEMP_BENCH_FORCE_DIST") == "1":       # FORCE_DIST: exercise the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -271,7 +271,7 @@ def main():
             for p in params:
                 p.grad = None
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # RCCL's watchdog thread polls events meanwhile
                 run().sum().backward()
             torch.cuda.synchronize()
         except Exception as e:                      # capture is an optimisation only
@@ -365,7 +365,14 @@ def main():
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
                                else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager")),
                    roofline=roof, cpu_baseline=cpu)
-        print(json.dumps(out))
+        # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
+        # that the JSON line is the LAST line of stdout
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
