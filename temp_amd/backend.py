@@ -319,6 +319,16 @@ class HipBackend:
         _lib.check(rc, "temp_scatter_add_rows")
         return table
 
+    def segment_sum_rows(self, src, seg_ptr, order, n_seg):
+        """out[s] = sum of src[order[seg_ptr[s]:seg_ptr[s+1]]] (deterministic adjoint of a static gather)."""
+        src, seg_ptr, order = _f32(src, "src"), _i32(seg_ptr, "seg_ptr"), _i32(order, "order")
+        if src.shape[0] == 0 or order.shape[0] == 0:
+            return torch.zeros(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
+        out = torch.empty(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
+        rc = self.lib.temp_segment_sum_rows(n_seg, src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(out), _stream())
+        _lib.check(rc, "temp_segment_sum_rows")
+        return out
+
     def copy_probe(self, src, dst):
         rc = self.lib.temp_copy_probe(_ptr(src), _ptr(dst), src.numel() * src.element_size(), _stream())
         _lib.check(rc, "temp_copy_probe")

@@ -88,20 +88,20 @@ class BiDynamicRGCN(DynamicRGCN):
         enc, dev = self.ent_encoder, self._device()
         plan_f, plan_b = wb.plan
         tf, tb = wb.target, wb.target_b
-        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
+        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all, wb.ids_inv)
         y1 = enc.layer_1.conv(wb.g_all, h0)
         y2 = enc.layer_2.conv(wb.g_all, y1)                   # ReLU fused (models/BiRRGCN.py:202-203)
         l2 = enc.layer_2
         lam, dec = l2.inv_temperature, l2.decay_spec()
         if wb.program is not None:
             prog = wb.program
-            H_all = gru_chain(TF.gather_rows(y2, wb.chain_rows), prog, [l2.forward_rnn, l2.backward_rnn], lam, isinstance(l2.forward_rnn, GRUCell))
+            H_all = gru_chain(TF.gather_rows(y2, wb.chain_rows, wb.chain_inv), prog, [l2.forward_rnn, l2.backward_rnn], lam, isinstance(l2.forward_rnn, GRUCell))
             rows = lambda i: H_all[prog.inst[i].h0:prog.inst[i].h0 + prog.inst[i].n] if i >= 0 else None
             out = rows(wb.out_inst[0]) + rows(wb.out_inst[1])
             Hf, Hb = rows(wb.hist_inst[0]), rows(wb.hist_inst[1])
             return out, ((Hf, Hf), (Hb, Hb))
         if wb.visit_rows is not None:                         # distinct-snapshot rows -> visit rows
-            y2 = TF.gather_rows(y2, wb.visit_rows)
+            y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))
 
         def chain(plan, rnn):
             H = None
@@ -143,7 +143,9 @@ class BiDynamicRGCN(DynamicRGCN):
         f_rows = base[:nf]
         b_rows = base[nf:nf + nb]
         t_rows = base[tf.row0:tf.row0 + nt]
-        wb.chain_rows = torch.from_numpy(np.concatenate([f_rows, t_rows, b_rows, t_rows]).astype(np.int32)).to(self._device())
+        chain = np.concatenate([f_rows, t_rows, b_rows, t_rows])
+        wb.chain_rows = torch.from_numpy(chain.astype(np.int32)).to(self._device())
+        wb.chain_inv = TF.gather_inverse(chain, int(wb.g_all.n), self._device())
         inst = []
         last = -1
         for st in plan_f.steps:

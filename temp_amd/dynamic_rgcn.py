@@ -135,11 +135,11 @@ class DynamicRGCN(TKG_Module):
 
     def _run_batched(self, wb):
         enc, dev = self.ent_encoder, self._device()
-        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
+        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all, wb.ids_inv)
         y1 = enc.layer_1.conv(wb.g_all, h0)
         y2 = enc.layer_2.conv(wb.g_all, y1)
         if wb.visit_rows is not None:                 # distinct-snapshot rows -> visit rows
-            y2 = TF.gather_rows(y2, wb.visit_rows)
+            y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))
         l2 = enc.layer_2
         if wb.program is not None:
             H_all = gru_chain(y2, wb.program, [l2.rnn], l2.inv_temperature, isinstance(l2.rnn, GRUCell))
@@ -184,9 +184,11 @@ class DynamicRGCN(TKG_Module):
             if self.dedup_snapshots:
                 wb.g_all, vr, wb.total_rows = concat_steps_dedup(wb.steps)
                 wb.visit_rows = torch.from_numpy(vr).to(dev) if vr is not None else None
+                wb.visit_inv = TF.gather_inverse(vr, int(wb.g_all.n), dev) if vr is not None else None
             else:
                 wb.g_all, wb.total_rows = concat_steps(wb.steps)
             wb.ids_all = torch.from_numpy(wb.g_all.gids.astype(np.int32)).to(dev)
+            wb.ids_inv = TF.gather_inverse(wb.g_all.gids, self.num_ents, dev)        # static ids: deterministic embedding gradient
             wb.g_all.device_graph(dev, 2 * self.num_rels)
             if self._can_chain():
                 self._build_program(wb)

@@ -99,22 +99,39 @@ def gru_step(x, prev, dt, w_ih, w_hh, b_ih, b_hh, lam, decay=None, prev_idx=None
 
 class _GatherRowsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, idx):
+    def forward(ctx, table, idx, inverse):
         ctx.save_for_backward(idx)
         ctx.rows = table.shape[0]
+        ctx.inverse = inverse
         return get_backend().gather_rows(table, idx)
 
     @staticmethod
     def backward(ctx, d_out):
         (idx,) = ctx.saved_tensors
+        be = get_backend()
+        if ctx.inverse is not None and d_out.shape[1] % 4 == 0 and d_out.shape[1] <= 256:
+            seg_ptr, order = ctx.inverse
+            return be.segment_sum_rows(d_out.contiguous(), seg_ptr, order, ctx.rows), None, None
         d_table = torch.zeros(ctx.rows, d_out.shape[1], dtype=d_out.dtype, device=d_out.device)
-        get_backend().scatter_add_rows(d_out.contiguous(), idx, d_table)
-        return d_table, None
+        be.scatter_add_rows(d_out.contiguous(), idx, d_table)
+        return d_table, None, None
 
 
-def gather_rows(table, idx):
-    """out[i] = table[idx[i]] (idx int32, -1 => zero row); backward scatter-adds."""
-    return _GatherRowsFn.apply(table, idx)
+def gather_rows(table, idx, inverse=None):
+    """out[i] = table[idx[i]] (idx int32, -1 => zero row).  Backward: atomic scatter-add, or -- when the caller
+    supplies `inverse` = gather_inverse(idx, rows) for a static index list -- a deterministic segment sum."""
+    return _GatherRowsFn.apply(table, idx, inverse)
+
+
+def gather_inverse(idx_np, n_rows, device):
+    """(seg_ptr int32 [n_rows+1], order int32) grouping the positions of a gather index list by table row."""
+    import numpy as np
+    idx_np = np.asarray(idx_np, dtype=np.int64)
+    pos = np.nonzero(idx_np >= 0)[0]
+    order = pos[np.argsort(idx_np[pos], kind="stable")]
+    counts = np.bincount(idx_np[pos], minlength=n_rows)
+    seg_ptr = np.concatenate([[0], np.cumsum(counts)])
+    return (torch.from_numpy(seg_ptr.astype(np.int32)).to(device), torch.from_numpy(order.astype(np.int32)).to(device))
 
 
 class _CandidateCEFn(torch.autograd.Function):

@@ -93,6 +93,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         wb.g_all.device_graph(dev, 2 * self.num_rels)
         as_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
         wb.ids_all = as_dev(wb.g_all.gids, np.int32)
+        wb.ids_inv = TF.gather_inverse(wb.g_all.gids, N, dev)
         wb.time_rows = as_dev(np.repeat(np.array(hist_ts + wb.target_times, dtype=np.int64), [g.n for g in all_graphs]), np.int32)
         wb.idx_tgt = as_dev(np.concatenate(idx_tgt, axis=0), np.int32)
         wb.idx_all = as_dev(np.concatenate(idx_all, axis=0), np.int32)
@@ -113,7 +114,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
         R = wb.n_hist_rows
-        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all)
+        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all, wb.ids_inv)
         y1 = l1.conv(wb.g_all, h0)
         y2 = l2.conv(wb.g_all, y1)
         s = y2 + TF.gather_rows(l2.time_embed, wb.time_rows)

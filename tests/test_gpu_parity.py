@@ -310,3 +310,20 @@ def test_self_attention_dense_api_gpu():
 def test_self_attention_evaluate_gpu(name):
     from tests.window_cases import check_sa_evaluate
     check_sa_evaluate(name, DEV)
+
+
+@pytest.mark.parametrize("rows,n,d", [(500, 100000, 200), (7128, 1800, 200), (64, 999, 32), (10, 0, 16), (3, 5000, 256)])
+def test_segment_sum_matches_scatter_and_is_deterministic(rows, n, d, hip_backend):
+    """temp_segment_sum_rows (deterministic adjoint of a static gather) against the atomic scatter-add."""
+    from temp_amd import functional as TF
+    rng = np.random.default_rng(rows + n)
+    idx = rng.integers(-1, rows, n).astype(np.int32)                 # -1 rows contribute nothing
+    src = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+    seg_ptr, order = TF.gather_inverse(idx, rows, DEV)
+    a = hip_backend.segment_sum_rows(src, seg_ptr, order, rows)
+    b = hip_backend.segment_sum_rows(src, seg_ptr, order, rows)
+    assert torch.equal(a, b)
+    want = torch.zeros(rows, d, dtype=torch.float64)
+    keep = idx >= 0
+    want.index_add_(0, torch.from_numpy(idx[keep].astype(np.int64)), src.cpu().double()[torch.from_numpy(keep)])
+    assert_close(a, want.float(), 1e-5, 1e-5 * max(1.0, (n / max(rows, 1)) ** 0.5), "segment sum")
