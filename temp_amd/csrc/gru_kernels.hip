@@ -555,7 +555,7 @@ struct GruGatesCell {
 };
 struct GruGatesBatch { GruGatesCell c[GRU_MAXP]; };
 
-template <int VARIANT>
+template <int VARIANT, int LPR>
 __global__ void __launch_bounds__(256) k_gru_bwd_gates(GruGatesBatch batch, int D, size_t plane, float lambda,
                                                        const float* __restrict__ decay_wb) {
   const GruGatesCell& cell = batch.c[blockIdx.y];
@@ -569,33 +569,47 @@ __global__ void __launch_bounds__(256) k_gru_bwd_gates(GruGatesBatch batch, int 
   float* __restrict__ dgh = cell.dgh;
   float* __restrict__ decv = cell.decv;
   float* __restrict__ dhz = cell.dhz;
-  const size_t nd = (size_t)n * D;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (size_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / D), col = (int)(i - (size_t)row * D);
-    const float rg = saved[i], zg = saved[plane + i], ng = saved[2 * plane + i], hn = saved[3 * plane + i], hd = saved[4 * plane + i];
-    float g = dh_up ? dh_up[i] : 0.f;
-    if (next_idx) {
-      const int nx = next_idx[row];
-      if (nx >= 0) g += d_prev_next[(size_t)nx * D + col];
+  // one float4 per thread: LPR (power of two >= D/4, at most 64) lanes per row, 256 / LPR rows per block pass;
+  // no per-element division (a runtime divisor costs more than the arithmetic of this kernel)
+  const int D4 = D >> 2;
+  const int lr = threadIdx.x & (LPR - 1), rsub = threadIdx.x / LPR;
+  constexpr int RPB = 256 / LPR;
+  for (int row = blockIdx.x * RPB + rsub; row < n; row += gridDim.x * RPB) {
+    int nx = -1;
+    if (next_idx) nx = next_idx[row];
+    if (lr == 0) decv[row] = decay_factor(dt[row], lambda, decay_wb);
+    for (int c4 = lr; c4 < D4; c4 += LPR) {
+      const size_t i = (size_t)row * D + 4 * c4;
+      const float4 rg = ld4(saved + i), zg = ld4(saved + plane + i), ng = ld4(saved + 2 * plane + i), hn = ld4(saved + 3 * plane + i),
+                   hd = ld4(saved + 4 * plane + i);
+      float4 g = dh_up ? ld4(dh_up + i) : zero4();
+      if (nx >= 0) g = add4(g, ld4(d_prev_next + (size_t)nx * D + 4 * c4));
+      float4 dr_pre, dz_pre, dn_pre, dhn, gz;
+#define TEMP_GATE(c)                                          \
+      {                                                       \
+        const float dn = g.c * (1.f - zg.c);                  \
+        const float dz = g.c * (hd.c - ng.c);                 \
+        dn_pre.c = dn * (1.f - ng.c * ng.c);                  \
+        dr_pre.c = dn_pre.c * hn.c * rg.c * (1.f - rg.c);     \
+        dz_pre.c = dz * zg.c * (1.f - zg.c);                  \
+        dhn.c = dn_pre.c * rg.c;                              \
+        gz.c = g.c * zg.c;                                    \
+      }
+      TEMP_GATE(x) TEMP_GATE(y) TEMP_GATE(z) TEMP_GATE(w)
+#undef TEMP_GATE
+      const size_t b3 = (size_t)row * 3 * D + 4 * c4;
+      if (VARIANT == TEMP_GRU_TORCH) {
+        st4(dgi + b3, dr_pre);
+        st4(dgi + b3 + D, dz_pre);
+        st4(dgi + b3 + 2 * D, dn_pre);
+      } else {
+        st4(dgi + i, dn_pre);
+      }
+      st4(dgh + b3, dr_pre);
+      st4(dgh + b3 + D, dz_pre);
+      st4(dgh + b3 + 2 * D, dhn);
+      st4(dhz + i, gz);
     }
-    const float dn = g * (1.f - zg);
-    const float dz = g * (hd - ng);
-    const float dn_pre = dn * (1.f - ng * ng);
-    const float dr_pre = dn_pre * hn * rg * (1.f - rg);
-    const float dz_pre = dz * zg * (1.f - zg);
-    const size_t b3 = (size_t)row * 3 * D + col;
-    if (VARIANT == TEMP_GRU_TORCH) {
-      dgi[b3] = dr_pre;
-      dgi[b3 + D] = dz_pre;
-      dgi[b3 + 2 * D] = dn_pre;
-    } else {
-      dgi[i] = dn_pre;
-    }
-    dgh[b3] = dr_pre;
-    dgh[b3 + D] = dz_pre;
-    dgh[b3 + 2 * D] = dn_pre * rg;
-    dhz[i] = g * zg;
-    if (col == 0) decv[row] = decay_factor(dt[row], lambda, decay_wb);
   }
 }
 
@@ -735,13 +749,16 @@ static int launch_gru_gates_batch(const GruGatesBatch& batch, int count, int d, 
   int max_n = 0;
   for (int i = 0; i < count; ++i) if (batch.c[i].n > max_n) max_n = batch.c[i].n;
   if (max_n <= 0) return TEMP_OK;
-  int gx = ceil_div((long long)max_n * d, 256);
-  if (gx > 2048) gx = 2048;
+  const int d4 = d / 4;
+  const int lpr = d4 <= 8 ? 8 : (d4 <= 16 ? 16 : (d4 <= 32 ? 32 : 64));
+  int gx = ceil_div(max_n, 256 / lpr);
+  if (gx > 4096) gx = 4096;
   dim3 grid(gx, count);
-  if (variant == TEMP_GRU_TORCH)
-    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TORCH>), grid, dim3(256), 0, st, batch, d, plane, lambda, decay_wb);
-  else
-    TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<TEMP_GRU_TYPE1>), grid, dim3(256), 0, st, batch, d, plane, lambda, decay_wb);
+#define TEMP_GATES(V, L) TEMP_LAUNCH(K_GRU_BWD_GATES, (k_gru_bwd_gates<V, L>), grid, dim3(256), 0, st, batch, d, plane, lambda, decay_wb)
+#define TEMP_GATES_V(V) do { if (lpr == 8) TEMP_GATES(V, 8); else if (lpr == 16) TEMP_GATES(V, 16); else if (lpr == 32) TEMP_GATES(V, 32); else TEMP_GATES(V, 64); } while (0)
+  if (variant == TEMP_GRU_TORCH) TEMP_GATES_V(TEMP_GRU_TORCH); else TEMP_GATES_V(TEMP_GRU_TYPE1);
+#undef TEMP_GATES_V
+#undef TEMP_GATES
   return launch_status();
 }
 
