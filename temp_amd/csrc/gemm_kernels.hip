@@ -8,6 +8,7 @@
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of lane l is
 // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
 #include "common.hpp"
+#include <type_traits>
 #include "gemm_wres.hpp"
 
 namespace temp {
@@ -64,11 +65,15 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 // and are summed in slice order by k_reduce_slices (deterministic).
 // ---------------------------------------------------------------------------------------------
 #define TN_MC 16
-template <int NT, int WPB>
+// SPLIT = 2: the block's WPB waves are KT = WPB/2 row tiles x 2 column halves (wave w and w + KT share a row tile and,
+// by the hardware's cyclic wave -> SIMD placement, a SIMD): for NT = 7 a SIMD runs a 4-tile and a 3-tile wave, i.e.
+// 7 tiles on every SIMD, where 7 full-width waves load the four SIMDs 2 : 2 : 2 : 1.
+template <int NT, int WPB, int SPLIT = 1>
 __global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb, int rows_per_slice, int nb_base,
                                                       float* __restrict__ part, float* __restrict__ bias_part) {
-  constexpr int T = WPB * 64, BK = WPB * 32, BN = NT * 32;
+  constexpr int KT = WPB / SPLIT, NT_LO = (NT + SPLIT - 1) / SPLIT;
+  constexpr int T = WPB * 64, BK = KT * 32, BN = NT * 32;
   constexpr int NVA = (TN_MC * BK / 4 + T - 1) / T;          // = 2
   constexpr int NVB = (TN_MC * BN / 4 + T - 1) / T;
   __shared__ __attribute__((aligned(16))) float As[2][TN_MC * BK];
@@ -76,14 +81,16 @@ __global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
   const int ka_blk = blockIdx.x * BK;
-  const int ka0 = ka_blk + wave * 32;
+  const int kt = wave % KT, part_id = wave / KT;
+  const int t_beg = part_id * NT_LO;                         // first column tile of this wave
+  const int ka0 = ka_blk + kt * 32;
   const int nb0 = nb_base + blockIdx.y * BN;
   const int slice = blockIdx.z;
   const int mbeg = slice * rows_per_slice, mend = min(M, mbeg + rows_per_slice);
   const bool wave_on = ka0 < Ka;
-  f32x16 acc[NT];
+  f32x16 acc[NT_LO];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT_LO; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -141,51 +148,62 @@ __global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, con
     store(0, mbeg);
   }
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    fetch(mbeg + (c + 1) * TN_MC);           // unconditional (past the end: clamped re-reads) so no value merge forces a wait here
-    __builtin_amdgcn_sched_barrier(0);
-    if (wave_on) {
-      const float* as = As[c & 1] + wave * 32 + li + hh * BK;
-      const float* bs = Bs[c & 1] + li + hh * BN;
-      // LDS operands of row pair mp+2 are read while the MFMAs of row pair mp issue
-      float a_cur = as[0], b_cur[NT];
+  // the whole main loop + epilogue, instantiated per tile count of the wave (NTW is a compile-time constant, so the
+  // MFMA body has no guards; both instantiations execute the same sequence of barriers)
+  auto run = [&](auto ntw_c) {
+    constexpr int NTW = decltype(ntw_c)::value;
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + 1 < nchunks;
+      fetch(mbeg + (c + 1) * TN_MC);           // unconditional (past the end: clamped re-reads) so no value merge forces a wait here
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave_on) {
+        const float* as = As[c & 1] + kt * 32 + li + hh * BK;
+        const float* bs = Bs[c & 1] + t_beg * 32 + li + hh * BN;
+        // LDS operands of row pair mp+2 are read while the MFMAs of row pair mp issue
+        float a_cur = as[0], b_cur[NTW];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b_cur[t] = bs[t * 32];
+        for (int t = 0; t < NTW; ++t) b_cur[t] = bs[t * 32];
 #pragma unroll
-      for (int mp = 0; mp < TN_MC; mp += 2) {
-        float a_nxt = 0.f, b_nxt[NT];
-        if (mp + 2 < TN_MC) {
-          a_nxt = as[(mp + 2) * BK];
+        for (int mp = 0; mp < TN_MC; mp += 2) {
+          float a_nxt = 0.f, b_nxt[NTW];
+          if (mp + 2 < TN_MC) {
+            a_nxt = as[(mp + 2) * BK];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) b_nxt[t] = bs[(mp + 2) * BN + t * 32];
-        }
+            for (int t = 0; t < NTW; ++t) b_nxt[t] = bs[(mp + 2) * BN + t * 32];
+          }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[t], a_cur, acc[t], 0, 0, 0);
-        if (mp + 2 < TN_MC) {
-          a_cur = a_nxt;
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[t], a_cur, acc[t], 0, 0, 0);
+          if (mp + 2 < TN_MC) {
+            a_cur = a_nxt;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) b_cur[t] = b_nxt[t];
+            for (int t = 0; t < NTW; ++t) b_cur[t] = b_nxt[t];
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) store((c + 1) & 1, mbeg + (c + 1) * TN_MC);
+      __syncthreads();
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) store((c + 1) & 1, mbeg + (c + 1) * TN_MC);
-    __syncthreads();
-  }
-  // swapped operands: lane (li, hh) holds output row ka0 + li, register quad q of tile t holds the
-  // four columns nb0 + t*32 + 8q + 4hh .. +3
-  const int row = ka0 + li;
-  if (!wave_on || row >= Ka) return;
-  float* p = part + (size_t)slice * Ka * Nb + (size_t)row * Nb;
+    // swapped operands: lane (li, hh) holds output row ka0 + li, register quad q of tile t holds the
+    // four columns nb0 + (t_beg + t)*32 + 8q + 4hh .. +3
+    const int row = ka0 + li;
+    if (!wave_on || row >= Ka) return;
+    float* p = part + (size_t)slice * Ka * Nb + (size_t)row * Nb;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NTW; ++t) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = nb0 + t * 32 + 8 * q + 4 * hh;
-      if (col < Nb) st4(p + col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]));
-      else if (bias_part && col == Nb) bias_part[(size_t)slice * Ka + row] = acc[t][4 * q];
+      for (int q = 0; q < 4; ++q) {
+        const int col = nb0 + (t_beg + t) * 32 + 8 * q + 4 * hh;
+        if (col < Nb) st4(p + col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]));
+        else if (bias_part && col == Nb) bias_part[(size_t)slice * Ka + row] = acc[t][4 * q];
+      }
     }
+  };
+  if constexpr (SPLIT == 1) {
+    run(std::integral_constant<int, NT>());
+  } else {
+    if (part_id == 0) run(std::integral_constant<int, NT_LO>());
+    else run(std::integral_constant<int, NT - NT_LO>());
   }
 }
 
@@ -219,7 +237,7 @@ void reduce_slices(int n_slices, size_t elems, int width, const float* part, flo
   TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, n_slices, elems, width, part, out, ldo);
 }
 
-struct TnCfg { int wpb, bk, kab, nt, nbb, slices; };
+struct TnCfg { int wpb, bk, kab, nt, nbb, slices, split; };
 static TnCfg tn_cfg(int M, int Ka, int Nb) {
   TnCfg c;
   const int ktiles = ceil_div(Ka, 32);
@@ -227,7 +245,11 @@ static TnCfg tn_cfg(int M, int Ka, int Nb) {
   // of Ka; 3D = 600 -> 19 tiles = 7 + 7 + 5.  (4-wave blocks, two per CU, measured 20 % slower: B is
   // staged twice as often.)
   c.wpb = (ceil_div(ktiles, 7) * 7 - ktiles <= ceil_div(ktiles, 8) * 8 - ktiles) ? 7 : 8;
-  c.bk = c.wpb * 32;
+  c.split = 1;
+  const int ntiles_n = ceil_div(Nb, 32);
+  static const int split_off = [] { const char* e = getenv("TEMP_TN_SPLIT"); return (e && e[0] == '0') ? 1 : 0; }();
+  if (ntiles_n >= 5 && ntiles_n <= 7 && !split_off) { c.wpb = 8; c.split = 2; }      // 4 row tiles x (4 + 3) column tiles per block
+  c.bk = (c.wpb / c.split) * 32;
   c.kab = ceil_div(Ka, c.bk);
   const int ntiles = ceil_div(Nb, 32);
   c.nt = ntiles >= 5 ? 7 : (ntiles >= 3 ? 4 : (ntiles == 2 ? 2 : 1));
@@ -252,6 +274,10 @@ template <int NT>
 static void launch_tn(const TnCfg& c, int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, int rps, float* part,
                       float* bpart, hipStream_t st) {
   dim3 grid(c.kab, c.nbb, c.slices);
+  if (c.split == 2) {
+    if constexpr (NT == 7) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<7, 8, 2>), grid, dim3(8 * 64), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part, bpart);
+    return;
+  }
   if (c.wpb == 7) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<NT, 7>), grid, dim3(7 * 64), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part, bpart);
   else TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn<NT, 8>), grid, dim3(8 * 64), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, 0, part, bpart);
 }
