@@ -297,9 +297,15 @@ int launch_wres_one(int kid, const PanelBatch<Epi>& batch, int count, const Wres
     attr_set = true;
   }
   const int roles = g.n_slices * (g.split ? count : 1);
+  const size_t lds = (size_t)NTS * 32 * g.ldk * 4;
+  // narrow slices leave LDS for more than two blocks per CU: up to 3 (12 waves) hide the A-stream latency better
+  if (local_blocks == WRES_LOCAL_BLOCKS) {
+    int per_cu = (int)((160 * 1024) / (lds + 1024));
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu > 2) local_blocks = 32 * per_cu;
+  }
   int bps = local_blocks / roles;
   if (bps < 1) bps = 1;
-  const size_t lds = (size_t)NTS * 32 * g.ldk * 4;
   TEMP_LAUNCH(kid, (k_gemm_wres<NTS, Epi>), dim3(roles * bps * 8), dim3(256), lds, st, batch, count, g, bps);
   return launch_status();
 }
