@@ -82,9 +82,13 @@ def algorithmic_costs(wb, D, bi, S=2):
     c["k_rgcn_agg<fwd>"] = dict(bytes=2 * (E * (row + 8) + n * row), flops=2 * E * 2 * D * S)
     c["k_rgcn_agg<dx>"] = dict(bytes=2 * (E * (row + 12) + n * row), flops=2 * E * 2 * D * S)
     c["k_rgcn_dw"] = dict(bytes=2 * (E * (2 * row + 12)), flops=2 * E * 2 * D * S)
-    c["k_gemm_panel<loop_fwd>"] = dict(bytes=2 * n * 3 * row, flops=2 * 2 * n * D * D)
-    c["k_gemm_panel<loop_dx>"] = dict(bytes=2 * n * 3 * row, flops=2 * 2 * n * D * D)
-    c["k_gemm_tn"] = dict(bytes=2 * n * 2 * row + n_gru * (2 * row + 6 * row), flops=2 * 2 * n * D * D + 2 * 2 * n_gru * 3 * D * D)
+    # self-loop GEMMs: layer 2 over the n node rows; layer 1 is fed by the embedding gather, so its self-loop product and
+    # both of its gradients run over the N_ents table rows (temp_rgcn_table_fwd/bwd)
+    nt = getattr(wb, "n_table_rows", 0)
+    c["k_gemm_panel<loop_fwd>"] = dict(bytes=n * 3 * row, flops=2 * n * D * D)
+    c["k_gemm_panel<loop_dx>"] = dict(bytes=n * 3 * row + nt * 3 * row, flops=2 * (n + nt) * D * D)
+    c["k_gemm_panel<isolated>"] = dict(bytes=nt * 3 * row, flops=2 * nt * D * D)
+    c["k_gemm_tn"] = dict(bytes=(n + nt) * 2 * row + n_gru * (2 * row + 6 * row), flops=2 * (n + nt) * D * D + 2 * 2 * n_gru * 3 * D * D)
     c["k_relu_bwd"] = dict(bytes=n * 3 * row, flops=0)
     c["k_gru_fwd"] = dict(bytes=n_gru * (row + 3 * row + row + 5 * row + 8), flops=6 * n_gru * D * D)   # hoisted: h-phase only
     c["k_gemm_panel<gru_gi>"] = dict(bytes=n_gru * (row + 3 * row), flops=2 * n_gru * 3 * D * D)
@@ -236,6 +240,7 @@ def main():
     else:
         model.sample_rng = np.random.default_rng(2 + rank)
         wb = model.prepare(targets, w["L"], train=True)
+        wb.n_table_rows = w["num_ents"]
         if a.with_loss:
             from temp_amd.sampling import CorruptTriples
             model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5 + rank)

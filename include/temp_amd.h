@@ -127,6 +127,26 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
                   float* d_h, float* d_weight, float* d_loop_w, float* d_bias /*nullable*/,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Same layer when its input is a ROW GATHER of a table, h = table[ids]  (layer 1 of every TeMP encoder:
+ * g.ndata['h'] = ent_embeds[g.ndata['id']], models/DynamicRGCN.py:93).  h is never materialised:
+ *   fwd: the aggregation gathers through ids; the self-loop term is (table . W_loop)[ids] -- one N_table-row GEMM
+ *        instead of one over every node row of the batch;
+ *   bwd: what is linear in the gathered rows is summed per table row first (inv_ptr / inv_order = the ids grouped
+ *        by table row, see temp_segment_sum_rows):  d_table = segsum(d_h_agg) + segsum(dz) . W_loop^T  [n_table, d_in]
+ *        (fully written, deterministic), d_loop_w = table^T . segsum(dz).
+ * Results equal temp_rgcn_fwd/bwd on h = table[ids] followed by the gather's adjoint, up to fp32 summation order.
+ * ---------------------------------------------------------------------------------------------- */
+size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out);
+int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* ids, int n_table, int d_in, int d_out, int num_bases,
+                        int n_rel_rows, const float* weight, const float* loop_w, const float* bias, int act, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+size_t temp_rgcn_table_bwd_workspace(const TempGraph* g, int n_table, int d_in, int d_out, int num_bases);
+int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* ids, const int32_t* inv_ptr, const int32_t* inv_order, int n_table,
+                        const float* out, const float* d_out_grad, int d_in, int d_out, int num_bases, int n_rel_rows, const float* weight,
+                        const float* loop_w, int has_bias, int act, float* d_table, float* d_weight, float* d_loop_w, float* d_bias,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Isolated-entity variant (RGCNLayer.forward_isolated, models/RGCN.py:78-89):
  *   out = act( e + e . loop_w [+ bias] )          e: [n, d]                                    */
 int temp_rgcn_isolated_fwd(int n, int d, const float* e, const float* loop_w, const float* bias /*nullable*/,

@@ -92,6 +92,36 @@ class HipBackend:
         _lib.check(rc, "temp_rgcn_bwd")
         return d_h, d_w, d_loop, d_bias
 
+    def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act):
+        """Layer on h = table[ids] without materialising h (include/temp_amd.h: temp_rgcn_table_fwd)."""
+        table, weight, loop_w, bias = _f32(table, "table"), _f32(weight, "weight"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
+        ids = _i32(ids, "ids")
+        d_in, d_out = loop_w.shape
+        out = torch.empty(dg.n_nodes, d_out, dtype=torch.float32, device=table.device)
+        ws = self._ws(self.lib.temp_rgcn_table_fwd_workspace(dg.ref(), table.shape[0], d_out), table.device)
+        rc = self.lib.temp_rgcn_table_fwd(dg.ref(), _ptr(table), _ptr(ids), table.shape[0], d_in, d_out, num_bases, weight.shape[0],
+                                          _ptr(weight), _ptr(loop_w), _ptr(bias), act, _ptr(out), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_rgcn_table_fwd")
+        return out
+
+    def rgcn_table_bwd(self, dg, table, ids, inverse, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
+        """-> (d_table [n_table, d_in] fully written, d_weight, d_loop_w, d_bias)."""
+        table, out, g = _f32(table, "table"), _f32(out, "out"), _f32(d_out_grad, "d_out")
+        weight, loop_w = _f32(weight, "weight"), _f32(loop_w, "loop_weight")
+        ids, inv_ptr, inv_order = _i32(ids, "ids"), _i32(inverse[0], "inv_ptr"), _i32(inverse[1], "inv_order")
+        d_in, d_out = loop_w.shape
+        dev = table.device
+        d_table = torch.empty_like(table)
+        d_w = torch.empty_like(weight)
+        d_loop = torch.empty_like(loop_w)
+        d_bias = torch.empty(d_out, dtype=torch.float32, device=dev) if has_bias else None
+        ws = self._ws(self.lib.temp_rgcn_table_bwd_workspace(dg.ref(), table.shape[0], d_in, d_out, num_bases), dev)
+        rc = self.lib.temp_rgcn_table_bwd(dg.ref(), _ptr(table), _ptr(ids), _ptr(inv_ptr), _ptr(inv_order), table.shape[0], _ptr(out), _ptr(g),
+                                          d_in, d_out, num_bases, weight.shape[0], _ptr(weight), _ptr(loop_w), int(has_bias), act,
+                                          _ptr(d_table), _ptr(d_w), _ptr(d_loop), _ptr(d_bias), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_rgcn_table_bwd")
+        return d_table, d_w, d_loop, d_bias
+
     def rgcn_isolated_fwd(self, e, loop_w, bias, act):
         e, loop_w, bias = _f32(e, "e"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
         out = torch.empty_like(e)

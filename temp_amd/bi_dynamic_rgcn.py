@@ -88,8 +88,7 @@ class BiDynamicRGCN(DynamicRGCN):
         enc, dev = self.ent_encoder, self._device()
         plan_f, plan_b = wb.plan
         tf, tb = wb.target, wb.target_b
-        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all, wb.ids_inv)
-        y1 = enc.layer_1.conv(wb.g_all, h0)
+        y1 = enc.layer_1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
         y2 = enc.layer_2.conv(wb.g_all, y1)                   # ReLU fused (models/BiRRGCN.py:202-203)
         l2 = enc.layer_2
         lam, dec = l2.inv_temperature, l2.decay_spec()

@@ -94,6 +94,10 @@ void reduce_slices(int n_slices, size_t elems, int width, const float* part, flo
 size_t colsum_workspace(int rows, int cols);
 int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, size_t ws_bytes, hipStream_t st);
 
+// out[s] = sum_{j in [seg_ptr[s], seg_ptr[s+1])} src[order[j]]  (rows with row_mask[row] <= 0 skipped; row_mask nullable)
+int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
+                     hipStream_t st);
+
 // dz = (y > 0) ? dy : 0
 int relu_bwd(size_t n, const float* y, const float* dy, float* dz, hipStream_t st);
 

@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) k_scatter_add_rows(int n, int d, const fl
 template <int LPR>
 __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
                                                           const int32_t* __restrict__ order, const float4* __restrict__ src,
-                                                          float4* __restrict__ out) {
+                                                          const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63, grp = lane / LPR, lr = lane - grp * LPR;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -390,12 +390,21 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, con
     int j = beg + grp;
     for (; j + 3 * G < end; j += 4 * G) {
       const int r0 = order[j], r1 = order[j + G], r2 = order[j + 2 * G], r3 = order[j + 3 * G];
+      const bool m0 = !row_mask || row_mask[r0] > 0, m1 = !row_mask || row_mask[r1] > 0, m2 = !row_mask || row_mask[r2] > 0,
+                 m3 = !row_mask || row_mask[r3] > 0;          // masked rows were never written by their producer
       float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4();
-      if (col_ok) { v0 = src[(size_t)r0 * d4 + lr]; v1 = src[(size_t)r1 * d4 + lr]; v2 = src[(size_t)r2 * d4 + lr]; v3 = src[(size_t)r3 * d4 + lr]; }
+      if (col_ok) {
+        if (m0) v0 = src[(size_t)r0 * d4 + lr];
+        if (m1) v1 = src[(size_t)r1 * d4 + lr];
+        if (m2) v2 = src[(size_t)r2 * d4 + lr];
+        if (m3) v3 = src[(size_t)r3 * d4 + lr];
+      }
       acc = add4(add4(acc, v0), add4(v1, add4(v2, v3)));
     }
-    for (; j < end; j += G)
-      if (col_ok) acc = add4(acc, src[(size_t)order[j] * d4 + lr]);
+    for (; j < end; j += G) {
+      const int r = order[j];
+      if (col_ok && (!row_mask || row_mask[r] > 0)) acc = add4(acc, src[(size_t)r * d4 + lr]);
+    }
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) acc = add4(acc, shfl_xor4(acc, m));
     if (grp == 0 && col_ok) out[(size_t)s * d4 + lr] = acc;
@@ -610,18 +619,26 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
   return launch_status();
 }
 
-int temp_segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream) {
-  if (n_seg < 0 || d <= 0 || (n_seg > 0 && (!seg_ptr || !src || !out))) return TEMP_E_BADARG;
+}  // extern "C"
+namespace temp {
+int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
+                     hipStream_t st) {
   if (d % 4 || d > 256) return TEMP_E_UNSUPPORTED;
   if (n_seg == 0) return TEMP_OK;
   const int d4 = d / 4;
   int grid = ceil_div(n_seg, 4);
   if (grid > 2048) grid = 2048;
-  hipStream_t st = (hipStream_t)stream;
-#define TEMP_SEGSUM(L) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src, (float4*)out)
+#define TEMP_SEGSUM(L) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)out)
   if (d4 <= 8) TEMP_SEGSUM(8); else if (d4 <= 16) TEMP_SEGSUM(16); else if (d4 <= 32) TEMP_SEGSUM(32); else TEMP_SEGSUM(64);
 #undef TEMP_SEGSUM
   return launch_status();
+}
+}  // namespace temp
+extern "C" {
+
+int temp_segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream) {
+  if (n_seg < 0 || d <= 0 || (n_seg > 0 && (!seg_ptr || !src || !out))) return TEMP_E_BADARG;
+  return segment_sum_rows(n_seg, d, seg_ptr, order, src, nullptr, out, (hipStream_t)stream);
 }
 
 struct EpiPlainStore {

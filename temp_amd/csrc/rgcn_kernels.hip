@@ -204,8 +204,8 @@ __global__ void __launch_bounds__(256) k_fixup(int n_fix, const int32_t* __restr
 // d/dweight: view = by-rel (a = src node, b = dst node).  Per edge the lane takes its 4 features of
 // x[src] and of c*dz[dst] and accumulates the S x S outer products of its blocks in registers.
 template <int S>
-__global__ void __launch_bounds__(256) k_rgcn_dw(TempEdgeView v, const float* __restrict__ x, const float* __restrict__ dz,
-                                                 const float* __restrict__ nnorm, int D, int lpr,
+__global__ void __launch_bounds__(256) k_rgcn_dw(TempEdgeView v, const float* __restrict__ x, const int32_t* __restrict__ x_ids,
+                                                 const float* __restrict__ dz, const float* __restrict__ nnorm, int D, int lpr,
                                                  float* __restrict__ dW, float* __restrict__ partial) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int lr = lane & (lpr - 1), gi = lane / lpr, epw = 64 / lpr;
@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(256) k_rgcn_dw(TempEdgeView v, const float* __
       float s_l = 0.f;
       if (lane < cnt) {
         a_l = v.a[beg + lane];
+        if (x_ids) a_l = x_ids[a_l];                      // x is a table, the node's row is x[x_ids[node]]
         b_l = v.b[beg + lane];
         const float nn = nnorm[b_l];
         s_l = nn * nn;
@@ -280,7 +281,8 @@ __global__ void __launch_bounds__(256) k_rgcn_dw(TempEdgeView v, const float* __
   }
 }
 
-__global__ void __launch_bounds__(256) k_rgcn_dw_generic(TempEdgeView v, const float* __restrict__ x, const float* __restrict__ dz,
+__global__ void __launch_bounds__(256) k_rgcn_dw_generic(TempEdgeView v, const float* __restrict__ x, const int32_t* __restrict__ x_ids,
+                                                         const float* __restrict__ dz,
                                                          const float* __restrict__ nnorm, int d_in, int d_out, int si, int so,
                                                          float* __restrict__ dW, float* __restrict__ partial) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_generic(TempEdgeView v, const f
       const int b = q / (si * so), rem = q - b * si * so, i = rem / so, o = rem - i * so;
       float acc = 0.f;
       for (int e = beg; e < end; ++e) {
-        const int src = v.a[e], dst = v.b[e];
+        const int src = x_ids ? x_ids[v.a[e]] : v.a[e], dst = v.b[e];
         const float nn = nnorm[dst];
         acc = fmaf(x[(size_t)src * d_in + b * si + i], nn * nn * dz[(size_t)dst * d_out + b * so + o], acc);
       }
@@ -375,7 +377,7 @@ static int run_agg(int mode, const TempEdgeView& v, const float* feat, int ldf, 
   return launch_status();
 }
 
-static int run_dw(const TempEdgeView& v, const float* x, const float* dz, const float* nnorm, int d_in, int d_out, int num_bases,
+static int run_dw(const TempEdgeView& v, const float* x, const int32_t* x_ids, const float* dz, const float* nnorm, int d_in, int d_out, int num_bases,
                   int n_rel_rows, float* dW, float* partial, hipStream_t st) {
   const int si = d_in / num_bases, so = d_out / num_bases;
   const size_t wrow = (size_t)num_bases * si * so;
@@ -386,16 +388,55 @@ static int run_dw(const TempEdgeView& v, const float* x, const float* dz, const 
     const int lpr = pick_lpr(d_in);
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
-    if (S == 1) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<1>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
-    else if (S == 2) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<2>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
-    else TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<4>), dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, lpr, dW, partial);
+    if (S == 1) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<1>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, lpr, dW, partial);
+    else if (S == 2) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<2>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, lpr, dW, partial);
+    else TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<4>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, lpr, dW, partial);
   } else {
     int grid = (v.n_chunks + 3) / 4;
     if (grid > 4096) grid = 4096;
-    TEMP_LAUNCH(K_RGCN_DW, k_rgcn_dw_generic, dim3(grid), dim3(256), 0, st, v, x, dz, nnorm, d_in, d_out, si, so, dW, partial);
+    TEMP_LAUNCH(K_RGCN_DW, k_rgcn_dw_generic, dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, d_out, si, so, dW, partial);
   }
   launch_fixup(v, partial, (int)wrow, dW, st);
   return launch_status();
+}
+
+// out[row] = act( (in_deg[row] > 0 ? out[row] : 0) + bias + t_loop[ids[row]] ): the self-loop term of a layer whose input
+// is a row gather of a table, taken from the table's own product table . W_loop instead of a GEMM over every row.
+__global__ void __launch_bounds__(256) k_loop_gather_epi(int n, int d4, const int32_t* __restrict__ ids, const int32_t* __restrict__ in_deg,
+                                                         const float4* __restrict__ t_loop, const float4* __restrict__ bias, int act,
+                                                         float4* __restrict__ out) {
+  const size_t total = (size_t)n * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / (unsigned)d4), c = (int)(i - (size_t)row * d4);
+    float4 v = in_deg[row] > 0 ? out[i] : zero4();
+    v = add4(v, t_loop[(size_t)ids[row] * d4 + c]);
+    if (bias) v = add4(v, bias[c]);
+    if (act == TEMP_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    out[i] = v;
+  }
+}
+
+struct TableBwdWs {
+  float *dz, *d_h, *part_dx, *part_dw, *seg_dz;
+  void *tn, *cs;
+  size_t tn_bytes, cs_bytes, total;
+};
+static TableBwdWs carve_table_bwd(const TempGraph* g, int n_table, int d_in, int d_out, int num_bases, char* base) {
+  TableBwdWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+  const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
+  w.dz = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
+  w.d_h = (float*)take((size_t)g->n_nodes * d_in * sizeof(float));
+  w.part_dx = (float*)take((size_t)g->by_src.n_partial * d_in * sizeof(float));
+  w.part_dw = (float*)take((size_t)g->by_rel.n_partial * wrow * sizeof(float));
+  w.seg_dz = (float*)take((size_t)n_table * d_out * sizeof(float));
+  w.tn_bytes = gemm_tn_workspace(n_table, d_in, d_out);
+  w.tn = take(w.tn_bytes);
+  w.cs_bytes = colsum_workspace(g->n_nodes, d_out);
+  w.cs = take(w.cs_bytes);
+  w.total = off + 256;
+  return w;
 }
 
 }  // namespace temp
@@ -403,6 +444,91 @@ static int run_dw(const TempEdgeView& v, const float* x, const float* dz, const 
 using namespace temp;
 
 extern "C" {
+
+size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out) {
+  if (!g || n_table < 0) return 0;
+  return align_up((size_t)g->by_dst.n_partial * d_out * sizeof(float), 256) + align_up((size_t)n_table * d_out * sizeof(float), 256) + 256;
+}
+
+int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* ids, int n_table, int d_in, int d_out, int num_bases,
+                        int n_rel_rows, const float* weight, const float* loop_w, const float* bias, int act, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!g || !table || !weight || !loop_w || !out || n_table <= 0 || d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
+  if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
+  if (g->n_nodes < 0 || !view_ok(g->by_dst) || (g->n_nodes > 0 && (!g->nnorm || !g->in_deg || !ids))) return TEMP_E_BADARG;
+  if (act != TEMP_ACT_NONE && act != TEMP_ACT_RELU) return TEMP_E_BADARG;
+  if (!workspace || workspace_bytes < temp_rgcn_table_fwd_workspace(g, n_table, d_out)) return TEMP_E_WORKSPACE;
+  if (g->n_nodes == 0) return TEMP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  float* t_loop = (float*)((char*)workspace + align_up((size_t)g->by_dst.n_partial * d_out * sizeof(float), 256));
+  int rc = gemm_add_bias_act(K_GEMM_ISO, n_table, d_out, d_in, table, d_in, nullptr, loop_w, d_out, 0, nullptr, 0, nullptr, nullptr, TEMP_ACT_NONE,
+                             t_loop, d_out, st);
+  if (rc) return rc;
+  rc = run_agg(MODE_FWD, g->by_dst, table, d_in, ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
+  if (rc) return rc;
+  int grid = ceil_div((long long)g->n_nodes * (d_out / 4), 256);
+  if (grid > 4096) grid = 4096;
+  TEMP_LAUNCH(K_GEMM_LOOP_FWD, k_loop_gather_epi, dim3(grid), dim3(256), 0, st, g->n_nodes, d_out / 4, ids, g->in_deg, (const float4*)t_loop,
+              (const float4*)bias, act, (float4*)out);
+  return launch_status();
+}
+
+size_t temp_rgcn_table_bwd_workspace(const TempGraph* g, int n_table, int d_in, int d_out, int num_bases) {
+  if (!g || num_bases <= 0 || d_in <= 0 || d_out <= 0 || n_table < 0) return 0;
+  return carve_table_bwd(g, n_table, d_in, d_out, num_bases, nullptr).total;
+}
+
+int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* ids, const int32_t* inv_ptr, const int32_t* inv_order, int n_table,
+                        const float* out, const float* d_out_grad, int d_in, int d_out, int num_bases, int n_rel_rows, const float* weight,
+                        const float* loop_w, int has_bias, int act, float* d_table, float* d_weight, float* d_loop_w, float* d_bias,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !table || !d_out_grad || !weight || !loop_w || !d_table || !d_weight || !d_loop_w || !inv_ptr) return TEMP_E_BADARG;
+  if (n_table <= 0 || d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
+  if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4 || d_in > 256 || d_out > 256) return TEMP_E_UNSUPPORTED;
+  if (act == TEMP_ACT_RELU && !out) return TEMP_E_BADARG;
+  if (has_bias && !d_bias) return TEMP_E_BADARG;
+  if (!view_ok(g->by_src) || !view_ok(g->by_rel) || (g->n_nodes > 0 && (!g->nnorm || !g->out_deg || !ids || !inv_order))) return TEMP_E_BADARG;
+  if (g->by_rel.n_seg != n_rel_rows) return TEMP_E_BADARG;
+  if (!workspace || workspace_bytes < temp_rgcn_table_bwd_workspace(g, n_table, d_in, d_out, num_bases)) return TEMP_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
+  if (g->n_nodes == 0) {
+    if (hipMemsetAsync(d_table, 0, (size_t)n_table * d_in * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    if (hipMemsetAsync(d_weight, 0, (size_t)n_rel_rows * wrow * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    if (hipMemsetAsync(d_loop_w, 0, (size_t)d_in * d_out * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    if (has_bias && hipMemsetAsync(d_bias, 0, (size_t)d_out * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    return TEMP_OK;
+  }
+  TableBwdWs w = carve_table_bwd(g, n_table, d_in, d_out, num_bases, (char*)workspace);
+  const float* dz = d_out_grad;
+  int rc;
+  if (act == TEMP_ACT_RELU) {
+    rc = relu_bwd((size_t)g->n_nodes * d_out, out, d_out_grad, w.dz, st);
+    if (rc) return rc;
+    dz = w.dz;
+  }
+  // aggregation part of d_h per node row, then everything that is linear in the gathered rows is summed per table row FIRST:
+  //   d_table = segsum(out_deg > 0 ? d_h : 0) + segsum(dz) . loop_w^T        d_loop_w = table^T . segsum(dz)
+  rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, w.d_h, w.part_dx, st);
+  if (rc) return rc;
+  rc = segment_sum_rows(n_table, d_in, inv_ptr, inv_order, w.d_h, g->out_deg, d_table, st);
+  if (rc) return rc;
+  rc = segment_sum_rows(n_table, d_out, inv_ptr, inv_order, dz, nullptr, w.seg_dz, st);
+  if (rc) return rc;
+  rc = gemm_add_bias_act(K_GEMM_LOOP_DX, n_table, d_in, d_out, w.seg_dz, d_out, nullptr, loop_w, d_out, 1, d_table, d_in, nullptr, nullptr,
+                         TEMP_ACT_NONE, d_table, d_in, st);
+  if (rc) return rc;
+  rc = run_dw(g->by_rel, table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+  if (rc) return rc;
+  rc = gemm_tn(n_table, d_in, d_out, table, d_in, w.seg_dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
+  if (rc) return rc;
+  if (has_bias) {
+    rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
+    if (rc) return rc;
+  }
+  return TEMP_OK;
+}
 
 size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out) {
   if (!g) return 0;
@@ -491,7 +617,7 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dz, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
                          d_h, d_in, st);
   if (rc) return rc;
-  rc = run_dw(g->by_rel, h, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+  rc = run_dw(g->by_rel, h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
   if (rc) return rc;
   rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
   if (rc) return rc;

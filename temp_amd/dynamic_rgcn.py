@@ -135,8 +135,7 @@ class DynamicRGCN(TKG_Module):
 
     def _run_batched(self, wb):
         enc, dev = self.ent_encoder, self._device()
-        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all, wb.ids_inv)
-        y1 = enc.layer_1.conv(wb.g_all, h0)
+        y1 = enc.layer_1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
         y2 = enc.layer_2.conv(wb.g_all, y1)
         if wb.visit_rows is not None:                 # distinct-snapshot rows -> visit rows
             y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))

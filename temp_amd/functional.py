@@ -38,6 +38,28 @@ def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None):
     return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act])
 
 
+class _RGCNTableLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, weight, loop_w, bias, ids, inverse, dg, num_bases, act):
+        out = get_backend().rgcn_table_fwd(dg, table, ids, weight, loop_w, bias, num_bases, act)
+        ctx.save_for_backward(table, weight, loop_w, out, ids)
+        ctx.dg, ctx.num_bases, ctx.act, ctx.has_bias, ctx.inverse = dg, num_bases, act, bias is not None, inverse
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        table, weight, loop_w, out, ids = ctx.saved_tensors
+        d_t, d_w, d_loop, d_bias = get_backend().rgcn_table_bwd(ctx.dg, table, ids, ctx.inverse, out, d_out.contiguous(), weight, loop_w,
+                                                               ctx.has_bias, ctx.num_bases, ctx.act)
+        return d_t, d_w, d_loop, d_bias, None, None, None, None, None
+
+
+def rgcn_layer_table(table, ids, inverse, dg, weight, loop_w, bias, num_bases, act=None):
+    """rgcn_layer on h = table[ids] (ids int32, static; inverse = gather_inverse(ids, rows)) without materialising h:
+    the self-loop product and its gradients run over the table's rows, not over every node row."""
+    return _RGCNTableLayerFn.apply(table, weight, loop_w, bias, ids, inverse, dg, num_bases, ACTS[act])
+
+
 class _RGCNIsolatedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e, loop_w, bias, act):

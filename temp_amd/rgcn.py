@@ -72,6 +72,16 @@ class RGCNLayer(nn.Module):
         out = TF.rgcn_layer(h, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act)
         return self._post_act(out) if self._post_act is not None else out
 
+    def conv_table(self, g, table, ids, inverse):
+        """conv(g, table[ids]) for a layer fed straight from an embedding table (layer 1: h = ent_embeds[id],
+        models/DynamicRGCN.py:93) -- the gather is folded into the kernels."""
+        self._check_dropout()
+        if inverse is None or self.in_feat > 256 or self.out_feat > 256:
+            return self.conv(g, TF.gather_rows(table, ids))
+        dg = g.device_graph(table.device, self.num_rels)
+        out = TF.rgcn_layer_table(table, ids, inverse, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act)
+        return self._post_act(out) if self._post_act is not None else out
+
     def conv_isolated(self, e):
         self._check_dropout()
         out = TF.rgcn_isolated(e, self.loop_weight, self._bias(), self._act)

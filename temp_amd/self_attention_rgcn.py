@@ -114,8 +114,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
         R = wb.n_hist_rows
-        h0 = TF.gather_rows(self.ent_embeds, wb.ids_all, wb.ids_inv)
-        y1 = l1.conv(wb.g_all, h0)
+        y1 = l1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
         y2 = l2.conv(wb.g_all, y1)
         s = y2 + TF.gather_rows(l2.time_embed, wb.time_rows)
         kv2 = l2.project_kv(s[:R])

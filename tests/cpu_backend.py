@@ -104,6 +104,14 @@ class CpuTestBackend:
         d_bias = dz.sum(0) if has_bias else None
         return d_h, d_w, d_loop, d_bias
 
+    def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act):
+        return self.rgcn_fwd(dg, table.detach()[ids.long()], None, weight, loop_w, bias, num_bases, act)
+
+    def rgcn_table_bwd(self, dg, table, ids, inverse, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
+        d_h, d_w, d_loop, d_bias = self.rgcn_bwd(dg, table.detach()[ids.long()], out, d_out_grad, weight, loop_w, has_bias, num_bases, act)
+        d_table = self.segment_sum_rows(d_h, inverse[0], inverse[1], table.shape[0])
+        return d_table, d_w, d_loop, d_bias
+
     def rgcn_isolated_fwd(self, e, loop_w, bias, act):
         out = e.detach() + torch.mm(e.detach(), loop_w.detach())
         if bias is not None:

@@ -327,3 +327,35 @@ def test_segment_sum_matches_scatter_and_is_deterministic(rows, n, d, hip_backen
     keep = idx >= 0
     want.index_add_(0, torch.from_numpy(idx[keep].astype(np.int64)), src.cpu().double()[torch.from_numpy(keep)])
     assert_close(a, want.float(), 1e-5, 1e-5 * max(1.0, (n / max(rows, 1)) ** 0.5), "segment sum")
+
+
+@pytest.mark.parametrize("n_table,n,E,D,B,R2,bias,act", [(500, 3000, 40000, 200, 100, 40, False, 0), (7128, 900, 2500, 200, 100, 460, True, 1),
+                                                          (64, 300, 900, 32, 8, 10, True, 1), (50, 20, 0, 16, 8, 6, False, 0)])
+def test_rgcn_table_layer_equals_gather_then_layer(n_table, n, E, D, B, R2, bias, act, hip_backend):
+    """temp_rgcn_table_fwd/bwd (input = table[ids], self-loop through the table, per-table-row sums) against the plain
+    layer on the materialised gather followed by the gather's adjoint."""
+    from temp_amd import functional as TF
+    rng = np.random.default_rng(n_table + n + E)
+    g = rand_graph(rng, n, E, R2, hub=E > 1000)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(DEV)
+    S = D // B
+    table, w, lw = f(n_table, D), f(R2, B * S * S) * 0.5, f(D, D) * 0.2
+    b = f(D) if bias else None
+    gy = f(n, D)
+    ids_np = rng.integers(0, n_table, n)
+    ids = torch.from_numpy(ids_np.astype(np.int32)).to(DEV)
+    inv = TF.gather_inverse(ids_np, n_table, DEV)
+    dg = g.device_graph(DEV, R2)
+    h = table[ids.long()].contiguous()
+    want = hip_backend.rgcn_fwd(dg, h, None, w, lw, b, B, act)
+    got = hip_backend.rgcn_table_fwd(dg, table, ids, w, lw, b, B, act)
+    assert_close(got, want, 1e-5, 5e-6, "table fwd")
+    wd = hip_backend.rgcn_bwd(dg, h, want, gy, w, lw, bias, B, act)
+    gd = hip_backend.rgcn_table_bwd(dg, table, ids, inv, got, gy, w, lw, bias, B, act)
+    d_table = torch.zeros_like(table).index_add_(0, ids.long(), wd[0])
+    scale = max(1.0, float(n) ** 0.5)
+    assert_close(gd[0], d_table, 2e-5, 1e-5 * max(1.0, (n / n_table) ** 0.5), "d_table")
+    assert_close(gd[1], wd[1], 2e-5, 1e-5 * scale, "d_weight")
+    assert_close(gd[2], wd[2], 2e-5, 1e-5 * scale, "d_loop")
+    if bias:
+        assert_close(gd[3], wd[3], 2e-5, 1e-5 * scale, "d_bias")
