@@ -254,9 +254,10 @@ int temp_gather_rows(int n, int d, const float* table, const int32_t* idx, float
 int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, float* table, void* stream);
 /* Deterministic adjoint of a gather with a STATIC index list (the ids of a prepared window batch):
  *   out[s] = sum_{j in [seg_ptr[s], seg_ptr[s+1])} src[order[j]]      out: [n_seg, d] fully written (empty segment = 0)
- * seg_ptr [n_seg+1] / order [n_rows] = the gather indices grouped by table row (built once on the host).
+ * seg_ptr [n_seg+1] / order [n_rows] = the gather indices grouped by table row (built once on the host;
+ * ids < 0 are left out, so n_rows may be smaller than the gather).
  * No atomics; d % 4 == 0, d <= 256. */
-int temp_segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream);
+int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plain fp32 MFMA GEMMs (the extra (n,D)@(D,D) terms of the linear-recurrence layers,

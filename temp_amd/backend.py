@@ -355,7 +355,7 @@ class HipBackend:
         if src.shape[0] == 0 or order.shape[0] == 0:
             return torch.zeros(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
         out = torch.empty(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
-        rc = self.lib.temp_segment_sum_rows(n_seg, src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(out), _stream())
+        rc = self.lib.temp_segment_sum_rows(n_seg, order.shape[0], src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(out), _stream())
         _lib.check(rc, "temp_segment_sum_rows")
         return out
 

@@ -621,11 +621,48 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
 
 }  // extern "C"
 namespace temp {
+// Long segments (a hot table: hundreds of gathered rows per table row): one BLOCK per segment, its 4 waves take every
+// 4th row with 8 row loads in flight each, partial sums meet in LDS in a fixed order.
+__global__ void __launch_bounds__(256) k_segment_sum_rows_blk(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
+                                                              const int32_t* __restrict__ order, const float4* __restrict__ src,
+                                                              const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool col_ok = lane < d4;
+  for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
+    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+    float4 acc = zero4();
+    for (int j0 = beg + wave; j0 < end; j0 += 32) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + 4 * u;
+        v[u] = zero4();
+        if (j < end && col_ok) {
+          const int r = order[j];
+          if (!row_mask || row_mask[r] > 0) v[u] = src[(size_t)r * d4 + lane];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col_ok) out[(size_t)s * d4 + lane] = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
+    __syncthreads();
+  }
+}
+
 int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
-                     hipStream_t st) {
+                     hipStream_t st, long long n_rows_hint) {
   if (d % 4 || d > 256) return TEMP_E_UNSUPPORTED;
   if (n_seg == 0) return TEMP_OK;
   const int d4 = d / 4;
+  if (n_rows_hint > 32LL * n_seg && d4 <= 64) {
+    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk, dim3(n_seg < 4096 ? n_seg : 4096), dim3(256), 0, st, n_seg, d4, seg_ptr, order,
+                (const float4*)src, row_mask, (float4*)out);
+    return launch_status();
+  }
   int grid = ceil_div(n_seg, 4);
   if (grid > 2048) grid = 2048;
 #define TEMP_SEGSUM(L) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)out)
@@ -636,9 +673,9 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
 }  // namespace temp
 extern "C" {
 
-int temp_segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream) {
+int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream) {
   if (n_seg < 0 || d <= 0 || (n_seg > 0 && (!seg_ptr || !src || !out))) return TEMP_E_BADARG;
-  return segment_sum_rows(n_seg, d, seg_ptr, order, src, nullptr, out, (hipStream_t)stream);
+  return segment_sum_rows(n_seg, d, seg_ptr, order, src, nullptr, out, (hipStream_t)stream, n_rows);
 }
 
 struct EpiPlainStore {

@@ -512,9 +512,9 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
   //   d_table = segsum(out_deg > 0 ? d_h : 0) + segsum(dz) . loop_w^T        d_loop_w = table^T . segsum(dz)
   rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, w.d_h, w.part_dx, st);
   if (rc) return rc;
-  rc = segment_sum_rows(n_table, d_in, inv_ptr, inv_order, w.d_h, g->out_deg, d_table, st);
+  rc = segment_sum_rows(n_table, d_in, inv_ptr, inv_order, w.d_h, g->out_deg, d_table, st, g->n_nodes);
   if (rc) return rc;
-  rc = segment_sum_rows(n_table, d_out, inv_ptr, inv_order, dz, nullptr, w.seg_dz, st);
+  rc = segment_sum_rows(n_table, d_out, inv_ptr, inv_order, dz, nullptr, w.seg_dz, st, g->n_nodes);
   if (rc) return rc;
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, n_table, d_in, d_out, w.seg_dz, d_out, nullptr, loop_w, d_out, 1, d_table, d_in, nullptr, nullptr,
                          TEMP_ACT_NONE, d_table, d_in, st);
