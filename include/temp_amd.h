@@ -298,8 +298,8 @@ int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* 
  *   out[i, d * heads + h] = o[i,h,d]      (the reference's transpose after squeeze, SARGCN.py:37)
  * heads must be 8 (SARGCN.py:21), D % 8 == 0, D <= 512, T <= 64.
  * fwd saves score [n, heads, T] (raw s, -inf where masked) and lse [n, heads] for bwd.
- * bwd: d_q / d_kc / d_vc fully written; d_kh / d_vh ACCUMULATED with atomics (zero them first; rows are
- * shared between query rows); d_decay [T] accumulated when non-NULL.
+ * bwd: d_q / d_kc / d_vc fully written; d_kh / d_vh either ACCUMULATED with atomics (zero them first; rows are
+ * shared between query rows) or, given the inverse maps, written once per table row; d_decay [T] accumulated when non-NULL.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct TempAttn {
   int32_t n, D, heads, T;
@@ -312,7 +312,10 @@ typedef struct TempAttn {
 int temp_sa_attn_fwd(const TempAttn* p, float* out, float* score, float* lse, void* stream);
 int temp_sa_attn_bwd(const TempAttn* p, const float* out, const float* score, const float* lse, const float* d_out,
                      float* d_q, int ld_dq, float* d_kh, float* d_vh, int ld_dh, float* d_kc, float* d_vc, int ld_dc,
-                     float* d_decay, void* stream);
+                     float* d_decay, int n_table, const int32_t* inv_ptr, const int32_t* inv_ref, float* ds_ws, void* stream);
+/* Deterministic form: inv_ptr [n_table+1] / inv_ref = idx grouped by history-table row (ref = i * (T-1) + t, the static
+ * maps of a prepared batch) and ds_ws [n * heads * T] scratch.  Then d_kh / d_vh rows [0, n_table) are each written once
+ * by a second pass over the table (no atomics, no zero-fill needed).  With inv_ptr = NULL the atomic form above is used. */
 
 /* Device-memory bandwidth probe used by bench.py to calibrate the achievable HBM peak
  * (float4 copy of `bytes` bytes, dst and src must not overlap). */

@@ -316,19 +316,25 @@ class HipBackend:
         _lib.check(rc, "temp_sa_attn_fwd")
         return out, score, lse
 
-    def sa_attn_bwd(self, qkv, kv_hist, idx, decay, out, score, lse, d_out):
-        """-> (d_qkv [n,3D], d_kv_hist [R,2D], d_decay [T] or None)."""
+    def sa_attn_bwd(self, qkv, kv_hist, idx, decay, out, score, lse, d_out, inverse=None):
+        """-> (d_qkv [n,3D], d_kv_hist [R,2D], d_decay [T] or None).  `inverse` = (inv_ptr, inv_ref) of idx grouped by
+        table row selects the deterministic two-pass form (no atomics)."""
         qkv, kv_hist, idx, decay = _f32(qkv, "qkv"), _f32(kv_hist, "kv_hist"), _i32(idx, "idx"), _f32(decay, "decay")
         d_out = _f32(d_out, "d_out")
         a, n, D, T = self._attn_desc(qkv, kv_hist, idx, decay)
         d_qkv = torch.empty_like(qkv)
-        d_hist = torch.zeros_like(kv_hist)
+        use_inv = inverse is not None and T > 1
+        d_hist = torch.empty_like(kv_hist) if use_inv else torch.zeros_like(kv_hist)
         d_decay = torch.zeros(T, dtype=torch.float32, device=qkv.device) if decay is not None else None
         db, dh = d_qkv.data_ptr(), d_hist.data_ptr()
         vp = ctypes.c_void_p
+        inv_ptr = inv_ref = ds_ws = None
+        if use_inv:
+            inv_ptr, inv_ref = _i32(inverse[0], "inv_ptr"), _i32(inverse[1], "inv_ref")
+            ds_ws = torch.empty(n * 8 * T, dtype=torch.float32, device=qkv.device)
         rc = self.lib.temp_sa_attn_bwd(ctypes.byref(a), _ptr(out), _ptr(score), _ptr(lse), _ptr(d_out),
                                        vp(db), 3 * D, vp(dh), vp(dh + 4 * D), 2 * D, vp(db + 4 * D), vp(db + 8 * D), 3 * D,
-                                       _ptr(d_decay), _stream())
+                                       _ptr(d_decay), kv_hist.shape[0], _ptr(inv_ptr), _ptr(inv_ref), _ptr(ds_ws), _stream())
         _lib.check(rc, "temp_sa_attn_bwd")
         return d_qkv, d_hist, d_decay
 

@@ -98,6 +98,7 @@ struct AttnGrads {
   float* d_kh; float* d_vh; int ld_dh;
   float* d_kc; float* d_vc; int ld_dc;
   float* d_decay;
+  float* ds;            // [n, 8, T] score gradients for the table pass; when set, no atomics are issued here
 };
 
 template <int MAXC>
@@ -161,14 +162,17 @@ __global__ __launch_bounds__(256) void k_sa_attn_bwd(AttnArgs a, const float* __
       const float p = __expf(srow[t] - L);
       const float ds = p * (dp - delta);
       if (want_decay && j == 0) atomicAdd(&s_decay[t], ds);
+      if (g.ds && j == 0) g.ds[((size_t)row * 8 + head) * a.T + t] = ds;
       const float gs = ds / a.sqrt_dk;
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
         dq[i] = fmaf(gs, kv[i], dq[i]);
         if (ok[i]) {
           if (hist) {
-            atomicAdd(&dkp[col[i]], gs * qv[i]);
-            atomicAdd(&dvp[col[i]], p * dov[i]);
+            if (!g.ds) {
+              atomicAdd(&dkp[col[i]], gs * qv[i]);
+              atomicAdd(&dvp[col[i]], p * dov[i]);
+            }
           } else {
             dkp[col[i]] = gs * qv[i];
             dvp[col[i]] = p * dov[i];
@@ -184,6 +188,50 @@ __global__ __launch_bounds__(256) void k_sa_attn_bwd(AttnArgs a, const float* __
     __syncthreads();
     if (threadIdx.x < a.T) atomicAdd(&g.d_decay[threadIdx.x], s_decay[threadIdx.x]);
   }
+}
+
+// Table pass of the deterministic backward: one wave per history-table row r walks the (query row, position)
+// pairs that attended to it (inv_ptr / inv_ref = idx grouped by table row, ref = i * (T-1) + t, built on the
+// host) and accumulates  dK[r] = sum ds/sqrt(dk) * q[i],  dV[r] = sum p * dO[i]  in a fixed order -- every table
+// row is written exactly once, no atomics, no zero-fill.
+template <int MAXC>
+__global__ __launch_bounds__(256) void k_sa_attn_bwd_table(AttnArgs a, int n_table, const int32_t* __restrict__ inv_ptr,
+                                                            const int32_t* __restrict__ inv_ref, const float* __restrict__ score,
+                                                            const float* __restrict__ lse, const float* __restrict__ ds,
+                                                            const float* __restrict__ d_out, float* __restrict__ d_kh,
+                                                            float* __restrict__ d_vh, int ld_dh) {
+  const int lane = threadIdx.x & 63, head = lane >> 3, j = lane & 7;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_table) return;
+  int col[MAXC];
+  bool ok[MAXC];
+  float ak[MAXC], av[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int d = j + 8 * i;
+    ok[i] = d < a.dk;
+    col[i] = head * a.dk + (ok[i] ? d : 0);
+    ak[i] = 0.f; av[i] = 0.f;
+  }
+  const int Th = a.T - 1;
+  const int beg = inv_ptr[r], end = inv_ptr[r + 1];
+  for (int e = beg; e < end; ++e) {
+    const int ref = __builtin_amdgcn_readfirstlane(inv_ref[e]);
+    const int row = ref / Th, t = ref - row * Th;
+    const size_t sidx = ((size_t)row * 8 + head) * a.T + t;
+    const float p = __expf(score[sidx] - lse[(size_t)row * 8 + head]);
+    const float gs = ds[sidx] / a.sqrt_dk;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      if (ok[i]) {
+        ak[i] = fmaf(gs, a.q[(size_t)row * a.ldq + col[i]], ak[i]);
+        av[i] = fmaf(p, d_out[(size_t)row * a.D + (size_t)(j + 8 * i) * 8 + head], av[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (ok[i]) { d_kh[(size_t)r * ld_dh + col[i]] = ak[i]; d_vh[(size_t)r * ld_dh + col[i]] = av[i]; }
 }
 
 static int attn_check(const TempAttn* p) {
@@ -229,14 +277,16 @@ int temp_sa_attn_fwd(const TempAttn* p, float* out, float* score, float* lse, vo
 
 int temp_sa_attn_bwd(const TempAttn* p, const float* out, const float* score, const float* lse, const float* d_out,
                      float* d_q, int ld_dq, float* d_kh, float* d_vh, int ld_dh, float* d_kc, float* d_vc, int ld_dc,
-                     float* d_decay, void* stream) {
+                     float* d_decay, int n_table, const int32_t* inv_ptr, const int32_t* inv_ref, float* ds_ws, void* stream) {
   int rc = attn_check(p);
   if (rc != TEMP_OK) return rc;
   if (p->n == 0) return TEMP_OK;
   if (!out || !score || !lse || !d_out || !d_q || !d_kc || !d_vc) return TEMP_E_BADARG;
   if (p->T > 1 && (!d_kh || !d_vh)) return TEMP_E_BADARG;
+  const bool table_pass = inv_ptr != nullptr && p->T > 1;
+  if (table_pass && (!ds_ws || n_table <= 0)) return TEMP_E_BADARG;
   const AttnArgs a = to_args(p);
-  AttnGrads g{d_q, ld_dq, d_kh, d_vh, ld_dh, d_kc, d_vc, ld_dc, d_decay};
+  AttnGrads g{d_q, ld_dq, d_kh, d_vh, ld_dh, d_kc, d_vc, ld_dc, d_decay, table_pass ? ds_ws : nullptr};
   const dim3 grid(ceil_div(p->n, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int mc = (a.dk + 7) / 8;
@@ -244,6 +294,12 @@ int temp_sa_attn_bwd(const TempAttn* p, const float* out, const float* score, co
   else if (mc <= 2) TEMP_LAUNCH(K_SA_ATTN_BWD, k_sa_attn_bwd<2>, grid, block, 0, st, a, out, score, lse, d_out, g);
   else if (mc <= 4) TEMP_LAUNCH(K_SA_ATTN_BWD, k_sa_attn_bwd<4>, grid, block, 0, st, a, out, score, lse, d_out, g);
   else TEMP_LAUNCH(K_SA_ATTN_BWD, k_sa_attn_bwd<8>, grid, block, 0, st, a, out, score, lse, d_out, g);
+  if (table_pass) {
+    const dim3 tg(ceil_div(n_table, 4));
+#define TEMP_TBL(M) TEMP_LAUNCH(K_SA_ATTN_BWD, k_sa_attn_bwd_table<M>, tg, block, 0, st, a, n_table, inv_ptr, inv_ref, score, lse, ds_ws, d_out, d_kh, d_vh, ld_dh)
+    if (mc <= 1) TEMP_TBL(1); else if (mc <= 2) TEMP_TBL(2); else if (mc <= 4) TEMP_TBL(4); else TEMP_TBL(8);
+#undef TEMP_TBL
+  }
   return launch_status();
 }
 

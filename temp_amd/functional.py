@@ -208,24 +208,39 @@ def linear(x, w):
 
 class _HistoryAttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, kv_hist, idx, decay):
+    def forward(ctx, qkv, kv_hist, idx, decay, inverse):
         out, score, lse = get_backend().sa_attn_fwd(qkv, kv_hist, idx, decay)
         ctx.save_for_backward(qkv, kv_hist, idx, decay if decay is not None else qkv.new_zeros(0), out, score, lse)
         ctx.has_decay = decay is not None
+        ctx.inverse = inverse
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         qkv, kv_hist, idx, decay, out, score, lse = ctx.saved_tensors
         d_qkv, d_hist, d_decay = get_backend().sa_attn_bwd(qkv, kv_hist, idx, decay if ctx.has_decay else None, out, score, lse,
-                                                           d_out.contiguous())
-        return d_qkv, d_hist, None, d_decay
+                                                           d_out.contiguous(), ctx.inverse)
+        return d_qkv, d_hist, None, d_decay, None
 
 
-def history_attention(qkv, kv_hist, idx, decay=None):
+def history_attention(qkv, kv_hist, idx, decay=None, inverse=None):
     """8-head attention of every query row over its active history rows + itself.
     qkv (n,3D) = [q | k | v] projections of the query rows' current states; kv_hist (R,2D) = [k | v]
     projections of the history table; idx (n,T-1) int32 rows of the table, -1 => masked;
-    decay (T,) additive score bias (already negated / clamped) or None.
+    decay (T,) additive score bias (already negated / clamped) or None;
+    inverse = attention_inverse(idx, R): static maps that make the backward deterministic (no atomics).
     Returns (n,D) in the reference's feature order (d * 8 + head)."""
-    return _HistoryAttentionFn.apply(qkv, kv_hist, idx, decay)
+    return _HistoryAttentionFn.apply(qkv, kv_hist, idx, decay, inverse)
+
+
+def attention_inverse(idx_np, n_table, device):
+    """(inv_ptr int32 [n_table+1], inv_ref int32): the (query row, position) pairs of idx (n, T-1) grouped by the table
+    row they point at; ref = i * (T-1) + t."""
+    import numpy as np
+    idx_np = np.asarray(idx_np, dtype=np.int64)
+    flat = idx_np.reshape(-1)
+    pos = np.nonzero(flat >= 0)[0]
+    order = pos[np.argsort(flat[pos], kind="stable")]
+    counts = np.bincount(flat[pos], minlength=n_table)
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    return (torch.from_numpy(ptr.astype(np.int32)).to(device), torch.from_numpy(order.astype(np.int32)).to(device))

@@ -51,12 +51,12 @@ class SARGCNLayer(RGCNLayer):
             return None
         return -torch.clamp(self.exponential_decay(time_diff.unsqueeze(1)), min=0).reshape(-1)
 
-    def attend(self, cur, kv_hist, idx, time_diff):
+    def attend(self, cur, kv_hist, idx, time_diff, inverse=None):
         """Attention of every row of `cur` (n,D) over kv_hist[idx[n,:]] (idx (n,T-1) int32, -1 masked)
-        and itself."""
+        and itself.  `inverse` = TF.attention_inverse(idx, R) (static maps) makes the backward deterministic."""
         if kv_hist.shape[0] == 0:
-            kv_hist = cur.new_zeros(1, 2 * self.in_feat)
-        return TF.history_attention(self.project_qkv(cur), kv_hist, idx, self.decay_bias(time_diff))
+            kv_hist, inverse = cur.new_zeros(1, 2 * self.in_feat), None
+        return TF.history_attention(self.project_qkv(cur), kv_hist, idx, self.decay_bias(time_diff), inverse)
 
     # -- reference (dense) API ----------------------------------------------------------------------------
     def calc_result(self, cur_embeddings, prev_embeddings, time_diff, local_attn_mask):

@@ -94,10 +94,17 @@ class SelfAttentionRGCN(DynamicRGCN):
         as_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
         wb.ids_all = as_dev(wb.g_all.gids, np.int32)
         wb.ids_inv = TF.gather_inverse(wb.g_all.gids, N, dev)
-        wb.time_rows = as_dev(np.repeat(np.array(hist_ts + wb.target_times, dtype=np.int64), [g.n for g in all_graphs]), np.int32)
-        wb.idx_tgt = as_dev(np.concatenate(idx_tgt, axis=0), np.int32)
-        wb.idx_all = as_dev(np.concatenate(idx_all, axis=0), np.int32)
-        wb.all_time_rows = as_dev(np.repeat(np.array(wb.target_times, dtype=np.int64), N), np.int32)
+        time_rows = np.repeat(np.array(hist_ts + wb.target_times, dtype=np.int64), [g.n for g in all_graphs])
+        wb.time_rows = as_dev(time_rows, np.int32)
+        wb.time_inv = TF.gather_inverse(time_rows, len(self.total_time), dev)
+        idx_tgt_np, idx_all_np = np.concatenate(idx_tgt, axis=0), np.concatenate(idx_all, axis=0)
+        wb.idx_tgt = as_dev(idx_tgt_np, np.int32)
+        wb.idx_all = as_dev(idx_all_np, np.int32)
+        wb.inv_tgt = TF.attention_inverse(idx_tgt_np, off, dev) if off > 0 and idx_tgt_np.shape[1] > 0 else None
+        wb.inv_all = TF.attention_inverse(idx_all_np, off, dev) if off > 0 and idx_all_np.shape[1] > 0 else None
+        all_time_rows = np.repeat(np.array(wb.target_times, dtype=np.int64), N)
+        wb.all_time_rows = as_dev(all_time_rows, np.int32)
+        wb.all_time_inv = TF.gather_inverse(all_time_rows, len(self.total_time), dev)
         wb.gid_dev = [torch.from_numpy(g.gids).to(dev) for g in wb.graphs]
         wb.time_diff = self.time_diff_train if seq_len == self.train_seq_len else self._time_diff(seq_len).to(dev)
         wb.batched = True
@@ -116,14 +123,14 @@ class SelfAttentionRGCN(DynamicRGCN):
         R = wb.n_hist_rows
         y1 = l1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
         y2 = l2.conv(wb.g_all, y1)
-        s = y2 + TF.gather_rows(l2.time_embed, wb.time_rows)
+        s = y2 + TF.gather_rows(l2.time_embed, wb.time_rows, wb.time_inv)
         kv2 = l2.project_kv(s[:R])
-        second = l2.attend(s[R:], kv2, wb.idx_tgt, wb.time_diff)
+        second = l2.attend(s[R:], kv2, wb.idx_tgt, wb.time_diff, wb.inv_tgt)
         if enc.rec_only_last_layer:
             return second, (None, kv2)
-        f = y1 + TF.gather_rows(l1.time_embed, wb.time_rows)
+        f = y1 + TF.gather_rows(l1.time_embed, wb.time_rows, wb.time_inv)
         kv1 = l1.project_kv(f[:R])
-        first = l1.attend(f[R:], kv1, wb.idx_tgt, wb.time_diff)
+        first = l1.attend(f[R:], kv1, wb.idx_tgt, wb.time_diff, wb.inv_tgt)
         return jk_max(first, second), (kv1, kv2)
 
     def all_embeds_batched(self, wb, per_graph, tables):
@@ -141,11 +148,11 @@ class SelfAttentionRGCN(DynamicRGCN):
                 y2 = l2.conv_isolated(y1).repeat(bsz, 1)
                 first = None
             else:
-                cur1 = y1.repeat(bsz, 1) + TF.gather_rows(l1.time_embed, wb.all_time_rows)
-                first = l1.attend(cur1, kv1, wb.idx_all, wb.time_diff)
+                cur1 = y1.repeat(bsz, 1) + TF.gather_rows(l1.time_embed, wb.all_time_rows, wb.all_time_inv)
+                first = l1.attend(cur1, kv1, wb.idx_all, wb.time_diff, wb.inv_all)
                 y2 = l2.conv_isolated(first)
-            cur2 = y2 + TF.gather_rows(l2.time_embed, wb.all_time_rows)
-            second = l2.attend(cur2, kv2, wb.idx_all, wb.time_diff)
+            cur2 = y2 + TF.gather_rows(l2.time_embed, wb.all_time_rows, wb.all_time_inv)
+            second = l2.attend(cur2, kv2, wb.idx_all, wb.time_diff, wb.inv_all)
             allh = second if first is None else jk_max(first, second)
             alls = [allh[b * N:(b + 1) * N] for b in range(bsz)]
         return [a.index_copy(0, wb.gid_dev[b], per_graph[b]) for b, a in enumerate(alls)]

@@ -267,7 +267,7 @@ class CpuTestBackend:
         with torch.no_grad():
             return self._attn(qkv.detach(), kv_hist.detach(), idx, decay.detach() if decay is not None else None)
 
-    def sa_attn_bwd(self, qkv, kv_hist, idx, decay, out, score, lse, d_out):
+    def sa_attn_bwd(self, qkv, kv_hist, idx, decay, out, score, lse, d_out, inverse=None):
         with torch.enable_grad():
             a = qkv.detach().clone().requires_grad_(True)
             b = kv_hist.detach().clone().requires_grad_(True)

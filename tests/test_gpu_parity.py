@@ -293,6 +293,14 @@ def test_history_attention_kernel_vs_dense(n, R, T, D, decay, hip_backend):
         assert_close(g[2], w[2], 5e-5, 2e-5, "d_decay")
     else:
         assert g[2] is None
+    if T > 1:                                      # deterministic two-pass form: same values, bitwise repeatable
+        from temp_amd import functional as TF
+        inv = TF.attention_inverse(idx.numpy(), R, DEV)
+        g1 = hip_backend.sa_attn_bwd(dev(qkv), dev(kvh), dev(idx), dev(dec), out, score, lse, dev(d_out), inv)
+        g2 = hip_backend.sa_attn_bwd(dev(qkv), dev(kvh), dev(idx), dev(dec), out, score, lse, dev(d_out), inv)
+        assert_close(g1[0], w[0], 2e-5, 3e-6, "d_qkv (table pass)")
+        assert_close(g1[1], w[1], 2e-5, 3e-6, "d_kv_hist (table pass)")
+        assert torch.equal(g1[1], g2[1]) and torch.equal(g1[0], g2[0])
 
 
 @pytest.mark.parametrize("name", ["G14_sa_uni_rol", "G14_sa_uni", "G14_sa_bi_rol"])
