@@ -39,6 +39,7 @@ class Snapshot:
         self.ndata = {}          # 'h' is put here by the caller, as in the reference
         self._dev = {}           # device -> _DeviceGraph
         self._ids_dict = None
+        self._views = {}         # n_rel_rows -> host-side sorted views (static per snapshot, built once)
 
     # ---- reference-style accessors --------------------------------------------------------
     @property
@@ -62,7 +63,7 @@ class Snapshot:
 
     def local_var(self):
         """Shallow copy sharing topology and device views (DGL's local_var)."""
-        g = Snapshot.__new__(Snapshot)
+        g = self.__class__.__new__(self.__class__)
         g.__dict__.update(self.__dict__)
         g.ndata = dict(self.ndata)
         return g
@@ -74,6 +75,21 @@ class Snapshot:
         return Snapshot(self.n, self.src[idx], self.dst[idx], self.rel[idx], self.gids)
 
     # ---- device views -----------------------------------------------------------------------
+    def local_views(self, n_rel_rows):
+        """Host-side sorted / chunked views of THIS graph (local node ids), cached: membership is static."""
+        v = self._views.get(n_rel_rows)
+        if v is None:
+            E = self.number_of_edges()
+            if E and (self.rel.min() < 0 or self.rel.max() >= n_rel_rows):
+                raise ValueError("relation id outside [0, %d)" % n_rel_rows)
+            v = dict(by_dst=build_view(self.dst, self.src, self.rel, self.n), by_src=build_view(self.src, self.dst, self.rel, self.n),
+                     by_rel=build_view(self.rel, self.src, self.dst, n_rel_rows, chunk=_lib.CHUNK_REL),
+                     in_deg=np.bincount(self.dst, minlength=self.n).astype(np.int32),
+                     out_deg=np.bincount(self.src, minlength=self.n).astype(np.int32))
+            v["rel_chunks"] = np.bincount(v["by_rel"]["chunk_seg"], minlength=n_rel_rows).astype(np.int64)
+            self._views[n_rel_rows] = v
+        return v
+
     def device_graph(self, device, n_rel_rows):
         key = (str(device), int(n_rel_rows))
         dg = self._dev.get(key)
@@ -83,20 +99,45 @@ class Snapshot:
         return dg
 
 
+class BatchedSnapshot(Snapshot):
+    """Disjoint union of snapshots (dgl.batch, models/DynamicRGCN.py:92).  The member snapshots are kept (`parts`):
+    their sorted edge views are static and cached, so the union's device views are assembled by offsetting and
+    concatenating them instead of re-sorting millions of edges for every batch; the union's own src / dst / rel
+    arrays are only materialised if something asks for them."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.node_sizes = [g.n for g in self.parts]
+        self.node_off = np.concatenate([[0], np.cumsum(self.node_sizes)]).astype(np.int64)
+        self.edge_off = np.concatenate([[0], np.cumsum([g.number_of_edges() for g in self.parts])]).astype(np.int64)
+        self.n = int(self.node_off[-1])
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
+        self.gids = cat([g.gids for g in self.parts], np.int64)
+        self.nnorm = cat([g.nnorm for g in self.parts], np.float32)
+        self.ndata = {}
+        self._dev = {}
+        self._ids_dict = None
+        self._views = {}
+        self._edges = None
+
+    def _materialise(self):
+        if self._edges is None:
+            cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, dtype=np.int64)
+            self._edges = (cat([g.src + o for g, o in zip(self.parts, self.node_off)]),
+                           cat([g.dst + o for g, o in zip(self.parts, self.node_off)]), cat([g.rel for g in self.parts]))
+        return self._edges
+
+    src = property(lambda self: self._materialise()[0])
+    dst = property(lambda self: self._materialise()[1])
+    rel = property(lambda self: self._materialise()[2])
+
+    def number_of_edges(self):
+        return int(self.edge_off[-1])
+
+
 def batch(snapshots):
     """dgl.batch as used at models/DynamicRGCN.py:92: disjoint union with node-id offsets."""
-    off, src, dst, rel, ids, nn_ = 0, [], [], [], [], []
-    for g in snapshots:
-        src.append(g.src + off)
-        dst.append(g.dst + off)
-        rel.append(g.rel)
-        ids.append(g.gids)
-        nn_.append(g.nnorm)
-        off += g.n
-    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
-    out = Snapshot(off, cat(src, np.int64), cat(dst, np.int64), cat(rel, np.int64), cat(ids, np.int64), cat(nn_, np.float32))
-    out.node_sizes = [g.n for g in snapshots]
-    return out
+    return BatchedSnapshot(snapshots)
 
 
 def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK):
@@ -182,6 +223,70 @@ def by_rel_view(snap, n_rel_rows):
     return build_view_tiled(snap.rel, snap.src, snap.dst, n_rel_rows, np.asarray(snap.dst, dtype=np.int64) // width, chunk=_lib.CHUNK_REL)
 
 
+def _concat_node_views(parts, name, node_off, edge_off, n_total):
+    """by_dst / by_src view of a disjoint union from the members' cached views: segments are nodes, so the union's
+    sorted order is the members' orders back to back."""
+    vs = [g[name] for g in parts]
+    p_off = np.concatenate([[0], np.cumsum([v["n_partial"] for v in vs])]).astype(np.int64)
+    cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)
+    out = dict(n_seg=int(n_total), n_edges=int(edge_off[-1]),
+               a=cat([v["a"] + no for v, no in zip(vs, node_off)]), b=cat([v["b"] for v in vs]),
+               chunk_seg=cat([v["chunk_seg"] + no for v, no in zip(vs, node_off)]),
+               chunk_beg=cat([v["chunk_beg"] + eo for v, eo in zip(vs, edge_off)]),
+               chunk_end=cat([v["chunk_end"] + eo for v, eo in zip(vs, edge_off)]),
+               chunk_slot=cat([np.where(v["chunk_slot"] >= 0, v["chunk_slot"] + po, -1) for v, po in zip(vs, p_off)]),
+               fix_seg=cat([v["fix_seg"] + no for v, no in zip(vs, node_off)]),
+               fix_slot=cat([v["fix_slot"] + po for v, po in zip(vs, p_off)]), fix_cnt=cat([v["fix_cnt"] for v in vs]))
+    out["n_chunks"], out["n_partial"], out["n_fix"] = int(out["chunk_seg"].shape[0]), int(p_off[-1]), int(out["fix_seg"].shape[0])
+    return out
+
+
+def _concat_rel_views(parts, node_off, edge_off, n_rel_rows):
+    """Tiled by-relation view of a disjoint union with tile = member snapshot (what build_view_tiled produces for
+    tile[e] = member of e): chunks member-major, every chunk of a relation that has more than one chunk in the whole
+    union goes through a partial slot, slots of one relation contiguous (ordered by member)."""
+    vs = [g["by_rel"] for g in parts]
+    counts = np.stack([g["rel_chunks"] for g in parts]) if parts else np.zeros((0, n_rel_rows), np.int64)   # (members, rels)
+    per_rel = counts.sum(axis=0)
+    multi = per_rel > 1
+    fix_seg = np.nonzero(multi)[0]
+    fix_cnt = per_rel[fix_seg]
+    fix_slot = np.cumsum(fix_cnt) - fix_cnt
+    base = np.full(n_rel_rows, -1, dtype=np.int64)
+    base[fix_seg] = fix_slot
+    before = np.cumsum(counts, axis=0) - counts                         # chunks of relation r in earlier members
+    slots = []
+    for m, v in enumerate(vs):
+        seg = v["chunk_seg"].astype(np.int64)
+        first = np.cumsum(counts[m]) - counts[m]                        # first chunk of each relation inside this member
+        k = np.arange(seg.shape[0], dtype=np.int64) - first[seg]
+        slots.append(np.where(multi[seg], base[seg] + before[m][seg] + k, -1))
+    cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)
+    out = dict(n_seg=int(n_rel_rows), n_edges=int(edge_off[-1]),
+               a=cat([v["a"] + no for v, no in zip(vs, node_off)]), b=cat([v["b"] + no for v, no in zip(vs, node_off)]),
+               chunk_seg=cat([v["chunk_seg"] for v in vs]),
+               chunk_beg=cat([v["chunk_beg"] + eo for v, eo in zip(vs, edge_off)]),
+               chunk_end=cat([v["chunk_end"] + eo for v, eo in zip(vs, edge_off)]),
+               chunk_slot=cat(slots), fix_seg=fix_seg.astype(np.int32), fix_slot=fix_slot.astype(np.int32), fix_cnt=fix_cnt.astype(np.int32))
+    out["n_chunks"], out["n_partial"], out["n_fix"] = int(out["chunk_seg"].shape[0]), int(per_rel[multi].sum()), int(fix_seg.shape[0])
+    return out
+
+
+def union_views(snap, n_rel_rows):
+    """(views, in_deg, out_deg) of a BatchedSnapshot from its members' cached views."""
+    lv = [g.local_views(n_rel_rows) for g in snap.parts]
+    no, eo = snap.node_off[:-1], snap.edge_off[:-1]
+    E = int(snap.edge_off[-1])
+    views = dict(by_dst=_concat_node_views(lv, "by_dst", no, np.append(eo, E), snap.n),
+                 by_src=_concat_node_views(lv, "by_src", no, np.append(eo, E), snap.n))
+    if E // (REL_GROUP_EDGES * max(n_rel_rows, 1)) > 1:                  # GDELT-like: a relation has many edges per snapshot
+        views["by_rel"] = _concat_rel_views(lv, no, np.append(eo, E), n_rel_rows)
+    else:                                                               # few edges per relation: one global sort (cheap at this size)
+        views["by_rel"] = build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL)
+    cat = lambda k: np.concatenate([g[k] for g in lv]) if lv else np.zeros(0, np.int32)
+    return views, cat("in_deg"), cat("out_deg")
+
+
 _VIEW_ARRAYS = ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")
 
 
@@ -191,13 +296,18 @@ class _DeviceGraph:
 
     def __init__(self, snap, device, n_rel_rows):
         n, E = snap.n, snap.number_of_edges()
-        views = dict(by_dst=build_view(snap.dst, snap.src, snap.rel, n),
-                     by_src=build_view(snap.src, snap.dst, snap.rel, n),
-                     by_rel=by_rel_view(snap, n_rel_rows))
-        if E and (snap.rel.min() < 0 or snap.rel.max() >= n_rel_rows):
-            raise ValueError("relation id outside [0, %d)" % n_rel_rows)
-        in_deg = np.bincount(snap.dst, minlength=n).astype(np.int32)
-        out_deg = np.bincount(snap.src, minlength=n).astype(np.int32)
+        if isinstance(snap, BatchedSnapshot) and len(snap.parts) > 1:
+            views, in_deg, out_deg = union_views(snap, n_rel_rows)
+        else:
+            one = snap.parts[0] if isinstance(snap, BatchedSnapshot) and snap.parts else snap
+            lv = one.local_views(n_rel_rows) if n else None
+            if lv is None:
+                z = np.zeros(0, np.int64)
+                views = dict(by_dst=build_view(z, z, z, 0), by_src=build_view(z, z, z, 0), by_rel=build_view(z, z, z, n_rel_rows, chunk=_lib.CHUNK_REL))
+                in_deg = out_deg = np.zeros(0, np.int32)
+            else:
+                views = dict(by_dst=lv["by_dst"], by_src=lv["by_src"], by_rel=by_rel_view(one, n_rel_rows))
+                in_deg, out_deg = lv["in_deg"], lv["out_deg"]
         parts, offs, off = [in_deg, out_deg], {}, 2 * n
         for vn, v in views.items():
             for an in _VIEW_ARRAYS:
