@@ -260,8 +260,17 @@ class DynamicRGCN(TKG_Module):
         return self.run_loss(wb, samples)
 
     def draw_samples(self, wb):
-        """Negative samples of every target graph of a prepared batch (host side)."""
-        return [self.corrupter.single_graph_negative_sampling(wb.rows[i][-1], g, self.num_ents)[:3] for i, g in enumerate(wb.graphs)]
+        """Negative samples of every target graph of a prepared batch.  On a GPU the draws and the true-triple filter
+        run on the device (sampling.DeviceCorruptTriples); `use_device_sampler = False` keeps the host sampler."""
+        dev = self._device()
+        c = self.corrupter
+        if dev.type == "cuda" and getattr(self, "use_device_sampler", True):
+            from .sampling import DeviceCorruptTriples
+            dc = getattr(self, "_dev_corrupter", None)
+            if dc is None or dc.device != dev:
+                dc = self._dev_corrupter = DeviceCorruptTriples(self.args, self.graph_dict_train, dev, seed=getattr(self.args, "seed", None))
+            c = dc
+        return [c.single_graph_negative_sampling(wb.rows[i][-1], g, self.num_ents)[:3] for i, g in enumerate(wb.graphs)]
 
     def _all_maps(self, wb):
         """Row maps / time gaps of ALL entities for every window of the batch, concatenated

