@@ -284,7 +284,7 @@ int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* 
  * ---------------------------------------------------------------------------------------------- */
 int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* cand, float* loss_rows, float* lse_rows, void* stream);
 int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* cand, const float* lse_rows, const float* scale,
-                       float inv_rows, float* d_scores, void* stream);
+                       float inv_rows, const float* row_scale /* nullable [P]: per-row weight instead of inv_rows */, float* d_scores, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * History attention of the self-attention encoder (SARGCNLayer.calc_result + attention,

@@ -277,11 +277,13 @@ class HipBackend:
         _lib.check(rc, "temp_gather_ce_fwd")
         return loss, lse
 
-    def gather_ce_bwd(self, scores, cand, lse, scale, inv_rows):
+    def gather_ce_bwd(self, scores, cand, lse, scale, inv_rows, row_scale=None):
         scores, cand, lse, scale = _f32(scores, "scores"), _i32(cand, "cand"), _f32(lse, "lse"), _f32(scale, "scale")
+        row_scale = _f32(row_scale, "row_scale")
         P, N = scores.shape
         d = torch.empty_like(scores)
-        rc = self.lib.temp_gather_ce_bwd(P, cand.shape[1], N, _ptr(scores), _ptr(cand), _ptr(lse), _ptr(scale), float(inv_rows), _ptr(d), _stream())
+        rc = self.lib.temp_gather_ce_bwd(P, cand.shape[1], N, _ptr(scores), _ptr(cand), _ptr(lse), _ptr(scale), float(inv_rows), _ptr(row_scale),
+                                         _ptr(d), _stream())
         _lib.check(rc, "temp_gather_ce_bwd")
         return d
 

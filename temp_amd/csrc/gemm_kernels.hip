@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(256) k_gather_ce_fwd(int C, int N, const float
 // d_scores[p, :] = scale * sum_k (softmax_k - [k == 0]) e_{cand[p,k]}   (row built in LDS, written once)
 __global__ void __launch_bounds__(256) k_gather_ce_bwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
                                                        const float* __restrict__ lse_rows, const float* __restrict__ scale_ptr, float inv_rows,
-                                                       float* __restrict__ d_scores) {
+                                                       const float* __restrict__ row_scale, float* __restrict__ d_scores) {
   extern __shared__ float row[];
   const int p = blockIdx.x;
   for (int i = threadIdx.x; i < N; i += 256) row[i] = 0.f;
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) k_gather_ce_bwd(int C, int N, const float
   const float* srow = scores + (size_t)p * N;
   const int32_t* crow = cand + (size_t)p * C;
   const float lse = lse_rows[p];
-  const float scale = scale_ptr[0] * inv_rows;
+  const float scale = scale_ptr[0] * (row_scale ? row_scale[p] : inv_rows);
   for (int k = threadIdx.x; k < C; k += 256) {
     const int e = crow[k];
     float g = expf(srow[e] - lse);
@@ -709,7 +709,7 @@ int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* 
 }
 
 int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* cand, const float* lse_rows, const float* scale,
-                       float inv_rows, float* d_scores, void* stream) {
+                       float inv_rows, const float* row_scale, float* d_scores, void* stream) {
   if (P < 0 || C <= 0 || N <= 0 || !scale || (P > 0 && (!scores || !cand || !lse_rows || !d_scores))) return TEMP_E_BADARG;
   if ((size_t)N * sizeof(float) > 160 * 1024 - 1024) return TEMP_E_UNSUPPORTED;
   if (P == 0) return TEMP_OK;
@@ -717,7 +717,7 @@ int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* 
   if (lds > 65536) {
     if (hipFuncSetAttribute((const void*)k_gather_ce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEMP_E_LAUNCH;
   }
-  TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_bwd, dim3(P), dim3(256), lds, (hipStream_t)stream, C, N, scores, cand, lse_rows, scale, inv_rows, d_scores);
+  TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_bwd, dim3(P), dim3(256), lds, (hipStream_t)stream, C, N, scores, cand, lse_rows, scale, inv_rows, row_scale, d_scores);
   return launch_status();
 }
 

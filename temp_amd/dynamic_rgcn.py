@@ -316,6 +316,14 @@ class DynamicRGCN(TKG_Module):
         batched = (wb.batched and not self.ent_encoder.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
                    and getattr(self.ent_encoder.layer_2, "num_layers", 1) == 1)
         all_list = self.all_embeds_batched(wb, per_graph, hist) if batched else None
+        if batched:
+            cache = getattr(wb, "_loss_inputs", None)
+            if cache is None or cache[0] is not samples:          # index tensors are static for a given sample set
+                offs = np.concatenate([[0], np.cumsum(wb.target.sizes)])[:-1]
+                cache = wb._loss_inputs = (samples, self.loss_inputs([int(o) for o in offs], samples, dev))
+            fused = self.batched_link_prediction(out, cache[1], all_list)
+            if fused is not None:
+                return fused
         loss = 0
         for i, (g, ent_embed) in enumerate(zip(wb.graphs, per_graph)):
             t = wb.rows[i][-1]

@@ -177,6 +177,37 @@ class _CandidateCEFn(torch.autograd.Function):
         return d_query, d_all, None
 
 
+class _BatchedCandidateCEFn(torch.autograd.Function):
+    """sum_b mean_{rows of window b} CE(query[p] . all_embeds_b[cand[p, :]]^T, label 0): the row-wise work (candidate CE
+    forward / backward) runs once over ALL windows' rows; only the three GEMMs are per window, because every window scores
+    against its own all-entity matrix."""
+
+    @staticmethod
+    def forward(ctx, query, cand, splits, row_w, *all_embeds):
+        be = get_backend()
+        scores = torch.cat([be.linear(query[a:b], e, True) for (a, b), e in zip(splits, all_embeds)], dim=0)    # (sum P, N)
+        loss_rows, lse = be.gather_ce_fwd(scores, cand)
+        ctx.save_for_backward(query, scores, lse, cand, row_w, *all_embeds)
+        ctx.splits = splits
+        return (loss_rows * row_w).sum()
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        query, scores, lse, cand, row_w = ctx.saved_tensors[:5]
+        all_embeds = ctx.saved_tensors[5:]
+        be = get_backend()
+        d_scores = be.gather_ce_bwd(scores, cand, lse, d_loss.reshape(1).contiguous(), 1.0, row_w)
+        d_query = torch.cat([be.linear(d_scores[a:b], e, False) for (a, b), e in zip(ctx.splits, all_embeds)], dim=0)
+        d_all = tuple(be.linear_tn(d_scores[a:b], query[a:b]) for (a, b) in ctx.splits)
+        return (d_query, None, None, None) + d_all
+
+
+def candidate_cross_entropy_batched(query, cand, splits, row_w, all_embeds):
+    """query (R, D), cand (R, C) int32, splits = [(row_begin, row_end)] per window, row_w (R,) = weight of every row's loss
+    (1 / P_b for a mean per window and direction), all_embeds = list of (N, D) per window."""
+    return _BatchedCandidateCEFn.apply(query, cand, splits, row_w, *all_embeds)
+
+
 def candidate_cross_entropy(query, all_embeds, cand):
     """F.cross_entropy(score(query, all_embeds[cand]), 0) for scorers that are bilinear in
     (query, candidate) -- DistMult and ComplEx (utils/scores.py:4-44).  cand: int32 (P, C), column 0

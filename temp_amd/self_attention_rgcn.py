@@ -169,6 +169,13 @@ class SelfAttentionRGCN(DynamicRGCN):
         if samples is None:
             samples = self.draw_samples(wb)
         all_list = self.all_embeds_batched(wb, per_graph, tables)
+        cache = getattr(wb, "_loss_inputs", None)
+        if cache is None or cache[0] is not samples:
+            offs = np.concatenate([[0], np.cumsum(wb.target_sizes)])[:-1]
+            cache = wb._loss_inputs = (samples, self.loss_inputs([int(o) for o in offs], samples, dev))
+        fused = self.batched_link_prediction(out, cache[1], all_list)
+        if fused is not None:
+            return fused
         loss = 0
         for i, ent_embed in enumerate(per_graph):
             triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])

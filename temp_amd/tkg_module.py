@@ -93,6 +93,47 @@ class TKG_Module(nn.Module):
         return (self.train_link_prediction(ent_embed, triplets, neg_tail, labels, all_embeds_g, corrupt_tail=True)
                 + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False))
 
+    @staticmethod
+    def loss_inputs(row_offsets, samples, dev):
+        """Index tensors of the batched loss for one set of samples (static for a prepared batch, so callers cache it):
+        per graph the stacked operand is [tail queries (P rows); head queries (P rows)]."""
+        known, rel, tail, cand, splits, weights = [], [], [], [], [], []
+        row = 0
+        for b, (trip, neg_tail, neg_head) in enumerate(samples):
+            P = trip.shape[0]
+            if P == 0:
+                splits.append((row, row))
+                continue
+            t = trip.to(dev)
+            known.append(torch.cat([t[:, 0], t[:, 2]]) + row_offsets[b])
+            rel.append(torch.cat([t[:, 1], t[:, 1]]))
+            tail.append(torch.cat([torch.ones(P, dtype=torch.bool, device=dev), torch.zeros(P, dtype=torch.bool, device=dev)]))
+            cand.append(neg_tail.to(dev)); cand.append(neg_head.to(dev))
+            splits.append((row, row + 2 * P))
+            weights.append(torch.full((2 * P,), 1.0 / P, dtype=torch.float32, device=dev))
+            row += 2 * P
+        if row == 0:
+            return None
+        return dict(known=torch.cat(known).to(torch.int32).contiguous(), rel=torch.cat(rel).to(torch.int32).contiguous(),
+                    is_tail=torch.cat(tail).view(-1, 1), cand=torch.cat(cand, dim=0).to(torch.int32).contiguous(), splits=splits,
+                    weights=torch.cat(weights))
+
+    def batched_link_prediction(self, ent_rows, inputs, all_embeds_list):
+        """Sum over the target graphs of loss_tail + loss_head (models/DynamicRGCN.py:186-193) with everything that is
+        row-wise done ONCE over all graphs' positives: `ent_rows` is the concatenation of the per-graph target embeddings,
+        `inputs` = loss_inputs(...).  Returns None when the scorer is not bilinear (caller takes the per-graph path)."""
+        name = self.args.score_function
+        if not (self.fused_loss and name in ("distmult", "complex") and all_embeds_list[0].shape[0] % 4 == 0):
+            return None
+        if inputs is None:
+            return ent_rows.sum() * 0.0
+        from . import functional as TF
+        known = TF.gather_rows(ent_rows, inputs["known"])
+        r = TF.gather_rows(self.rel_embeds, inputs["rel"])
+        q = torch.where(inputs["is_tail"], scores.bilinear_query(name, known, r, "tail"), scores.bilinear_query(name, known, r, "head"))
+        return TF.candidate_cross_entropy_batched(q.contiguous(), inputs["cand"], inputs["splits"], inputs["weights"],
+                                                  [e.contiguous() for e in all_embeds_list])
+
     def link_classification_loss(self, ent_embed, rel_embeds, triplets, labels):
         score = self.calc_score(ent_embed[triplets[:, 0]], rel_embeds[triplets[:, 1]], ent_embed[triplets[:, 2]])
         return F.binary_cross_entropy_with_logits(score, labels)

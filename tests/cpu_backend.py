@@ -232,12 +232,13 @@ class CpuTestBackend:
         lse = torch.logsumexp(logits, dim=1)
         return lse - logits[:, 0], lse
 
-    def gather_ce_bwd(self, scores, cand, lse, scale, inv_rows):
+    def gather_ce_bwd(self, scores, cand, lse, scale, inv_rows, row_scale=None):
         c = cand.long()
         g = torch.exp(scores.detach().gather(1, c) - lse.view(-1, 1))
         g[:, 0] -= 1.0
         d = torch.zeros_like(scores)
-        d.scatter_add_(1, c, g * (scale.reshape(-1)[0] * inv_rows))
+        w = scale.reshape(-1)[0] * (row_scale.view(-1, 1) if row_scale is not None else inv_rows)
+        d.scatter_add_(1, c, g * w)
         return d
 
     # ---- history attention (same sparse formulation as the kernel, dense torch ops) -------------------
