@@ -266,197 +266,6 @@ __global__ void __launch_bounds__(256) k_gru_fwd(GruFwdBatch batch, int D, float
   gru_cell_epilogue<VARIANT, HOISTED>(cell, D, plane, arow, arow_ok, prow, dec, j0, hh, acc_r, acc_z, acc_in, acc_hn);
 }
 
-// Weights-resident cell kernel (hoisted input gates only): the per-position launches of the window chain have
-// few rows (bsz * n), so the streaming kernel above spends its time re-staging W_hh chunk by chunk behind
-// barriers.  Here block role = (cell, 32-column group j): the block copies the three gate slices of W_hh for
-// its columns (96 x D floats, [col][k], row stride D+4 -> conflict-free ds_read_b128) into LDS ONCE, then
-// its waves take 32-row panels of that cell: the whole decayed A fragment (D/8 float4 per lane) is issued
-// up front, the D/2 x 3 MFMAs run without any barrier, and the gate epilogue follows.  blocks b, b+8, ...
-// share an XCD, so XCD x takes the x-th eighth of each cell's panels for all column groups.
-#define GRUR_MAXQ 32                       // D <= 256
-#define GRUR_LDS_BYTES (96 * (256 + 4) * 4)
-template <int VARIANT>
-__global__ void __launch_bounds__(256, 2) k_gru_fwd_res(GruFwdBatch batch, int count, int D, float lambda, const float* __restrict__ decay_wb,
-                                                         size_t plane, int bpr) {
-  extern __shared__ __attribute__((aligned(16))) float Wr[];
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int role = local / bpr, idx = local - role * bpr;
-  const int ncg = (D + 31) >> 5;
-  const int z = role / ncg, j0 = (role - z * ncg) * 32;
-  if (z >= count) return;
-  const GruFwdCell& cell = batch.c[z];
-  const int n = cell.n;
-  if (n <= 0) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hh = lane >> 5, li = lane & 31;
-  const int kpad = (D + 7) & ~7, ldk = kpad + (((kpad >> 2) & 1) ? 8 : 4), k4n = kpad >> 2;
-  {                                         // prologue: W_hh rows g*D + j0 + c  ->  Wr[(g*32 + c)][k]
-    const float* __restrict__ W = cell.w_hh;
-    const int total = 96 * k4n;
-    for (int base = threadIdx.x; base < total; base += 256 * 8) {
-      float4 v[8];
-      int dst[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int p = base + u * 256;
-        const int cg = p / k4n, k = (p - cg * k4n) * 4;
-        const int g = cg >> 5, c = cg & 31;
-        const bool ok = p < total && (j0 + c < D) && (k < D);
-        dst[u] = p < total ? cg * ldk + k : -1;
-        const float4 x = ld4(W + (ok ? (size_t)(g * D + j0 + c) * D + k : 0));
-        v[u] = ok ? x : zero4();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (dst[u] >= 0) st4(Wr + dst[u], v[u]);
-    }
-  }
-  __syncthreads();
-  const float* __restrict__ prev = cell.prev;
-  const int32_t* __restrict__ prev_idx = cell.prev_idx;
-  const float* __restrict__ dt = cell.dt;
-  const int panels = (n + 31) >> 5;
-  const int per_xcd = (panels + 7) >> 3;
-  const int p_end = min(panels, (xcd + 1) * per_xcd);
-  const int nq = kpad >> 3;
-  const float* wrow = Wr + (size_t)li * ldk + 4 * hh;
-  for (int panel = xcd * per_xcd + idx * 4 + wave; panel < p_end; panel += bpr * 4) {
-    const int arow = panel * 32 + li;
-    const bool arow_ok = arow < n;
-    int prow = -1;
-    float dec = 0.f;
-    if (arow_ok) {
-      prow = prev_idx ? prev_idx[arow] : arow;
-      dec = decay_factor(dt[arow], lambda, decay_wb);
-    }
-    const bool h_ok = arow_ok && prow >= 0;
-    const float* ha = prev + (size_t)(h_ok ? prow : 0) * D + 4 * hh;
-    float4 av[GRUR_MAXQ];
-#pragma unroll
-    for (int q = 0; q < GRUR_MAXQ; ++q) {
-      const bool ok = h_ok && q < nq && (q * 8 + 4 * hh < D);
-      av[q] = ld4(ha + (ok ? q * 8 : -4 * hh));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc_r, acc_z, acc_hn, acc_in;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_hn[r] = 0.f; acc_in[r] = 0.f; }
-#pragma unroll
-    for (int q = 0; q < GRUR_MAXQ; ++q) {
-      if (q < nq) {
-        const bool ok = h_ok && (q * 8 + 4 * hh < D);
-        const float4 a = ok ? scale4(av[q], dec) : zero4();
-        const float4 w0 = ld4(wrow + q * 8), w1 = ld4(wrow + (size_t)32 * ldk + q * 8), w2 = ld4(wrow + (size_t)64 * ldk + q * 8);
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, a.x, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, a.x, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.x, a.x, acc_hn, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, a.y, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, a.y, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.y, a.y, acc_hn, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, a.z, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, a.z, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.z, a.z, acc_hn, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, a.w, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, a.w, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.w, a.w, acc_hn, 0, 0, 0);
-      }
-    }
-    gru_cell_epilogue<VARIANT, true>(cell, D, plane, arow, arow_ok, prow, dec, j0, hh, acc_r, acc_z, acc_in, acc_hn);
-  }
-}
-
-// Panel-block cell kernel (hoisted input gates only).  One block = ONE 32-row panel of one cell; its
-// ceil(D/32) waves each own a 32-column group of all three gates.  The decayed previous-state rows of the
-// panel (gathered through prev_idx) are built ONCE per block in LDS ([row][k], stride D+4: conflict-free
-// ds_read_b128) instead of once per column group; the W_hh operand needs no staging at all: W_hh is stored
-// [3D][D], so lane (column li, k-half hh) reads one float4 of its own weight row per 4 MFMAs straight from
-// global memory (L2-resident, 480 KB), prefetched GRUP_PF q-steps ahead.  No prologue, one barrier.
-#define GRUP_PF 6
-template <int VARIANT>
-__global__ void __launch_bounds__(512) k_gru_fwd_pb(GruFwdBatch batch, int count, int D, float lambda, const float* __restrict__ decay_wb,
-                                                     size_t plane) {
-  extern __shared__ __attribute__((aligned(16))) float As[];
-  int z = 0, panel = blockIdx.x;
-  for (; z < count; ++z) {
-    const int np = (batch.c[z].n + 31) >> 5;
-    if (panel < np) break;
-    panel -= np;
-  }
-  if (z >= count) return;
-  const GruFwdCell& cell = batch.c[z];
-  const int n = cell.n;
-  const float* __restrict__ prev = cell.prev;
-  const int32_t* __restrict__ prev_idx = cell.prev_idx;
-  const float* __restrict__ dt = cell.dt;
-  const float* __restrict__ W = cell.w_hh;
-  const int kpad = (D + 7) & ~7, ldk = kpad + (((kpad >> 2) & 1) ? 8 : 4), k4n = kpad >> 2;
-  const int m0 = panel * 32;
-  // phase A: As[r][k] = dec(r) * prev[prev_idx[r]][k]  (zero rows for inactive / out-of-range)
-  for (int p = threadIdx.x; p < 32 * k4n; p += blockDim.x) {
-    const int r = p / k4n, k = (p - r * k4n) * 4;
-    const int row = m0 + r;
-    float4 v = zero4();
-    if (row < n && k < D) {
-      const int pr = prev_idx ? prev_idx[row] : row;
-      if (pr >= 0) v = scale4(ld4(prev + (size_t)pr * D + k), decay_factor(dt[row], lambda, decay_wb));
-    }
-    st4(As + (size_t)r * ldk + k, v);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hh = lane >> 5, li = lane & 31;
-  const int j0 = wave * 32;
-  if (j0 >= D) return;
-  const int nq = kpad >> 3;
-  const bool col_ok = j0 + li < D;
-  const float* w0p = W + (size_t)(col_ok ? j0 + li : 0) * D + 4 * hh;
-  const float* w1p = w0p + (size_t)D * D;
-  const float* w2p = w1p + (size_t)D * D;
-  const float* arow_p = As + (size_t)li * ldk + 4 * hh;
-  f32x16 acc_r, acc_z, acc_hn, acc_in;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_hn[r] = 0.f; acc_in[r] = 0.f; }
-  float4 w0[GRUP_PF], w1[GRUP_PF], w2[GRUP_PF];
-  auto kofs = [&](int q) { return (q < nq && (q * 8 + 4 * hh < D)) ? q * 8 : -4 * hh; };   // out of range: re-read k = 0..3, zeroed at use
-#pragma unroll
-  for (int q = 0; q < GRUP_PF; ++q) { const int o = kofs(q); w0[q] = ld4(w0p + o); w1[q] = ld4(w1p + o); w2[q] = ld4(w2p + o); }
-  for (int qb = 0; qb < nq; qb += GRUP_PF) {
-#pragma unroll
-    for (int u = 0; u < GRUP_PF; ++u) {
-      const int q = qb + u;
-      const bool ok = col_ok && q < nq && (q * 8 + 4 * hh < D);
-      const float4 a = ld4(arow_p + (q < nq ? q * 8 : 0));
-      const float4 x0 = ok ? w0[u] : zero4(), x1 = ok ? w1[u] : zero4(), x2 = ok ? w2[u] : zero4();
-      const int o = kofs(q + GRUP_PF);
-      w0[u] = ld4(w0p + o); w1[u] = ld4(w1p + o); w2[u] = ld4(w2p + o);          // refill the slot for q + GRUP_PF
-      if (q < nq) {
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, a.x, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, a.x, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, a.x, acc_hn, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, a.y, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, a.y, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, a.y, acc_hn, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, a.z, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, a.z, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.z, a.z, acc_hn, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, a.w, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, a.w, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.w, a.w, acc_hn, 0, 0, 0);
-      }
-    }
-  }
-  const int arow = m0 + li;
-  const bool arow_ok = arow < n;
-  int prow = -1;
-  float dec = 0.f;
-  if (arow_ok) {
-    prow = prev_idx ? prev_idx[arow] : arow;
-    dec = decay_factor(dt[arow], lambda, decay_wb);
-  }
-  gru_cell_epilogue<VARIANT, true>(cell, D, plane, arow, arow_ok, prow, dec, j0, hh, acc_r, acc_z, acc_in, acc_hn);
-}
-
 // Grouped epilogue of the weights-resident GEMM (gemm_wres.hpp, GRU mode): the recurrent half of a cell,
 //   acc[g] = prev[prev_idx[row]] . W_hh[g]^T   (UNdecayed: the per-row decay commutes with the product),
 // finished into gates / new state exactly like gru_cell_epilogue.  Its own operands (hoisted input gates,
@@ -686,47 +495,12 @@ static int launch_gru_fwd_batch(const GruFwdBatch& batch, int count, int d, int 
   int max_n = 0;
   for (int i = 0; i < count; ++i) if (batch.c[i].n > max_n) max_n = batch.c[i].n;
   if (max_n <= 0) return TEMP_OK;
-  static const bool res_off = [] { const char* e = getenv("TEMP_GRU_STREAM"); return e && e[0] == '1'; }();
-  static const int pb_mode = [] { const char* e = getenv("TEMP_GRU_PB"); return e ? atoi(e) : 2; }();
-  if (hoisted && d % 8 == 0 && !res_off && pb_mode == 2) {
+  static const bool stream_only = [] { const char* e = getenv("TEMP_GRU_STREAM"); return e && e[0] == '1'; }();   // A/B switch
+  if (hoisted && d % 8 == 0 && !stream_only) {
+    // window-chain cells: weights-resident GEMM with the grouped gate epilogue (EpiGruCell)
     int rc = (variant == TEMP_GRU_TORCH) ? launch_gru_fwd_wres<TEMP_GRU_TORCH>(batch, count, d, lambda, decay_wb, plane, st)
                                          : launch_gru_fwd_wres<TEMP_GRU_TYPE1>(batch, count, d, lambda, decay_wb, plane, st);
     if (rc != TEMP_E_UNSUPPORTED) return rc;
-  }
-  if (hoisted && d <= 256 && d % 8 == 0 && !res_off && pb_mode == 1) {
-    int panels = 0;
-    for (int i = 0; i < count; ++i) panels += ceil_div(batch.c[i].n > 0 ? batch.c[i].n : 0, 32);
-    const int waves = ceil_div(d, 32);
-    const int kp = (d + 7) & ~7;
-    const size_t lds = (size_t)32 * (kp + 8) * 4;
-    if (variant == TEMP_GRU_TORCH)
-      TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_pb<TEMP_GRU_TORCH>), dim3(panels), dim3(waves * 64), lds, st, batch, count, d, lambda, decay_wb, plane);
-    else
-      TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_pb<TEMP_GRU_TYPE1>), dim3(panels), dim3(waves * 64), lds, st, batch, count, d, lambda, decay_wb, plane);
-    return launch_status();
-  }
-  if (hoisted && d <= 256 && d % 8 == 0 && !res_off) {
-    // weights-resident variant: roles = (cell, 32-column group); 64 block slots per XCD shared by the roles
-    const int roles = count * ceil_div(d, 32);
-    int bpr = 64 / roles;
-    const int need = ceil_div(ceil_div(ceil_div(max_n, 32), 8), 4);        // blocks that still get a panel per XCD
-    if (bpr > need) bpr = need;
-    static const int bpr_force = [] { const char* e = getenv("TEMP_GRU_BPR"); return e ? atoi(e) : 0; }();
-    if (bpr_force > 0) bpr = bpr_force;
-    if (bpr >= 1) {
-      const size_t lds = (size_t)96 * (((d + 7) & ~7) + 8) * 4;
-      static bool attr[2] = {false, false};
-      const int vi = variant == TEMP_GRU_TORCH ? 0 : 1;
-      const void* fn = vi == 0 ? (const void*)k_gru_fwd_res<TEMP_GRU_TORCH> : (const void*)k_gru_fwd_res<TEMP_GRU_TYPE1>;
-      if (!attr[vi]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GRUR_LDS_BYTES) != hipSuccess) return TEMP_E_LAUNCH;
-        attr[vi] = true;
-      }
-      const dim3 g(roles * bpr * 8);
-      if (vi == 0) TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_res<TEMP_GRU_TORCH>), g, dim3(256), lds, st, batch, count, d, lambda, decay_wb, plane, bpr);
-      else TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd_res<TEMP_GRU_TYPE1>), g, dim3(256), lds, st, batch, count, d, lambda, decay_wb, plane, bpr);
-      return launch_status();
-    }
   }
   dim3 grid(ceil_div(max_n, 128), ceil_div(d, 32), count);
 #define TEMP_GRU_FWD(V, H) TEMP_LAUNCH(K_GRU_FWD, (k_gru_fwd<V, H>), grid, dim3(256), 0, st, batch, d, lambda, decay_wb, plane)
