@@ -273,6 +273,12 @@ __global__ void __launch_bounds__(256) k_gru_fwd(GruFwdBatch batch, int D, float
 template <int VARIANT>
 struct EpiGruCell {
   GruFwdCell cell; int D; size_t plane; float lambda; const float* decay_wb;
+  unsigned long long* dbg = nullptr;        // tools/wres_probe.hip only: per-wave s_memtime stamps (VAR bit 3 of the kernel)
+  __device__ __forceinline__ void stamp(int k, unsigned long long t) const {
+    if ((threadIdx.x & 63) != 0 || !dbg) return;
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    if (d[k] == 0) d[k] = t;
+  }
   struct RowCtx {};
   __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
   __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }

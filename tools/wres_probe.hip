@@ -2,13 +2,13 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Itemp_amd/csrc tools/wres_probe.hip -o tools/wres_probe
 #include "common.hpp"
 #include "gemm_wres.hpp"
+#include "../temp_amd/csrc/gemm_kernels.hip"
+#include "../temp_amd/csrc/gru_kernels.hip"
 #include <cstdio>
 #include <vector>
 using namespace temp;
 static unsigned long long* DBG = nullptr;
 
-int temp::trace_open(int, hipStream_t) { return -1; }
-void temp::trace_close(int, hipStream_t) {}
 
 struct EpiP {
   float* out; int ldo;
@@ -95,6 +95,57 @@ static void timeline(const char* name, int M, int N, int K, const float* A, cons
   hipFree(d);
 }
 
+static void gru_timeline(int n, int D) {
+  // one window-chain level: 2 cells of n rows, hoisted gi, previous state gathered through an identity map
+  typedef EpiGruCell<TEMP_GRU_TORCH> Epi;
+  const int cells = 2;
+  float *gi, *prev, *W, *bh, *dt, *H, *saved;
+  int32_t* idx;
+  hipMalloc(&gi, (size_t)cells * n * 3 * D * 4); hipMalloc(&prev, (size_t)cells * n * D * 4); hipMalloc(&W, (size_t)cells * 3 * D * D * 4);
+  hipMalloc(&bh, 3 * D * 4); hipMalloc(&dt, (size_t)n * 4); hipMalloc(&H, (size_t)cells * n * D * 4); hipMalloc(&saved, (size_t)5 * cells * n * D * 4);
+  hipMalloc(&idx, (size_t)n * 4);
+  hipMemset(gi, 0, (size_t)cells * n * 3 * D * 4); hipMemset(prev, 0, (size_t)cells * n * D * 4); hipMemset(W, 0, (size_t)cells * 3 * D * D * 4);
+  hipMemset(bh, 0, 3 * D * 4); hipMemset(dt, 0, (size_t)n * 4);
+  std::vector<int32_t> hi(n);
+  for (int i = 0; i < n; ++i) hi[i] = i;
+  hipMemcpy(idx, hi.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+  WresGeom g;
+  wres_plan(3 * D, D, D, D, 1, 1 << 20, &g);
+  g.tps = 3; g.n_slices = (D + 31) / 32; g.tail_store = 3; g.gate_stride = D; g.split = 1;
+  const int roles = g.n_slices * cells, bps = 64 / roles, nblk = roles * bps * 8, nw = nblk * 4;
+  unsigned long long* d;
+  hipMalloc(&d, (size_t)nw * 64);
+  PanelBatch<Epi> pb;
+  const size_t plane = (size_t)cells * n * D;
+  for (int i = 0; i < PANEL_MAXP; ++i) {
+    const int c = i < cells ? i : 0;
+    GruFwdCell cell{i < cells ? n : 0, nullptr, gi + (size_t)c * n * 3 * D, prev + (size_t)c * n * D, idx, dt, nullptr, W + (size_t)c * 3 * D * D, nullptr, bh,
+                    H + (size_t)c * n * D, saved + (size_t)c * n * D};
+    Epi e{cell, D, plane, 0.1f, nullptr};
+    e.dbg = d;
+    pb.p[i] = PanelProblem<Epi>{cell.n, cell.prev, cell.prev_idx, cell.w_hh, e};
+  }
+  hipFuncSetAttribute((const void*)k_gemm_wres<3, Epi, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
+  hipFuncSetAttribute((const void*)k_gemm_wres<3, Epi, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
+  const size_t lds = (size_t)96 * g.ldk * 4;
+  float ms = time_ms([&] { hipLaunchKernelGGL((k_gemm_wres<3, Epi, 0>), dim3(nblk), dim3(256), lds, 0, pb, cells, g, bps); });
+  hipMemset(d, 0, (size_t)nw * 64);
+  hipLaunchKernelGGL((k_gemm_wres<3, Epi, 8>), dim3(nblk), dim3(256), lds, 0, pb, cells, g, bps);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h((size_t)nw * 8);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  const char* lab[5] = {"prologue", "panel 1: A latency + MFMAs", "panel 1: gate epilogue", "rest", "whole wave"};
+  double sum[5] = {0}, mx[5] = {0};
+  int cnt[5] = {0};
+  auto add = [&](int k, unsigned long long a, unsigned long long b) { if (a && b && b >= a) { const double v = (double)(b - a); sum[k] += v; if (v > mx[k]) mx[k] = v; cnt[k]++; } };
+  for (int w = 0; w < nw; ++w) {
+    const unsigned long long* t = &h[(size_t)w * 8];
+    add(0, t[0], t[1]); add(1, t[1], t[2]); add(2, t[2], t[3]); add(3, t[3], t[4]); add(4, t[0], t[4]);
+  }
+  printf("GRU cell level: %d cells x %d rows, D=%d, %d blocks: kernel %.1f us; s_memtime ticks per wave (avg / max)\n", cells, n, D, nblk, ms * 1e3);
+  for (int k = 0; k < 5; ++k) printf("   %-32s avg %9.0f  max %9.0f  (n=%d)\n", lab[k], cnt[k] ? sum[k] / cnt[k] : 0.0, mx[k], cnt[k]);
+}
+
 int main() {
   const int MM = 120000;
   float *A, *B, *C;
@@ -103,6 +154,7 @@ int main() {
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
   hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)600 * 600 * 4, hipMemcpyHostToDevice);
+  gru_timeline(4000, 200);
   timeline<3>("gi-shape 2blk/CU", 8000, 600, 200, A, B, C, 1, 2);
   timeline<3>("gi-shape 1blk/CU", 8000, 600, 200, A, B, C, 1, 1);
   timeline<3>("gi-shape 2blk/CU", 120000, 600, 200, A, B, C, 1, 2);
