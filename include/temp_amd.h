@@ -64,7 +64,7 @@ const char* temp_error_string(int code);
  *                one segment are consecutive and are summed in order => deterministic).
  * ---------------------------------------------------------------------------------------------- */
 #define TEMP_CHUNK 64
-#define TEMP_CHUNK_REL 256
+#define TEMP_CHUNK_REL 128
 
 typedef struct TempEdgeView {
   int32_t n_seg;            /* number of segments (nodes, or relation rows)                        */

@@ -16,7 +16,7 @@ c_vp = ctypes.c_void_p
 ACT_NONE, ACT_RELU = 0, 1
 GRU_TORCH, GRU_TYPE1 = 0, 1
 CHUNK = 64
-CHUNK_REL = 256
+CHUNK_REL = 128
 
 
 class TempEdgeView(ctypes.Structure):
