@@ -383,3 +383,38 @@ def test_forward_with_device_sampler_end_to_end_gpu():
     assert {"ent_embeds", "rel_embeds", "ent_encoder.layer_1.weight", "ent_encoder.layer_2.forward_rnn.weight_hh_l0"} <= set(grads)
     assert all(torch.isfinite(g).all() for g in grads.values())
     assert m._dev_corrupter.device.type == "cuda"
+
+
+def test_full_size_step_properties_gpu():
+    """BASELINE's full headline size (S-gdelt: 8 windows x 29 positions x 7 475 edges, D = 200), where the oracle is far too
+    slow: size-independent properties instead --
+      * the restructured step (distinct snapshots once, table layer, one GRU program, segment-sum adjoints) equals the
+        reference-granular path (one encoder call per window position through the drop-in BiRRGCN API) on the same draws,
+      * with and without snapshot de-duplication,
+      * bitwise repeatable."""
+    import bench
+    from temp_amd import synthetic
+    w = synthetic.workload("S-gdelt", seed=0)
+    model = bench.build_model(w, DEV)
+    targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)
+
+    def run(batched, dedup):
+        model.use_batched_path, model.dedup_snapshots = batched, dedup
+        model.sample_rng = np.random.default_rng(2)
+        for p in model.parameters():
+            p.grad = None
+        wb = model.prepare(targets, w["L"], train=True)
+        out = model.run(wb)[0]
+        (out * out).sum().backward()
+        return out.detach().clone(), model.ent_embeds.grad.clone(), model.ent_encoder.layer_2.forward_rnn.weight_hh_l0.grad.clone()
+
+    a = run(True, True)
+    b = run(True, True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)), "step is not bitwise repeatable"
+    c = run(True, False)
+    g = run(False, True)
+    for other, name in ((c, "no dedup"), (g, "reference-granular")):
+        assert_close(other[0], a[0], 2e-5, 2e-6, "target embeddings vs " + name)
+        assert_close(other[1], a[1], 1e-4, 1e-4 * float(a[1].abs().max()), "d ent_embeds vs " + name)
+        assert_close(other[2], a[2], 1e-4, 1e-4 * float(a[2].abs().max()), "d W_hh vs " + name)
+    model.use_batched_path, model.dedup_snapshots = True, True
