@@ -273,38 +273,62 @@ class DynamicRGCN(TKG_Module):
         return [c.single_graph_negative_sampling(wb.rows[i][-1], g, self.num_ents)[:3] for i, g in enumerate(wb.graphs)]
 
     def _all_maps(self, wb):
-        """Row maps / time gaps of ALL entities for every window of the batch, concatenated
-        (bsz * N_ents), cached on the batch: inputs of the batched isolated pass."""
+        """Inputs of the batched isolated pass, cached on the batch.  Only the entities that are NOT nodes of a window's
+        target graph need it (the active rows are overwritten by the graph convolution's output, models/DynamicRGCN.py:60-63):
+        per chain plan the previous-state row map / time gap of those entities, concatenated over the windows, and ONE
+        row map that assembles every window's (N_ents, D) matrix from [target rows ; isolated rows]."""
         if getattr(wb, "all_maps", None) is None:
             dev = self._device()
+            N = self.num_ents
             plans = wb.plan if isinstance(wb.plan, tuple) else (wb.plan,)
             L = plans[0].seq_len
+            inact = [np.setdiff1d(np.arange(N, dtype=np.int64), g.gids) for g in wb.graphs]
             maps = []
             for plan in plans:
-                idx = np.concatenate([plan.final_all(b, L - 1)[0] for b in range(plan.bsz)]).astype(np.int32)
-                dt = np.concatenate([plan.final_all(b, L - 1)[1] for b in range(plan.bsz)]).astype(np.float32)
+                idx = np.concatenate([plan.final_all(b, L - 1)[0][inact[b]] for b in range(plan.bsz)]).astype(np.int32)
+                dt = np.concatenate([plan.final_all(b, L - 1)[1][inact[b]] for b in range(plan.bsz)]).astype(np.float32)
                 maps.append((torch.from_numpy(idx).to(dev), torch.from_numpy(dt).view(-1, 1).to(dev)))
             wb.all_maps = maps
-            wb.gid_dev = [torch.from_numpy(g.gids).to(dev) for g in wb.graphs]
+            sizes = [g.n for g in wb.graphs]
+            n_out = int(sum(sizes))
+            off_out = np.concatenate([[0], np.cumsum(sizes)])
+            off_in = np.concatenate([[0], np.cumsum([len(x) for x in inact])])
+            asm = np.empty((len(wb.graphs), N), dtype=np.int64)
+            for b, g in enumerate(wb.graphs):
+                asm[b, g.gids] = off_out[b] + np.arange(g.n)
+                asm[b, inact[b]] = n_out + off_in[b] + np.arange(len(inact[b]))
+            wb.inactive_ent = torch.from_numpy(np.concatenate(inact).astype(np.int32)).to(dev)
+            wb.n_inactive = int(off_in[-1])
+            wb.assemble = torch.from_numpy(asm.reshape(-1).astype(np.int32)).to(dev)
+            wb.assemble_inv = TF.gather_inverse(asm.reshape(-1), n_out + wb.n_inactive, dev)
+            wb.inactive_inv = TF.gather_inverse(np.concatenate(inact), N, dev)
         return wb.all_maps
 
-    def all_embeds_batched(self, wb, per_graph, hist):
-        """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64): with only the last
-        layer recurrent the isolated RGCN trunk e -> Iso2(Iso1(e)) is the same for every window, so it
-        runs ONCE over the N_ents entities; the GRU then runs once over bsz * N_ents rows, each window
-        reading its own previous states through its row map.  Returns a list of (N_ents, D)."""
+    def _assemble_all(self, wb, out, isolated):
+        """-> list of per-window (N_ents, D) views: active rows from `out` (concatenated target rows), the rest from the
+        isolated pass (None when every entity is active in its window's target graph)."""
+        src = out if isolated is None else torch.cat([out, isolated], dim=0)
+        big = TF.gather_rows(src, wb.assemble, wb.assemble_inv)
+        N = self.num_ents
+        return [big[b * N:(b + 1) * N] for b in range(len(wb.graphs))]
+
+    def all_embeds_batched(self, wb, out, hist):
+        """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64): with only the last layer recurrent the
+        isolated RGCN trunk e -> Iso2(Iso1(e)) is the same for every window, so it runs ONCE over the N_ents entities; the
+        GRU then runs once over the inactive entities of all windows, each window reading its own previous states through its
+        row map.  `out` = the concatenated target rows of the encoder.  Returns a list of (N_ents, D)."""
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
-        bsz = len(per_graph)
         (idx, dt), = self._all_maps(wb)
+        if wb.n_inactive == 0:
+            return self._assemble_all(wb, out, None)
         y1 = l1.conv_isolated(self.ent_embeds)
-        x = l2.conv_isolated(y1).repeat(bsz, 1)
+        x = TF.gather_rows(l2.conv_isolated(y1), wb.inactive_ent, wb.inactive_inv)
         H = hist[1]
         prev = H if H is not None else x.new_zeros(1, x.shape[1])
         pidx = idx if H is not None else torch.full_like(idx, -1)
         allh = run_rnn(l2.rnn, x, prev, dt, l2.inv_temperature, l2.decay_spec(), pidx)
-        N = self.num_ents
-        return [allh[b * N:(b + 1) * N].index_copy(0, wb.gid_dev[b], per_graph[b]) for b in range(bsz)]
+        return self._assemble_all(wb, out, allh)
 
     def run_loss(self, wb, samples=None):
         """Encoder pass + the per-window link-prediction losses (summed, as the reference does)."""
@@ -315,7 +339,7 @@ class DynamicRGCN(TKG_Module):
             samples = self.draw_samples(wb)
         batched = (wb.batched and not self.ent_encoder.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
                    and getattr(self.ent_encoder.layer_2, "num_layers", 1) == 1)
-        all_list = self.all_embeds_batched(wb, per_graph, hist) if batched else None
+        all_list = self.all_embeds_batched(wb, out, hist) if batched else None
         if batched:
             cache = getattr(wb, "_loss_inputs", None)
             if cache is None or cache[0] is not samples:          # index tensors are static for a given sample set

@@ -97,15 +97,30 @@ class SelfAttentionRGCN(DynamicRGCN):
         time_rows = np.repeat(np.array(hist_ts + wb.target_times, dtype=np.int64), [g.n for g in all_graphs])
         wb.time_rows = as_dev(time_rows, np.int32)
         wb.time_inv = TF.gather_inverse(time_rows, len(self.total_time), dev)
-        idx_tgt_np, idx_all_np = np.concatenate(idx_tgt, axis=0), np.concatenate(idx_all, axis=0)
+        # the isolated (all-entity) pass is only needed for the entities that are NOT nodes of a window's target graph
+        inact = [np.setdiff1d(np.arange(N, dtype=np.int64), g.gids) for g in wb.graphs]
+        idx_tgt_np = np.concatenate(idx_tgt, axis=0)
+        idx_all_np = np.concatenate([idx_all[b][inact[b]] for b in range(len(idx_all))], axis=0)
         wb.idx_tgt = as_dev(idx_tgt_np, np.int32)
         wb.idx_all = as_dev(idx_all_np, np.int32)
         wb.inv_tgt = TF.attention_inverse(idx_tgt_np, off, dev) if off > 0 and idx_tgt_np.shape[1] > 0 else None
-        wb.inv_all = TF.attention_inverse(idx_all_np, off, dev) if off > 0 and idx_all_np.shape[1] > 0 else None
-        all_time_rows = np.repeat(np.array(wb.target_times, dtype=np.int64), N)
+        wb.inv_all = TF.attention_inverse(idx_all_np, off, dev) if off > 0 and idx_all_np.shape[1] > 0 and idx_all_np.shape[0] > 0 else None
+        all_time_rows = np.repeat(np.array(wb.target_times, dtype=np.int64), [len(x) for x in inact])
         wb.all_time_rows = as_dev(all_time_rows, np.int32)
         wb.all_time_inv = TF.gather_inverse(all_time_rows, len(self.total_time), dev)
-        wb.gid_dev = [torch.from_numpy(g.gids).to(dev) for g in wb.graphs]
+        sizes = [g.n for g in wb.graphs]
+        n_out = int(sum(sizes))
+        off_out = np.concatenate([[0], np.cumsum(sizes)])
+        off_in = np.concatenate([[0], np.cumsum([len(x) for x in inact])])
+        asm = np.empty((len(wb.graphs), N), dtype=np.int64)
+        for b, g in enumerate(wb.graphs):
+            asm[b, g.gids] = off_out[b] + np.arange(g.n)
+            asm[b, inact[b]] = n_out + off_in[b] + np.arange(len(inact[b]))
+        wb.inactive_ent = as_dev(np.concatenate(inact), np.int32)
+        wb.n_inactive = int(off_in[-1])
+        wb.assemble = as_dev(asm.reshape(-1), np.int32)
+        wb.assemble_inv = TF.gather_inverse(asm.reshape(-1), n_out + wb.n_inactive, dev)
+        wb.inactive_inv = TF.gather_inverse(np.concatenate(inact), N, dev)
         wb.time_diff = self.time_diff_train if seq_len == self.train_seq_len else self._time_diff(seq_len).to(dev)
         wb.batched = True
         wb.n_edge_visits = int(sum(self.graph_dict_train[t].number_of_edges() for times in wb.hist_times for t in times if t is not None)
@@ -133,29 +148,28 @@ class SelfAttentionRGCN(DynamicRGCN):
         first = l1.attend(f[R:], kv1, wb.idx_tgt, wb.time_diff, wb.inv_tgt)
         return jk_max(first, second), (kv1, kv2)
 
-    def all_embeds_batched(self, wb, per_graph, tables):
+    def all_embeds_batched(self, wb, out, tables):
         """get_all_embeds_Gt for every window at once (models/SelfAttentionRGCN.py:28-45 with
-        SARGCN.forward_isolated, models/SARGCN.py:119-125) -> list of (N_ents, D)."""
+        SARGCN.forward_isolated, models/SARGCN.py:119-125) -> list of (N_ents, D).  `out` = the concatenated target rows;
+        the isolated pass runs only over the entities that are inactive in their window's target graph."""
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
-        N, bsz = self.num_ents, len(per_graph)
+        if wb.n_inactive == 0:
+            return self._assemble_all(wb, out, None)
         if getattr(self.args, "use_embed_for_non_active", False):
-            alls = [self.ent_embeds] * bsz
+            return self._assemble_all(wb, out, TF.gather_rows(self.ent_embeds, wb.inactive_ent, wb.inactive_inv))
+        kv1, kv2 = tables
+        y1 = l1.conv_isolated(self.ent_embeds)
+        if enc.rec_only_last_layer:
+            y2 = TF.gather_rows(l2.conv_isolated(y1), wb.inactive_ent, wb.inactive_inv)
+            first = None
         else:
-            kv1, kv2 = tables
-            y1 = l1.conv_isolated(self.ent_embeds)
-            if enc.rec_only_last_layer:
-                y2 = l2.conv_isolated(y1).repeat(bsz, 1)
-                first = None
-            else:
-                cur1 = y1.repeat(bsz, 1) + TF.gather_rows(l1.time_embed, wb.all_time_rows, wb.all_time_inv)
-                first = l1.attend(cur1, kv1, wb.idx_all, wb.time_diff, wb.inv_all)
-                y2 = l2.conv_isolated(first)
-            cur2 = y2 + TF.gather_rows(l2.time_embed, wb.all_time_rows, wb.all_time_inv)
-            second = l2.attend(cur2, kv2, wb.idx_all, wb.time_diff, wb.inv_all)
-            allh = second if first is None else jk_max(first, second)
-            alls = [allh[b * N:(b + 1) * N] for b in range(bsz)]
-        return [a.index_copy(0, wb.gid_dev[b], per_graph[b]) for b, a in enumerate(alls)]
+            cur1 = TF.gather_rows(y1, wb.inactive_ent, wb.inactive_inv) + TF.gather_rows(l1.time_embed, wb.all_time_rows, wb.all_time_inv)
+            first = l1.attend(cur1, kv1, wb.idx_all, wb.time_diff, wb.inv_all)
+            y2 = l2.conv_isolated(first)
+        cur2 = y2 + TF.gather_rows(l2.time_embed, wb.all_time_rows, wb.all_time_inv)
+        second = l2.attend(cur2, kv2, wb.idx_all, wb.time_diff, wb.inv_all)
+        return self._assemble_all(wb, out, second if first is None else jk_max(first, second))
 
     def encode(self, t_list, seq_len, train=True, target_edge_ids=None):
         wb = self.prepare(t_list, seq_len, train, target_edge_ids)
@@ -168,7 +182,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         per_graph = list(out.split(wb.target_sizes))
         if samples is None:
             samples = self.draw_samples(wb)
-        all_list = self.all_embeds_batched(wb, per_graph, tables)
+        all_list = self.all_embeds_batched(wb, out, tables)
         cache = getattr(wb, "_loss_inputs", None)
         if cache is None or cache[0] is not samples:
             offs = np.concatenate([[0], np.cumsum(wb.target_sizes)])[:-1]
@@ -192,7 +206,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         dev = self._device()
         with torch.no_grad():
             per_graph, wb, tables = self.encode(t_list, self.test_seq_len, train=False)
-            all_list = self.all_embeds_batched(wb, per_graph, tables)
+            all_list = self.all_embeds_batched(wb, torch.cat(per_graph, dim=0), tables)
             ranks, losses = [], []
             for i, ent_embed in enumerate(per_graph):
                 t = wb.rows[i][-1]

@@ -255,7 +255,7 @@ def check_sa_evaluate(name, device):
     assert ranks.numel() > 0 and int(ranks.min()) >= 1 and int(ranks.max()) <= s["num_e"] and np.isfinite(loss)
     with torch.no_grad():
         per_graph, wb, tables = m.encode(t_list, int(z["L"]), train=False)
-        all_list = m.all_embeds_batched(wb, per_graph, tables)
+        all_list = m.all_embeds_batched(wb, torch.cat(per_graph, dim=0), tables)
     from tests.test_oracle_golden import slice_graphs
     _, _, times, gd = slice_graphs()
     tl = sorted([int(t) for t in z["t_list"]], reverse=True)
