@@ -90,6 +90,33 @@ class Snapshot:
             self._views[n_rel_rows] = v
         return v
 
+    def device_views(self, device, n_rel_rows):
+        """The cached local views as int32 tensors resident on `device` (the snapshot store: uploaded once per snapshot)."""
+        key = ("views", str(device), int(n_rel_rows))
+        dv = self._dev.get(key)
+        if dv is None:
+            lv = self.local_views(n_rel_rows)
+            seg = lv["by_rel"]["chunk_seg"].astype(np.int64)
+            first = np.cumsum(lv["rel_chunks"]) - lv["rel_chunks"]
+            arrays = [((vn, an), lv[vn][an]) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS]
+            arrays += [("rel_rank", np.arange(seg.shape[0], dtype=np.int64) - first[seg]),        # rank of a chunk inside its relation
+                       ("in_deg", lv["in_deg"]), ("out_deg", lv["out_deg"])]
+            sizes = [int(a.shape[0]) for _, a in arrays]
+            packed = np.concatenate([np.ascontiguousarray(a, dtype=np.int32) for _, a in arrays]) if sum(sizes) else np.zeros(1, np.int32)
+            buf = torch.from_numpy(packed).to(device)                  # ONE upload per snapshot
+            dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": buf}
+            off = 0
+            for (key_, _), n_ in zip(arrays, sizes):
+                t = buf[off:off + n_]
+                off += n_
+                if isinstance(key_, tuple):
+                    dv[key_[0]][key_[1]] = t
+                else:
+                    dv[key_] = t
+            dv["nnorm"] = torch.from_numpy(self.nnorm).to(device)
+            self._dev[key] = dv
+        return dv
+
     def device_graph(self, device, n_rel_rows):
         key = (str(device), int(n_rel_rows))
         dg = self._dev.get(key)
@@ -287,6 +314,74 @@ def union_views(snap, n_rel_rows):
     return views, cat("in_deg"), cat("out_deg")
 
 
+DEVICE_STORE = True      # assemble union views on the GPU from per-snapshot device-resident views (no host concat, no H2D)
+
+
+def union_views_device(snap, n_rel_rows, device):
+    """Device-side union_views: the members' cached device views are concatenated and offset with a handful of torch
+    kernels; only per-member counts / offsets (a few KB) come from the host.  Returns (views: name -> {array -> tensor,
+    count -> int}, in_deg, out_deg, nnorm) or None when the by-relation view needs the global sort (few edges per relation)."""
+    E = int(snap.edge_off[-1])
+    if E // (REL_GROUP_EDGES * max(n_rel_rows, 1)) <= 1:
+        return None
+    lv = [g.local_views(n_rel_rows) for g in snap.parts]
+    dv = [g.device_views(device, n_rel_rows) for g in snap.parts]
+    i64 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.int64)).to(device)
+    node_off, edge_off = i64(snap.node_off[:-1]), i64(snap.edge_off[:-1])
+
+    def rep(vals, counts_np):
+        total = int(counts_np.sum())
+        return torch.repeat_interleave(vals, i64(counts_np), output_size=total)
+
+    def cat(vn, an):
+        return torch.cat([d[vn][an] for d in dv])
+
+    views = {}
+    for vn in ("by_dst", "by_src", "by_rel"):
+        vs = [l[vn] for l in lv]
+        e_cnt = np.array([v["n_edges"] for v in vs], dtype=np.int64)
+        c_cnt = np.array([v["n_chunks"] for v in vs], dtype=np.int64)
+        node_e, node_c, edge_c = rep(node_off, e_cnt), rep(node_off, c_cnt), rep(edge_off, c_cnt)
+        out = dict(n_edges=E, n_chunks=int(c_cnt.sum()))
+        out["a"] = (cat(vn, "a") + node_e).to(torch.int32)
+        out["chunk_beg"] = (cat(vn, "chunk_beg") + edge_c).to(torch.int32)
+        out["chunk_end"] = (cat(vn, "chunk_end") + edge_c).to(torch.int32)
+        if vn != "by_rel":
+            f_cnt = np.array([v["n_fix"] for v in vs], dtype=np.int64)
+            p_off = i64(np.concatenate([[0], np.cumsum([v["n_partial"] for v in vs])])[:-1])
+            out["b"] = cat(vn, "b")
+            out["chunk_seg"] = (cat(vn, "chunk_seg") + node_c).to(torch.int32)
+            slot = cat(vn, "chunk_slot").to(torch.int64)
+            out["chunk_slot"] = torch.where(slot >= 0, slot + rep(p_off, c_cnt), slot).to(torch.int32)
+            out["fix_seg"] = (cat(vn, "fix_seg") + rep(node_off, f_cnt)).to(torch.int32)
+            out["fix_slot"] = (cat(vn, "fix_slot") + rep(p_off, f_cnt)).to(torch.int32)
+            out["fix_cnt"] = cat(vn, "fix_cnt")
+            out["n_seg"], out["n_partial"], out["n_fix"] = int(snap.n), int(sum(v["n_partial"] for v in vs)), int(f_cnt.sum())
+        else:                                            # tile = member snapshot, see _concat_rel_views
+            counts = np.stack([l["rel_chunks"] for l in lv])
+            per_rel = counts.sum(axis=0)
+            multi = per_rel > 1
+            fix_seg = np.nonzero(multi)[0]
+            fix_cnt = per_rel[fix_seg]
+            fix_slot = np.cumsum(fix_cnt) - fix_cnt
+            base = np.full(n_rel_rows, -1, dtype=np.int64)
+            base[fix_seg] = fix_slot
+            table = np.where(multi[None, :], base[None, :] + (np.cumsum(counts, axis=0) - counts), -1)      # (members, rels)
+            seg = cat(vn, "chunk_seg").to(torch.int64)
+            tab = i64(table.reshape(-1))[rep(i64(np.arange(len(lv)) * n_rel_rows), c_cnt) + seg]
+            rank = torch.cat([d["rel_rank"] for d in dv]).to(torch.int64)
+            out["b"] = (cat(vn, "b") + node_e).to(torch.int32)
+            out["chunk_seg"] = seg.to(torch.int32)
+            out["chunk_slot"] = torch.where(tab >= 0, tab + rank, tab).to(torch.int32)
+            out["fix_seg"], out["fix_slot"], out["fix_cnt"] = (torch.from_numpy(x.astype(np.int32)).to(device) for x in (fix_seg, fix_slot, fix_cnt))
+            out["n_seg"], out["n_partial"], out["n_fix"] = int(n_rel_rows), int(per_rel[multi].sum()), int(fix_seg.shape[0])
+        views[vn] = out
+    in_deg = torch.cat([d["in_deg"] for d in dv])
+    out_deg = torch.cat([d["out_deg"] for d in dv])
+    nnorm = torch.cat([d["nnorm"] for d in dv])
+    return views, in_deg, out_deg, nnorm
+
+
 _VIEW_ARRAYS = ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")
 
 
@@ -296,6 +391,12 @@ class _DeviceGraph:
 
     def __init__(self, snap, device, n_rel_rows):
         n, E = snap.n, snap.number_of_edges()
+        device = torch.device(device)
+        if DEVICE_STORE and device.type == "cuda" and isinstance(snap, BatchedSnapshot) and len(snap.parts) > 1:
+            dev_union = union_views_device(snap, n_rel_rows, device)
+            if dev_union is not None:
+                self._init_from_device(dev_union, n, E, n_rel_rows, device)
+                return
         if isinstance(snap, BatchedSnapshot) and len(snap.parts) > 1:
             views, in_deg, out_deg = union_views(snap, n_rel_rows)
         else:
@@ -339,8 +440,32 @@ class _DeviceGraph:
         self.c = g
         self.offs = offs
 
+    def _init_from_device(self, dev_union, n, E, n_rel_rows, device):
+        views, self.in_deg, self.out_deg, self.nnorm = dev_union
+        self.views = views                          # arrays are DEVICE tensors here (host copies only exist on the CPU path)
+        self.ints = None
+        self.n_nodes, self.n_edges, self.n_rel_rows = n, E, n_rel_rows
+        self.device = device
+        g = _lib.TempGraph()
+        g.n_nodes, g.n_edges = n, E
+        g.nnorm = self.nnorm.data_ptr()
+        g.in_deg = self.in_deg.data_ptr()
+        g.out_deg = self.out_deg.data_ptr()
+        for vn, v in views.items():
+            ev = getattr(g, vn)
+            for fld in ("n_seg", "n_edges", "n_chunks", "n_partial", "n_fix"):
+                setattr(ev, fld, v[fld])
+            for an in _VIEW_ARRAYS:
+                t = v[an]
+                assert t.dtype == torch.int32 and t.is_contiguous()
+                setattr(ev, an, t.data_ptr() if t.numel() else 0)
+        self.c = g
+        self.offs = None
+
     def view_tensor(self, view, name):
         """Device int32 tensor of one view array (used by tests and the CPU test backend)."""
+        if self.offs is None:
+            return self.views[view][name]
         o = self.offs[(view, name)]
         return self.ints[o:o + self.views[view][name].shape[0]]
 

@@ -418,3 +418,25 @@ def test_full_size_step_properties_gpu():
         assert_close(other[1], a[1], 1e-4, 1e-4 * float(a[1].abs().max()), "d ent_embeds vs " + name)
         assert_close(other[2], a[2], 1e-4, 1e-4 * float(a[2].abs().max()), "d W_hh vs " + name)
     model.use_batched_path, model.dedup_snapshots = True, True
+
+
+def test_device_union_views_equal_host_union_gpu():
+    """Snapshot store: union views assembled on the GPU from per-snapshot resident views are identical, array by array,
+    to the host-assembled union (and to what a CPU device graph holds)."""
+    from temp_amd import snapshot as S
+    from temp_amd import synthetic
+    w = synthetic.workload("S-gdelt", seed=0)
+    parts = [w["snapshots"][t] for t in (3, 40, 7, 3 + 100, 12)]
+    parts.append(parts[1].edge_subgraph(np.arange(0, parts[1].number_of_edges(), 2)))        # a subsampled target graph
+    R2 = 2 * w["num_rels"]
+    g = S.batch(parts)
+    host_views, in_deg, out_deg = S.union_views(g, R2)
+    dg = g.device_graph(DEV, R2)
+    assert dg.offs is None, "device store path was not taken"
+    for vn, hv in host_views.items():
+        for k in ("n_seg", "n_edges", "n_chunks", "n_partial", "n_fix"):
+            assert dg.views[vn][k] == hv[k], (vn, k)
+        for an in S._VIEW_ARRAYS:
+            assert np.array_equal(dg.view_tensor(vn, an).cpu().numpy(), hv[an]), (vn, an)
+    assert np.array_equal(dg.in_deg.cpu().numpy(), in_deg) and np.array_equal(dg.out_deg.cpu().numpy(), out_deg)
+    assert np.array_equal(dg.nnorm.cpu().numpy(), g.nnorm)

@@ -17,7 +17,7 @@ w = synthetic.workload(sys.argv[1] if len(sys.argv) > 1 else "S-gdelt", seed=0)
 dev = torch.device("cuda:0")
 model = bench.build_model(w, dev)
 model.sample_rng = np.random.default_rng(2)
-for rep in range(3):
+for rep in range(12):
     targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rep)
     torch.cuda.synchronize()
     t0 = time.time()
@@ -26,7 +26,7 @@ for rep in range(3):
     print("prepare #%d: %.1f ms" % (rep, 1e3 * (time.time() - t0)))
 pr = cProfile.Profile()
 pr.enable()
-wb = model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 7), w["L"], train=True)
+wb = model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 3), w["L"], train=True)
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
