@@ -66,6 +66,15 @@ const char* temp_error_string(int code);
 #define TEMP_CHUNK 64
 #define TEMP_CHUNK_REL 128
 
+/* Dropout of the self-loop message (RGCNLayer.forward, models/RGCN.py:57-59; the reference's default --dropout is 0.1).
+ * The keep mask is a counter-based hash of (seed, node row, output column), so forward and backward regenerate the
+ * same mask and nothing is stored:  loop_message[row, col] *= (hash(seed, row, col) < p) ? 0 : 1 / (1 - p).
+ * A NULL TempDropout* (or p == 0) means no dropout. */
+typedef struct TempDropout {
+  float p;
+  uint64_t seed;
+} TempDropout;
+
 typedef struct TempEdgeView {
   int32_t n_seg;            /* number of segments (nodes, or relation rows)                        */
   int32_t n_edges;          /* E                                                                   */
@@ -111,7 +120,7 @@ size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out);
 int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids /*nullable*/,
                   int d_in, int d_out, int num_bases, int n_rel_rows,
                   const float* weight, const float* loop_w, const float* bias /*nullable*/, int act,
-                  float* out, void* workspace, size_t workspace_bytes, void* stream);
+                  float* out, void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream);
 
 /* Backward of the above (autograd of models/RGCN.py:53-104).
  *   d_h      [n_nodes, d_in]   written (not accumulated)
@@ -125,7 +134,7 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
                   int d_in, int d_out, int num_bases, int n_rel_rows,
                   const float* weight, const float* loop_w, int has_bias, int act,
                   float* d_h, float* d_weight, float* d_loop_w, float* d_bias /*nullable*/,
-                  void* workspace, size_t workspace_bytes, void* stream);
+                  void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Same layer when its input is a ROW GATHER of a table, h = table[ids]  (layer 1 of every TeMP encoder:
@@ -140,22 +149,22 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
 size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out);
 int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* ids, int n_table, int d_in, int d_out, int num_bases,
                         int n_rel_rows, const float* weight, const float* loop_w, const float* bias, int act, float* out, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        size_t workspace_bytes, const TempDropout* drop, void* stream);
 size_t temp_rgcn_table_bwd_workspace(const TempGraph* g, int n_table, int d_in, int d_out, int num_bases);
 int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* ids, const int32_t* inv_ptr, const int32_t* inv_order, int n_table,
                         const float* out, const float* d_out_grad, int d_in, int d_out, int num_bases, int n_rel_rows, const float* weight,
                         const float* loop_w, int has_bias, int act, float* d_table, float* d_weight, float* d_loop_w, float* d_bias,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream);
 
 /* Isolated-entity variant (RGCNLayer.forward_isolated, models/RGCN.py:78-89):
  *   out = act( e + e . loop_w [+ bias] )          e: [n, d]                                    */
 int temp_rgcn_isolated_fwd(int n, int d, const float* e, const float* loop_w, const float* bias /*nullable*/,
-                           int act, float* out, void* stream);
+                           int act, float* out, const TempDropout* drop, void* stream);
 size_t temp_rgcn_isolated_bwd_workspace(int n, int d);
 int temp_rgcn_isolated_bwd(int n, int d, const float* e, const float* out, const float* d_out_grad,
                            const float* loop_w, int has_bias, int act,
                            float* d_e, float* d_loop_w, float* d_bias /*nullable*/,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Recurrent update: decay of the previous state + one GRU step

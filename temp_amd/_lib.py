@@ -41,6 +41,10 @@ class TempGruCellBwd(ctypes.Structure):
                 ("w_hh", c_vp), ("dgi", c_vp), ("dgh", c_vp), ("decv", c_vp), ("d_prev", c_vp)]
 
 
+class TempDropout(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64)]
+
+
 class TempAttn(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("D", ctypes.c_int32), ("heads", ctypes.c_int32), ("T", ctypes.c_int32),
                 ("q", c_vp), ("ldq", ctypes.c_int32), ("kh", c_vp), ("vh", c_vp), ("ldh", ctypes.c_int32),
@@ -54,17 +58,17 @@ SYMBOLS = {
     "temp_abi_version": (_I, []),
     "temp_error_string": (ctypes.c_char_p, [_I]),
     "temp_rgcn_fwd_workspace": (_SZ, [_G, _I]),
-    "temp_rgcn_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp]),
+    "temp_rgcn_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_rgcn_bwd_workspace": (_SZ, [_G, _I, _I, _I, _I]),
-    "temp_rgcn_bwd": (_I, [_G, c_vp, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_rgcn_bwd": (_I, [_G, c_vp, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_rgcn_table_fwd_workspace": (_SZ, [_G, _I, _I]),
-    "temp_rgcn_table_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp]),
+    "temp_rgcn_table_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_rgcn_table_bwd_workspace": (_SZ, [_G, _I, _I, _I, _I]),
     "temp_rgcn_table_bwd": (_I, [_G, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp,
-                                 c_vp, _SZ, c_vp]),
-    "temp_rgcn_isolated_fwd": (_I, [_I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp]),
+                                 c_vp, _SZ, c_vp, c_vp]),
+    "temp_rgcn_isolated_fwd": (_I, [_I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, c_vp]),
     "temp_rgcn_isolated_bwd_workspace": (_SZ, [_I, _I]),
-    "temp_rgcn_isolated_bwd": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_rgcn_isolated_bwd": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_gru_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_bwd_workspace": (_SZ, [_I, _I, _I]),
     "temp_gru_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -53,6 +53,15 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _drop(drop):
+    """(p, seed) or None -> ctypes TempDropout by reference (NULL for no dropout)."""
+    if drop is None or drop[0] <= 0.0:
+        return None
+    d = _lib.TempDropout()
+    d.p, d.seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF
+    return ctypes.byref(d)
+
+
 class HipBackend:
     name = "hip"
 
@@ -63,7 +72,7 @@ class HipBackend:
         return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
     # ---- RGCN layer ----------------------------------------------------------------------------
-    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act):
+    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act, drop=None):
         h, weight, loop_w, bias = _f32(h, "h"), _f32(weight, "weight"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
         h_ids = _i32(h_ids, "h_ids")
         d_in, d_out = loop_w.shape
@@ -71,11 +80,11 @@ class HipBackend:
         nb = self.lib.temp_rgcn_fwd_workspace(dg.ref(), d_out)
         ws = self._ws(nb, h.device)
         rc = self.lib.temp_rgcn_fwd(dg.ref(), _ptr(h), _ptr(h_ids), d_in, d_out, num_bases, weight.shape[0], _ptr(weight),
-                                    _ptr(loop_w), _ptr(bias), act, _ptr(out), _ptr(ws), ws.numel(), _stream())
+                                    _ptr(loop_w), _ptr(bias), act, _ptr(out), _ptr(ws), ws.numel(), _drop(drop), _stream())
         _lib.check(rc, "temp_rgcn_fwd")
         return out
 
-    def rgcn_bwd(self, dg, h, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
+    def rgcn_bwd(self, dg, h, out, d_out_grad, weight, loop_w, has_bias, num_bases, act, drop=None):
         h, out, g = _f32(h, "h"), _f32(out, "out"), _f32(d_out_grad, "d_out")
         weight, loop_w = _f32(weight, "weight"), _f32(loop_w, "loop_weight")
         d_in, d_out = loop_w.shape
@@ -88,11 +97,11 @@ class HipBackend:
         ws = self._ws(nb, dev)
         rc = self.lib.temp_rgcn_bwd(dg.ref(), _ptr(h), _ptr(out), _ptr(g), d_in, d_out, num_bases, weight.shape[0], _ptr(weight),
                                     _ptr(loop_w), int(has_bias), act, _ptr(d_h), _ptr(d_w), _ptr(d_loop), _ptr(d_bias), _ptr(ws),
-                                    ws.numel(), _stream())
+                                    ws.numel(), _drop(drop), _stream())
         _lib.check(rc, "temp_rgcn_bwd")
         return d_h, d_w, d_loop, d_bias
 
-    def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act):
+    def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act, drop=None):
         """Layer on h = table[ids] without materialising h (include/temp_amd.h: temp_rgcn_table_fwd)."""
         table, weight, loop_w, bias = _f32(table, "table"), _f32(weight, "weight"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
         ids = _i32(ids, "ids")
@@ -100,11 +109,11 @@ class HipBackend:
         out = torch.empty(dg.n_nodes, d_out, dtype=torch.float32, device=table.device)
         ws = self._ws(self.lib.temp_rgcn_table_fwd_workspace(dg.ref(), table.shape[0], d_out), table.device)
         rc = self.lib.temp_rgcn_table_fwd(dg.ref(), _ptr(table), _ptr(ids), table.shape[0], d_in, d_out, num_bases, weight.shape[0],
-                                          _ptr(weight), _ptr(loop_w), _ptr(bias), act, _ptr(out), _ptr(ws), ws.numel(), _stream())
+                                          _ptr(weight), _ptr(loop_w), _ptr(bias), act, _ptr(out), _ptr(ws), ws.numel(), _drop(drop), _stream())
         _lib.check(rc, "temp_rgcn_table_fwd")
         return out
 
-    def rgcn_table_bwd(self, dg, table, ids, inverse, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
+    def rgcn_table_bwd(self, dg, table, ids, inverse, out, d_out_grad, weight, loop_w, has_bias, num_bases, act, drop=None):
         """-> (d_table [n_table, d_in] fully written, d_weight, d_loop_w, d_bias)."""
         table, out, g = _f32(table, "table"), _f32(out, "out"), _f32(d_out_grad, "d_out")
         weight, loop_w = _f32(weight, "weight"), _f32(loop_w, "loop_weight")
@@ -118,18 +127,18 @@ class HipBackend:
         ws = self._ws(self.lib.temp_rgcn_table_bwd_workspace(dg.ref(), table.shape[0], d_in, d_out, num_bases), dev)
         rc = self.lib.temp_rgcn_table_bwd(dg.ref(), _ptr(table), _ptr(ids), _ptr(inv_ptr), _ptr(inv_order), table.shape[0], _ptr(out), _ptr(g),
                                           d_in, d_out, num_bases, weight.shape[0], _ptr(weight), _ptr(loop_w), int(has_bias), act,
-                                          _ptr(d_table), _ptr(d_w), _ptr(d_loop), _ptr(d_bias), _ptr(ws), ws.numel(), _stream())
+                                          _ptr(d_table), _ptr(d_w), _ptr(d_loop), _ptr(d_bias), _ptr(ws), ws.numel(), _drop(drop), _stream())
         _lib.check(rc, "temp_rgcn_table_bwd")
         return d_table, d_w, d_loop, d_bias
 
-    def rgcn_isolated_fwd(self, e, loop_w, bias, act):
+    def rgcn_isolated_fwd(self, e, loop_w, bias, act, drop=None):
         e, loop_w, bias = _f32(e, "e"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
         out = torch.empty_like(e)
-        rc = self.lib.temp_rgcn_isolated_fwd(e.shape[0], e.shape[1], _ptr(e), _ptr(loop_w), _ptr(bias), act, _ptr(out), _stream())
+        rc = self.lib.temp_rgcn_isolated_fwd(e.shape[0], e.shape[1], _ptr(e), _ptr(loop_w), _ptr(bias), act, _ptr(out), _drop(drop), _stream())
         _lib.check(rc, "temp_rgcn_isolated_fwd")
         return out
 
-    def rgcn_isolated_bwd(self, e, out, d_out_grad, loop_w, has_bias, act):
+    def rgcn_isolated_bwd(self, e, out, d_out_grad, loop_w, has_bias, act, drop=None):
         e, out, g, loop_w = _f32(e, "e"), _f32(out, "out"), _f32(d_out_grad, "d_out"), _f32(loop_w, "loop_weight")
         n, d = e.shape
         d_e = torch.empty_like(e)
@@ -137,7 +146,7 @@ class HipBackend:
         d_bias = torch.empty(d, dtype=torch.float32, device=e.device) if has_bias else None
         ws = self._ws(self.lib.temp_rgcn_isolated_bwd_workspace(n, d), e.device)
         rc = self.lib.temp_rgcn_isolated_bwd(n, d, _ptr(e), _ptr(out), _ptr(g), _ptr(loop_w), int(has_bias), act, _ptr(d_e),
-                                             _ptr(d_loop), _ptr(d_bias), _ptr(ws), ws.numel(), _stream())
+                                             _ptr(d_loop), _ptr(d_bias), _ptr(ws), ws.numel(), _drop(drop), _stream())
         _lib.check(rc, "temp_rgcn_isolated_bwd")
         return d_e, d_loop, d_bias
 

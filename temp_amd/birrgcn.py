@@ -91,9 +91,8 @@ class BiRRGCNLayer(RGCNLayer):
         return out
 
     def _core(self, g, h):
-        self._check_dropout()
         dg = g.device_graph(h.device, self.num_rels)
-        return TF.rgcn_layer(h, dg, self.weight, self.loop_weight, None, self.num_bases, None)
+        return TF.rgcn_layer(h, dg, self.weight, self.loop_weight, None, self.num_bases, None, self._drop())
 
     def forward(self, g, prev_graph_embeds_forward, time_diff_tensor_forward, prev_graph_embeds_backward,
                 time_diff_tensor_backward, time_batched_list_t, node_sizes):
@@ -115,9 +114,8 @@ class BiRRGCNLayer(RGCNLayer):
 
     def forward_isolated(self, node_repr, prev_graph_embeds_forward, prev_graph_embeds_backward, time_diff_tensor_forward,
                          time_diff_tensor_backward, time):
-        self._check_dropout()
         lam = self.inv_temperature
-        pre = TF.rgcn_isolated(node_repr, self.loop_weight, None, None)
+        pre = TF.rgcn_isolated(node_repr, self.loop_weight, None, None, self._drop())
         pre = pre + torch.mm(prev_graph_embeds_forward * torch.exp(-time_diff_tensor_forward * lam), self.time_weight_forward)
         pre = pre + torch.mm(prev_graph_embeds_backward * torch.exp(-time_diff_tensor_backward * lam), self.time_weight_backward)
         return self._finish(pre), (self.time_embed[int(time)] if self.compute_time_embedding else None)

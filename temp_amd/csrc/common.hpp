@@ -45,6 +45,25 @@ __device__ __forceinline__ ItemRange xcd_items(int n_items, int per_block) {
   return r;
 }
 
+// Self-loop dropout (include/temp_amd.h: TempDropout): keep-scale of element (row, col), a counter-based hash so the
+// backward pass regenerates the forward mask.
+struct DropSpec { float p; float inv_keep; unsigned long long seed; };
+inline DropSpec drop_spec(const TempDropout* d) {
+  DropSpec s{0.f, 1.f, 0ull};
+  if (d && d->p > 0.f) { s.p = d->p; s.inv_keep = 1.f / (1.f - d->p); s.seed = d->seed; }
+  return s;
+}
+__device__ __forceinline__ float drop_scale(const DropSpec& d, unsigned row, unsigned col) {
+  unsigned long long x = d.seed ^ (((unsigned long long)row << 32) | col);
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  const float u = (float)(x >> 40) * (1.0f / 16777216.0f);
+  return u < d.p ? 0.f : d.inv_keep;
+}
+__device__ __forceinline__ float4 drop4(const DropSpec& d, unsigned row, unsigned col, float4 v) {
+  return make_float4(v.x * drop_scale(d, row, col), v.y * drop_scale(d, row, col + 1), v.z * drop_scale(d, row, col + 2),
+                     v.w * drop_scale(d, row, col + 3));
+}
+
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -79,7 +98,10 @@ struct EpiAddBiasAct;   // gemm_kernels.hip
 int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx,
                       const float* B, int ldb, int trans_b,
                       const float* addend, int ld_add, const int32_t* row_mask, const float* bias, int act,
-                      float* out, int ldo, hipStream_t st);
+                      float* out, int ldo, hipStream_t st, const DropSpec* drop = nullptr);   // drop: mask on the PRODUCT (A.B) only
+
+// dst[row, :] = src[row, :] * keep-scale(row, col)   (the masked gradient of a dropped-out self-loop message)
+int mask_rows(int n, int d, const float* src, float* dst, const DropSpec& drop, hipStream_t st);
 
 // out[Ka,Nb] = sum_m A[m,ka] * B[m,nb]   (split over m, deterministic two-pass reduce)
 size_t gemm_tn_workspace(int M, int Ka, int Nb);

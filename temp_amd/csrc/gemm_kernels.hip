@@ -45,11 +45,42 @@ struct EpiAddBiasAct {
   }
 };
 
+// Same epilogue with dropout of the product term (the self-loop message in training mode): a separate type, so the
+// common no-dropout instantiations carry neither the extra kernel arguments nor the hash code.
+struct EpiAddBiasActDrop : EpiAddBiasAct {
+  DropSpec drop;
+  __device__ __forceinline__ void fin4(const RowCtx& c, int row, int col, float4 acc, float4 p) const {
+    EpiAddBiasAct::fin4(c, row, col, drop4(drop, (unsigned)row, (unsigned)col, acc), p);
+  }
+};
+
 int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, const int32_t* a_idx, const float* B, int ldb, int trans_b,
                       const float* addend, int ld_add, const int32_t* row_mask, const float* bias, int act, float* out, int ldo,
-                      hipStream_t st) {
+                      hipStream_t st, const DropSpec* drop) {
   EpiAddBiasAct epi{addend, ld_add, row_mask, bias, act, out, ldo};
+  if (drop && drop->p > 0.f) {
+    EpiAddBiasActDrop ed;
+    static_cast<EpiAddBiasAct&>(ed) = epi;
+    ed.drop = *drop;
+    return launch_gemm_panel(kid, M, N, K, A, lda, a_idx, B, ldb, trans_b, ed, st);
+  }
   return launch_gemm_panel(kid, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi, st);
+}
+
+__global__ void __launch_bounds__(256) k_mask_rows(size_t n4, int d4, const float4* __restrict__ src, float4* __restrict__ dst, DropSpec drop) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned row = (unsigned)(i / (unsigned)d4), c4 = (unsigned)(i - (size_t)row * d4);
+    dst[i] = drop4(drop, row, c4 * 4, src[i]);
+  }
+}
+
+int mask_rows(int n, int d, const float* src, float* dst, const DropSpec& drop, hipStream_t st) {
+  if (n <= 0) return TEMP_OK;
+  const size_t n4 = (size_t)n * (d / 4);
+  int grid = ceil_div((long long)n4, 256);
+  if (grid > 4096) grid = 4096;
+  TEMP_LAUNCH(K_RELU_BWD, k_mask_rows, dim3(grid), dim3(256), 0, st, n4, d / 4, (const float4*)src, (float4*)dst, drop);
+  return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,19 +588,22 @@ const char* temp_error_string(int code) {
   }
 }
 
-int temp_rgcn_isolated_fwd(int n, int d, const float* e, const float* loop_w, const float* bias, int act, float* out, void* stream) {
+int temp_rgcn_isolated_fwd(int n, int d, const float* e, const float* loop_w, const float* bias, int act, float* out, const TempDropout* drop,
+                           void* stream) {
   if (n < 0 || d <= 0 || !loop_w || (n > 0 && (!e || !out))) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
-  return gemm_add_bias_act(K_GEMM_ISO, n, d, d, e, d, nullptr, loop_w, d, 0, e, d, nullptr, bias, act, out, d, (hipStream_t)stream);
+  const DropSpec ds = drop_spec(drop);
+  return gemm_add_bias_act(K_GEMM_ISO, n, d, d, e, d, nullptr, loop_w, d, 0, e, d, nullptr, bias, act, out, d, (hipStream_t)stream, &ds);
 }
 
 size_t temp_rgcn_isolated_bwd_workspace(int n, int d) {
   if (n < 0 || d <= 0) return 0;
-  return align_up((size_t)n * d * sizeof(float), 256) + gemm_tn_workspace(n, d, d) + colsum_workspace(n, d) + 256;
+  return 2 * align_up((size_t)n * d * sizeof(float), 256) + gemm_tn_workspace(n, d, d) + colsum_workspace(n, d) + 256;
 }
 
 int temp_rgcn_isolated_bwd(int n, int d, const float* e, const float* out, const float* d_out_grad, const float* loop_w, int has_bias,
-                           int act, float* d_e, float* d_loop_w, float* d_bias, void* workspace, size_t workspace_bytes, void* stream) {
+                           int act, float* d_e, float* d_loop_w, float* d_bias, void* workspace, size_t workspace_bytes, const TempDropout* drop,
+                           void* stream) {
   if (n < 0 || d <= 0 || !loop_w || !d_loop_w || (n > 0 && (!e || !d_out_grad || !d_e))) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
   if (act == TEMP_ACT_RELU && !out) return TEMP_E_BADARG;
@@ -578,6 +612,8 @@ int temp_rgcn_isolated_bwd(int n, int d, const float* e, const float* out, const
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)workspace;
   float* dzbuf = (float*)base;
+  base += align_up((size_t)n * d * sizeof(float), 256);
+  float* dzm_buf = (float*)base;
   base += align_up((size_t)n * d * sizeof(float), 256);
   void* tn = base;
   const size_t tnb = gemm_tn_workspace(n, d, d);
@@ -591,10 +627,17 @@ int temp_rgcn_isolated_bwd(int n, int d, const float* e, const float* out, const
     if (rc) return rc;
     dz = dzbuf;
   }
-  // d_e = dz + dz . loop_w^T
-  rc = gemm_add_bias_act(K_GEMM_ISO, n, d, d, dz, d, nullptr, loop_w, d, 1, dz, d, nullptr, nullptr, TEMP_ACT_NONE, d_e, d, st);
+  // d_e = dz + dzm . loop_w^T,  d_loop_w = e^T . dzm   (dzm = dz masked like the forward loop message; = dz without dropout)
+  const DropSpec ds = drop_spec(drop);
+  const float* dzm = dz;
+  if (ds.p > 0.f) {
+    rc = mask_rows(n, d, dz, dzm_buf, ds, st);
+    if (rc) return rc;
+    dzm = dzm_buf;
+  }
+  rc = gemm_add_bias_act(K_GEMM_ISO, n, d, d, dzm, d, nullptr, loop_w, d, 1, dz, d, nullptr, nullptr, TEMP_ACT_NONE, d_e, d, st);
   if (rc) return rc;
-  rc = gemm_tn(n, d, d, e, d, dz, d, d_loop_w, d, tn, tnb, st);
+  rc = gemm_tn(n, d, d, e, d, dzm, d, d_loop_w, d, tn, tnb, st);
   if (rc) return rc;
   if (has_bias) rc = colsum(n, d, dz, d, d_bias, cs, csb, st);
   return rc;

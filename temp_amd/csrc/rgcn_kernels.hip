@@ -404,12 +404,14 @@ static int run_dw(const TempEdgeView& v, const float* x, const int32_t* x_ids, c
 // is a row gather of a table, taken from the table's own product table . W_loop instead of a GEMM over every row.
 __global__ void __launch_bounds__(256) k_loop_gather_epi(int n, int d4, const int32_t* __restrict__ ids, const int32_t* __restrict__ in_deg,
                                                          const float4* __restrict__ t_loop, const float4* __restrict__ bias, int act,
-                                                         float4* __restrict__ out) {
+                                                         DropSpec drop, float4* __restrict__ out) {
   const size_t total = (size_t)n * d4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / (unsigned)d4), c = (int)(i - (size_t)row * d4);
     float4 v = in_deg[row] > 0 ? out[i] : zero4();
-    v = add4(v, t_loop[(size_t)ids[row] * d4 + c]);
+    float4 lm = t_loop[(size_t)ids[row] * d4 + c];
+    if (drop.p > 0.f) lm = drop4(drop, (unsigned)row, (unsigned)c * 4, lm);
+    v = add4(v, lm);
     if (bias) v = add4(v, bias[c]);
     if (act == TEMP_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     out[i] = v;
@@ -417,7 +419,7 @@ __global__ void __launch_bounds__(256) k_loop_gather_epi(int n, int d4, const in
 }
 
 struct TableBwdWs {
-  float *dz, *d_h, *part_dx, *part_dw, *seg_dz;
+  float *dz, *dzm, *d_h, *part_dx, *part_dw, *seg_dz;
   void *tn, *cs;
   size_t tn_bytes, cs_bytes, total;
 };
@@ -427,6 +429,7 @@ static TableBwdWs carve_table_bwd(const TempGraph* g, int n_table, int d_in, int
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
   const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
   w.dz = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
+  w.dzm = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
   w.d_h = (float*)take((size_t)g->n_nodes * d_in * sizeof(float));
   w.part_dx = (float*)take((size_t)g->by_src.n_partial * d_in * sizeof(float));
   w.part_dw = (float*)take((size_t)g->by_rel.n_partial * wrow * sizeof(float));
@@ -452,7 +455,7 @@ size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out)
 
 int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* ids, int n_table, int d_in, int d_out, int num_bases,
                         int n_rel_rows, const float* weight, const float* loop_w, const float* bias, int act, float* out, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        size_t workspace_bytes, const TempDropout* drop, void* stream) {
   if (!g || !table || !weight || !loop_w || !out || n_table <= 0 || d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
   if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
   if (g->n_nodes < 0 || !view_ok(g->by_dst) || (g->n_nodes > 0 && (!g->nnorm || !g->in_deg || !ids))) return TEMP_E_BADARG;
@@ -470,7 +473,7 @@ int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* i
   int grid = ceil_div((long long)g->n_nodes * (d_out / 4), 256);
   if (grid > 4096) grid = 4096;
   TEMP_LAUNCH(K_GEMM_LOOP_FWD, k_loop_gather_epi, dim3(grid), dim3(256), 0, st, g->n_nodes, d_out / 4, ids, g->in_deg, (const float4*)t_loop,
-              (const float4*)bias, act, (float4*)out);
+              (const float4*)bias, act, drop_spec(drop), (float4*)out);
   return launch_status();
 }
 
@@ -482,7 +485,7 @@ size_t temp_rgcn_table_bwd_workspace(const TempGraph* g, int n_table, int d_in, 
 int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* ids, const int32_t* inv_ptr, const int32_t* inv_order, int n_table,
                         const float* out, const float* d_out_grad, int d_in, int d_out, int num_bases, int n_rel_rows, const float* weight,
                         const float* loop_w, int has_bias, int act, float* d_table, float* d_weight, float* d_loop_w, float* d_bias,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream) {
   if (!g || !table || !d_out_grad || !weight || !loop_w || !d_table || !d_weight || !d_loop_w || !inv_ptr) return TEMP_E_BADARG;
   if (n_table <= 0 || d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
   if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4 || d_in > 256 || d_out > 256) return TEMP_E_UNSUPPORTED;
@@ -514,7 +517,14 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
   if (rc) return rc;
   rc = segment_sum_rows(n_table, d_in, inv_ptr, inv_order, w.d_h, g->out_deg, d_table, st, g->n_nodes);
   if (rc) return rc;
-  rc = segment_sum_rows(n_table, d_out, inv_ptr, inv_order, dz, nullptr, w.seg_dz, st, g->n_nodes);
+  const DropSpec ds = drop_spec(drop);
+  const float* dzm = dz;                       // gradient of the (dropped-out) self-loop message
+  if (ds.p > 0.f) {
+    rc = mask_rows(g->n_nodes, d_out, dz, w.dzm, ds, st);
+    if (rc) return rc;
+    dzm = w.dzm;
+  }
+  rc = segment_sum_rows(n_table, d_out, inv_ptr, inv_order, dzm, nullptr, w.seg_dz, st, g->n_nodes);
   if (rc) return rc;
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, n_table, d_in, d_out, w.seg_dz, d_out, nullptr, loop_w, d_out, 1, d_table, d_in, nullptr, nullptr,
                          TEMP_ACT_NONE, d_table, d_in, st);
@@ -537,7 +547,7 @@ size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out) {
 
 int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids, int d_in, int d_out, int num_bases, int n_rel_rows,
                   const float* weight, const float* loop_w, const float* bias, int act, float* out, void* workspace,
-                  size_t workspace_bytes, void* stream) {
+                  size_t workspace_bytes, const TempDropout* drop, void* stream) {
   if (!g || !h || !weight || !loop_w || !out || d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
   if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
   if (g->n_nodes < 0 || !view_ok(g->by_dst) || (g->n_nodes > 0 && (!g->nnorm || !g->in_deg))) return TEMP_E_BADARG;
@@ -549,11 +559,13 @@ int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids, int 
   int rc = run_agg(MODE_FWD, g->by_dst, h, d_in, h_ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
   if (rc) return rc;
   // out = act( (in_deg>0 ? out : 0) + bias + h . loop_w )       (MFMA fp32 GEMM, fused epilogue)
-  return gemm_add_bias_act(K_GEMM_LOOP_FWD, g->n_nodes, d_out, d_in, h, d_in, h_ids, loop_w, d_out, 0, out, d_out, g->in_deg, bias, act, out, d_out, st);
+  const DropSpec ds = drop_spec(drop);
+  return gemm_add_bias_act(K_GEMM_LOOP_FWD, g->n_nodes, d_out, d_in, h, d_in, h_ids, loop_w, d_out, 0, out, d_out, g->in_deg, bias, act, out, d_out, st, &ds);
 }
 
 struct BwdWs {
   float* dz;        // [n, d_out]  (only when act == relu)
+  float* dzm;       // [n, d_out]  dz masked like the forward self-loop message (only with dropout)
   float* part_dx;   // by_src partial slots [n_partial, d_in]
   float* part_dw;   // by_rel partial slots [n_partial, wrow]
   void* tn;         // gemm_tn workspace
@@ -568,6 +580,7 @@ static BwdWs carve_bwd(const TempGraph* g, int d_in, int d_out, int num_bases, c
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
   const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
   w.dz = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
+  w.dzm = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
   w.part_dx = (float*)take((size_t)g->by_src.n_partial * d_in * sizeof(float));
   w.part_dw = (float*)take((size_t)g->by_rel.n_partial * wrow * sizeof(float));
   w.tn_bytes = gemm_tn_workspace(g->n_nodes, d_in, d_out);
@@ -586,7 +599,7 @@ size_t temp_rgcn_bwd_workspace(const TempGraph* g, int d_in, int d_out, int num_
 
 int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const float* d_out_grad, int d_in, int d_out, int num_bases,
                   int n_rel_rows, const float* weight, const float* loop_w, int has_bias, int act, float* d_h, float* d_weight,
-                  float* d_loop_w, float* d_bias, void* workspace, size_t workspace_bytes, void* stream) {
+                  float* d_loop_w, float* d_bias, void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream) {
   if (!g || !h || !d_out_grad || !weight || !loop_w || !d_h || !d_weight || !d_loop_w) return TEMP_E_BADARG;
   if (d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
   if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
@@ -614,12 +627,19 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
   // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
   rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
   if (rc) return rc;
-  rc = gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dz, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
+  const DropSpec ds = drop_spec(drop);
+  const float* dzm = dz;                       // gradient of the (dropped-out) self-loop message
+  if (ds.p > 0.f) {
+    rc = mask_rows(g->n_nodes, d_out, dz, w.dzm, ds, st);
+    if (rc) return rc;
+    dzm = w.dzm;
+  }
+  rc = gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dzm, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
                          d_h, d_in, st);
   if (rc) return rc;
   rc = run_dw(g->by_rel, h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
   if (rc) return rc;
-  rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
+  rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dzm, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
   if (rc) return rc;
   if (has_bias) {
     rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);

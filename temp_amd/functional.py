@@ -18,66 +18,67 @@ ACTS = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU}
 
 class _RGCNLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, weight, loop_w, bias, dg, num_bases, act):
+    def forward(ctx, h, weight, loop_w, bias, dg, num_bases, act, drop):
         be = get_backend()
-        out = be.rgcn_fwd(dg, h, None, weight, loop_w, bias, num_bases, act)
+        out = be.rgcn_fwd(dg, h, None, weight, loop_w, bias, num_bases, act, drop)
         ctx.save_for_backward(h, weight, loop_w, out)
-        ctx.dg, ctx.num_bases, ctx.act, ctx.has_bias = dg, num_bases, act, bias is not None
+        ctx.dg, ctx.num_bases, ctx.act, ctx.has_bias, ctx.drop = dg, num_bases, act, bias is not None, drop
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         h, weight, loop_w, out = ctx.saved_tensors
         d_h, d_w, d_loop, d_bias = get_backend().rgcn_bwd(ctx.dg, h, out, d_out.contiguous(), weight, loop_w, ctx.has_bias,
-                                                          ctx.num_bases, ctx.act)
-        return d_h, d_w, d_loop, d_bias, None, None, None
+                                                          ctx.num_bases, ctx.act, ctx.drop)
+        return d_h, d_w, d_loop, d_bias, None, None, None, None
 
 
-def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None):
-    """out = act(nnorm^2 * sum_in h_u BD(W_r) [+bias] + h W_loop) on a device graph `dg`."""
-    return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act])
+def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None, drop=None):
+    """out = act(nnorm^2 * sum_in h_u BD(W_r) [+bias] + dropout(h W_loop)) on a device graph `dg`.
+    drop = (p, seed) or None: dropout of the self-loop message (models/RGCN.py:57-59), mask = hash(seed, row, col)."""
+    return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act], drop)
 
 
 class _RGCNTableLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, weight, loop_w, bias, ids, inverse, dg, num_bases, act):
-        out = get_backend().rgcn_table_fwd(dg, table, ids, weight, loop_w, bias, num_bases, act)
+    def forward(ctx, table, weight, loop_w, bias, ids, inverse, dg, num_bases, act, drop):
+        out = get_backend().rgcn_table_fwd(dg, table, ids, weight, loop_w, bias, num_bases, act, drop)
         ctx.save_for_backward(table, weight, loop_w, out, ids)
-        ctx.dg, ctx.num_bases, ctx.act, ctx.has_bias, ctx.inverse = dg, num_bases, act, bias is not None, inverse
+        ctx.dg, ctx.num_bases, ctx.act, ctx.has_bias, ctx.inverse, ctx.drop = dg, num_bases, act, bias is not None, inverse, drop
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         table, weight, loop_w, out, ids = ctx.saved_tensors
         d_t, d_w, d_loop, d_bias = get_backend().rgcn_table_bwd(ctx.dg, table, ids, ctx.inverse, out, d_out.contiguous(), weight, loop_w,
-                                                               ctx.has_bias, ctx.num_bases, ctx.act)
-        return d_t, d_w, d_loop, d_bias, None, None, None, None, None
+                                                               ctx.has_bias, ctx.num_bases, ctx.act, ctx.drop)
+        return d_t, d_w, d_loop, d_bias, None, None, None, None, None, None
 
 
-def rgcn_layer_table(table, ids, inverse, dg, weight, loop_w, bias, num_bases, act=None):
+def rgcn_layer_table(table, ids, inverse, dg, weight, loop_w, bias, num_bases, act=None, drop=None):
     """rgcn_layer on h = table[ids] (ids int32, static; inverse = gather_inverse(ids, rows)) without materialising h:
     the self-loop product and its gradients run over the table's rows, not over every node row."""
-    return _RGCNTableLayerFn.apply(table, weight, loop_w, bias, ids, inverse, dg, num_bases, ACTS[act])
+    return _RGCNTableLayerFn.apply(table, weight, loop_w, bias, ids, inverse, dg, num_bases, ACTS[act], drop)
 
 
 class _RGCNIsolatedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e, loop_w, bias, act):
-        out = get_backend().rgcn_isolated_fwd(e, loop_w, bias, act)
+    def forward(ctx, e, loop_w, bias, act, drop):
+        out = get_backend().rgcn_isolated_fwd(e, loop_w, bias, act, drop)
         ctx.save_for_backward(e, loop_w, out)
-        ctx.act, ctx.has_bias = act, bias is not None
+        ctx.act, ctx.has_bias, ctx.drop = act, bias is not None, drop
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         e, loop_w, out = ctx.saved_tensors
-        d_e, d_loop, d_bias = get_backend().rgcn_isolated_bwd(e, out, d_out.contiguous(), loop_w, ctx.has_bias, ctx.act)
-        return d_e, d_loop, d_bias, None
+        d_e, d_loop, d_bias = get_backend().rgcn_isolated_bwd(e, out, d_out.contiguous(), loop_w, ctx.has_bias, ctx.act, ctx.drop)
+        return d_e, d_loop, d_bias, None, None
 
 
-def rgcn_isolated(e, loop_w, bias, act=None):
-    """out = act(e + e W_loop [+bias])."""
-    return _RGCNIsolatedFn.apply(e, loop_w, bias, ACTS[act])
+def rgcn_isolated(e, loop_w, bias, act=None, drop=None):
+    """out = act(e + dropout(e W_loop) [+bias])."""
+    return _RGCNIsolatedFn.apply(e, loop_w, bias, ACTS[act], drop)
 
 
 class _GRUStepFn(torch.autograd.Function):

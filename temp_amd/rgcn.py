@@ -57,34 +57,33 @@ class RGCNLayer(nn.Module):
         self.compute_time_embedding = True      # containers switch it off when use_time_embedding is False
 
     # -- helpers --------------------------------------------------------------------------------
-    def _check_dropout(self):
+    def _drop(self):
+        """(p, seed) of the self-loop dropout for THIS call (models/RGCN.py:57-59, training mode only), else None.
+        The kernels derive the keep mask from the seed, so the autograd node only remembers the pair."""
         if self.dropout_p > 0 and self.training:
-            raise NotImplementedError("loop-message dropout (models/RGCN.py:57-59) is not fused yet: "
-                                      "build the encoder with dropout=0 or call .eval()")
+            return (self.dropout_p, int(torch.randint(0, 2 ** 62, (1,)).item()))
+        return None
 
     def _bias(self):
         return self.h_bias if self.bias else None
 
     def conv(self, g, h):
         """The fused layer on node features `h` of graph `g` (models/RGCN.py:53-70)."""
-        self._check_dropout()
         dg = g.device_graph(h.device, self.num_rels)
-        out = TF.rgcn_layer(h, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act)
+        out = TF.rgcn_layer(h, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act, self._drop())
         return self._post_act(out) if self._post_act is not None else out
 
     def conv_table(self, g, table, ids, inverse):
         """conv(g, table[ids]) for a layer fed straight from an embedding table (layer 1: h = ent_embeds[id],
         models/DynamicRGCN.py:93) -- the gather is folded into the kernels."""
-        self._check_dropout()
         if inverse is None or self.in_feat > 256 or self.out_feat > 256:
             return self.conv(g, TF.gather_rows(table, ids))
         dg = g.device_graph(table.device, self.num_rels)
-        out = TF.rgcn_layer_table(table, ids, inverse, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act)
+        out = TF.rgcn_layer_table(table, ids, inverse, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act, self._drop())
         return self._post_act(out) if self._post_act is not None else out
 
     def conv_isolated(self, e):
-        self._check_dropout()
-        out = TF.rgcn_isolated(e, self.loop_weight, self._bias(), self._act)
+        out = TF.rgcn_isolated(e, self.loop_weight, self._bias(), self._act, self._drop())
         return self._post_act(out) if self._post_act is not None else out
 
     def get_time_embedding(self, time_batched_list_t, node_sizes):

@@ -85,9 +85,8 @@ class RRGCNLayer(RGCNLayer):
         return out
 
     def _linear_core(self, g, h):
-        self._check_dropout()
         dg = g.device_graph(h.device, self.num_rels)
-        return TF.rgcn_layer(h, dg, self.weight, self.loop_weight, None, self.num_bases, None)
+        return TF.rgcn_layer(h, dg, self.weight, self.loop_weight, None, self.num_bases, None, self._drop())
 
     def forward(self, g, prev_graph_embeds, time_diff_tensor, time_batched_list_t, node_sizes):
         g = g.local_var()
@@ -97,8 +96,7 @@ class RRGCNLayer(RGCNLayer):
         return g, self.get_time_embedding(time_batched_list_t, node_sizes)
 
     def forward_isolated(self, ent_embeds, prev_graph_embeds, time_diff_tensor, time):
-        self._check_dropout()
-        pre = TF.rgcn_isolated(ent_embeds, self.loop_weight, None, None)
+        pre = TF.rgcn_isolated(ent_embeds, self.loop_weight, None, None, self._drop())
         rec = torch.mm(prev_graph_embeds, self.time_weight) * torch.exp(-time_diff_tensor * self.inv_temperature)
         return self._finish(pre, rec), (self.time_embed[int(time)] if self.compute_time_embedding else None)
 

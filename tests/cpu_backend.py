@@ -43,6 +43,23 @@ def _chunk_reduce(dg, name, per_edge_fn, width, n_out, dtype):
     return out
 
 
+def drop_mask(drop, n, d):
+    """Keep-scale matrix of the self-loop dropout, the same counter-based hash as csrc/common.hpp: drop_scale()."""
+    import numpy as np
+    if drop is None or drop[0] <= 0.0:
+        return None
+    p, seed = float(drop[0]), np.uint64(int(drop[1]) & 0xFFFFFFFFFFFFFFFF)
+    row = np.arange(n, dtype=np.uint64).reshape(-1, 1)
+    col = np.arange(d, dtype=np.uint64).reshape(1, -1)
+    with np.errstate(over="ignore"):
+        x = seed ^ ((row << np.uint64(32)) | col)
+        x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd); x ^= x >> np.uint64(33)
+        x *= np.uint64(0xc4ceb9fe1a85ec53); x ^= x >> np.uint64(33)
+    u = (x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    keep = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(u < np.float32(p), np.float32(0.0), keep).astype(np.float32))
+
+
 def _blocks(weight, rel, B):
     return weight.index_select(0, rel).view(rel.shape[0], B, -1)
 
@@ -51,7 +68,7 @@ class CpuTestBackend:
     name = "cpu-test"
 
     # ---- RGCN ---------------------------------------------------------------------------------
-    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act):
+    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act, drop=None):
         h, weight, loop_w = h.detach(), weight.detach(), loop_w.detach()
         d_in, d_out = loop_w.shape
         si, so = d_in // num_bases, d_out // num_bases
@@ -67,14 +84,16 @@ class CpuTestBackend:
         has_in = dg.in_deg.cpu().long() > 0
         agg = torch.where(has_in.view(-1, 1), agg, torch.zeros_like(agg))
         x = rows(torch.arange(dg.n_nodes))
-        out = agg + torch.mm(x, loop_w)
+        loop = torch.mm(x, loop_w)
+        m = drop_mask(drop, loop.shape[0], loop.shape[1])
+        out = agg + (loop * m if m is not None else loop)
         if bias is not None:
             out = out + bias.detach()
         if act == _lib.ACT_RELU:
             out = torch.relu(out)
         return out
 
-    def rgcn_bwd(self, dg, h, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
+    def rgcn_bwd(self, dg, h, out, d_out_grad, weight, loop_w, has_bias, num_bases, act, drop=None):
         h, weight, loop_w = h.detach(), weight.detach(), loop_w.detach()
         d_in, d_out = loop_w.shape
         si, so = d_in // num_bases, d_out // num_bases
@@ -90,7 +109,9 @@ class CpuTestBackend:
 
         d_h = _chunk_reduce(dg, 'by_src', dx_edge, d_in, dg.n_nodes, h.dtype)
         has_out = dg.out_deg.cpu().long() > 0
-        d_h = torch.where(has_out.view(-1, 1), d_h, torch.zeros_like(d_h)) + torch.mm(dz, loop_w.t())
+        m = drop_mask(drop, dz.shape[0], dz.shape[1])
+        dzm = dz * m if m is not None else dz
+        d_h = torch.where(has_out.view(-1, 1), d_h, torch.zeros_like(d_h)) + torch.mm(dzm, loop_w.t())
 
         def dw_edge(src, dst):
             g = (dz[dst] * (nn[dst] ** 2).view(-1, 1)).view(-1, num_bases, 1, so)
@@ -100,30 +121,34 @@ class CpuTestBackend:
         wrow = num_bases * si * so
         d_w = _chunk_reduce(dg, 'by_rel', dw_edge, wrow, weight.shape[0], h.dtype)
         d_w = torch.where(torch.isnan(d_w), torch.zeros_like(d_w), d_w)      # kernel memsets dW first
-        d_loop = torch.mm(h.t(), dz)
+        d_loop = torch.mm(h.t(), dzm)
         d_bias = dz.sum(0) if has_bias else None
         return d_h, d_w, d_loop, d_bias
 
-    def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act):
-        return self.rgcn_fwd(dg, table.detach()[ids.long()], None, weight, loop_w, bias, num_bases, act)
+    def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act, drop=None):
+        return self.rgcn_fwd(dg, table.detach()[ids.long()], None, weight, loop_w, bias, num_bases, act, drop)
 
-    def rgcn_table_bwd(self, dg, table, ids, inverse, out, d_out_grad, weight, loop_w, has_bias, num_bases, act):
-        d_h, d_w, d_loop, d_bias = self.rgcn_bwd(dg, table.detach()[ids.long()], out, d_out_grad, weight, loop_w, has_bias, num_bases, act)
+    def rgcn_table_bwd(self, dg, table, ids, inverse, out, d_out_grad, weight, loop_w, has_bias, num_bases, act, drop=None):
+        d_h, d_w, d_loop, d_bias = self.rgcn_bwd(dg, table.detach()[ids.long()], out, d_out_grad, weight, loop_w, has_bias, num_bases, act, drop)
         d_table = self.segment_sum_rows(d_h, inverse[0], inverse[1], table.shape[0])
         return d_table, d_w, d_loop, d_bias
 
-    def rgcn_isolated_fwd(self, e, loop_w, bias, act):
-        out = e.detach() + torch.mm(e.detach(), loop_w.detach())
+    def rgcn_isolated_fwd(self, e, loop_w, bias, act, drop=None):
+        loop = torch.mm(e.detach(), loop_w.detach())
+        m = drop_mask(drop, loop.shape[0], loop.shape[1])
+        out = e.detach() + (loop * m if m is not None else loop)
         if bias is not None:
             out = out + bias.detach()
         return torch.relu(out) if act == _lib.ACT_RELU else out
 
-    def rgcn_isolated_bwd(self, e, out, d_out_grad, loop_w, has_bias, act):
+    def rgcn_isolated_bwd(self, e, out, d_out_grad, loop_w, has_bias, act, drop=None):
         dz = d_out_grad.detach()
         if act == _lib.ACT_RELU:
             dz = torch.where(out.detach() > 0, dz, torch.zeros_like(dz))
-        d_e = dz + torch.mm(dz, loop_w.detach().t())
-        return d_e, torch.mm(e.detach().t(), dz), (dz.sum(0) if has_bias else None)
+        m = drop_mask(drop, dz.shape[0], dz.shape[1])
+        dzm = dz * m if m is not None else dz
+        d_e = dz + torch.mm(dzm, loop_w.detach().t())
+        return d_e, torch.mm(e.detach().t(), dzm), (dz.sum(0) if has_bias else None)
 
     # ---- decay + GRU ----------------------------------------------------------------------------
     @staticmethod

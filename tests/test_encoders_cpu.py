@@ -73,3 +73,42 @@ def test_tiled_relation_view_reduces_like_plain_view():
     dg.views["by_rel"] = plain
     d_w_plain = be.rgcn_bwd(dg, h, out, gy, w, lw, False, B, 0)[1]
     assert torch.allclose(d_w_tiled[:R2 - 1], d_w_plain[:R2 - 1], rtol=1e-4, atol=1e-4)
+
+
+def test_self_loop_dropout_semantics_and_gradients():
+    """Dropout of the self-loop message (models/RGCN.py:57-59; the reference's default --dropout is 0.1): training mode
+    drops ~p of the loop-message entries and rescales the rest, eval mode is the deterministic layer, and the autograd
+    gradients equal those of the explicit formula out = prop + mask * (h W_loop) with the mask the kernels hash."""
+    import numpy as np
+    from oracle import temp_oracle as O
+    from temp_amd import snapshot as S
+    from temp_amd.rgcn import RGCNLayer
+    from tests.cpu_backend import drop_mask
+    from tests.window_cases import make_args
+    rng = np.random.default_rng(11)
+    n, E, R2, D, B = 120, 900, 10, 32, 8
+    g = S.Snapshot(n, rng.integers(0, n, E), rng.integers(0, n, E), rng.integers(0, R2, E), np.arange(n))
+    layer = RGCNLayer(make_args(dropout=0.25), D, D, R2, B, list(range(5)), bias=True, activation=None, self_loop=True, dropout=0.25)
+    h = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32)).requires_grad_(True)
+    layer.eval()
+    ref = O.rgcn_layer(h.detach(), O.SnapGraph(n, g.src, g.dst, g.rel, g.gids), layer.weight.detach(), layer.loop_weight.detach(), B,
+                       layer.h_bias.detach(), None)
+    assert torch.allclose(layer.conv(g, h), ref, rtol=1e-5, atol=1e-5)
+    layer.train()
+    torch.manual_seed(5)
+    out = layer.conv(g, h)
+    torch.manual_seed(5)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())                  # what RGCNLayer._drop() drew
+    m = drop_mask((0.25, seed), n, D)
+    dropped = float((m == 0).float().mean())
+    assert 0.2 < dropped < 0.3 and torch.allclose(m[m > 0], torch.tensor(1.0 / 0.75))
+    loop = torch.mm(h.detach(), layer.loop_weight.detach())
+    assert torch.allclose(out, ref - loop + loop * m, rtol=1e-5, atol=1e-5)
+    gy = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32))
+    out.backward(gy)
+    h2 = h.detach().clone().requires_grad_(True)
+    lw2 = layer.loop_weight.detach().clone().requires_grad_(True)
+    prop = O.rgcn_propagate(h2, O.SnapGraph(n, g.src, g.dst, g.rel, g.gids), layer.weight.detach(), B)
+    (prop + layer.h_bias.detach() + torch.mm(h2, lw2) * m).backward(gy)
+    assert torch.allclose(h.grad, h2.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(layer.loop_weight.grad, lw2.grad, rtol=1e-4, atol=1e-4)

@@ -440,3 +440,71 @@ def test_device_union_views_equal_host_union_gpu():
             assert np.array_equal(dg.view_tensor(vn, an).cpu().numpy(), hv[an]), (vn, an)
     assert np.array_equal(dg.in_deg.cpu().numpy(), in_deg) and np.array_equal(dg.out_deg.cpu().numpy(), out_deg)
     assert np.array_equal(dg.nnorm.cpu().numpy(), g.nnorm)
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_self_loop_dropout_kernels_vs_cpu_backend(p, hip_backend):
+    """Dropout of the self-loop message: the HIP kernels and the test backend derive the same keep mask from (seed, row,
+    col), so layer / table layer / isolated layer agree with dropout on, forward and backward."""
+    from temp_amd import functional as TF
+    rng = np.random.default_rng(17)
+    n, E, R2, D, B, n_table = 700, 5000, 12, 64, 16, 90
+    g = rand_graph(rng, n, E, R2, hub=True)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    h, w, lw, b, gy = f(n, D), f(R2, B * 4 * 4) * 0.5, f(D, D) * 0.2, f(D), f(n, D)
+    drop = (p, 0x1234ABCD5678 + int(p * 100))
+    cpu = CpuTestBackend()
+    dg_c, dg = g.device_graph(torch.device("cpu"), R2), g.device_graph(DEV, R2)
+    cu = lambda t: t.to(DEV)
+    want = cpu.rgcn_fwd(dg_c, h, None, w, lw, b, B, 1, drop)
+    got = hip_backend.rgcn_fwd(dg, cu(h), None, cu(w), cu(lw), cu(b), B, 1, drop)
+    assert_close(got, want, 1e-5, 5e-6, "dropout fwd")
+    nodrop = hip_backend.rgcn_fwd(dg, cu(h), None, cu(w), cu(lw), cu(b), B, 1, None)
+    assert not torch.allclose(got, nodrop)
+    wd = cpu.rgcn_bwd(dg_c, h, want, gy, w, lw, True, B, 1, drop)
+    gd = hip_backend.rgcn_bwd(dg, cu(h), got, cu(gy), cu(w), cu(lw), True, B, 1, drop)
+    for a_, b_, nm in zip(gd, wd, ("d_h", "d_weight", "d_loop", "d_bias")):
+        assert_close(a_, b_, 2e-5, 3e-4, "dropout " + nm)
+    # table layer
+    table = f(n_table, D)
+    ids_np = rng.integers(0, n_table, n)
+    ids = torch.from_numpy(ids_np.astype(np.int32))
+    inv_c, inv = TF.gather_inverse(ids_np, n_table, torch.device("cpu")), TF.gather_inverse(ids_np, n_table, DEV)
+    want = cpu.rgcn_table_fwd(dg_c, table, ids, w, lw, b, B, 0, drop)
+    got = hip_backend.rgcn_table_fwd(dg, cu(table), cu(ids), cu(w), cu(lw), cu(b), B, 0, drop)
+    assert_close(got, want, 1e-5, 5e-6, "dropout table fwd")
+    wd = cpu.rgcn_table_bwd(dg_c, table, ids, inv_c, want, gy, w, lw, True, B, 0, drop)
+    gd = hip_backend.rgcn_table_bwd(dg, cu(table), cu(ids), inv, got, cu(gy), cu(w), cu(lw), True, B, 0, drop)
+    for a_, b_, nm in zip(gd, wd, ("d_table", "d_weight", "d_loop", "d_bias")):
+        assert_close(a_, b_, 2e-5, 3e-4, "dropout table " + nm)
+    # isolated layer
+    e = f(n, D)
+    want = cpu.rgcn_isolated_fwd(e, lw, b, 1, drop)
+    got = hip_backend.rgcn_isolated_fwd(cu(e), cu(lw), cu(b), 1, drop)
+    assert_close(got, want, 1e-5, 5e-6, "dropout iso fwd")
+    wd = cpu.rgcn_isolated_bwd(e, want, gy, lw, True, 1, drop)
+    gd = hip_backend.rgcn_isolated_bwd(cu(e), got, cu(gy), cu(lw), True, 1, drop)
+    for a_, b_, nm in zip(gd, wd, ("d_e", "d_loop", "d_bias")):
+        assert_close(a_, b_, 2e-5, 3e-4, "dropout iso " + nm)
+
+
+def test_window_model_with_reference_default_dropout_gpu():
+    """The reference's default --dropout is 0.1 (utils/args.py:17): the window models must train with it (self-loop message
+    dropout in every RGCN layer, fresh mask per call) and be deterministic in eval mode."""
+    from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
+    from tests.window_cases import make_args, slice_snapshots
+    s = slice_snapshots()
+    args = make_args(module="BiGRRGCN", rec_only_last_layer=True, dropout=0.1, train_seq_len=5, test_seq_len=5)
+    torch.manual_seed(0)
+    m = BiDynamicRGCN(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(DEV)
+    t_list = torch.tensor([s["times"][i] for i in (15, 9, 4)])
+    wb = m.prepare(t_list, 5, train=True)
+    m.train()
+    a = m.run(wb)[0]
+    b = m.run(wb)[0]
+    assert torch.isfinite(a).all() and not torch.equal(a, b), "training mode must draw a fresh dropout mask per call"
+    (a * a).sum().backward()
+    assert m.ent_encoder.layer_1.loop_weight.grad is not None and torch.isfinite(m.ent_encoder.layer_1.loop_weight.grad).all()
+    m.eval()
+    c, d = m.run(wb)[0], m.run(wb)[0]
+    assert torch.equal(c, d)
