@@ -508,3 +508,46 @@ def test_window_model_with_reference_default_dropout_gpu():
     m.eval()
     c, d = m.run(wb)[0], m.run(wb)[0]
     assert torch.equal(c, d)
+
+
+@pytest.mark.parametrize("module,rec_only", [("BiGRRGCN", True), ("GRRGCN", True), ("GRRGCN", False)])
+def test_reference_default_sizes_paths_agree_gpu(module, rec_only):
+    """The reference's default hyper-parameters (utils/args.py: embed = hidden = 128, n_bases = 128 -> 1x1 blocks, 15-step
+    windows): the restructured step and the reference-granular path (different kernels: streaming GEMMs, per-call GRU) agree
+    on outputs and gradients, and with the CPU test backend on the outputs."""
+    from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
+    from temp_amd.dynamic_rgcn import DynamicRGCN
+    from tests.window_cases import make_args, slice_snapshots
+    s = slice_snapshots()
+    args = make_args(module=module, rec_only_last_layer=rec_only, embed_size=128, hidden_size=128, n_bases=128, train_seq_len=15,
+                     test_seq_len=15)
+    cls = BiDynamicRGCN if module.startswith("Bi") else DynamicRGCN
+    torch.manual_seed(3)
+    m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(DEV)
+    t_list = torch.tensor([s["times"][i] for i in (20, 16, 11, 2)])
+    res = []
+    for batched in (True, False):
+        m.use_batched_path = batched
+        m.sample_rng = np.random.default_rng(4)
+        for p in m.parameters():
+            p.grad = None
+        wb = m.prepare(t_list, 15, train=True)
+        assert wb.batched == (batched and rec_only)
+        out = m.run(wb)[0]
+        (out * out).sum().backward()
+        res.append((out.detach().clone(), m.ent_embeds.grad.clone(), m.ent_encoder.layer_1.weight.grad.clone()))
+    assert_close(res[1][0], res[0][0], 2e-5, 2e-6, "outputs")
+    assert_close(res[1][1], res[0][1], 1e-4, 1e-5 * float(res[0][1].abs().max() + 1), "d ent_embeds")
+    assert_close(res[1][2], res[0][2], 1e-4, 1e-5 * float(res[0][2].abs().max() + 1), "d weight")
+    # same model on the CPU test backend (torch ops through the same views)
+    TB.set_backend(CpuTestBackend())
+    try:
+        mc = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
+        mc.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+        mc.use_batched_path = False
+        mc.sample_rng = np.random.default_rng(4)
+        with torch.no_grad():
+            want = mc.run(mc.prepare(t_list, 15, train=True))[0]
+    finally:
+        TB.set_backend(None)
+    assert_close(res[0][0], want, 2e-5, 2e-6, "outputs vs CPU test backend")
