@@ -296,6 +296,21 @@ int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* 
                        float inv_rows, const float* row_scale /* nullable [P]: per-row weight instead of inv_rows */, float* d_scores, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Filtered ranking (EvaluationFilter.calc_metrics_single_graph / perturb_and_get_rank / sort_and_rank,
+ * utils/evaluation.py:40-106).  scores [P, ld] = the P test triples scored against ALL N entities
+ * (temp_linear with the folded query, trans_b = 1).  The reference overwrites the scores of the other
+ * entities known to be true for the same (relation, known entity) with -10e6, applies a sigmoid and takes
+ * the index of the target in a descending torch.sort.  Here:
+ *   ranks[p] = 1 + #{ j : v_j > v_t  or  (v_j == v_t and j < target[p]) },
+ *   v_j = sigmoid(scores[p,j]),  or 0 for j in the row's filter list  filt_ids[filt_ptr[p] .. filt_ptr[p+1])
+ * (unique global ids; an entry equal to target[p] is ignored) -- the position in a STABLE descending order,
+ * so exact sigmoid ties resolve by entity id where the reference's unstable sort leaves them arbitrary.
+ * filt_ptr may be NULL (raw ranking); filt_ids may be NULL only when every list is empty.  ld % 4 == 0, ld >= N.  Integer output, deterministic.
+ * ---------------------------------------------------------------------------------------------- */
+int temp_filtered_rank(int P, int N, int ld, const float* scores, const int32_t* target, const int32_t* filt_ptr,
+                       const int32_t* filt_ids, int32_t* ranks, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * History attention of the self-attention encoder (SARGCNLayer.calc_result + attention,
  * models/SARGCN.py:25-53; callers models/SARGCN.py:39-62, models/SelfAttentionRGCN.py:88-96).
  * The reference builds a dense (n, T, D) tensor [history ..., current] (zero rows + a -10e9 additive

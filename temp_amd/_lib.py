@@ -88,6 +88,7 @@ SYMBOLS = {
     "temp_linear_tn": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, c_vp, _I, c_vp, _SZ, c_vp]),
     "temp_gather_ce_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gather_ce_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp]),
+    "temp_filtered_rank": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_fwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_bwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_copy_probe": (_I, [c_vp, c_vp, _SZ, c_vp]),

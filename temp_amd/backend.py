@@ -296,6 +296,19 @@ class HipBackend:
         _lib.check(rc, "temp_gather_ce_bwd")
         return d
 
+    def filtered_rank(self, scores, target, filt_ptr=None, filt_ids=None):
+        """1-indexed filtered ranks (int64) of `target` in every row of scores [P,N] (see temp_filtered_rank)."""
+        scores, target = _f32(scores, "scores"), _i32(target, "target")
+        P, N = scores.shape
+        if N % 4:
+            raise ValueError("filtered_rank: the score row length must be a multiple of 4")
+        ranks = torch.empty(P, dtype=torch.int32, device=scores.device)
+        if filt_ptr is not None:
+            filt_ptr, filt_ids = _i32(filt_ptr, "filt_ptr"), _i32(filt_ids, "filt_ids")
+        rc = self.lib.temp_filtered_rank(P, N, N, _ptr(scores), _ptr(target), _ptr(filt_ptr), _ptr(filt_ids), _ptr(ranks), _stream())
+        _lib.check(rc, "temp_filtered_rank")
+        return ranks.long()
+
     # ---- history attention (self-attention encoder) ------------------------------------------------------
     def _attn_desc(self, qkv, kv_hist, idx, decay):
         n, D3 = qkv.shape

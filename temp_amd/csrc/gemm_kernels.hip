@@ -480,6 +480,45 @@ __global__ void __launch_bounds__(256) k_gather_ce_fwd(int C, int N, const float
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Filtered rank of one test triple per workgroup (utils/evaluation.py:40-106): the reference sets the scores of the
+// other known-true entities to -10e6, applies a sigmoid and takes the target's position in a descending sort.
+// Position in a STABLE descending order = #(strictly larger) + #(equal with a smaller entity id) + 1, so nothing is
+// sorted: one pass over the score row counts, a second pass over the row's filter list replaces the contribution of
+// each filtered entity by that of sigmoid(-10e6) = 0.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rank_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ int rank_ahead(float v, int j, float ts, int tgt) { return (v > ts) | ((v == ts) & (j < tgt)); }
+
+__global__ void __launch_bounds__(256) k_filtered_rank(int N, int ld, const float* __restrict__ scores, const int32_t* __restrict__ target,
+                                                       const int32_t* __restrict__ filt_ptr, const int32_t* __restrict__ filt_ids,
+                                                       int32_t* __restrict__ ranks) {
+  __shared__ int red[4];
+  const int p = blockIdx.x;
+  const float* srow = scores + (size_t)p * ld;
+  const int tgt = target[p];
+  const float ts = rank_sigmoid(srow[tgt]);
+  int cnt = 0;
+  const int n4 = N & ~3;
+  for (int j = threadIdx.x * 4; j < n4; j += 1024) {
+    const float4 s = *reinterpret_cast<const float4*>(srow + j);
+    cnt += rank_ahead(rank_sigmoid(s.x), j, ts, tgt) + rank_ahead(rank_sigmoid(s.y), j + 1, ts, tgt)
+         + rank_ahead(rank_sigmoid(s.z), j + 2, ts, tgt) + rank_ahead(rank_sigmoid(s.w), j + 3, ts, tgt);
+  }
+  for (int j = n4 + threadIdx.x; j < N; j += 256) cnt += rank_ahead(rank_sigmoid(srow[j]), j, ts, tgt);
+  if (filt_ptr) {
+    for (int f = filt_ptr[p] + threadIdx.x; f < filt_ptr[p + 1]; f += 256) {
+      const int j = filt_ids[f];
+      if (j == tgt) continue;
+      cnt += rank_ahead(0.0f, j, ts, tgt) - rank_ahead(rank_sigmoid(srow[j]), j, ts, tgt);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) ranks[p] = red[0] + red[1] + red[2] + red[3] + 1;
+}
+
 // d_scores[p, :] = scale * sum_k (softmax_k - [k == 0]) e_{cand[p,k]}   (row built in LDS, written once)
 __global__ void __launch_bounds__(256) k_gather_ce_bwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
                                                        const float* __restrict__ lse_rows, const float* __restrict__ scale_ptr, float inv_rows,
@@ -761,6 +800,14 @@ int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* 
     if (hipFuncSetAttribute((const void*)k_gather_ce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEMP_E_LAUNCH;
   }
   TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_bwd, dim3(P), dim3(256), lds, (hipStream_t)stream, C, N, scores, cand, lse_rows, scale, inv_rows, row_scale, d_scores);
+  return launch_status();
+}
+
+int temp_filtered_rank(int P, int N, int ld, const float* scores, const int32_t* target, const int32_t* filt_ptr,
+                       const int32_t* filt_ids, int32_t* ranks, void* stream) {
+  if (P < 0 || N <= 0 || ld < N || ld % 4 || (P > 0 && (!scores || !target || !ranks))) return TEMP_E_BADARG;
+  if (P == 0) return TEMP_OK;
+  TEMP_LAUNCH(K_GATHER_CE, k_filtered_rank, dim3(P), dim3(256), 0, (hipStream_t)stream, N, ld, scores, target, filt_ptr, filt_ids, ranks);
   return launch_status();
 }
 

@@ -3,11 +3,19 @@
 ALL entities, mask the other entities known to be true for the same (relation, object) (resp.
 (subject, relation)) at that timestamp in train+valid+test, and report the 1-indexed rank.
 
-Vectorised: the known-true sets are sorted composite keys (searchsorted instead of per-triple Python
-dict lookups); the rank is the target's position in a stable descending order, computed by counting
-instead of sorting."""
+Restructured for the device:
+  * the known-true sets are sorted composite keys, the per-triple filter lists come out of two
+    `searchsorted` calls (no per-triple Python dict lookups) and are cached per (timestamp, split, mode)
+    on the device;
+  * DistMult / ComplEx are bilinear, so the P x N score matrix is ONE GEMM of the folded query against the
+    all-entity table (`temp_linear`), never a (P, N, D) broadcast;
+  * the rank is the target's position in a stable descending order, computed by counting
+    (`temp_filtered_rank`) instead of sorting."""
 import numpy as np
 import torch
+
+from . import scores as S
+from .backend import get_backend
 
 
 class EvaluationFilter:
@@ -16,6 +24,7 @@ class EvaluationFilter:
         self.calc_score = calc_score
         self.graph_dicts = (graph_dict_train, graph_dict_val, graph_dict_test)
         self._keys = {}
+        self._lists = {}
 
     def _true_keys(self, time, num_ent):
         """Sorted keys (h*R + r)*N + global(t) and (t*R + r)*N + global(h) over the three splits at `time`."""
@@ -31,18 +40,32 @@ class EvaluationFilter:
         return k
 
     @staticmethod
-    def _mask(prefix, keys, num_ent, target_global):
-        """Boolean (P, N) mask of the entities that form a known-true triple with `prefix`, target excluded."""
-        P = prefix.shape[0]
+    def filter_lists(prefix, keys, num_ent):
+        """CSR lists of the global entity ids that form a known-true triple with every `prefix`:
+        -> (ptr [P+1] int32, ids [ptr[-1]] int32), each row's ids unique and ascending."""
         lo = np.searchsorted(keys, prefix * num_ent, side="left")
         hi = np.searchsorted(keys, (prefix + 1) * num_ent, side="left")
         cnt = hi - lo
-        rows = np.repeat(np.arange(P), cnt)
-        pos = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if cnt.sum() else np.zeros(0, np.int64)
-        mask = np.zeros((P, num_ent), dtype=bool)
-        mask[rows, keys[pos] % num_ent] = True
-        mask[np.arange(P), target_global] = False
-        return mask
+        ptr = np.zeros(prefix.shape[0] + 1, dtype=np.int64)
+        np.cumsum(cnt, out=ptr[1:])
+        pos = np.repeat(lo - ptr[:-1], cnt) + np.arange(int(ptr[-1]), dtype=np.int64)
+        return ptr.astype(np.int32), (keys[pos] % num_ent).astype(np.int32)
+
+    def _mode_inputs(self, mode, samples_np, graph, time, num_ent, dev):
+        """(target [P], filt_ptr [P+1], filt_ids) on `dev` for one corruption mode; static per (time, graph), cached."""
+        key = (time, id(graph), mode, str(dev))
+        got = self._lists.get(key)
+        if got is None:
+            R, tails, heads = self._true_keys(time, num_ent)
+            gid = graph.gids
+            if mode == "tail":
+                prefix, keys, tgt = samples_np[:, 0] * R + samples_np[:, 1], tails, gid[samples_np[:, 2]]
+            else:
+                prefix, keys, tgt = samples_np[:, 2] * R + samples_np[:, 1], heads, gid[samples_np[:, 0]]
+            ptr, ids = self.filter_lists(prefix, keys, num_ent)
+            got = self._lists[key] = (torch.from_numpy(tgt.astype(np.int32)).to(dev), torch.from_numpy(ptr).to(dev),
+                                      torch.from_numpy(ids).to(dev))
+        return got
 
     def calc_metrics_single_graph(self, ent_mean, rel_enc_means, all_ent_embeds, samples, graph, time, eval_bz=100):
         """-> ranks (2P,) int64, subject-corruption ranks first, then object-corruption (reference order)."""
@@ -50,31 +73,39 @@ class EvaluationFilter:
             dev = all_ent_embeds.device
             num_ent = all_ent_embeds.shape[0]
             time = int(time)
+            P = samples.shape[0]
+            if P == 0:
+                return torch.zeros(0, dtype=torch.int64, device=dev)
             s_np = samples.detach().cpu().numpy().astype(np.int64)
-            R, tails, heads = self._true_keys(time, num_ent)
-            gid = graph.gids
+            name = getattr(self.args, "score_function", None)
+            fused = name in ("distmult", "complex") and num_ent % 4 == 0 and all_ent_embeds.shape[1] % 4 == 0
             out = {}
             for mode in ("head", "tail"):
-                if mode == "tail":
-                    prefix, keys, tgt = s_np[:, 0] * R + s_np[:, 1], tails, gid[s_np[:, 2]]
-                else:
-                    prefix, keys, tgt = s_np[:, 2] * R + s_np[:, 1], heads, gid[s_np[:, 0]]
-                mask = torch.from_numpy(self._mask(prefix, keys, num_ent, tgt)).to(dev)
-                target = torch.from_numpy(tgt).to(dev)
-                ent_index = torch.arange(num_ent, device=dev).view(1, -1)
+                target, ptr, ids = self._mode_inputs(mode, s_np, graph, time, num_ent, dev)
+                known = ent_mean[samples[:, 0] if mode == "tail" else samples[:, 2]]
+                r = rel_enc_means[samples[:, 1]]
+                if fused:
+                    q = S.bilinear_query(name, known, r, mode).contiguous()
+                    score = get_backend().linear(q, all_ent_embeds.contiguous(), True)
+                    out[mode] = get_backend().filtered_rank(score, target, ptr, ids)
+                    continue
                 ranks = []
-                for a in range(0, s_np.shape[0], eval_bz):
-                    b = min(s_np.shape[0], a + eval_bz)
-                    r = rel_enc_means[samples[a:b, 1]]
+                for a in range(0, P, eval_bz):
+                    b = min(P, a + eval_bz)
                     if mode == "tail":
-                        score = self.calc_score(ent_mean[samples[a:b, 0]], r, all_ent_embeds, mode="tail")
+                        score = self.calc_score(known[a:b], r[a:b], all_ent_embeds, mode="tail")
                     else:
-                        score = self.calc_score(all_ent_embeds, r, ent_mean[samples[a:b, 2]], mode="head")
-                    score = torch.sigmoid(torch.where(mask[a:b], torch.full_like(score, -10e6), score))
-                    ts = score.gather(1, target[a:b].view(-1, 1))
-                    # position in a stable descending sort: strictly better candidates, then equal-scored
-                    # candidates with a smaller entity id (sigmoid in fp32 produces real ties near 0.5)
-                    ahead = (score > ts) | ((score == ts) & (ent_index < target[a:b].view(-1, 1)))
-                    ranks.append(ahead.sum(dim=1) + 1)
-                out[mode] = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
+                        score = self.calc_score(all_ent_embeds, r[a:b], known[a:b], mode="head")
+                    lo, hi = int(ptr[a]), int(ptr[b])
+                    ranks.append(get_backend().filtered_rank(_pad4(score), target[a:b], ptr[a:b + 1] - lo, ids[lo:hi]))
+                out[mode] = torch.cat(ranks)
             return torch.cat([out["head"], out["tail"]])
+
+
+def _pad4(score):
+    """Score rows padded to a multiple of 4 columns with -inf (sigmoid 0 at ids above every target: never ahead)."""
+    n = score.shape[1]
+    if n % 4 == 0:
+        return score.contiguous()
+    pad = score.new_full((score.shape[0], 4 - n % 4), float("-inf"))
+    return torch.cat([score, pad], dim=1).contiguous()

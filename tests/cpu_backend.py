@@ -266,6 +266,21 @@ class CpuTestBackend:
         d.scatter_add_(1, c, g * w)
         return d
 
+    def filtered_rank(self, scores, target, filt_ptr=None, filt_ids=None):
+        s = scores.detach().clone()
+        P, N = s.shape
+        tgt = target.long()
+        if filt_ptr is not None:
+            ptr = filt_ptr.long()
+            rows = torch.repeat_interleave(torch.arange(P), ptr[1:] - ptr[:-1])
+            ids = filt_ids.long()
+            keep = ids != tgt[rows]
+            s[rows[keep], ids[keep]] = -10e6
+        v = torch.sigmoid(s)
+        tv = v.gather(1, tgt.view(-1, 1))
+        ahead = (v > tv) | ((v == tv) & (torch.arange(N).view(1, -1) < tgt.view(-1, 1)))
+        return ahead.sum(dim=1) + 1
+
     # ---- history attention (same sparse formulation as the kernel, dense torch ops) -------------------
     @staticmethod
     def _attn(qkv, kv_hist, idx, decay):

@@ -551,3 +551,31 @@ def test_reference_default_sizes_paths_agree_gpu(module, rec_only):
     finally:
         TB.set_backend(None)
     assert_close(res[0][0], want, 2e-5, 2e-6, "outputs vs CPU test backend")
+
+
+@pytest.mark.parametrize("P,N", [(37, 500), (200, 7128), (7475, 500), (5, 10488), (0, 500)])
+def test_filtered_rank_kernel_bit_exact(P, N):
+    """temp_filtered_rank vs the test backend's masked-sigmoid counting on the same score matrix.  Scores are multiples of
+    0.25 (distinct scores differ by far more than an ulp after the sigmoid, so only EXACT ties occur -- many of them) plus
+    saturated rows (|score| >= 20: sigmoid is exactly 1 resp. < 1e-8) and filter lists that contain the target."""
+    g = torch.Generator().manual_seed(P * 31 + N)
+    sc = torch.randint(-32, 33, (P, N), generator=g).float() * 0.25
+    if P:
+        sc[::3] = torch.randint(-3, 4, (sc[::3].shape[0], N), generator=g).float() * 20.0
+    tgt = torch.randint(0, N, (P,), generator=g).int()
+    cnt = torch.randint(0, 40, (P,), generator=g)
+    if P:
+        cnt[0] = 0
+    ptr = torch.zeros(P + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(cnt, 0).int()
+    ids = torch.cat([torch.randperm(N, generator=g)[:c].sort().values for c in cnt.tolist()] + [torch.zeros(0, dtype=torch.int64)]).int()
+    if P > 1:
+        ids[ptr[1]] = tgt[1]                                    # the target itself is listed: must be ignored
+    want = CpuTestBackend().filtered_rank(sc, tgt, ptr, ids)
+    got = TB.get_backend().filtered_rank(sc.to(DEV), tgt.to(DEV), ptr.to(DEV), ids.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    want_raw = CpuTestBackend().filtered_rank(sc, tgt)
+    got_raw = TB.get_backend().filtered_rank(sc.to(DEV), tgt.to(DEV)).cpu()
+    assert torch.equal(got_raw, want_raw)
+    if P:
+        assert int(got.min()) >= 1 and int(got.max()) <= N and bool((got <= got_raw).all())
