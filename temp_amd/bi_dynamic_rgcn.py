@@ -172,6 +172,9 @@ class BiDynamicRGCN(DynamicRGCN):
         plan_f = ChainPlan(wb.rows, self.graph_dict_train, self.num_ents, seq_len)
         plan_b = ChainPlan(rows_b, self.graph_dict_train, self.num_ents, seq_len).flipped()
         wb.plan = (plan_f, plan_b)
+        if train and self.random_dropout:
+            self.sample_history_graphs(plan_f)
+            self.sample_history_graphs(plan_b)
         wb.graphs = [self.graph_dict_train[r[-1]] for r in wb.rows]
         tgt = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
         wb.target, wb.target_b = self._bi_target(plan_f, plan_b, wb.rows, tgt)

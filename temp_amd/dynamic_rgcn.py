@@ -39,8 +39,10 @@ class DynamicRGCN(TKG_Module):
         self.rel_embeds = nn.Parameter(torch.Tensor(self.num_rels * 2, self.embed_size))
         self.edge_dropout = getattr(args, "edge_dropout", False)
         self.post_aggregation = getattr(args, "post_aggregation", False)
+        self.random_dropout = getattr(args, "random_dropout", False)
         if self.edge_dropout:
-            raise NotImplementedError("--edge-dropout (utils/DropEdge.py) is outside the hot-path scope (SURVEY section 2)")
+            raise NotImplementedError("--edge-dropout: the reference's DropEdge.sample_subgraph reads drop_rate_cache, which is never built "
+                                      "(utils/DropEdge.py:31-32,126); not on the hot path (SURVEY section 2)")
         nn.init.xavier_uniform_(self.ent_embeds, gain=nn.init.calculate_gain('relu'))
         nn.init.xavier_uniform_(self.rel_embeds, gain=nn.init.calculate_gain('relu'))
         self.sample_rng = np.random.default_rng(getattr(args, "seed", None))
@@ -77,6 +79,14 @@ class DynamicRGCN(TKG_Module):
             idx = edge_ids[i] if edge_ids is not None else self.sample_rng.choice(np.arange(E), size=int(rate * E), replace=False)
             out.append(g.edge_subgraph(idx))
         return out
+
+    def sample_history_graphs(self, plan, rate=0.8):
+        """--random-dropout: every training visit of a history snapshot runs on its own random 80 % of the edges, same
+        nodes, norms recomputed (get_per_graph_ent_embeds(full=False, rate=0.8) -> get_batch_graph_embeds,
+        models/DynamicRGCN.py:76-90,162-171).  Row maps depend only on the node sets, so the plan is unchanged."""
+        for st in plan.steps:
+            st.graphs = self.sample_target_graphs(st.graphs, rate)
+            st.graph = None
 
     def _target_step(self, plan, rows, graphs):
         L = plan.seq_len
@@ -166,6 +176,8 @@ class DynamicRGCN(TKG_Module):
         wb = WindowBatch()
         wb.rows = window_times(t_list, seq_len, self.total_time)
         wb.plan = ChainPlan(wb.rows, self.graph_dict_train, self.num_ents, seq_len)
+        if train and self.random_dropout:
+            self.sample_history_graphs(wb.plan)
         wb.graphs = [self.graph_dict_train[r[-1]] for r in wb.rows]
         tgt = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
         wb.target = self._target_step(wb.plan, wb.rows, tgt)

@@ -34,8 +34,6 @@ class SelfAttentionRGCN(DynamicRGCN):
         self.EMA = getattr(args, "EMA", False)
         if self.EMA:
             raise NotImplementedError("--EMA (models/SARGCN.py:64-81 stops in pdb.set_trace()) is outside the hot-path scope")
-        if getattr(args, "random_dropout", False):
-            raise NotImplementedError("--random-dropout (per-visit edge subsampling of the history) is outside the hot-path scope")
 
     def build_model(self):
         self.ent_encoder = SARGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
@@ -72,21 +70,26 @@ class SelfAttentionRGCN(DynamicRGCN):
         wb.target_sizes = [g.n for g in wb.targets]
         wb.target_times = [r[-1] for r in wb.rows]
         # distinct history snapshots, in first-use order
+        # (--random-dropout: every training visit is its own 80 % edge subsample, so visits are keyed per window)
+        resample = train and self.random_dropout
         node_row, hist_graphs, hist_ts, off = {}, [], [], 0
-        for times in wb.hist_times:
+        for b, times in enumerate(wb.hist_times):
             for t in times:
-                if t is not None and t not in node_row:
+                key = (b, t) if resample else t
+                if t is not None and key not in node_row:
                     g = self.graph_dict_train[t]
+                    if resample:
+                        g = self.sample_target_graphs([g], 0.8)[0]
                     m = np.full(N, -1, dtype=np.int32)
                     m[g.gids] = off + np.arange(g.n, dtype=np.int32)
-                    node_row[t] = m
+                    node_row[key] = m
                     hist_graphs.append(g)
                     hist_ts.append(t)
                     off += g.n
         wb.n_hist_rows = off
         none_row = np.full(N, -1, dtype=np.int32)
-        idx_all = [np.stack([node_row[t] if t is not None else none_row for t in times], axis=1) if times
-                   else np.zeros((N, 0), np.int32) for times in wb.hist_times]                     # bsz x (N, Th)
+        idx_all = [np.stack([node_row[(b, t) if resample else t] if t is not None else none_row for t in times], axis=1) if times
+                   else np.zeros((N, 0), np.int32) for b, times in enumerate(wb.hist_times)]                     # bsz x (N, Th)
         idx_tgt = [idx_all[b][g.gids] for b, g in enumerate(wb.targets)]
         all_graphs = hist_graphs + list(wb.targets)
         wb.g_all = S.batch(all_graphs)

@@ -217,3 +217,51 @@ def test_filtered_ranks_equal_masked_sort(score_function):
         want = torch.tensor(want)
         assert got.shape == want.shape
         assert (got == want).float().mean() > 0.97 and (got - want).abs().max() <= 2, (score_function, n_ent)
+
+
+@pytest.mark.parametrize("module", ["GRRGCN", "BiGRRGCN", "SARGCN"])
+def test_random_dropout_resamples_history_visits(module):
+    """--random-dropout (models/DynamicRGCN.py:162-171): every TRAINING visit of a history snapshot keeps a random
+    80 % of its edges with norms recomputed; evaluation and the node sets / row maps are untouched; the restructured
+    and the reference-granular paths see the same draws and agree."""
+    from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
+    from temp_amd.dynamic_rgcn import DynamicRGCN
+    from temp_amd.self_attention_rgcn import SelfAttentionRGCN
+    from tests.window_cases import make_args
+    s = slice_snapshots()
+    cls = {"GRRGCN": DynamicRGCN, "BiGRRGCN": BiDynamicRGCN, "SARGCN": SelfAttentionRGCN}[module]
+    args = make_args(module=module, rec_only_last_layer=True, embed_size=16, hidden_size=16, n_bases=4, train_seq_len=5, test_seq_len=5,
+                     random_dropout=True, use_time_embedding=(module == "SARGCN"))
+    torch.manual_seed(1)
+    m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
+    t_list = torch.tensor([s["times"][i] for i in (12, 9, 7)])
+    full = m.prepare(t_list, 5, train=False)
+    m.sample_rng = np.random.default_rng(8)
+    wb = m.prepare(t_list, 5, train=True)
+    if module == "SARGCN":
+        hist_full = full.g_all.number_of_edges() - sum(g.number_of_edges() for g in full.targets)
+        hist_drop = wb.g_all.number_of_edges() - sum(g.number_of_edges() for g in wb.targets)
+        visits = sum(1 for times in wb.hist_times for t in times if t is not None)
+        assert wb.n_hist_rows >= full.n_hist_rows                     # visits are no longer shared between windows
+        want = sum(int(0.8 * s["tr"][t].number_of_edges()) for times in wb.hist_times for t in times if t is not None)
+        assert hist_drop == want and visits > 0 and hist_full > 0
+    else:
+        plans = wb.plan if isinstance(wb.plan, tuple) else (wb.plan,)
+        fplans = full.plan if isinstance(full.plan, tuple) else (full.plan,)
+        for pl, fp in zip(plans, fplans):
+            for st, fs in zip(pl.steps, fp.steps):
+                assert [g.number_of_edges() for g in st.graphs] == [int(0.8 * g.number_of_edges()) for g in fs.graphs]
+                assert all(np.array_equal(a.gids, b.gids) for a, b in zip(st.graphs, fs.graphs))
+                assert np.array_equal(st.prev_idx, fs.prev_idx)
+                for g in st.graphs:                                   # norms recomputed from the subgraph's in-degrees
+                    deg = np.bincount(g.dst, minlength=g.n)
+                    assert np.allclose(g.nnorm, np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0))
+        outs = []
+        for batched in (True, False):
+            m.use_batched_path = batched
+            m.sample_rng = np.random.default_rng(8)
+            outs.append(m.run(m.prepare(t_list, 5, train=True))[0])
+        assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=2e-6)
+    loss = m.run_loss(wb)
+    loss.backward()
+    assert torch.isfinite(loss) and m.ent_embeds.grad.abs().sum() > 0
