@@ -276,6 +276,12 @@ int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, 
  * K, N, Ka, Nb and all leading dimensions must be multiples of 4.
  * ---------------------------------------------------------------------------------------------- */
 int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, void* stream);
+/* Several independent products of the same shape class in ONE launch sequence (up to 4 problems per launch):
+ *   C_i[M_i, N] = A_i[M_i, K] . B_i        same N, K, leading dimensions and transposition; M_i may differ.
+ * The per-window score matrices of the loss (every window scores against its own all-entity table) and their
+ * input gradients.  `probs` is a HOST array. */
+typedef struct TempLinearProblem { int M; const float* A; const float* B; float* C; } TempLinearProblem;
+int temp_linear_multi(int count, const TempLinearProblem* probs, int N, int K, int lda, int ldb, int trans_b, int ldc, void* stream);
 size_t temp_linear_tn_workspace(int M, int Ka, int Nb);
 int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo,
                    void* workspace, size_t workspace_bytes, void* stream);
@@ -294,6 +300,21 @@ int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* 
 int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* cand, float* loss_rows, float* lse_rows, void* stream);
 int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* cand, const float* lse_rows, const float* scale,
                        float inv_rows, const float* row_scale /* nullable [P]: per-row weight instead of inv_rows */, float* d_scores, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Folded query of the bilinear scorers, row gathers fused in (utils/scores.py:4-12 distmult, :26-44 complex;
+ * the s / r / o row selections of train_link_prediction, models/TKG_Module.py:202-213):
+ *   k = ent_rows[known_idx[p]], r = rel[rel_idx[p]]          (both [*, d] row-major, d % 4 == 0; complex: d % 8 == 0)
+ *   q[p] such that  score(p, candidate c) = <q[p], c>;  is_tail[p] != 0: k is the subject and candidates are
+ *   objects (mode 'tail'), else k is the object and candidates are subjects (mode 'head'; ignored by distmult).
+ *   bwd: per-row gradients d_known_rows[p], d_rel_rows[p] (the caller sums them over the index lists).
+ * ---------------------------------------------------------------------------------------------- */
+#define TEMP_SCORE_DISTMULT 0
+#define TEMP_SCORE_COMPLEX 1
+int temp_bilinear_query_fwd(int P, int d, int kind, const float* ent_rows, const int32_t* known_idx, const float* rel, const int32_t* rel_idx,
+                            const int32_t* is_tail, float* q, void* stream);
+int temp_bilinear_query_bwd(int P, int d, int kind, const float* ent_rows, const int32_t* known_idx, const float* rel, const int32_t* rel_idx,
+                            const int32_t* is_tail, const float* d_q, float* d_known_rows, float* d_rel_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Filtered ranking (EvaluationFilter.calc_metrics_single_graph / perturb_and_get_rank / sort_and_rank,

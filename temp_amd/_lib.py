@@ -51,6 +51,12 @@ class TempAttn(ctypes.Structure):
                 ("kc", c_vp), ("vc", c_vp), ("ldc", ctypes.c_int32), ("idx", c_vp), ("decay", c_vp)]
 
 
+class TempLinearProblem(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int32), ("A", c_vp), ("B", c_vp), ("C", c_vp)]
+
+
+SCORE_KINDS = {"distmult": 0, "complex": 1}
+
 # name -> (restype, argtypes); mirrors include/temp_amd.h one to one
 _G = ctypes.POINTER(TempGraph)
 _I, _F, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -84,10 +90,13 @@ SYMBOLS = {
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_segment_sum_rows": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_linear": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, _I, c_vp, _I, c_vp]),
+    "temp_linear_multi": (_I, [_I, ctypes.POINTER(TempLinearProblem), _I, _I, _I, _I, _I, _I, c_vp]),
     "temp_linear_tn_workspace": (_SZ, [_I, _I, _I]),
     "temp_linear_tn": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, c_vp, _I, c_vp, _SZ, c_vp]),
     "temp_gather_ce_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gather_ce_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp]),
+    "temp_bilinear_query_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_bilinear_query_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_filtered_rank": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_fwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_bwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, _I, c_vp, c_vp, c_vp, c_vp]),

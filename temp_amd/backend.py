@@ -266,12 +266,57 @@ class HipBackend:
         _lib.check(rc, "temp_linear")
         return c
 
-    def linear_tn(self, a, b):
-        """a[M,Ka]^T . b[M,Nb] -> [Ka,Nb]."""
+    def linear_multi(self, a_list, b_list, trans_b, out):
+        """out rows [r_i, r_i + M_i) = a_i[M_i,K] . b_i  for every problem i, r_i = running row offset: the per-window
+        products of the loss in ceil(count / 4) launches.  `out` is a preallocated (sum M_i, N) matrix."""
+        K = a_list[0].shape[1]
+        N = out.shape[1]
+        arr = (_lib.TempLinearProblem * len(a_list))()
+        row, keep = 0, []
+        for i, (a, b) in enumerate(zip(a_list, b_list)):
+            a, b = _f32(a, "a"), _f32(b, "b")
+            keep.append((a, b))
+            if a.shape[1] != K or b.shape != ((N, K) if trans_b else (K, N)):
+                raise ValueError("linear_multi: problems must share N, K and the layout of b")
+            arr[i].M, arr[i].A, arr[i].B = a.shape[0], a.data_ptr(), b.data_ptr()
+            arr[i].C = out.data_ptr() + row * N * 4
+            row += a.shape[0]
+        if row != out.shape[0] or not out.is_contiguous():
+            raise ValueError("linear_multi: out must be a contiguous (sum M_i, N) matrix")
+        rc = self.lib.temp_linear_multi(len(a_list), arr, N, K, K, K if trans_b else N, int(trans_b), N, _stream())
+        _lib.check(rc, "temp_linear_multi")
+        return out
+
+    def bilinear_query_fwd(self, kind, ent_rows, known_idx, rel, rel_idx, is_tail):
+        ent_rows, rel = _f32(ent_rows, "ent_rows"), _f32(rel, "rel")
+        known_idx, rel_idx, is_tail = _i32(known_idx, "known_idx"), _i32(rel_idx, "rel_idx"), _i32(is_tail, "is_tail")
+        P, d = known_idx.shape[0], ent_rows.shape[1]
+        q = torch.empty(P, d, dtype=torch.float32, device=ent_rows.device)
+        rc = self.lib.temp_bilinear_query_fwd(P, d, _lib.SCORE_KINDS[kind], _ptr(ent_rows), _ptr(known_idx), _ptr(rel), _ptr(rel_idx), _ptr(is_tail),
+                                              _ptr(q), _stream())
+        _lib.check(rc, "temp_bilinear_query_fwd")
+        return q
+
+    def bilinear_query_bwd(self, kind, ent_rows, known_idx, rel, rel_idx, is_tail, d_q):
+        ent_rows, rel, d_q = _f32(ent_rows, "ent_rows"), _f32(rel, "rel"), _f32(d_q, "d_q")
+        known_idx, rel_idx, is_tail = _i32(known_idx, "known_idx"), _i32(rel_idx, "rel_idx"), _i32(is_tail, "is_tail")
+        P, d = known_idx.shape[0], ent_rows.shape[1]
+        dk = torch.empty(P, d, dtype=torch.float32, device=ent_rows.device)
+        dr = torch.empty(P, d, dtype=torch.float32, device=ent_rows.device)
+        rc = self.lib.temp_bilinear_query_bwd(P, d, _lib.SCORE_KINDS[kind], _ptr(ent_rows), _ptr(known_idx), _ptr(rel), _ptr(rel_idx), _ptr(is_tail),
+                                              _ptr(d_q), _ptr(dk), _ptr(dr), _stream())
+        _lib.check(rc, "temp_bilinear_query_bwd")
+        return dk, dr
+
+    def linear_tn(self, a, b, out=None):
+        """a[M,Ka]^T . b[M,Nb] -> [Ka,Nb] (written into `out`, a contiguous (Ka, Nb) view, when given)."""
         a, b = _f32(a, "a"), _f32(b, "b")
         M, Ka = a.shape
         Nb = b.shape[1]
-        out = torch.empty(Ka, Nb, dtype=torch.float32, device=a.device)
+        if out is None:
+            out = torch.empty(Ka, Nb, dtype=torch.float32, device=a.device)
+        elif out.shape != (Ka, Nb) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("linear_tn: out must be a contiguous float32 (Ka, Nb) matrix")
         ws = self._ws(self.lib.temp_linear_tn_workspace(M, Ka, Nb), a.device)
         rc = self.lib.temp_linear_tn(M, Ka, Nb, _ptr(a), Ka, _ptr(b), Nb, _ptr(out), Nb, _ptr(ws), ws.numel(), _stream())
         _lib.check(rc, "temp_linear_tn")

@@ -481,6 +481,55 @@ __global__ void __launch_bounds__(256) k_gather_ce_fwd(int C, int N, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// Folded query of the bilinear scorers (utils/scores.py:4-12 DistMult, :26-44 ComplEx), with the two row gathers
+// fused in:  k = ent_rows[known_idx[p]],  r = rel[rel_idx[p]],
+//   DistMult            q = k * r
+//   ComplEx, tail mode  q = [re_k re_r - im_k im_r | re_k im_r + im_k re_r]      (k is the subject, candidates are objects)
+//   ComplEx, head mode  q = [re_r re_k + im_r im_k | re_r im_k - im_r re_k]      (k is the object, candidates are subjects)
+// so that score(candidate c) = <q, c>.  One thread per float4 of the half width; the backward writes the per-row
+// gradients of k and r (the caller reduces them over the static index lists with temp_segment_sum_rows).
+// ---------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bilinear_query(int P, int d, int kind, const float* __restrict__ ent_rows, const int32_t* __restrict__ known_idx,
+                                                        const float* __restrict__ rel, const int32_t* __restrict__ rel_idx,
+                                                        const int32_t* __restrict__ is_tail, const float* __restrict__ dq, float* __restrict__ o0,
+                                                        float* __restrict__ o1) {
+  const int half = kind == TEMP_SCORE_COMPLEX ? d / 2 : d;
+  const int g4 = half / 4;
+  const size_t total = (size_t)P * g4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i / g4), j = (int)(i - (size_t)p * g4) * 4;
+    const float* k = ent_rows + (size_t)known_idx[p] * d + j;
+    const float* r = rel + (size_t)rel_idx[p] * d + j;
+    const size_t o = (size_t)p * d + j;
+    if (kind != TEMP_SCORE_COMPLEX) {
+      const float4 kv = ld4(k), rv = ld4(r);
+      if (!BWD) {
+        st4(o0 + o, make_float4(kv.x * rv.x, kv.y * rv.y, kv.z * rv.z, kv.w * rv.w));
+      } else {
+        const float4 g = ld4(dq + o);
+        st4(o0 + o, make_float4(g.x * rv.x, g.y * rv.y, g.z * rv.z, g.w * rv.w));
+        st4(o1 + o, make_float4(g.x * kv.x, g.y * kv.y, g.z * kv.z, g.w * kv.w));
+      }
+      continue;
+    }
+    const float4 rk = ld4(k), ik = ld4(k + half), rr = ld4(r), ir = ld4(r + half);
+    const float sg = is_tail[p] ? 1.f : -1.f;       // tail: q1 = rk rr - ik ir, q2 = rk ir + ik rr;  head: q1 = rk rr + ik ir, q2 = ik rr - rk ir
+    if (!BWD) {
+      st4(o0 + o, make_float4(rk.x * rr.x - sg * ik.x * ir.x, rk.y * rr.y - sg * ik.y * ir.y, rk.z * rr.z - sg * ik.z * ir.z, rk.w * rr.w - sg * ik.w * ir.w));
+      st4(o0 + o + half, make_float4(ik.x * rr.x + sg * rk.x * ir.x, ik.y * rr.y + sg * rk.y * ir.y, ik.z * rr.z + sg * rk.z * ir.z, ik.w * rr.w + sg * rk.w * ir.w));
+    } else {
+      const float4 a = ld4(dq + o), b = ld4(dq + o + half);
+      // q1 = rk rr - sg ik ir ; q2 = ik rr + sg rk ir
+      st4(o0 + o, make_float4(a.x * rr.x + sg * b.x * ir.x, a.y * rr.y + sg * b.y * ir.y, a.z * rr.z + sg * b.z * ir.z, a.w * rr.w + sg * b.w * ir.w));                 // d re_k
+      st4(o0 + o + half, make_float4(b.x * rr.x - sg * a.x * ir.x, b.y * rr.y - sg * a.y * ir.y, b.z * rr.z - sg * a.z * ir.z, b.w * rr.w - sg * a.w * ir.w));          // d im_k
+      st4(o1 + o, make_float4(a.x * rk.x + b.x * ik.x, a.y * rk.y + b.y * ik.y, a.z * rk.z + b.z * ik.z, a.w * rk.w + b.w * ik.w));                                     // d re_r
+      st4(o1 + o + half, make_float4(sg * (b.x * rk.x - a.x * ik.x), sg * (b.y * rk.y - a.y * ik.y), sg * (b.z * rk.z - a.z * ik.z), sg * (b.w * rk.w - a.w * ik.w)));  // d im_r
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Filtered rank of one test triple per workgroup (utils/evaluation.py:40-106): the reference sets the scores of the
 // other known-true entities to -10e6, applies a sigmoid and takes the target's position in a descending sort.
 // Position in a STABLE descending order = #(strictly larger) + #(equal with a smaller entity id) + 1, so nothing is
@@ -772,6 +821,55 @@ int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, in
   if (M < 0 || N <= 0 || K <= 0 || !B || (M > 0 && (!A || !C))) return TEMP_E_BADARG;
   if (ldc % 4) return TEMP_E_UNSUPPORTED;
   return launch_gemm_panel(K_GEMM_LINEAR, M, N, K, A, lda, nullptr, B, ldb, trans_b, EpiPlainStore{C, ldc}, (hipStream_t)stream);
+}
+
+static int bilinear_query_args(int P, int d, int kind, const void* a, const void* b, const void* c, const void* e, const void* f) {
+  if (P < 0 || d <= 0 || (kind != TEMP_SCORE_DISTMULT && kind != TEMP_SCORE_COMPLEX)) return TEMP_E_BADARG;
+  if (kind == TEMP_SCORE_COMPLEX ? d % 8 : d % 4) return TEMP_E_UNSUPPORTED;
+  if (P > 0 && (!a || !b || !c || !e || (kind == TEMP_SCORE_COMPLEX && !f))) return TEMP_E_BADARG;
+  return TEMP_OK;
+}
+
+int temp_bilinear_query_fwd(int P, int d, int kind, const float* ent_rows, const int32_t* known_idx, const float* rel, const int32_t* rel_idx,
+                            const int32_t* is_tail, float* q, void* stream) {
+  int rc = bilinear_query_args(P, d, kind, ent_rows, known_idx, rel, rel_idx, is_tail);
+  if (rc != TEMP_OK || P == 0) return rc;
+  if (!q) return TEMP_E_BADARG;
+  int grid = ceil_div((long long)P * (d / 4), 256);
+  if (grid > 8192) grid = 8192;
+  TEMP_LAUNCH(K_GATHER_CE, k_bilinear_query<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, P, d, kind, ent_rows, known_idx, rel, rel_idx, is_tail,
+              (const float*)nullptr, q, (float*)nullptr);
+  return launch_status();
+}
+
+int temp_bilinear_query_bwd(int P, int d, int kind, const float* ent_rows, const int32_t* known_idx, const float* rel, const int32_t* rel_idx,
+                            const int32_t* is_tail, const float* d_q, float* d_known_rows, float* d_rel_rows, void* stream) {
+  int rc = bilinear_query_args(P, d, kind, ent_rows, known_idx, rel, rel_idx, is_tail);
+  if (rc != TEMP_OK || P == 0) return rc;
+  if (!d_q || !d_known_rows || !d_rel_rows) return TEMP_E_BADARG;
+  int grid = ceil_div((long long)P * (d / 4), 256);
+  if (grid > 8192) grid = 8192;
+  TEMP_LAUNCH(K_GATHER_CE, k_bilinear_query<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, P, d, kind, ent_rows, known_idx, rel, rel_idx, is_tail,
+              d_q, d_known_rows, d_rel_rows);
+  return launch_status();
+}
+
+int temp_linear_multi(int count, const TempLinearProblem* probs, int N, int K, int lda, int ldb, int trans_b, int ldc, void* stream) {
+  if (count < 0 || N <= 0 || K <= 0 || (count > 0 && !probs)) return TEMP_E_BADARG;
+  if (ldc % 4) return TEMP_E_UNSUPPORTED;
+  for (int i = 0; i < count; ++i)
+    if (probs[i].M < 0 || !probs[i].B || (probs[i].M > 0 && (!probs[i].A || !probs[i].C))) return TEMP_E_BADARG;
+  for (int i0 = 0; i0 < count; i0 += PANEL_MAXP) {
+    const int n = count - i0 < PANEL_MAXP ? count - i0 : PANEL_MAXP;
+    PanelBatch<EpiPlainStore> batch;
+    for (int i = 0; i < PANEL_MAXP; ++i) {
+      const TempLinearProblem& q = probs[i0 + (i < n ? i : 0)];
+      batch.p[i] = PanelProblem<EpiPlainStore>{i < n ? q.M : 0, q.A, nullptr, q.B, EpiPlainStore{q.C, ldc}};
+    }
+    const int rc = launch_gemm_panel_multi(K_GEMM_LINEAR, batch, n, N, K, lda, ldb, trans_b, (hipStream_t)stream);
+    if (rc != TEMP_OK) return rc;
+  }
+  return TEMP_OK;
 }
 
 size_t temp_linear_tn_workspace(int M, int Ka, int Nb) { return (M < 0 || Ka <= 0 || Nb <= 0) ? 0 : gemm_tn_workspace(M, Ka, Nb) + 256; }

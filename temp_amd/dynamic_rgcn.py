@@ -317,18 +317,17 @@ class DynamicRGCN(TKG_Module):
         return wb.all_maps
 
     def _assemble_all(self, wb, out, isolated):
-        """-> list of per-window (N_ents, D) views: active rows from `out` (concatenated target rows), the rest from the
-        isolated pass (None when every entity is active in its window's target graph)."""
+        """-> (B, N_ents, D): per window the active rows from `out` (concatenated target rows), the rest from the
+        isolated pass (None when every entity is active in its window's target graph).  One gather through a static map."""
         src = out if isolated is None else torch.cat([out, isolated], dim=0)
         big = TF.gather_rows(src, wb.assemble, wb.assemble_inv)
-        N = self.num_ents
-        return [big[b * N:(b + 1) * N] for b in range(len(wb.graphs))]
+        return big.view(len(wb.graphs), self.num_ents, big.shape[1])
 
     def all_embeds_batched(self, wb, out, hist):
         """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64): with only the last layer recurrent the
         isolated RGCN trunk e -> Iso2(Iso1(e)) is the same for every window, so it runs ONCE over the N_ents entities; the
         GRU then runs once over the inactive entities of all windows, each window reading its own previous states through its
-        row map.  `out` = the concatenated target rows of the encoder.  Returns a list of (N_ents, D)."""
+        row map.  `out` = the concatenated target rows of the encoder.  Returns (B, N_ents, D)."""
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
         (idx, dt), = self._all_maps(wb)
@@ -356,7 +355,7 @@ class DynamicRGCN(TKG_Module):
             cache = getattr(wb, "_loss_inputs", None)
             if cache is None or cache[0] is not samples:          # index tensors are static for a given sample set
                 offs = np.concatenate([[0], np.cumsum(wb.target.sizes)])[:-1]
-                cache = wb._loss_inputs = (samples, self.loss_inputs([int(o) for o in offs], samples, dev))
+                cache = wb._loss_inputs = (samples, self.loss_inputs([int(o) for o in offs], samples, dev, out.shape[0], self.rel_embeds.shape[0]))
             fused = self.batched_link_prediction(out, cache[1], all_list)
             if fused is not None:
                 return fused

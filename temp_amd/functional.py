@@ -203,6 +203,50 @@ class _BatchedCandidateCEFn(torch.autograd.Function):
         return (d_query, None, None, None) + d_all
 
 
+class _BatchedLinkPredictionFn(torch.autograd.Function):
+    """The whole batched link-prediction loss as ONE autograd node:
+        q      = bilinear_query(ent_rows[known], rel[rel_idx])                 (gathers fused, temp_bilinear_query_fwd)
+        scores = q[rows of window b] . all_b^T   for every window b             (temp_linear_multi, 4 windows per launch)
+        loss   = sum_rows w_row * CE(scores[row, cand[row, :]], label 0)        (temp_gather_ce_fwd)
+    `big` is the (B * N, D) stack of the windows' all-entity matrices.  The backward mirrors it and reduces the per-row
+    gradients of the gathered operands with deterministic segment sums over the static index lists."""
+
+    @staticmethod
+    def forward(ctx, ent_rows, rel, big, kind, inp):
+        be = get_backend()
+        N = big.shape[0] // len(inp["splits"])
+        q = be.bilinear_query_fwd(kind, ent_rows, inp["known"], rel, inp["rel"], inp["is_tail"])
+        live = [(b, a0, a1) for b, (a0, a1) in enumerate(inp["splits"]) if a1 > a0]
+        scores = torch.empty(q.shape[0], N, dtype=torch.float32, device=q.device)
+        be.linear_multi([q[a0:a1] for _, a0, a1 in live], [big[b * N:(b + 1) * N] for b, _, _ in live], True, scores)
+        loss_rows, lse = be.gather_ce_fwd(scores, inp["cand"])
+        ctx.save_for_backward(ent_rows, rel, big, q, scores, lse)
+        ctx.kind, ctx.inp, ctx.live, ctx.N = kind, inp, live, N
+        return (loss_rows * inp["weights"]).sum()
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        ent_rows, rel, big, q, scores, lse = ctx.saved_tensors
+        inp, live, N = ctx.inp, ctx.live, ctx.N
+        be = get_backend()
+        d_scores = be.gather_ce_bwd(scores, inp["cand"], lse, d_loss.reshape(1).contiguous(), 1.0, inp["weights"])
+        d_q = torch.empty_like(q)
+        be.linear_multi([d_scores[a0:a1] for _, a0, a1 in live], [big[b * N:(b + 1) * N] for b, _, _ in live], False, d_q)
+        d_big = torch.empty_like(big) if len(live) == len(inp["splits"]) else torch.zeros_like(big)
+        for b, a0, a1 in live:
+            be.linear_tn(d_scores[a0:a1], q[a0:a1], out=d_big[b * N:(b + 1) * N])
+        dk, dr = be.bilinear_query_bwd(ctx.kind, ent_rows, inp["known"], rel, inp["rel"], inp["is_tail"], d_q)
+        d_ent = be.segment_sum_rows(dk, inp["known_inv"][0], inp["known_inv"][1], ent_rows.shape[0])
+        d_rel = be.segment_sum_rows(dr, inp["rel_inv"][0], inp["rel_inv"][1], rel.shape[0])
+        return d_ent, d_rel, d_big, None, None
+
+
+def batched_link_prediction(ent_rows, rel, big, kind, inputs):
+    """sum over windows of CE_tail + CE_head (models/DynamicRGCN.py:186-193) for a bilinear scorer `kind`
+    ('distmult' | 'complex'); `inputs` = TKG_Module.loss_inputs(...)."""
+    return _BatchedLinkPredictionFn.apply(ent_rows, rel, big, kind, inputs)
+
+
 def candidate_cross_entropy_batched(query, cand, splits, row_w, all_embeds):
     """query (R, D), cand (R, C) int32, splits = [(row_begin, row_end)] per window, row_w (R,) = weight of every row's loss
     (1 / P_b for a mean per window and direction), all_embeds = list of (N, D) per window."""

@@ -153,7 +153,7 @@ class SelfAttentionRGCN(DynamicRGCN):
 
     def all_embeds_batched(self, wb, out, tables):
         """get_all_embeds_Gt for every window at once (models/SelfAttentionRGCN.py:28-45 with
-        SARGCN.forward_isolated, models/SARGCN.py:119-125) -> list of (N_ents, D).  `out` = the concatenated target rows;
+        SARGCN.forward_isolated, models/SARGCN.py:119-125) -> (B, N_ents, D).  `out` = the concatenated target rows;
         the isolated pass runs only over the entities that are inactive in their window's target graph."""
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
@@ -189,7 +189,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         cache = getattr(wb, "_loss_inputs", None)
         if cache is None or cache[0] is not samples:
             offs = np.concatenate([[0], np.cumsum(wb.target_sizes)])[:-1]
-            cache = wb._loss_inputs = (samples, self.loss_inputs([int(o) for o in offs], samples, dev))
+            cache = wb._loss_inputs = (samples, self.loss_inputs([int(o) for o in offs], samples, dev, out.shape[0], self.rel_embeds.shape[0]))
         fused = self.batched_link_prediction(out, cache[1], all_list)
         if fused is not None:
             return fused

@@ -94,9 +94,10 @@ class TKG_Module(nn.Module):
                 + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False))
 
     @staticmethod
-    def loss_inputs(row_offsets, samples, dev):
+    def loss_inputs(row_offsets, samples, dev, n_rows=None, n_rel_rows=None):
         """Index tensors of the batched loss for one set of samples (static for a prepared batch, so callers cache it):
-        per graph the stacked operand is [tail queries (P rows); head queries (P rows)]."""
+        per graph the stacked operand is [tail queries (P rows); head queries (P rows)].  `n_rows` / `n_rel_rows` (the row
+        counts of the target-embedding stack and of rel_embeds) add the inverse maps the deterministic backward reduces over."""
         known, rel, tail, cand, splits, weights = [], [], [], [], [], []
         row = 0
         for b, (trip, neg_tail, neg_head) in enumerate(samples):
@@ -107,32 +108,37 @@ class TKG_Module(nn.Module):
             t = trip.to(dev)
             known.append(torch.cat([t[:, 0], t[:, 2]]) + row_offsets[b])
             rel.append(torch.cat([t[:, 1], t[:, 1]]))
-            tail.append(torch.cat([torch.ones(P, dtype=torch.bool, device=dev), torch.zeros(P, dtype=torch.bool, device=dev)]))
+            tail.append(torch.cat([torch.ones(P, dtype=torch.int32, device=dev), torch.zeros(P, dtype=torch.int32, device=dev)]))
             cand.append(neg_tail.to(dev)); cand.append(neg_head.to(dev))
             splits.append((row, row + 2 * P))
             weights.append(torch.full((2 * P,), 1.0 / P, dtype=torch.float32, device=dev))
             row += 2 * P
         if row == 0:
             return None
-        return dict(known=torch.cat(known).to(torch.int32).contiguous(), rel=torch.cat(rel).to(torch.int32).contiguous(),
-                    is_tail=torch.cat(tail).view(-1, 1), cand=torch.cat(cand, dim=0).to(torch.int32).contiguous(), splits=splits,
-                    weights=torch.cat(weights))
+        out = dict(known=torch.cat(known).to(torch.int32).contiguous(), rel=torch.cat(rel).to(torch.int32).contiguous(),
+                   is_tail=torch.cat(tail).contiguous(), cand=torch.cat(cand, dim=0).to(torch.int32).contiguous(), splits=splits,
+                   weights=torch.cat(weights))
+        if n_rows is not None:
+            from . import functional as TF
+            out["known_inv"] = TF.gather_inverse(out["known"].cpu().numpy(), n_rows, dev)
+            out["rel_inv"] = TF.gather_inverse(out["rel"].cpu().numpy(), n_rel_rows, dev)
+        return out
 
-    def batched_link_prediction(self, ent_rows, inputs, all_embeds_list):
-        """Sum over the target graphs of loss_tail + loss_head (models/DynamicRGCN.py:186-193) with everything that is
-        row-wise done ONCE over all graphs' positives: `ent_rows` is the concatenation of the per-graph target embeddings,
-        `inputs` = loss_inputs(...).  Returns None when the scorer is not bilinear (caller takes the per-graph path)."""
+    def batched_link_prediction(self, ent_rows, inputs, all_embeds):
+        """Sum over the target graphs of loss_tail + loss_head (models/DynamicRGCN.py:186-193) as one fused node
+        (functional.batched_link_prediction): `ent_rows` is the concatenation of the per-graph target embeddings,
+        `inputs` = loss_inputs(..., n_rows, n_rel_rows), `all_embeds` the (B * N_ents, D) stack of the windows' all-entity
+        matrices (or a list of B (N_ents, D) matrices).  Returns None when the scorer is not bilinear or the shapes are
+        outside the kernels' alignment (the caller takes the per-graph path)."""
         name = self.args.score_function
-        if not (self.fused_loss and name in ("distmult", "complex") and all_embeds_list[0].shape[0] % 4 == 0):
+        D = ent_rows.shape[1]
+        if not (self.fused_loss and name in ("distmult", "complex") and self.num_ents % 4 == 0 and D % (8 if name == "complex" else 4) == 0):
             return None
         if inputs is None:
             return ent_rows.sum() * 0.0
         from . import functional as TF
-        known = TF.gather_rows(ent_rows, inputs["known"])
-        r = TF.gather_rows(self.rel_embeds, inputs["rel"])
-        q = torch.where(inputs["is_tail"], scores.bilinear_query(name, known, r, "tail"), scores.bilinear_query(name, known, r, "head"))
-        return TF.candidate_cross_entropy_batched(q.contiguous(), inputs["cand"], inputs["splits"], inputs["weights"],
-                                                  [e.contiguous() for e in all_embeds_list])
+        big = all_embeds if torch.is_tensor(all_embeds) else torch.cat(list(all_embeds), dim=0)
+        return TF.batched_link_prediction(ent_rows, self.rel_embeds, big.reshape(-1, D).contiguous(), name, inputs)
 
     def link_classification_loss(self, ent_embed, rel_embeds, triplets, labels):
         score = self.calc_score(ent_embed[triplets[:, 0]], rel_embeds[triplets[:, 1]], ent_embed[triplets[:, 2]])

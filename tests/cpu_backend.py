@@ -249,8 +249,43 @@ class CpuTestBackend:
     def linear(self, a, b, trans_b):
         return torch.mm(a.detach(), b.detach().t() if trans_b else b.detach())
 
-    def linear_tn(self, a, b):
-        return torch.mm(a.detach().t(), b.detach())
+    def linear_tn(self, a, b, out=None):
+        r = torch.mm(a.detach().t(), b.detach())
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def linear_multi(self, a_list, b_list, trans_b, out):
+        row = 0
+        for a, b in zip(a_list, b_list):
+            out[row:row + a.shape[0]] = torch.mm(a.detach(), b.detach().t() if trans_b else b.detach())
+            row += a.shape[0]
+        return out
+
+    @staticmethod
+    def _bq(kind, ent_rows, known_idx, rel, rel_idx, is_tail):
+        from temp_amd import scores as SC
+        k = ent_rows[known_idx.long()]
+        r = rel[rel_idx.long()]
+        if kind == "distmult":
+            return SC.bilinear_query(kind, k, r, "tail")
+        return torch.where(is_tail.view(-1, 1) != 0, SC.bilinear_query(kind, k, r, "tail"), SC.bilinear_query(kind, k, r, "head"))
+
+    def bilinear_query_fwd(self, kind, ent_rows, known_idx, rel, rel_idx, is_tail):
+        return self._bq(kind, ent_rows.detach(), known_idx, rel.detach(), rel_idx, is_tail)
+
+    def bilinear_query_bwd(self, kind, ent_rows, known_idx, rel, rel_idx, is_tail, d_q):
+        k = ent_rows.detach()[known_idx.long()].requires_grad_(True)
+        r = rel.detach()[rel_idx.long()].requires_grad_(True)
+        from temp_amd import scores as SC
+        with torch.enable_grad():
+            if kind == "distmult":
+                q = SC.bilinear_query(kind, k, r, "tail")
+            else:
+                q = torch.where(is_tail.view(-1, 1) != 0, SC.bilinear_query(kind, k, r, "tail"), SC.bilinear_query(kind, k, r, "head"))
+            dk, dr = torch.autograd.grad(q, (k, r), d_q)
+        return dk, dr
 
     def gather_ce_fwd(self, scores, cand):
         logits = scores.detach().gather(1, cand.long())

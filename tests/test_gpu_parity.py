@@ -579,3 +579,58 @@ def test_filtered_rank_kernel_bit_exact(P, N):
     assert torch.equal(got_raw, want_raw)
     if P:
         assert int(got.min()) >= 1 and int(got.max()) <= N and bool((got <= got_raw).all())
+
+
+@pytest.mark.parametrize("kind,D", [("complex", 200), ("distmult", 200), ("complex", 32), ("distmult", 36)])
+def test_bilinear_query_kernels_vs_scores_module(kind, D):
+    """temp_bilinear_query_fwd / _bwd (row gathers fused) vs temp_amd.scores.bilinear_query + autograd on the CPU."""
+    g = torch.Generator().manual_seed(D)
+    n_rows, R2, P = 700, 40, 1531
+    ent = torch.randn(n_rows, D, generator=g)
+    rel = torch.randn(R2, D, generator=g)
+    known = torch.randint(0, n_rows, (P,), generator=g).int()
+    ridx = torch.randint(0, R2, (P,), generator=g).int()
+    tail = (torch.rand(P, generator=g) < 0.5).int()
+    dq = torch.randn(P, D, generator=g)
+    ref = CpuTestBackend()
+    want = ref.bilinear_query_fwd(kind, ent, known, rel, ridx, tail)
+    wdk, wdr = ref.bilinear_query_bwd(kind, ent, known, rel, ridx, tail, dq)
+    be = TB.get_backend()
+    dev = lambda t: t.to(DEV)
+    got = be.bilinear_query_fwd(kind, dev(ent), dev(known), dev(rel), dev(ridx), dev(tail))
+    gdk, gdr = be.bilinear_query_bwd(kind, dev(ent), dev(known), dev(rel), dev(ridx), dev(tail), dev(dq))
+    assert_close(got, want, 1e-6, 1e-6, "query")
+    assert_close(gdk, wdk, 1e-6, 1e-6, "d known rows")
+    assert_close(gdr, wdr, 1e-6, 1e-6, "d rel rows")
+    # the folded query reproduces the scorer on explicit candidates (utils/scores.py semantics)
+    from temp_amd import scores as SC
+    cand = torch.randn(P, 3, D, generator=g)
+    fn = getattr(SC, kind)
+    k, r = ent[known.long()], rel[ridx.long()]
+    s_tail = fn(k, r, cand, mode="tail")
+    s_head = fn(cand, r, k, mode="head")
+    want_s = torch.where(tail.view(-1, 1) != 0, s_tail, s_head)
+    assert_close((got.cpu().unsqueeze(1) * cand).sum(-1), want_s, 1e-5, 1e-5, "score through the folded query")
+
+
+def test_linear_multi_matches_single_products():
+    g = torch.Generator().manual_seed(9)
+    N, K = 500, 200
+    Ms = [6000, 0, 4100, 37, 5000, 6000]
+    a = [torch.randn(m, K, generator=g).to(DEV) for m in Ms]
+    b = [torch.randn(N, K, generator=g).to(DEV) for _ in Ms]
+    be = TB.get_backend()
+    out = torch.empty(sum(Ms), N, device=DEV)
+    be.linear_multi(a, b, True, out)
+    row = 0
+    for ai, bi in zip(a, b):
+        assert_close(out[row:row + ai.shape[0]], ai.double() @ bi.double().t(), 1e-5, 1e-4, "A . B^T")
+        row += ai.shape[0]
+    b2 = [torch.randn(K, N, generator=g).to(DEV) for _ in Ms]          # not transposed: d_query = d_scores . all_embeds
+    a2 = [torch.randn(m, K, generator=g).to(DEV) for m in Ms]
+    out2 = torch.empty(sum(Ms), N, device=DEV)
+    be.linear_multi(a2, b2, False, out2)
+    row = 0
+    for ai, bi in zip(a2, b2):
+        assert_close(out2[row:row + ai.shape[0]], ai.double() @ bi.double(), 1e-5, 1e-4, "A . B")
+        row += ai.shape[0]
