@@ -265,8 +265,12 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
  *   out[s] = sum_{j in [seg_ptr[s], seg_ptr[s+1])} src[order[j]]      out: [n_seg, d] fully written (empty segment = 0)
  * seg_ptr [n_seg+1] / order [n_rows] = the gather indices grouped by table row (built once on the host;
  * ids < 0 are left out, so n_rows may be smaller than the gather).
- * No atomics; d % 4 == 0, d <= 256. */
-int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream);
+ * No atomics; d % 4 == 0, d <= 256.  Tables with very long segments (>= 512 rows per segment on average, e.g. the
+ * relation table under the loss) are reduced in two deterministic stages through `workspace`
+ * (temp_segment_sum_rows_workspace bytes; 0 for ordinary shapes; NULL falls back to one block per segment). */
+size_t temp_segment_sum_rows_workspace(int n_seg, int n_rows, int d);
+int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plain fp32 MFMA GEMMs (the extra (n,D)@(D,D) terms of the linear-recurrence layers,

@@ -88,7 +88,8 @@ SYMBOLS = {
     "temp_gru_weight_grads": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
-    "temp_segment_sum_rows": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_segment_sum_rows_workspace": (_SZ, [_I, _I, _I]),
+    "temp_segment_sum_rows": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_linear": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, _I, c_vp, _I, c_vp]),
     "temp_linear_multi": (_I, [_I, ctypes.POINTER(TempLinearProblem), _I, _I, _I, _I, _I, _I, c_vp]),
     "temp_linear_tn_workspace": (_SZ, [_I, _I, _I]),

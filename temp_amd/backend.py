@@ -430,7 +430,10 @@ class HipBackend:
         if src.shape[0] == 0 or order.shape[0] == 0:
             return torch.zeros(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
         out = torch.empty(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
-        rc = self.lib.temp_segment_sum_rows(n_seg, order.shape[0], src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(out), _stream())
+        nb = self.lib.temp_segment_sum_rows_workspace(n_seg, order.shape[0], src.shape[1])
+        ws = self._ws(nb, src.device) if nb else None
+        rc = self.lib.temp_segment_sum_rows(n_seg, order.shape[0], src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(out),
+                                            _ptr(ws), nb, _stream())
         _lib.check(rc, "temp_segment_sum_rows")
         return out
 

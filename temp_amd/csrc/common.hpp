@@ -118,7 +118,8 @@ int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, si
 
 // out[s] = sum_{j in [seg_ptr[s], seg_ptr[s+1])} src[order[j]]  (rows with row_mask[row] <= 0 skipped; row_mask nullable)
 int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
-                     hipStream_t st, long long n_rows_hint = 0);   // n_rows_hint = length of `order` (picks the long-segment kernel)
+                     hipStream_t st, long long n_rows_hint, void* ws = nullptr, size_t ws_bytes = 0);
+size_t segment_sum_rows_workspace(int n_seg, long long n_rows, int d);   // n_rows_hint = length of `order` (picks the long-segment kernel)
 
 // dz = (y > 0) ? dy : 0
 int relu_bwd(size_t n, const float* y, const float* dy, float* dz, hipStream_t st);

@@ -784,11 +784,68 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows_blk(int n_seg, int d4,
   }
 }
 
+// Very long segments (a 40-row relation table gathered 48 000 times by the loss): every segment is cut into S equal
+// parts, one block per part writes its partial sum into the workspace, a second kernel adds the S partials in order.
+__global__ void __launch_bounds__(256) k_segment_sum_part(int S, int d4, const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
+                                                          const float4* __restrict__ src, const int32_t* __restrict__ row_mask,
+                                                          float4* __restrict__ part) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool col_ok = lane < d4;
+  const int s = blockIdx.y, p = blockIdx.x;
+  const int beg0 = seg_ptr[s], end0 = seg_ptr[s + 1];
+  const int chunk = (end0 - beg0 + S - 1) / S;
+  const int beg = beg0 + p * chunk, end = min(end0, beg + chunk);
+  float4 acc = zero4();
+  for (int j0 = beg + wave; j0 < end; j0 += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + 4 * u;
+      v[u] = zero4();
+      if (j < end && col_ok) {
+        const int r = order[j];
+        if (!row_mask || row_mask[r] > 0) v[u] = src[(size_t)r * d4 + lane];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col_ok) part[((size_t)s * S + p) * d4 + lane] = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
+}
+
+__global__ void __launch_bounds__(256) k_segment_sum_fin(int n_seg, int S, int d4, const float4* __restrict__ part, float4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_seg * d4) return;
+  const size_t s = i / d4, c = i - s * d4;
+  float4 acc = zero4();
+  for (int p = 0; p < S; ++p) acc = add4(acc, part[(s * S + p) * d4 + c]);
+  out[i] = acc;
+}
+
+static int segsum_splits(int n_seg, long long n_rows) {
+  if (n_seg <= 0 || n_rows < 512LL * n_seg) return 1;
+  int S = 2048 / n_seg;
+  if (S > 64) S = 64;
+  return S < 2 ? 1 : S;
+}
+
+size_t segment_sum_rows_workspace(int n_seg, long long n_rows, int d) {
+  const int S = segsum_splits(n_seg, n_rows);
+  return S > 1 ? (size_t)n_seg * S * d * sizeof(float) : 0;
+}
+
 int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
-                     hipStream_t st, long long n_rows_hint) {
-  if (d % 4 || d > 256) return TEMP_E_UNSUPPORTED;
-  if (n_seg == 0) return TEMP_OK;
+                     hipStream_t st, long long n_rows_hint, void* ws, size_t ws_bytes) {
   const int d4 = d / 4;
+  const int S = segsum_splits(n_seg, n_rows_hint);
+  if (S > 1 && d4 <= 64 && ws && ws_bytes >= segment_sum_rows_workspace(n_seg, n_rows_hint, d)) {
+    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_part, dim3(S, n_seg), dim3(256), 0, st, S, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)ws);
+    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_fin, dim3(ceil_div((long long)n_seg * d4, 256)), dim3(256), 0, st, n_seg, S, d4, (const float4*)ws, (float4*)out);
+    return launch_status();
+  }
   if (n_rows_hint > 32LL * n_seg && d4 <= 64) {
     TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk, dim3(n_seg < 4096 ? n_seg : 4096), dim3(256), 0, st, n_seg, d4, seg_ptr, order,
                 (const float4*)src, row_mask, (float4*)out);
@@ -804,9 +861,12 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
 }  // namespace temp
 extern "C" {
 
-int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out, void* stream) {
+size_t temp_segment_sum_rows_workspace(int n_seg, int n_rows, int d) { return (n_seg <= 0 || d <= 0) ? 0 : segment_sum_rows_workspace(n_seg, n_rows, d); }
+
+int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   if (n_seg < 0 || d <= 0 || (n_seg > 0 && (!seg_ptr || !src || !out))) return TEMP_E_BADARG;
-  return segment_sum_rows(n_seg, d, seg_ptr, order, src, nullptr, out, (hipStream_t)stream, n_rows);
+  return segment_sum_rows(n_seg, d, seg_ptr, order, src, nullptr, out, (hipStream_t)stream, n_rows, workspace, workspace_bytes);
 }
 
 struct EpiPlainStore {

@@ -320,7 +320,8 @@ def test_self_attention_evaluate_gpu(name):
     check_sa_evaluate(name, DEV)
 
 
-@pytest.mark.parametrize("rows,n,d", [(500, 100000, 200), (7128, 1800, 200), (64, 999, 32), (10, 0, 16), (3, 5000, 256)])
+@pytest.mark.parametrize("rows,n,d", [(500, 100000, 200), (7128, 1800, 200), (64, 999, 32), (10, 0, 16), (3, 5000, 256),
+                                       (40, 48000, 200), (1, 30000, 128)])      # the last two: split (two-stage) reduction
 def test_segment_sum_matches_scatter_and_is_deterministic(rows, n, d, hip_backend):
     """temp_segment_sum_rows (deterministic adjoint of a static gather) against the atomic scatter-add."""
     from temp_amd import functional as TF
