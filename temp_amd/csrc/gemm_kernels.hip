@@ -449,34 +449,101 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, con
 // cross-entropy with label 0 -- nothing of shape (P, 1+neg, D) is ever materialised.
 // One workgroup per row.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce_256(float v, float* red, bool is_max) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  __syncthreads();                                     // red may still be read from a previous reduction
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Candidate lists shorter than half a score row: gather the C logits once (<= 4 per thread in registers).
 __global__ void __launch_bounds__(256) k_gather_ce_fwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
                                                        float* __restrict__ loss_rows, float* __restrict__ lse_rows) {
-  __shared__ float red[256];
+  __shared__ float red[4];
   const int p = blockIdx.x;
   const float* srow = scores + (size_t)p * N;
   const int32_t* crow = cand + (size_t)p * C;
-  float mx = -INFINITY;
-  for (int k = threadIdx.x; k < C; k += 256) mx = fmaxf(mx, srow[crow[k]]);
-  red[threadIdx.x] = mx;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
-    __syncthreads();
+  float mx = -INFINITY, sum = 0.f;
+  if (C <= 1024) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = threadIdx.x + 256 * u;
+      v[u] = k < C ? srow[crow[k]] : -INFINITY;
+      mx = fmaxf(mx, v[u]);
+    }
+    mx = block_reduce_256(mx, red, true);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sum += expf(v[u] - mx);                 // exp(-inf) = 0 for the padding
+  } else {
+    for (int k = threadIdx.x; k < C; k += 256) mx = fmaxf(mx, srow[crow[k]]);
+    mx = block_reduce_256(mx, red, true);
+    for (int k = threadIdx.x; k < C; k += 256) sum += expf(srow[crow[k]] - mx);
   }
-  mx = red[0];
-  __syncthreads();
-  float sum = 0.f;
-  for (int k = threadIdx.x; k < C; k += 256) sum += expf(srow[crow[k]] - mx);
-  red[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
+  sum = block_reduce_256(sum, red, false);
   if (threadIdx.x == 0) {
-    const float lse = mx + logf(red[0]);
+    const float lse = mx + logf(sum);
     lse_rows[p] = lse;
     loss_rows[p] = lse - srow[crow[0]];
+  }
+}
+
+// Candidate lists about as long as the row (negative_rate ~ N_ents: the same entity is drawn several times): count the
+// multiplicity of every entity with integer LDS atomics (order-independent), then ONE coalesced pass over the score row:
+//   lse = log sum_e cnt[e] exp(s[e]).
+__global__ void __launch_bounds__(256) k_gather_ce_fwd_cnt(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
+                                                           float* __restrict__ loss_rows, float* __restrict__ lse_rows) {
+  extern __shared__ int cnt[];
+  __shared__ float red[4];
+  const int p = blockIdx.x;
+  for (int i = threadIdx.x; i < N; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const float* srow = scores + (size_t)p * N;
+  const int32_t* crow = cand + (size_t)p * C;
+  for (int k = threadIdx.x; k < C; k += 256) atomicAdd(&cnt[crow[k]], 1);
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256)
+    if (cnt[i]) mx = fmaxf(mx, srow[i]);
+  mx = block_reduce_256(mx, red, true);
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256)
+    if (cnt[i]) sum += (float)cnt[i] * expf(srow[i] - mx);
+  sum = block_reduce_256(sum, red, false);
+  if (threadIdx.x == 0) {
+    const float lse = mx + logf(sum);
+    lse_rows[p] = lse;
+    loss_rows[p] = lse - srow[crow[0]];
+  }
+}
+
+// d_scores[p, e] = scale * (cnt[e] * softmax(e) - [e == cand[p,0]])   (row written once, coalesced; multiplicities counted
+// with integer LDS atomics, so the result does not depend on the order the candidates are visited in)
+__global__ void __launch_bounds__(256) k_gather_ce_bwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
+                                                       const float* __restrict__ lse_rows, const float* __restrict__ scale_ptr, float inv_rows,
+                                                       const float* __restrict__ row_scale, float* __restrict__ d_scores) {
+  extern __shared__ int cnt[];
+  const int p = blockIdx.x;
+  for (int i = threadIdx.x; i < N; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const float* srow = scores + (size_t)p * N;
+  const int32_t* crow = cand + (size_t)p * C;
+  for (int k = threadIdx.x; k < C; k += 256) atomicAdd(&cnt[crow[k]], 1);
+  __syncthreads();
+  const float lse = lse_rows[p];
+  const float scale = scale_ptr[0] * (row_scale ? row_scale[p] : inv_rows);
+  const int truth = crow[0];
+  float* drow = d_scores + (size_t)p * N;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const int c = cnt[i];
+    float g = c ? (float)c * expf(srow[i] - lse) : 0.f;
+    if (i == truth) g -= 1.f;
+    drow[i] = g * scale;
   }
 }
 
@@ -566,29 +633,6 @@ __global__ void __launch_bounds__(256) k_filtered_rank(int N, int ld, const floa
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) ranks[p] = red[0] + red[1] + red[2] + red[3] + 1;
-}
-
-// d_scores[p, :] = scale * sum_k (softmax_k - [k == 0]) e_{cand[p,k]}   (row built in LDS, written once)
-__global__ void __launch_bounds__(256) k_gather_ce_bwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
-                                                       const float* __restrict__ lse_rows, const float* __restrict__ scale_ptr, float inv_rows,
-                                                       const float* __restrict__ row_scale, float* __restrict__ d_scores) {
-  extern __shared__ float row[];
-  const int p = blockIdx.x;
-  for (int i = threadIdx.x; i < N; i += 256) row[i] = 0.f;
-  __syncthreads();
-  const float* srow = scores + (size_t)p * N;
-  const int32_t* crow = cand + (size_t)p * C;
-  const float lse = lse_rows[p];
-  const float scale = scale_ptr[0] * (row_scale ? row_scale[p] : inv_rows);
-  for (int k = threadIdx.x; k < C; k += 256) {
-    const int e = crow[k];
-    float g = expf(srow[e] - lse);
-    if (k == 0) g -= 1.f;
-    atomicAdd(&row[e], g * scale);
-  }
-  __syncthreads();
-  float* drow = d_scores + (size_t)p * N;
-  for (int i = threadIdx.x; i < N; i += 256) drow[i] = row[i];
 }
 
 __global__ void __launch_bounds__(256) k_copy(size_t n16, const float4* __restrict__ src, float4* __restrict__ dst) {
@@ -944,7 +988,10 @@ int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* 
 int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* cand, float* loss_rows, float* lse_rows, void* stream) {
   if (P < 0 || C <= 0 || N <= 0 || (P > 0 && (!scores || !cand || !loss_rows || !lse_rows))) return TEMP_E_BADARG;
   if (P == 0) return TEMP_OK;
-  TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_fwd, dim3(P), dim3(256), 0, (hipStream_t)stream, C, N, scores, cand, loss_rows, lse_rows);
+  if (2 * (long long)C >= N && (size_t)N * sizeof(int) <= 64 * 1024)
+    TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_fwd_cnt, dim3(P), dim3(256), (size_t)N * sizeof(int), (hipStream_t)stream, C, N, scores, cand, loss_rows, lse_rows);
+  else
+    TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_fwd, dim3(P), dim3(256), 0, (hipStream_t)stream, C, N, scores, cand, loss_rows, lse_rows);
   return launch_status();
 }
 

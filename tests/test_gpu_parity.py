@@ -236,7 +236,7 @@ def test_evaluate_ranks_golden_gpu(name):
     check_evaluate(name, DEV)
 
 
-@pytest.mark.parametrize("P,C,N,D", [(1, 3, 8, 8), (200, 51, 7128, 32), (3000, 501, 500, 200), (17, 501, 500, 200)])
+@pytest.mark.parametrize("P,C,N,D", [(1, 3, 8, 8), (200, 51, 7128, 32), (3000, 501, 500, 200), (17, 501, 500, 200), (40, 1300, 4000, 32)])
 def test_candidate_cross_entropy_vs_torch(P, C, N, D, hip_backend):
     """Fused link-prediction loss (one GEMM against all entities + candidate CE kernel) vs the
     reference formulation: gather (P, C, D) candidates, DistMult-style dot, F.cross_entropy(label 0)."""
