@@ -321,6 +321,18 @@ int temp_bilinear_query_bwd(int P, int d, int kind, const float* ent_rows, const
                             const int32_t* is_tail, const float* d_q, float* d_known_rows, float* d_rel_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Filtered negative sampling (CorruptTriples.negative_sampling / corrupt_triple, utils/CorrptTriples.py:36-85):
+ *   cand[row, 0] = truth[row];   cand[row, 1..K] = uniform draws over [0, N) that are not in the row's
+ *   known-true set ids[lo[row] .. hi[row])  (global entity ids, ascending within a row; lo/hi NULL = no filter).
+ * Exactly uniform over the entities outside the set: short sets by drawing the u-th entity of the complement directly,
+ * long sets by rejection (binary search per attempt) with that as the fallback -- no unbounded resampling loop.
+ * The draws are a counter-based hash of (seed, row, column, attempt): same seed => same samples, any launch shape.
+ * cand: [R, 1+K] int32, fully written.
+ * ---------------------------------------------------------------------------------------------- */
+int temp_corrupt_sample(int R, int K, int N, uint64_t seed, const int32_t* truth, const int32_t* lo, const int32_t* hi, const int32_t* ids,
+                        int32_t* cand, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Filtered ranking (EvaluationFilter.calc_metrics_single_graph / perturb_and_get_rank / sort_and_rank,
  * utils/evaluation.py:40-106).  scores [P, ld] = the P test triples scored against ALL N entities
  * (temp_linear with the folded query, trans_b = 1).  The reference overwrites the scores of the other

@@ -4,6 +4,7 @@ There is NO CPU fallback: if the shared library is missing or a symbol cannot be
 raises, and every op in the package fails loudly.
 """
 import ctypes
+import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -98,6 +99,7 @@ SYMBOLS = {
     "temp_gather_ce_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp]),
     "temp_bilinear_query_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_bilinear_query_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_corrupt_sample": (_I, [_I, _I, _I, ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_filtered_rank": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_fwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_bwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, _I, c_vp, c_vp, c_vp, c_vp]),
@@ -137,3 +139,35 @@ def check(rc, what):
     if rc != 0:
         msg = load().temp_error_string(rc).decode()
         raise TempAmdError("%s failed: %s (code %d)" % (what, msg, rc))
+
+
+_STAGE_BYTES = 32 << 20
+_stage = threading.local()
+
+
+def to_device(host, device):
+    """Host tensor / numpy array -> `device`.  On a GPU the bytes are staged in a per-thread pinned ring buffer and the
+    copy is stream-ordered (non_blocking): no host-side wait per upload.  A pageable copy blocks the calling thread until
+    the stream reaches it -- tens of microseconds each even when idle, and a window batch has dozens of small index vectors.
+    The ring is recycled after a synchronize of the thread's current stream (once per 32 MB of uploads)."""
+    import numpy as _np
+    import torch as _torch
+    t = _torch.from_numpy(_np.ascontiguousarray(host)) if isinstance(host, _np.ndarray) else host
+    device = _torch.device(device)
+    nbytes = t.numel() * t.element_size()
+    if device.type != "cuda" or nbytes == 0 or t.is_cuda or nbytes > _STAGE_BYTES // 4 or not t.is_contiguous():
+        return t.to(device)
+    buf = getattr(_stage, "buf", None)
+    if buf is None:
+        buf = _stage.buf = _torch.empty(_STAGE_BYTES, dtype=_torch.uint8, pin_memory=True)
+        _stage.np = buf.numpy()
+        _stage.off = 0
+    if _stage.off + nbytes > _STAGE_BYTES:
+        _torch.cuda.current_stream(device).synchronize()
+        _stage.off = 0
+    off = _stage.off
+    _stage.off += (nbytes + 255) & ~255
+    _stage.np[off:off + nbytes] = t.numpy().reshape(-1).view(_np.uint8)      # plain single-threaded memcpy
+    out = _torch.empty(t.shape, dtype=t.dtype, device=device)
+    out.copy_(buf[off:off + nbytes].view(t.dtype).view(t.shape), non_blocking=True)
+    return out

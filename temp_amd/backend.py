@@ -341,6 +341,18 @@ class HipBackend:
         _lib.check(rc, "temp_gather_ce_bwd")
         return d
 
+    def corrupt_sample(self, seed, truth, lo, hi, ids, K, N):
+        """(R, 1+K) int32 candidate lists: column 0 = truth, the rest filtered uniform draws (see temp_corrupt_sample)."""
+        truth = _i32(truth, "truth")
+        R = truth.shape[0]
+        cand = torch.empty(R, K + 1, dtype=torch.int32, device=truth.device)
+        if lo is not None:
+            lo, hi, ids = _i32(lo, "lo"), _i32(hi, "hi"), _i32(ids, "ids")
+        rc = self.lib.temp_corrupt_sample(R, int(K), int(N), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(truth), _ptr(lo), _ptr(hi), _ptr(ids) if lo is not None else None,
+                                          _ptr(cand), _stream())
+        _lib.check(rc, "temp_corrupt_sample")
+        return cand
+
     def filtered_rank(self, scores, target, filt_ptr=None, filt_ids=None):
         """1-indexed filtered ranks (int64) of `target` in every row of scores [P,N] (see temp_filtered_rank)."""
         scores, target = _f32(scores, "scores"), _i32(target, "target")

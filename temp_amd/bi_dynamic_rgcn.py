@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import functional as TF
+from . import _lib
 from .birrgcn import BiGRRGCNLayer, BiRRGCN
 from .dynamic_rgcn import DynamicRGCN, WindowBatch
 from .gru_cell import GRUCell
@@ -143,7 +144,7 @@ class BiDynamicRGCN(DynamicRGCN):
         b_rows = base[nf:nf + nb]
         t_rows = base[tf.row0:tf.row0 + nt]
         chain = np.concatenate([f_rows, t_rows, b_rows, t_rows])
-        wb.chain_rows = torch.from_numpy(chain.astype(np.int32)).to(self._device())
+        wb.chain_rows = _lib.to_device(chain.astype(np.int32), self._device())
         wb.chain_inv = TF.gather_inverse(chain, int(wb.g_all.n), self._device())
         inst = []
         last = -1
@@ -181,7 +182,10 @@ class BiDynamicRGCN(DynamicRGCN):
         wb.batched = self._can_batch()
         wb.steps = plan_f.steps + plan_b.steps + [wb.target]
         self._upload(wb, dev)
-        wb.target_b.tensors(dev)
+        if wb.program is None:
+            wb.target_b.tensors(dev)
+        if train:
+            self._plan_loss(wb)
         return wb
 
     def encode(self, t_list, seq_len, train=True, target_edge_ids=None):

@@ -597,6 +597,52 @@ __global__ void __launch_bounds__(256) k_bilinear_query(int P, int d, int kind, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Filtered negative sampling (CorruptTriples.negative_sampling / corrupt_triple, utils/CorrptTriples.py:36-85):
+// for every positive row, K corrupted entities drawn uniformly over ALL entities, redrawing those that form a true
+// triple of the target snapshot (the row's known-true set is the slice ids[lo[row] .. hi[row]) of a resident store).
+// One thread per candidate; the draw is a counter-based hash of (seed, row, column, attempt), so a step's samples
+// are a pure function of its seed (no generator state, no rejection ROUNDS over the whole matrix).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_corrupt_sample(long long total, int K1, int N, unsigned long long seed, const int32_t* __restrict__ truth,
+                                                        const int32_t* __restrict__ lo, const int32_t* __restrict__ hi,
+                                                        const int32_t* __restrict__ ids, int32_t* __restrict__ cand) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / K1), k = (int)(i - (long long)row * K1);
+    if (k == 0) { cand[i] = truth[row]; continue; }
+    const int a = lo ? lo[row] : 0, b = lo ? hi[row] : 0;
+    const unsigned long long base = splitmix64(seed ^ ((unsigned long long)row * 0xD1B54A32D192ED03ull + (unsigned long long)k));
+    const int len = b - a;
+    int c = 0;
+    bool done = false;
+    if (len > 16 && len < N) {                        // long known-true set: rejection with a binary search per attempt
+      for (int attempt = 0; attempt < 64 && !done; ++attempt) {
+        const unsigned long long x = splitmix64(base + attempt);
+        c = (int)(((x >> 32) * (unsigned long long)N) >> 32);
+        int l = a, h = b;
+        while (l < h) { const int m = (l + h) >> 1; if (ids[m] < c) l = m + 1; else h = m; }
+        done = !(l < b && ids[l] == c);
+      }
+    }
+    if (!done) {
+      // exact: the u-th entity of the complement, u uniform in [0, N - len) -- walk the ascending list, skipping its members
+      const int free_n = len < N ? N - len : N;       // nothing allowed (the reference would loop forever): plain uniform draw
+      const unsigned long long x = splitmix64(base + 64);
+      c = (int)(((x >> 32) * (unsigned long long)free_n) >> 32);
+      if (len < N)
+        for (int j = a; j < b && ids[j] <= c; ++j) ++c;
+    }
+    cand[i] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Filtered rank of one test triple per workgroup (utils/evaluation.py:40-106): the reference sets the scores of the
 // other known-true entities to -10e6, applies a sigmoid and takes the target's position in a descending sort.
 // Position in a STABLE descending order = #(strictly larger) + #(equal with a smaller entity id) + 1, so nothing is
@@ -1005,6 +1051,17 @@ int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* 
     if (hipFuncSetAttribute((const void*)k_gather_ce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEMP_E_LAUNCH;
   }
   TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_bwd, dim3(P), dim3(256), lds, (hipStream_t)stream, C, N, scores, cand, lse_rows, scale, inv_rows, row_scale, d_scores);
+  return launch_status();
+}
+
+int temp_corrupt_sample(int R, int K, int N, uint64_t seed, const int32_t* truth, const int32_t* lo, const int32_t* hi, const int32_t* ids,
+                        int32_t* cand, void* stream) {
+  if (R < 0 || K < 0 || N <= 0 || (R > 0 && (!truth || !cand)) || ((lo != nullptr) != (hi != nullptr))) return TEMP_E_BADARG;
+  if (R == 0) return TEMP_OK;
+  const long long total = (long long)R * (K + 1);
+  int grid = ceil_div(total, 256);
+  if (grid > 16384) grid = 16384;
+  TEMP_LAUNCH(K_GATHER_CE, k_corrupt_sample, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, K + 1, N, (unsigned long long)seed, truth, lo, hi, ids, cand);
   return launch_status();
 }
 

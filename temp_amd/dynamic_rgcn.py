@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as TF
+from . import _lib
 from . import snapshot as S
 from .rrgcn import RRGCN, GRRGCNLayer, run_rnn
 from .tkg_module import TKG_Module
@@ -23,6 +24,8 @@ from .gru_chain import GruInstance, GruProgram, gru_chain
 from .gru_cell import GRUCell
 from .window import ChainPlan, Step, concat_steps, concat_steps_dedup, window_times
 
+
+from .backend import get_backend  # noqa: E402
 
 class WindowBatch:
     """Everything `run` needs for one batch of windows (plans, batched graphs, device index tensors)."""
@@ -46,6 +49,8 @@ class DynamicRGCN(TKG_Module):
         nn.init.xavier_uniform_(self.ent_embeds, gain=nn.init.calculate_gain('relu'))
         nn.init.xavier_uniform_(self.rel_embeds, gain=nn.init.calculate_gain('relu'))
         self.sample_rng = np.random.default_rng(getattr(args, "seed", None))
+        self.seed_rng = np.random.default_rng(None if getattr(args, "seed", None) is None else int(args.seed) + 1)   # per-step sampler seeds (main thread)
+        self.plan_loss_in_prepare = True
         self.use_batched_path = True
         self.use_gru_chain = True
         self.dedup_snapshots = True
@@ -184,21 +189,21 @@ class DynamicRGCN(TKG_Module):
         wb.batched = self._can_batch()
         wb.steps = wb.plan.steps + [wb.target]
         self._upload(wb, dev)
+        if train:
+            self._plan_loss(wb)
         return wb
 
     def _upload(self, wb, dev):
-        for st in wb.steps:
-            st.tensors(dev)
         wb.program = None
         wb.visit_rows = None
         if wb.batched:
             if self.dedup_snapshots:
                 wb.g_all, vr, wb.total_rows = concat_steps_dedup(wb.steps)
-                wb.visit_rows = torch.from_numpy(vr).to(dev) if vr is not None else None
+                wb.visit_rows = _lib.to_device(vr, dev) if vr is not None else None
                 wb.visit_inv = TF.gather_inverse(vr, int(wb.g_all.n), dev) if vr is not None else None
             else:
                 wb.g_all, wb.total_rows = concat_steps(wb.steps)
-            wb.ids_all = torch.from_numpy(wb.g_all.gids.astype(np.int32)).to(dev)
+            wb.ids_all = _lib.to_device(wb.g_all.gids.astype(np.int32), dev)
             wb.ids_inv = TF.gather_inverse(wb.g_all.gids, self.num_ents, dev)        # static ids: deterministic embedding gradient
             wb.g_all.device_graph(dev, 2 * self.num_rels)
             if self._can_chain():
@@ -207,6 +212,9 @@ class DynamicRGCN(TKG_Module):
         else:
             for st in wb.steps:
                 st.batched().device_graph(dev, 2 * self.num_rels)
+        if wb.program is None:                       # the per-step row maps are only read outside the chain program
+            for st in wb.steps:
+                st.tensors(dev)
         wb.n_edge_visits = int(sum(g.number_of_edges() for st in wb.steps for g in st.graphs))
         wb.n_edges_distinct = int(wb.g_all.number_of_edges()) if wb.batched else wb.n_edge_visits
         wb.n_nodes_distinct = int(wb.g_all.n) if wb.batched else 0
@@ -271,6 +279,35 @@ class DynamicRGCN(TKG_Module):
         wb = self.prepare(t_list, self.train_seq_len, True, target_edge_ids)
         return self.run_loss(wb, samples)
 
+    def _plan_loss(self, wb):
+        """Host half of the fused loss, done with the rest of `prepare` (i.e. by the prefetch thread): positives, operand
+        index lists, known-true slices for the device sampler, static inverses, all-entity row maps."""
+        wb.loss_plan = None
+        if not (self.plan_loss_in_prepare and getattr(self, "use_device_sampler", True) and self.fused_loss
+                and self.args.score_function in ("distmult", "complex")):
+            return
+        from .sampling import TrueSetStore, plan_batch_loss
+        dev = self._device()
+        store = getattr(self, "_true_store", None)
+        if store is None or store.device != dev:
+            store = self._true_store = TrueSetStore(self.graph_dict_train, self.num_ents, dev)
+        sizes = self._target_sizes(wb)
+        offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+        wb.loss_plan = plan_batch_loss(store, [r[-1] for r in wb.rows], wb.graphs, offs, self.args.num_pos_facts, self.sample_rng,
+                                       int(sum(sizes)), int(self.rel_embeds.shape[0]), dev)
+        if wb.batched:
+            self._all_maps(wb)
+
+    def _target_sizes(self, wb):
+        return wb.target.sizes
+
+    def _sampled_loss(self, wb, out, all_embeds):
+        """Fused loss on fresh negatives: ONE sampler launch (temp_corrupt_sample) + the fused link-prediction node."""
+        plan = wb.loss_plan
+        cand = get_backend().corrupt_sample(int(self.seed_rng.integers(1 << 62)), plan["truth"], plan["lo"], plan["hi"], plan["ids"],
+                                            self.args.negative_rate, self.num_ents)
+        return self.batched_link_prediction(out, dict(plan, cand=cand), all_embeds)
+
     def draw_samples(self, wb):
         """Negative samples of every target graph of a prepared batch.  On a GPU the draws and the true-triple filter
         run on the device (sampling.DeviceCorruptTriples); `use_device_sampler = False` keeps the host sampler."""
@@ -295,12 +332,8 @@ class DynamicRGCN(TKG_Module):
             plans = wb.plan if isinstance(wb.plan, tuple) else (wb.plan,)
             L = plans[0].seq_len
             inact = [np.setdiff1d(np.arange(N, dtype=np.int64), g.gids) for g in wb.graphs]
-            maps = []
-            for plan in plans:
-                idx = np.concatenate([plan.final_all(b, L - 1)[0][inact[b]] for b in range(plan.bsz)]).astype(np.int32)
-                dt = np.concatenate([plan.final_all(b, L - 1)[1][inact[b]] for b in range(plan.bsz)]).astype(np.float32)
-                maps.append((torch.from_numpy(idx).to(dev), torch.from_numpy(dt).view(-1, 1).to(dev)))
-            wb.all_maps = maps
+            idxs = [np.concatenate([plan.final_all(b, L - 1)[0][inact[b]] for b in range(plan.bsz)]).astype(np.int32) for plan in plans]
+            dts = [np.concatenate([plan.final_all(b, L - 1)[1][inact[b]] for b in range(plan.bsz)]).astype(np.float32) for plan in plans]
             sizes = [g.n for g in wb.graphs]
             n_out = int(sum(sizes))
             off_out = np.concatenate([[0], np.cumsum(sizes)])
@@ -309,11 +342,17 @@ class DynamicRGCN(TKG_Module):
             for b, g in enumerate(wb.graphs):
                 asm[b, g.gids] = off_out[b] + np.arange(g.n)
                 asm[b, inact[b]] = n_out + off_in[b] + np.arange(len(inact[b]))
-            wb.inactive_ent = torch.from_numpy(np.concatenate(inact).astype(np.int32)).to(dev)
+            inact_all = np.concatenate(inact)
+            host = {"asm": asm.reshape(-1), "inact": inact_all}
+            for i, (a, t) in enumerate(zip(idxs, dts)):
+                host["idx%d" % i], host["dt%d" % i] = a, t.view(np.int32)            # float bits ride in the int32 pack
+            d = S.upload_packed(host, dev, np.int32)
+            wb.all_maps = [(d["idx%d" % i], d["dt%d" % i].view(torch.float32).view(-1, 1)) for i in range(len(plans))]
+            wb.inactive_ent = d["inact"]
             wb.n_inactive = int(off_in[-1])
-            wb.assemble = torch.from_numpy(asm.reshape(-1).astype(np.int32)).to(dev)
+            wb.assemble = d["asm"]
             wb.assemble_inv = TF.gather_inverse(asm.reshape(-1), n_out + wb.n_inactive, dev)
-            wb.inactive_inv = TF.gather_inverse(np.concatenate(inact), N, dev)
+            wb.inactive_inv = TF.gather_inverse(inact_all, N, dev)
         return wb.all_maps
 
     def _assemble_all(self, wb, out, isolated):
@@ -346,11 +385,15 @@ class DynamicRGCN(TKG_Module):
         dev = self._device()
         out, hist = self.run(wb)
         per_graph = list(out.split(wb.target.sizes))
-        if samples is None:
-            samples = self.draw_samples(wb)
         batched = (wb.batched and not self.ent_encoder.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
                    and getattr(self.ent_encoder.layer_2, "num_layers", 1) == 1)
         all_list = self.all_embeds_batched(wb, out, hist) if batched else None
+        if samples is None and batched and getattr(wb, "loss_plan", None) is not None:
+            fused = self._sampled_loss(wb, out, all_list)
+            if fused is not None:
+                return fused
+        if samples is None:
+            samples = self.draw_samples(wb)
         if batched:
             cache = getattr(wb, "_loss_inputs", None)
             if cache is None or cache[0] is not samples:          # index tensors are static for a given sample set

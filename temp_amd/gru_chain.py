@@ -74,13 +74,25 @@ class GruProgram:
         self.dev = None
 
     def upload(self, device):
+        """Row maps and time gaps of every instance on `device`: packed on the host into ONE int32 buffer (the float gaps as
+        raw bits) and uploaded with one copy; the per-instance tensors are views."""
         if self.dev is not None and self.dev[0] == str(device):
             return self.dev[1]
-        t = []
+        parts, spans, off = [], [], 0
         for it in self.inst:
-            pi = torch.from_numpy(it.prev_idx.astype(np.int32)).to(device) if it.prev >= 0 else None
-            ni = torch.from_numpy(it.next_idx).to(device) if it.next_idx is not None else None
-            t.append((pi, ni, torch.from_numpy(it.dt.astype(np.float32)).to(device)))
+            span = []
+            for arr in (it.prev_idx.astype(np.int32) if it.prev >= 0 else None, it.next_idx,
+                        np.ascontiguousarray(it.dt, dtype=np.float32).view(np.int32)):
+                if arr is None:
+                    span.append(None)
+                    continue
+                parts.append(arr.reshape(-1))
+                span.append((off, off + arr.size))
+                off += arr.size
+            spans.append(span)
+        buf = _lib.to_device(np.concatenate(parts) if parts else np.zeros(0, np.int32), device)
+        cut = lambda sp: buf[sp[0]:sp[1]] if sp is not None else None
+        t = [(cut(a), cut(b), cut(c).view(torch.float32)) for a, b, c in spans]
         self.dev = (str(device), t)
         return t
 

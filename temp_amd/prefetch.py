@@ -10,27 +10,66 @@ The reference builds its batched DGL graphs inline at the top of every forward (
 this replaces that with a bounded queue.  numpy releases the GIL in the sorting / concatenation calls that
 dominate `prepare`, so one thread is enough.
 """
+import collections
 import queue
 import threading
 
+import torch
+
 
 class BatchPrefetcher:
+    """On a GPU the worker prepares under its OWN HIP stream: the (pageable, hence synchronous) uploads and the small device
+    sorts of `prepare` then queue behind each other only, not behind the training step's kernels on the main stream -- on the
+    shared stream every one of the ~100 small copies of a batch would wait for the step in flight.  The consumer's stream waits
+    for the batch's `ready` event; a consumed batch is kept alive until the main stream has passed it, so the caching
+    allocator cannot hand its memory (allocated on the worker's stream) to the next batch while kernels still read it."""
+
     def __init__(self, model, batches, seq_len=None, train=True, depth=2):
         self.model, self.batches, self.train = model, batches, train
         self.seq_len = seq_len if seq_len is not None else model.train_seq_len
         self.q = queue.Queue(maxsize=max(1, depth))
         self.thread = None
+        dev = next(model.parameters()).device
+        self.device = dev if dev.type == "cuda" else None
+        self._inflight = collections.deque()
 
     def _work(self):
         try:
+            stream = torch.cuda.Stream(self.device) if self.device is not None else None
             for t_list in self.batches:
-                self.q.put(("ok", self.model.prepare(t_list, self.seq_len, self.train)))
+                if stream is None:
+                    wb = self.model.prepare(t_list, self.seq_len, self.train)
+                else:
+                    with torch.cuda.stream(stream):
+                        wb = self.model.prepare(t_list, self.seq_len, self.train)
+                        wb.ready = torch.cuda.Event()
+                        wb.ready.record(stream)
+                self.q.put(("ok", wb))
         except BaseException as e:          # surfaced in the consumer
             self.q.put(("err", e))
             return
         self.q.put(("end", None))
 
+    def _retire(self, wb):
+        """Called when the consumer is done issuing work for `wb`."""
+        if self.device is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._inflight.append((ev, wb))
+        while self._inflight and self._inflight[0][0].query():
+            self._inflight.popleft()
+
     def __iter__(self):
+        import sys
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 2e-4))        # both threads issue many short calls: hand the GIL over quickly
+        try:
+            yield from self._iterate()
+        finally:
+            sys.setswitchinterval(old_interval)
+
+    def _iterate(self):
         self.thread = threading.Thread(target=self._work, daemon=True)
         self.thread.start()
         while True:
@@ -39,5 +78,12 @@ class BatchPrefetcher:
                 break
             if kind == "err":
                 raise item
+            if getattr(item, "ready", None) is not None:
+                torch.cuda.current_stream(self.device).wait_event(item.ready)
             yield item
+            self._retire(item)
+            item = None
         self.thread.join()
+        if self.device is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+        self._inflight.clear()

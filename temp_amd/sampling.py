@@ -11,6 +11,8 @@ tests inject the reference's recorded samples instead.
 import numpy as np
 import torch
 
+from . import _lib
+
 
 class CorruptTriples:
     def __init__(self, args, graph_dict_train, seed=None):
@@ -107,3 +109,85 @@ class DeviceCorruptTriples(CorruptTriples):
         neg_tail = torch.cat([gid[trip[:, 2]].view(-1, 1), self._draw_dev(trip[:, 0] * R + trip[:, 1], key_tail, num_ents, K)], dim=1)
         neg_head = torch.cat([gid[trip[:, 0]].view(-1, 1), self._draw_dev(trip[:, 2] * R + trip[:, 1], key_head, num_ents, K)], dim=1)
         return trip, neg_tail, neg_head, torch.zeros(P, dtype=torch.int64, device=self.device)
+
+
+class TrueSetStore:
+    """Known-true entity lists of the train snapshots, resident on the device for temp_corrupt_sample.
+
+    Per snapshot (built on first use, appended to ONE growing device array): for every edge e = (h, r, t) the slice of
+    global ids that are true tails of (h, r) and the slice that are true heads of (r, t) in that snapshot
+    (get_true_head_and_tail_per_graph, utils/CorrptTriples.py:87-106), each ascending.  `rows(t, edge_idx)` returns the
+    absolute [lo, hi) offsets of the chosen edges' slices; offsets stay valid when the array grows."""
+
+    def __init__(self, graph_dict_train, num_ents, device):
+        self.graphs, self.N, self.device = graph_dict_train, int(num_ents), torch.device(device)
+        self._snap = {}
+        self.ids = torch.zeros(1024, dtype=torch.int32, device=self.device)
+        self.size = 0
+
+    def _append(self, arr):
+        n = arr.shape[0]
+        if self.size + n > self.ids.shape[0]:
+            grown = torch.zeros(max(2 * self.ids.shape[0], self.size + n), dtype=torch.int32, device=self.device)
+            grown[:self.size] = self.ids[:self.size]
+            self.ids = grown
+        self.ids[self.size:self.size + n] = _lib.to_device(arr, self.device)
+        base = self.size
+        self.size += n
+        return base
+
+    def snapshot(self, t):
+        s = self._snap.get(t)
+        if s is None:
+            g, N = self.graphs[t], self.N
+            gid = g.gids.astype(np.int64)
+            src, rel, dst = g.src.astype(np.int64), g.rel.astype(np.int64), g.dst.astype(np.int64)
+            R = int(rel.max()) + 1 if rel.shape[0] else 1
+            pt, ph = src * R + rel, dst * R + rel
+            kt = np.unique(pt * N + gid[dst]) if rel.shape[0] else np.zeros(0, np.int64)
+            kh = np.unique(ph * N + gid[src]) if rel.shape[0] else np.zeros(0, np.int64)
+            base = self._append(np.concatenate([kt % N, kh % N]).astype(np.int32))
+            off_h = base + kt.shape[0]
+            s = self._snap[t] = dict(
+                tail_lo=(base + np.searchsorted(kt, pt * N)).astype(np.int32), tail_hi=(base + np.searchsorted(kt, (pt + 1) * N)).astype(np.int32),
+                head_lo=(off_h + np.searchsorted(kh, ph * N)).astype(np.int32), head_hi=(off_h + np.searchsorted(kh, (ph + 1) * N)).astype(np.int32))
+        return s
+
+
+def plan_batch_loss(store, times, graphs, row_offsets, num_pos_facts, rng, n_rows, n_rel_rows, device):
+    """Everything of a window batch's link-prediction loss that does not depend on the negative draws, built on the host
+    (no device round trip) and uploaded once: per target graph the P = min(E, num_pos_facts) positives (a random subset
+    when E is larger, utils/CorrptTriples.py:37-40), stacked as [tail-corruption rows ; head-corruption rows]:
+      known / rel / is_tail   operands of the folded query      truth, lo, hi    inputs of temp_corrupt_sample
+      weights (1 / P), splits, known_inv / rel_inv (static inverses for the deterministic backward), triples (host, per graph)."""
+    from . import functional as TF
+    known, rel, tail, truth, lo, hi, weights, splits, triples = [], [], [], [], [], [], [], [], []
+    row = 0
+    for b, (t, g) in enumerate(zip(times, graphs)):
+        E = g.number_of_edges()
+        P = min(E, num_pos_facts)
+        if P == 0:
+            splits.append((row, row))
+            triples.append(np.zeros((0, 3), np.int64))
+            continue
+        idx = rng.permutation(E)[:P] if num_pos_facts < E else np.arange(E)
+        s = store.snapshot(t)
+        src, r, dst = g.src[idx], g.rel[idx], g.dst[idx]
+        triples.append(np.stack([src, r, dst], axis=1))
+        known.append(np.concatenate([src, dst]) + row_offsets[b])
+        rel.append(np.concatenate([r, r]))
+        tail.append(np.concatenate([np.ones(P, np.int32), np.zeros(P, np.int32)]))
+        truth.append(np.concatenate([g.gids[dst], g.gids[src]]))
+        lo.append(np.concatenate([s["tail_lo"][idx], s["head_lo"][idx]]))
+        hi.append(np.concatenate([s["tail_hi"][idx], s["head_hi"][idx]]))
+        weights.append(np.full(2 * P, 1.0 / P, np.float32))
+        splits.append((row, row + 2 * P))
+        row += 2 * P
+    if row == 0:
+        return None
+    known, rel = np.concatenate(known), np.concatenate(rel)
+    packed = np.stack([known, rel, np.concatenate(tail), np.concatenate(truth), np.concatenate(lo), np.concatenate(hi)]).astype(np.int32)
+    dev_i = _lib.to_device(packed, device)                       # ONE upload for the six index vectors
+    return dict(known=dev_i[0], rel=dev_i[1], is_tail=dev_i[2], truth=dev_i[3], lo=dev_i[4], hi=dev_i[5], ids=store.ids,
+                weights=_lib.to_device(np.concatenate(weights), device), splits=splits, triples=triples,
+                known_inv=TF.gather_inverse(known, n_rows, device), rel_inv=TF.gather_inverse(rel, n_rel_rows, device))

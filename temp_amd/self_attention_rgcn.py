@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import functional as TF
+from . import _lib
 from . import snapshot as S
 from .dynamic_rgcn import DynamicRGCN, WindowBatch
 from .sargcn import SARGCN, jk_max
@@ -94,7 +95,7 @@ class SelfAttentionRGCN(DynamicRGCN):
         all_graphs = hist_graphs + list(wb.targets)
         wb.g_all = S.batch(all_graphs)
         wb.g_all.device_graph(dev, 2 * self.num_rels)
-        as_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+        as_dev = lambda a, dt: _lib.to_device(np.ascontiguousarray(a).astype(dt), dev)
         wb.ids_all = as_dev(wb.g_all.gids, np.int32)
         wb.ids_inv = TF.gather_inverse(wb.g_all.gids, N, dev)
         time_rows = np.repeat(np.array(hist_ts + wb.target_times, dtype=np.int64), [g.n for g in all_graphs])
@@ -132,7 +133,15 @@ class SelfAttentionRGCN(DynamicRGCN):
         wb.n_nodes_distinct = int(wb.g_all.n)
         wb.n_node_visits = int(sum(self.graph_dict_train[t].n for times in wb.hist_times for t in times if t is not None)
                                + sum(wb.target_sizes))
+        if train:
+            self._plan_loss(wb)
         return wb
+
+    def _target_sizes(self, wb):
+        return wb.target_sizes
+
+    def _all_maps(self, wb):
+        return None                                   # this model's all-entity maps are built in prepare
 
     def run(self, wb):
         """-> (target rows (sum n_b, D), (layer-1 K/V table or None, layer-2 K/V table))."""
@@ -183,9 +192,13 @@ class SelfAttentionRGCN(DynamicRGCN):
         dev = self._device()
         out, tables = self.run(wb)
         per_graph = list(out.split(wb.target_sizes))
+        all_list = self.all_embeds_batched(wb, out, tables)
+        if samples is None and getattr(wb, "loss_plan", None) is not None:
+            fused = self._sampled_loss(wb, out, all_list)
+            if fused is not None:
+                return fused
         if samples is None:
             samples = self.draw_samples(wb)
-        all_list = self.all_embeds_batched(wb, out, tables)
         cache = getattr(wb, "_loss_inputs", None)
         if cache is None or cache[0] is not samples:
             offs = np.concatenate([[0], np.cumsum(wb.target_sizes)])[:-1]

@@ -100,10 +100,11 @@ class Snapshot:
             first = np.cumsum(lv["rel_chunks"]) - lv["rel_chunks"]
             arrays = [((vn, an), lv[vn][an]) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS]
             arrays += [("rel_rank", np.arange(seg.shape[0], dtype=np.int64) - first[seg]),        # rank of a chunk inside its relation
-                       ("in_deg", lv["in_deg"]), ("out_deg", lv["out_deg"])]
+                       ("in_deg", lv["in_deg"]), ("out_deg", lv["out_deg"]),
+                       ("nnorm", np.ascontiguousarray(self.nnorm, dtype=np.float32).view(np.int32))]   # float bits ride along
             sizes = [int(a.shape[0]) for _, a in arrays]
             packed = np.concatenate([np.ascontiguousarray(a, dtype=np.int32) for _, a in arrays]) if sum(sizes) else np.zeros(1, np.int32)
-            buf = torch.from_numpy(packed).to(device)                  # ONE upload per snapshot
+            buf = _lib.to_device(packed, device)                  # ONE upload per snapshot
             dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": buf}
             off = 0
             for (key_, _), n_ in zip(arrays, sizes):
@@ -113,7 +114,7 @@ class Snapshot:
                     dv[key_[0]][key_[1]] = t
                 else:
                     dv[key_] = t
-            dv["nnorm"] = torch.from_numpy(self.nnorm).to(device)
+            dv["nnorm"] = dv["nnorm"].view(torch.float32)
             self._dev[key] = dv
         return dv
 
@@ -317,68 +318,90 @@ def union_views(snap, n_rel_rows):
 DEVICE_STORE = True      # assemble union views on the GPU from per-snapshot device-resident views (no host concat, no H2D)
 
 
+def upload_packed(arrays, device, dtype=np.int64):
+    """name -> 1-D host array  =>  name -> device tensor, through ONE concatenated upload (each small synchronous copy
+    costs tens of microseconds, more while the GPU is busy; a window batch needs dozens of these little index vectors)."""
+    names = list(arrays)
+    flat = [np.ascontiguousarray(arrays[k], dtype=dtype).reshape(-1) for k in names]
+    buf = _lib.to_device(np.concatenate(flat) if flat else np.zeros(0, dtype), device)
+    out, off = {}, 0
+    for k, a in zip(names, flat):
+        out[k] = buf[off:off + a.shape[0]]
+        off += a.shape[0]
+    return out
+
+
 def union_views_device(snap, n_rel_rows, device):
     """Device-side union_views: the members' cached device views are concatenated and offset with a handful of torch
-    kernels; only per-member counts / offsets (a few KB) come from the host.  Returns (views: name -> {array -> tensor,
-    count -> int}, in_deg, out_deg, nnorm) or None when the by-relation view needs the global sort (few edges per relation)."""
+    kernels; only per-member counts / offsets (a few KB, ONE packed upload) come from the host.  Returns (views: name ->
+    {array -> tensor, count -> int}, in_deg, out_deg, nnorm) or None when the by-relation view needs the global sort (few
+    edges per relation)."""
     E = int(snap.edge_off[-1])
     if E // (REL_GROUP_EDGES * max(n_rel_rows, 1)) <= 1:
         return None
     lv = [g.local_views(n_rel_rows) for g in snap.parts]
     dv = [g.device_views(device, n_rel_rows) for g in snap.parts]
-    i64 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.int64)).to(device)
-    node_off, edge_off = i64(snap.node_off[:-1]), i64(snap.edge_off[:-1])
+    # ---- host side: every small vector the assembly needs, uploaded together
+    host = dict(node_off=snap.node_off[:-1], edge_off=snap.edge_off[:-1])
+    for vn in ("by_dst", "by_src", "by_rel"):
+        vs = [l[vn] for l in lv]
+        host[vn + "/e"] = np.array([v["n_edges"] for v in vs], dtype=np.int64)
+        host[vn + "/c"] = np.array([v["n_chunks"] for v in vs], dtype=np.int64)
+        if vn != "by_rel":
+            host[vn + "/f"] = np.array([v["n_fix"] for v in vs], dtype=np.int64)
+            host[vn + "/p"] = np.concatenate([[0], np.cumsum([v["n_partial"] for v in vs])])[:-1]
+    counts = np.stack([l["rel_chunks"] for l in lv])
+    per_rel = counts.sum(axis=0)
+    multi = per_rel > 1
+    fix_seg = np.nonzero(multi)[0]
+    fix_cnt = per_rel[fix_seg]
+    fix_slot = np.cumsum(fix_cnt) - fix_cnt
+    base = np.full(n_rel_rows, -1, dtype=np.int64)
+    base[fix_seg] = fix_slot
+    host["rel/table"] = np.where(multi[None, :], base[None, :] + (np.cumsum(counts, axis=0) - counts), -1).reshape(-1)    # (members, rels)
+    host["rel/member"] = np.arange(len(lv)) * n_rel_rows
+    host["rel/fix_seg"], host["rel/fix_slot"], host["rel/fix_cnt"] = fix_seg, fix_slot, fix_cnt
+    d = upload_packed(host, device)
+    node_off, edge_off = d["node_off"], d["edge_off"]
 
-    def rep(vals, counts_np):
-        total = int(counts_np.sum())
-        return torch.repeat_interleave(vals, i64(counts_np), output_size=total)
+    def rep(vals, counts_dev, counts_np):
+        return torch.repeat_interleave(vals, counts_dev, output_size=int(counts_np.sum()))
 
     def cat(vn, an):
-        return torch.cat([d[vn][an] for d in dv])
+        return torch.cat([x[vn][an] for x in dv])
 
     views = {}
     for vn in ("by_dst", "by_src", "by_rel"):
         vs = [l[vn] for l in lv]
-        e_cnt = np.array([v["n_edges"] for v in vs], dtype=np.int64)
-        c_cnt = np.array([v["n_chunks"] for v in vs], dtype=np.int64)
-        node_e, node_c, edge_c = rep(node_off, e_cnt), rep(node_off, c_cnt), rep(edge_off, c_cnt)
-        out = dict(n_edges=E, n_chunks=int(c_cnt.sum()))
+        e_np, c_np = host[vn + "/e"], host[vn + "/c"]
+        node_e, node_c, edge_c = rep(node_off, d[vn + "/e"], e_np), rep(node_off, d[vn + "/c"], c_np), rep(edge_off, d[vn + "/c"], c_np)
+        out = dict(n_edges=E, n_chunks=int(c_np.sum()))
         out["a"] = (cat(vn, "a") + node_e).to(torch.int32)
         out["chunk_beg"] = (cat(vn, "chunk_beg") + edge_c).to(torch.int32)
         out["chunk_end"] = (cat(vn, "chunk_end") + edge_c).to(torch.int32)
         if vn != "by_rel":
-            f_cnt = np.array([v["n_fix"] for v in vs], dtype=np.int64)
-            p_off = i64(np.concatenate([[0], np.cumsum([v["n_partial"] for v in vs])])[:-1])
+            f_np = host[vn + "/f"]
             out["b"] = cat(vn, "b")
             out["chunk_seg"] = (cat(vn, "chunk_seg") + node_c).to(torch.int32)
             slot = cat(vn, "chunk_slot").to(torch.int64)
-            out["chunk_slot"] = torch.where(slot >= 0, slot + rep(p_off, c_cnt), slot).to(torch.int32)
-            out["fix_seg"] = (cat(vn, "fix_seg") + rep(node_off, f_cnt)).to(torch.int32)
-            out["fix_slot"] = (cat(vn, "fix_slot") + rep(p_off, f_cnt)).to(torch.int32)
+            out["chunk_slot"] = torch.where(slot >= 0, slot + rep(d[vn + "/p"], d[vn + "/c"], c_np), slot).to(torch.int32)
+            out["fix_seg"] = (cat(vn, "fix_seg") + rep(node_off, d[vn + "/f"], f_np)).to(torch.int32)
+            out["fix_slot"] = (cat(vn, "fix_slot") + rep(d[vn + "/p"], d[vn + "/f"], f_np)).to(torch.int32)
             out["fix_cnt"] = cat(vn, "fix_cnt")
-            out["n_seg"], out["n_partial"], out["n_fix"] = int(snap.n), int(sum(v["n_partial"] for v in vs)), int(f_cnt.sum())
+            out["n_seg"], out["n_partial"], out["n_fix"] = int(snap.n), int(sum(v["n_partial"] for v in vs)), int(f_np.sum())
         else:                                            # tile = member snapshot, see _concat_rel_views
-            counts = np.stack([l["rel_chunks"] for l in lv])
-            per_rel = counts.sum(axis=0)
-            multi = per_rel > 1
-            fix_seg = np.nonzero(multi)[0]
-            fix_cnt = per_rel[fix_seg]
-            fix_slot = np.cumsum(fix_cnt) - fix_cnt
-            base = np.full(n_rel_rows, -1, dtype=np.int64)
-            base[fix_seg] = fix_slot
-            table = np.where(multi[None, :], base[None, :] + (np.cumsum(counts, axis=0) - counts), -1)      # (members, rels)
             seg = cat(vn, "chunk_seg").to(torch.int64)
-            tab = i64(table.reshape(-1))[rep(i64(np.arange(len(lv)) * n_rel_rows), c_cnt) + seg]
-            rank = torch.cat([d["rel_rank"] for d in dv]).to(torch.int64)
+            tab = d["rel/table"][rep(d["rel/member"], d[vn + "/c"], c_np) + seg]
+            rank = torch.cat([x["rel_rank"] for x in dv]).to(torch.int64)
             out["b"] = (cat(vn, "b") + node_e).to(torch.int32)
             out["chunk_seg"] = seg.to(torch.int32)
             out["chunk_slot"] = torch.where(tab >= 0, tab + rank, tab).to(torch.int32)
-            out["fix_seg"], out["fix_slot"], out["fix_cnt"] = (torch.from_numpy(x.astype(np.int32)).to(device) for x in (fix_seg, fix_slot, fix_cnt))
+            out["fix_seg"], out["fix_slot"], out["fix_cnt"] = (d[k].to(torch.int32) for k in ("rel/fix_seg", "rel/fix_slot", "rel/fix_cnt"))
             out["n_seg"], out["n_partial"], out["n_fix"] = int(n_rel_rows), int(per_rel[multi].sum()), int(fix_seg.shape[0])
         views[vn] = out
-    in_deg = torch.cat([d["in_deg"] for d in dv])
-    out_deg = torch.cat([d["out_deg"] for d in dv])
-    nnorm = torch.cat([d["nnorm"] for d in dv])
+    in_deg = torch.cat([x["in_deg"] for x in dv])
+    out_deg = torch.cat([x["out_deg"] for x in dv])
+    nnorm = torch.cat([x["nnorm"] for x in dv])
     return views, in_deg, out_deg, nnorm
 
 
@@ -418,8 +441,8 @@ class _DeviceGraph:
         packed = np.concatenate(parts) if parts else np.zeros(0, np.int32)
         if packed.shape[0] == 0:
             packed = np.zeros(1, np.int32)
-        self.ints = torch.from_numpy(packed).to(device)
-        self.nnorm = torch.from_numpy(snap.nnorm if n else np.zeros(1, np.float32)).to(device)
+        self.ints = _lib.to_device(packed, device)
+        self.nnorm = _lib.to_device(snap.nnorm if n else np.zeros(1, np.float32), device)
         self.in_deg = self.ints[0:n]
         self.out_deg = self.ints[n:2 * n]
         self.views = views

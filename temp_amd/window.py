@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import snapshot as S
+from . import _lib
 
 
 def window_times(t_list, seq_len, times, ascending=False):
@@ -66,9 +67,9 @@ class Step:
         key = str(device)
         t = self.dev.get(key)
         if t is None:
-            t = (torch.from_numpy(self.ids.astype(np.int32)).to(device),
-                 torch.from_numpy(self.prev_idx.astype(np.int32)).to(device),
-                 torch.from_numpy(self.dt.astype(np.float32)).view(-1, 1).to(device))
+            t = (_lib.to_device(self.ids.astype(np.int32), device),
+                 _lib.to_device(self.prev_idx.astype(np.int32), device),
+                 _lib.to_device(self.dt.astype(np.float32), device).view(-1, 1))
             self.dev[key] = t
         return t
 

@@ -5,6 +5,7 @@ It follows the C-ABI contract of include/temp_amd.h *through the same sorted/chu
 the kernels read* (so a wrong view shows up here), using torch CPU ops and the oracle's GRU
 equations.  It lives under tests/ and is never imported by the product package.
 """
+import numpy as np
 import torch
 
 from oracle import temp_oracle as O
@@ -300,6 +301,25 @@ class CpuTestBackend:
         w = scale.reshape(-1)[0] * (row_scale.view(-1, 1) if row_scale is not None else inv_rows)
         d.scatter_add_(1, c, g * w)
         return d
+
+    def corrupt_sample(self, seed, truth, lo, hi, ids, K, N):
+        """Same contract as the kernel (column 0 = truth, filtered uniform draws), numpy random stream."""
+        rng = np.random.default_rng(int(seed) & 0xFFFFFFFF)
+        R = truth.shape[0]
+        out = rng.integers(0, N, size=(R, K + 1)).astype(np.int32)
+        out[:, 0] = truth.numpy()
+        if lo is not None and R:
+            lo_n, hi_n, ids_n = lo.numpy(), hi.numpy(), ids.numpy()
+            for r in range(R):
+                bad = ids_n[lo_n[r]:hi_n[r]]
+                if bad.size == 0:
+                    continue
+                for _ in range(64):
+                    m = np.isin(out[r, 1:], bad)
+                    if not m.any():
+                        break
+                    out[r, 1:][m] = rng.integers(0, N, size=int(m.sum()))
+        return torch.from_numpy(out)
 
     def filtered_rank(self, scores, target, filt_ptr=None, filt_ids=None):
         s = scores.detach().clone()

@@ -383,7 +383,10 @@ def test_forward_with_device_sampler_end_to_end_gpu():
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}     # time_embed etc. are unused in this config
     assert {"ent_embeds", "rel_embeds", "ent_encoder.layer_1.weight", "ent_encoder.layer_2.forward_rnn.weight_hh_l0"} <= set(grads)
     assert all(torch.isfinite(g).all() for g in grads.values())
-    assert m._dev_corrupter.device.type == "cuda"
+    assert m._true_store.device.type == "cuda" and m._true_store.size > 0          # planned loss + one sampler launch
+    wb = m.prepare(torch.tensor([20, 15, 9]), m.train_seq_len, train=True)
+    trip, neg_tail, neg_head = m.draw_samples(wb)[0]                                 # the per-graph sampler interface
+    assert m._dev_corrupter.device.type == "cuda" and neg_tail.is_cuda and neg_tail.shape == (trip.shape[0], 1 + m.args.negative_rate)
 
 
 def test_full_size_step_properties_gpu():
@@ -635,3 +638,64 @@ def test_linear_multi_matches_single_products():
     for ai, bi in zip(a2, b2):
         assert_close(out2[row:row + ai.shape[0]], ai.double() @ bi.double(), 1e-5, 1e-4, "A . B")
         row += ai.shape[0]
+
+
+def test_corrupt_sample_kernel_contract():
+    """temp_corrupt_sample: column 0 = truth, draws in range and never in the row's known-true slice (short slices: linear
+    scan, long ones: binary search), a pure function of the seed, uniform over the entities that are allowed."""
+    g = torch.Generator().manual_seed(4)
+    R, K, N = 3000, 500, 500
+    truth = torch.randint(0, N, (R,), generator=g).int()
+    cnt = torch.randint(0, 6, (R,), generator=g)
+    cnt[::7] = 200                                               # long known-true sets (40 % of all entities)
+    cnt[5] = N - 1                                               # a single allowed entity
+    lists = [torch.randperm(N, generator=g)[:c].sort().values for c in cnt.tolist()]
+    ids = torch.cat(lists).int()
+    hi = torch.cumsum(cnt, 0).int()
+    lo = hi - cnt.int()
+    be = TB.get_backend()
+    d = lambda t: t.to(DEV)
+    a = be.corrupt_sample(11, d(truth), d(lo), d(hi), d(ids), K, N).cpu()
+    b = be.corrupt_sample(11, d(truth), d(lo), d(hi), d(ids), K, N).cpu()
+    c = be.corrupt_sample(12, d(truth), d(lo), d(hi), d(ids), K, N).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert a.shape == (R, K + 1) and torch.equal(a[:, 0], truth) and int(a.min()) >= 0 and int(a.max()) < N
+    an = a.numpy()
+    for r in range(R):
+        assert not np.isin(an[r, 1:], lists[r].numpy()).any(), r
+    allowed5 = np.setdiff1d(np.arange(N), lists[5].numpy())
+    assert (an[5, 1:] == allowed5[0]).all()
+    free = an[cnt.numpy() == 0][:, 1:]                           # unfiltered rows: uniform over [0, N)
+    hist = np.bincount(free.reshape(-1), minlength=N)
+    exp = free.size / N
+    assert abs(hist - exp).max() < 6 * np.sqrt(exp)
+    raw = be.corrupt_sample(3, d(truth), None, None, None, K, N).cpu()
+    assert torch.equal(raw[:, 0], truth) and int(raw.max()) < N
+    assert be.corrupt_sample(3, d(truth[:0]), None, None, None, K, N).shape == (0, K + 1)
+
+
+def test_training_step_with_planned_loss_gpu():
+    """The default training path on the GPU: prepare() plans the loss, run_loss draws negatives with ONE kernel launch;
+    equal to feeding the same candidates through the samples= interface."""
+    from tests.window_cases import build_window_model
+    from tests.golden_util import load
+    z = load("G10_bi_grrgcn_rol")
+    m = build_window_model(z, DEV)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    m.sample_rng = np.random.default_rng(3)
+    wb = m.prepare(t_list, int(z["L"]), train=True)
+    plan = wb.loss_plan
+    assert plan is not None
+    m.seed_rng = np.random.default_rng(7)
+    loss1 = m.run_loss(wb)
+    m.seed_rng = np.random.default_rng(7)
+    cand = TB.get_backend().corrupt_sample(int(m.seed_rng.integers(1 << 62)), plan["truth"], plan["lo"], plan["hi"], plan["ids"],
+                                           m.args.negative_rate, m.num_ents)
+    samples = []
+    for b, (a0, a1) in enumerate(plan["splits"]):
+        P = (a1 - a0) // 2
+        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a1].long()))
+    loss2 = m.run_loss(wb, samples)
+    assert abs(loss1.item() - loss2.item()) < 2e-5 * max(1.0, abs(loss2.item()))
+    loss1.backward()
+    assert torch.isfinite(m.ent_embeds.grad).all()

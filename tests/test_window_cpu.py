@@ -265,3 +265,52 @@ def test_random_dropout_resamples_history_visits(module):
     loss = m.run_loss(wb)
     loss.backward()
     assert torch.isfinite(loss) and m.ent_embeds.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("name", ["G10_bi_grrgcn_rol", "G10_uni_grrgcn_rol"])
+def test_planned_loss_equals_injected_samples(name):
+    """prepare() plans the loss on the host (positives, operand indices, known-true slices of the resident store); run_loss
+    then needs ONE sampler call.  The result equals the reference-shaped path fed with the same candidates, the store's
+    slices equal the reference's true_tail / true_head dictionaries, and no drawn candidate is a true triple."""
+    from tests.window_cases import build_window_model
+    z = load(name)
+    m = build_window_model(z, torch.device("cpu"))
+    m.args.num_pos_facts = 40                                   # below some graphs' edge counts: exercises the random subset
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    m.sample_rng = np.random.default_rng(3)
+    wb = m.prepare(t_list, int(z["L"]), train=True)
+    plan = wb.loss_plan
+    assert plan is not None and getattr(wb, "all_maps", None) is not None
+    s = slice_snapshots()
+    ids = plan["ids"].numpy()
+    lo, hi, truth, is_tail = (plan[k].numpy() for k in ("lo", "hi", "truth", "is_tail"))
+    row = 0
+    for b, g in enumerate(wb.graphs):
+        trip = plan["triples"][b]
+        P = trip.shape[0]
+        assert P == min(g.number_of_edges(), 40) and plan["splits"][b] == (row, row + 2 * P)
+        tails, heads = {}, {}
+        for h, r, o in zip(g.src, g.rel, g.dst):
+            tails.setdefault((int(h), int(r)), set()).add(int(g.gids[o]))
+            heads.setdefault((int(r), int(o)), set()).add(int(g.gids[h]))
+        for i, (h, r, o) in enumerate(trip):
+            assert set(ids[lo[row + i]:hi[row + i]].tolist()) == tails[(int(h), int(r))] and truth[row + i] == g.gids[o] and is_tail[row + i] == 1
+            assert set(ids[lo[row + P + i]:hi[row + P + i]].tolist()) == heads[(int(r), int(o))] and truth[row + P + i] == g.gids[h]
+        row += 2 * P
+    m.seed_rng = np.random.default_rng(7)
+    loss1 = m.run_loss(wb)
+    m.seed_rng = np.random.default_rng(7)
+    cand = TB.get_backend().corrupt_sample(int(m.seed_rng.integers(1 << 62)), plan["truth"], plan["lo"], plan["hi"], plan["ids"],
+                                           m.args.negative_rate, m.num_ents)
+    cn = cand.numpy()
+    assert cn.shape == (row, 1 + m.args.negative_rate) and np.array_equal(cn[:, 0], truth) and cn.min() >= 0 and cn.max() < m.num_ents
+    for r in range(row):
+        assert not np.isin(cn[r, 1:], ids[lo[r]:hi[r]]).any()
+    samples = []
+    for b, (a0, a1) in enumerate(plan["splits"]):
+        P = (a1 - a0) // 2
+        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a1].long()))
+    loss2 = m.run_loss(wb, samples)
+    assert abs(loss1.item() - loss2.item()) < 1e-5 * max(1.0, abs(loss2.item()))
+    loss1.backward()
+    assert torch.isfinite(m.ent_embeds.grad).all() and m.rel_embeds.grad.abs().sum() > 0

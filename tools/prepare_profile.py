@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Host-side cost of preparing one window batch (plan + views + upload) on the GPU box: python tools/prepare_profile.py"""
+"""Host-side cost of preparing one window batch (plan + views + upload) on the GPU box, steady state (per-snapshot caches warm):
+python tools/prepare_profile.py [workload] [tottime|cumulative]"""
 import cProfile
 import os
 import pstats
@@ -17,16 +18,19 @@ w = synthetic.workload(sys.argv[1] if len(sys.argv) > 1 else "S-gdelt", seed=0)
 dev = torch.device("cuda:0")
 model = bench.build_model(w, dev)
 model.sample_rng = np.random.default_rng(2)
-for rep in range(12):
-    targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rep)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    wb = model.prepare(targets, w["L"], train=True)
-    torch.cuda.synchronize()
-    print("prepare #%d: %.1f ms" % (rep, 1e3 * (time.time() - t0)))
+batches = [synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rep) for rep in range(20)]
+for b in batches:
+    model.prepare(b, w["L"], train=True)
+torch.cuda.synchronize()
+t0 = time.time()
+for b in batches:
+    model.prepare(b, w["L"], train=True)
+torch.cuda.synchronize()
+print("steady-state prepare: %.2f ms per batch" % (1e3 * (time.time() - t0) / len(batches)))
 pr = cProfile.Profile()
 pr.enable()
-wb = model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 3), w["L"], train=True)
+for b in batches:
+    model.prepare(b, w["L"], train=True)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+pstats.Stats(pr).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "tottime").print_stats(40)
