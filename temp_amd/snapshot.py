@@ -172,7 +172,7 @@ def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK):
     """Sort edges by `seg` (stable) and cut every segment into chunks of <= `chunk` edges.
     Returns a dict of int32 numpy arrays + counts (layout of TempEdgeView)."""
     seg = np.asarray(seg, dtype=np.int64)
-    order = np.argsort(seg, kind="stable")
+    order = np.argsort(seg.astype(np.uint16) if n_seg <= 65536 else seg, kind="stable")     # 16-bit keys: numpy radix-sorts them
     seg_s = seg[order]
     counts = np.bincount(seg_s, minlength=n_seg).astype(np.int64)
     ptr = np.concatenate([[0], np.cumsum(counts)])

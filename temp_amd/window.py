@@ -85,7 +85,7 @@ class ChainPlan:
         self.rows = rows
         row_of = np.full((self.bsz, num_ents), -1, dtype=np.int64)     # row in the previous executed step's output
         last = np.zeros((self.bsz, num_ents), dtype=np.float32)        # start_time_tensor
-        set_ids = [np.zeros(0, np.int64) for _ in range(self.bsz)]
+        prev_pairs = None
         self.steps = []
         for p in range(seq_len - 1):
             win = [b for b in range(self.bsz) if rows[b][p] is not None]
@@ -93,19 +93,15 @@ class ChainPlan:
                 continue
             assert win == list(range(len(win))), "padded windows must form a suffix of the batch"
             st = Step(p, win, [graph_dict[rows[b][p]] for b in win], [rows[b][p] for b in win])
-            pidx, dts = [], []
-            for j, b in enumerate(win):
-                ids = st.graphs[j].gids
-                pidx.append(row_of[b][ids])
-                dts.append(p - last[b][ids])
-            st.prev_idx = np.concatenate(pidx) if pidx else np.zeros(0, np.int64)
-            st.dt = np.concatenate(dts) if dts else np.zeros(0, np.float32)
-            for j, b in enumerate(win):                                # F8: history holds ONLY this step's nodes
-                ids = st.graphs[j].gids
-                row_of[b][set_ids[b]] = -1
-                row_of[b][ids] = st.offsets[j] + np.arange(len(ids))
-                set_ids[b] = ids
-                last[b][ids] = p
+            # all windows of the position at once: (window, entity) pairs of the step's rows
+            bb = np.repeat(np.asarray(win, dtype=np.int64), st.sizes)
+            st.prev_idx = row_of[bb, st.ids]
+            st.dt = (p - last[bb, st.ids]).astype(np.float32)
+            if prev_pairs is not None:                                 # F8: history holds ONLY this step's nodes
+                row_of[prev_pairs] = -1                                # (left padding: a window, once active, stays active)
+            row_of[bb, st.ids] = np.arange(st.n_rows, dtype=np.int64)
+            last[bb, st.ids] = p
+            prev_pairs = (bb, st.ids)
             self.steps.append(st)
         self.row_of, self.last = row_of, last
 
