@@ -149,7 +149,7 @@ def to_device(host, device):
     """Host tensor / numpy array -> `device`.  On a GPU the bytes are staged in a per-thread pinned ring buffer and the
     copy is stream-ordered (non_blocking): no host-side wait per upload.  A pageable copy blocks the calling thread until
     the stream reaches it -- tens of microseconds each even when idle, and a window batch has dozens of small index vectors.
-    The ring is recycled after a synchronize of the thread's current stream (once per 32 MB of uploads)."""
+    The ring is recycled after a device synchronize (once per 32 MB of uploads)."""
     import numpy as _np
     import torch as _torch
     t = _torch.from_numpy(_np.ascontiguousarray(host)) if isinstance(host, _np.ndarray) else host
@@ -163,7 +163,7 @@ def to_device(host, device):
         _stage.np = buf.numpy()
         _stage.off = 0
     if _stage.off + nbytes > _STAGE_BYTES:
-        _torch.cuda.current_stream(device).synchronize()
+        _torch.cuda.synchronize(device)              # every copy staged in the ring has landed, whatever stream carried it
         _stage.off = 0
     off = _stage.off
     _stage.off += (nbytes + 255) & ~255
