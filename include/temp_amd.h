@@ -321,6 +321,20 @@ int temp_bilinear_query_bwd(int P, int d, int kind, const float* ent_rows, const
                             const int32_t* is_tail, const float* d_q, float* d_known_rows, float* d_rel_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Snapshot store (build_interpolation_graphs / get_train_val_test_graph_at_t keep one DGL graph per timestamp,
+ * utils/dataset.py:151-232,268-305; dgl.batch rebuilds the union every call, models/DynamicRGCN.py:92).  Here every
+ * snapshot's sorted / chunked edge views stay resident on the device; a batch's TempGraph arrays are assembled from them
+ * by ONE launch: descriptor j copies member array src[0..len) to out[dst_off ..) shifted by `add`
+ *   mode 0: v + add     mode 1: v >= 0 ? v + add : v     mode 2: t = table[add + aux[i]]; t >= 0 ? t + v : t
+ * and piece p = elements [piece_start[p], piece_start[p] + TEMP_ASSEMBLE_PIECE) of descriptor piece_desc[p].
+ * All pointers are DEVICE pointers (descs included).
+ * ---------------------------------------------------------------------------------------------- */
+#define TEMP_ASSEMBLE_PIECE 4096
+typedef struct TempCopyDesc { const int32_t* src; const int32_t* aux; int32_t dst_off; int32_t len; int32_t add; int32_t mode; } TempCopyDesc;
+int temp_assemble_views(int n_pieces, const int32_t* piece_desc, const int32_t* piece_start, const TempCopyDesc* descs, const int32_t* table,
+                        int32_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Filtered negative sampling (CorruptTriples.negative_sampling / corrupt_triple, utils/CorrptTriples.py:36-85):
  *   cand[row, 0] = truth[row];   cand[row, 1..K] = uniform draws over [0, N) that are not in the row's
  *   known-true set ids[lo[row] .. hi[row])  (global entity ids, ascending within a row; lo/hi NULL = no filter).

@@ -56,6 +56,7 @@ class TempLinearProblem(ctypes.Structure):
     _fields_ = [("M", ctypes.c_int32), ("A", c_vp), ("B", c_vp), ("C", c_vp)]
 
 
+ASSEMBLE_PIECE = 4096
 SCORE_KINDS = {"distmult": 0, "complex": 1}
 
 # name -> (restype, argtypes); mirrors include/temp_amd.h one to one
@@ -99,6 +100,7 @@ SYMBOLS = {
     "temp_gather_ce_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp]),
     "temp_bilinear_query_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_bilinear_query_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_assemble_views": (_I, [_I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_corrupt_sample": (_I, [_I, _I, _I, ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_filtered_rank": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_fwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp]),

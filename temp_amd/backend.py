@@ -341,6 +341,12 @@ class HipBackend:
         _lib.check(rc, "temp_gather_ce_bwd")
         return d
 
+    def assemble_views(self, piece_desc, piece_start, descs, table, out):
+        """One launch of temp_assemble_views; all arguments are device tensors (descs: raw bytes of TempCopyDesc records)."""
+        rc = self.lib.temp_assemble_views(int(piece_desc.shape[0]), _ptr(piece_desc), _ptr(piece_start), _ptr(descs), _ptr(table), _ptr(out), _stream())
+        _lib.check(rc, "temp_assemble_views")
+        return out
+
     def corrupt_sample(self, seed, truth, lo, hi, ids, K, N):
         """(R, 1+K) int32 candidate lists: column 0 = truth, the rest filtered uniform draws (see temp_corrupt_sample)."""
         truth = _i32(truth, "truth")

@@ -597,6 +597,31 @@ __global__ void __launch_bounds__(256) k_bilinear_query(int P, int d, int kind, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Snapshot store: the edge views of a batch (a disjoint union of member snapshots whose sorted / chunked views are
+// resident on the device) are the members' arrays back to back with per-member offsets added.  One launch copies every
+// array of every member: a descriptor names a member array, its place in the packed output and how to shift it;
+// a piece is up to TEMP_ASSEMBLE_PIECE elements of one descriptor (one workgroup each).
+//   mode 0: out = v + add        mode 1: out = v >= 0 ? v + add : v   (partial-sum slots, -1 = none)
+//   mode 2: t = table[add + aux[i]];  out = t >= 0 ? t + v : t        (by-relation slots: base of the member x relation + rank)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_assemble_views(const int32_t* __restrict__ piece_desc, const int32_t* __restrict__ piece_start,
+                                                        const TempCopyDesc* __restrict__ descs, const int32_t* __restrict__ table,
+                                                        int32_t* __restrict__ out) {
+  const TempCopyDesc d = descs[piece_desc[blockIdx.x]];
+  const int start = piece_start[blockIdx.x];
+  const int end = min(d.len, start + TEMP_ASSEMBLE_PIECE);
+  int32_t* __restrict__ o = out + d.dst_off;
+  for (int i = start + threadIdx.x; i < end; i += 256) {
+    const int v = d.src[i];
+    int r;
+    if (d.mode == 0) r = v + d.add;
+    else if (d.mode == 1) r = v >= 0 ? v + d.add : v;
+    else { const int t = table[d.add + d.aux[i]]; r = t >= 0 ? t + v : t; }
+    o[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Filtered negative sampling (CorruptTriples.negative_sampling / corrupt_triple, utils/CorrptTriples.py:36-85):
 // for every positive row, K corrupted entities drawn uniformly over ALL entities, redrawing those that form a true
 // triple of the target snapshot (the row's known-true set is the slice ids[lo[row] .. hi[row]) of a resident store).
@@ -1051,6 +1076,14 @@ int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* 
     if (hipFuncSetAttribute((const void*)k_gather_ce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEMP_E_LAUNCH;
   }
   TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_bwd, dim3(P), dim3(256), lds, (hipStream_t)stream, C, N, scores, cand, lse_rows, scale, inv_rows, row_scale, d_scores);
+  return launch_status();
+}
+
+int temp_assemble_views(int n_pieces, const int32_t* piece_desc, const int32_t* piece_start, const TempCopyDesc* descs, const int32_t* table,
+                        int32_t* out, void* stream) {
+  if (n_pieces < 0 || (n_pieces > 0 && (!piece_desc || !piece_start || !descs || !out))) return TEMP_E_BADARG;
+  if (n_pieces == 0) return TEMP_OK;
+  TEMP_LAUNCH(K_COPY, k_assemble_views, dim3(n_pieces), dim3(256), 0, (hipStream_t)stream, piece_desc, piece_start, descs, table, out);
   return launch_status();
 }
 
