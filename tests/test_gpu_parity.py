@@ -699,3 +699,42 @@ def test_training_step_with_planned_loss_gpu():
     assert abs(loss1.item() - loss2.item()) < 2e-5 * max(1.0, abs(loss2.item()))
     loss1.backward()
     assert torch.isfinite(m.ent_embeds.grad).all()
+
+
+def test_full_size_loss_properties_gpu():
+    """BASELINE's headline size with the link-prediction loss (8 windows, 500 entities, negative_rate 500): the fused loss node
+    (folded-query kernel, multi-problem score GEMMs, counting CE, segment-sum adjoints) equals the reference-shaped
+    formulation -- gather (P, 1 + neg, D) candidates, utils/scores.py complex(), F.cross_entropy -- on the same candidates,
+    loss and gradients; and it is bitwise repeatable."""
+    import bench
+    from temp_amd import synthetic
+    w = synthetic.workload("S-gdelt", seed=0)
+    model = bench.build_model(w, DEV)
+    model.args.num_pos_facts = 400                      # the reference-shaped path materialises P x 501 x D floats per direction
+    targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)
+    model.sample_rng = np.random.default_rng(2)
+    wb = model.prepare(targets, w["L"], train=True)
+    plan = wb.loss_plan
+    assert plan is not None and plan["truth"].shape[0] == 8 * 2 * 400
+    cand = TB.get_backend().corrupt_sample(99, plan["truth"], plan["lo"], plan["hi"], plan["ids"], model.args.negative_rate, model.num_ents)
+    samples = []
+    for b, (a0, a1) in enumerate(plan["splits"]):
+        P = (a1 - a0) // 2
+        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a1].long()))
+
+    def run(fused):
+        model.fused_loss = fused
+        for p in model.parameters():
+            p.grad = None
+        loss = model.run_loss(wb, samples)
+        loss.backward()
+        return loss.detach().clone(), model.ent_embeds.grad.clone(), model.rel_embeds.grad.clone()
+
+    a = run(True)
+    b = run(True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)), "fused loss is not bitwise repeatable"
+    r = run(False)
+    model.fused_loss = True
+    assert abs(a[0].item() - r[0].item()) < 2e-5 * abs(r[0].item())
+    assert_close(a[1], r[1], 1e-4, 1e-5 * float(r[1].abs().max()), "d ent_embeds, fused vs reference-shaped loss")
+    assert_close(a[2], r[2], 1e-4, 1e-5 * float(r[2].abs().max()), "d rel_embeds, fused vs reference-shaped loss")
