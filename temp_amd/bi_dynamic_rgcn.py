@@ -193,22 +193,10 @@ class BiDynamicRGCN(DynamicRGCN):
         out, hist = self.run(wb)
         return list(out.split(wb.target.sizes)), wb.plan, wb.rows, wb.graphs, hist
 
-    def all_embeds_batched(self, wb, out, hist):
-        """Bidirectional version (models/BiDynamicRGCN.py:102-112, models/BiRRGCN.py:65-82): shared isolated trunk
-        (layer 2 with ReLU), then GRU_f + GRU_b over the entities that are inactive in their window's target graph."""
-        enc = self.ent_encoder
-        l1, l2 = enc.layer_1, enc.layer_2
-        (idx_f, dt_f), (idx_b, dt_b) = self._all_maps(wb)
-        if wb.n_inactive == 0:
-            return self._assemble_all(wb, out, None)
-        y1 = l1.conv_isolated(self.ent_embeds)
-        x = TF.gather_rows(l2.conv_isolated(y1), wb.inactive_ent, wb.inactive_inv)
+    def _isolated_rnns(self, hist):
+        l2 = self.ent_encoder.layer_2
         (Hf, _), (Hb, _) = hist
-        zero = x.new_zeros(1, x.shape[1])
-        lam, dec = l2.inv_temperature, l2.decay_spec()
-        allh = run_rnn(l2.forward_rnn, x, Hf if Hf is not None else zero, dt_f, lam, dec, idx_f if Hf is not None else torch.full_like(idx_f, -1)) + \
-            run_rnn(l2.backward_rnn, x, Hb if Hb is not None else zero, dt_b, lam, dec, idx_b if Hb is not None else torch.full_like(idx_b, -1))
-        return self._assemble_all(wb, out, allh)
+        return [(l2.forward_rnn, Hf), (l2.backward_rnn, Hb)]
 
     def get_all_embeds_Gt(self, convoluted_embeds, g, t, plans, b, hist):
         """models/BiDynamicRGCN.py:102-112."""

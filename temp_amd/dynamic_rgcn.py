@@ -322,37 +322,55 @@ class DynamicRGCN(TKG_Module):
         return [c.single_graph_negative_sampling(wb.rows[i][-1], g, self.num_ents)[:3] for i, g in enumerate(wb.graphs)]
 
     def _all_maps(self, wb):
-        """Inputs of the batched isolated pass, cached on the batch.  Only the entities that are NOT nodes of a window's
-        target graph need it (the active rows are overwritten by the graph convolution's output, models/DynamicRGCN.py:60-63):
-        per chain plan the previous-state row map / time gap of those entities, concatenated over the windows, and ONE
-        row map that assembles every window's (N_ents, D) matrix from [target rows ; isolated rows]."""
+        """Row maps of the batched all-entity pass (get_all_embeds_Gt for every window at once), cached on the batch.
+        An entity of window b falls in one of three classes:
+          active in b's target graph      -> its row of the encoder output (models/DynamicRGCN.py:60-63);
+          inactive, with a previous state -> one row of a GRU pass over exactly those (window, entity) pairs;
+          inactive, never seen in the window's history (previous state 0, the vast majority at ICEWS scale)
+                                          -> GRU(x_e, 0), which does not depend on the window: row e of ONE N_ents-row table.
+        Per chain plan (direction): the pairs with a previous state (entity, history row, time gap) and the map that assembles
+        the (B, N_ents) rows from [encoder output ; pair rows ; table]; for the second direction of a bidirectional encoder
+        the active rows map to -1 (the encoder output already holds both directions' sum)."""
         if getattr(wb, "all_maps", None) is None:
             dev = self._device()
-            N = self.num_ents
+            N, B = self.num_ents, len(wb.graphs)
             plans = wb.plan if isinstance(wb.plan, tuple) else (wb.plan,)
             L = plans[0].seq_len
-            inact = [np.setdiff1d(np.arange(N, dtype=np.int64), g.gids) for g in wb.graphs]
-            idxs = [np.concatenate([plan.final_all(b, L - 1)[0][inact[b]] for b in range(plan.bsz)]).astype(np.int32) for plan in plans]
-            dts = [np.concatenate([plan.final_all(b, L - 1)[1][inact[b]] for b in range(plan.bsz)]).astype(np.float32) for plan in plans]
+            act = np.zeros((B, N), dtype=bool)
             sizes = [g.n for g in wb.graphs]
             n_out = int(sum(sizes))
             off_out = np.concatenate([[0], np.cumsum(sizes)])
-            off_in = np.concatenate([[0], np.cumsum([len(x) for x in inact])])
-            asm = np.empty((len(wb.graphs), N), dtype=np.int64)
             for b, g in enumerate(wb.graphs):
-                asm[b, g.gids] = off_out[b] + np.arange(g.n)
-                asm[b, inact[b]] = n_out + off_in[b] + np.arange(len(inact[b]))
-            inact_all = np.concatenate(inact)
-            host = {"asm": asm.reshape(-1), "inact": inact_all}
-            for i, (a, t) in enumerate(zip(idxs, dts)):
-                host["idx%d" % i], host["dt%d" % i] = a, t.view(np.int32)            # float bits ride in the int32 pack
-            d = S.upload_packed(host, dev, np.int32)
-            wb.all_maps = [(d["idx%d" % i], d["dt%d" % i].view(torch.float32).view(-1, 1)) for i in range(len(plans))]
-            wb.inactive_ent = d["inact"]
-            wb.n_inactive = int(off_in[-1])
-            wb.assemble = d["asm"]
-            wb.assemble_inv = TF.gather_inverse(asm.reshape(-1), n_out + wb.n_inactive, dev)
-            wb.inactive_inv = TF.gather_inverse(inact_all, N, dev)
+                act[b, g.gids] = True
+            wb.n_inactive = int(B * N - act.sum())
+            host, meta = {}, []
+            ent = np.arange(N, dtype=np.int64)[None, :]
+            for d, plan in enumerate(plans):
+                row_of = np.stack([plan.final_all(b, L - 1)[0] for b in range(B)])
+                gap = np.stack([plan.final_all(b, L - 1)[1] for b in range(B)])
+                has = ~act & (row_of >= 0)
+                bb, ee = np.nonzero(has)                                   # window-major
+                n_prev = int(bb.shape[0])
+                if d == 0:
+                    asm = np.broadcast_to(n_out + n_prev + ent, (B, N)).copy()
+                    asm[has] = n_out + np.arange(n_prev)
+                    for b, g in enumerate(wb.graphs):
+                        asm[b, g.gids] = off_out[b] + np.arange(g.n)
+                    n_src = n_out + n_prev + N
+                else:
+                    asm = np.broadcast_to(n_prev + ent, (B, N)).copy()
+                    asm[has] = np.arange(n_prev)
+                    asm[act] = -1
+                    n_src = n_prev + N
+                host["ent%d" % d], host["idx%d" % d], host["asm%d" % d] = ee, row_of[bb, ee], asm.reshape(-1)
+                host["dt%d" % d] = gap[bb, ee].astype(np.float32).view(np.int32)           # float bits ride in the int32 pack
+                meta.append((n_prev, n_src, ee, asm.reshape(-1)))
+            dd = S.upload_packed(host, dev, np.int32)
+            wb.all_maps = []
+            for d, (n_prev, n_src, ee, asm) in enumerate(meta):
+                wb.all_maps.append(dict(n_prev=n_prev, ent=dd["ent%d" % d], idx=dd["idx%d" % d], dt=dd["dt%d" % d].view(torch.float32).view(-1, 1),
+                                        asm=dd["asm%d" % d], ent_inv=TF.gather_inverse(ee, N, dev) if n_prev else None,
+                                        asm_inv=TF.gather_inverse(asm, n_src if wb.n_inactive else n_out, dev)))
         return wb.all_maps
 
     def _assemble_all(self, wb, out, isolated):
@@ -362,23 +380,37 @@ class DynamicRGCN(TKG_Module):
         big = TF.gather_rows(src, wb.assemble, wb.assemble_inv)
         return big.view(len(wb.graphs), self.num_ents, big.shape[1])
 
+    def _isolated_rnns(self, hist):
+        """[(GRU, final history of its direction)] of the recurrent layer."""
+        return [(self.ent_encoder.layer_2.rnn, hist[1])]
+
     def all_embeds_batched(self, wb, out, hist):
-        """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64): with only the last layer recurrent the
-        isolated RGCN trunk e -> Iso2(Iso1(e)) is the same for every window, so it runs ONCE over the N_ents entities; the
-        GRU then runs once over the inactive entities of all windows, each window reading its own previous states through its
-        row map.  `out` = the concatenated target rows of the encoder.  Returns (B, N_ents, D)."""
+        """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64; Bi: models/BiDynamicRGCN.py:102-112,
+        models/BiRRGCN.py:65-82).  With only the last layer recurrent the isolated RGCN trunk e -> Iso2(Iso1(e)) is the same
+        for every window, so it runs ONCE over the N_ents entities; so does the GRU from a zero state.  Only the (window,
+        entity) pairs that carry a previous state get their own GRU rows (see _all_maps).  `out` = the concatenated target
+        rows of the encoder.  Returns (B, N_ents, D)."""
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
-        (idx, dt), = self._all_maps(wb)
+        maps = self._all_maps(wb)
+        B, N = len(wb.graphs), self.num_ents
         if wb.n_inactive == 0:
-            return self._assemble_all(wb, out, None)
-        y1 = l1.conv_isolated(self.ent_embeds)
-        x = TF.gather_rows(l2.conv_isolated(y1), wb.inactive_ent, wb.inactive_inv)
-        H = hist[1]
-        prev = H if H is not None else x.new_zeros(1, x.shape[1])
-        pidx = idx if H is not None else torch.full_like(idx, -1)
-        allh = run_rnn(l2.rnn, x, prev, dt, l2.inv_temperature, l2.decay_spec(), pidx)
-        return self._assemble_all(wb, out, allh)
+            return TF.gather_rows(out, maps[0]["asm"], maps[0]["asm_inv"]).view(B, N, out.shape[1])
+        x = l2.conv_isolated(l1.conv_isolated(self.ent_embeds))
+        lam, dec = l2.inv_temperature, l2.decay_spec()
+        zero = x.new_zeros(1, x.shape[1])
+        dt0 = x.new_zeros(N, 1)
+        none = torch.full((N,), -1, dtype=torch.int32, device=x.device)
+        big = None
+        for d, (m, (rnn, H)) in enumerate(zip(maps, self._isolated_rnns(hist))):
+            parts = [out] if d == 0 else []
+            if m["n_prev"]:
+                xp = TF.gather_rows(x, m["ent"], m["ent_inv"])
+                parts.append(run_rnn(rnn, xp, H, m["dt"], lam, dec, m["idx"]))
+            parts.append(run_rnn(rnn, x, zero, dt0, lam, dec, none))             # GRU(x_e, 0): one row per entity, every window
+            g = TF.gather_rows(torch.cat(parts, dim=0), m["asm"], m["asm_inv"])
+            big = g if big is None else big + g
+        return big.view(B, N, big.shape[1])
 
     def run_loss(self, wb, samples=None):
         """Encoder pass + the per-window link-prediction losses (summed, as the reference does)."""
