@@ -306,6 +306,12 @@ int launch_wres_one(int kid, const PanelBatch<Epi>& batch, int count, const Wres
   }
   int bps = local_blocks / roles;
   if (bps < 1) bps = 1;
+  // small problems (a window position at ICEWS scale is a few hundred rows): no more blocks than there are 32-row panels
+  // to walk -- every extra block would still copy its 78 KB slice of B into LDS and find nothing to do
+  int max_m = 0;
+  for (int i = 0; i < count; ++i) max_m = batch.p[i].M > max_m ? batch.p[i].M : max_m;
+  const int need = ceil_div(ceil_div(ceil_div(max_m, 32), 8), 4);
+  if (bps > need) bps = need < 1 ? 1 : need;
   TEMP_LAUNCH(kid, (k_gemm_wres<NTS, Epi>), dim3(roles * bps * 8), dim3(256), lds, st, batch, count, g, bps);
   return launch_status();
 }
