@@ -1,0 +1,58 @@
+/* temp_amd host-side planner: plain C ABI, no GPU, no torch.
+ *
+ * The reference rebuilds its batched DGL graph (dgl.batch is C++ inside DGL) and its dense history tensors inside
+ * every forward (models/DynamicRGCN.py:35-54,76-94,156-174).  Here the per-batch host work is index bookkeeping over
+ * cached per-snapshot arrays; the two pieces that were interpreter-bound loops live in this library:
+ *   temp_host_build_view   the sorted / chunked edge view of ONE snapshot (TempEdgeView layout of temp_amd.h);
+ *   temp_host_chain_plan   the row maps of a window chain (which row of the previous executed position every node
+ *                          continues from, and the time gap), i.e. get_prev_embeddings +
+ *                          update_time_diff_hist_embeddings (models/DynamicRGCN.py:35-54) as int32 / float rows
+ *                          instead of a dense re-zeroed (bsz, 2, N_ents, D) history.
+ * All buffers are caller-owned; return value 0 = ok, non-zero = bad argument.
+ */
+#ifndef TEMP_AMD_HOST_H
+#define TEMP_AMD_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Stable sort of the E edges by `seg` (0 <= seg < n_seg), every segment cut into chunks of <= `chunk` edges.
+ *   order[E]                 the permutation (edge ids in view order)
+ *   a_out[E], b_out[E]       a[order], b[order] as int32
+ *   chunk_seg/beg/end/slot   one entry per chunk (capacity E): segment, edge range, partial-sum slot (-1 = single-chunk segment)
+ *   fix_seg/slot/cnt         one entry per multi-chunk segment (capacity E): segment, first slot, number of chunks
+ *   counts[3]                n_chunks, n_partial (chunks that go through slots), n_fix */
+int temp_host_build_view(int64_t E, const int64_t* seg, const int64_t* a, const int64_t* b, int64_t n_seg, int64_t chunk,
+                         int64_t* order, int32_t* a_out, int32_t* b_out,
+                         int32_t* chunk_seg, int32_t* chunk_beg, int32_t* chunk_end, int32_t* chunk_slot,
+                         int32_t* fix_seg, int32_t* fix_slot, int32_t* fix_cnt, int64_t* counts);
+
+/* Row maps of one chain (one direction) over its executed positions.
+ *   n_steps executed positions; step s is window position pos[s] with n_win[s] active windows (windows 0 .. n_win[s]-1:
+ *   left-padded windows form a suffix of the batch and, once active, stay active);
+ *   gids[s * bsz + j] / gid_n[s * bsz + j]: global entity ids of window j's snapshot at step s (its node rows, in order).
+ * Outputs, concatenated over steps in (step, window, node) order:
+ *   prev_idx  row of the same entity in the PREVIOUS executed step's output of that window, -1 if it was not a node there
+ *             (the reference's history is re-zeroed every position: only the immediately preceding step's nodes carry state)
+ *   dt        pos[s] - (position at which the entity was last a node of the window, 0 if never)
+ * and the final state after the last step: row_of[bsz * num_ents] (same meaning, for the target / all-entity consumers)
+ * and last[bsz * num_ents] (last active position, 0 if never).  row_of / last are fully written. */
+int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* pos, const int32_t* n_win,
+                         const int64_t* const* gids, const int64_t* gid_n,
+                         int64_t* prev_idx, float* dt, int64_t* row_of, float* last);
+
+/* Index lists of a batch's link-prediction loss (train_link_prediction + negative_sampling set-up,
+ * models/TKG_Module.py:202-213, utils/CorrptTriples.py:36-56): for graph g with P_g chosen positives idx[g][0..P_g) the
+ * 2 P_g rows [tail-corruption rows ; head-corruption rows] are appended to six int32 vectors of length R = 2 sum P_g
+ * (packed[6][R]: known row, relation, is_tail, true entity (global id), lo, hi of the known-true slice) and weights[R] = 1/P_g;
+ * triples[sum P_g][3] (local src, rel, dst) in graph order.
+ *   graph_ptrs[g][8] = { src, rel, dst, gids (int64 arrays) , tail_lo, tail_hi, head_lo, head_hi (int32 arrays, per edge) } */
+int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* const* idx, const int64_t* n_pos, const int64_t* row_offset,
+                        int64_t R, int32_t* packed, float* weights, int64_t* triples);
+
+int temp_host_abi_version(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

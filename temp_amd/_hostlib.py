@@ -1,0 +1,118 @@
+"""ctypes binding of libtemp_host.so (include/temp_amd_host.h): the host-side planner pieces that were interpreter-bound
+loops.  Plain C++ (g++), no GPU: built on first use when the in-tree library is missing or older than its source."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+SRC = os.path.join(PKG, "csrc", "host_planner.cpp")
+HDR = os.path.join(REPO, "include", "temp_amd_host.h")
+LIB_PATH = os.path.join(PKG, "libtemp_host.so")
+_lib = None
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+SYMBOLS = {
+    "temp_host_abi_version": (ctypes.c_int, []),
+    "temp_host_build_view": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "temp_host_plan_loss": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+
+def build(force=False, verbose=False):
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in (SRC, HDR))
+    if force or stale:
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(REPO, "include"), "-o", LIB_PATH, SRC]
+        if verbose:
+            print("[temp_amd.build] " + " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.temp_host_abi_version() != 1:
+            raise RuntimeError("libtemp_host.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _i64(x):
+    return np.ascontiguousarray(x, dtype=np.int64)
+
+
+def build_view(seg, a, b, n_seg, chunk):
+    """Sorted / chunked edge view of one snapshot (see temp_host_build_view) -> dict in the layout snapshot.py uses."""
+    seg, a, b = _i64(seg), _i64(a), _i64(b)
+    E = int(seg.shape[0])
+    cap = max(E, 1)
+    order = np.empty(cap, np.int64)
+    out = {k: np.empty(cap, np.int32) for k in ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")}
+    counts = np.zeros(3, np.int64)
+    rc = load().temp_host_build_view(E, seg.ctypes.data, a.ctypes.data, b.ctypes.data, int(n_seg), int(chunk), order.ctypes.data,
+                                     out["a"].ctypes.data, out["b"].ctypes.data, out["chunk_seg"].ctypes.data, out["chunk_beg"].ctypes.data,
+                                     out["chunk_end"].ctypes.data, out["chunk_slot"].ctypes.data, out["fix_seg"].ctypes.data,
+                                     out["fix_slot"].ctypes.data, out["fix_cnt"].ctypes.data, counts.ctypes.data)
+    if rc != 0:
+        raise ValueError("temp_host_build_view: bad argument (code %d): segment id outside [0, %d)?" % (rc, n_seg))
+    nch, npart, nfix = (int(c) for c in counts)
+    res = dict(n_seg=int(n_seg), n_edges=E, a=out["a"][:E], b=out["b"][:E], n_chunks=nch, n_partial=npart, n_fix=nfix, order=order[:E])
+    for k in ("chunk_seg", "chunk_beg", "chunk_end", "chunk_slot"):
+        res[k] = out[k][:nch]
+    for k in ("fix_seg", "fix_slot", "fix_cnt"):
+        res[k] = out[k][:nfix]
+    return res
+
+
+def chain_plan(bsz, num_ents, positions, n_win, gid_arrays):
+    """Row maps of one window chain (see temp_host_chain_plan).  gid_arrays[s][j] = int64 gids of window j at executed step s.
+    -> (prev_idx [total], dt [total], row_of [bsz, num_ents], last [bsz, num_ents])"""
+    n_steps = len(positions)
+    ptrs = np.zeros(max(n_steps * bsz, 1), np.int64)
+    lens = np.zeros(max(n_steps * bsz, 1), np.int64)
+    for s, arrs in enumerate(gid_arrays):
+        for j, g in enumerate(arrs):
+            ptrs[s * bsz + j] = g.ctypes.data
+            lens[s * bsz + j] = g.shape[0]
+    total = int(lens.sum())
+    prev_idx = np.empty(max(total, 1), np.int64)
+    dt = np.empty(max(total, 1), np.float32)
+    row_of = np.empty((bsz, num_ents), np.int64)
+    last = np.empty((bsz, num_ents), np.float32)
+    pos = np.ascontiguousarray(positions, dtype=np.int32)
+    nw = np.ascontiguousarray(n_win, dtype=np.int32)
+    rc = load().temp_host_chain_plan(int(bsz), int(num_ents), n_steps, pos.ctypes.data, nw.ctypes.data, ptrs.ctypes.data, lens.ctypes.data,
+                                     prev_idx.ctypes.data, dt.ctypes.data, row_of.ctypes.data, last.ctypes.data)
+    if rc != 0:
+        raise ValueError("temp_host_chain_plan: bad argument (code %d)" % rc)
+    return prev_idx[:total], dt[:total], row_of, last
+
+
+def plan_loss(graph_ptrs, idx_list, row_offsets):
+    """See temp_host_plan_loss.  graph_ptrs: (G, 8) int64 addresses; idx_list: G int64 arrays of chosen edge ids.
+    -> (packed int32 [6, R], weights float32 [R], triples int64 [sum P, 3])"""
+    G = len(idx_list)
+    idx_list = [_i64(x) for x in idx_list]
+    n_pos = np.array([x.shape[0] for x in idx_list], dtype=np.int64)
+    R = int(2 * n_pos.sum())
+    packed = np.empty((6, max(R, 1)), np.int32)
+    weights = np.empty(max(R, 1), np.float32)
+    triples = np.empty((max(R // 2, 1), 3), np.int64)
+    ptrs = np.array([x.ctypes.data for x in idx_list], dtype=np.int64) if G else np.zeros(1, np.int64)
+    gp = np.ascontiguousarray(graph_ptrs, dtype=np.int64) if G else np.zeros((1, 8), np.int64)
+    ro = _i64(row_offsets) if G else np.zeros(1, np.int64)
+    rc = load().temp_host_plan_loss(G, gp.ctypes.data, ptrs.ctypes.data, n_pos.ctypes.data, ro.ctypes.data, R, packed.ctypes.data,
+                                    weights.ctypes.data, triples.ctypes.data)
+    if rc != 0:
+        raise ValueError("temp_host_plan_loss: bad argument (code %d)" % rc)
+    return packed[:, :R], weights[:R], triples[:R // 2], n_pos

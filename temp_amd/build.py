@@ -1,4 +1,4 @@
-"""Build libtemp_amd.so (hand-written HIP kernels + C ABI) for gfx950, in-tree.
+"""Build libtemp_amd.so (hand-written HIP kernels + C ABI) for gfx950 and libtemp_host.so (host planner, g++), in-tree.
 
     python -m temp_amd.build [--force]
 
@@ -25,6 +25,8 @@ def _stale():
 
 
 def build(force=False, verbose=True):
+    from . import _hostlib
+    _hostlib.build(force=force, verbose=verbose)            # host planner (plain C++, g++): temp_amd/libtemp_host.so
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -151,6 +151,9 @@ class TrueSetStore:
             s = self._snap[t] = dict(
                 tail_lo=(base + np.searchsorted(kt, pt * N)).astype(np.int32), tail_hi=(base + np.searchsorted(kt, (pt + 1) * N)).astype(np.int32),
                 head_lo=(off_h + np.searchsorted(kh, ph * N)).astype(np.int32), head_hi=(off_h + np.searchsorted(kh, (ph + 1) * N)).astype(np.int32))
+            # addresses of the per-edge arrays for the host planner (the arrays live as long as the snapshot / this store)
+            s["ptrs"] = np.array([g.src.ctypes.data, g.rel.ctypes.data, g.dst.ctypes.data, g.gids.ctypes.data, s["tail_lo"].ctypes.data,
+                                  s["tail_hi"].ctypes.data, s["head_lo"].ctypes.data, s["head_hi"].ctypes.data], dtype=np.int64)
         return s
 
 
@@ -160,34 +163,22 @@ def plan_batch_loss(store, times, graphs, row_offsets, num_pos_facts, rng, n_row
     when E is larger, utils/CorrptTriples.py:37-40), stacked as [tail-corruption rows ; head-corruption rows]:
       known / rel / is_tail   operands of the folded query      truth, lo, hi    inputs of temp_corrupt_sample
       weights (1 / P), splits, known_inv / rel_inv (static inverses for the deterministic backward), triples (host, per graph)."""
+    from . import _hostlib
     from . import functional as TF
-    known, rel, tail, truth, lo, hi, weights, splits, triples = [], [], [], [], [], [], [], [], []
-    row = 0
-    for b, (t, g) in enumerate(zip(times, graphs)):
+    ptrs, idxs = [], []
+    for t, g in zip(times, graphs):
         E = g.number_of_edges()
         P = min(E, num_pos_facts)
-        if P == 0:
-            splits.append((row, row))
-            triples.append(np.zeros((0, 3), np.int64))
-            continue
-        idx = rng.permutation(E)[:P] if num_pos_facts < E else np.arange(E)
-        s = store.snapshot(t)
-        src, r, dst = g.src[idx], g.rel[idx], g.dst[idx]
-        triples.append(np.stack([src, r, dst], axis=1))
-        known.append(np.concatenate([src, dst]) + row_offsets[b])
-        rel.append(np.concatenate([r, r]))
-        tail.append(np.concatenate([np.ones(P, np.int32), np.zeros(P, np.int32)]))
-        truth.append(np.concatenate([g.gids[dst], g.gids[src]]))
-        lo.append(np.concatenate([s["tail_lo"][idx], s["head_lo"][idx]]))
-        hi.append(np.concatenate([s["tail_hi"][idx], s["head_hi"][idx]]))
-        weights.append(np.full(2 * P, 1.0 / P, np.float32))
-        splits.append((row, row + 2 * P))
-        row += 2 * P
-    if row == 0:
+        idxs.append(rng.permutation(E)[:P] if num_pos_facts < E else np.arange(E, dtype=np.int64))
+        ptrs.append(store.snapshot(t)["ptrs"])
+    packed, weights, trip_all, n_pos = _hostlib.plan_loss(np.stack(ptrs) if ptrs else np.zeros((0, 8), np.int64), idxs, np.asarray(row_offsets, dtype=np.int64))
+    if packed.shape[1] == 0:
         return None
-    known, rel = np.concatenate(known), np.concatenate(rel)
-    packed = np.stack([known, rel, np.concatenate(tail), np.concatenate(truth), np.concatenate(lo), np.concatenate(hi)]).astype(np.int32)
+    ends = np.cumsum(2 * n_pos)
+    splits = [(int(e - 2 * p), int(e)) for e, p in zip(ends, n_pos)]
+    tcut = np.cumsum(n_pos)
+    triples = [trip_all[int(e - p):int(e)] for e, p in zip(tcut, n_pos)]
     dev_i = _lib.to_device(packed, device)                       # ONE upload for the six index vectors
     return dict(known=dev_i[0], rel=dev_i[1], is_tail=dev_i[2], truth=dev_i[3], lo=dev_i[4], hi=dev_i[5], ids=store.ids,
-                weights=_lib.to_device(np.concatenate(weights), device), splits=splits, triples=triples,
-                known_inv=TF.gather_inverse(known, n_rows, device), rel_inv=TF.gather_inverse(rel, n_rel_rows, device))
+                weights=_lib.to_device(weights, device), splits=splits, triples=triples,
+                known_inv=TF.gather_inverse(packed[0], n_rows, device), rel_inv=TF.gather_inverse(packed[1], n_rel_rows, device))

@@ -174,30 +174,10 @@ def batch(snapshots):
 
 def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK):
     """Sort edges by `seg` (stable) and cut every segment into chunks of <= `chunk` edges.
-    Returns a dict of int32 numpy arrays + counts (layout of TempEdgeView)."""
-    seg = np.asarray(seg, dtype=np.int64)
-    order = np.argsort(seg.astype(np.uint16) if n_seg <= 65536 else seg, kind="stable")     # 16-bit keys: numpy radix-sorts them
-    seg_s = seg[order]
-    counts = np.bincount(seg_s, minlength=n_seg).astype(np.int64)
-    ptr = np.concatenate([[0], np.cumsum(counts)])
-    nch = (counts + chunk - 1) // chunk
-    total = int(nch.sum())
-    chunk_seg = np.repeat(np.arange(n_seg, dtype=np.int64), nch)
-    first = np.cumsum(nch) - nch
-    k = np.arange(total, dtype=np.int64) - first[chunk_seg]
-    chunk_beg = ptr[chunk_seg] + k * chunk
-    chunk_end = np.minimum(chunk_beg + chunk, ptr[chunk_seg + 1])
-    multi = nch > 1
-    is_multi = multi[chunk_seg]
-    slot = np.where(is_multi, np.cumsum(is_multi) - 1, -1)
-    fix_seg = np.nonzero(multi)[0]
-    fix_cnt = nch[fix_seg]
-    fix_slot = np.cumsum(fix_cnt) - fix_cnt
-    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
-    return dict(n_seg=int(n_seg), n_edges=int(seg.shape[0]), a=i32(np.asarray(a)[order]), b=i32(np.asarray(b)[order]),
-                n_chunks=total, chunk_seg=i32(chunk_seg), chunk_beg=i32(chunk_beg), chunk_end=i32(chunk_end),
-                chunk_slot=i32(slot), n_partial=int(is_multi.sum()), n_fix=int(fix_seg.shape[0]),
-                fix_seg=i32(fix_seg), fix_slot=i32(fix_slot), fix_cnt=i32(fix_cnt), order=order)
+    Returns a dict of int32 numpy arrays + counts (layout of TempEdgeView).  One counting-sort pass in the host
+    planner library (temp_host_build_view); tests/host_reference.py holds the numpy formulation it is checked against."""
+    from . import _hostlib
+    return _hostlib.build_view(seg, a, b, n_seg, chunk)
 
 
 def build_view_tiled(seg, a, b, n_seg, tile, chunk=_lib.CHUNK):

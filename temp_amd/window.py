@@ -83,26 +83,22 @@ class ChainPlan:
         self.seq_len = seq_len
         self.num_ents = num_ents
         self.rows = rows
-        row_of = np.full((self.bsz, num_ents), -1, dtype=np.int64)     # row in the previous executed step's output
-        last = np.zeros((self.bsz, num_ents), dtype=np.float32)        # start_time_tensor
-        prev_pairs = None
         self.steps = []
         for p in range(seq_len - 1):
             win = [b for b in range(self.bsz) if rows[b][p] is not None]
             if not win:
                 continue
             assert win == list(range(len(win))), "padded windows must form a suffix of the batch"
-            st = Step(p, win, [graph_dict[rows[b][p]] for b in win], [rows[b][p] for b in win])
-            # all windows of the position at once: (window, entity) pairs of the step's rows
-            bb = np.repeat(np.asarray(win, dtype=np.int64), st.sizes)
-            st.prev_idx = row_of[bb, st.ids]
-            st.dt = (p - last[bb, st.ids]).astype(np.float32)
-            if prev_pairs is not None:                                 # F8: history holds ONLY this step's nodes
-                row_of[prev_pairs] = -1                                # (left padding: a window, once active, stays active)
-            row_of[bb, st.ids] = np.arange(st.n_rows, dtype=np.int64)
-            last[bb, st.ids] = p
-            prev_pairs = (bb, st.ids)
-            self.steps.append(st)
+            self.steps.append(Step(p, win, [graph_dict[rows[b][p]] for b in win], [rows[b][p] for b in win]))
+        # row maps of every executed position in one pass of the host planner library (temp_host_chain_plan):
+        # prev_idx = row in the previous executed step's output (F8: the history holds ONLY that step's nodes), dt = gap
+        from . import _hostlib
+        prev_idx, dt, row_of, last = _hostlib.chain_plan(self.bsz, num_ents, [st.p for st in self.steps], [len(st.windows) for st in self.steps],
+                                                         [[g.gids for g in st.graphs] for st in self.steps])
+        off = 0
+        for st in self.steps:
+            st.prev_idx, st.dt = prev_idx[off:off + st.n_rows], dt[off:off + st.n_rows]
+            off += st.n_rows
         self.row_of, self.last = row_of, last
 
     def flipped(self):
