@@ -51,6 +51,11 @@ int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* 
 int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* const* idx, const int64_t* n_pos, const int64_t* row_offset,
                         int64_t R, int32_t* packed, float* weights, int64_t* triples);
 
+/* Inverse of a gather index list (the static maps the deterministic segment-sum adjoints reduce over, temp_segment_sum_rows):
+ * positions i of idx[0..n) grouped by table row idx[i] (stable, entries < 0 skipped):
+ *   seg_ptr[n_rows + 1], order[count of non-negative entries];  returns that count, or -1 on a bad argument. */
+int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, int32_t* seg_ptr, int32_t* order);
+
 int temp_host_abi_version(void);
 #ifdef __cplusplus
 }

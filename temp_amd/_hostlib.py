@@ -19,6 +19,7 @@ SYMBOLS = {
     "temp_host_abi_version": (ctypes.c_int, []),
     "temp_host_build_view": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "temp_host_plan_loss": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "temp_host_gather_inverse": (_I64, [_I64, _P, _I64, _P, _P]),
     "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
@@ -116,3 +117,14 @@ def plan_loss(graph_ptrs, idx_list, row_offsets):
     if rc != 0:
         raise ValueError("temp_host_plan_loss: bad argument (code %d)" % rc)
     return packed[:, :R], weights[:R], triples[:R // 2], n_pos
+
+
+def gather_inverse(idx, n_rows):
+    """See temp_host_gather_inverse -> one int32 array [seg_ptr (n_rows + 1) | order (count)] and the count."""
+    idx = _i64(idx).reshape(-1)
+    n = int(idx.shape[0])
+    both = np.empty(n_rows + 1 + max(n, 1), np.int32)
+    cnt = load().temp_host_gather_inverse(n, idx.ctypes.data, int(n_rows), both.ctypes.data, both[n_rows + 1:].ctypes.data)
+    if cnt < 0:
+        raise ValueError("temp_host_gather_inverse: index outside [.., %d)" % n_rows)
+    return both[:n_rows + 1 + cnt], int(cnt)

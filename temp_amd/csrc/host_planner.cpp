@@ -129,4 +129,18 @@ int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* 
   return row == R ? 0 : 3;
 }
 
+int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, int32_t* seg_ptr, int32_t* order) {
+  if (n < 0 || n_rows < 0 || !seg_ptr || (n > 0 && (!idx || !order))) return -1;
+  for (int64_t r = 0; r <= n_rows; ++r) seg_ptr[r] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (idx[i] >= n_rows) return -1;
+    if (idx[i] >= 0) ++seg_ptr[idx[i] + 1];
+  }
+  for (int64_t r = 0; r < n_rows; ++r) seg_ptr[r + 1] += seg_ptr[r];
+  std::vector<int32_t> cur(seg_ptr, seg_ptr + n_rows);
+  for (int64_t i = 0; i < n; ++i)
+    if (idx[i] >= 0) order[cur[(size_t)idx[i]]++] = (int32_t)i;
+  return seg_ptr[n_rows];
+}
+
 }  // extern "C"

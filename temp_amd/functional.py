@@ -148,38 +148,12 @@ def gather_rows(table, idx, inverse=None):
 
 def gather_inverse(idx_np, n_rows, device):
     """(seg_ptr int32 [n_rows+1], order int32) grouping the positions of a gather index list by table row
-    (positions of negative entries are left out).  The grouping is a stable sort: on a GPU it runs there (one upload of
-    the index list, a device radix sort), on the host numpy's stable sort of 16-bit keys (a radix sort) when the table is small."""
-    import numpy as np
-    idx_np = np.asarray(idx_np)
-    if idx_np.dtype.kind != "i":
-        idx_np = idx_np.astype(np.int64)
-    has_neg = bool(idx_np.size) and int(idx_np.min()) < 0
-    device = torch.device(device)
-    if device.type == "cuda":
-        idx = _lib.to_device(idx_np, device)
-        pos = None
-        if has_neg:
-            pos = torch.nonzero(idx >= 0).view(-1)
-            idx = idx[pos]
-        order = torch.sort(idx, stable=True).indices
-        if pos is not None:
-            order = pos[order]
-        seg_ptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=device)
-        if idx.numel():
-            seg_ptr[1:] = torch.cumsum(torch.bincount(idx.long(), minlength=n_rows), 0)
-        return seg_ptr, order.to(torch.int32)
-    if has_neg:
-        pos = np.nonzero(idx_np >= 0)[0]
-        key = idx_np[pos]
-    else:
-        pos, key = None, idx_np
-    order = np.argsort(key.astype(np.uint16) if n_rows <= 65536 else key, kind="stable")
-    if pos is not None:
-        order = pos[order]
-    seg_ptr = np.zeros(n_rows + 1, dtype=np.int32)
-    np.cumsum(np.bincount(key, minlength=n_rows), out=seg_ptr[1:])
-    return torch.from_numpy(seg_ptr).to(device), torch.from_numpy(order.astype(np.int32)).to(device)
+    (positions of negative entries are left out): a stable counting sort in the host planner library
+    (temp_host_gather_inverse), one upload."""
+    from . import _hostlib
+    both, _ = _hostlib.gather_inverse(idx_np, n_rows)
+    dev = _lib.to_device(both, device)
+    return dev[:n_rows + 1], dev[n_rows + 1:]
 
 
 class _CandidateCEFn(torch.autograd.Function):

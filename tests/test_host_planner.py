@@ -16,7 +16,7 @@ def test_host_library_exports_every_declared_symbol():
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(temp_host_[a-z0-9_]+)\s*\(", src)))
     lib = _hostlib.load()
-    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 4
+    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 5
     for n in names:
         assert hasattr(lib, n)
     assert lib.temp_host_abi_version() == 1
@@ -62,3 +62,16 @@ def test_chain_plan_matches_numpy(bsz, N, L, pad):
     want = chain_plan_numpy(bsz, N, positions, n_win, arrs)
     for g, w in zip(got, want):
         assert g.dtype == w.dtype and np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("n,n_rows", [(0, 5), (1, 1), (48000, 40), (116000, 81000), (5000, 70000)])
+def test_gather_inverse_matches_stable_argsort(n, n_rows):
+    rng = np.random.default_rng(n + n_rows)
+    idx = rng.integers(-1, n_rows, n)
+    both, cnt = _hostlib.gather_inverse(idx, n_rows)
+    keep = np.nonzero(idx >= 0)[0]
+    assert cnt == keep.shape[0] and both.dtype == np.int32
+    assert np.array_equal(both[n_rows + 1:], keep[np.argsort(idx[keep], kind="stable")])
+    assert both[0] == 0 and np.array_equal(both[1:n_rows + 1], np.cumsum(np.bincount(idx[keep], minlength=n_rows)))
+    with pytest.raises(ValueError):
+        _hostlib.gather_inverse(np.array([n_rows]), n_rows)
