@@ -51,6 +51,22 @@ int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* 
 int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* const* idx, const int64_t* n_pos, const int64_t* row_offset,
                         int64_t R, int32_t* packed, float* weights, int64_t* triples);
 
+/* All three edge views of ONE snapshot (by destination, by source: chunk; by relation: chunk_rel) in the packed int32 layout
+ * the device-side snapshot store keeps per snapshot:
+ *   [by_dst: a b chunk_seg chunk_beg chunk_end chunk_slot fix_seg fix_slot fix_cnt][by_src: ...][by_rel: ...]
+ *   [rel_rank: rank of every by-relation chunk inside its relation][in_deg n][out_deg n][nnorm bits n]
+ * by_dst: seg = dst, a = src, b = rel;  by_src: seg = src, a = dst, b = rel;  by_rel: seg = rel, a = src, b = dst.
+ * sizes[31] = length of each array in that order, n_partial[3], rel_chunks[n_rel_rows] = chunks per relation.
+ * packed must hold 28 * max(E, 1) + 3 * n entries.  Returns the number of entries written, or -1. */
+int64_t temp_host_snapshot_pack(int64_t n, int64_t E, const int64_t* src, const int64_t* dst, const int64_t* rel, const float* nnorm,
+                                int64_t n_rel_rows, int64_t chunk, int64_t chunk_rel,
+                                int32_t* packed, int64_t* sizes, int64_t* n_partial, int64_t* rel_chunks);
+
+/* k distinct integers of [0, n), uniformly at random, in random order (np.random.choice(n, k, replace=False) /
+ * torch.randperm(n)[:k] of the reference: models/DynamicRGCN.py:81, utils/CorrptTriples.py:38-40): a partial Fisher-Yates
+ * shuffle driven by splitmix64(seed).  out[k]. */
+int temp_host_sample_subset(int64_t n, int64_t k, uint64_t seed, int64_t* out);
+
 /* Inverse of a gather index list (the static maps the deterministic segment-sum adjoints reduce over, temp_segment_sum_rows):
  * positions i of idx[0..n) grouped by table row idx[i] (stable, entries < 0 skipped):
  *   seg_ptr[n_rows + 1], order[count of non-negative entries];  returns that count, or -1 on a bad argument. */

@@ -19,6 +19,8 @@ SYMBOLS = {
     "temp_host_abi_version": (ctypes.c_int, []),
     "temp_host_build_view": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "temp_host_plan_loss": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "temp_host_snapshot_pack": (_I64, [_I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "temp_host_sample_subset": (ctypes.c_int, [_I64, _I64, ctypes.c_uint64, _P]),
     "temp_host_gather_inverse": (_I64, [_I64, _P, _I64, _P, _P]),
     "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
@@ -128,3 +130,26 @@ def gather_inverse(idx, n_rows):
     if cnt < 0:
         raise ValueError("temp_host_gather_inverse: index outside [.., %d)" % n_rows)
     return both[:n_rows + 1 + cnt], int(cnt)
+
+
+def snapshot_pack(n, src, dst, rel, nnorm, n_rel_rows, chunk, chunk_rel):
+    """See temp_host_snapshot_pack -> (packed int32, sizes int64[31], n_partial int64[3], rel_chunks int64[n_rel_rows])."""
+    src, dst, rel = _i64(src), _i64(dst), _i64(rel)
+    nnorm = np.ascontiguousarray(nnorm, dtype=np.float32)
+    E = int(src.shape[0])
+    packed = np.empty(28 * max(E, 1) + 3 * int(n) + 1, np.int32)
+    sizes, n_partial, rel_chunks = np.zeros(31, np.int64), np.zeros(3, np.int64), np.zeros(max(int(n_rel_rows), 1), np.int64)
+    w = load().temp_host_snapshot_pack(int(n), E, src.ctypes.data, dst.ctypes.data, rel.ctypes.data, nnorm.ctypes.data, int(n_rel_rows),
+                                       int(chunk), int(chunk_rel), packed.ctypes.data, sizes.ctypes.data, n_partial.ctypes.data, rel_chunks.ctypes.data)
+    if w < 0:
+        raise ValueError("temp_host_snapshot_pack: bad argument (node or relation id out of range?)")
+    return packed[:w], sizes, n_partial, rel_chunks[:n_rel_rows]
+
+
+def sample_subset(n, k, rng):
+    """k distinct integers of [0, n) (see temp_host_sample_subset); the seed is one draw of the numpy generator `rng`."""
+    out = np.empty(max(int(k), 1), np.int64)
+    rc = load().temp_host_sample_subset(int(n), int(k), int(rng.integers(0, 1 << 63)), out.ctypes.data)
+    if rc != 0:
+        raise ValueError("temp_host_sample_subset: need 0 <= k <= n")
+    return out[:int(k)]

@@ -129,6 +129,110 @@ int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* 
   return row == R ? 0 : 3;
 }
 
+// one view written compactly at `out`; returns entries written (or -1), fills sizes[9], *n_partial, optionally per-segment
+// chunk counts and per-chunk ranks (by-relation view)
+static int64_t pack_view(int64_t E, const int64_t* seg, const int64_t* a, const int64_t* b, int64_t n_seg, int64_t chunk, int32_t* out,
+                         int64_t* sizes, int64_t* n_partial, int32_t* seg_count /* nullable [n_seg] */, int64_t* seg_chunks /* nullable [n_seg] */,
+                         std::vector<int32_t>* rank /* nullable */) {
+  std::vector<int64_t> ptr((size_t)n_seg + 1, 0);
+  for (int64_t e = 0; e < E; ++e) {
+    if (seg[e] < 0 || seg[e] >= n_seg) return -1;
+    ++ptr[(size_t)seg[e] + 1];
+  }
+  if (seg_count) for (int64_t s = 0; s < n_seg; ++s) seg_count[s] = (int32_t)ptr[(size_t)s + 1];
+  for (int64_t s = 0; s < n_seg; ++s) ptr[(size_t)s + 1] += ptr[(size_t)s];
+  int64_t n_chunks = 0, n_fix = 0;
+  for (int64_t s = 0; s < n_seg; ++s) {
+    const int64_t nch = (ptr[(size_t)s + 1] - ptr[(size_t)s] + chunk - 1) / chunk;
+    n_chunks += nch;
+    n_fix += nch > 1;
+    if (seg_chunks) seg_chunks[s] = nch;
+  }
+  int32_t* a_o = out;
+  int32_t* b_o = a_o + E;
+  int32_t* c_seg = b_o + E;
+  int32_t* c_beg = c_seg + n_chunks;
+  int32_t* c_end = c_beg + n_chunks;
+  int32_t* c_slot = c_end + n_chunks;
+  int32_t* f_seg = c_slot + n_chunks;
+  int32_t* f_slot = f_seg + n_fix;
+  int32_t* f_cnt = f_slot + n_fix;
+  {
+    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t e = 0; e < E; ++e) { const int64_t p = cur[(size_t)seg[e]]++; a_o[p] = (int32_t)a[e]; b_o[p] = (int32_t)b[e]; }
+  }
+  if (rank) rank->resize((size_t)n_chunks);
+  int64_t c = 0, part = 0, f = 0;
+  for (int64_t s = 0; s < n_seg; ++s) {
+    const int64_t beg = ptr[(size_t)s], end = ptr[(size_t)s + 1];
+    const int64_t nch = (end - beg + chunk - 1) / chunk;
+    if (nch > 1) { f_seg[f] = (int32_t)s; f_slot[f] = (int32_t)part; f_cnt[f] = (int32_t)nch; ++f; }
+    for (int64_t k = 0; k < nch; ++k, ++c) {
+      c_seg[c] = (int32_t)s;
+      c_beg[c] = (int32_t)(beg + k * chunk);
+      c_end[c] = (int32_t)((beg + (k + 1) * chunk < end) ? beg + (k + 1) * chunk : end);
+      c_slot[c] = nch > 1 ? (int32_t)part++ : -1;
+      if (rank) (*rank)[(size_t)c] = (int32_t)k;
+    }
+  }
+  sizes[0] = E; sizes[1] = E; sizes[2] = sizes[3] = sizes[4] = sizes[5] = n_chunks; sizes[6] = sizes[7] = sizes[8] = n_fix;
+  *n_partial = part;
+  return 2 * E + 4 * n_chunks + 3 * n_fix;
+}
+
+int64_t temp_host_snapshot_pack(int64_t n, int64_t E, const int64_t* src, const int64_t* dst, const int64_t* rel, const float* nnorm,
+                                int64_t n_rel_rows, int64_t chunk, int64_t chunk_rel,
+                                int32_t* packed, int64_t* sizes, int64_t* n_partial, int64_t* rel_chunks) {
+  if (n < 0 || E < 0 || n_rel_rows < 0 || chunk <= 0 || chunk_rel <= 0 || !packed || !sizes || !n_partial || (n_rel_rows > 0 && !rel_chunks) ||
+      (E > 0 && (!src || !dst || !rel)) || (n > 0 && !nnorm)) return -1;
+  std::vector<int32_t> in_deg((size_t)n), out_deg((size_t)n), rank;
+  int64_t off = 0;
+  int64_t w = pack_view(E, dst, src, rel, n, chunk, packed + off, sizes, n_partial, in_deg.data(), nullptr, nullptr);
+  if (w < 0) return -1;
+  off += w;
+  w = pack_view(E, src, dst, rel, n, chunk, packed + off, sizes + 9, n_partial + 1, out_deg.data(), nullptr, nullptr);
+  if (w < 0) return -1;
+  off += w;
+  w = pack_view(E, rel, src, dst, n_rel_rows, chunk_rel, packed + off, sizes + 18, n_partial + 2, nullptr, rel_chunks, &rank);
+  if (w < 0) return -1;
+  off += w;
+  for (size_t i = 0; i < rank.size(); ++i) packed[off + (int64_t)i] = rank[i];
+  sizes[27] = (int64_t)rank.size();
+  off += (int64_t)rank.size();
+  for (int64_t i = 0; i < n; ++i) packed[off + i] = in_deg[(size_t)i];
+  off += n;
+  for (int64_t i = 0; i < n; ++i) packed[off + i] = out_deg[(size_t)i];
+  off += n;
+  const int32_t* bits = reinterpret_cast<const int32_t*>(nnorm);
+  for (int64_t i = 0; i < n; ++i) packed[off + i] = bits[i];
+  off += n;
+  sizes[28] = sizes[29] = sizes[30] = n;
+  return off;
+}
+
+static inline uint64_t splitmix64_next(uint64_t& state) {
+  uint64_t x = (state += 0x9E3779B97F4A7C15ull);
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+int temp_host_sample_subset(int64_t n, int64_t k, uint64_t seed, int64_t* out) {
+  if (n < 0 || k < 0 || k > n || (k > 0 && !out)) return 1;
+  std::vector<int64_t> pool((size_t)n);
+  for (int64_t i = 0; i < n; ++i) pool[(size_t)i] = i;
+  uint64_t state = seed;
+  for (int64_t i = 0; i < k; ++i) {
+    // unbiased enough for sampling edges: 64-bit draw reduced by multiply-shift over the n - i remaining slots
+    const uint64_t r = splitmix64_next(state);
+    const uint64_t span = (uint64_t)(n - i);
+    const int64_t j = i + (int64_t)(((unsigned __int128)r * span) >> 64);
+    const int64_t t = pool[(size_t)i]; pool[(size_t)i] = pool[(size_t)j]; pool[(size_t)j] = t;
+    out[i] = pool[(size_t)i];
+  }
+  return 0;
+}
+
 int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, int32_t* seg_ptr, int32_t* order) {
   if (n < 0 || n_rows < 0 || !seg_ptr || (n > 0 && (!idx || !order))) return -1;
   for (int64_t r = 0; r <= n_rows; ++r) seg_ptr[r] = 0;

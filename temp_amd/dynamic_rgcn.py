@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from . import functional as TF
 from . import _lib
+from . import _hostlib
 from . import snapshot as S
 from .rrgcn import RRGCN, GRRGCNLayer, run_rnn
 from .tkg_module import TKG_Module
@@ -81,7 +82,7 @@ class DynamicRGCN(TKG_Module):
         out = []
         for i, g in enumerate(graphs):
             E = g.number_of_edges()
-            idx = edge_ids[i] if edge_ids is not None else self.sample_rng.choice(np.arange(E), size=int(rate * E), replace=False)
+            idx = edge_ids[i] if edge_ids is not None else _hostlib.sample_subset(E, int(rate * E), self.sample_rng)
             out.append(g.edge_subgraph(idx))
         return out
 

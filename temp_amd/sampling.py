@@ -169,7 +169,7 @@ def plan_batch_loss(store, times, graphs, row_offsets, num_pos_facts, rng, n_row
     for t, g in zip(times, graphs):
         E = g.number_of_edges()
         P = min(E, num_pos_facts)
-        idxs.append(rng.permutation(E)[:P] if num_pos_facts < E else np.arange(E, dtype=np.int64))
+        idxs.append(_hostlib.sample_subset(E, P, rng) if num_pos_facts < E else np.arange(E, dtype=np.int64))
         ptrs.append(store.snapshot(t)["ptrs"])
     packed, weights, trip_all, n_pos = _hostlib.plan_loss(np.stack(ptrs) if ptrs else np.zeros((0, 8), np.int64), idxs, np.asarray(row_offsets, dtype=np.int64))
     if packed.shape[1] == 0:

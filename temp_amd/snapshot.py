@@ -95,19 +95,29 @@ class Snapshot:
         key = ("views", str(device), int(n_rel_rows))
         dv = self._dev.get(key)
         if dv is None:
-            lv = self.local_views(n_rel_rows)
-            seg = lv["by_rel"]["chunk_seg"].astype(np.int64)
-            first = np.cumsum(lv["rel_chunks"]) - lv["rel_chunks"]
-            arrays = [((vn, an), lv[vn][an]) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS]
-            arrays += [("rel_rank", np.arange(seg.shape[0], dtype=np.int64) - first[seg]),        # rank of a chunk inside its relation
-                       ("in_deg", lv["in_deg"]), ("out_deg", lv["out_deg"]),
-                       ("nnorm", np.ascontiguousarray(self.nnorm, dtype=np.float32).view(np.int32))]   # float bits ride along
-            sizes = [int(a.shape[0]) for _, a in arrays]
-            packed = np.concatenate([np.ascontiguousarray(a, dtype=np.int32) for _, a in arrays]) if sum(sizes) else np.zeros(1, np.int32)
+            names = [(vn, an) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS] + ["rel_rank", "in_deg", "out_deg", "nnorm"]
+            if self._views.get(n_rel_rows) is None:
+                # no host-side views cached (a freshly subsampled target graph): all three views + the pack in ONE pass of
+                # the host planner library
+                from . import _hostlib
+                packed, sizes_np, n_partial, rel_chunks = _hostlib.snapshot_pack(self.n, self.src, self.dst, self.rel, self.nnorm, n_rel_rows,
+                                                                                 _lib.CHUNK, _lib.CHUNK_REL)
+                sizes = [int(x) for x in sizes_np]
+            else:
+                lv = self.local_views(n_rel_rows)
+                seg = lv["by_rel"]["chunk_seg"].astype(np.int64)
+                first = np.cumsum(lv["rel_chunks"]) - lv["rel_chunks"]
+                arrays = [lv[vn][an] for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS]
+                arrays += [np.arange(seg.shape[0], dtype=np.int64) - first[seg],        # rank of a chunk inside its relation
+                           lv["in_deg"], lv["out_deg"], np.ascontiguousarray(self.nnorm, dtype=np.float32).view(np.int32)]   # float bits ride along
+                sizes = [int(a.shape[0]) for a in arrays]
+                packed = np.concatenate([np.ascontiguousarray(a, dtype=np.int32) for a in arrays]) if sum(sizes) else np.zeros(1, np.int32)
+                n_partial = np.array([lv[vn]["n_partial"] for vn in ("by_dst", "by_src", "by_rel")], dtype=np.int64)
+                rel_chunks = lv["rel_chunks"]
             buf = _lib.to_device(packed, device)                  # ONE upload per snapshot
             dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": buf}
             off = 0
-            for (key_, _), n_ in zip(arrays, sizes):
+            for key_, n_ in zip(names, sizes):
                 t = buf[off:off + n_]
                 off += n_
                 if isinstance(key_, tuple):
@@ -117,8 +127,7 @@ class Snapshot:
             dv["nnorm"] = dv["nnorm"].view(torch.float32)
             offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
             dv["_meta"] = dict(ptr=int(buf.data_ptr()), off=offs.astype(np.int64), size=np.asarray(sizes, dtype=np.int64),
-                               n_partial=np.array([lv[vn]["n_partial"] for vn in ("by_dst", "by_src", "by_rel")], dtype=np.int64),
-                               rel_chunks=lv["rel_chunks"])
+                               n_partial=np.asarray(n_partial, dtype=np.int64), rel_chunks=np.asarray(rel_chunks, dtype=np.int64))
             self._dev[key] = dv
         return dv
 

@@ -16,7 +16,7 @@ def test_host_library_exports_every_declared_symbol():
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(temp_host_[a-z0-9_]+)\s*\(", src)))
     lib = _hostlib.load()
-    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 5
+    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 7
     for n in names:
         assert hasattr(lib, n)
     assert lib.temp_host_abi_version() == 1
@@ -75,3 +75,45 @@ def test_gather_inverse_matches_stable_argsort(n, n_rows):
     assert both[0] == 0 and np.array_equal(both[1:n_rows + 1], np.cumsum(np.bincount(idx[keep], minlength=n_rows)))
     with pytest.raises(ValueError):
         _hostlib.gather_inverse(np.array([n_rows]), n_rows)
+
+
+@pytest.mark.parametrize("n,E,R2,hub", [(500, 7475, 40, True), (227, 200, 460, False), (30, 0, 6, False), (1, 5, 2, False), (64, 3000, 3, True)])
+def test_snapshot_pack_matches_view_by_view_pack(n, E, R2, hub):
+    """temp_host_snapshot_pack (all three views + the device-store layout in one pass) == packing the three cached host views."""
+    import torch
+    from temp_amd.snapshot import Snapshot
+    rng = np.random.default_rng(n + E)
+    src, dst, rel = rng.integers(0, n, E), rng.integers(0, n, E), rng.integers(0, R2, E)
+    if hub and E:
+        dst[: E // 2] = rng.integers(0, 2, E // 2)
+    gids = rng.permutation(10 * n)[:n]
+    a, b = Snapshot(n, src, dst, rel, gids), Snapshot(n, src, dst, rel, gids)
+    b.local_views(R2)                                            # b takes the view-by-view path
+    da, db = a.device_views("cpu", R2), b.device_views("cpu", R2)
+    assert a._views.get(R2) is None and b._views.get(R2) is not None
+    assert torch.equal(da["_buf"], db["_buf"])
+    for k in ("off", "size", "n_partial", "rel_chunks"):
+        assert np.array_equal(da["_meta"][k], db["_meta"][k]), k
+    for vn in ("by_dst", "by_src", "by_rel"):
+        for an, t in db[vn].items():
+            assert torch.equal(da[vn][an], t), (vn, an)
+    assert torch.equal(da["nnorm"], db["nnorm"]) and torch.equal(da["rel_rank"], db["rel_rank"])
+
+
+def test_sample_subset_is_a_uniform_subset():
+    rng = np.random.default_rng(0)
+    n, k = 200, 60
+    hits = np.zeros(n)
+    first = np.zeros(n)
+    for _ in range(4000):
+        s = _hostlib.sample_subset(n, k, rng)
+        assert s.shape == (k,) and np.unique(s).shape[0] == k and s.min() >= 0 and s.max() < n
+        hits[s] += 1
+        first[s[0]] += 1
+    exp = 4000 * k / n
+    assert np.abs(hits - exp).max() < 6 * np.sqrt(exp)                       # every element equally likely to be chosen ...
+    assert np.abs(first - 4000 / n).max() < 6 * np.sqrt(4000 / n) + 1         # ... and to come first
+    assert _hostlib.sample_subset(5, 5, rng).tolist() != [] and sorted(_hostlib.sample_subset(5, 5, rng).tolist()) == [0, 1, 2, 3, 4]
+    assert _hostlib.sample_subset(7, 0, rng).shape == (0,)
+    with pytest.raises(ValueError):
+        _hostlib.sample_subset(3, 4, rng)
