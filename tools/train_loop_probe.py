@@ -17,7 +17,7 @@ from temp_amd.prefetch import BatchPrefetcher  # noqa: E402
 w = synthetic.workload(sys.argv[1] if len(sys.argv) > 1 else "S-gdelt", seed=0)
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 dev = torch.device("cuda:0")
-model = bench.build_model(w, dev)
+model = bench.build_model(w, dev, os.environ.get("PROBE_ENCODER", "gru"))
 model.sample_rng = np.random.default_rng(2)
 from temp_amd.sampling import CorruptTriples  # noqa: E402
 model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
