@@ -64,6 +64,36 @@ def build_model(w, device, encoder="gru"):
     return m.to(device)
 
 
+def train_loop(model, w, steps):
+    """Wall time of a training loop in which EVERY step is a new window batch (what main.py's trainer does): host-side
+    prepare, fresh negative samples (one kernel launch), link-prediction loss, backward, Adam; eager launches.  Reported next
+    to the headline (which replays one resident batch as a HIP graph), never as the headline."""
+    from temp_amd import synthetic
+    from temp_amd.sampling import CorruptTriples
+    if not hasattr(model, "corrupter"):
+        model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    batches = [synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 1000 + r) for r in range(steps + 5)]
+    for b in batches:                       # the first visit of a snapshot builds and uploads its cached views: once per run
+        model.prepare(b, w["L"], True)
+    edges, t0 = 0, None
+    for i, b in enumerate(batches):
+        if i == 5:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        wb = model.prepare(b, w["L"], True)
+        loss = model.run_loss(wb)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        if i >= 5:
+            edges += wb.n_edge_visits
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(ms_per_step=1e3 * dt / steps, edges_per_s=edges / dt, steps=steps,
+                what="new batch every step: host prepare + negatives + loss + backward + Adam, eager launches (host-bound)")
+
+
 def algorithmic_costs(wb, D, bi, S=2):
     """Per-step ALGORITHMIC bytes / flops of every kernel family of the batched path (fp32, int32
     ids).  n = node visits, E = edge visits of the step; the GRU runs once per node visit (twice on
@@ -188,6 +218,9 @@ def main():
                          "visits of a global batch of bsz*N windows sharded across ranks with an all-gather of per-snapshot "
                          "node states before the recurrent chain (north_star variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-loop-steps", type=int, default=30,
+                    help="also time this many steps of a real training loop (new batch every step: host prepare, fresh negatives, loss, "
+                         "backward, Adam, eager launches) and report it under config.train_loop; 0 = skip")
     ap.add_argument("--with-loss", action="store_true",
                     help="also run the all-entity pass + scorer + cross-entropy (negative_rate 500, fixed negatives) in the step "
                          "(reported separately from the headline encoder-only metric, SURVEY 8d)")
@@ -357,6 +390,12 @@ def main():
         roof["step_frac_of_hbm"] = (wb.n_edge_visits * a.steps / elapsed if world == 1 else value / world) * bytes_per_edge / (HBM_PEAK_GBS * 1e9)
     if rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(model, w, targets)
+    loop = None
+    if rank == 0 and world == 1 and a.train_loop_steps > 0 and not sharded:
+        try:
+            loop = train_loop(model, w, a.train_loop_steps)
+        except Exception as e:                      # an extra, never the headline
+            print("bench: training-loop probe failed (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
 
     if rank == 0:
         out = dict(metric="edges/sec (fwd+bwd) RGCN+%s seq_len=%d%s" % ("GRU" if a.encoder == "gru" else "self-attention", w["L"], " + link-prediction loss" if a.with_loss else ""), value=value, unit="edges/s", n_gpus=world,
@@ -368,7 +407,8 @@ def main():
                                edge_visits_per_step_per_gpu=wb.n_edge_visits, node_visits_per_step_per_gpu=wb.n_node_visits,
                                distinct_snapshot_edges_per_step=getattr(wb, "n_edges_distinct", None), targets=targets,
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
-                               else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager")),
+                               else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager"),
+                               train_loop=loop),
                    roofline=roof, cpu_baseline=cpu)
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
         # that the JSON line is the LAST line of stdout
