@@ -95,10 +95,11 @@ class BiDynamicRGCN(DynamicRGCN):
         lam, dec = l2.inv_temperature, l2.decay_spec()
         if wb.program is not None:
             prog = wb.program
-            H_all = gru_chain(TF.gather_rows(y2, wb.chain_rows, wb.chain_inv), prog, [l2.forward_rnn, l2.backward_rnn], lam, isinstance(l2.forward_rnn, GRUCell))
-            rows = lambda i: H_all[prog.inst[i].h0:prog.inst[i].h0 + prog.inst[i].n] if i >= 0 else None
-            out = rows(wb.out_inst[0]) + rows(wb.out_inst[1])
-            Hf, Hb = rows(wb.hist_inst[0]), rows(wb.hist_inst[1])
+            want = [i for i in (wb.out_inst[0], wb.out_inst[1], wb.hist_inst[0], wb.hist_inst[1]) if i >= 0]
+            got = dict(zip(want, gru_chain(TF.gather_rows(y2, wb.chain_rows, wb.chain_inv), prog, [l2.forward_rnn, l2.backward_rnn], lam,
+                                           isinstance(l2.forward_rnn, GRUCell), want=want)))
+            out = got[wb.out_inst[0]] + got[wb.out_inst[1]]
+            Hf, Hb = got.get(wb.hist_inst[0]), got.get(wb.hist_inst[1])
             return out, ((Hf, Hf), (Hb, Hb))
         if wb.visit_rows is not None:                         # distinct-snapshot rows -> visit rows
             y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))

@@ -157,10 +157,10 @@ class DynamicRGCN(TKG_Module):
             y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))
         l2 = enc.layer_2
         if wb.program is not None:
-            H_all = gru_chain(y2, wb.program, [l2.rnn], l2.inv_temperature, isinstance(l2.rnn, GRUCell))
-            rows = lambda i: H_all[wb.program.inst[i].h0:wb.program.inst[i].h0 + wb.program.inst[i].n]
-            hist = rows(wb.hist_inst) if wb.hist_inst >= 0 else None
-            return rows(wb.out_inst[0]), (hist, hist)
+            want = [wb.out_inst[0]] + ([wb.hist_inst] if wb.hist_inst >= 0 else [])
+            got = gru_chain(y2, wb.program, [l2.rnn], l2.inv_temperature, isinstance(l2.rnn, GRUCell), want=want)
+            hist = got[1] if wb.hist_inst >= 0 else None
+            return got[0], (hist, hist)
         H, hist = None, None
         for st in wb.steps:
             _, pidx, dt = st.tensors(dev)

@@ -99,7 +99,7 @@ class GruProgram:
 
 class _GruChainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_all, prog, lam, variant, n_rnn, *weights):
+    def forward(ctx, x_all, prog, lam, variant, n_rnn, want, *weights):
         be = get_backend()
         dev = x_all.device
         d = x_all.shape[1]
@@ -130,18 +130,27 @@ class _GruChainFn(torch.autograd.Function):
                                   h_out=H[it.h0:it.h0 + it.n], row0=it.h0))
             be.gru_cell_fwd_multi(cells, lam, variant, saved)
         ctx.save_for_backward(x_all, saved, *[w for ws in W for w in ws])
-        ctx.prog, ctx.lam, ctx.variant, ctx.n_rnn, ctx.G = prog, lam, variant, n_rnn, G
-        return H
+        ctx.prog, ctx.lam, ctx.variant, ctx.n_rnn, ctx.G, ctx.want = prog, lam, variant, n_rnn, G, want
+        if want is None:
+            return H
+        # only these instances' states are consumed downstream: hand them out as row ranges of H, so that the backward receives
+        # one small gradient per range instead of autograd zero-filling and summing full-size (n_total, d) tensors per slice
+        return tuple(H[prog.inst[i].h0:prog.inst[i].h0 + prog.inst[i].n] for i in want)
 
     @staticmethod
-    def backward(ctx, dH):
+    def backward(ctx, *d_outs):
         be = get_backend()
         x_all, saved = ctx.saved_tensors[:2]
         flat = ctx.saved_tensors[2:]
         W = [flat[4 * r:4 * r + 4] for r in range(ctx.n_rnn)]
         prog, lam, variant, G = ctx.prog, ctx.lam, ctx.variant, ctx.G
         dev, d, N = x_all.device, x_all.shape[1], prog.n_total
-        dH = dH.contiguous()
+        if ctx.want is None:
+            dH = d_outs[0].contiguous()
+            up = lambda i, it: dH[it.h0:it.h0 + it.n]
+        else:
+            given = {i: g.contiguous() for i, g in zip(ctx.want, d_outs) if g is not None}
+            up = lambda i, it: given.get(i)                  # None: no upstream gradient for this instance's rows
         tens = prog.upload(dev)
         dgi = torch.empty(N, G, dtype=torch.float32, device=dev)
         dgh = torch.empty(N, 3 * d, dtype=torch.float32, device=dev)
@@ -154,7 +163,7 @@ class _GruChainFn(torch.autograd.Function):
                 _, ni, dt = tens[i]
                 nxt = prog.inst[it.next] if (it.next >= 0 and prog.inst[it.next].n > 0) else None
                 sl = slice(it.h0, it.h0 + it.n)
-                cells.append(dict(row0=it.h0, n=it.n, dh_up=dH[sl], d_prev_next=d_prev[nxt.h0:nxt.h0 + nxt.n] if nxt is not None else None,
+                cells.append(dict(row0=it.h0, n=it.n, dh_up=up(i, it), d_prev_next=d_prev[nxt.h0:nxt.h0 + nxt.n] if nxt is not None else None,
                                   next_idx=ni if nxt is not None else None, dt=dt, w_hh=W[it.rnn][1], dgi=dgi[sl], dgh=dgh[sl],
                                   decv=decv[sl], d_prev=d_prev[sl]))
             be.gru_cell_bwd_multi(cells, lam, variant, saved)
@@ -175,16 +184,18 @@ class _GruChainFn(torch.autograd.Function):
                 grads[j] = gw[k] if grads[j] is None else grads[j] + gw[k]
         if not written.all():
             d_x_all[torch.from_numpy(~written).to(dev)] = 0
-        return (d_x_all, None, None, None, None) + tuple(grads)
+        return (d_x_all, None, None, None, None, None) + tuple(grads)
 
 
-def gru_chain(x_all, prog, rnns, lam, type1=False):
+def gru_chain(x_all, prog, rnns, lam, type1=False, want=None):
     """Run a GruProgram.  `rnns`: list of modules holding (weight_ih, weight_hh, bias_ih, bias_hh)
-    (nn.GRU layer 0 or the type-1 GRUCell).  Returns H_all (prog.n_total, d)."""
+    (nn.GRU layer 0 or the type-1 GRUCell).  Returns H_all (prog.n_total, d), or -- with `want` = a list of instance ids --
+    the states of just those instances (a tuple of (n_i, d) tensors; instances with 0 rows give empty tensors)."""
     ws = []
     for r in rnns:
         if type1:
             ws += [r.weight_ih, r.weight_hh, r.bias_ih, r.bias_hh]
         else:
             ws += [r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0]
-    return _GruChainFn.apply(x_all, prog, float(lam), _lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH, len(rnns), *ws)
+    return _GruChainFn.apply(x_all, prog, float(lam), _lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH, len(rnns),
+                             tuple(want) if want is not None else None, *ws)
