@@ -73,6 +73,15 @@ class GruProgram:
                 self.levels.append(idx[k:k + 4])
         self.dev = None
 
+    def constants(self, device, d):
+        """(zero previous-state row, all -1 row map long enough for any first-position instance), created once per program."""
+        key = (str(device), int(d))
+        c = getattr(self, "_const", None)
+        if c is None or c[0] != key:
+            n0 = max([it.n for it in self.inst if it.prev < 0] + [1])
+            c = self._const = (key, torch.zeros(1, d, dtype=torch.float32, device=device), torch.full((n0,), -1, dtype=torch.int32, device=device))
+        return c[1], c[2]
+
     def upload(self, device):
         """Row maps and time gaps of every instance on `device`: packed on the host into ONE int32 buffer (the float gaps as
         raw bits) and uploaded with one copy; the per-instance tensors are views."""
@@ -114,7 +123,7 @@ class _GruChainFn(torch.autograd.Function):
             be.gru_input_gates(x_all[g["x0"]:g["x1"]], w_ih, b_ih, variant, gi[g["h0"]:g["h1"]])
         H = torch.empty(N, d, dtype=torch.float32, device=dev)
         saved = torch.empty(5, N, d, dtype=torch.float32, device=dev)
-        zero = torch.zeros(1, d, dtype=torch.float32, device=dev)
+        zero, none_idx = prog.constants(dev, d)
         for level in prog.levels:
             cells = []
             for i in level:
@@ -125,7 +134,7 @@ class _GruChainFn(torch.autograd.Function):
                     p = prog.inst[it.prev]
                     prev, pidx = H[p.h0:p.h0 + p.n], pi
                 else:                                 # no history yet: every previous state is zero
-                    prev, pidx = zero, torch.full((it.n,), -1, dtype=torch.int32, device=dev)
+                    prev, pidx = zero, none_idx[:it.n]
                 cells.append(dict(gi=gi[it.h0:it.h0 + it.n], prev=prev, prev_idx=pidx, dt=dt, w_hh=w_hh, b_hh=b_hh,
                                   h_out=H[it.h0:it.h0 + it.n], row0=it.h0))
             be.gru_cell_fwd_multi(cells, lam, variant, saved)
