@@ -218,9 +218,10 @@ def main():
                          "visits of a global batch of bsz*N windows sharded across ranks with an all-gather of per-snapshot "
                          "node states before the recurrent chain (north_star variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-loop-steps", type=int, default=30,
+    ap.add_argument("--train-loop-steps", type=int, default=0,
                     help="also time this many steps of a real training loop (new batch every step: host prepare, fresh negatives, loss, "
-                         "backward, Adam, eager launches) and report it under config.train_loop; 0 = skip")
+                         "backward, Adam, eager launches) and report it under config.train_loop; off by default so that a rocprofv3 "
+                         "summary of the default command holds the headline step's kernels only")
     ap.add_argument("--with-loss", action="store_true",
                     help="also run the all-entity pass + scorer + cross-entropy (negative_rate 500, fixed negatives) in the step "
                          "(reported separately from the headline encoder-only metric, SURVEY 8d)")
