@@ -15,7 +15,7 @@ from .dynamic_rgcn import DynamicRGCN, WindowBatch
 from .gru_cell import GRUCell
 from .gru_chain import GruInstance, GruProgram, gru_chain
 from .rrgcn import run_rnn
-from .window import ChainPlan, Step, concat_steps, window_times
+from .window import ChainPlan, Step, window_times
 
 
 class BiDynamicRGCN(DynamicRGCN):

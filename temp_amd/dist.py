@@ -23,7 +23,7 @@ import torch.distributed as dist
 from . import functional as TF
 from .gru_cell import GRUCell
 from .gru_chain import GruInstance, GruProgram, gru_chain
-from .window import ChainPlan, Step, concat_steps, window_times
+from .window import ChainPlan, Step, window_times
 
 
 def allreduce_gradients(params, world=None, average=True, group=None):

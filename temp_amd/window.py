@@ -13,7 +13,6 @@ Because snapshot membership is static, the plan is pure integer work on the host
 sees `prev_idx` (row into the previous position's output, -1 => zero) and `dt`.
 """
 import numpy as np
-import torch
 
 from . import snapshot as S
 from . import _lib
