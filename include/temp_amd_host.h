@@ -35,12 +35,14 @@ int temp_host_build_view(int64_t E, const int64_t* seg, const int64_t* a, const 
  * Outputs, concatenated over steps in (step, window, node) order:
  *   prev_idx  row of the same entity in the PREVIOUS executed step's output of that window, -1 if it was not a node there
  *             (the reference's history is re-zeroed every position: only the immediately preceding step's nodes carry state)
+ *   next_idx  the inverse map: which row of the NEXT executed step continues from this row, -1 if none (the last step's
+ *             entries are all -1: its consumer, the target position, is planned by the caller)
  *   dt        pos[s] - (position at which the entity was last a node of the window, 0 if never)
  * and the final state after the last step: row_of[bsz * num_ents] (same meaning, for the target / all-entity consumers)
  * and last[bsz * num_ents] (last active position, 0 if never).  row_of / last are fully written. */
 int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* pos, const int32_t* n_win,
                          const int64_t* const* gids, const int64_t* gid_n,
-                         int64_t* prev_idx, float* dt, int64_t* row_of, float* last);
+                         int32_t* prev_idx, int32_t* next_idx, float* dt, int64_t* row_of, float* last);
 
 /* Index lists of a batch's link-prediction loss (train_link_prediction + negative_sampling set-up,
  * models/TKG_Module.py:202-213, utils/CorrptTriples.py:36-56): for graph g with P_g chosen positives idx[g][0..P_g) the

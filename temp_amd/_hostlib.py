@@ -22,7 +22,7 @@ SYMBOLS = {
     "temp_host_snapshot_pack": (_I64, [_I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "temp_host_sample_subset": (ctypes.c_int, [_I64, _I64, ctypes.c_uint64, _P]),
     "temp_host_gather_inverse": (_I64, [_I64, _P, _I64, _P, _P]),
-    "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 
@@ -79,7 +79,7 @@ def build_view(seg, a, b, n_seg, chunk):
 
 def chain_plan(bsz, num_ents, positions, n_win, gid_arrays):
     """Row maps of one window chain (see temp_host_chain_plan).  gid_arrays[s][j] = int64 gids of window j at executed step s.
-    -> (prev_idx [total], dt [total], row_of [bsz, num_ents], last [bsz, num_ents])"""
+    -> (prev_idx int32 [total], next_idx int32 [total], dt [total], row_of [bsz, num_ents], last [bsz, num_ents])"""
     n_steps = len(positions)
     ptrs = np.zeros(max(n_steps * bsz, 1), np.int64)
     lens = np.zeros(max(n_steps * bsz, 1), np.int64)
@@ -88,17 +88,18 @@ def chain_plan(bsz, num_ents, positions, n_win, gid_arrays):
             ptrs[s * bsz + j] = g.ctypes.data
             lens[s * bsz + j] = g.shape[0]
     total = int(lens.sum())
-    prev_idx = np.empty(max(total, 1), np.int64)
+    prev_idx = np.empty(max(total, 1), np.int32)
+    next_idx = np.empty(max(total, 1), np.int32)
     dt = np.empty(max(total, 1), np.float32)
     row_of = np.empty((bsz, num_ents), np.int64)
     last = np.empty((bsz, num_ents), np.float32)
     pos = np.ascontiguousarray(positions, dtype=np.int32)
     nw = np.ascontiguousarray(n_win, dtype=np.int32)
     rc = load().temp_host_chain_plan(int(bsz), int(num_ents), n_steps, pos.ctypes.data, nw.ctypes.data, ptrs.ctypes.data, lens.ctypes.data,
-                                     prev_idx.ctypes.data, dt.ctypes.data, row_of.ctypes.data, last.ctypes.data)
+                                     prev_idx.ctypes.data, next_idx.ctypes.data, dt.ctypes.data, row_of.ctypes.data, last.ctypes.data)
     if rc != 0:
         raise ValueError("temp_host_chain_plan: bad argument (code %d)" % rc)
-    return prev_idx[:total], dt[:total], row_of, last
+    return prev_idx[:total], next_idx[:total], dt[:total], row_of, last
 
 
 def plan_loss(graph_ptrs, idx_list, row_offsets):

@@ -150,13 +150,13 @@ class BiDynamicRGCN(DynamicRGCN):
         inst = []
         last = -1
         for st in plan_f.steps:
-            inst.append(GruInstance(st.n_rows, st.row0, 0, last, st.prev_idx, st.dt))
+            inst.append(GruInstance(st.n_rows, st.row0, 0, last, st.prev_idx, st.dt, st.next_idx))
             last = len(inst) - 1
         inst.append(GruInstance(nt, nf, 0, last, tf.prev_idx, tf.dt))
         hist_f, out_f = last, len(inst) - 1
         last = -1
         for st in plan_b.steps:
-            inst.append(GruInstance(st.n_rows, st.row0 + nt, 1, last, st.prev_idx, st.dt))      # backward rows sit after the target copy
+            inst.append(GruInstance(st.n_rows, st.row0 + nt, 1, last, st.prev_idx, st.dt, st.next_idx))      # backward rows sit after the target copy
             last = len(inst) - 1
         inst.append(GruInstance(nt, nf + nt + nb, 1, last, tb.prev_idx, tb.dt))
         hist_b, out_b = last, len(inst) - 1

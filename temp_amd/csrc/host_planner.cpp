@@ -42,13 +42,14 @@ int temp_host_build_view(int64_t E, const int64_t* seg, const int64_t* a, const 
 
 int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* pos, const int32_t* n_win,
                          const int64_t* const* gids, const int64_t* gid_n,
-                         int64_t* prev_idx, float* dt, int64_t* row_of, float* last) {
+                         int32_t* prev_idx, int32_t* next_idx, float* dt, int64_t* row_of, float* last) {
   if (bsz < 0 || num_ents < 0 || n_steps < 0 || !row_of || !last || (n_steps > 0 && (!pos || !n_win || !gids || !gid_n))) return 1;
   const size_t total = (size_t)bsz * (size_t)num_ents;
   for (size_t i = 0; i < total; ++i) { row_of[i] = -1; last[i] = 0.f; }
-  int64_t out = 0;
+  int64_t out = 0, prev_out = 0;                       // first output row of this step / of the previous executed step
   int prev_step = -1;
   for (int s = 0; s < n_steps; ++s) {
+    const int64_t step_out = out;
     const int nw = n_win[s];
     if (nw < 0 || nw > bsz) return 2;
     const float p = (float)pos[s];
@@ -61,11 +62,14 @@ int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* 
       for (int64_t i = 0; i < n; ++i) {
         const int64_t e = g[i];
         if (e < 0 || e >= num_ents) return 3;
-        prev_idx[out + i] = ro[e];
+        prev_idx[out + i] = (int32_t)ro[e];
+        next_idx[out + i] = -1;
+        if (ro[e] >= 0) next_idx[prev_out + ro[e]] = (int32_t)(out + i - step_out);
         dt[out + i] = p - la[e];
       }
       out += n;
     }
+    prev_out = step_out;
     // the history holds ONLY this step's nodes: forget the previous step's rows, then record this step's
     if (prev_step >= 0) {
       const int pw = n_win[prev_step];

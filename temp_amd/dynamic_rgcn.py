@@ -144,7 +144,7 @@ class DynamicRGCN(TKG_Module):
         inst = []
         for k, st in enumerate(wb.steps):
             has_prev = k > 0
-            inst.append(GruInstance(st.n_rows, st.row0, 0, k - 1 if has_prev else -1, st.prev_idx, st.dt))
+            inst.append(GruInstance(st.n_rows, st.row0, 0, k - 1 if has_prev else -1, st.prev_idx, st.dt, st.next_idx))
         wb.program = GruProgram(inst)
         wb.out_inst = [len(inst) - 1]
         wb.hist_inst = len(inst) - 2 if len(inst) > 1 else -1

@@ -23,12 +23,12 @@ from .backend import get_backend
 class GruInstance:
     __slots__ = ("n", "x0", "h0", "rnn", "prev", "next", "prev_idx", "next_idx", "dt", "group")
 
-    def __init__(self, n, x0, rnn, prev, prev_idx_np, dt_np):
+    def __init__(self, n, x0, rnn, prev, prev_idx_np, dt_np, next_idx_np=None):
         self.n, self.x0, self.rnn, self.prev = int(n), int(x0), rnn, prev
         self.h0 = 0
         self.next = -1
         self.prev_idx = prev_idx_np
-        self.next_idx = None
+        self.next_idx = next_idx_np      # inverse of the successor's prev_idx when the planner already has it
         self.dt = dt_np
         self.group = -1
 
@@ -47,10 +47,11 @@ class GruProgram:
                 p = instances[it.prev]
                 assert p.next == -1, "an instance feeds at most one successor"
                 p.next = i
-                inv = np.full(p.n, -1, dtype=np.int32)
-                ok = it.prev_idx >= 0
-                inv[it.prev_idx[ok]] = np.nonzero(ok)[0].astype(np.int32)
-                p.next_idx = inv
+                if p.next_idx is None:
+                    inv = np.full(p.n, -1, dtype=np.int32)
+                    ok = it.prev_idx >= 0
+                    inv[it.prev_idx[ok]] = np.nonzero(ok)[0].astype(np.int32)
+                    p.next_idx = inv
         # groups: maximal runs of instances with the same weights and contiguous x and h rows
         self.groups = []
         for i, it in enumerate(instances):

@@ -41,7 +41,7 @@ def window_times(t_list, seq_len, times, ascending=False):
 
 class Step:
     """One executed window position: the graphs of the windows active there, batched."""
-    __slots__ = ("p", "windows", "graphs", "times", "sizes", "offsets", "n_rows", "ids", "prev_idx", "dt", "graph",
+    __slots__ = ("p", "windows", "graphs", "times", "sizes", "offsets", "n_rows", "ids", "prev_idx", "next_idx", "dt", "graph",
                  "row0", "dev")
 
     def __init__(self, p, windows, graphs, times):
@@ -51,6 +51,7 @@ class Step:
         self.n_rows = int(self.offsets[-1])
         self.ids = np.concatenate([g.gids for g in graphs]) if graphs else np.zeros(0, np.int64)
         self.prev_idx = None
+        self.next_idx = None         # inverse of the next executed step's prev_idx (filled by ChainPlan for history steps)
         self.dt = None
         self.graph = None            # batched Snapshot (built lazily)
         self.row0 = 0                # first row inside an all-visits batch (fast path)
@@ -92,12 +93,14 @@ class ChainPlan:
         # row maps of every executed position in one pass of the host planner library (temp_host_chain_plan):
         # prev_idx = row in the previous executed step's output (F8: the history holds ONLY that step's nodes), dt = gap
         from . import _hostlib
-        prev_idx, dt, row_of, last = _hostlib.chain_plan(self.bsz, num_ents, [st.p for st in self.steps], [len(st.windows) for st in self.steps],
+        prev_idx, next_idx, dt, row_of, last = _hostlib.chain_plan(self.bsz, num_ents, [st.p for st in self.steps], [len(st.windows) for st in self.steps],
                                                          [[g.gids for g in st.graphs] for st in self.steps])
         off = 0
         for st in self.steps:
-            st.prev_idx, st.dt = prev_idx[off:off + st.n_rows], dt[off:off + st.n_rows]
+            st.prev_idx, st.dt, st.next_idx = prev_idx[off:off + st.n_rows], dt[off:off + st.n_rows], next_idx[off:off + st.n_rows]
             off += st.n_rows
+        if self.steps:
+            self.steps[-1].next_idx = None                      # consumed by the target position, planned by the caller
         self.row_of, self.last = row_of, last
 
     def flipped(self):
@@ -128,24 +131,30 @@ def concat_steps_dedup(steps):
     Returns (batched graph over the distinct snapshots, visit_rows, total visit rows): visit_rows is
     an int32 array mapping every visit row (step.row0 layout) to its row in the distinct layout, or
     None when nothing is shared."""
-    uniq, first_row, graphs = {}, [], []
+    uniq, graphs = {}, []
     off_u = 0
-    visit_rows = []
+    bases, sizes = [], []
     off = 0
     shared = False
     for st in steps:
         st.row0 = off
         for g in st.graphs:
             key = id(g)
-            if key in uniq:
-                shared = True
-            else:
-                uniq[key] = off_u
+            base = uniq.get(key)
+            if base is None:
+                base = uniq[key] = off_u
                 graphs.append(g)
                 off_u += g.n
-            visit_rows.append(uniq[key] + np.arange(g.n, dtype=np.int64))
+            else:
+                shared = True
+            bases.append(base)
+            sizes.append(g.n)
         off += st.n_rows
-    vr = np.concatenate(visit_rows).astype(np.int32) if (shared and visit_rows) else None
+    vr = None
+    if shared and bases:
+        sizes = np.asarray(sizes, dtype=np.int64)
+        start = np.cumsum(sizes) - sizes                         # first visit row of every visit
+        vr = (np.repeat(np.asarray(bases, dtype=np.int64) - start, sizes) + np.arange(off, dtype=np.int64)).astype(np.int32)
     return S.batch(graphs), vr, off
 
 

@@ -38,12 +38,16 @@ def chain_plan_numpy(bsz, num_ents, positions, n_win, gid_arrays):
     row_of = np.full((bsz, num_ents), -1, dtype=np.int64)
     last = np.zeros((bsz, num_ents), dtype=np.float32)
     prev_pairs = None
-    pidx, dts = [], []
+    pidx, nidx, dts = [], [], []
     for p, nw, arrs in zip(positions, n_win, gid_arrays):
         sizes = [len(g) for g in arrs]
         ids = np.concatenate(arrs) if arrs else np.zeros(0, np.int64)
         bb = np.repeat(np.arange(nw, dtype=np.int64), sizes)
-        pidx.append(row_of[bb, ids])
+        pidx.append(row_of[bb, ids].astype(np.int32))
+        if nidx:                                               # inverse map of this step's prev_idx = the previous step's next_idx
+            ok = pidx[-1] >= 0
+            nidx[-1][pidx[-1][ok]] = np.nonzero(ok)[0].astype(np.int32)
+        nidx.append(np.full(ids.shape[0], -1, dtype=np.int32))
         dts.append((p - last[bb, ids]).astype(np.float32))
         if prev_pairs is not None:
             row_of[prev_pairs] = -1
@@ -51,4 +55,4 @@ def chain_plan_numpy(bsz, num_ents, positions, n_win, gid_arrays):
         last[bb, ids] = p
         prev_pairs = (bb, ids)
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
-    return cat(pidx, np.int64), cat(dts, np.float32), row_of, last
+    return cat(pidx, np.int32), cat(nidx, np.int32), cat(dts, np.float32), row_of, last
