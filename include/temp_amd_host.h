@@ -64,6 +64,19 @@ int64_t temp_host_snapshot_pack(int64_t n, int64_t E, const int64_t* src, const 
                                 int64_t n_rel_rows, int64_t chunk, int64_t chunk_rel,
                                 int32_t* packed, int64_t* sizes, int64_t* n_partial, int64_t* rel_chunks);
 
+/* Control block of temp_assemble_views (include/temp_amd.h) for a batch = disjoint union of M member snapshots whose packed
+ * views are resident on the device.  meta[m] (int64, 66 + n_rel_rows entries) = { size[31], offset[31] of the member's arrays
+ * inside its packed buffer, device address of that buffer, n_partial[3], chunks per relation[n_rel_rows] }; node_off / edge_off
+ * [M] = first node / edge of every member inside the union.
+ * ctl (int32) receives  [descriptors (8 words each) | piece_desc | piece_start | slot table M x n_rel_rows | fix_seg | fix_slot | fix_cnt]
+ * and summary (int64[72]) = { [0] n_desc, [1] n_pieces, [2] n_fix, [3] tail0 = words of the member-fed arrays,
+ * [4..31] first word of each of the 27 member-fed output arrays + their end, [35..61] their lengths,
+ * [65..67] partial slots of by_dst, by_src, by_rel }.  The 27 arrays, in output order:
+ * in_deg, out_deg, nnorm, the nine by_dst arrays, the nine by_src arrays, by_rel a / b / chunk_seg / chunk_beg / chunk_end /
+ * chunk_slot.  Returns the number of ctl words written, or -1 (bad argument / ctl_cap too small). */
+int64_t temp_host_union_plan(int64_t M, int64_t n_rel_rows, const int64_t* meta, const int64_t* node_off, const int64_t* edge_off,
+                             int64_t piece, int32_t* ctl, int64_t ctl_cap, int64_t* summary);
+
 /* k distinct integers of [0, n), uniformly at random, in random order (np.random.choice(n, k, replace=False) /
  * torch.randperm(n)[:k] of the reference: models/DynamicRGCN.py:81, utils/CorrptTriples.py:38-40): a partial Fisher-Yates
  * shuffle driven by splitmix64(seed).  out[k]. */

@@ -20,6 +20,7 @@ SYMBOLS = {
     "temp_host_build_view": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "temp_host_plan_loss": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "temp_host_snapshot_pack": (_I64, [_I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "temp_host_union_plan": (_I64, [_I64, _I64, _P, _P, _P, _I64, _P, _I64, _P]),
     "temp_host_sample_subset": (ctypes.c_int, [_I64, _I64, ctypes.c_uint64, _P]),
     "temp_host_gather_inverse": (_I64, [_I64, _P, _I64, _P, _P]),
     "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -154,3 +155,19 @@ def sample_subset(n, k, rng):
     if rc != 0:
         raise ValueError("temp_host_sample_subset: need 0 <= k <= n")
     return out[:int(k)]
+
+
+def union_plan(meta, node_off, edge_off, n_rel_rows, piece):
+    """See temp_host_union_plan.  meta: (M, 66 + n_rel_rows) int64 -> (ctl int32, summary int64[72])."""
+    meta = np.ascontiguousarray(meta, dtype=np.int64)
+    M = int(meta.shape[0])
+    node_off, edge_off = _i64(node_off), _i64(edge_off)
+    words = int(meta[:, :31].sum()) if M else 0
+    cap = 8 * 27 * M + 2 * (27 * M + words // int(piece) + 64) + M * int(n_rel_rows) + 3 * int(n_rel_rows) + 16
+    ctl = np.empty(cap, np.int32)
+    summary = np.zeros(72, np.int64)
+    w = load().temp_host_union_plan(M, int(n_rel_rows), meta.ctypes.data, node_off.ctypes.data, edge_off.ctypes.data, int(piece),
+                                    ctl.ctypes.data, cap, summary.ctypes.data)
+    if w < 0:
+        raise ValueError("temp_host_union_plan: bad argument")
+    return ctl[:w], summary

@@ -214,6 +214,98 @@ int64_t temp_host_snapshot_pack(int64_t n, int64_t E, const int64_t* src, const 
   return off;
 }
 
+int64_t temp_host_union_plan(int64_t M, int64_t R, const int64_t* meta, const int64_t* node_off, const int64_t* edge_off,
+                             int64_t piece, int32_t* ctl, int64_t ctl_cap, int64_t* summary) {
+  if (M < 0 || R < 0 || piece <= 0 || !ctl || !summary || (M > 0 && (!meta || !node_off || !edge_off))) return -1;
+  const int64_t W = 66 + R;
+  enum { ZERO, NODE, EDGE, PDST, PSRC, MEMB };
+  struct Spec { int col, add, mode, aux; };
+  static const Spec spec[30] = {
+      {28, ZERO, 0, -1}, {29, ZERO, 0, -1}, {30, ZERO, 0, -1},
+      {0, NODE, 0, -1}, {1, ZERO, 0, -1}, {2, NODE, 0, -1}, {3, EDGE, 0, -1}, {4, EDGE, 0, -1}, {5, PDST, 1, -1}, {6, NODE, 0, -1}, {7, PDST, 0, -1}, {8, ZERO, 0, -1},
+      {9, NODE, 0, -1}, {10, ZERO, 0, -1}, {11, NODE, 0, -1}, {12, EDGE, 0, -1}, {13, EDGE, 0, -1}, {14, PSRC, 1, -1}, {15, NODE, 0, -1}, {16, PSRC, 0, -1}, {17, ZERO, 0, -1},
+      {18, NODE, 0, -1}, {19, NODE, 0, -1}, {20, ZERO, 0, -1}, {21, EDGE, 0, -1}, {22, EDGE, 0, -1}, {27, MEMB, 2, 20}};
+  const int n_out = 27;                                  // 3 + 9 + 9 + 6
+  auto size_of = [&](int64_t m, int c) { return meta[m * W + c]; };
+  auto off_of = [&](int64_t m, int c) { return meta[m * W + 31 + c]; };
+  auto ptr_of = [&](int64_t m) { return meta[m * W + 62]; };
+  // partial-slot offsets of the node views, per-relation chunk totals
+  std::vector<int64_t> p_dst((size_t)M), p_src((size_t)M), per_rel((size_t)R, 0);
+  int64_t acc_d = 0, acc_s = 0;
+  for (int64_t m = 0; m < M; ++m) {
+    p_dst[(size_t)m] = acc_d; acc_d += meta[m * W + 63];
+    p_src[(size_t)m] = acc_s; acc_s += meta[m * W + 64];
+    for (int64_t r = 0; r < R; ++r) per_rel[(size_t)r] += meta[m * W + 66 + r];
+  }
+  int64_t n_fix = 0, rel_partial = 0;
+  std::vector<int64_t> base((size_t)R, -1);
+  for (int64_t r = 0; r < R; ++r)
+    if (per_rel[(size_t)r] > 1) { base[(size_t)r] = rel_partial; rel_partial += per_rel[(size_t)r]; ++n_fix; }
+  // sizes of the sections
+  int64_t n_desc = 0, n_pieces = 0;
+  int64_t totals[30] = {0};
+  for (int o = 0; o < n_out; ++o)
+    for (int64_t m = 0; m < M; ++m) {
+      const int64_t len = size_of(m, spec[o].col);
+      totals[o] += len;
+      if (len > 0) { ++n_desc; n_pieces += (len + piece - 1) / piece; }
+    }
+  const int64_t need = 8 * n_desc + 2 * n_pieces + M * R + 3 * n_fix;
+  if (need > ctl_cap) return -1;
+  int32_t* desc = ctl;
+  int32_t* pd = ctl + 8 * n_desc;
+  int32_t* ps = pd + n_pieces;
+  int32_t* table = ps + n_pieces;
+  int32_t* f_seg = table + M * R;
+  int32_t* f_slot = f_seg + n_fix;
+  int32_t* f_cnt = f_slot + n_fix;
+  int64_t out_base = 0, d = 0, pc = 0;
+  for (int o = 0; o < n_out; ++o) {
+    summary[4 + o] = out_base;
+    int64_t dst = out_base;
+    for (int64_t m = 0; m < M; ++m) {
+      const int64_t len = size_of(m, spec[o].col);
+      if (len > 0) {
+        int64_t add = 0;
+        switch (spec[o].add) {
+          case NODE: add = node_off[m]; break;
+          case EDGE: add = edge_off[m]; break;
+          case PDST: add = p_dst[(size_t)m]; break;
+          case PSRC: add = p_src[(size_t)m]; break;
+          case MEMB: add = m * R; break;
+          default: break;
+        }
+        const int64_t src = ptr_of(m) + 4 * off_of(m, spec[o].col);
+        const int64_t aux = ptr_of(m) + 4 * off_of(m, spec[o].aux < 0 ? 0 : spec[o].aux);
+        int32_t* rec = desc + 8 * d;
+        rec[0] = (int32_t)(uint32_t)(src & 0xffffffffll); rec[1] = (int32_t)(src >> 32);
+        rec[2] = (int32_t)(uint32_t)(aux & 0xffffffffll); rec[3] = (int32_t)(aux >> 32);
+        rec[4] = (int32_t)dst; rec[5] = (int32_t)len; rec[6] = (int32_t)add; rec[7] = spec[o].mode;
+        for (int64_t st = 0; st < len; st += piece, ++pc) { pd[pc] = (int32_t)d; ps[pc] = (int32_t)st; }
+        ++d;
+      }
+      dst += len;
+    }
+    out_base += totals[o];
+  }
+  summary[4 + n_out] = out_base;
+  // slot table of the by-relation view: member m's chunks of relation r start at base[r] + (chunks of r in earlier members)
+  {
+    std::vector<int64_t> run((size_t)R, 0);
+    for (int64_t m = 0; m < M; ++m)
+      for (int64_t r = 0; r < R; ++r) {
+        table[m * R + r] = per_rel[(size_t)r] > 1 ? (int32_t)(base[(size_t)r] + run[(size_t)r]) : -1;
+        run[(size_t)r] += meta[m * W + 66 + r];
+      }
+  }
+  for (int64_t r = 0, f = 0; r < R; ++r)
+    if (per_rel[(size_t)r] > 1) { f_seg[f] = (int32_t)r; f_slot[f] = (int32_t)base[(size_t)r]; f_cnt[f] = (int32_t)per_rel[(size_t)r]; ++f; }
+  summary[0] = n_desc; summary[1] = n_pieces; summary[2] = n_fix; summary[3] = out_base;
+  for (int o = 0; o < n_out; ++o) summary[4 + 31 + o] = totals[o];
+  summary[4 + 31 + 30] = acc_d; summary[4 + 31 + 31] = acc_s; summary[4 + 31 + 32] = rel_partial;
+  return need;
+}
+
 static inline uint64_t splitmix64_next(uint64_t& state) {
   uint64_t x = (state += 0x9E3779B97F4A7C15ull);
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;

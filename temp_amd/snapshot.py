@@ -128,6 +128,9 @@ class Snapshot:
             offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
             dv["_meta"] = dict(ptr=int(buf.data_ptr()), off=offs.astype(np.int64), size=np.asarray(sizes, dtype=np.int64),
                                n_partial=np.asarray(n_partial, dtype=np.int64), rel_chunks=np.asarray(rel_chunks, dtype=np.int64))
+            m = dv["_meta"]                                      # one int64 row for the host planner (temp_host_union_plan)
+            m["row"] = np.concatenate([m["size"], m["off"], [m["ptr"]], m["n_partial"], m["rel_chunks"][:n_rel_rows],
+                                       np.zeros(max(0, n_rel_rows - m["rel_chunks"].shape[0]), np.int64)]).astype(np.int64)
             self._dev[key] = dv
         return dv
 
@@ -403,13 +406,12 @@ def union_views_device(snap, n_rel_rows, device):
 _COL = {(vn, an): i * 9 + j for i, vn in enumerate(("by_dst", "by_src", "by_rel"))
         for j, an in enumerate(("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt"))}
 _COL.update(rel_rank=27, in_deg=28, out_deg=29, nnorm=30)
-_DESC_DTYPE = np.dtype([("src", np.int64), ("aux", np.int64), ("dst_off", np.int32), ("len", np.int32), ("add", np.int32), ("mode", np.int32)])
 
 
 def union_graph_packed(snap, n_rel_rows, device):
     """The union's TempGraph arrays in ONE packed int32 device buffer, assembled from the members' resident views by a
-    single temp_assemble_views launch (the host only stacks the members' cached size / offset rows and computes, with a few
-    vectorised numpy calls, where every member array lands).  Returns None when the by-relation view needs the global sort.
+    single temp_assemble_views launch (the host stacks the members' cached meta rows; the host planner library turns them
+    into the descriptor table, temp_host_union_plan).  Returns None when the by-relation view needs the global sort.
     -> (ints, offs {(view, array) | 'in_deg' | 'out_deg' | 'nnorm': offset}, sizes {...}, counts {view: {...}})"""
     from .backend import get_backend
     E = int(snap.edge_off[-1])
@@ -422,73 +424,30 @@ def union_graph_packed(snap, n_rel_rows, device):
         if m is None:
             m = g._dev[key] = g.device_views(device, n_rel_rows)["_meta"]
         metas.append(m)
-    M = len(metas)
-    size = np.stack([m["size"] for m in metas])                      # (M, 31)
-    moff = np.stack([m["off"] for m in metas])
-    ptr = np.array([m["ptr"] for m in metas], dtype=np.int64)
-    n_part = np.stack([m["n_partial"] for m in metas])               # (M, 3)
-    node_off, edge_off = snap.node_off[:-1].astype(np.int64), snap.edge_off[:-1].astype(np.int64)
-    zero = np.zeros(M, dtype=np.int64)
-    p_off = {vn: np.concatenate([[0], np.cumsum(n_part[:, i])])[:-1] for i, vn in enumerate(("by_dst", "by_src"))}
-    # by-relation slots: a relation with more than one chunk over all members owns a run of partial-sum slots
-    counts_rel = np.stack([m["rel_chunks"] for m in metas])
-    per_rel = counts_rel.sum(axis=0)
-    multi = per_rel > 1
-    fix_seg = np.nonzero(multi)[0]
-    fix_cnt = per_rel[fix_seg]
-    fix_slot = np.cumsum(fix_cnt) - fix_cnt
-    base = np.full(n_rel_rows, -1, dtype=np.int64)
-    base[fix_seg] = fix_slot
-    table = np.where(multi[None, :], base[None, :] + (np.cumsum(counts_rel, axis=0) - counts_rel), -1).reshape(-1)
-    # output arrays: (key, member column, add per member, mode, aux column)
-    spec = [("in_deg", _COL["in_deg"], zero, 0, -1), ("out_deg", _COL["out_deg"], zero, 0, -1), ("nnorm", _COL["nnorm"], zero, 0, -1)]
-    for vn in ("by_dst", "by_src"):
-        for an, add, mode in (("a", node_off, 0), ("b", zero, 0), ("chunk_seg", node_off, 0), ("chunk_beg", edge_off, 0), ("chunk_end", edge_off, 0),
-                              ("chunk_slot", p_off[vn], 1), ("fix_seg", node_off, 0), ("fix_slot", p_off[vn], 0), ("fix_cnt", zero, 0)):
-            spec.append(((vn, an), _COL[(vn, an)], add, mode, -1))
-    for an, add in (("a", node_off), ("b", node_off), ("chunk_seg", zero), ("chunk_beg", edge_off), ("chunk_end", edge_off)):
-        spec.append((("by_rel", an), _COL[("by_rel", an)], add, 0, -1))
-    spec.append((("by_rel", "chunk_slot"), _COL["rel_rank"], np.arange(M, dtype=np.int64) * n_rel_rows, 2, _COL[("by_rel", "chunk_seg")]))
-    cols = np.array([c for _, c, _, _, _ in spec])
-    lens = size[:, cols].T                                            # (n_out, M)
-    totals = lens.sum(axis=1)
-    out_base = np.concatenate([[0], np.cumsum(totals)])
-    dst = out_base[:-1, None] + np.cumsum(lens, axis=1) - lens        # (n_out, M)
-    desc = np.zeros(lens.shape, dtype=_DESC_DTYPE)
-    desc["src"] = ptr[None, :] + 4 * moff[:, cols].T
-    aux_cols = np.array([max(a, 0) for *_, a in spec])
-    desc["aux"] = ptr[None, :] + 4 * moff[:, aux_cols].T
-    desc["dst_off"], desc["len"] = dst, lens
-    desc["add"] = np.stack([a for _, _, a, _, _ in spec])
-    desc["mode"] = np.array([m for _, _, _, m, _ in spec])[:, None]
-    desc = desc.reshape(-1)
-    desc = desc[desc["len"] > 0]
-    n_p = (desc["len"].astype(np.int64) + _lib.ASSEMBLE_PIECE - 1) // _lib.ASSEMBLE_PIECE
-    piece_desc = np.repeat(np.arange(desc.shape[0], dtype=np.int64), n_p)
-    first = np.cumsum(n_p) - n_p
-    piece_start = (np.arange(piece_desc.shape[0], dtype=np.int64) - first[piece_desc]) * _lib.ASSEMBLE_PIECE
-    # the three by-relation fix arrays come from the host: they ride at the end of the packed output
-    tail0 = int(out_base[-1])
-    nfix = int(fix_seg.shape[0])
-    ctl = np.concatenate([desc.view(np.int32), piece_desc.astype(np.int32), piece_start.astype(np.int32), table.astype(np.int32),
-                          fix_seg.astype(np.int32), fix_slot.astype(np.int32), fix_cnt.astype(np.int32)])
+    from . import _hostlib
+    ctl, sm = _hostlib.union_plan(np.stack([m["row"] for m in metas]), snap.node_off[:-1], snap.edge_off[:-1], n_rel_rows, _lib.ASSEMBLE_PIECE)
+    n_desc, npc, nfix, tail0 = (int(x) for x in sm[:4])
+    out_base, totals = sm[4:32], sm[35:62]
+    names = ["in_deg", "out_deg", "nnorm"] + [(vn, an) for vn in ("by_dst", "by_src") for an in _VIEW_ARRAYS] + \
+            [("by_rel", an) for an in ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot")]
+    table_words = len(metas) * n_rel_rows
     ctl_dev = _lib.to_device(ctl, device)
-    nd, npc = desc.shape[0] * 8, piece_desc.shape[0]
+    nd = n_desc * 8
     d_desc, d_pd, d_ps = ctl_dev[:nd], ctl_dev[nd:nd + npc], ctl_dev[nd + npc:nd + 2 * npc]
-    d_table = ctl_dev[nd + 2 * npc:nd + 2 * npc + table.shape[0]]
-    d_fix = ctl_dev[nd + 2 * npc + table.shape[0]:]
+    d_table = ctl_dev[nd + 2 * npc:nd + 2 * npc + table_words]
+    d_fix = ctl_dev[nd + 2 * npc + table_words:]
     ints = torch.empty(tail0 + 3 * nfix + 1, dtype=torch.int32, device=device)
     if nfix:
         ints[tail0:tail0 + 3 * nfix] = d_fix
     get_backend().assemble_views(d_pd, d_ps, d_desc, d_table, ints)
-    offs = {k: int(out_base[i]) for i, (k, *_r) in enumerate(spec)}
-    sizes = {k: int(totals[i]) for i, (k, *_r) in enumerate(spec)}
+    offs = {k: int(out_base[i]) for i, k in enumerate(names)}
+    sizes = {k: int(totals[i]) for i, k in enumerate(names)}
     for j, an in enumerate(("fix_seg", "fix_slot", "fix_cnt")):
         offs[("by_rel", an)], sizes[("by_rel", an)] = tail0 + j * nfix, nfix
     counts = {}
     for i, vn in enumerate(("by_dst", "by_src")):
-        counts[vn] = dict(n_seg=int(snap.n), n_edges=E, n_chunks=sizes[(vn, "chunk_seg")], n_partial=int(n_part[:, i].sum()), n_fix=sizes[(vn, "fix_seg")])
-    counts["by_rel"] = dict(n_seg=int(n_rel_rows), n_edges=E, n_chunks=sizes[("by_rel", "chunk_seg")], n_partial=int(per_rel[multi].sum()), n_fix=nfix)
+        counts[vn] = dict(n_seg=int(snap.n), n_edges=E, n_chunks=sizes[(vn, "chunk_seg")], n_partial=int(sm[65 + i]), n_fix=sizes[(vn, "fix_seg")])
+    counts["by_rel"] = dict(n_seg=int(n_rel_rows), n_edges=E, n_chunks=sizes[("by_rel", "chunk_seg")], n_partial=int(sm[67]), n_fix=nfix)
     return ints, offs, sizes, counts, ctl_dev
 
 

@@ -56,3 +56,52 @@ def chain_plan_numpy(bsz, num_ents, positions, n_win, gid_arrays):
         prev_pairs = (bb, ids)
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
     return cat(pidx, np.int32), cat(nidx, np.int32), cat(dts, np.float32), row_of, last
+
+
+def union_plan_numpy(size, moff, ptr, n_part, counts_rel, node_off, edge_off, n_rel_rows, piece):
+    """Control block of temp_assemble_views, numpy formulation: -> (ctl int32, summary dict)."""
+    M = size.shape[0]
+    COL = {(vn, an): i * 9 + j for i, vn in enumerate(("by_dst", "by_src", "by_rel"))
+           for j, an in enumerate(("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt"))}
+    COL.update(rel_rank=27, in_deg=28, out_deg=29, nnorm=30)
+    DESC = np.dtype([("src", np.int64), ("aux", np.int64), ("dst_off", np.int32), ("len", np.int32), ("add", np.int32), ("mode", np.int32)])
+    zero = np.zeros(M, dtype=np.int64)
+    p_off = {vn: np.concatenate([[0], np.cumsum(n_part[:, i])])[:-1] for i, vn in enumerate(("by_dst", "by_src"))}
+    per_rel = counts_rel.sum(axis=0)
+    multi = per_rel > 1
+    fix_seg = np.nonzero(multi)[0]
+    fix_cnt = per_rel[fix_seg]
+    fix_slot = np.cumsum(fix_cnt) - fix_cnt
+    base = np.full(n_rel_rows, -1, dtype=np.int64)
+    base[fix_seg] = fix_slot
+    table = np.where(multi[None, :], base[None, :] + (np.cumsum(counts_rel, axis=0) - counts_rel), -1).reshape(-1)
+    spec = [("in_deg", COL["in_deg"], zero, 0, -1), ("out_deg", COL["out_deg"], zero, 0, -1), ("nnorm", COL["nnorm"], zero, 0, -1)]
+    for vn in ("by_dst", "by_src"):
+        for an, add, mode in (("a", node_off, 0), ("b", zero, 0), ("chunk_seg", node_off, 0), ("chunk_beg", edge_off, 0), ("chunk_end", edge_off, 0),
+                              ("chunk_slot", p_off[vn], 1), ("fix_seg", node_off, 0), ("fix_slot", p_off[vn], 0), ("fix_cnt", zero, 0)):
+            spec.append(((vn, an), COL[(vn, an)], add, mode, -1))
+    for an, add in (("a", node_off), ("b", node_off), ("chunk_seg", zero), ("chunk_beg", edge_off), ("chunk_end", edge_off)):
+        spec.append((("by_rel", an), COL[("by_rel", an)], add, 0, -1))
+    spec.append((("by_rel", "chunk_slot"), COL["rel_rank"], np.arange(M, dtype=np.int64) * n_rel_rows, 2, COL[("by_rel", "chunk_seg")]))
+    cols = np.array([c for _, c, _, _, _ in spec])
+    lens = size[:, cols].T
+    totals = lens.sum(axis=1)
+    out_base = np.concatenate([[0], np.cumsum(totals)])
+    dst = out_base[:-1, None] + np.cumsum(lens, axis=1) - lens
+    desc = np.zeros(lens.shape, dtype=DESC)
+    desc["src"] = ptr[None, :] + 4 * moff[:, cols].T
+    aux_cols = np.array([max(a, 0) for *_, a in spec])
+    desc["aux"] = ptr[None, :] + 4 * moff[:, aux_cols].T
+    desc["dst_off"], desc["len"] = dst, lens
+    desc["add"] = np.stack([a for _, _, a, _, _ in spec])
+    desc["mode"] = np.array([m for _, _, _, m, _ in spec])[:, None]
+    desc = desc.reshape(-1)
+    desc = desc[desc["len"] > 0]
+    n_p = (desc["len"].astype(np.int64) + piece - 1) // piece
+    piece_desc = np.repeat(np.arange(desc.shape[0], dtype=np.int64), n_p)
+    first = np.cumsum(n_p) - n_p
+    piece_start = (np.arange(piece_desc.shape[0], dtype=np.int64) - first[piece_desc]) * piece
+    ctl = np.concatenate([desc.view(np.int32), piece_desc.astype(np.int32), piece_start.astype(np.int32), table.astype(np.int32),
+                          fix_seg.astype(np.int32), fix_slot.astype(np.int32), fix_cnt.astype(np.int32)])
+    return ctl, dict(n_desc=desc.shape[0], n_pieces=piece_desc.shape[0], n_fix=fix_seg.shape[0], out_base=out_base, totals=totals,
+                     partial=(int(n_part[:, 0].sum()), int(n_part[:, 1].sum()), int(per_rel[multi].sum())))

@@ -16,7 +16,7 @@ def test_host_library_exports_every_declared_symbol():
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(temp_host_[a-z0-9_]+)\s*\(", src)))
     lib = _hostlib.load()
-    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 7
+    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 8
     for n in names:
         assert hasattr(lib, n)
     assert lib.temp_host_abi_version() == 1
@@ -117,3 +117,25 @@ def test_sample_subset_is_a_uniform_subset():
     assert _hostlib.sample_subset(7, 0, rng).shape == (0,)
     with pytest.raises(ValueError):
         _hostlib.sample_subset(3, 4, rng)
+
+
+@pytest.mark.parametrize("M,R,piece", [(1, 4, 4096), (6, 40, 4096), (183, 40, 4096), (9, 3, 16)])
+def test_union_plan_matches_numpy(M, R, piece):
+    """temp_host_union_plan (descriptor table / pieces / slot table / fix arrays of temp_assemble_views) vs the numpy formulation."""
+    from tests.host_reference import union_plan_numpy
+    rng = np.random.default_rng(M * 7 + R)
+    size = rng.integers(0, 9000, (M, 31))
+    size[rng.random((M, 31)) < 0.15] = 0                              # empty arrays (no hub segments, empty graphs)
+    moff = np.cumsum(size, axis=1) - size
+    ptr = (rng.integers(1, 1 << 20, M) << 8) + (1 << 40)              # 64-bit device addresses
+    n_part = rng.integers(0, 50, (M, 3))
+    counts_rel = rng.integers(0, 3, (M, R))
+    node_off = np.cumsum(rng.integers(1, 600, M)) - 1
+    edge_off = np.cumsum(rng.integers(0, 8000, M))
+    meta = np.concatenate([size, moff, ptr[:, None], n_part, counts_rel], axis=1).astype(np.int64)
+    ctl, sm = _hostlib.union_plan(meta, node_off, edge_off, R, piece)
+    want, info = union_plan_numpy(size, moff, ptr, n_part, counts_rel, node_off, edge_off, R, piece)
+    assert ctl.dtype == np.int32 and np.array_equal(ctl, want)
+    assert (int(sm[0]), int(sm[1]), int(sm[2])) == (info["n_desc"], info["n_pieces"], info["n_fix"]) and int(sm[3]) == int(info["out_base"][-1])
+    assert np.array_equal(sm[4:32], info["out_base"]) and np.array_equal(sm[35:62], info["totals"])
+    assert tuple(int(x) for x in sm[65:68]) == info["partial"]
