@@ -198,7 +198,7 @@ class SelfAttentionRGCN(DynamicRGCN):
             if fused is not None:
                 return fused
         if samples is None:
-            samples = self.draw_samples(wb)
+            samples = self._samples_from_plan(wb) if getattr(wb, "loss_plan", None) is not None else self.draw_samples(wb)
         cache = getattr(wb, "_loss_inputs", None)
         if cache is None or cache[0] is not samples:
             offs = np.concatenate([[0], np.cumsum(wb.target_sizes)])[:-1]
