@@ -296,7 +296,7 @@ class DynamicRGCN(TKG_Module):
         offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
         wb.loss_plan = plan_batch_loss(store, [r[-1] for r in wb.rows], wb.graphs, offs, self.args.num_pos_facts, self.sample_rng,
                                        int(sum(sizes)), int(self.rel_embeds.shape[0]), dev)
-        if wb.batched:
+        if self._fused_all_entity_ok(wb):
             self._all_maps(wb)
 
     def _target_sizes(self, wb):
@@ -397,28 +397,48 @@ class DynamicRGCN(TKG_Module):
         """[(GRU, final history of its direction)] of the recurrent layer."""
         return [(self.ent_encoder.layer_2.rnn, hist[1])]
 
+    def _fused_all_entity_ok(self, wb):
+        """The batched all-entity pass + fused loss apply: always on the batched path; on the reference-granular path when the
+        model is the unidirectional GRU encoder with BOTH layers recurrent (the reference's default flags), where the entity
+        classes of _all_maps carry over to the first layer as well."""
+        enc = self.ent_encoder
+        plain = (not enc.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
+                 and getattr(enc.layer_2, "num_layers", 1) == 1)
+        if wb.batched:
+            return plain
+        return (plain and self.use_batched_path and not isinstance(wb.plan, tuple) and isinstance(enc.layer_1, GRRGCNLayer)
+                and isinstance(enc.layer_2, GRRGCNLayer) and not (enc.layer_1._extra() or enc.layer_2._extra()))
+
     def all_embeds_batched(self, wb, out, hist):
         """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64; Bi: models/BiDynamicRGCN.py:102-112,
-        models/BiRRGCN.py:65-82).  With only the last layer recurrent the isolated RGCN trunk e -> Iso2(Iso1(e)) is the same
-        for every window, so it runs ONCE over the N_ents entities; so does the GRU from a zero state.  Only the (window,
-        entity) pairs that carry a previous state get their own GRU rows (see _all_maps).  `out` = the concatenated target
-        rows of the encoder.  Returns (B, N_ents, D)."""
+        models/BiRRGCN.py:65-82).  The isolated RGCN trunk e -> Iso2(Iso1(e)) does not depend on the window, so it runs ONCE
+        over the N_ents entities; so does every GRU from a zero state.  Only the (window, entity) pairs that carry a previous
+        state get their own GRU rows (see _all_maps) -- through BOTH layers when the first one is recurrent too
+        (rec_only_last_layer = False: y1 = GRU_1(Iso1(e), prev), y2 = GRU_2(Iso2(y1), prev), models/RRGCN.py:234-253).
+        `out` = the concatenated target rows of the encoder.  Returns (B, N_ents, D)."""
         enc = self.ent_encoder
         l1, l2 = enc.layer_1, enc.layer_2
         maps = self._all_maps(wb)
         B, N = len(wb.graphs), self.num_ents
         if wb.n_inactive == 0:
             return TF.gather_rows(out, maps[0]["asm"], maps[0]["asm_inv"]).view(B, N, out.shape[1])
-        x = l2.conv_isolated(l1.conv_isolated(self.ent_embeds))
+        l1_rec = isinstance(l1, GRRGCNLayer)
+        iso1 = l1.conv_isolated(self.ent_embeds)
+        zero = iso1.new_zeros(1, iso1.shape[1])
+        dt0 = iso1.new_zeros(N, 1)
+        none = torch.full((N,), -1, dtype=torch.int32, device=iso1.device)
+        t1 = run_rnn(l1.rnn, iso1, zero, dt0, l1.inv_temperature, l1.decay_spec(), none) if l1_rec else iso1
+        x = l2.conv_isolated(t1)
         lam, dec = l2.inv_temperature, l2.decay_spec()
-        zero = x.new_zeros(1, x.shape[1])
-        dt0 = x.new_zeros(N, 1)
-        none = torch.full((N,), -1, dtype=torch.int32, device=x.device)
         big = None
         for d, (m, (rnn, H)) in enumerate(zip(maps, self._isolated_rnns(hist))):
             parts = [out] if d == 0 else []
             if m["n_prev"]:
-                xp = TF.gather_rows(x, m["ent"], m["ent_inv"])
+                if l1_rec:                                    # the pair's own first-layer state, then the second layer's input
+                    y1p = run_rnn(l1.rnn, TF.gather_rows(iso1, m["ent"], m["ent_inv"]), hist[0], m["dt"], l1.inv_temperature, l1.decay_spec(), m["idx"])
+                    xp = l2.conv_isolated(y1p)
+                else:
+                    xp = TF.gather_rows(x, m["ent"], m["ent_inv"])
                 parts.append(run_rnn(rnn, xp, H, m["dt"], lam, dec, m["idx"]))
             parts.append(run_rnn(rnn, x, zero, dt0, lam, dec, none))             # GRU(x_e, 0): one row per entity, every window
             g = TF.gather_rows(torch.cat(parts, dim=0), m["asm"], m["asm_inv"])
@@ -430,8 +450,7 @@ class DynamicRGCN(TKG_Module):
         dev = self._device()
         out, hist = self.run(wb)
         per_graph = list(out.split(wb.target.sizes))
-        batched = (wb.batched and not self.ent_encoder.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
-                   and getattr(self.ent_encoder.layer_2, "num_layers", 1) == 1)
+        batched = self._fused_all_entity_ok(wb)
         all_list = self.all_embeds_batched(wb, out, hist) if batched else None
         if samples is None and batched and getattr(wb, "loss_plan", None) is not None:
             fused = self._sampled_loss(wb, out, all_list)

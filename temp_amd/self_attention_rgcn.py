@@ -143,6 +143,9 @@ class SelfAttentionRGCN(DynamicRGCN):
     def _all_maps(self, wb):
         return None                                   # this model's all-entity maps are built in prepare
 
+    def _fused_all_entity_ok(self, wb):
+        return False                                  # (its own run_loss always takes the batched all-entity pass)
+
     def run(self, wb):
         """-> (target rows (sum n_b, D), (layer-1 K/V table or None, layer-2 K/V table))."""
         enc = self.ent_encoder
