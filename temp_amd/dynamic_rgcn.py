@@ -259,14 +259,18 @@ class DynamicRGCN(TKG_Module):
         graph_dict = self.graph_dict_val if val else self.graph_dict_test
         dev = self._device()
         with torch.no_grad():
-            per_graph, plan, rows, graphs, hist = self.encode(t_list, self.test_seq_len, train=False)
+            wb = self.prepare(t_list, self.test_seq_len, train=False)
+            out, hist = self.run(wb)
+            per_graph, plan, rows = list(out.split(wb.target.sizes)), wb.plan, wb.rows
+            # all windows' all-entity matrices in one batched pass when the model allows it (same classes as the training loss)
+            all_b = self.all_embeds_batched(wb, out, hist) if self._fused_all_entity_ok(wb) else None
             ranks, losses = [], []
             for i, ent_embed in enumerate(per_graph):
                 t = rows[i][-1]
                 g = graph_dict[t]
                 if g.number_of_edges() == 0:
                     continue
-                all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, plan, i, hist)
+                all_embeds_g = all_b[i] if all_b is not None else self.get_all_embeds_Gt(ent_embed, g, t, plan, i, hist)
                 index_sample = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(dev)
                 label = torch.ones(index_sample.shape[0], device=dev)
                 ranks.append(self.evaluater.calc_metrics_single_graph(ent_embed, self.rel_embeds, all_embeds_g, index_sample, g, t))
