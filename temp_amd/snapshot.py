@@ -454,6 +454,24 @@ def union_graph_packed(snap, n_rel_rows, device):
 _VIEW_ARRAYS = ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")
 
 
+def _pack_small_union(snap, n_rel_rows, device):
+    """(ints, offs, sizes, counts, None) of a BatchedSnapshot from ONE temp_host_snapshot_pack call over its materialised edges."""
+    from . import _hostlib
+    E = snap.number_of_edges()
+    if E and (snap.rel.min() < 0 or snap.rel.max() >= n_rel_rows):
+        raise ValueError("relation id outside [0, %d)" % n_rel_rows)
+    packed, sz, n_partial, _ = _hostlib.snapshot_pack(snap.n, snap.src, snap.dst, snap.rel, snap.nnorm, n_rel_rows, _lib.CHUNK, _lib.CHUNK_REL)
+    names = [(vn, an) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS] + ["rel_rank", "in_deg", "out_deg", "nnorm"]
+    off = np.concatenate([[0], np.cumsum(sz)])
+    offs = {k: int(off[i]) for i, k in enumerate(names)}
+    sizes = {k: int(sz[i]) for i, k in enumerate(names)}
+    counts = {}
+    for i, (vn, n_seg) in enumerate((("by_dst", snap.n), ("by_src", snap.n), ("by_rel", n_rel_rows))):
+        counts[vn] = dict(n_seg=int(n_seg), n_edges=int(E), n_chunks=sizes[(vn, "chunk_seg")], n_partial=int(n_partial[i]), n_fix=sizes[(vn, "fix_seg")])
+    ints = _lib.to_device(np.concatenate([packed, np.zeros(1, np.int32)]), device)
+    return ints, offs, sizes, counts, None
+
+
 class _DeviceGraph:
     """Device-resident TempGraph: one packed int32 buffer + nnorm, and the ctypes struct whose
     pointers refer into them (kept alive by this object)."""
@@ -469,6 +487,11 @@ class _DeviceGraph:
             dev_union = union_views_device(snap, n_rel_rows, device) if DEVICE_STORE != "kernel" else None
             if dev_union is not None:
                 self._init_from_device(dev_union, n, E, n_rel_rows, device)
+                return
+            if DEVICE_STORE == "kernel" and n > 0:
+                # a small union (few edges per relation: ICEWS-like positions): one pass of the host planner over the union's
+                # own edge list -- the by-relation view is then the global sort this shape wants
+                self._init_from_packed(_pack_small_union(snap, n_rel_rows, device), n, E, n_rel_rows, device)
                 return
         if isinstance(snap, BatchedSnapshot) and len(snap.parts) > 1:
             views, in_deg, out_deg = union_views(snap, n_rel_rows)
