@@ -5,6 +5,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _hostlib
+from . import _lib
 from . import functional as TF
 from . import snapshot as S
 from .rgcn import RGCN
@@ -19,6 +21,8 @@ class StaticRGCN(TKG_Module):
         nn.init.xavier_uniform_(self.ent_embeds, gain=nn.init.calculate_gain('relu'))
         nn.init.xavier_uniform_(self.rel_embeds, gain=nn.init.calculate_gain('relu'))
         self.sample_rng = np.random.default_rng(getattr(args, "seed", None))
+        self.seed_rng = np.random.default_rng(None if getattr(args, "seed", None) is None else int(args.seed) + 1)
+        self.use_device_sampler = True
 
     def build_model(self):
         self.train_seq_len = self.args.train_seq_len
@@ -33,13 +37,14 @@ class StaticRGCN(TKG_Module):
             graphs = []
             for i, g in enumerate(graph_train_list):
                 E = g.number_of_edges()
-                idx = edge_ids[i] if edge_ids is not None else self.sample_rng.choice(np.arange(E), size=int(0.5 * E), replace=False)
+                idx = edge_ids[i] if edge_ids is not None else _hostlib.sample_subset(E, int(0.5 * E), self.sample_rng)
                 graphs.append(g.edge_subgraph(idx))
         bg = S.batch(graphs)
         ids = torch.from_numpy(bg.gids.astype(np.int32)).to(self.ent_embeds.device)
         bg.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
         sizes = [g.n for g in graph_train_list]
         out = self.ent_encoder(bg, [int(t) for t in t_list], sizes)
+        self._last_rows = out.ndata['h']                      # the unsplit (sum n_b, D) rows (the fused loss consumes them whole)
         return out.ndata['h'].split(sizes)
 
     def get_all_embeds_Gt(self, t, g, convoluted_embeds):
@@ -75,12 +80,50 @@ class StaticRGCN(TKG_Module):
         ranks = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
         return ranks, (float(np.mean(losses)) if losses else float("nan"))
 
+    def _fused_loss_ok(self):
+        return (self.use_device_sampler and self.fused_loss and self.args.score_function in ("distmult", "complex")
+                and not self.ent_encoder.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
+                and self.num_ents % 4 == 0)
+
+    def _fused_forward(self, ts, g_list, out):
+        """All windows' losses as ONE fused node (functional.batched_link_prediction), like the recurrent models: the isolated
+        pass RGCN.forward_isolated(ent_embeds) does not depend on the window (no time embedding), so it runs once; every
+        window's all-entity matrix is [its graph's rows ; the table] through one static row map; positives / operand
+        indices / known-true slices are planned on the host and the negatives of all graphs come from one launch."""
+        from .backend import get_backend
+        from .sampling import TrueSetStore, plan_batch_loss
+        dev = self.ent_embeds.device
+        N, B = self.num_ents, len(g_list)
+        sizes = [g.n for g in g_list]
+        n_out = int(sum(sizes))
+        off_out = np.concatenate([[0], np.cumsum(sizes)])
+        asm = np.broadcast_to(n_out + np.arange(N, dtype=np.int64)[None, :], (B, N)).copy()
+        for b, g in enumerate(g_list):
+            asm[b, g.gids] = off_out[b] + np.arange(g.n)
+        store = getattr(self, "_true_store", None)
+        if store is None or store.device != dev:
+            store = self._true_store = TrueSetStore(self.graph_dict_train, N, dev)
+        plan = plan_batch_loss(store, ts, g_list, off_out[:-1], self.args.num_pos_facts, self.sample_rng, n_out, int(self.rel_embeds.shape[0]), dev)
+        if plan is None:
+            return out.sum() * 0.0
+        table = self.ent_encoder.forward_isolated(self.ent_embeds, ts[0])
+        big = TF.gather_rows(torch.cat([out, table], dim=0), _lib.to_device(asm.reshape(-1).astype(np.int32), dev),
+                             TF.gather_inverse(asm.reshape(-1), n_out + N, dev))
+        cand = get_backend().corrupt_sample(int(self.seed_rng.integers(1 << 62)), plan["truth"], plan["lo"], plan["hi"], plan["ids"],
+                                            self.args.negative_rate, N)
+        self._last_plan = (plan, cand)
+        return self.batched_link_prediction(out, dict(plan, cand=cand), big.view(B, N, big.shape[1]))
+
     def forward(self, t_list, target_edge_ids=None, samples=None):
         """baselines/StaticRGCN.py:36-46."""
         dev = self.ent_embeds.device
         ts = [int(t) for t in t_list]
         g_list = [self.graph_dict_train[t] for t in ts]
         per_graph = self.get_per_graph_ent_embeds(ts, g_list, edge_ids=target_edge_ids)
+        if samples is None and self._fused_loss_ok():
+            fused = self._fused_forward(ts, g_list, self._last_rows)
+            if fused is not None:
+                return fused
         loss = 0
         for i, (t, g, ent_embed) in enumerate(zip(ts, g_list, per_graph)):
             if samples is not None:

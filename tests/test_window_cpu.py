@@ -314,3 +314,32 @@ def test_planned_loss_equals_injected_samples(name):
     assert abs(loss1.item() - loss2.item()) < 1e-5 * max(1.0, abs(loss2.item()))
     loss1.backward()
     assert torch.isfinite(m.ent_embeds.grad).all() and m.rel_embeds.grad.abs().sum() > 0
+
+
+def test_static_rgcn_fused_loss_equals_per_graph_path():
+    """StaticRGCN.forward: the fused all-window loss (shared isolated table, planned positives, one sampler call) equals the
+    reference-shaped per-graph loop fed with the same target-edge subsample and the same candidates; gradients too."""
+    from temp_amd.static_rgcn import StaticRGCN
+    from tests.window_cases import make_args
+    s = slice_snapshots()
+    args = make_args(module="SRGCN", embed_size=16, hidden_size=16, n_bases=4, negative_rate=20, num_pos_facts=30)
+    torch.manual_seed(2)
+    m = StaticRGCN(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
+    tl = [s["times"][i] for i in (3, 9, 17)]
+    rng = np.random.default_rng(1)
+    edge_ids = [rng.choice(s["tr"][t].number_of_edges(), size=s["tr"][t].number_of_edges() // 2, replace=False) for t in tl]
+    loss1 = m(torch.tensor(tl), target_edge_ids=edge_ids)
+    plan, cand = m._last_plan
+    loss1.backward()
+    g1 = (m.ent_embeds.grad.clone(), m.rel_embeds.grad.clone(), m.ent_encoder.layer_1.weight.grad.clone())
+    samples = []
+    for trip, (a0, _) in zip(plan["triples"], plan["splits"]):
+        P = trip.shape[0]
+        samples.append((torch.from_numpy(trip), cand[a0:a0 + P].long(), cand[a0 + P:a0 + 2 * P].long()))
+    for p in m.parameters():
+        p.grad = None
+    loss2 = m(torch.tensor(tl), target_edge_ids=edge_ids, samples=samples)
+    loss2.backward()
+    assert abs(loss1.item() - loss2.item()) < 1e-5 * max(1.0, abs(loss2.item()))
+    for a, b in zip(g1, (m.ent_embeds.grad, m.rel_embeds.grad, m.ent_encoder.layer_1.weight.grad)):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
