@@ -310,12 +310,6 @@ def history_attention(qkv, kv_hist, idx, decay=None, inverse=None):
 
 def attention_inverse(idx_np, n_table, device):
     """(inv_ptr int32 [n_table+1], inv_ref int32): the (query row, position) pairs of idx (n, T-1) grouped by the table
-    row they point at; ref = i * (T-1) + t."""
+    row they point at; ref = i * (T-1) + t.  Same stable counting sort as gather_inverse, over the flattened index matrix."""
     import numpy as np
-    idx_np = np.asarray(idx_np, dtype=np.int64)
-    flat = idx_np.reshape(-1)
-    pos = np.nonzero(flat >= 0)[0]
-    order = pos[np.argsort(flat[pos], kind="stable")]
-    counts = np.bincount(flat[pos], minlength=n_table)
-    ptr = np.concatenate([[0], np.cumsum(counts)])
-    return (_lib.to_device(ptr.astype(np.int32), device), _lib.to_device(order.astype(np.int32), device))
+    return gather_inverse(np.asarray(idx_np).reshape(-1), n_table, device)
