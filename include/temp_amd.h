@@ -244,6 +244,8 @@ typedef struct TempGruCellBwd {
   int32_t n; const float* saved; const float* dh_up /*nullable*/; const float* d_prev_next /*nullable*/;
   const int32_t* next_idx /*nullable*/; const float* dt; const float* w_hh;
   float* dgi; float* dgh; float* decv; float* d_prev;
+  int32_t no_prev;   /* != 0: the cell started from a zero state (first position of a chain): nothing consumes d_prev, so its
+                        GEMM is skipped and d_prev is left holding only the gate kernel's seed */
 } TempGruCellBwd;
 int temp_gru_cell_fwd_multi(int count, const TempGruCellFwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream);
 int temp_gru_cell_bwd_multi(int count, const TempGruCellBwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream);

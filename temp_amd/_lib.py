@@ -39,7 +39,7 @@ class TempGruCellFwd(ctypes.Structure):
 
 class TempGruCellBwd(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("saved", c_vp), ("dh_up", c_vp), ("d_prev_next", c_vp), ("next_idx", c_vp), ("dt", c_vp),
-                ("w_hh", c_vp), ("dgi", c_vp), ("dgh", c_vp), ("decv", c_vp), ("d_prev", c_vp)]
+                ("w_hh", c_vp), ("dgi", c_vp), ("dgh", c_vp), ("decv", c_vp), ("d_prev", c_vp), ("no_prev", ctypes.c_int32)]
 
 
 class TempDropout(ctypes.Structure):

@@ -238,6 +238,7 @@ class HipBackend:
             a.dh_up, a.d_prev_next, a.next_idx = opt(c["dh_up"]), opt(c["d_prev_next"]), opt(nidx)
             a.dt, a.w_hh = dt.data_ptr(), w_hh.data_ptr()
             a.dgi, a.dgh, a.decv, a.d_prev = c["dgi"].data_ptr(), c["dgh"].data_ptr(), c["decv"].data_ptr(), c["d_prev"].data_ptr()
+            a.no_prev = 1 if c.get("no_prev") else 0
         rc = self.lib.temp_gru_cell_bwd_multi(len(cells), arr, d, variant, float(lam), saved_all.shape[1] * d, _stream())
         _lib.check(rc, "temp_gru_cell_bwd_multi")
 

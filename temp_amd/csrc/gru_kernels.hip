@@ -688,7 +688,7 @@ int temp_gru_cell_bwd_multi(int count, const TempGruCellBwd* cells, int d, int v
     if (c.n > 0 && (!c.saved || !c.dt || !c.dgi || !c.dgh || !c.decv || !c.d_prev)) return TEMP_E_BADARG;
     if (c.next_idx && !c.d_prev_next) return TEMP_E_BADARG;
     gb.c[i] = GruGatesCell{c.n, c.saved, c.dh_up, c.d_prev_next, c.next_idx, c.dt, c.dgi, c.dgh, c.decv, c.d_prev};
-    pb.p[i] = PanelProblem<EpiGruDprev>{c.n, c.dgh, nullptr, c.w_hh, EpiGruDprev{c.decv, c.d_prev, d}};
+    pb.p[i] = PanelProblem<EpiGruDprev>{c.no_prev ? 0 : c.n, c.dgh, nullptr, c.w_hh, EpiGruDprev{c.decv, c.d_prev, d}};
   }
   int rc = launch_gru_gates_batch(gb, count, d, variant, saved_plane, lambda, nullptr, st);
   if (rc) return rc;

@@ -175,7 +175,7 @@ class _GruChainFn(torch.autograd.Function):
                 sl = slice(it.h0, it.h0 + it.n)
                 cells.append(dict(row0=it.h0, n=it.n, dh_up=up(i, it), d_prev_next=d_prev[nxt.h0:nxt.h0 + nxt.n] if nxt is not None else None,
                                   next_idx=ni if nxt is not None else None, dt=dt, w_hh=W[it.rnn][1], dgi=dgi[sl], dgh=dgh[sl],
-                                  decv=decv[sl], d_prev=d_prev[sl]))
+                                  decv=decv[sl], d_prev=d_prev[sl], no_prev=it.prev < 0))
             be.gru_cell_bwd_multi(cells, lam, variant, saved)
         d_x_all = torch.empty_like(x_all)
         written = np.zeros(x_all.shape[0], dtype=bool)
