@@ -237,7 +237,8 @@ int temp_gru_cell_bwd(int n, int d, int variant, const float* saved, size_t save
 /* Several independent cells in ONE launch each (forward chain and backward chain of the bidirectional
  * window advance position by position together; count <= 4; arrays are HOST arrays of structs). */
 typedef struct TempGruCellFwd {
-  int32_t n; const float* gi; const float* prev; const int32_t* prev_idx /*nullable*/; const float* dt;
+  int32_t n; const float* gi; const float* prev /* NULL: the cell starts from the zero state (pointwise, no GEMM) */;
+  const int32_t* prev_idx /*nullable*/; const float* dt;
   const float* w_hh; const float* b_hh; float* h_out; float* saved /* first row of the cell inside the [5, N, d] planes */;
 } TempGruCellFwd;
 typedef struct TempGruCellBwd {

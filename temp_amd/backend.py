@@ -218,7 +218,8 @@ class HipBackend:
             w_hh, b_hh = _f32(c["w_hh"], "w_hh"), _f32(c["b_hh"], "b_hh")
             keep += [prev, pidx, dt, w_hh, b_hh]
             a.n = c["h_out"].shape[0]
-            a.gi, a.prev, a.prev_idx, a.dt = c["gi"].data_ptr(), prev.data_ptr(), (pidx.data_ptr() if pidx is not None else None), dt.data_ptr()
+            a.gi, a.prev = c["gi"].data_ptr(), (prev.data_ptr() if prev is not None else None)      # prev None: zero-state cell
+            a.prev_idx, a.dt = (pidx.data_ptr() if pidx is not None else None), dt.data_ptr()
             a.w_hh, a.b_hh, a.h_out = w_hh.data_ptr(), b_hh.data_ptr(), c["h_out"].data_ptr()
             a.saved = saved_all.data_ptr() + 4 * c["row0"] * d
         rc = self.lib.temp_gru_cell_fwd_multi(len(cells), arr, d, variant, float(lam), saved_all.shape[1] * d, _stream())

@@ -341,6 +341,46 @@ struct EpiGruCell {
   }
 };
 
+// A cell that starts from the zero state (first position of a chain, the once-per-entity rows of the all-entity pass):
+// prev . W_hh^T = 0, so the whole cell is pointwise in the hoisted input gates and b_hh -- no GEMM.  Same outputs as
+// EpiGruCell with acc = 0, hdec = 0 (saved planes r, z, n, b_hn, 0).
+struct GruZeroCell { int n; const float* gi; const float* b_hh; float* h_out; float* saved; };
+struct GruZeroBatch { GruZeroCell c[GRU_MAXP]; };
+
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_gru_fwd_zero(GruZeroBatch batch, int D, size_t plane) {
+  const GruZeroCell& cell = batch.c[blockIdx.y];
+  const int d4 = D / 4;
+  const int G = (VARIANT == TEMP_GRU_TORCH) ? 3 * D : D;
+  const size_t total = (size_t)cell.n * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / d4;
+    const int col = (int)(i - row * d4) * 4;
+    const float* g = cell.gi + row * G + col;
+    float4 g0 = zero4(), g1 = zero4(), g2;
+    if (VARIANT == TEMP_GRU_TORCH) { g0 = ld4(g); g1 = ld4(g + D); g2 = ld4(g + 2 * D); } else { g2 = ld4(g); }
+    const float4 bhr = ld4(cell.b_hh + col), bhz = ld4(cell.b_hh + D + col), bhn = ld4(cell.b_hh + 2 * D + col);
+    const float g0v[4] = {g0.x, g0.y, g0.z, g0.w}, g1v[4] = {g1.x, g1.y, g1.z, g1.w}, g2v[4] = {g2.x, g2.y, g2.z, g2.w};
+    const float brv[4] = {bhr.x, bhr.y, bhr.z, bhr.w}, bzv[4] = {bhz.x, bhz.y, bhz.z, bhz.w}, bnv[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
+    float o_h[4], o_r[4], o_z[4], o_n[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float rg = gate_sigmoid(g0v[e] + brv[e]);
+      const float zg = gate_sigmoid(g1v[e] + bzv[e]);
+      const float ng = gate_tanh(g2v[e] + rg * bnv[e]);
+      o_h[e] = (VARIANT == TEMP_GRU_TORCH) ? (1.f - zg) * ng : (ng - zg * ng);
+      o_r[e] = rg; o_z[e] = zg; o_n[e] = ng;
+    }
+    const size_t o = row * D + col;
+    st4(cell.h_out + o, make_float4(o_h[0], o_h[1], o_h[2], o_h[3]));
+    st4(cell.saved + o, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
+    st4(cell.saved + plane + o, make_float4(o_z[0], o_z[1], o_z[2], o_z[3]));
+    st4(cell.saved + 2 * plane + o, make_float4(o_n[0], o_n[1], o_n[2], o_n[3]));
+    st4(cell.saved + 3 * plane + o, bhn);
+    st4(cell.saved + 4 * plane + o, zero4());
+  }
+}
+
 template <int VARIANT>
 static int launch_gru_fwd_wres(const GruFwdBatch& batch, int count, int d, float lambda, const float* decay_wb, size_t plane, hipStream_t st) {
   typedef EpiGruCell<VARIANT> Epi;
@@ -665,13 +705,29 @@ int temp_gru_cell_fwd_multi(int count, const TempGruCellFwd* cells, int d, int v
   if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
   GruFwdBatch batch = {};
+  GruZeroBatch zb = {};
+  int n_gemm = 0, n_zero = 0, max_zero = 0;
   for (int i = 0; i < count; ++i) {
     const TempGruCellFwd& c = cells[i];
     if (c.n < 0 || !c.w_hh || !c.b_hh) return TEMP_E_BADARG;
-    if (c.n > 0 && (!c.gi || !c.prev || !c.dt || !c.h_out || !c.saved || saved_plane < (size_t)c.n * d)) return TEMP_E_BADARG;
-    batch.c[i] = GruFwdCell{c.n, nullptr, c.gi, c.prev, c.prev_idx, c.dt, nullptr, c.w_hh, nullptr, c.b_hh, c.h_out, c.saved};
+    if (c.n > 0 && (!c.gi || !c.dt || !c.h_out || !c.saved || saved_plane < (size_t)c.n * d)) return TEMP_E_BADARG;
+    if (!c.prev) {                                    // zero previous state: pointwise cell, no GEMM
+      if (c.n > 0) { zb.c[n_zero++] = GruZeroCell{c.n, c.gi, c.b_hh, c.h_out, c.saved}; if (c.n > max_zero) max_zero = c.n; }
+      continue;
+    }
+    batch.c[n_gemm++] = GruFwdCell{c.n, nullptr, c.gi, c.prev, c.prev_idx, c.dt, nullptr, c.w_hh, nullptr, c.b_hh, c.h_out, c.saved};
   }
-  return launch_gru_fwd_batch(batch, count, d, variant, true, lambda, nullptr, saved_plane, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_zero) {
+    int gx = ceil_div((long long)max_zero * (d / 4), 256);
+    if (gx > 2048) gx = 2048;
+    if (variant == TEMP_GRU_TORCH) TEMP_LAUNCH(K_GRU_FWD, k_gru_fwd_zero<TEMP_GRU_TORCH>, dim3(gx, n_zero), dim3(256), 0, st, zb, d, saved_plane);
+    else TEMP_LAUNCH(K_GRU_FWD, k_gru_fwd_zero<TEMP_GRU_TYPE1>, dim3(gx, n_zero), dim3(256), 0, st, zb, d, saved_plane);
+    const int rc = launch_status();
+    if (rc) return rc;
+  }
+  if (!n_gemm) return TEMP_OK;
+  return launch_gru_fwd_batch(batch, n_gemm, d, variant, true, lambda, nullptr, saved_plane, st);
 }
 
 int temp_gru_cell_bwd_multi(int count, const TempGruCellBwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream) {

@@ -134,8 +134,8 @@ class _GruChainFn(torch.autograd.Function):
                 if it.prev >= 0:
                     p = prog.inst[it.prev]
                     prev, pidx = H[p.h0:p.h0 + p.n], pi
-                else:                                 # no history yet: every previous state is zero
-                    prev, pidx = zero, none_idx[:it.n]
+                else:                                 # no history yet: every previous state is zero (pointwise cell)
+                    prev, pidx = None, none_idx[:it.n]
                 cells.append(dict(gi=gi[it.h0:it.h0 + it.n], prev=prev, prev_idx=pidx, dt=dt, w_hh=w_hh, b_hh=b_hh,
                                   h_out=H[it.h0:it.h0 + it.n], row0=it.h0))
             be.gru_cell_fwd_multi(cells, lam, variant, saved)

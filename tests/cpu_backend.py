@@ -194,6 +194,8 @@ class CpuTestBackend:
 
     def gru_cell_fwd(self, gi, prev, prev_idx, dt, lam, w_hh, b_hh, variant, h_out, saved_all, row0):
         n, d = h_out.shape
+        if prev is None:                                        # zero-state cell
+            prev, prev_idx = torch.zeros(n, d), None
         prev, w_hh, b_hh = prev.detach(), w_hh.detach(), b_hh.detach()
         if prev_idx is not None:
             idx = prev_idx.long()
