@@ -251,6 +251,7 @@ typedef struct TempGruCellBwd {
 int temp_gru_cell_fwd_multi(int count, const TempGruCellFwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream);
 int temp_gru_cell_bwd_multi(int count, const TempGruCellBwd* cells, int d, int variant, float lambda, size_t saved_plane, void* stream);
 size_t temp_gru_weight_grads_workspace(int n, int d, int variant);
+/* hdec may be NULL when every row started from the zero state (d_w_hh = 0, d_b_hh = column sums of dgh). */
 int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float* hdec, const float* dgi, const float* dgh,
                           const float* w_ih, float* d_x /*nullable*/, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh,
                           void* workspace, size_t workspace_bytes, void* stream);

@@ -619,12 +619,18 @@ static int gru_weight_grads(int n, int d, int variant, const float* x, const flo
   const bool fuse = gemm_tn_can_fuse_bias(d);      // bias gradients ride along as a ones column of the TN GEMM
   rc = gemm_tn(n, gi_w, d, dgi, gi_w, x, d, d_w_ih, d, tn, tn_bytes, st, fuse ? d_b_ih : nullptr);
   if (rc) return rc;
-  rc = gemm_tn(n, 3 * d, d, dgh, 3 * d, hdec, d, d_w_hh, d, tn, tn_bytes, st, fuse ? d_b_hh : nullptr);
-  if (rc) return rc;
+  if (hdec) {
+    rc = gemm_tn(n, 3 * d, d, dgh, 3 * d, hdec, d, d_w_hh, d, tn, tn_bytes, st, fuse ? d_b_hh : nullptr);
+    if (rc) return rc;
+  } else {                         // every row started from the zero state: hdec = 0, so d_W_hh = 0 and only the bias needs dgh
+    if (hipMemsetAsync(d_w_hh, 0, (size_t)3 * d * d * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    rc = colsum(n, 3 * d, dgh, 3 * d, d_b_hh, cs, cs_bytes, st);
+    if (rc) return rc;
+  }
   if (fuse) return TEMP_OK;
   rc = colsum(n, gi_w, dgi, gi_w, d_b_ih, cs, cs_bytes, st);
   if (rc) return rc;
-  return colsum(n, 3 * d, dgh, 3 * d, d_b_hh, cs, cs_bytes, st);
+  return hdec ? colsum(n, 3 * d, dgh, 3 * d, d_b_hh, cs, cs_bytes, st) : TEMP_OK;
 }
 
 int temp_gru_bwd(int n, int d, int variant, const float* x, const float* prev, const int32_t* prev_idx, const float* dt, float lambda,
@@ -764,7 +770,7 @@ int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float
                           size_t workspace_bytes, void* stream) {
   if (n < 0 || d <= 0 || !w_ih || !d_w_ih || !d_w_hh || !d_b_ih || !d_b_hh) return TEMP_E_BADARG;
   if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
-  if (n > 0 && (!x || !hdec || !dgi || !dgh)) return TEMP_E_BADARG;
+  if (n > 0 && (!x || !dgi || !dgh)) return TEMP_E_BADARG;          // hdec NULL: all rows started from the zero state
   if (d % 4) return TEMP_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < temp_gru_weight_grads_workspace(n, d, variant)) return TEMP_E_WORKSPACE;
   const int gi_w = (variant == TEMP_GRU_TORCH) ? 3 * d : d;

@@ -21,7 +21,7 @@ from . import _hostlib
 from . import snapshot as S
 from .rrgcn import RRGCN, GRRGCNLayer, run_rnn
 from .tkg_module import TKG_Module
-from .gru_chain import GruInstance, GruProgram, gru_chain
+from .gru_chain import GruInstance, GruProgram, gru_chain, zero_state_program
 from .gru_cell import GRUCell
 from .window import ChainPlan, Step, concat_steps, concat_steps_dedup, window_times
 
@@ -413,6 +413,19 @@ class DynamicRGCN(TKG_Module):
         return (plain and self.use_batched_path and not isinstance(wb.plan, tuple) and isinstance(enc.layer_1, GRRGCNLayer)
                 and isinstance(enc.layer_2, GRRGCNLayer) and not (enc.layer_1._extra() or enc.layer_2._extra()))
 
+    def _zero_state_rows(self, rnn, x, layer):
+        """GRU(x, 0) over all rows of x: input-gate GEMM + pointwise cell (gru_chain.zero_state_program); the general
+        single-step kernel would still run its recurrent GEMM and d_prev / d_W_hh products on zeros."""
+        if getattr(rnn, "num_layers", 1) != 1:
+            N = x.shape[0]
+            return run_rnn(rnn, x, x.new_zeros(1, x.shape[1]), x.new_zeros(N, 1), layer.inv_temperature, layer.decay_spec(),
+                           torch.full((N,), -1, dtype=torch.int32, device=x.device))
+        progs = self.__dict__.setdefault("_zero_progs", {})
+        prog = progs.get(x.shape[0])
+        if prog is None:
+            prog = progs[x.shape[0]] = zero_state_program(x.shape[0])
+        return gru_chain(x, prog, [rnn], layer.inv_temperature, isinstance(rnn, GRUCell), want=[0])[0]
+
     def all_embeds_batched(self, wb, out, hist):
         """get_all_embeds_Gt for ALL windows at once (models/DynamicRGCN.py:56-64; Bi: models/BiDynamicRGCN.py:102-112,
         models/BiRRGCN.py:65-82).  The isolated RGCN trunk e -> Iso2(Iso1(e)) does not depend on the window, so it runs ONCE
@@ -428,10 +441,7 @@ class DynamicRGCN(TKG_Module):
             return TF.gather_rows(out, maps[0]["asm"], maps[0]["asm_inv"]).view(B, N, out.shape[1])
         l1_rec = isinstance(l1, GRRGCNLayer)
         iso1 = l1.conv_isolated(self.ent_embeds)
-        zero = iso1.new_zeros(1, iso1.shape[1])
-        dt0 = iso1.new_zeros(N, 1)
-        none = torch.full((N,), -1, dtype=torch.int32, device=iso1.device)
-        t1 = run_rnn(l1.rnn, iso1, zero, dt0, l1.inv_temperature, l1.decay_spec(), none) if l1_rec else iso1
+        t1 = self._zero_state_rows(l1.rnn, iso1, l1) if l1_rec else iso1
         x = l2.conv_isolated(t1)
         lam, dec = l2.inv_temperature, l2.decay_spec()
         big = None
@@ -444,7 +454,7 @@ class DynamicRGCN(TKG_Module):
                 else:
                     xp = TF.gather_rows(x, m["ent"], m["ent_inv"])
                 parts.append(run_rnn(rnn, xp, H, m["dt"], lam, dec, m["idx"]))
-            parts.append(run_rnn(rnn, x, zero, dt0, lam, dec, none))             # GRU(x_e, 0): one row per entity, every window
+            parts.append(self._zero_state_rows(rnn, x, l2))                      # GRU(x_e, 0): one row per entity, every window
             g = TF.gather_rows(torch.cat(parts, dim=0), m["asm"], m["asm_inv"])
             big = g if big is None else big + g
         return big.view(B, N, big.shape[1])

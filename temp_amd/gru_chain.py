@@ -185,7 +185,8 @@ class _GruChainFn(torch.autograd.Function):
             first = not written[xs].any()
             assert first or written[xs].all()
             tgt = d_x_all[xs] if first else torch.empty(g["x1"] - g["x0"], d, dtype=torch.float32, device=dev)
-            gw = be.gru_weight_grads(x_all[xs], saved[4, hs], dgi[hs], dgh[hs], W[g["rnn"]][0], variant, tgt)
+            zero_state = all(it.prev < 0 for it in prog.inst if it.group == prog.groups.index(g))     # hdec = 0 on every row
+            gw = be.gru_weight_grads(x_all[xs], None if zero_state else saved[4, hs], dgi[hs], dgh[hs], W[g["rnn"]][0], variant, tgt)
             if not first:
                 d_x_all[xs] += tgt
             written[xs] = True
@@ -195,6 +196,12 @@ class _GruChainFn(torch.autograd.Function):
         if not written.all():
             d_x_all[torch.from_numpy(~written).to(dev)] = 0
         return (d_x_all, None, None, None, None, None) + tuple(grads)
+
+
+def zero_state_program(n):
+    """Program of ONE cell over n rows that starts from the zero state (GRU(x, 0): the once-per-entity rows of the all-entity
+    pass): hoisted input-gate GEMM + pointwise cell forward; gate gradients, d_x and d_W_ih backward -- no recurrent GEMM."""
+    return GruProgram([GruInstance(n, 0, 0, -1, np.full(n, -1, dtype=np.int32), np.zeros(n, dtype=np.float32))])
 
 
 def gru_chain(x_all, prog, rnns, lam, type1=False, want=None):

@@ -246,7 +246,8 @@ class CpuTestBackend:
     def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
         if d_x is not None:
             d_x.copy_(torch.mm(dgi, w_ih.detach()))
-        return torch.mm(dgi.t(), x.detach()), torch.mm(dgh.t(), hdec), dgi.sum(0), dgh.sum(0)
+        d_w_hh = torch.mm(dgh.t(), hdec) if hdec is not None else torch.zeros(dgh.shape[1], x.shape[1])
+        return torch.mm(dgi.t(), x.detach()), d_w_hh, dgi.sum(0), dgh.sum(0)
 
     # ---- plain GEMMs + candidate cross-entropy ------------------------------------------------
     def linear(self, a, b, trans_b):
