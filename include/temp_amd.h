@@ -284,6 +284,10 @@ int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, 
  * K, N, Ka, Nb and all leading dimensions must be multiples of 4.
  * ---------------------------------------------------------------------------------------------- */
 int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, void* stream);
+/* Same product, result stored TRANSPOSED: Ct[N, ldct] with Ct[n, m] = (A . B)[m, n]  (ldct >= M).  For "few rows x many columns"
+ * outputs -- a window's ~200 positives scored against 10 000 entities -- the entity axis is made the tall one:
+ * scores[P, N_ents] = temp_linear_t(M = N_ents, N = P, A = all_embeds, B = queries (trans_b = 1), Ct = scores). */
+int temp_linear_t(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* Ct, int ldct, void* stream);
 /* Several independent products of the same shape class in ONE launch sequence (up to 4 problems per launch):
  *   C_i[M_i, N] = A_i[M_i, K] . B_i        same N, K, leading dimensions and transposition; M_i may differ.
  * The per-window score matrices of the loss (every window scores against its own all-entity table) and their

@@ -49,9 +49,11 @@ int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* 
  * 2 P_g rows [tail-corruption rows ; head-corruption rows] are appended to six int32 vectors of length R = 2 sum P_g
  * (packed[6][R]: known row, relation, is_tail, true entity (global id), lo, hi of the known-true slice) and weights[R] = 1/P_g;
  * triples[sum P_g][3] (local src, rel, dst) in graph order.
- *   graph_ptrs[g][8] = { src, rel, dst, gids (int64 arrays) , tail_lo, tail_hi, head_lo, head_hi (int32 arrays, per edge) } */
+ *   graph_ptrs[g][8] = { src, rel, dst, gids (int64 arrays) , tail_lo, tail_hi, head_lo, head_hi (int32 arrays, per edge) }
+ * pad4 != 0: every graph's block of 2 P_g rows is rounded up to a multiple of 4 rows with weight-0 rows (known = the graph's
+ * first row, relation 0, empty known-true slice), so a block can be the N or K extent of an MFMA GEMM; R counts the padding. */
 int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* const* idx, const int64_t* n_pos, const int64_t* row_offset,
-                        int64_t R, int32_t* packed, float* weights, int64_t* triples);
+                        int pad4, int64_t R, int32_t* packed, float* weights, int64_t* triples);
 
 /* All three edge views of ONE snapshot (by destination, by source: chunk; by relation: chunk_rel) in the packed int32 layout
  * the device-side snapshot store keeps per snapshot:

@@ -18,7 +18,7 @@ _I64 = ctypes.c_int64
 SYMBOLS = {
     "temp_host_abi_version": (ctypes.c_int, []),
     "temp_host_build_view": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "temp_host_plan_loss": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "temp_host_plan_loss": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, ctypes.c_int, _I64, _P, _P, _P]),
     "temp_host_snapshot_pack": (_I64, [_I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "temp_host_union_plan": (_I64, [_I64, _I64, _P, _P, _P, _I64, _P, _I64, _P]),
     "temp_host_sample_subset": (ctypes.c_int, [_I64, _I64, ctypes.c_uint64, _P]),
@@ -103,24 +103,25 @@ def chain_plan(bsz, num_ents, positions, n_win, gid_arrays):
     return prev_idx[:total], next_idx[:total], dt[:total], row_of, last
 
 
-def plan_loss(graph_ptrs, idx_list, row_offsets):
+def plan_loss(graph_ptrs, idx_list, row_offsets, pad4=True):
     """See temp_host_plan_loss.  graph_ptrs: (G, 8) int64 addresses; idx_list: G int64 arrays of chosen edge ids.
-    -> (packed int32 [6, R], weights float32 [R], triples int64 [sum P, 3])"""
+    -> (packed int32 [6, R], weights float32 [R], triples int64 [sum P, 3], n_pos, rows per graph incl. padding)"""
     G = len(idx_list)
     idx_list = [_i64(x) for x in idx_list]
     n_pos = np.array([x.shape[0] for x in idx_list], dtype=np.int64)
-    R = int(2 * n_pos.sum())
+    block = 2 * n_pos + (((4 - (2 * n_pos) % 4) % 4) if pad4 else 0) * (n_pos > 0)
+    R = int(block.sum())
     packed = np.empty((6, max(R, 1)), np.int32)
     weights = np.empty(max(R, 1), np.float32)
-    triples = np.empty((max(R // 2, 1), 3), np.int64)
+    triples = np.empty((max(int(n_pos.sum()), 1), 3), np.int64)
     ptrs = np.array([x.ctypes.data for x in idx_list], dtype=np.int64) if G else np.zeros(1, np.int64)
     gp = np.ascontiguousarray(graph_ptrs, dtype=np.int64) if G else np.zeros((1, 8), np.int64)
     ro = _i64(row_offsets) if G else np.zeros(1, np.int64)
-    rc = load().temp_host_plan_loss(G, gp.ctypes.data, ptrs.ctypes.data, n_pos.ctypes.data, ro.ctypes.data, R, packed.ctypes.data,
-                                    weights.ctypes.data, triples.ctypes.data)
+    rc = load().temp_host_plan_loss(G, gp.ctypes.data, ptrs.ctypes.data, n_pos.ctypes.data, ro.ctypes.data, 1 if pad4 else 0, R,
+                                    packed.ctypes.data, weights.ctypes.data, triples.ctypes.data)
     if rc != 0:
         raise ValueError("temp_host_plan_loss: bad argument (code %d)" % rc)
-    return packed[:, :R], weights[:R], triples[:R // 2], n_pos
+    return packed[:, :R], weights[:R], triples[:int(n_pos.sum())], n_pos, block
 
 
 def gather_inverse(idx, n_rows):

@@ -268,6 +268,17 @@ class HipBackend:
         _lib.check(rc, "temp_linear")
         return c
 
+    def linear_t(self, a, b, trans_b, out_t):
+        """out_t[N, M] = (a[M,K] . b)^T written into the contiguous matrix `out_t` (b is [K,N], or [N,K] when trans_b)."""
+        a, b = _f32(a, "a"), _f32(b, "b")
+        M, K = a.shape
+        N = b.shape[0] if trans_b else b.shape[1]
+        if out_t.shape != (N, M) or not out_t.is_contiguous() or out_t.dtype != torch.float32:
+            raise ValueError("linear_t: out_t must be a contiguous float32 (N, M) matrix")
+        rc = self.lib.temp_linear_t(M, N, K, _ptr(a), K, _ptr(b), b.shape[1], int(trans_b), _ptr(out_t), M, _stream())
+        _lib.check(rc, "temp_linear_t")
+        return out_t
+
     def linear_multi(self, a_list, b_list, trans_b, out):
         """out rows [r_i, r_i + M_i) = a_i[M_i,K] . b_i  for every problem i, r_i = running row offset: the per-window
         products of the loss in ceil(count / 4) launches.  `out` is a preallocated (sum M_i, N) matrix."""

@@ -992,6 +992,24 @@ struct EpiPlainStore {
   __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const { st4(out + (size_t)row * ldo + col, acc); }
 };
 
+// C^T written: out[col * ldo + row].  A lane of the weights-resident kernel owns one row and four consecutive columns, so for a
+// fixed column the 32 lanes of a half-wave write 32 consecutive floats: coalesced 128-B segments.
+struct EpiPlainStoreT {
+  float* out; int ldo;
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
+  __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
+  __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const {
+    float* o = out + (size_t)col * ldo + row;
+    o[0] = acc.x; o[ldo] = acc.y; o[2 * (size_t)ldo] = acc.z; o[3 * (size_t)ldo] = acc.w;
+  }
+};
+
+int temp_linear_t(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* Ct, int ldct, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || !B || (M > 0 && (!A || !Ct)) || ldct < M) return TEMP_E_BADARG;
+  return launch_gemm_panel(K_GEMM_LINEAR, M, N, K, A, lda, nullptr, B, ldb, trans_b, EpiPlainStoreT{Ct, ldct}, (hipStream_t)stream);
+}
+
 int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !B || (M > 0 && (!A || !C))) return TEMP_E_BADARG;
   if (ldc % 4) return TEMP_E_UNSUPPORTED;

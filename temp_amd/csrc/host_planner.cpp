@@ -95,7 +95,7 @@ int temp_host_chain_plan(int bsz, int64_t num_ents, int n_steps, const int32_t* 
 }
 
 int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* const* idx, const int64_t* n_pos, const int64_t* row_offset,
-                        int64_t R, int32_t* packed, float* weights, int64_t* triples) {
+                        int pad4, int64_t R, int32_t* packed, float* weights, int64_t* triples) {
   if (n_graphs < 0 || R < 0 || (n_graphs > 0 && (!graph_ptrs || !idx || !n_pos || !row_offset)) || (R > 0 && (!packed || !weights || !triples))) return 1;
   int32_t* known = packed;
   int32_t* rel_o = packed + R;
@@ -106,7 +106,8 @@ int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* 
   int64_t row = 0, trow = 0;
   for (int g = 0; g < n_graphs; ++g) {
     const int64_t P = n_pos[g];
-    if (P < 0 || row + 2 * P > R) return 2;
+    const int64_t pad = (pad4 && P > 0) ? ((4 - (2 * P) % 4) % 4) : 0;
+    if (P < 0 || row + 2 * P + pad > R) return 2;
     if (P == 0) continue;
     const int64_t* gp = graph_ptrs + (size_t)g * 8;
     const int64_t* src = (const int64_t*)gp[0];
@@ -128,6 +129,9 @@ int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* 
       known[b] = (int32_t)(d + off); rel_o[b] = (int32_t)r; tail[b] = 0; truth[b] = (int32_t)gid[s]; lo[b] = hlo[e]; hi[b] = hhi[e]; weights[b] = w;
     }
     row += 2 * P;
+    for (int64_t i = 0; i < pad; ++i, ++row) {
+      known[row] = (int32_t)off; rel_o[row] = 0; tail[row] = 0; truth[row] = 0; lo[row] = 0; hi[row] = 0; weights[row] = 0.f;
+    }
     trow += P;
   }
   return row == R ? 0 : 3;

@@ -171,11 +171,12 @@ def plan_batch_loss(store, times, graphs, row_offsets, num_pos_facts, rng, n_row
         P = min(E, num_pos_facts)
         idxs.append(_hostlib.sample_subset(E, P, rng) if num_pos_facts < E else np.arange(E, dtype=np.int64))
         ptrs.append(store.snapshot(t)["ptrs"])
-    packed, weights, trip_all, n_pos = _hostlib.plan_loss(np.stack(ptrs) if ptrs else np.zeros((0, 8), np.int64), idxs, np.asarray(row_offsets, dtype=np.int64))
+    packed, weights, trip_all, n_pos, block = _hostlib.plan_loss(np.stack(ptrs) if ptrs else np.zeros((0, 8), np.int64), idxs,
+                                                                 np.asarray(row_offsets, dtype=np.int64))
     if packed.shape[1] == 0:
         return None
-    ends = np.cumsum(2 * n_pos)
-    splits = [(int(e - 2 * p), int(e)) for e, p in zip(ends, n_pos)]
+    ends = np.cumsum(block)                                     # a graph's block = 2 P rows (+ weight-0 padding to a multiple of 4)
+    splits = [(int(e - k), int(e)) for e, k in zip(ends, block)]
     tcut = np.cumsum(n_pos)
     triples = [trip_all[int(e - p):int(e)] for e, p in zip(tcut, n_pos)]
     dev_i = _lib.to_device(packed, device)                       # ONE upload for the six index vectors

@@ -260,6 +260,10 @@ class CpuTestBackend:
             return out
         return r
 
+    def linear_t(self, a, b, trans_b, out_t):
+        out_t.copy_(torch.mm(a.detach(), b.detach().t() if trans_b else b.detach()).t())
+        return out_t
+
     def linear_multi(self, a_list, b_list, trans_b, out):
         row = 0
         for a, b in zip(a_list, b_list):

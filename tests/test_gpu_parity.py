@@ -693,8 +693,8 @@ def test_training_step_with_planned_loss_gpu():
                                            m.args.negative_rate, m.num_ents)
     samples = []
     for b, (a0, a1) in enumerate(plan["splits"]):
-        P = (a1 - a0) // 2
-        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a1].long()))
+        P = plan["triples"][b].shape[0]                          # (a block may end in weight-0 padding rows)
+        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a0 + 2 * P].long()))
     loss2 = m.run_loss(wb, samples)
     assert abs(loss1.item() - loss2.item()) < 2e-5 * max(1.0, abs(loss2.item()))
     loss1.backward()
@@ -719,8 +719,8 @@ def test_full_size_loss_properties_gpu():
     cand = TB.get_backend().corrupt_sample(99, plan["truth"], plan["lo"], plan["hi"], plan["ids"], model.args.negative_rate, model.num_ents)
     samples = []
     for b, (a0, a1) in enumerate(plan["splits"]):
-        P = (a1 - a0) // 2
-        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a1].long()))
+        P = plan["triples"][b].shape[0]                          # (a block may end in weight-0 padding rows)
+        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a0 + 2 * P].long()))
 
     def run(fused):
         model.fused_loss = fused
@@ -738,3 +738,39 @@ def test_full_size_loss_properties_gpu():
     assert abs(a[0].item() - r[0].item()) < 2e-5 * abs(r[0].item())
     assert_close(a[1], r[1], 1e-4, 1e-5 * float(r[1].abs().max()), "d ent_embeds, fused vs reference-shaped loss")
     assert_close(a[2], r[2], 1e-4, 1e-5 * float(r[2].abs().max()), "d rel_embeds, fused vs reference-shaped loss")
+
+
+@pytest.mark.parametrize("M,N,K", [(10488, 184, 200), (7128, 400, 200), (300, 8, 16), (5000, 36, 128)])
+def test_linear_t_transposed_store(M, N, K):
+    """temp_linear_t: (A . B^T)^T written through the transposed-store epilogue == the plain product, transposed."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(DEV)
+    b = torch.randn(N, K, generator=g).to(DEV)
+    out_t = torch.empty(N, M, device=DEV)
+    TB.get_backend().linear_t(a, b, True, out_t)
+    assert_close(out_t, (a.double() @ b.double().t()).t(), 1e-5, 1e-4, "linear_t")
+
+
+def test_fused_loss_entity_major_variant_matches(monkeypatch):
+    """The opt-in entity-major formulation of the fused loss (TEMP_LOSS_TALL=1: scores through temp_linear_t, backward from
+    d_scores^T) equals the default one on an ICEWS-shaped batch."""
+    from temp_amd import functional as TF
+    from tests.window_cases import build_window_model
+    from tests.golden_util import load
+    z = load("G10_bi_grrgcn_rol")
+    m = build_window_model(z, DEV)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    m.sample_rng = np.random.default_rng(3)
+    wb = m.prepare(t_list, int(z["L"]), train=True)
+    res = []
+    for tall in (False, True):
+        monkeypatch.setattr(TF, "_TALL_SCORES", tall)
+        for p in m.parameters():
+            p.grad = None
+        m.seed_rng = np.random.default_rng(7)
+        loss = m.run_loss(wb)
+        loss.backward()
+        res.append((loss.detach().clone(), m.ent_embeds.grad.clone(), m.rel_embeds.grad.clone()))
+    assert abs(res[0][0].item() - res[1][0].item()) < 2e-5 * abs(res[0][0].item())
+    assert_close(res[1][1], res[0][1], 1e-4, 1e-5 * float(res[0][1].abs().max()), "d ent_embeds")
+    assert_close(res[1][2], res[0][2], 1e-4, 1e-5 * float(res[0][2].abs().max()), "d rel_embeds")

@@ -275,7 +275,7 @@ def test_planned_loss_equals_injected_samples(name):
     from tests.window_cases import build_window_model
     z = load(name)
     m = build_window_model(z, torch.device("cpu"))
-    m.args.num_pos_facts = 40                                   # below some graphs' edge counts: exercises the random subset
+    m.args.num_pos_facts = 37                                   # below some graphs' edge counts: random subset; odd: row padding
     t_list = torch.tensor([int(t) for t in z["t_list"]])
     m.sample_rng = np.random.default_rng(3)
     wb = m.prepare(t_list, int(z["L"]), train=True)
@@ -288,7 +288,10 @@ def test_planned_loss_equals_injected_samples(name):
     for b, g in enumerate(wb.graphs):
         trip = plan["triples"][b]
         P = trip.shape[0]
-        assert P == min(g.number_of_edges(), 40) and plan["splits"][b] == (row, row + 2 * P)
+        pad = (-2 * P) % 4                                      # weight-0 rows that round the window's block up to 4 rows
+        assert P == min(g.number_of_edges(), 37) and plan["splits"][b] == (row, row + 2 * P + pad)
+        wts = plan["weights"].numpy()
+        assert (wts[row:row + 2 * P] == np.float32(1.0 / P)).all() and (wts[row + 2 * P:row + 2 * P + pad] == 0).all()
         tails, heads = {}, {}
         for h, r, o in zip(g.src, g.rel, g.dst):
             tails.setdefault((int(h), int(r)), set()).add(int(g.gids[o]))
@@ -296,7 +299,7 @@ def test_planned_loss_equals_injected_samples(name):
         for i, (h, r, o) in enumerate(trip):
             assert set(ids[lo[row + i]:hi[row + i]].tolist()) == tails[(int(h), int(r))] and truth[row + i] == g.gids[o] and is_tail[row + i] == 1
             assert set(ids[lo[row + P + i]:hi[row + P + i]].tolist()) == heads[(int(r), int(o))] and truth[row + P + i] == g.gids[h]
-        row += 2 * P
+        row += 2 * P + pad
     m.seed_rng = np.random.default_rng(7)
     loss1 = m.run_loss(wb)
     m.seed_rng = np.random.default_rng(7)
@@ -308,8 +311,8 @@ def test_planned_loss_equals_injected_samples(name):
         assert not np.isin(cn[r, 1:], ids[lo[r]:hi[r]]).any()
     samples = []
     for b, (a0, a1) in enumerate(plan["splits"]):
-        P = (a1 - a0) // 2
-        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a1].long()))
+        P = plan["triples"][b].shape[0]                          # (a block may end in weight-0 padding rows)
+        samples.append((torch.from_numpy(plan["triples"][b]), cand[a0:a0 + P].long(), cand[a0 + P:a0 + 2 * P].long()))
     loss2 = m.run_loss(wb, samples)
     assert abs(loss1.item() - loss2.item()) < 1e-5 * max(1.0, abs(loss2.item()))
     loss1.backward()
