@@ -225,11 +225,8 @@ class SnapshotShardedEncoder:
         x = y2_all.index_select(0, sb.x_index)
         l2 = enc.layer_2
         rnns = [l2.forward_rnn, l2.backward_rnn] if hasattr(l2, "forward_rnn") else [l2.rnn]
-        H = gru_chain(x, sb.program, rnns, l2.inv_temperature, isinstance(rnns[0], GRUCell))
-        prog = sb.program
+        pieces = gru_chain(x, sb.program, rnns, l2.inv_temperature, isinstance(rnns[0], GRUCell), want=list(sb.out_inst))
         out = None
-        for i in sb.out_inst:
-            it = prog.inst[i]
-            piece = H[it.h0:it.h0 + it.n]
+        for piece in pieces:                          # only the target-position states are consumed (no full-size gradient buffers)
             out = piece if out is None else out + piece
         return out

@@ -16,7 +16,7 @@ wrap(dynamic_rgcn, "concat_steps_dedup"); wrap(snapshot, "union_graph_packed"); 
 wrap(functional, "gather_inverse"); wrap(sampling, "plan_batch_loss"); wrap(gru_chain.GruProgram, "upload", "program.upload")
 wrap(dynamic_rgcn.DynamicRGCN, "sample_target_graphs"); wrap(bi_dynamic_rgcn.BiDynamicRGCN, "_build_program"); wrap(bi_dynamic_rgcn.BiDynamicRGCN, "_bi_target")
 wrap(dynamic_rgcn.DynamicRGCN, "_all_maps"); wrap(dynamic_rgcn.DynamicRGCN, "_upload"); wrap(dynamic_rgcn.DynamicRGCN, "_plan_loss")
-w = synthetic.workload("S-gdelt", seed=0)
+w = synthetic.workload(sys.argv[1] if len(sys.argv) > 1 else "S-gdelt", seed=0)
 dev = torch.device("cuda:0")
 model = bench.build_model(w, dev)
 model.sample_rng = np.random.default_rng(2)
