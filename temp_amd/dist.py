@@ -148,6 +148,7 @@ class SnapshotShardedEncoder:
                 k += 1
         sb = type("ShardBatch", (), {})()
         sb.g_local, sb.ids_local = g_local, torch.from_numpy(g_local.gids.astype(np.int32)).to(dev)
+        sb.ids_inv = TF.gather_inverse(g_local.gids, self.model.num_ents, dev)          # static ids: table layer + deterministic gradient
         sb.n_max, sb.canon_index = n_max, torch.from_numpy(canon_index).to(dev)
         sb.n_edge_visits_local = int(sum(g.number_of_edges() for g in mine))
         sb.n_edge_visits_global = int(sum(g.number_of_edges() for _, _, g in visits))
@@ -209,7 +210,10 @@ class SnapshotShardedEncoder:
         x_rows.append(t_rows)
         sb.program = GruProgram(inst)
         sb.program.upload(dev)
-        sb.x_index = torch.from_numpy(np.concatenate(x_rows) if x_rows else np.zeros(0, np.int64)).to(dev)
+        x_index = np.concatenate(x_rows) if x_rows else np.zeros(0, np.int64)
+        sb.x_index = torch.from_numpy(x_index).to(dev)
+        sb.x_index32 = sb.x_index.to(torch.int32)
+        sb.x_inv = TF.gather_inverse(x_index, int(canon_off[-1]), dev)                      # y2_all has one row per canonical visit row
         sb.out_inst, sb.target_sizes, sb.target_windows = out_inst, t_sizes, tw
         return sb
 
@@ -218,11 +222,10 @@ class SnapshotShardedEncoder:
         """-> (target-position embeddings of THIS rank's windows, concatenated, forward order)."""
         m = self.model
         enc = m.ent_encoder
-        h0 = TF.gather_rows(m.ent_embeds, sb.ids_local)
-        y1 = enc.layer_1.conv(sb.g_local, h0)
+        y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table (DESIGN 3b)
         y2 = enc.layer_2.conv(sb.g_local, y1)
         y2_all = _AllGatherRows.apply(y2, sb.n_max, sb.canon_index, self.world, self.rank, self.group)
-        x = y2_all.index_select(0, sb.x_index)
+        x = TF.gather_rows(y2_all, sb.x_index32, sb.x_inv)                                   # deterministic adjoint (segment sum)
         l2 = enc.layer_2
         rnns = [l2.forward_rnn, l2.backward_rnn] if hasattr(l2, "forward_rnn") else [l2.rnn]
         pieces = gru_chain(x, sb.program, rnns, l2.inv_temperature, isinstance(rnns[0], GRUCell), want=list(sb.out_inst))
