@@ -121,19 +121,28 @@ class SnapshotShardedEncoder:
         for si, st in enumerate(steps):
             for j, g in enumerate(st.graphs):
                 visits.append((si, j, g))
-        bounds = split_visits_by_edges([g.number_of_edges() for _, _, g in visits], W)
-        sizes = np.array([g.n for _, _, g in visits], dtype=np.int64)
+        # a snapshot visited by several windows (or by one window's forward chain and another's backward chain) enters the
+        # RGCN -- and the all-gather -- ONCE: the shards are cut over the DISTINCT snapshots, visits index their rows
+        uniq, dgraphs, visit_d = {}, [], []
+        for _, _, g in visits:
+            k = uniq.get(id(g))
+            if k is None:
+                k = uniq[id(g)] = len(dgraphs)
+                dgraphs.append(g)
+            visit_d.append(k)
+        bounds = split_visits_by_edges([g.number_of_edges() for g in dgraphs], W)
+        sizes = np.array([g.n for g in dgraphs], dtype=np.int64)
         canon_off = np.concatenate([[0], np.cumsum(sizes)])
         shard_rows = [int(sizes[bounds[r]:bounds[r + 1]].sum()) for r in range(W)]
         n_max = max(max(shard_rows), 1)
-        canon_index = np.empty(int(canon_off[-1]), dtype=np.int64)      # canonical row -> row in the padded gather
+        canon_index = np.empty(int(canon_off[-1]), dtype=np.int64)      # canonical (distinct) row -> row in the padded gather
         for r in range(W):
             lo, hi = bounds[r], bounds[r + 1]
             n_r = int(canon_off[hi] - canon_off[lo])
             canon_index[canon_off[lo]:canon_off[hi]] = r * n_max + np.arange(n_r)
         # ---- this rank's RGCN shard ------------------------------------------------------------------
         from . import snapshot as S
-        mine = [g for _, _, g in visits[bounds[R]:bounds[R + 1]]]
+        mine = dgraphs[bounds[R]:bounds[R + 1]]
         g_local = S.batch(mine)
         g_local.device_graph(dev, 2 * m.num_rels)
         # ---- this rank's windows of the recurrence ---------------------------------------------------
@@ -144,7 +153,7 @@ class SnapshotShardedEncoder:
         k = 0
         for si, st in enumerate(steps):
             for j in range(len(st.graphs)):
-                first_row[(si, j)] = int(canon_off[k])
+                first_row[(si, j)] = int(canon_off[visit_d[k]])
                 k += 1
         sb = type("ShardBatch", (), {})()
         sb.g_local, sb.ids_local = g_local, torch.from_numpy(g_local.gids.astype(np.int32)).to(dev)
