@@ -274,9 +274,9 @@ class DynamicRGCN(TKG_Module):
                 index_sample = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(dev)
                 label = torch.ones(index_sample.shape[0], device=dev)
                 ranks.append(self.evaluater.calc_metrics_single_graph(ent_embed, self.rel_embeds, all_embeds_g, index_sample, g, t))
-                losses.append(self.link_classification_loss(ent_embed, self.rel_embeds, index_sample, label).item())
+                losses.append(self.link_classification_loss(ent_embed, self.rel_embeds, index_sample, label))
         ranks = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
-        return ranks, (float(np.mean(losses)) if losses else float("nan"))
+        return ranks, (float(torch.stack(losses).mean().item()) if losses else float("nan"))     # ONE device->host sync per batch
 
     def forward(self, t_list, reverse=False, target_edge_ids=None, samples=None):
         """models/DynamicRGCN.py:176-194.  `target_edge_ids` / `samples` inject the random draws

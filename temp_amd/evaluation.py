@@ -51,11 +51,13 @@ class EvaluationFilter:
         pos = np.repeat(lo - ptr[:-1], cnt) + np.arange(int(ptr[-1]), dtype=np.int64)
         return ptr.astype(np.int32), (keys[pos] % num_ent).astype(np.int32)
 
-    def _mode_inputs(self, mode, samples_np, graph, time, num_ent, dev):
-        """(target [P], filt_ptr [P+1], filt_ids) on `dev` for one corruption mode; static per (time, graph), cached."""
+    def _mode_inputs(self, mode, samples, graph, time, num_ent, dev):
+        """(target [P], filt_ptr [P+1], filt_ids) on `dev` for one corruption mode; static per (time, graph), cached
+        (the triples are only brought to the host on a cache miss)."""
         key = (time, id(graph), mode, str(dev))
         got = self._lists.get(key)
         if got is None:
+            samples_np = samples.detach().cpu().numpy().astype(np.int64)
             R, tails, heads = self._true_keys(time, num_ent)
             gid = graph.gids
             if mode == "tail":
@@ -76,12 +78,11 @@ class EvaluationFilter:
             P = samples.shape[0]
             if P == 0:
                 return torch.zeros(0, dtype=torch.int64, device=dev)
-            s_np = samples.detach().cpu().numpy().astype(np.int64)
             name = getattr(self.args, "score_function", None)
             fused = name in ("distmult", "complex") and num_ent % 4 == 0 and all_ent_embeds.shape[1] % 4 == 0
             out = {}
             for mode in ("head", "tail"):
-                target, ptr, ids = self._mode_inputs(mode, s_np, graph, time, num_ent, dev)
+                target, ptr, ids = self._mode_inputs(mode, samples, graph, time, num_ent, dev)
                 known = ent_mean[samples[:, 0] if mode == "tail" else samples[:, 2]]
                 r = rel_enc_means[samples[:, 1]]
                 if fused:
