@@ -10,6 +10,7 @@ import torch
 
 from . import functional as TF
 from . import _lib
+from . import snapshot as S
 from .birrgcn import BiGRRGCNLayer, BiRRGCN
 from .dynamic_rgcn import DynamicRGCN, WindowBatch
 from .gru_cell import GRUCell
@@ -198,6 +199,84 @@ class BiDynamicRGCN(DynamicRGCN):
         l2 = self.ent_encoder.layer_2
         (Hf, _), (Hb, _) = hist
         return [(l2.forward_rnn, Hf), (l2.backward_rnn, Hb)]
+
+    # -- reference-default flags (both layers recurrent): all-entity pass of all windows at once -------------------
+    def _fused_all_entity_ok(self, wb):
+        if wb.batched:
+            return super()._fused_all_entity_ok(wb)
+        enc = self.ent_encoder
+        return (self.use_batched_path and not enc.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
+                and isinstance(enc.layer_1, BiGRRGCNLayer) and isinstance(enc.layer_2, BiGRRGCNLayer)
+                and getattr(enc.layer_2, "num_layers", 1) == 1 and not (enc.layer_1._extra() or enc.layer_2._extra()))
+
+    def _all_maps(self, wb):
+        """Batched path: per-direction maps (DynamicRGCN._all_maps).  Reference-granular path (both layers recurrent): the
+        first layer's state of a (window, entity) pair depends on BOTH directions' previous states, so the pairs are the union
+        -- a previous state in either direction -- each with its two history rows (-1 = zero state in that direction); every
+        other inactive entity takes its row of the once-per-entity table."""
+        if wb.batched:
+            return super()._all_maps(wb)
+        if getattr(wb, "all_maps", None) is None:
+            dev = self._device()
+            N, B = self.num_ents, len(wb.graphs)
+            plan_f, plan_b = wb.plan
+            L = plan_f.seq_len
+            act = np.zeros((B, N), dtype=bool)
+            sizes = [g.n for g in wb.graphs]
+            n_out = int(sum(sizes))
+            off_out = np.concatenate([[0], np.cumsum(sizes)])
+            for b, g in enumerate(wb.graphs):
+                act[b, g.gids] = True
+            wb.n_inactive = int(B * N - act.sum())
+            rf = np.stack([plan_f.final_all(b, L - 1)[0] for b in range(B)])
+            rb = np.stack([plan_b.final_all(b, L - 1)[0] for b in range(B)])
+            gf = np.stack([plan_f.final_all(b, L - 1)[1] for b in range(B)])
+            gb = np.stack([plan_b.final_all(b, L - 1)[1] for b in range(B)])
+            has = ~act & ((rf >= 0) | (rb >= 0))
+            bb, ee = np.nonzero(has)
+            n_prev = int(bb.shape[0])
+            asm = np.broadcast_to(n_out + n_prev + np.arange(N, dtype=np.int64)[None, :], (B, N)).copy()
+            asm[has] = n_out + np.arange(n_prev)
+            for b, g in enumerate(wb.graphs):
+                asm[b, g.gids] = off_out[b] + np.arange(g.n)
+            host = dict(ent=ee, idx_f=rf[bb, ee], idx_b=rb[bb, ee], asm=asm.reshape(-1),
+                        dt_f=gf[bb, ee].astype(np.float32).view(np.int32), dt_b=gb[bb, ee].astype(np.float32).view(np.int32))
+            d = S.upload_packed(host, dev, np.int32)
+            f32 = lambda t: t.view(torch.float32).view(-1, 1)
+            wb.all_maps = [dict(n_prev=n_prev, ent=d["ent"], idx_f=d["idx_f"], idx_b=d["idx_b"], dt_f=f32(d["dt_f"]), dt_b=f32(d["dt_b"]),
+                                asm=d["asm"], ent_inv=TF.gather_inverse(ee, N, dev) if n_prev else None,
+                                asm_inv=TF.gather_inverse(asm.reshape(-1), n_out + n_prev + N if wb.n_inactive else n_out, dev))]
+        return wb.all_maps
+
+    def all_embeds_batched(self, wb, out, hist):
+        if wb.batched:
+            return super().all_embeds_batched(wb, out, hist)
+        # both layers recurrent (models/BiRRGCN.py:242-257): zero-state rows once per entity through both layers' GRU pairs,
+        # own rows for the union pairs
+        enc = self.ent_encoder
+        l1, l2 = enc.layer_1, enc.layer_2
+        (m,) = self._all_maps(wb)
+        B, N = len(wb.graphs), self.num_ents
+        if wb.n_inactive == 0:
+            return TF.gather_rows(out, m["asm"], m["asm_inv"]).view(B, N, out.shape[1])
+        (f1, f2), (b1, b2) = hist
+        iso1 = l1.conv_isolated(self.ent_embeds)
+        t1 = self._zero_state_rows(l1.forward_rnn, iso1, l1) + self._zero_state_rows(l1.backward_rnn, iso1, l1)
+        x2 = l2.conv_isolated(t1)
+        parts = [out]
+        if m["n_prev"]:
+            zero = iso1.new_zeros(1, iso1.shape[1])
+
+            def both(layer, x, pf, pb):
+                lam, dec = layer.inv_temperature, layer.decay_spec()
+                none = torch.full_like(m["idx_f"], -1)
+                return run_rnn(layer.forward_rnn, x, pf if pf is not None else zero, m["dt_f"], lam, dec, m["idx_f"] if pf is not None else none) + \
+                    run_rnn(layer.backward_rnn, x, pb if pb is not None else zero, m["dt_b"], lam, dec, m["idx_b"] if pb is not None else none)
+            h1p = both(l1, TF.gather_rows(iso1, m["ent"], m["ent_inv"]), f1, b1)
+            parts.append(both(l2, l2.conv_isolated(h1p), f2, b2))
+        parts.append(self._zero_state_rows(l2.forward_rnn, x2, l2) + self._zero_state_rows(l2.backward_rnn, x2, l2))
+        big = TF.gather_rows(torch.cat(parts, dim=0), m["asm"], m["asm_inv"])
+        return big.view(B, N, big.shape[1])
 
     def get_all_embeds_Gt(self, convoluted_embeds, g, t, plans, b, hist):
         """models/BiDynamicRGCN.py:102-112."""
