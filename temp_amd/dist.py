@@ -26,23 +26,59 @@ from .gru_chain import GruInstance, GruProgram, gru_chain
 from .window import ChainPlan, Step, window_times
 
 
+class GradBucket:
+    """ONE preallocated flat buffer over ALL trainable parameters, in a fixed order that is identical on every rank.
+    A parameter without a gradient on this rank (a rank that owns no window of a short last batch, a weight its shard
+    never touches) contributes zeros, so the collective has the same size everywhere and is never skipped."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.spans, off = [], 0
+        for p in self.params:
+            self.spans.append((off, off + p.numel()))
+            off += p.numel()
+        self.numel = off
+        self.flat = None
+
+    def _buffer(self):
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        return self.flat
+
+    def allreduce(self, world=None, average=True, group=None):
+        if world is None:
+            world = dist.get_world_size(group)
+        if world == 1 or not self.params:
+            return
+        flat = self._buffer()
+        for p, (a, b) in zip(self.params, self.spans):
+            if p.grad is None:
+                flat[a:b].zero_()
+            else:
+                flat[a:b].copy_(p.grad.reshape(-1))
+        dist.all_reduce(flat, group=group)
+        if average:
+            flat.div_(world)
+        for p, (a, b) in zip(self.params, self.spans):
+            if p.grad is None:
+                p.grad = flat[a:b].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[a:b].view_as(p))
+
+
 def allreduce_gradients(params, world=None, average=True, group=None):
-    """One flat bucket for all parameter gradients (about 2.5 M floats at D=200 on ICEWS14)."""
-    if world is None:
-        world = dist.get_world_size(group)
-    if world == 1:
+    """One flat bucket for all parameter gradients (about 2.5 M floats at D=200 on ICEWS14); the bucket (layout + buffer) is
+    built once per parameter list and kept on its first parameter."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
-        return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, group=group)
-    if average:
-        flat.div_(world)
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    key = tuple(id(p) for p in params)
+    bucket = getattr(params[0], "_temp_grad_bucket", None)
+    if bucket is None or bucket[0] != key:
+        bucket = (key, GradBucket(params))
+        params[0]._temp_grad_bucket = bucket
+    bucket[1].allreduce(world, average, group)
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -228,7 +264,9 @@ class SnapshotShardedEncoder:
 
     # ---------------------------------------------------------------------------------------------
     def run(self, sb):
-        """-> (target-position embeddings of THIS rank's windows, concatenated, forward order)."""
+        """-> (target-position embeddings of THIS rank's windows, concatenated, forward order).  A rank that owns no window
+        (bsz < world) gets a (0, D) tensor that is still attached to the graph: EVERY rank must run backward on (a function
+        of) its output -- `out.sum()` is enough -- because the adjoint of the all-gather is a collective."""
         m = self.model
         enc = m.ent_encoder
         y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table (DESIGN 3b)

@@ -24,7 +24,6 @@ class EvaluationFilter:
         self.calc_score = calc_score
         self.graph_dicts = (graph_dict_train, graph_dict_val, graph_dict_test)
         self._keys = {}
-        self._lists = {}
 
     def _true_keys(self, time, num_ent):
         """Sorted keys (h*R + r)*N + global(t) and (t*R + r)*N + global(h) over the three splits at `time`."""
@@ -52,10 +51,17 @@ class EvaluationFilter:
         return ptr.astype(np.int32), (keys[pos] % num_ent).astype(np.int32)
 
     def _mode_inputs(self, mode, samples, graph, time, num_ent, dev):
-        """(target [P], filt_ptr [P+1], filt_ids) on `dev` for one corruption mode; static per (time, graph), cached
-        (the triples are only brought to the host on a cache miss)."""
-        key = (time, id(graph), mode, str(dev))
-        got = self._lists.get(key)
+        """(target [P], filt_ptr [P+1], filt_ids) on `dev` for one corruption mode.  Cached ON the graph object (so the entry
+        dies with the graph: no id() reuse) together with the sample tensor it was built from; any other `samples` -- a
+        subset, a re-ordering, different triples -- rebuilds the lists."""
+        cache = graph.__dict__.setdefault("_filter_lists", {})
+        key = (id(self), time, mode, str(dev))
+        got = cache.get(key)
+        if got is not None:
+            ref = got[0]
+            same = ref is samples or (ref.shape == samples.shape and ref.device == samples.device and bool(torch.equal(ref, samples)))
+            if not same:
+                got = None
         if got is None:
             samples_np = samples.detach().cpu().numpy().astype(np.int64)
             R, tails, heads = self._true_keys(time, num_ent)
@@ -65,9 +71,11 @@ class EvaluationFilter:
             else:
                 prefix, keys, tgt = samples_np[:, 2] * R + samples_np[:, 1], heads, gid[samples_np[:, 0]]
             ptr, ids = self.filter_lists(prefix, keys, num_ent)
-            got = self._lists[key] = (torch.from_numpy(tgt.astype(np.int32)).to(dev), torch.from_numpy(ptr).to(dev),
-                                      torch.from_numpy(ids).to(dev))
-        return got
+            got = cache[key] = (samples.detach().clone(), torch.from_numpy(tgt.astype(np.int32)).to(dev), torch.from_numpy(ptr).to(dev),
+                                torch.from_numpy(ids).to(dev))
+        target, ptr, ids = got[1:]
+        assert target.shape[0] == samples.shape[0] and ptr.shape[0] == samples.shape[0] + 1, "filter lists do not match the samples"
+        return target, ptr, ids
 
     def calc_metrics_single_graph(self, ent_mean, rel_enc_means, all_ent_embeds, samples, graph, time, eval_bz=100):
         """-> ranks (2P,) int64, subject-corruption ranks first, then object-corruption (reference order)."""
