@@ -463,7 +463,7 @@ def gen_G9():
     save("G9_scores", **out)
 
 
-def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, trace=False, te=False):
+def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, trace=False, te=False, ent_row_stride=1):
     num_e, num_r, tr, va, te_g = graphs()
     args = rh.make_args(module=module, rec_only_last_layer=rec_only, hidden_size=D, embed_size=D, n_bases=B,
                         train_seq_len=L, test_seq_len=L, batch_size=bsz_args, negative_rate=neg, use_time_embedding=te)
@@ -515,6 +515,9 @@ def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, tra
         out['trip_%d' % i], out['negtail_%d' % i], out['neghead_%d' % i] = trip, nt, nh
     eg = m.ent_embeds.grad
     nz = torch.nonzero(eg.abs().sum(1)).view(-1)
+    if ent_row_stride > 1:                 # large-D fixtures: every k-th non-zero row + the global sums (gabs_/gsum_ent_embeds)
+        nz = nz[::ent_row_stride]
+        out['d_ent_sub'] = ent_row_stride
     out['d_ent_nz_rows'] = nz
     out['d_ent_nz_vals'] = eg[nz]
     out['d_rel'] = m.rel_embeds.grad
@@ -551,6 +554,10 @@ def gen_G10():
     save("G10_bi_grrgcn_rol", **_run_window(BiDynamicRGCN, 'BiGRRGCN', True, 32, 16, 503, T([20, 15, 9, 3]), 8, 4, 20))
     save("G10_bi_grrgcn", **_run_window(BiDynamicRGCN, 'BiGRRGCN', False, 16, 4, 504, T([22, 10, 1]), 5, 4, 20))
     save("G10_uni_grrgcn_d200", **_run_window(DynamicRGCN, 'GRRGCN', True, 200, 100, 505, T([9, 4]), 4, 4, 10))
+    # BASELINE's headline shape at window level: bidirectional, L=15, D=200 / 100 bases, rec-only-last-layer (config 4's model on
+    # the ICEWS14 slice; windows are clipped by the slice's 24 timestamps exactly as the reference clips them at the data's ends)
+    save("G10_bi_grrgcn_rol_d200", **_run_window(BiDynamicRGCN, 'BiGRRGCN', True, 200, 100, 506, T([21, 14, 8, 2]), 15, 4, 10,
+                                                 ent_row_stride=9))
 
 
 def gen_G12():
@@ -572,15 +579,61 @@ def gen_G12():
     with torch.no_grad():
         embeds = m.get_per_graph_ent_embeds(t_list, gl, val=True)
         iso = m.ent_encoder.forward_isolated(m.ent_embeds[:200], t_list[0])
-    out = dict(D=D, B=B, seed=seed, t_list=t_list.numpy(), times=np.array(times), iso=iso, param_checksum=checksum(model))
+    out = dict(D=D, B=B, seed=seed, t_list=t_list.numpy(), times=np.array(times), iso=iso, param_checksum=checksum(model), neg=20)
     for i, e in enumerate(embeds):
         out['emb_%d' % i] = e
+    # training step (baselines/StaticRGCN.py:36-46): loss + gradients with the reference's random draws recorded
+    np.random.seed(seed)
+    choices, samples = [], []
+    orig_choice = np.random.choice
+
+    def rec_choice(*a, **k):
+        r = orig_choice(*a, **k)
+        choices.append(np.asarray(r).copy())
+        return r
+
+    orig_neg = m.corrupter.single_graph_negative_sampling
+
+    def rec_neg(t, g, n):
+        res = orig_neg(t, g, n)
+        samples.append([x.clone() for x in res[:3]])
+        return res
+
+    m.corrupter.single_graph_negative_sampling = rec_neg
+    np.random.choice = rec_choice
+    try:
+        loss = m(t_list)
+    finally:
+        np.random.choice = orig_choice
+    loss.backward()
+    out.update(loss=loss.item(), n_choices=len(choices), n_samples=len(samples))
+    for i, c in enumerate(choices):
+        out['choice_%d' % i] = c
+    for i, (trip, nt, nh) in enumerate(samples):
+        out['trip_%d' % i], out['negtail_%d' % i], out['neghead_%d' % i] = trip, nt, nh
+    eg = m.ent_embeds.grad
+    nz = torch.nonzero(eg.abs().sum(1)).view(-1)
+    out['d_ent_nz_rows'], out['d_ent_nz_vals'], out['d_rel'] = nz, eg[nz], m.rel_embeds.grad
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            out['gabs_' + k] = v.grad.double().abs().sum().item()
+    for ln in ('layer_1', 'layer_2'):
+        out['d_bias_' + ln] = getattr(m.ent_encoder, ln).h_bias.grad
     save("G12_static_rgcn", **out)
+
+
+G13_REL_SCALE = 250.0      # rel_embeds multiplier: the untrained D=32 model scores every candidate within 1e-3 of 0, i.e.
+                            # sigmoid = 0.5 +- 2e-4 in fp32 -- hundreds of exact ties per row; scaled, the scores spread over ~[-3, 3]
+G13_BAND = 1.5e-6           # |sigmoid(score_e) - sigmoid(score_target)| below this is "inside the tie band" (fp32 rounding of
+                            # two different but equally valid evaluation orders can swap such a pair)
 
 
 def gen_G13():
     """evaluate(): filtered ranks + classification loss (models/DynamicRGCN.py:118-144,196-220,
-    models/BiDynamicRGCN.py:146-208, utils/evaluation.py:34-106)."""
+    models/BiDynamicRGCN.py:146-208, utils/evaluation.py:34-106).  For every ranked row the generator also records
+    `nclose` = the number of unfiltered competitors whose sigmoid score lies within G13_BAND of the target's: rows with
+    nclose == 0 have a rank that no rounding can move (tests demand exact equality there), the others may move by at most
+    nclose."""
     from models.DynamicRGCN import DynamicRGCN
     from models.BiDynamicRGCN import BiDynamicRGCN
     num_e, num_r, tr, va, te_g = graphs()
@@ -592,16 +645,45 @@ def gen_G13():
                             train_seq_len=L, test_seq_len=L, batch_size=4, negative_rate=20)
         cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=False)
         model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
+        model['rel_embeds'] = model['rel_embeds'] * G13_REL_SCALE
         m = cls(args, num_e, num_r, tr, va, te_g)
         m.load_state_dict(to_ref_state_dict(model), strict=True)
         t_list = [int(times[i]) for i in idx]
         out = dict(module=module, rec_only=int(rec_only), D=D, B=B, seed=seed, L=L, te=0, neg=20, t_list=np.array(t_list),
-                   param_checksum=checksum(model))
+                   param_checksum=checksum(model), rel_scale=G13_REL_SCALE, band=G13_BAND)
+        ev = m.evaluater
+        rec = dict(mode=None, graphs=[])
+        orig_single, orig_perturb, orig_sort = ev.calc_metrics_single_graph, ev.perturb_and_get_rank, ev.sort_and_rank
+
+        def single(*a, **k):
+            rec['graphs'].append(dict(head=[], tail=[]))
+            return orig_single(*a, **k)
+
+        def perturb(*a, **k):
+            rec['mode'] = k.get('mode', a[-1] if a and isinstance(a[-1], str) else 'tail')
+            return orig_perturb(*a, **k)
+
+        def sort_and_rank(score, target):
+            ts = score.gather(1, target.view(-1, 1))
+            d = (score - ts).abs()
+            d.scatter_(1, target.view(-1, 1), float('inf'))
+            rec['graphs'][-1][rec['mode']].append(((d <= G13_BAND) & (score > 1e-30)).sum(1))
+            rec.setdefault('spread', []).append(score[score > 1e-30].std().item())
+            return orig_sort(score, target)
+
+        ev.calc_metrics_single_graph, ev.perturb_and_get_rank, ev.sort_and_rank = single, perturb, sort_and_rank
         with torch.no_grad():
             for split, val in (("val", True), ("test", False)):
+                rec['graphs'] = []
                 ranks, loss = m.evaluate(torch.tensor(t_list), val=val)
+                nclose = torch.cat([torch.cat(g['head'] + g['tail']) for g in rec['graphs']])     # ranks = [head ranks ; tail ranks] per graph
+                assert nclose.shape == ranks.shape
                 out["ranks_" + split] = ranks
+                out["nclose_" + split] = nclose
                 out["loss_" + split] = float(loss)
+                print("  %s %s: %d ranks, %.1f%% outside every tie band, sigmoid spread %.3f, mean rank %.1f" %
+                      (name, split, ranks.numel(), 100.0 * (nclose == 0).float().mean().item(), float(np.mean(rec['spread'])),
+                       ranks.float().mean().item()))
         save(name, **out)
 
 

@@ -711,6 +711,73 @@ def static_forward_embeds(model, cfg, target_graphs, target_times):
     return list(out.split(sizes))
 
 
+def static_forward_loss(model, cfg, graph_dict, t_list, target_graphs, samples, score='complex'):
+    """StaticRGCN.forward, baselines/StaticRGCN.py:36-58: per target graph the encoder rows, the isolated pass over ALL
+    entities with the graph's rows written over it, and loss_tail + loss_head (t_list order is kept: no window sorting)."""
+    fn = SCORERS[score]
+    per_graph = static_forward_embeds(model, cfg, target_graphs, t_list)
+    loss = 0
+    for i, (t, g, emb) in enumerate(zip(t_list, target_graphs, per_graph)):
+        trip, neg_tail, neg_head = samples[i]
+        all_e = static_rgcn_isolated(model['ent_encoder'], cfg, model['ent_embeds'], t).index_copy(0, torch.as_tensor(g.ids), emb)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_tail, all_e, True)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_head, all_e, False)
+    return loss, per_graph
+
+
+def filtered_ranks(score_fn, ent_embed, rel_embeds, all_embeds, triples, gids, true_tails, true_heads, batch=100):
+    """EvaluationFilter.calc_metrics_single_graph, utils/evaluation.py:34-106: for every triple (local ids) score the true
+    subject / object against ALL entities, overwrite the OTHER known-true entities with -10e6 (the target itself stays),
+    sigmoid, sort descending (torch.sort: order inside a tie group is whatever it returns), rank = position of the target,
+    1-indexed.  -> [subject-corruption ranks ; object-corruption ranks].
+    true_tails[(h, r)] / true_heads[(r, t)]: local node ids known true at this timestamp over train+valid+test."""
+    gids = torch.as_tensor(gids)
+    P, N = triples.shape[0], all_embeds.shape[0]
+    out = {}
+    for mode in ('tail', 'head'):
+        mask = torch.zeros(P, N, dtype=torch.bool)
+        for i in range(P):
+            h, r, t = (int(x) for x in triples[i])
+            if mode == 'tail':
+                mask[i, gids[torch.as_tensor(sorted(true_tails[(h, r)]))]] = True
+                mask[i, gids[t]] = False
+            else:
+                mask[i, gids[torch.as_tensor(sorted(true_heads[(r, t)]))]] = True
+                mask[i, gids[h]] = False
+        ranks = []
+        for a in range(0, P, batch):
+            b = min(P, a + batch)
+            r = rel_embeds[triples[a:b, 1]]
+            if mode == 'tail':
+                sc = score_fn(ent_embed[triples[a:b, 0]], r, all_embeds, mode='tail')
+                target = gids[triples[a:b, 2]]
+            else:
+                sc = score_fn(all_embeds, r, ent_embed[triples[a:b, 2]], mode='head')
+                target = gids[triples[a:b, 0]]
+            ranks.append(rank_from_scores(sc, mask[a:b], target))
+        out[mode] = torch.cat(ranks)
+    return torch.cat([out['head'], out['tail']])
+
+
+def rank_from_scores(score, mask, target):
+    """perturb_and_get_rank + sort_and_rank, utils/evaluation.py:75-78,101-106: masked entries -> -10e6, sigmoid, sort
+    descending, 1-indexed position of the target."""
+    sc = torch.sigmoid(torch.where(mask, torch.full_like(score, -10e6), score))
+    _, idx = torch.sort(sc, dim=1, descending=True)
+    return torch.nonzero(idx == target.view(-1, 1))[:, 1].view(-1) + 1
+
+
+def true_heads_and_tails(triple_sets):
+    """CorruptTriples.get_true_head_and_tail_per_graph over the concatenated train/valid/test triples of one timestamp
+    (utils/evaluation.py:16-32): {(h, r): {t}}, {(r, t): {h}} in LOCAL node ids."""
+    tails, heads = {}, {}
+    for trip in triple_sets:
+        for h, r, t in trip.tolist():
+            tails.setdefault((h, r), set()).add(t)
+            heads.setdefault((r, t), set()).add(h)
+    return heads, tails
+
+
 # --------------------------------------------------------------------------------------
 # Parameter init (SURVEY Appendix B) + state_dict conversion helpers
 # --------------------------------------------------------------------------------------

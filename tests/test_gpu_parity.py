@@ -216,7 +216,7 @@ from tests.window_cases import check_batched_equals_generic, check_static, check
 
 
 @pytest.mark.parametrize("name", ["G10_uni_grrgcn", "G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol", "G10_bi_grrgcn",
-                                  "G10_uni_grrgcn_d200"])
+                                  "G10_uni_grrgcn_d200", "G10_bi_grrgcn_rol_d200"])
 def test_window_loss_and_grads_golden_gpu(name):
     check_window(name, DEV)
 

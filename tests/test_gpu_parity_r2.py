@@ -1,0 +1,173 @@
+"""GPU parity tests added in round 2 (-m gpu): the HIP path against the CPU ORACLE (oracle/temp_oracle.py, pinned by the
+reference's golden vectors) at the sizes BASELINE.json names, and the integer / scorer pieces against the reference's own
+recorded outputs.
+
+  * full S-gdelt windows (D = 200, 100 bases, L = 15, bidirectional, --rec-only-last-layer): target embeddings and
+    gradients of the batched HIP step vs the oracle's dense-history restatement of the reference op sequence;
+  * the same workload through the self-attention encoder (config 5) vs O.sa_encode;
+  * temp_filtered_rank vs the oracle's mask / sigmoid / sort formulation on tie-free scores (bit-exact);
+  * temp_amd.scores and the folded-query kernels vs G9_scores.npz (recorded from utils/scores.py).
+Tolerance: 1e-5 relative fp32 with a small absolute floor on outputs; gradients that sum over ~10^5 rows get 1e-4."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import temp_oracle as O
+from temp_amd import backend as TB
+from tests.golden_util import T, assert_close, load
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def hip_backend():
+    TB.set_backend(None)
+    be = TB.get_backend()
+    assert be.name == "hip"
+    yield be
+
+
+def _oracle_model(model, w, module, te=False):
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = dict(module=module, n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=te)
+    om = O.model_from_state_dict(sd, cfg)
+    gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
+    return om, cfg, gd
+
+
+def _upstream(sizes, D, seed):
+    """Fixed pseudo-random upstream gradient per window (a plain sum would hide sign / permutation errors)."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(n, D, generator=g) for n in sizes]
+
+
+@pytest.mark.parametrize("workload,n_windows", [("S-gdelt", 3), ("S-icews0515", 3)])
+def test_full_size_windows_vs_oracle_gpu(workload, n_windows):
+    """BASELINE's headline shape: full windows of the S-gdelt (and the ICEWS05-15-shaped) workload through the batched HIP
+    step (distinct snapshots once, table layer, one GRU chain program) against the oracle (0.3 s per window on the CPU)."""
+    import bench
+    from temp_amd import synthetic
+    w = synthetic.workload(workload, seed=0)
+    model = bench.build_model(w, DEV)
+    targets = sorted(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:n_windows], reverse=True)
+    L, D = w["L"], w["D"]
+    # ---- HIP path ---------------------------------------------------------------------------------------------------
+    wb = model.prepare(targets, L, train=False)
+    assert wb.batched and wb.program is not None
+    out = model.run(wb)[0]
+    pieces = list(out.split(wb.target.sizes))
+    ups = _upstream(wb.target.sizes, D, 7)
+    sum((p * u.to(DEV)).sum() for p, u in zip(pieces, ups)).backward()
+    torch.cuda.synchronize()
+    # ---- oracle (reference op sequence, dense re-zeroed history) ------------------------------------------------------
+    om, cfg, gd = _oracle_model(model, w, w["module"])
+    times = sorted(gd.keys())
+    leaves = O.leaf_tensors(om)
+    for v in leaves.values():
+        v.requires_grad_(True)
+    tf, tb = O.get_batch_graph_list_bi(targets, L, times)
+    Hf = O.bi_pre_forward(om, cfg, gd, tf, L, True)
+    Hb = O.bi_pre_forward(om, cfg, gd, tb, L, False)
+    want = O.bi_target_embeds(om, cfg, Hf, Hb, [gd[t] for t in targets], tf[-1], L)
+    sum((p * u).sum() for p, u in zip(want, ups)).backward()
+    for i, (a, b) in enumerate(zip(pieces, want)):
+        assert_close(a, b, 1e-5, 3e-6, "%s window %d target embeddings" % (workload, i))
+    enc = model.ent_encoder
+    l2o = om["ent_encoder"]["layer_2"]
+    checks = [("ent_embeds", model.ent_embeds.grad, om["ent_embeds"].grad),
+              ("layer_1.weight", enc.layer_1.weight.grad, om["ent_encoder"]["layer_1"]["weight"].grad),
+              ("layer_1.loop_weight", enc.layer_1.loop_weight.grad, om["ent_encoder"]["layer_1"]["loop_weight"].grad),
+              ("layer_2.weight", enc.layer_2.weight.grad, l2o["weight"].grad),
+              ("layer_2.loop_weight", enc.layer_2.loop_weight.grad, l2o["loop_weight"].grad)]
+    for name, rnn in (("forward_rnn", enc.layer_2.forward_rnn), ("backward_rnn", enc.layer_2.backward_rnn)):
+        q = l2o[name][0]
+        checks += [("%s.w_hh" % name, rnn.weight_hh_l0.grad, q["w_hh"].grad), ("%s.w_ih" % name, rnn.weight_ih_l0.grad, q["w_ih"].grad),
+                   ("%s.b_hh" % name, rnn.bias_hh_l0.grad, q["b_hh"].grad), ("%s.b_ih" % name, rnn.bias_ih_l0.grad, q["b_ih"].grad)]
+    for name, got, ref in checks:
+        assert got is not None and ref is not None, name
+        assert_close(got, ref, 1e-4, 2e-5 * float(ref.abs().max()), "%s d %s" % (workload, name))
+
+
+@pytest.mark.parametrize("workload,n_windows", [("S-gdelt", 2)])
+def test_full_size_attention_windows_vs_oracle_gpu(workload, n_windows):
+    """Config 5 at the headline size: BiSelfAttentionRGCN (8-head attention of every target node over its window history)
+    on full S-gdelt windows vs the oracle's dense (n, T, D) formulation (O.sa_encode)."""
+    import bench
+    from temp_amd import synthetic
+    w = synthetic.workload(workload, seed=0)
+    model = bench.build_model(w, DEV, "attention")
+    targets = sorted(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:n_windows], reverse=True)
+    L, D = w["L"], w["D"]
+    per_graph, wb, tables = model.encode(torch.tensor(targets), L, train=False)
+    ups = _upstream([p.shape[0] for p in per_graph], D, 11)
+    sum((p * u.to(DEV)).sum() for p, u in zip(per_graph, ups)).backward()
+    torch.cuda.synchronize()
+    om, cfg, gd = _oracle_model(model, w, "BiSARGCN", te=True)
+    cfg["learnable_lambda"] = False
+    times = sorted(gd.keys())
+    leaves = O.leaf_tensors(om)
+    for v in leaves.values():
+        v.requires_grad_(True)
+    want, *_ = O.sa_encode(om, cfg, gd, targets, times, L, [gd[t] for t in targets], bi=True)
+    sum((p * u).sum() for p, u in zip(want, ups)).backward()
+    for i, (a, b) in enumerate(zip(per_graph, want)):
+        assert_close(a, b, 1e-5, 3e-6, "attention window %d target embeddings" % i)
+    enc, eo = model.ent_encoder, om["ent_encoder"]
+    for name, got, ref in [("ent_embeds", model.ent_embeds.grad, om["ent_embeds"].grad),
+                           ("layer_2.weight", enc.layer_2.weight.grad, eo["layer_2"]["weight"].grad),
+                           ("layer_2.q_linear", enc.layer_2.q_linear.weight.grad, eo["layer_2"]["q_linear"].grad),
+                           ("layer_2.k_linear", enc.layer_2.k_linear.weight.grad, eo["layer_2"]["k_linear"].grad),
+                           ("layer_2.v_linear", enc.layer_2.v_linear.weight.grad, eo["layer_2"]["v_linear"].grad),
+                           ("layer_1.loop_weight", enc.layer_1.loop_weight.grad, eo["layer_1"]["loop_weight"].grad)]:
+        assert got is not None and ref is not None, name
+        assert_close(got, ref, 1e-4, 2e-5 * float(ref.abs().max()), "attention d " + name)
+
+
+@pytest.mark.parametrize("P,N", [(37, 500), (200, 7128), (1500, 500), (5, 10488)])
+def test_filtered_rank_kernel_vs_oracle_tie_free(P, N):
+    """temp_filtered_rank against the oracle's restatement of utils/evaluation.py:53-106 (mask -> -10e6 -> sigmoid -> sort
+    descending -> index of the target) on TIE-FREE scores: every row is a permutation of N equally spaced values in
+    [-4, 4], so neighbouring sigmoids differ by > 1e-5 and the integer ranks must be identical."""
+    g = torch.Generator().manual_seed(P * 13 + N)
+    sc = torch.stack([(torch.randperm(N, generator=g).float() - N / 2) * (8.0 / N) for _ in range(P)])
+    tgt = torch.randint(0, N, (P,), generator=g)
+    cnt = torch.randint(0, 40, (P,), generator=g)
+    cnt[0] = 0
+    ptr = torch.zeros(P + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(cnt, 0).int()
+    lists = [torch.randperm(N, generator=g)[:c].sort().values for c in cnt.tolist()]
+    if P > 1 and cnt[1] > 0:
+        lists[1][0] = tgt[1]                                     # the target itself is listed: the reference un-masks it
+        lists[1] = lists[1].unique()
+        ptr[1:] = torch.cumsum(torch.tensor([len(x) for x in lists]), 0).int()
+    ids = torch.cat(lists + [torch.zeros(0, dtype=torch.int64)]).int()
+    mask = torch.zeros(P, N, dtype=torch.bool)
+    for i, l in enumerate(lists):
+        mask[i, l] = True
+        mask[i, tgt[i]] = False
+    want = O.rank_from_scores(sc, mask, tgt)
+    got = TB.get_backend().filtered_rank(sc.to(DEV), tgt.int().to(DEV), ptr.to(DEV), ids.to(DEV)).cpu()
+    assert torch.equal(got, want)
+
+
+def test_scores_and_query_kernels_vs_reference_golden():
+    """temp_amd.scores (the preserved distmult / complex / transE call signatures) and the folded-query HIP kernels
+    (temp_bilinear_query_fwd) against G9_scores.npz, recorded from the reference's utils/scores.py."""
+    from temp_amd import scores as SC
+    z = load("G9_scores")
+    s, r, o, cand = (T(z[k]).to(DEV) for k in ("s", "r", "o", "cand"))
+    for name in ("distmult", "complex", "transE"):
+        fn = getattr(SC, name)
+        assert_close(fn(s, r, o), z[name + "_single"], 1e-5, 1e-6, name + " single")
+        assert_close(fn(s, r, cand, mode="tail"), z[name + "_tail"], 1e-5, 1e-6, name + " tail")
+        assert_close(fn(cand, r, o, mode="head"), z[name + "_head"], 1e-5, 1e-6, name + " head")
+    be = TB.get_backend()
+    P, D = s.shape
+    idx = torch.arange(P, dtype=torch.int32, device=DEV)
+    for name in ("distmult", "complex"):
+        for mode, known, flag in (("tail", s, 1), ("head", o, 0)):
+            q = be.bilinear_query_fwd(name, known.contiguous(), idx, r.contiguous(), idx, torch.full((P,), flag, dtype=torch.int32, device=DEV))
+            assert_close((q.unsqueeze(1) * cand).sum(-1), z["%s_%s" % (name, mode)], 1e-5, 1e-6, "%s %s through the folded-query kernel" % (name, mode))

@@ -61,7 +61,7 @@ def test_plan_matches_dense_history_semantics():
         assert np.array_equal(a, hist_mark[b]) and np.array_equal(d, L - 1 - start[b])
 
 
-@pytest.mark.parametrize("name", ["G10_uni_grrgcn", "G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol", "G10_bi_grrgcn"])
+@pytest.mark.parametrize("name", ["G10_uni_grrgcn", "G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol", "G10_bi_grrgcn", "G10_bi_grrgcn_rol_d200"])
 def test_window_loss_and_grads_golden(name):
     check_window(name, torch.device("cpu"))
 

@@ -61,7 +61,9 @@ def build_window_model(z, device, batched=True, chain=True):
     module, rec_only, D, B, L = str(z["module"]), bool(z["rec_only"]), int(z["D"]), int(z["B"]), int(z["L"])
     cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=bool(z["te"]))
     model = O.init_model(cfg, s["num_e"], s["num_r"], len(s["times"]), D, seed=int(z["seed"]))
-    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6
+    if "rel_scale" in z.files:              # G13: relation embeddings scaled so that the scores spread (oracle/gen_golden.py:G13_REL_SCALE)
+        model["rel_embeds"] = model["rel_embeds"] * float(z["rel_scale"])
+    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6 * max(1.0, float(z["param_checksum"]) * 1e-6)
     args = make_args(module=module, rec_only_last_layer=rec_only, embed_size=D, hidden_size=D, n_bases=B, train_seq_len=L,
                      test_seq_len=L, negative_rate=int(z["neg"]), use_time_embedding=bool(z["te"]))
     cls = BiDynamicRGCN if module.startswith("Bi") else DynamicRGCN
@@ -91,9 +93,10 @@ def check_window(name, device, batched=True):
     eg = m.ent_embeds.grad
     rows = T(z["d_ent_nz_rows"]).long().to(device)
     assert_close(eg[rows], z["d_ent_nz_vals"], 1e-4, 3e-6, name + " d_ent")
-    mask = torch.ones(eg.shape[0], dtype=torch.bool, device=device)
-    mask[rows] = False
-    assert float(eg[mask].abs().max()) < 1e-7
+    if "d_ent_sub" not in z.files:          # full list of non-zero rows: every other row must be exactly untouched
+        mask = torch.ones(eg.shape[0], dtype=torch.bool, device=device)
+        mask[rows] = False
+        assert float(eg[mask].abs().max()) < 1e-7
     assert_close(m.rel_embeds.grad, z["d_rel"], 1e-4, 3e-6, name + " d_rel")
     checked = 0
     for k, v in m.named_parameters():
@@ -150,7 +153,31 @@ def check_static(device):
     for i, e in enumerate(embeds):
         assert_close(e, z["emb_%d" % i], 1e-5, 2e-6, "G12 emb %d" % i)
     assert_close(iso, z["iso"], 1e-5, 2e-6, "G12 iso")
-    loss = m(torch.tensor(tl))            # end-to-end with its own sampler: finite, differentiable
+    # training step with the reference's recorded draws: golden loss + gradients (baselines/StaticRGCN.py:36-46)
+    edge_ids, samples = window_inputs(z)
+    loss = m(torch.tensor(tl), target_edge_ids=edge_ids, samples=samples)
+    want = float(z["loss"])
+    assert abs(loss.item() - want) < 3e-5 * abs(want), (loss.item(), want)
+    loss.backward()
+    eg = m.ent_embeds.grad
+    rows = T(z["d_ent_nz_rows"]).long().to(device)
+    assert_close(eg[rows], z["d_ent_nz_vals"], 1e-4, 3e-6, "G12 d_ent")
+    mask = torch.ones(eg.shape[0], dtype=torch.bool, device=device)
+    mask[rows] = False
+    assert float(eg[mask].abs().max()) < 1e-7
+    assert_close(m.rel_embeds.grad, z["d_rel"], 1e-4, 3e-6, "G12 d_rel")
+    for ln in ("layer_1", "layer_2"):
+        assert_close(getattr(m.ent_encoder, ln).h_bias.grad, z["d_bias_" + ln], 1e-4, 3e-6, "G12 d_bias " + ln)
+    checked = 0
+    for k, v in m.named_parameters():
+        gk = "gabs_" + k
+        if gk in z.files and v.grad is not None:
+            w = float(z[gk])
+            assert abs(v.grad.double().abs().sum().item() - w) < 3e-4 * max(w, 1e-3), (k, w)
+            checked += 1
+    assert checked >= 8, checked
+    m.zero_grad()
+    loss = m(torch.tensor(tl))            # and end-to-end with its own sampler (fused loss path): finite, differentiable
     loss.backward()
     assert torch.isfinite(loss) and m.ent_embeds.grad.abs().sum() > 0
     ranks, ev_loss = m.evaluate(torch.tensor(tl))
@@ -158,21 +185,25 @@ def check_static(device):
 
 
 def check_evaluate(name, device):
-    """evaluate(): ranks and loss against the reference's own evaluate() on the ICEWS14 slice (G13)."""
+    """evaluate(): filtered ranks and loss against the reference's own evaluate() on the ICEWS14 slice (G13).
+
+    Integer parity: the fixture records, for every ranked row, how many unfiltered competitors have a sigmoid score within
+    `band` (1.5e-6, a few fp32 ulps at 0.5) of the target's -- pairs that two valid fp32 evaluation orders may swap (and
+    that the reference itself resolves by whatever order torch.sort returns).  Rows with no such competitor (about 90 %)
+    must match the reference's rank EXACTLY; any other row may differ by at most its number of in-band competitors."""
     z = load(name)
     m = build_window_model(z, device)
     t_list = torch.tensor([int(t) for t in z["t_list"]])
     for split, val in (("val", True), ("test", False)):
         ranks, loss = m.evaluate(t_list, val=val)
         want = T(z["ranks_" + split]).long()
+        nclose = T(z["nclose_" + split]).long()
         assert ranks.shape == want.shape
-        # sigmoid(score) in fp32 has real ties near 0.5; the reference breaks them by the (unstable) order
-        # torch.sort happens to produce, so individual ranks may differ by the size of a tie group
         got = ranks.cpu()
-        assert (got == want).float().mean().item() > 0.75, (name, split)
-        assert (got - want).abs().max().item() <= 6, (name, split)
-        mrr_g, mrr_w = (1.0 / got.float()).mean().item(), (1.0 / want.float()).mean().item()
-        assert abs(mrr_g - mrr_w) < 2e-3 * mrr_w, (name, split, mrr_g, mrr_w)
+        safe = nclose == 0
+        assert safe.float().mean().item() > 0.85, (name, split)
+        assert torch.equal(got[safe], want[safe]), (name, split, int((got[safe] != want[safe]).sum()))
+        assert bool(((got - want).abs() <= nclose).all()), (name, split)
         assert abs(loss - float(z["loss_" + split])) < 2e-5 * max(1.0, abs(float(z["loss_" + split])))
 
 
