@@ -257,6 +257,49 @@ int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Persistent window chain: ALL positions of the recurrence in ONE launch per direction of time.
+ *
+ * The recurrence of the window models is per (window, direction, entity): a row at position p reads only the state of the
+ * SAME entity at position p-1 (`prev_idx`; models/DynamicRGCN.py:35-54, models/RRGCN.py:77-89).  So the rows of a chain
+ * program split into independent *panels* of <= 32 entity tracks; a workgroup owns a panel, keeps its 32 states in LDS and
+ * walks all positions of the chain without ever meeting another workgroup: no grid barrier, no relaunch.  Per position a
+ * panel does  hdec . W_hh^T  (32 x 3d x d) on the fp32 MFMA pipe with W_hh streamed from L2 in fragment order
+ * (temp_gru_chain_pack), then the gates / blend pointwise; the backward walks the positions in reverse with
+ * d_prev = (dgh . W_hh + dh*z) * decay kept in LDS.  Replaces 15 x (temp_gru_cell_fwd_multi) and
+ * 15 x (temp_gru_cell_bwd_multi) launches of a seq_len-15 bidirectional window.
+ *
+ * Tables (device, int32), built once per prepared batch on the host:
+ *   panel [n_panels][4] : { GRU index (< n_rnn), first step (row of the step tables), number of steps, 0 }
+ *   rows  [S][32]       : per step and track: row in the [N_total, *] buffers | TEMP_CHAIN_HAS_PREV if the track carries a
+ *                         state from the step before (else the state is zero), or -1 (track idle at this step)
+ *   sinfo [S][4]        : { flags (bit0: some track of the step has a previous state, bit1: write h_out rows),
+ *                           up: index into `up` of the upstream gradient block of the step's rows or -1,
+ *                           up_row0: first row of that block in the [N_total] row space, 0 }
+ * Steps of a panel are consecutive table rows in chain order.  gi / saved / dgi / dgh / h: as for temp_gru_cell_*.
+ * Fixed decay only.  d % 4 == 0 and d <= TEMP_CHAIN_MAX_D (LDS), else TEMP_E_UNSUPPORTED.
+ * ---------------------------------------------------------------------------------------------- */
+#define TEMP_CHAIN_HAS_PREV (1 << 30)
+#define TEMP_CHAIN_TRACKS 32
+#define TEMP_CHAIN_MAX_RNN 4
+#define TEMP_CHAIN_MAX_UP 8
+typedef struct TempGruChain {
+  int32_t d, variant, n_panels, n_steps;
+  const int32_t* panel; const int32_t* rows; const int32_t* sinfo;
+  const float* dt;                       /* [N_total] time gap of every row */
+  float lambda;
+  size_t saved_plane;
+  int32_t n_rnn;
+  const float* packed[TEMP_CHAIN_MAX_RNN];   /* temp_gru_chain_pack of each GRU's W_hh */
+  const float* b_hh[TEMP_CHAIN_MAX_RNN];
+} TempGruChain;
+int temp_gru_chain_supported(int d);
+size_t temp_gru_chain_pack_floats(int d);                                   /* floats of one packed W_hh */
+int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream);
+int temp_gru_chain_fwd(const TempGruChain* c, const float* gi, float* h_out, float* saved, void* stream);
+int temp_gru_chain_bwd(const TempGruChain* c, const float* saved, int n_up, const float* const* up /* HOST array of device pointers */,
+                       float* dgi, float* dgh, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row gather / scatter helpers of the window loop
  * (get_prev_embeddings / update_time_diff_hist_embeddings / ent_embeds[id],
  *  models/DynamicRGCN.py:35-54,93).

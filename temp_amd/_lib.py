@@ -42,6 +42,19 @@ class TempGruCellBwd(ctypes.Structure):
                 ("w_hh", c_vp), ("dgi", c_vp), ("dgh", c_vp), ("decv", c_vp), ("d_prev", c_vp), ("no_prev", ctypes.c_int32)]
 
 
+CHAIN_HAS_PREV = 1 << 30
+CHAIN_TRACKS = 32
+CHAIN_MAX_RNN = 4
+CHAIN_MAX_UP = 8
+CHAIN_MAX_STEPS = 64
+
+
+class TempGruChain(ctypes.Structure):
+    _fields_ = [("d", ctypes.c_int32), ("variant", ctypes.c_int32), ("n_panels", ctypes.c_int32), ("n_steps", ctypes.c_int32),
+                ("panel", c_vp), ("rows", c_vp), ("sinfo", c_vp), ("dt", c_vp), ("lambda_", ctypes.c_float),
+                ("saved_plane", ctypes.c_size_t), ("n_rnn", ctypes.c_int32), ("packed", c_vp * CHAIN_MAX_RNN), ("b_hh", c_vp * CHAIN_MAX_RNN)]
+
+
 class TempDropout(ctypes.Structure):
     _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64)]
 
@@ -88,6 +101,11 @@ SYMBOLS = {
     "temp_gru_cell_bwd_multi": (_I, [_I, ctypes.POINTER(TempGruCellBwd), _I, _I, _F, _SZ, c_vp]),
     "temp_gru_weight_grads_workspace": (_SZ, [_I, _I, _I]),
     "temp_gru_weight_grads": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_gru_chain_supported": (_I, [_I]),
+    "temp_gru_chain_pack_floats": (_SZ, [_I]),
+    "temp_gru_chain_pack": (_I, [_I, c_vp, c_vp, c_vp]),
+    "temp_gru_chain_fwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_chain_bwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_segment_sum_rows_workspace": (_SZ, [_I, _I, _I]),

@@ -243,6 +243,44 @@ class HipBackend:
         rc = self.lib.temp_gru_cell_bwd_multi(len(cells), arr, d, variant, float(lam), saved_all.shape[1] * d, _stream())
         _lib.check(rc, "temp_gru_cell_bwd_multi")
 
+    # ---- persistent window chain (include/temp_amd.h: TempGruChain) -------------------------------
+    def gru_chain_supported(self, d):
+        return bool(self.lib.temp_gru_chain_supported(int(d)))
+
+    def gru_chain_pack(self, w_hh):
+        """W_hh [3d, d] -> the chain kernels' fragment order (one small launch; the weights change every optimiser step)."""
+        w_hh = _f32(w_hh, "w_hh")
+        d = w_hh.shape[1]
+        out = torch.empty(self.lib.temp_gru_chain_pack_floats(d), dtype=torch.float32, device=w_hh.device)
+        _lib.check(self.lib.temp_gru_chain_pack(d, _ptr(w_hh), _ptr(out), _stream()), "temp_gru_chain_pack")
+        return out
+
+    def _chain_desc(self, tabs, d, variant, lam, plane, packs, b_hhs):
+        c = _lib.TempGruChain()
+        c.d, c.variant, c.n_panels, c.n_steps = d, variant, tabs["n_panels"], tabs["n_steps"]
+        c.panel, c.rows, c.sinfo, c.dt = (_i32(tabs[k], k).data_ptr() for k in ("panel", "rows", "sinfo", "dt_bits"))
+        c.lambda_, c.saved_plane, c.n_rnn = float(lam), plane, len(packs)
+        keep = []
+        for i, (pk, b) in enumerate(zip(packs, b_hhs)):
+            pk, b = _f32(pk, "packed"), _f32(b, "b_hh")
+            keep += [pk, b]
+            c.packed[i], c.b_hh[i] = pk.data_ptr(), b.data_ptr()
+        return c, keep
+
+    def gru_chain_fwd(self, tabs, gi, lam, variant, packs, b_hhs, h_out, saved_all):
+        d = saved_all.shape[2]
+        c, keep = self._chain_desc(tabs, d, variant, lam, saved_all.shape[1] * d, packs, b_hhs)
+        rc = self.lib.temp_gru_chain_fwd(ctypes.byref(c), _ptr(_f32(gi, "gi")), _ptr(h_out), _ptr(saved_all), _stream())
+        _lib.check(rc, "temp_gru_chain_fwd")
+
+    def gru_chain_bwd(self, tabs, saved_all, ups, lam, variant, packs, b_hhs, dgi, dgh):
+        d = saved_all.shape[2]
+        c, keep = self._chain_desc(tabs, d, variant, lam, saved_all.shape[1] * d, packs, b_hhs)
+        ups = [_f32(u, "upstream") for u in ups]
+        arr = (ctypes.c_void_p * max(len(ups), 1))(*[u.data_ptr() if u is not None else None for u in ups])
+        rc = self.lib.temp_gru_chain_bwd(ctypes.byref(c), _ptr(saved_all), len(ups), arr, _ptr(dgi), _ptr(dgh), _stream())
+        _lib.check(rc, "temp_gru_chain_bwd")
+
     def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
         n, d = x.shape
         w_ih = _f32(w_ih, "w_ih")

@@ -12,29 +12,42 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtemp_amd.so")
-SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip", "attn_kernels.hip"]
+SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip", "gru_chain.hip", "attn_kernels.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")] + [os.path.join(REPO, "include", "temp_amd.h")]
+OBJDIR = os.path.join(CSRC, "build")
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _newer(deps, target):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=True):
+    """One object per .hip source (recompiled only when it or a header changed, in parallel), then one link."""
     from . import _hostlib
     _hostlib.build(force=force, verbose=verbose)            # host planner (plain C++, g++): temp_amd/libtemp_host.so
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
-           "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print("[temp_amd.build] " + " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJDIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    objs, procs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer([src] + HEADERS, obj):
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print("[temp_amd.build] " + " ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if procs or force or _newer(objs, LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[temp_amd.build] " + " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

@@ -774,7 +774,8 @@ const char* temp_trace_kernel_name(int id) {
                                 "k_gemm_panel<loop_dx>", "k_gemm_tn", "k_reduce_slices", "k_colsum_part", "k_relu_bwd", "k_gru_fwd",
                                 "k_gru_bwd_gates", "k_gemm_panel<gru_dx>", "k_gemm_panel<gru_dprev>", "k_gather_rows",
                                 "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>", "k_gemm_panel<gru_gi>",
-                                "k_gemm_panel<linear>", "k_gather_ce", "k_sa_attn_fwd", "k_sa_attn_bwd"};
+                                "k_gemm_panel<linear>", "k_gather_ce", "k_sa_attn_fwd", "k_sa_attn_bwd", "k_gru_chain_fwd", "k_gru_chain_bwd",
+                                "k_gru_chain_pack"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 

@@ -1,0 +1,537 @@
+// Persistent window-chain kernels of the TeMP snapshot encoder on gfx950 (include/temp_amd.h: TempGruChain).
+//
+// The GRU recurrence over the train-seq-len window (models/DynamicRGCN.py:156-174, models/BiDynamicRGCN.py:51-100,
+// GRRGCNLayer.forward models/RRGCN.py:77-89) is independent per (window, direction, entity): position p of an entity
+// reads only that entity's state at position p-1.  A workgroup therefore owns a PANEL of 32 entity tracks, keeps the 32
+// current states in LDS and walks every position of the chain inside one launch -- no grid barrier, no relaunch, the
+// state never leaves the CU.  512 (forward) / 768 (backward) threads per workgroup, one workgroup per CU:
+//   waves 0-3  "matrix" role, one per SIMD:  acc[32 x tile] += W_hh-fragment x state-fragment on v_mfma_f32_32x32x2_f32.
+//              W_hh arrives straight from L2 in MFMA fragment order (packed once per step by k_gru_chain_pack: one
+//              coalesced 1-KB load per wave per 4 MFMAs per tile), the state fragment is one ds_read_b128 per 4 MFMAs of
+//              all tiles; the raw 32 x 3d products are handed over through LDS.
+//   waves 4+   "memory" role: everything that touches HBM.  The hoisted input gates (forward) / saved gate planes
+//              (backward) of the NEXT position are loaded into registers while the matrix waves work on the current one;
+//              after the hand-over barrier these waves apply the gates, write the saved planes / gate gradients with
+//              row-contiguous float4 stores and put the new state (resp. d_prev) back into LDS.
+// The matrix waves never wait on HBM: their only global loads are L2 hits on the packed weights.
+#include "common.hpp"
+#include "gru_math.hpp"
+
+namespace temp {
+
+#define CH_SLOTS TEMP_CHAIN_TRACKS
+#define CH_HAS_PREV TEMP_CHAIN_HAS_PREV
+#define CH_ROW_MASK (TEMP_CHAIN_HAS_PREV - 1)
+#define CH_LDS_LIMIT (160 * 1024)
+
+struct ChainRnn { const float4* wf; const float4* wb; const float* b_hh; };
+struct ChainArgs {
+  int D, n_panels;
+  const int32_t* panel; const int32_t* rows; const int32_t* sinfo;
+  const float* dt;
+  float lambda;
+  size_t plane;
+  ChainRnn rnn[TEMP_CHAIN_MAX_RNN];
+};
+struct ChainUps { const float* p[TEMP_CHAIN_MAX_UP]; };
+
+struct ChainGeom {
+  int NT, NQ;        // forward: tiles of 32 gate columns (3d), k-steps of 8 (d)
+  int NTb, NQb;      // backward: tiles of 32 state columns (d), k-steps of 8 (3d)
+  int lda, ldh;      // forward LDS strides (floats): product rows, state rows
+  int ldA, ldz;      // backward LDS strides: dgh rows, gz / d_prev rows
+};
+__host__ __device__ inline ChainGeom chain_geom(int D) {
+  ChainGeom g;
+  g.NT = (3 * D + 31) >> 5; g.NQ = (D + 7) >> 3;
+  g.NTb = (D + 31) >> 5; g.NQb = (3 * D + 7) >> 3;
+  g.lda = g.NT * 32 + 4; g.ldh = g.NQ * 8 + 4;          // (stride / 4) odd: conflict-free ds_read_b128 / ds_write_b128 across rows
+  g.ldA = g.NQb * 8 + 4; g.ldz = g.NTb * 32 + 4;
+  return g;
+}
+#define CH_MAX_STEPS 64      // steps of one panel (their flags are staged in LDS)
+inline size_t chain_lds_fwd(int D) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.lda + 2 * CH_SLOTS * g.ldh + 4 * CH_SLOTS + CH_MAX_STEPS) * 4; }
+inline size_t chain_lds_bwd(int D) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.ldA + 2 * CH_SLOTS * g.ldz + 4 * CH_SLOTS + CH_MAX_STEPS) * 4; }
+
+// ---- W_hh -> fragment order ---------------------------------------------------------------------------------------
+// forward  piece (tile, q, lane): float4 e -> W_hh[tile*32 + li][8q + 4hh + e]      (gate column x k)
+// backward piece (tile, q, lane): float4 e -> W_hh[8q + 4hh + e][tile*32 + li]      (k = gate column, state column)
+// zero outside the matrix.  li = lane & 31, hh = lane >> 5: the A-operand layout of v_mfma_f32_32x32x2_f32 (lane supplies
+// A[i = li][k = hh]); one float4 feeds 4 consecutive MFMAs, the state fragment uses the same k order.
+__global__ void __launch_bounds__(256) k_gru_chain_pack(int D, const float* __restrict__ W, float4* __restrict__ out) {
+  const ChainGeom g = chain_geom(D);
+  const int nf = g.NT * g.NQ * 64, nb = g.NTb * g.NQb * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+    const bool fwd = i < nf;
+    const int j = fwd ? i : i - nf;
+    const int lane = j & 63, rest = j >> 6;
+    const int nq = fwd ? g.NQ : g.NQb;
+    const int tile = rest / nq, q = rest - tile * nq;
+    const int n = tile * 32 + (lane & 31), k = 8 * q + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (fwd) v[e] = (n < 3 * D && k + e < D) ? W[(size_t)n * D + k + e] : 0.f;
+      else v[e] = (n < D && k + e < 3 * D) ? W[(size_t)(k + e) * D + n] : 0.f;
+    }
+    out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ---- forward --------------------------------------------------------------------------------------------------------
+// TPW = tiles per matrix wave (ceil(NT / 4)), MW = memory waves (4 or 8).
+template <int VARIANT, int TPW, int MW>
+__global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, const float* __restrict__ gi, float* __restrict__ H,
+                                                                  float* __restrict__ saved) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int PASSES = CH_SLOTS / MW;
+  const int D = a.D, D4 = D >> 2;
+  const int G = (VARIANT == TEMP_GRU_TORCH) ? 3 * D : D;
+  const ChainGeom g = chain_geom(D);
+  const int NT = g.NT, NQ = g.NQ, lda = g.lda, ldh = g.ldh;
+  float* accb = lds;                                   // [32][lda]  raw products of the current position
+  float* hb = accb + CH_SLOTS * lda;                   // [2][32][ldh] states (double buffered)
+  int* rowb = (int*)(hb + 2 * CH_SLOTS * ldh);         // [2][32] row table entries of the current / next position
+  float* decb = (float*)(rowb + 2 * CH_SLOTS);         // [2][32] decay factors
+  int* flagb = (int*)(decb + 2 * CH_SLOTS);            // [CH_MAX_STEPS] step flags of the panel
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const size_t plane = a.plane;
+
+  for (int p = blockIdx.x; p < a.n_panels; p += gridDim.x) {
+    const int rnn_id = a.panel[4 * p], s0 = a.panel[4 * p + 1], ns = a.panel[4 * p + 2];
+    const ChainRnn R = a.rnn[rnn_id];
+    for (int i = tid; i < 2 * CH_SLOTS * ldh; i += blockDim.x) hb[i] = 0.f;      // k padding of the state rows must be 0, not NaN
+    if (tid < CH_SLOTS) {
+      const int e = a.rows[(size_t)s0 * CH_SLOTS + tid];
+      rowb[tid] = e;
+      decb[tid] = e >= 0 ? expf(-a.dt[e & CH_ROW_MASK] * a.lambda) : 0.f;
+    }
+    if (tid >= 64 && tid < 64 + ns) flagb[tid - 64] = a.sinfo[4 * (size_t)(s0 + tid - 64)];
+    __syncthreads();
+
+    if (wave < 4) {
+      // ------------------------------------------------------------------ matrix role
+      const int li = lane & 31, hh = lane >> 5;
+      bool tval[TPW];
+      int tidx[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) { tidx[j] = wave + 4 * j; tval[j] = tidx[j] < NT; if (!tval[j]) tidx[j] = NT - 1; }
+      f32x16 acc[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      float4 wA[TPW], wB[TPW];
+      auto wload = [&](float4 (&w)[TPW], int q) {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) w[j] = R.wf[((size_t)tidx[j] * NQ + q) * 64 + lane];
+      };
+      wload(wA, 0);
+      for (int s = 0; s < ns; ++s) {
+        const int cur = s & 1;
+        const int flags = flagb[s];
+        if (flags & 1) {
+          const int e = rowb[cur * CH_SLOTS + li];
+          const bool ok = e >= 0 && (e & CH_HAS_PREV);
+          const float dec = decb[cur * CH_SLOTS + li];
+          const float* hrow = hb + (size_t)cur * CH_SLOTS * ldh + li * ldh + 4 * hh;
+          auto stage = [&](const float4 (&w)[TPW], int q) {
+            float4 h4 = ld4(hrow + 8 * q);
+            h4 = ok ? scale4(h4, dec) : zero4();                      // decayed previous state (models/RRGCN.py:83)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].x, h4.x, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].y, h4.y, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].z, h4.z, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, h4.w, acc[j], 0, 0, 0);
+          };
+          for (int q = 0; q < NQ; q += 2) {
+            wload(wB, q + 1 < NQ ? q + 1 : NQ - 1);
+            stage(wA, q);
+            wload(wA, q + 2 < NQ ? q + 2 : 0);                        // past the end: stage 0 of the NEXT position
+            if (q + 1 < NQ) stage(wB, q + 1);
+          }
+          // lane (li, hh) owns track li and, per register quad qq, gate columns tile*32 + 8qq + 4hh .. +3
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            if (!tval[j]) continue;
+            float* dst = accb + (size_t)li * lda + tidx[j] * 32 + 4 * hh;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              st4(dst + 8 * qq, make_float4(acc[j][4 * qq], acc[j][4 * qq + 1], acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
+              acc[j][4 * qq] = 0.f; acc[j][4 * qq + 1] = 0.f; acc[j][4 * qq + 2] = 0.f; acc[j][4 * qq + 3] = 0.f;
+            }
+          }
+        }
+        __syncthreads();      // A: products of position s are in LDS
+        __syncthreads();      // B: states of position s (and the row table of s + 1) are in LDS
+      }
+    } else {
+      // ------------------------------------------------------------------ memory role
+      const int mw = wave - 4, c4 = lane, col = 4 * c4;
+      const bool cact = c4 < D4;
+      float4 bhr = zero4(), bhz = zero4(), bhn = zero4();
+      if (cact) { bhr = ld4(R.b_hh + col); bhz = ld4(R.b_hh + D + col); bhn = ld4(R.b_hh + 2 * D + col); }
+      int erow[PASSES];
+      float4 g0[PASSES], g1[PASSES], g2[PASSES];
+      auto prefetch = [&](int s) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int e = a.rows[(size_t)(s0 + s) * CH_SLOTS + ps * MW + mw];
+          erow[ps] = e;
+          const bool ok = e >= 0 && cact;
+          const float* src = gi + (ok ? (size_t)(e & CH_ROW_MASK) * G + col : 0);
+          if (VARIANT == TEMP_GRU_TORCH) { g0[ps] = ld4(src); g1[ps] = ld4(src + (ok ? D : 0)); g2[ps] = ld4(src + (ok ? 2 * D : 0)); }
+          else { g0[ps] = zero4(); g1[ps] = zero4(); g2[ps] = ld4(src); }
+        }
+      };
+      prefetch(0);
+      int ne = -1;               // (first memory wave, lanes < 32) table entry / decay of the NEXT position
+      float ndec = 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const int cur = s & 1;
+        const int flags = flagb[s];
+        if (mw == 0 && lane < CH_SLOTS && s + 1 < ns) {
+          ne = a.rows[(size_t)(s0 + s + 1) * CH_SLOTS + lane];
+          ndec = ne >= 0 ? expf(-a.dt[ne & CH_ROW_MASK] * a.lambda) : 0.f;
+        }
+        __syncthreads();      // A
+        const float* hcur = hb + (size_t)cur * CH_SLOTS * ldh;
+        float* hnext = hb + (size_t)(cur ^ 1) * CH_SLOTS * ldh;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int slot = ps * MW + mw;
+          const int e = erow[ps];
+          if (e < 0 || !cact) continue;
+          const size_t row = (size_t)(e & CH_ROW_MASK);
+          const bool hp = (e & CH_HAS_PREV) != 0;
+          float4 ar = zero4(), az = zero4(), an = zero4(), hd = zero4();
+          if (hp) {                                   // (a track without a previous state contributed zeros to the products)
+            const float* ab = accb + (size_t)slot * lda + col;
+            ar = ld4(ab); az = ld4(ab + D); an = ld4(ab + 2 * D);
+            hd = scale4(ld4(hcur + (size_t)slot * ldh + col), decb[cur * CH_SLOTS + slot]);
+          }
+          float o_h[4], o_r[4], o_z[4], o_n[4], o_hn[4];
+          const float arv[4] = {ar.x, ar.y, ar.z, ar.w}, azv[4] = {az.x, az.y, az.z, az.w}, anv[4] = {an.x, an.y, an.z, an.w};
+          const float hdv[4] = {hd.x, hd.y, hd.z, hd.w};
+          const float g0v[4] = {g0[ps].x, g0[ps].y, g0[ps].z, g0[ps].w}, g1v[4] = {g1[ps].x, g1[ps].y, g1[ps].z, g1[ps].w};
+          const float g2v[4] = {g2[ps].x, g2[ps].y, g2[ps].z, g2[ps].w};
+          const float brv[4] = {bhr.x, bhr.y, bhr.z, bhr.w}, bzv[4] = {bhz.x, bhz.y, bhz.z, bhz.w}, bnv[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float xr = arv[k], xz = azv[k];
+            if (VARIANT == TEMP_GRU_TORCH) { xr += g0v[k]; xz += g1v[k]; }
+            const float rg = gate_sigmoid(xr + brv[k]);
+            const float zg = gate_sigmoid(xz + bzv[k]);
+            const float hn = anv[k] + bnv[k];
+            const float ng = gate_tanh(g2v[k] + rg * hn);
+            o_h[k] = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg) * ng + zg * hdv[k]) : (ng + zg * (hdv[k] - ng));
+            o_r[k] = rg; o_z[k] = zg; o_n[k] = ng; o_hn[k] = hn;
+          }
+          const float4 h4 = make_float4(o_h[0], o_h[1], o_h[2], o_h[3]);
+          st4(hnext + (size_t)slot * ldh + col, h4);
+          const size_t o = row * D + col;
+          if (flags & 2) st4(H + o, h4);
+          st4(saved + o, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
+          st4(saved + plane + o, make_float4(o_z[0], o_z[1], o_z[2], o_z[3]));
+          st4(saved + 2 * plane + o, make_float4(o_n[0], o_n[1], o_n[2], o_n[3]));
+          st4(saved + 3 * plane + o, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
+          st4(saved + 4 * plane + o, hd);
+        }
+        if (mw == 0 && lane < CH_SLOTS && s + 1 < ns) { rowb[(cur ^ 1) * CH_SLOTS + lane] = ne; decb[(cur ^ 1) * CH_SLOTS + lane] = ndec; }
+        if (s + 1 < ns) prefetch(s + 1);       // in flight while the matrix waves run position s + 1
+        __syncthreads();      // B
+      }
+    }
+    __syncthreads();          // LDS is re-initialised for the next panel
+  }
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------------
+template <int VARIANT, int TPWB, int MW>
+__global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, ChainUps ups, const float* __restrict__ saved,
+                                                                  float* __restrict__ dgi, float* __restrict__ dgh) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int PASSES = CH_SLOTS / MW;
+  const int D = a.D, D4 = D >> 2;
+  const int G = (VARIANT == TEMP_GRU_TORCH) ? 3 * D : D;
+  const ChainGeom g = chain_geom(D);
+  const int NTb = g.NTb, NQb = g.NQb, ldA = g.ldA, ldz = g.ldz;
+  float* ab = lds;                                     // [32][ldA]  gate gradients w.r.t. the recurrent pre-activations (dgh)
+  float* gzb = ab + CH_SLOTS * ldA;                    // [32][ldz]  dh * z
+  float* dpb = gzb + CH_SLOTS * ldz;                   // [32][ldz]  d_prev of the position just processed
+  float* decb = dpb + CH_SLOTS * ldz;                  // [2][32]
+  int* flagb = (int*)(decb + 4 * CH_SLOTS);            // [CH_MAX_STEPS]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const size_t plane = a.plane;
+
+  for (int p = blockIdx.x; p < a.n_panels; p += gridDim.x) {
+    const int rnn_id = a.panel[4 * p], s0 = a.panel[4 * p + 1], ns = a.panel[4 * p + 2];
+    const ChainRnn R = a.rnn[rnn_id];
+    for (int i = tid; i < CH_SLOTS * ldA; i += blockDim.x) ab[i] = 0.f;          // k padding of the dgh rows
+    if (tid < ns) flagb[tid] = a.sinfo[4 * (size_t)(s0 + tid)];
+    __syncthreads();
+
+    if (wave < 4) {
+      // ------------------------------------------------------------------ matrix role: d_prev = (dgh . W_hh + dh*z) * decay
+      const int li = lane & 31, hh = lane >> 5;
+      bool tval[TPWB];
+      int tidx[TPWB];
+#pragma unroll
+      for (int j = 0; j < TPWB; ++j) { tidx[j] = wave + 4 * j; tval[j] = tidx[j] < NTb; if (!tval[j]) tidx[j] = NTb - 1; }
+      f32x16 acc[TPWB];
+#pragma unroll
+      for (int j = 0; j < TPWB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      float4 wA[TPWB], wB[TPWB];
+      auto wload = [&](float4 (&w)[TPWB], int q) {
+#pragma unroll
+        for (int j = 0; j < TPWB; ++j) w[j] = R.wb[((size_t)tidx[j] * NQb + q) * 64 + lane];
+      };
+      wload(wA, 0);
+      for (int s = ns - 1; s >= 0; --s) {
+        const int cur = s & 1;
+        const int flags = flagb[s];
+        __syncthreads();      // A: dgh / dh*z / decay of position s are in LDS
+        if (flags & 1) {
+          const float* arow = ab + (size_t)li * ldA + 4 * hh;
+          auto stage = [&](const float4 (&w)[TPWB], int q) {
+            const float4 d4 = ld4(arow + 8 * q);
+#pragma unroll
+            for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].x, d4.x, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].y, d4.y, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].z, d4.z, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, d4.w, acc[j], 0, 0, 0);
+          };
+          for (int q = 0; q < NQb; q += 2) {
+            wload(wB, q + 1 < NQb ? q + 1 : NQb - 1);
+            stage(wA, q);
+            wload(wA, q + 2 < NQb ? q + 2 : 0);
+            if (q + 1 < NQb) stage(wB, q + 1);
+          }
+          const float dec = decb[cur * CH_SLOTS + li];
+#pragma unroll
+          for (int j = 0; j < TPWB; ++j) {
+            if (!tval[j]) continue;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const int c = tidx[j] * 32 + 8 * qq + 4 * hh;
+              const float4 gz = ld4(gzb + (size_t)li * ldz + c);
+              st4(dpb + (size_t)li * ldz + c, make_float4((acc[j][4 * qq] + gz.x) * dec, (acc[j][4 * qq + 1] + gz.y) * dec,
+                                                           (acc[j][4 * qq + 2] + gz.z) * dec, (acc[j][4 * qq + 3] + gz.w) * dec));
+              acc[j][4 * qq] = 0.f; acc[j][4 * qq + 1] = 0.f; acc[j][4 * qq + 2] = 0.f; acc[j][4 * qq + 3] = 0.f;
+            }
+          }
+        }
+        __syncthreads();      // B: d_prev of position s is in LDS
+      }
+    } else {
+      // ------------------------------------------------------------------ memory role: gate gradients
+      const int mw = wave - 4, c4 = lane, col = 4 * c4;
+      const bool cact = c4 < D4;
+      int erow[PASSES];
+      bool nxt[PASSES];
+      float4 sr[PASSES], sz[PASSES], sn[PASSES], shn[PASSES], shd[PASSES];
+      auto prefetch = [&](int s) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int slot = ps * MW + mw;
+          const int e = a.rows[(size_t)(s0 + s) * CH_SLOTS + slot];
+          erow[ps] = e;
+          int en = -1;
+          if (s + 1 < ns) en = a.rows[(size_t)(s0 + s + 1) * CH_SLOTS + slot];
+          nxt[ps] = en >= 0 && (en & CH_HAS_PREV);
+          const bool ok = e >= 0 && cact;
+          const size_t row = ok ? (size_t)(e & CH_ROW_MASK) : 0;
+          const float* src = saved + row * D + (ok ? col : 0);
+          sr[ps] = ld4(src); sz[ps] = ld4(src + plane); sn[ps] = ld4(src + 2 * plane); shn[ps] = ld4(src + 3 * plane);
+          shd[ps] = ld4(src + 4 * plane);
+        }
+      };
+      float cdec = 0.f;          // (first memory wave, lanes < 32) decay of the track's row at the position about to be processed
+      auto prefetch_dec = [&](int s) {
+        if (mw == 0 && lane < CH_SLOTS) {
+          const int e = a.rows[(size_t)(s0 + s) * CH_SLOTS + lane];
+          cdec = e >= 0 ? expf(-a.dt[e & CH_ROW_MASK] * a.lambda) : 0.f;
+        }
+      };
+      prefetch(ns - 1);
+      prefetch_dec(ns - 1);
+      for (int s = ns - 1; s >= 0; --s) {
+        const int cur = s & 1;
+        // upstream gradient of the step's rows (only the positions whose states are consumed outside the chain -- the
+        // target, the last history position -- have one: loaded on demand instead of holding registers for it all the time)
+        const int up_sel = a.sinfo[4 * (size_t)(s0 + s) + 1], up_row0 = a.sinfo[4 * (size_t)(s0 + s) + 2];
+        const float* upp = up_sel >= 0 ? ups.p[up_sel] : nullptr;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int slot = ps * MW + mw;
+          const int e = erow[ps];
+          if (!cact) continue;
+          if (e < 0) continue;                 // idle track: whatever its LDS rows hold only reaches its own, unread, d_prev row
+          const size_t row = (size_t)(e & CH_ROW_MASK);
+          float4 gd = upp ? ld4(upp + (row - (size_t)up_row0) * D + col) : zero4();
+          if (nxt[ps]) gd = add4(gd, ld4(dpb + (size_t)slot * ldz + col));
+          const float4 rg = sr[ps], zg = sz[ps], ng = sn[ps], hn = shn[ps], hd = shd[ps];
+          float4 dr_pre, dz_pre, dn_pre, dhn, gz;
+#define TEMP_GATE(c)                                          \
+          {                                                   \
+            const float dn = gd.c * (1.f - zg.c);             \
+            const float dz = gd.c * (hd.c - ng.c);            \
+            dn_pre.c = dn * (1.f - ng.c * ng.c);              \
+            dr_pre.c = dn_pre.c * hn.c * rg.c * (1.f - rg.c); \
+            dz_pre.c = dz * zg.c * (1.f - zg.c);              \
+            dhn.c = dn_pre.c * rg.c;                          \
+            gz.c = gd.c * zg.c;                               \
+          }
+          TEMP_GATE(x) TEMP_GATE(y) TEMP_GATE(z) TEMP_GATE(w)
+#undef TEMP_GATE
+          float* arow = ab + (size_t)slot * ldA + col;
+          st4(arow, dr_pre); st4(arow + D, dz_pre); st4(arow + 2 * D, dhn);
+          st4(gzb + (size_t)slot * ldz + col, gz);
+          const size_t b3 = row * 3 * D + col;
+          if (VARIANT == TEMP_GRU_TORCH) { st4(dgi + b3, dr_pre); st4(dgi + b3 + D, dz_pre); st4(dgi + b3 + 2 * D, dn_pre); }
+          else st4(dgi + row * D + col, dn_pre);
+          st4(dgh + b3, dr_pre); st4(dgh + b3 + D, dz_pre); st4(dgh + b3 + 2 * D, dhn);
+        }
+        if (mw == 0 && lane < CH_SLOTS) decb[cur * CH_SLOTS + lane] = cdec;
+        if (s > 0) { prefetch(s - 1); prefetch_dec(s - 1); }      // in flight while the matrix waves run position s
+        __syncthreads();      // A
+        __syncthreads();      // B
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int chain_check(const TempGruChain* c) {
+  if (!c || c->d <= 0 || c->n_panels < 0 || c->n_steps < 0 || c->n_rnn <= 0 || c->n_rnn > TEMP_CHAIN_MAX_RNN) return TEMP_E_BADARG;
+  if (c->variant != TEMP_GRU_TORCH && c->variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
+  if (c->n_panels > 0 && (!c->panel || !c->rows || !c->sinfo || !c->dt)) return TEMP_E_BADARG;
+  for (int i = 0; i < c->n_rnn; ++i) if (!c->packed[i] || !c->b_hh[i]) return TEMP_E_BADARG;
+  if (!temp_gru_chain_supported(c->d)) return TEMP_E_UNSUPPORTED;
+  return TEMP_OK;
+}
+
+static ChainArgs chain_args(const TempGruChain* c) {
+  ChainArgs a = {};
+  const ChainGeom g = chain_geom(c->d);
+  a.D = c->d; a.n_panels = c->n_panels; a.panel = c->panel; a.rows = c->rows; a.sinfo = c->sinfo; a.dt = c->dt;
+  a.lambda = c->lambda; a.plane = c->saved_plane;
+  for (int i = 0; i < c->n_rnn; ++i) {
+    a.rnn[i].wf = (const float4*)c->packed[i];
+    a.rnn[i].wb = (const float4*)c->packed[i] + (size_t)g.NT * g.NQ * 64;
+    a.rnn[i].b_hh = c->b_hh[i];
+  }
+  return a;
+}
+
+template <class K>
+static int chain_lds_attr(K kernel, size_t bytes, bool* done) {
+  if (*done) return TEMP_OK;
+  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_LIMIT) != hipSuccess) return TEMP_E_LAUNCH;
+  (void)bytes;
+  *done = true;
+  return TEMP_OK;
+}
+
+template <int VARIANT, int TPW>
+static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float* saved, hipStream_t st) {
+  static bool attr = false;
+  auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4>;
+  const size_t lds = chain_lds_fwd(a.D);
+  int rc = chain_lds_attr(kernel, lds, &attr);
+  if (rc) return rc;
+  TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds, st, a, gi, h, saved);
+  return launch_status();
+}
+
+template <int VARIANT, int TPWB>
+static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float* saved, float* dgi, float* dgh, hipStream_t st) {
+  static bool attr = false;
+  auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8>;
+  const size_t lds = chain_lds_bwd(a.D);
+  int rc = chain_lds_attr(kernel, lds, &attr);
+  if (rc) return rc;
+  TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds, st, a, ups, saved, dgi, dgh);
+  return launch_status();
+}
+
+}  // namespace temp
+
+using namespace temp;
+
+extern "C" {
+
+int temp_gru_chain_supported(int d) {
+  if (d <= 0 || d % 4) return 0;
+  return chain_lds_fwd(d) <= CH_LDS_LIMIT && chain_lds_bwd(d) <= CH_LDS_LIMIT && chain_geom(d).NT <= 24 && chain_geom(d).NTb <= 8;
+}
+
+size_t temp_gru_chain_pack_floats(int d) {
+  if (d <= 0) return 0;
+  const ChainGeom g = chain_geom(d);
+  return ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64 * 4;
+}
+
+int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream) {
+  if (d <= 0 || !w_hh || !packed) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  const size_t n4 = temp_gru_chain_pack_floats(d) / 4;
+  int gx = ceil_div((long long)n4, 256);
+  if (gx > 1024) gx = 1024;
+  TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_gru_chain_pack, dim3(gx), dim3(256), 0, (hipStream_t)stream, d, w_hh, (float4*)packed);
+  return launch_status();
+}
+
+int temp_gru_chain_fwd(const TempGruChain* c, const float* gi, float* h_out, float* saved, void* stream) {
+  int rc = chain_check(c);
+  if (rc) return rc;
+  if (c->n_panels == 0) return TEMP_OK;
+  if (!gi || !h_out || !saved) return TEMP_E_BADARG;
+  const ChainArgs a = chain_args(c);
+  hipStream_t st = (hipStream_t)stream;
+  const int tpw = ceil_div(chain_geom(c->d).NT, 4);
+#define TEMP_CHAIN_FWD(V)                                                            \
+  switch (tpw) {                                                                     \
+    case 1: return launch_chain_fwd<V, 1>(a, gi, h_out, saved, st);                  \
+    case 2: return launch_chain_fwd<V, 2>(a, gi, h_out, saved, st);                  \
+    case 3: return launch_chain_fwd<V, 3>(a, gi, h_out, saved, st);                  \
+    case 4: return launch_chain_fwd<V, 4>(a, gi, h_out, saved, st);                  \
+    case 5: return launch_chain_fwd<V, 5>(a, gi, h_out, saved, st);                  \
+    case 6: return launch_chain_fwd<V, 6>(a, gi, h_out, saved, st);                  \
+    default: return TEMP_E_UNSUPPORTED;                                              \
+  }
+  if (c->variant == TEMP_GRU_TORCH) { TEMP_CHAIN_FWD(TEMP_GRU_TORCH) }
+  TEMP_CHAIN_FWD(TEMP_GRU_TYPE1)
+#undef TEMP_CHAIN_FWD
+}
+
+int temp_gru_chain_bwd(const TempGruChain* c, const float* saved, int n_up, const float* const* up, float* dgi, float* dgh, void* stream) {
+  int rc = chain_check(c);
+  if (rc) return rc;
+  if (n_up < 0 || n_up > TEMP_CHAIN_MAX_UP || (n_up > 0 && !up)) return TEMP_E_BADARG;
+  if (c->n_panels == 0) return TEMP_OK;
+  if (!saved || !dgi || !dgh) return TEMP_E_BADARG;
+  const ChainArgs a = chain_args(c);
+  ChainUps ups = {};
+  for (int i = 0; i < n_up; ++i) ups.p[i] = up[i];
+  hipStream_t st = (hipStream_t)stream;
+  const int tpw = ceil_div(chain_geom(c->d).NTb, 4);
+  if (c->variant == TEMP_GRU_TORCH) {
+    if (tpw == 1) return launch_chain_bwd<TEMP_GRU_TORCH, 1>(a, ups, saved, dgi, dgh, st);
+    if (tpw == 2) return launch_chain_bwd<TEMP_GRU_TORCH, 2>(a, ups, saved, dgi, dgh, st);
+  } else {
+    if (tpw == 1) return launch_chain_bwd<TEMP_GRU_TYPE1, 1>(a, ups, saved, dgi, dgh, st);
+    if (tpw == 2) return launch_chain_bwd<TEMP_GRU_TYPE1, 2>(a, ups, saved, dgi, dgh, st);
+  }
+  return TEMP_E_UNSUPPORTED;
+}
+
+}  // extern "C"

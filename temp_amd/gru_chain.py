@@ -20,6 +20,9 @@ from . import _lib
 from .backend import get_backend
 
 
+CHAIN_KERNELS = True        # A/B switch: False keeps the per-position launches (temp_gru_cell_*_multi)
+
+
 class GruInstance:
     __slots__ = ("n", "x0", "h0", "rnn", "prev", "next", "prev_idx", "next_idx", "dt", "group")
 
@@ -74,6 +77,120 @@ class GruProgram:
                 self.levels.append(idx[k:k + 4])
         self.dev = None
 
+    # ---- persistent chain kernels: panels of 32 entity tracks (include/temp_amd.h: TempGruChain) ------------------------
+    def chain_plan(self):
+        """Host half of the persistent-chain tables, independent of `want` and cached: every row of every instance gets a
+        TRACK -- it inherits its predecessor's (prev_idx >= 0), otherwise takes the lowest track that no row of its instance
+        inherits (a state survives exactly one position, so a track whose entity was absent is free again) -- and tracks are
+        cut into panels of 32.  A panel's steps are the positions at which it has a row; a position where the whole panel is
+        idle is dropped (none of its tracks can carry a state across it).
+        -> None when the program is not a set of chains with one GRU each (the per-position kernels are used then), else
+           dict(panel [P,4], rows [S,32], any_prev [S], step_inst [S])."""
+        if getattr(self, "_chain_plan", False) is not False:
+            return self._chain_plan
+        inst = self.inst
+        T = _lib.CHAIN_TRACKS
+        panel, rows_tab, any_prev, step_inst = [], [], [], []
+        s_base = 0
+        plan = None
+        ok = any(it.prev >= 0 and it.n > 0 for it in inst)            # at least one real recurrence step
+        for head, it0 in enumerate(inst):
+            if not ok:
+                break
+            if it0.prev >= 0:
+                continue
+            chain = [head]
+            while inst[chain[-1]].next >= 0:
+                chain.append(inst[chain[-1]].next)
+            chain = [i for i in chain]
+            if any(inst[i].rnn != it0.rnn for i in chain):
+                ok = False
+                break
+            n_tracks, prev_tr, steps = 0, None, []
+            for k, i in enumerate(chain):
+                it = inst[i]
+                tr = np.full(it.n, -1, dtype=np.int64)
+                has = np.zeros(it.n, dtype=bool)
+                if k > 0 and it.n:
+                    pi = np.asarray(it.prev_idx, dtype=np.int64)
+                    has = pi >= 0
+                    tr[has] = prev_tr[pi[has]]
+                new = np.nonzero(~has)[0]
+                if new.size:
+                    used = np.zeros(n_tracks, dtype=bool)
+                    used[tr[has]] = True
+                    free = np.nonzero(~used)[0]
+                    take = min(free.size, new.size)
+                    tr[new[:take]] = free[:take]
+                    extra = new.size - take
+                    if extra:
+                        tr[new[take:]] = n_tracks + np.arange(extra)
+                        n_tracks += extra
+                steps.append((i, tr, has))
+                prev_tr = tr
+            if n_tracks == 0:
+                continue
+            n_pan = (n_tracks + T - 1) // T
+            tab = np.full((len(chain), n_pan * T), -1, dtype=np.int64)
+            for k, (i, tr, has) in enumerate(steps):
+                if tr.size:
+                    tab[k, tr] = (inst[i].h0 + np.arange(tr.size)) | (has.astype(np.int64) << 30)
+            tab = tab.reshape(len(chain), n_pan, T)
+            active = (tab >= 0).any(axis=2)                              # [K, P]
+            anyp = ((tab >= 0) & ((tab >> 30) & 1).astype(bool)).any(axis=2)
+            act_t = active.T                                             # panel-major, position-minor
+            counts = act_t.sum(axis=1)
+            if counts.max() > _lib.CHAIN_MAX_STEPS:
+                ok = False
+                break
+            first = s_base + np.concatenate([[0], np.cumsum(counts)[:-1]])
+            panel.append(np.stack([np.full(n_pan, it0.rnn), first, counts, np.zeros(n_pan, dtype=np.int64)], axis=1))
+            rows_tab.append(tab.transpose(1, 0, 2)[act_t])
+            any_prev.append(anyp.T[act_t])
+            step_inst.append(np.broadcast_to(np.asarray(chain)[None, :], act_t.shape)[act_t])
+            s_base += int(counts.sum())
+        if ok and panel:
+            pn = np.concatenate(panel)
+            pn = pn[pn[:, 2] > 0]
+            plan = dict(panel=pn.astype(np.int32), rows=np.concatenate(rows_tab).astype(np.int32),
+                        any_prev=np.concatenate(any_prev), step_inst=np.concatenate(step_inst).astype(np.int64))
+        self._chain_plan = plan
+        return plan
+
+    def chain_tables(self, device, want):
+        """Device tables of the persistent chain kernels for one set of consumed instances (`want`: the instances whose
+        states are handed out -- their rows are written to H and receive an upstream gradient; None = all rows, one dense
+        gradient).  One packed upload, cached per (device, want)."""
+        plan = self.chain_plan()
+        if plan is None or (want is not None and len(want) > _lib.CHAIN_MAX_UP):
+            return None
+        cache = self.__dict__.setdefault("_chain_tabs", {})
+        key = (str(device), want)
+        tabs = cache.get(key)
+        if tabs is None:
+            S = plan["rows"].shape[0]
+            sinfo = np.zeros((S, 4), dtype=np.int32)
+            si = plan["step_inst"]
+            if want is None:
+                sinfo[:, 0] = plan["any_prev"].astype(np.int32) | 2
+            else:
+                sel = np.full(len(self.inst), -1, dtype=np.int32)
+                sel[list(want)] = np.arange(len(want), dtype=np.int32)
+                h0 = np.array([it.h0 for it in self.inst], dtype=np.int32)
+                sinfo[:, 0] = plan["any_prev"].astype(np.int32) | np.where(sel[si] >= 0, 2, 0)
+                sinfo[:, 1] = sel[si]
+                sinfo[:, 2] = np.where(sel[si] >= 0, h0[si], 0)
+            dt = np.zeros(self.n_total, dtype=np.float32)
+            for it in self.inst:
+                if it.n:
+                    dt[it.h0:it.h0 + it.n] = np.asarray(it.dt, dtype=np.float32).reshape(-1)
+            parts = [plan["panel"].reshape(-1), plan["rows"].reshape(-1), sinfo.reshape(-1), dt.view(np.int32)]
+            buf = _lib.to_device(np.concatenate(parts), device)
+            cuts = np.cumsum([0] + [p.size for p in parts])
+            tabs = cache[key] = dict(n_panels=int(plan["panel"].shape[0]), n_steps=int(S), panel=buf[cuts[0]:cuts[1]], rows=buf[cuts[1]:cuts[2]],
+                                     sinfo=buf[cuts[2]:cuts[3]], dt_bits=buf[cuts[3]:cuts[4]])
+        return tabs
+
     def constants(self, device, d):
         """(zero previous-state row, all -1 row map long enough for any first-position instance), created once per program."""
         key = (str(device), int(d))
@@ -117,15 +234,24 @@ class _GruChainFn(torch.autograd.Function):
         N = prog.n_total
         x_all = x_all.detach().contiguous()
         W = [tuple(w.detach().contiguous() for w in weights[4 * r:4 * r + 4]) for r in range(n_rnn)]   # (w_ih, w_hh, b_ih, b_hh)
-        tens = prog.upload(dev)
+        # persistent chain kernels (one launch for ALL positions) when the backend has them and the program is a set of chains
+        tabs = None
+        if CHAIN_KERNELS and hasattr(be, "gru_chain_fwd") and n_rnn <= _lib.CHAIN_MAX_RNN and be.gru_chain_supported(d):
+            tabs = prog.chain_tables(dev, want)
         gi = torch.empty(N, G, dtype=torch.float32, device=dev)
         for g in prog.groups:
             w_ih, _, b_ih, _ = W[g["rnn"]]
             be.gru_input_gates(x_all[g["x0"]:g["x1"]], w_ih, b_ih, variant, gi[g["h0"]:g["h1"]])
         H = torch.empty(N, d, dtype=torch.float32, device=dev)
         saved = torch.empty(5, N, d, dtype=torch.float32, device=dev)
-        zero, none_idx = prog.constants(dev, d)
-        for level in prog.levels:
+        packs = None
+        if tabs is not None:
+            packs = [be.gru_chain_pack(W[r][1]) for r in range(n_rnn)]
+            be.gru_chain_fwd(tabs, gi, lam, variant, packs, [W[r][3] for r in range(n_rnn)], H, saved)
+        else:
+            tens = prog.upload(dev)
+            zero, none_idx = prog.constants(dev, d)
+        for level in (prog.levels if tabs is None else ()):
             cells = []
             for i in level:
                 it = prog.inst[i]
@@ -141,6 +267,7 @@ class _GruChainFn(torch.autograd.Function):
             be.gru_cell_fwd_multi(cells, lam, variant, saved)
         ctx.save_for_backward(x_all, saved, *[w for ws in W for w in ws])
         ctx.prog, ctx.lam, ctx.variant, ctx.n_rnn, ctx.G, ctx.want = prog, lam, variant, n_rnn, G, want
+        ctx.tabs, ctx.packs = tabs, packs
         if want is None:
             return H
         # only these instances' states are consumed downstream: hand them out as row ranges of H, so that the backward receives
@@ -161,12 +288,16 @@ class _GruChainFn(torch.autograd.Function):
         else:
             given = {i: g.contiguous() for i, g in zip(ctx.want, d_outs) if g is not None}
             up = lambda i, it: given.get(i)                  # None: no upstream gradient for this instance's rows
-        tens = prog.upload(dev)
         dgi = torch.empty(N, G, dtype=torch.float32, device=dev)
         dgh = torch.empty(N, 3 * d, dtype=torch.float32, device=dev)
-        decv = torch.empty(N, dtype=torch.float32, device=dev)
-        d_prev = torch.empty(N, d, dtype=torch.float32, device=dev)
-        for level in reversed(prog.levels):
+        if ctx.tabs is not None:
+            ups = [dH] if ctx.want is None else [given.get(i) for i in ctx.want]
+            be.gru_chain_bwd(ctx.tabs, saved, ups, lam, variant, ctx.packs, [W[r][3] for r in range(ctx.n_rnn)], dgi, dgh)
+        else:
+            tens = prog.upload(dev)
+            decv = torch.empty(N, dtype=torch.float32, device=dev)
+            d_prev = torch.empty(N, d, dtype=torch.float32, device=dev)
+        for level in (reversed(prog.levels) if ctx.tabs is None else ()):
             cells = []
             for i in level:
                 it = prog.inst[i]

@@ -197,6 +197,8 @@ class CpuTestBackend:
         if prev is None:                                        # zero-state cell
             prev, prev_idx = torch.zeros(n, d), None
         prev, w_hh, b_hh = prev.detach(), w_hh.detach(), b_hh.detach()
+        if prev.shape[0] == 0:                                  # the previous position was empty: every row map entry is -1
+            prev = torch.zeros(1, d)
         if prev_idx is not None:
             idx = prev_idx.long()
             rows = prev[idx.clamp(min=0)] * (idx >= 0).to(prev.dtype).view(-1, 1)
@@ -242,6 +244,80 @@ class CpuTestBackend:
         for c in cells:
             self.gru_cell_bwd(saved_all, c["row0"], c["n"], c["dh_up"], c["d_prev_next"], c["next_idx"], c["dt"], lam, c["w_hh"], variant,
                               c["dgi"], c["dgh"], c["decv"], c["d_prev"])
+
+    # ---- persistent window chain: the SAME tables the HIP kernels walk (include/temp_amd.h: TempGruChain), panel by panel ----
+    def gru_chain_supported(self, d):
+        return d % 4 == 0
+
+    def gru_chain_pack(self, w_hh):
+        return w_hh.detach().clone()
+
+    @staticmethod
+    def _chain_tables(tabs):
+        P, S = tabs["n_panels"], tabs["n_steps"]
+        return (tabs["panel"].view(P, 4).long(), tabs["rows"].view(S, _lib.CHAIN_TRACKS).long(), tabs["sinfo"].view(S, 4).long(),
+                tabs["dt_bits"].view(torch.float32))
+
+    def gru_chain_fwd(self, tabs, gi, lam, variant, packs, b_hhs, h_out, saved_all):
+        panel, rows, sinfo, dt = self._chain_tables(tabs)
+        d = saved_all.shape[2]
+        mask = _lib.CHAIN_HAS_PREV - 1
+        for rnn, s0, ns, _ in panel.tolist():
+            w_hh, b_hh = packs[rnn], b_hhs[rnn].detach()
+            state = torch.zeros(_lib.CHAIN_TRACKS, d)
+            for s in range(s0, s0 + ns):
+                e = rows[s]
+                act = e >= 0
+                r = (e & mask)[act]
+                hp = (((e >> 30) & 1) == 1)[act]
+                assert bool(hp.any()) == bool(sinfo[s, 0] & 1)
+                hd = state[act] * torch.exp(-dt[r] * lam).view(-1, 1) * hp.view(-1, 1).to(state.dtype)
+                gh = torch.mm(hd, w_hh.t()) + b_hh
+                h_r, h_z, h_n = gh.chunk(3, 1)
+                g = gi[r]
+                if variant == _lib.GRU_TORCH:
+                    i_r, i_z, i_n = g.chunk(3, 1)
+                    rg, zg = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+                else:
+                    i_n = g
+                    rg, zg = torch.sigmoid(h_r), torch.sigmoid(h_z)
+                ng = torch.tanh(i_n + rg * h_n)
+                h = (1 - zg) * ng + zg * hd
+                for k, v in enumerate((rg, zg, ng, h_n, hd)):
+                    saved_all[k, r] = v
+                if sinfo[s, 0] & 2:
+                    h_out[r] = h
+                state = torch.zeros_like(state)
+                state[act] = h
+
+    def gru_chain_bwd(self, tabs, saved_all, ups, lam, variant, packs, b_hhs, dgi, dgh):
+        panel, rows, sinfo, dt = self._chain_tables(tabs)
+        d = saved_all.shape[2]
+        mask = _lib.CHAIN_HAS_PREV - 1
+        for rnn, s0, ns, _ in panel.tolist():
+            w_hh = packs[rnn]
+            dprev = torch.zeros(_lib.CHAIN_TRACKS, d)
+            nxt_has = torch.zeros(_lib.CHAIN_TRACKS, dtype=torch.bool)
+            for s in range(s0 + ns - 1, s0 - 1, -1):
+                e = rows[s]
+                act = e >= 0
+                r = (e & mask)[act]
+                rg, zg, ng, hn, hd = (saved_all[k, r] for k in range(5))
+                g = torch.zeros(r.shape[0], d)
+                sel = int(sinfo[s, 1])
+                if sel >= 0 and ups[sel] is not None:
+                    g = g + ups[sel].detach()[r - int(sinfo[s, 2])]
+                g = g + dprev[act] * nxt_has[act].view(-1, 1).to(g.dtype)
+                dn_pre = g * (1 - zg) * (1 - ng * ng)
+                dz_pre = g * (hd - ng) * zg * (1 - zg)
+                dr_pre = dn_pre * hn * rg * (1 - rg)
+                dgi[r] = torch.cat([dr_pre, dz_pre, dn_pre], 1) if variant == _lib.GRU_TORCH else dn_pre
+                gh = torch.cat([dr_pre, dz_pre, dn_pre * rg], 1)
+                dgh[r] = gh
+                dp = (torch.mm(gh, w_hh) + g * zg) * torch.exp(-dt[r] * lam).view(-1, 1)
+                dprev = torch.zeros_like(dprev)
+                dprev[act] = dp
+                nxt_has = act & (((e >> 30) & 1) == 1)
 
     def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
         if d_x is not None:

@@ -1,0 +1,55 @@
+"""Persistent window chain, host side: the track / panel planner (GruProgram.chain_plan) and the table semantics, executed
+by the test backend's panel-by-panel reference, against the per-position path."""
+import numpy as np
+import pytest
+import torch
+
+from temp_amd import backend as TB
+from tests.chain_cases import check_plan_invariants, make_rnns, random_program, run_program
+from tests.cpu_backend import CpuTestBackend
+from tests.golden_util import assert_close
+
+
+@pytest.fixture(autouse=True)
+def cpu_backend():
+    TB.set_backend(CpuTestBackend())
+    yield
+    TB.set_backend(None)
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(n_chain=1, K=9, E=40, lo=1, hi=40)), (3, dict(n_chain=3, K=4, E=300, lo=100, hi=300)),
+                                     (4, dict(dense_first=True, E=70))])
+def test_chain_plan_invariants(seed, kw):
+    prog, _ = random_program(seed, **kw)
+    plan = check_plan_invariants(prog)
+    fill = (plan["rows"] >= 0).mean()
+    assert fill > 0.3
+
+
+def test_chain_plan_dense_panels_are_full():
+    """Every entity active at every position (the GDELT-shaped case): tracks = entities, panels of 32 consecutive rows."""
+    prog, _ = random_program(5, n_chain=1, K=5, E=96, lo=96, hi=96)
+    plan = check_plan_invariants(prog)
+    assert plan["panel"].shape[0] == 3 and (plan["rows"] >= 0).all()
+    assert (plan["panel"][:, 2] == 5).all()
+
+
+def test_single_position_programs_keep_the_pointwise_path():
+    from temp_amd.gru_chain import zero_state_program
+    assert zero_state_program(50).chain_plan() is None
+
+
+@pytest.mark.parametrize("type1", [False, True])
+@pytest.mark.parametrize("want", [None, "ends"])
+def test_chain_tables_reproduce_per_position_path(type1, want):
+    d = 16
+    prog, n_x = random_program(7)
+    w = None if want is None else tuple(i for i, it in enumerate(prog.inst) if it.next < 0 or i % 4 == 1)
+    rnns = make_rnns(2, d, type1, 3)
+    a = run_program(prog, n_x, d, rnns, torch.device("cpu"), w, type1, 11, chain_kernels=True)
+    b = run_program(prog, n_x, d, rnns, torch.device("cpu"), w, type1, 11, chain_kernels=False)
+    for x, y in zip(a[0], b[0]):
+        assert_close(x, y, 1e-5, 1e-6, "states")
+    assert_close(a[1], b[1], 1e-5, 1e-6, "d_x")
+    for x, y in zip(a[2], b[2]):
+        assert_close(x, y, 1e-4, 1e-5, "GRU parameter gradient")
