@@ -126,6 +126,11 @@ def algorithmic_costs(wb, D, bi, S=2):
     c["k_gemm_panel<gru_dx>"] = dict(bytes=n_gru * (3 * row + row), flops=2 * n_gru * 3 * D * D)
     c["k_gemm_panel<gru_dprev>"] = dict(bytes=n_gru * (3 * row + 3 * row), flops=2 * n_gru * 3 * D * D)
     c["k_colsum_part"] = dict(bytes=n_gru * 6 * row, flops=0)
+    # persistent window chain (one launch per direction of time for ALL positions): forward reads gi (3 rows) and writes h + 5 saved
+    # planes; backward reads the 5 planes (+ upstream rows) and writes dgi + dgh (6 rows); 6 n D^2 flop each (W_hh product)
+    c["k_gru_chain_fwd"] = dict(bytes=n_gru * (3 * row + 6 * row), flops=6 * n_gru * D * D)
+    c["k_gru_chain_bwd"] = dict(bytes=n_gru * (5 * row + 6 * row), flops=6 * n_gru * D * D)
+    c["k_gru_chain_pack"] = dict(bytes=4 * 2 * 3 * D * D * 4, flops=0)
     if hasattr(wb, "idx_tgt"):                    # attention mixer over the target rows (encoder-only step)
         nq, act = int(wb.idx_tgt.shape[0]), int((wb.idx_tgt >= 0).sum().item())
         c["k_sa_attn_fwd"] = dict(bytes=nq * 4 * row + act * 2 * row, flops=4 * (act + nq) * D)
@@ -135,7 +140,7 @@ def algorithmic_costs(wb, D, bi, S=2):
     return c
 
 
-MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd")
+MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd", "k_gru_chain_fwd", "k_gru_chain_bwd")
 
 
 def traced_steps(step_fn, n_steps, lib):
@@ -162,7 +167,7 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
     cores: one window (bsz=1) at a time, fwd+bwd, repeated over the rank-0 targets until at least
     `min_seconds` of CPU work has been timed."""
     from oracle import temp_oracle as O
-    nthreads = min(os.cpu_count() or 1, 16)        # more threads only add OpenMP overhead on these small ops
+    nthreads = os.cpu_count() or 1                 # all host cores of the box (SURVEY 8d)
     torch.set_num_threads(nthreads)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     bi = w["module"].startswith("Bi")
@@ -201,9 +206,19 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
         dt = time.perf_counter() - t0
         if dt >= min_seconds or nwin >= max_windows:
             break
-    return dict(value=edges / dt, unit="edges/s", cores=nthreads, kind="port",
+    return dict(value=edges / dt, unit="edges/s", cores=nthreads, cpu_model=_cpu_model(), kind="port",
                 sample="%d windows (bsz=1 each) of %s: %d snapshot visits, %d edge visits, full target graphs, fwd+bwd, %.1f s"
                        % (nwin, w["name"], visits, edges, dt))
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -218,10 +233,10 @@ def main():
                          "visits of a global batch of bsz*N windows sharded across ranks with an all-gather of per-snapshot "
                          "node states before the recurrent chain (north_star variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-loop-steps", type=int, default=0,
+    ap.add_argument("--train-loop-steps", type=int, default=30,
                     help="also time this many steps of a real training loop (new batch every step: host prepare, fresh negatives, loss, "
-                         "backward, Adam, eager launches) and report it under config.train_loop; off by default so that a rocprofv3 "
-                         "summary of the default command holds the headline step's kernels only")
+                         "backward, Adam, eager launches) and report it under config.train_loop, after the timed region (never the "
+                         "headline); pass 0 when profiling, so that a rocprofv3 summary holds the headline step's kernels only")
     ap.add_argument("--with-loss", action="store_true",
                     help="also run the all-entity pass + scorer + cross-entropy (negative_rate 500, fixed negatives) in the step "
                          "(reported separately from the headline encoder-only metric, SURVEY 8d)")
@@ -383,12 +398,31 @@ def main():
                 roof["algorithmic_per_launch"] = cst["flops" if roof["bound"] == "mfma" else "bytes"] / max(tr[dom]["launches_per_step"], 1e-9)
         roof.update(avg_launch_ms=tr[dom]["avg_ms"], launches_per_step=tr[dom]["launches_per_step"],
                     share_of_kernel_time=tr[dom]["ms_per_step"] / total_ms, traced_kernel_ms_per_step=total_ms)
-        # whole-step view against the HBM roofline with SURVEY 8d's per-edge-visit byte model
-        n_over_e = wb.n_node_visits / max(wb.n_edge_visits, 1)
+        # whole-step view against the HBM roofline with SURVEY 8d's byte model (2 RGCN layers + 1 GRU cell, fwd+bwd, fp32, int32 ids):
+        #   per edge 2*(12D+24) B, per RGCN node row 2*(20D+16) B, per GRU row 32D+4 B.
+        # (a) as the survey states it, per snapshot-edge VISIT (every visit pays its RGCN bytes), and
+        # (b) for the work the kernels actually do: the RGCN layers run once per DISTINCT snapshot of the step (a snapshot shared by
+        #     overlapping windows is computed once -- a result-identical restructuring), the GRU once per node visit.
         D = w["D"]
+        n_over_e = wb.n_node_visits / max(wb.n_edge_visits, 1)
         bytes_per_edge = 2 * (12 * D + 24) + n_over_e * (2 * (20 * D + 16) + 32 * D + 4)
+        steps_per_s = a.steps / elapsed
+        E_d = getattr(wb, "n_edges_distinct", 0) or wb.n_edge_visits
+        n_d = getattr(wb, "n_nodes_distinct", 0) or wb.n_node_visits
+        n_gru = wb.n_node_visits + (wb.target.n_rows if (bi and hasattr(wb, "target")) else 0)
+        bytes_dedup = E_d * 2 * (12 * D + 24) + n_d * 2 * (20 * D + 16) + n_gru * (32 * D + 4)
+        flops_step = sum(c.get("flops", 0) for k, c in costs.items() if k in tr)
         roof["step_bytes_per_edge_visit"] = bytes_per_edge
-        roof["step_frac_of_hbm"] = (wb.n_edge_visits * a.steps / elapsed if world == 1 else value / world) * bytes_per_edge / (HBM_PEAK_GBS * 1e9)
+        roof["step_frac_of_hbm_visit_model"] = wb.n_edge_visits * steps_per_s * bytes_per_edge / (HBM_PEAK_GBS * 1e9)
+        roof["step_algorithmic_bytes"] = bytes_dedup
+        roof["step_frac_of_hbm"] = bytes_dedup * steps_per_s / (HBM_PEAK_GBS * 1e9)
+        roof["step_algorithmic_flops"] = flops_step
+        roof["step_frac_of_mfma"] = flops_step * steps_per_s / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        if os.path.exists(pmc_path) and a.workload == "S-gdelt" and a.encoder == "gru" and not a.with_loss:
+            tot = json.load(open(pmc_path)).get("step_traffic_bytes")
+            if tot:
+                roof["step_traffic_bytes"] = tot
+                roof["step_traffic_over_algorithmic"] = tot / bytes_dedup
     if rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(model, w, targets)
     loop = None
@@ -402,11 +436,16 @@ def main():
         out = dict(metric="edges/sec (fwd+bwd) RGCN+%s seq_len=%d%s" % ("GRU" if a.encoder == "gru" else "self-attention", w["L"], " + link-prediction loss" if a.with_loss else ""), value=value, unit="edges/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
+                   value_note="edge VISITS per second (a visit = one snapshot at one window position of one window, BASELINE.md section 3); "
+                              "value_distinct = edges the RGCN kernels actually process per second (snapshots shared by overlapping "
+                              "windows are computed once)",
+                   value_distinct=(value * getattr(wb, "n_edges_distinct", wb.n_edge_visits) / max(wb.n_edge_visits, 1)) if not sharded else None,
                    config=dict(workload=w["name"], encoder=w["module"] if a.encoder == "gru" else ("BiSARGCN" if bi else "SARGCN"), rec_only_last_layer=True, seq_len=w["L"],
                                windows_per_gpu=w["bsz"], embed=w["D"], n_bases=w["B"], entities=w["num_ents"],
                                relations=w["num_rels"], edges_per_snapshot=w["edges_per_snap"],
                                edge_visits_per_step_per_gpu=wb.n_edge_visits, node_visits_per_step_per_gpu=wb.n_node_visits,
-                               distinct_snapshot_edges_per_step=getattr(wb, "n_edges_distinct", None), targets=targets,
+                               distinct_snapshot_edges_per_step=getattr(wb, "n_edges_distinct", None),
+                               distinct_snapshot_nodes_per_step=getattr(wb, "n_nodes_distinct", None), targets=targets,
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
                                else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager"),
                                train_loop=loop),

@@ -284,6 +284,7 @@ int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float
 #define TEMP_CHAIN_MAX_UP 8
 typedef struct TempGruChain {
   int32_t d, variant, n_panels, n_steps;
+  int32_t max_steps;                     /* longest panel (<= 64): sizes the per-panel tables the kernels stage in LDS */
   const int32_t* panel; const int32_t* rows; const int32_t* sinfo;
   const float* dt;                       /* [N_total] time gap of every row */
   float lambda;

@@ -51,7 +51,7 @@ CHAIN_MAX_STEPS = 64
 
 class TempGruChain(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int32), ("variant", ctypes.c_int32), ("n_panels", ctypes.c_int32), ("n_steps", ctypes.c_int32),
-                ("panel", c_vp), ("rows", c_vp), ("sinfo", c_vp), ("dt", c_vp), ("lambda_", ctypes.c_float),
+                ("max_steps", ctypes.c_int32), ("panel", c_vp), ("rows", c_vp), ("sinfo", c_vp), ("dt", c_vp), ("lambda_", ctypes.c_float),
                 ("saved_plane", ctypes.c_size_t), ("n_rnn", ctypes.c_int32), ("packed", c_vp * CHAIN_MAX_RNN), ("b_hh", c_vp * CHAIN_MAX_RNN)]
 
 

@@ -257,7 +257,7 @@ class HipBackend:
 
     def _chain_desc(self, tabs, d, variant, lam, plane, packs, b_hhs):
         c = _lib.TempGruChain()
-        c.d, c.variant, c.n_panels, c.n_steps = d, variant, tabs["n_panels"], tabs["n_steps"]
+        c.d, c.variant, c.n_panels, c.n_steps, c.max_steps = d, variant, tabs["n_panels"], tabs["n_steps"], tabs["max_steps"]
         c.panel, c.rows, c.sinfo, c.dt = (_i32(tabs[k], k).data_ptr() for k in ("panel", "rows", "sinfo", "dt_bits"))
         c.lambda_, c.saved_plane, c.n_rnn = float(lam), plane, len(packs)
         keep = []

@@ -26,7 +26,7 @@ namespace temp {
 
 struct ChainRnn { const float4* wf; const float4* wb; const float* b_hh; };
 struct ChainArgs {
-  int D, n_panels;
+  int D, n_panels, max_steps;
   const int32_t* panel; const int32_t* rows; const int32_t* sinfo;
   const float* dt;
   float lambda;
@@ -36,22 +36,23 @@ struct ChainArgs {
 struct ChainUps { const float* p[TEMP_CHAIN_MAX_UP]; };
 
 struct ChainGeom {
-  int NT, NQ;        // forward: tiles of 32 gate columns (3d), k-steps of 8 (d)
-  int NTb, NQb;      // backward: tiles of 32 state columns (d), k-steps of 8 (3d)
+  int NT, NQ;        // forward: tiles of 32 gate columns (3d), k-steps of 8 (d), even
+  int NTb, NQb;      // backward: tiles of 32 state columns (d), k-steps of 8 (3d), multiple of 4
   int lda, ldh;      // forward LDS strides (floats): product rows, state rows
   int ldA, ldz;      // backward LDS strides: dgh rows, gz / d_prev rows
 };
 __host__ __device__ inline ChainGeom chain_geom(int D) {
   ChainGeom g;
-  g.NT = (3 * D + 31) >> 5; g.NQ = (D + 7) >> 3;
-  g.NTb = (D + 31) >> 5; g.NQb = (3 * D + 7) >> 3;
+  g.NT = (3 * D + 31) >> 5; g.NQ = ((D + 15) >> 4) << 1;          // k-steps come in groups (the loops are unrolled by two,
+  g.NTb = (D + 31) >> 5; g.NQb = ((3 * D + 31) >> 5) << 2;        // by four in the backward, branch-free): padded with zero stages
   g.lda = g.NT * 32 + 4; g.ldh = g.NQ * 8 + 4;          // (stride / 4) odd: conflict-free ds_read_b128 / ds_write_b128 across rows
   g.ldA = g.NQb * 8 + 4; g.ldz = g.NTb * 32 + 4;
   return g;
 }
-#define CH_MAX_STEPS 64      // steps of one panel (their flags are staged in LDS)
-inline size_t chain_lds_fwd(int D) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.lda + 2 * CH_SLOTS * g.ldh + 4 * CH_SLOTS + CH_MAX_STEPS) * 4; }
-inline size_t chain_lds_bwd(int D) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.ldA + 2 * CH_SLOTS * g.ldz + 4 * CH_SLOTS + CH_MAX_STEPS) * 4; }
+#define CH_MAX_STEPS 64      // steps of one panel: its row table, decay factors and step flags are staged in LDS
+// `ms` = the longest panel of the launch (<= CH_MAX_STEPS)
+inline size_t chain_lds_fwd(int D, int ms) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.lda + 2 * CH_SLOTS * g.ldh + (2 * CH_SLOTS + 1) * (size_t)ms) * 4; }
+inline size_t chain_lds_bwd(int D, int ms) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.ldA + 2 * CH_SLOTS * g.ldz + (2 * CH_SLOTS + 1) * (size_t)ms) * 4; }
 
 // ---- W_hh -> fragment order ---------------------------------------------------------------------------------------
 // forward  piece (tile, q, lane): float4 e -> W_hh[tile*32 + li][8q + 4hh + e]      (gate column x k)
@@ -91,9 +92,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
   const int NT = g.NT, NQ = g.NQ, lda = g.lda, ldh = g.ldh;
   float* accb = lds;                                   // [32][lda]  raw products of the current position
   float* hb = accb + CH_SLOTS * lda;                   // [2][32][ldh] states (double buffered)
-  int* rowb = (int*)(hb + 2 * CH_SLOTS * ldh);         // [2][32] row table entries of the current / next position
-  float* decb = (float*)(rowb + 2 * CH_SLOTS);         // [2][32] decay factors
-  int* flagb = (int*)(decb + 2 * CH_SLOTS);            // [CH_MAX_STEPS] step flags of the panel
+  int* tabb = (int*)(hb + 2 * CH_SLOTS * ldh);         // [ms][32] the panel's row table
+  float* decb = (float*)(tabb + CH_SLOTS * a.max_steps);   // [ms][32] decay factor of every row
+  int* flagb = (int*)(decb + CH_SLOTS * a.max_steps);  // [ms] step flags
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const size_t plane = a.plane;
 
@@ -101,12 +102,12 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
     const int rnn_id = a.panel[4 * p], s0 = a.panel[4 * p + 1], ns = a.panel[4 * p + 2];
     const ChainRnn R = a.rnn[rnn_id];
     for (int i = tid; i < 2 * CH_SLOTS * ldh; i += blockDim.x) hb[i] = 0.f;      // k padding of the state rows must be 0, not NaN
-    if (tid < CH_SLOTS) {
-      const int e = a.rows[(size_t)s0 * CH_SLOTS + tid];
-      rowb[tid] = e;
-      decb[tid] = e >= 0 ? expf(-a.dt[e & CH_ROW_MASK] * a.lambda) : 0.f;
+    for (int i = tid; i < ns * CH_SLOTS; i += blockDim.x) {
+      const int e = a.rows[(size_t)s0 * CH_SLOTS + i];
+      tabb[i] = e;
+      decb[i] = e >= 0 ? expf(-a.dt[e & CH_ROW_MASK] * a.lambda) : 0.f;
     }
-    if (tid >= 64 && tid < 64 + ns) flagb[tid - 64] = a.sinfo[4 * (size_t)(s0 + tid - 64)];
+    if (tid < ns) flagb[tid] = a.sinfo[4 * (size_t)(s0 + tid)];
     __syncthreads();
 
     if (wave < 4) {
@@ -131,13 +132,11 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
         const int cur = s & 1;
         const int flags = flagb[s];
         if (flags & 1) {
-          const int e = rowb[cur * CH_SLOTS + li];
-          const bool ok = e >= 0 && (e & CH_HAS_PREV);
-          const float dec = decb[cur * CH_SLOTS + li];
+          const int e = tabb[s * CH_SLOTS + li];
+          // decayed previous state (models/RRGCN.py:83); a track without one multiplies (finite) stale LDS contents by 0
+          const float decm = (e >= 0 && (e & CH_HAS_PREV)) ? decb[s * CH_SLOTS + li] : 0.f;
           const float* hrow = hb + (size_t)cur * CH_SLOTS * ldh + li * ldh + 4 * hh;
-          auto stage = [&](const float4 (&w)[TPW], int q) {
-            float4 h4 = ld4(hrow + 8 * q);
-            h4 = ok ? scale4(h4, dec) : zero4();                      // decayed previous state (models/RRGCN.py:83)
+          auto stage = [&](const float4 (&w)[TPW], const float4 h4) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].x, h4.x, acc[j], 0, 0, 0);
 #pragma unroll
@@ -147,11 +146,21 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
 #pragma unroll
             for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, h4.w, acc[j], 0, 0, 0);
           };
+          // both operands of stage q + 1 (weights: L2, state: LDS) are requested before the MFMAs of stage q issue; the
+          // scheduling barriers keep the compiler from sinking a prefetch down to its first use
+          float4 hA = scale4(ld4(hrow), decm), hB;
           for (int q = 0; q < NQ; q += 2) {
-            wload(wB, q + 1 < NQ ? q + 1 : NQ - 1);
-            stage(wA, q);
-            wload(wA, q + 2 < NQ ? q + 2 : 0);                        // past the end: stage 0 of the NEXT position
-            if (q + 1 < NQ) stage(wB, q + 1);
+            const int q2 = q + 2 < NQ ? q + 2 : 0;
+            wload(wB, q + 1);
+            hB = scale4(ld4(hrow + 8 * (q + 1)), decm);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(wA, hA);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(wA, q2);                                            // past the end: stage 0 of the NEXT position
+            hA = scale4(ld4(hrow + 8 * q2), decm);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(wB, hB);
+            __builtin_amdgcn_sched_barrier(0);
           }
           // lane (li, hh) owns track li and, per register quad qq, gate columns tile*32 + 8qq + 4hh .. +3
 #pragma unroll
@@ -166,7 +175,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
           }
         }
         __syncthreads();      // A: products of position s are in LDS
-        __syncthreads();      // B: states of position s (and the row table of s + 1) are in LDS
+        __syncthreads();      // B: states of position s are in LDS
       }
     } else {
       // ------------------------------------------------------------------ memory role
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
       auto prefetch = [&](int s) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-          const int e = a.rows[(size_t)(s0 + s) * CH_SLOTS + ps * MW + mw];
+          const int e = tabb[s * CH_SLOTS + ps * MW + mw];
           erow[ps] = e;
           const bool ok = e >= 0 && cact;
           const float* src = gi + (ok ? (size_t)(e & CH_ROW_MASK) * G + col : 0);
@@ -188,15 +197,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
         }
       };
       prefetch(0);
-      int ne = -1;               // (first memory wave, lanes < 32) table entry / decay of the NEXT position
-      float ndec = 0.f;
       for (int s = 0; s < ns; ++s) {
         const int cur = s & 1;
         const int flags = flagb[s];
-        if (mw == 0 && lane < CH_SLOTS && s + 1 < ns) {
-          ne = a.rows[(size_t)(s0 + s + 1) * CH_SLOTS + lane];
-          ndec = ne >= 0 ? expf(-a.dt[ne & CH_ROW_MASK] * a.lambda) : 0.f;
-        }
         __syncthreads();      // A
         const float* hcur = hb + (size_t)cur * CH_SLOTS * ldh;
         float* hnext = hb + (size_t)(cur ^ 1) * CH_SLOTS * ldh;
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
           if (hp) {                                   // (a track without a previous state contributed zeros to the products)
             const float* ab = accb + (size_t)slot * lda + col;
             ar = ld4(ab); az = ld4(ab + D); an = ld4(ab + 2 * D);
-            hd = scale4(ld4(hcur + (size_t)slot * ldh + col), decb[cur * CH_SLOTS + slot]);
+            hd = scale4(ld4(hcur + (size_t)slot * ldh + col), decb[s * CH_SLOTS + slot]);
           }
           float o_h[4], o_r[4], o_z[4], o_n[4], o_hn[4];
           const float arv[4] = {ar.x, ar.y, ar.z, ar.w}, azv[4] = {az.x, az.y, az.z, az.w}, anv[4] = {an.x, an.y, an.z, an.w};
@@ -240,7 +243,6 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
           st4(saved + 3 * plane + o, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
           st4(saved + 4 * plane + o, hd);
         }
-        if (mw == 0 && lane < CH_SLOTS && s + 1 < ns) { rowb[(cur ^ 1) * CH_SLOTS + lane] = ne; decb[(cur ^ 1) * CH_SLOTS + lane] = ndec; }
         if (s + 1 < ns) prefetch(s + 1);       // in flight while the matrix waves run position s + 1
         __syncthreads();      // B
       }
@@ -262,8 +264,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
   float* ab = lds;                                     // [32][ldA]  gate gradients w.r.t. the recurrent pre-activations (dgh)
   float* gzb = ab + CH_SLOTS * ldA;                    // [32][ldz]  dh * z
   float* dpb = gzb + CH_SLOTS * ldz;                   // [32][ldz]  d_prev of the position just processed
-  float* decb = dpb + CH_SLOTS * ldz;                  // [2][32]
-  int* flagb = (int*)(decb + 4 * CH_SLOTS);            // [CH_MAX_STEPS]
+  int* tabb = (int*)(dpb + CH_SLOTS * ldz);            // [ms][32] the panel's row table
+  float* decb = (float*)(tabb + CH_SLOTS * a.max_steps);   // [ms][32]
+  int* flagb = (int*)(decb + CH_SLOTS * a.max_steps);  // [ms]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const size_t plane = a.plane;
 
@@ -271,6 +274,11 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
     const int rnn_id = a.panel[4 * p], s0 = a.panel[4 * p + 1], ns = a.panel[4 * p + 2];
     const ChainRnn R = a.rnn[rnn_id];
     for (int i = tid; i < CH_SLOTS * ldA; i += blockDim.x) ab[i] = 0.f;          // k padding of the dgh rows
+    for (int i = tid; i < ns * CH_SLOTS; i += blockDim.x) {
+      const int e = a.rows[(size_t)s0 * CH_SLOTS + i];
+      tabb[i] = e;
+      decb[i] = e >= 0 ? expf(-a.dt[e & CH_ROW_MASK] * a.lambda) : 0.f;
+    }
     if (tid < ns) flagb[tid] = a.sinfo[4 * (size_t)(s0 + tid)];
     __syncthreads();
 
@@ -286,20 +294,20 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
       for (int j = 0; j < TPWB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-      float4 wA[TPWB], wB[TPWB];
+      // weights: a ring of four stage buffers, i.e. three stages (3 x 8 MFMAs = 1.5 k cycles) of L2 latency cover
+      float4 w0[TPWB], w1[TPWB], w2[TPWB], w3[TPWB];
       auto wload = [&](float4 (&w)[TPWB], int q) {
 #pragma unroll
         for (int j = 0; j < TPWB; ++j) w[j] = R.wb[((size_t)tidx[j] * NQb + q) * 64 + lane];
       };
-      wload(wA, 0);
+      wload(w0, 0); wload(w1, 1); wload(w2, 2);
       for (int s = ns - 1; s >= 0; --s) {
         const int cur = s & 1;
         const int flags = flagb[s];
         __syncthreads();      // A: dgh / dh*z / decay of position s are in LDS
         if (flags & 1) {
           const float* arow = ab + (size_t)li * ldA + 4 * hh;
-          auto stage = [&](const float4 (&w)[TPWB], int q) {
-            const float4 d4 = ld4(arow + 8 * q);
+          auto stage = [&](const float4 (&w)[TPWB], const float4 d4) {
 #pragma unroll
             for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].x, d4.x, acc[j], 0, 0, 0);
 #pragma unroll
@@ -309,13 +317,31 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
 #pragma unroll
             for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, d4.w, acc[j], 0, 0, 0);
           };
-          for (int q = 0; q < NQb; q += 2) {
-            wload(wB, q + 1 < NQb ? q + 1 : NQb - 1);
-            stage(wA, q);
-            wload(wA, q + 2 < NQb ? q + 2 : 0);
-            if (q + 1 < NQb) stage(wB, q + 1);
+          float4 dA = ld4(arow), dB;
+          for (int q = 0; q < NQb; q += 4) {
+            const int qa = q + 4 < NQb ? q + 4 : 0, qb = q + 5 < NQb ? q + 5 : 1, qc = q + 6 < NQb ? q + 6 : 2;   // wrap: the NEXT position
+            wload(w3, q + 3);
+            dB = ld4(arow + 8 * (q + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            stage(w0, dA);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(w0, qa);
+            dA = ld4(arow + 8 * (q + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            stage(w1, dB);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(w1, qb);
+            dB = ld4(arow + 8 * (q + 3));
+            __builtin_amdgcn_sched_barrier(0);
+            stage(w2, dA);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(w2, qc);
+            dA = ld4(arow + 8 * (q + 4 < NQb ? q + 4 : 0));
+            __builtin_amdgcn_sched_barrier(0);
+            stage(w3, dB);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          const float dec = decb[cur * CH_SLOTS + li];
+          const float dec = decb[s * CH_SLOTS + li];
 #pragma unroll
           for (int j = 0; j < TPWB; ++j) {
             if (!tval[j]) continue;
@@ -342,10 +368,10 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
           const int slot = ps * MW + mw;
-          const int e = a.rows[(size_t)(s0 + s) * CH_SLOTS + slot];
+          const int e = tabb[s * CH_SLOTS + slot];
           erow[ps] = e;
           int en = -1;
-          if (s + 1 < ns) en = a.rows[(size_t)(s0 + s + 1) * CH_SLOTS + slot];
+          if (s + 1 < ns) en = tabb[(s + 1) * CH_SLOTS + slot];
           nxt[ps] = en >= 0 && (en & CH_HAS_PREV);
           const bool ok = e >= 0 && cact;
           const size_t row = ok ? (size_t)(e & CH_ROW_MASK) : 0;
@@ -354,15 +380,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
           shd[ps] = ld4(src + 4 * plane);
         }
       };
-      float cdec = 0.f;          // (first memory wave, lanes < 32) decay of the track's row at the position about to be processed
-      auto prefetch_dec = [&](int s) {
-        if (mw == 0 && lane < CH_SLOTS) {
-          const int e = a.rows[(size_t)(s0 + s) * CH_SLOTS + lane];
-          cdec = e >= 0 ? expf(-a.dt[e & CH_ROW_MASK] * a.lambda) : 0.f;
-        }
-      };
       prefetch(ns - 1);
-      prefetch_dec(ns - 1);
       for (int s = ns - 1; s >= 0; --s) {
         const int cur = s & 1;
         // upstream gradient of the step's rows (only the positions whose states are consumed outside the chain -- the
@@ -400,8 +418,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
           else st4(dgi + row * D + col, dn_pre);
           st4(dgh + b3, dr_pre); st4(dgh + b3 + D, dz_pre); st4(dgh + b3 + 2 * D, dhn);
         }
-        if (mw == 0 && lane < CH_SLOTS) decb[cur * CH_SLOTS + lane] = cdec;
-        if (s > 0) { prefetch(s - 1); prefetch_dec(s - 1); }      // in flight while the matrix waves run position s
+        if (s > 0) prefetch(s - 1);            // in flight while the matrix waves run position s
         __syncthreads();      // A
         __syncthreads();      // B
       }
@@ -415,6 +432,7 @@ static int chain_check(const TempGruChain* c) {
   if (c->variant != TEMP_GRU_TORCH && c->variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
   if (c->n_panels > 0 && (!c->panel || !c->rows || !c->sinfo || !c->dt)) return TEMP_E_BADARG;
   for (int i = 0; i < c->n_rnn; ++i) if (!c->packed[i] || !c->b_hh[i]) return TEMP_E_BADARG;
+  if (c->max_steps <= 0 || c->max_steps > CH_MAX_STEPS) return TEMP_E_BADARG;
   if (!temp_gru_chain_supported(c->d)) return TEMP_E_UNSUPPORTED;
   return TEMP_OK;
 }
@@ -422,7 +440,7 @@ static int chain_check(const TempGruChain* c) {
 static ChainArgs chain_args(const TempGruChain* c) {
   ChainArgs a = {};
   const ChainGeom g = chain_geom(c->d);
-  a.D = c->d; a.n_panels = c->n_panels; a.panel = c->panel; a.rows = c->rows; a.sinfo = c->sinfo; a.dt = c->dt;
+  a.D = c->d; a.n_panels = c->n_panels; a.max_steps = c->max_steps; a.panel = c->panel; a.rows = c->rows; a.sinfo = c->sinfo; a.dt = c->dt;
   a.lambda = c->lambda; a.plane = c->saved_plane;
   for (int i = 0; i < c->n_rnn; ++i) {
     a.rnn[i].wf = (const float4*)c->packed[i];
@@ -445,7 +463,7 @@ template <int VARIANT, int TPW>
 static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float* saved, hipStream_t st) {
   static bool attr = false;
   auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4>;
-  const size_t lds = chain_lds_fwd(a.D);
+  const size_t lds = chain_lds_fwd(a.D, a.max_steps);
   int rc = chain_lds_attr(kernel, lds, &attr);
   if (rc) return rc;
   TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds, st, a, gi, h, saved);
@@ -456,7 +474,7 @@ template <int VARIANT, int TPWB>
 static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float* saved, float* dgi, float* dgh, hipStream_t st) {
   static bool attr = false;
   auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8>;
-  const size_t lds = chain_lds_bwd(a.D);
+  const size_t lds = chain_lds_bwd(a.D, a.max_steps);
   int rc = chain_lds_attr(kernel, lds, &attr);
   if (rc) return rc;
   TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds, st, a, ups, saved, dgi, dgh);
@@ -471,7 +489,7 @@ extern "C" {
 
 int temp_gru_chain_supported(int d) {
   if (d <= 0 || d % 4) return 0;
-  return chain_lds_fwd(d) <= CH_LDS_LIMIT && chain_lds_bwd(d) <= CH_LDS_LIMIT && chain_geom(d).NT <= 24 && chain_geom(d).NTb <= 8;
+  return chain_lds_fwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && chain_lds_bwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && chain_geom(d).NT <= 24 && chain_geom(d).NTb <= 8;
 }
 
 size_t temp_gru_chain_pack_floats(int d) {

@@ -187,7 +187,7 @@ class GruProgram:
             parts = [plan["panel"].reshape(-1), plan["rows"].reshape(-1), sinfo.reshape(-1), dt.view(np.int32)]
             buf = _lib.to_device(np.concatenate(parts), device)
             cuts = np.cumsum([0] + [p.size for p in parts])
-            tabs = cache[key] = dict(n_panels=int(plan["panel"].shape[0]), n_steps=int(S), panel=buf[cuts[0]:cuts[1]], rows=buf[cuts[1]:cuts[2]],
+            tabs = cache[key] = dict(n_panels=int(plan["panel"].shape[0]), n_steps=int(S), max_steps=int(plan["panel"][:, 2].max()), panel=buf[cuts[0]:cuts[1]], rows=buf[cuts[1]:cuts[2]],
                                      sinfo=buf[cuts[2]:cuts[3]], dt_bits=buf[cuts[3]:cuts[4]])
         return tabs
 
