@@ -463,15 +463,19 @@ def gen_G9():
     save("G9_scores", **out)
 
 
-def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, trace=False, te=False, ent_row_stride=1):
+def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, trace=False, te=False, ent_row_stride=1, extra_args=None,
+                tweak=None):
     num_e, num_r, tr, va, te_g = graphs()
     args = rh.make_args(module=module, rec_only_last_layer=rec_only, hidden_size=D, embed_size=D, n_bases=B,
-                        train_seq_len=L, test_seq_len=L, batch_size=bsz_args, negative_rate=neg, use_time_embedding=te)
+                        train_seq_len=L, test_seq_len=L, batch_size=bsz_args, negative_rate=neg, use_time_embedding=te, **(extra_args or {}))
     cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=te)
     model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
     torch.manual_seed(0)
     m = cls(args, num_e, num_r, tr, va, te_g)
-    m.load_state_dict(to_ref_state_dict(model), strict=True)
+    missing = m.load_state_dict(to_ref_state_dict(model), strict=False)
+    assert not missing.unexpected_keys and all("impute_weight" in k for k in missing.missing_keys), missing
+    if tweak is not None:
+        tweak(m)
     np.random.seed(seed)
     # capture the reference's unseeded random draws (F11) -----------------------------
     choices, samples, trace_rec = [], [], []
@@ -759,7 +763,107 @@ def _run_window_sa(cls, module, rec_only, learn, D, B, seed, t_list, L, neg):
     return out
 
 
-ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14)
+def _sparse_rows(prefix, t, out):
+    """dense (N, D) tensor -> non-zero rows + values under `prefix`."""
+    nz = torch.nonzero(t.abs().sum(1)).view(-1)
+    out[prefix + "_rows"], out[prefix + "_vals"] = nz, t[nz]
+
+
+def gen_G15():
+    """Config 3 at window level: the post-ensemble / impute window loops (models/PostBiDynamicRGCN.py:77-101,103-124,
+    models/PostDynamicRGCN.py:29-96) with the three history streams (local, layer-1, layer-2) and the entry points they call:
+    BiRRGCN.forward_post_ensemble_one_direction / forward_post_ensemble / forward_post_ensemble_isolated /
+    forward_isolated_impute (models/BiRRGCN.py:259-338) and their RRGCN counterparts (models/RRGCN.py:219-272).
+      G15_post_bi    BiGRRGCN --rec-only-last-layer --post-ensemble, L = 15: (local, temporal) target embeddings, the local
+                     history streams, the all-entity (local, temporal) matrices of every window, gradients of a seeded
+                     weighted sum of all of them.  (The frequency-gated score combination of PostEnsembleBiDynamicRGCN is
+                     out of scope)
+      G15_impute_bi  ImputeBiDynamicRGCN.forward (--impute): loss + gradients with the recorded draws.
+      G15_impute_uni ImputeDynamicRGCN.forward."""
+    from models.PostBiDynamicRGCN import ImputeBiDynamicRGCN
+    from models.PostDynamicRGCN import ImputeDynamicRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    T = lambda idx: [int(times[i]) for i in idx]
+
+    # ---- post-ensemble, bidirectional, rec-only-last-layer (BASELINE config 3's flags) ---------------------------------------
+    D, B, L, seed = 32, 16, 15, 901
+    t_list = T([21, 13, 7, 2])
+    args = rh.make_args(module='BiGRRGCN', rec_only_last_layer=True, post_ensemble=True, hidden_size=D, embed_size=D, n_bases=B,
+                        train_seq_len=L, test_seq_len=L, batch_size=4, negative_rate=20)
+    cfg = dict(module='BiGRRGCN', n_bases=B, inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+    model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
+    m = ImputeBiDynamicRGCN(args, num_e, num_r, tr, va, te_g)
+    m.load_state_dict(to_ref_state_dict(model), strict=True)
+    np.random.seed(seed)
+    choices = []
+    orig_choice = np.random.choice
+
+    def rec_choice(*a, **k):
+        r = orig_choice(*a, **k)
+        choices.append(np.asarray(r).copy())
+        return r
+
+    np.random.choice = rec_choice
+    try:
+        gf, tf, gb, tb = m.get_batch_graph_list(torch.tensor(t_list), L, m.graph_dict_train)
+        f_loc, f_rec, f_start = m.pre_forward(gf, tf, forward=True)
+        b_loc, b_rec, b_start = m.pre_forward(gb, tb, forward=False)
+        train_graphs, tt = gf[-1], tf[-1]
+        loc, rec = m.get_final_graph_embeds(train_graphs, tt, L, f_loc, f_rec, f_start, b_loc, b_rec, b_start, full=False)
+    finally:
+        np.random.choice = orig_choice
+    out = dict(module='BiGRRGCN', rec_only=1, D=D, B=B, seed=seed, L=L, neg=20, te=0, t_list=np.array(t_list), times=np.array(times),
+               param_checksum=checksum(model), n_choices=len(choices), bsz=len(loc))
+    for i, c in enumerate(choices):
+        out['choice_%d' % i] = c
+    gen = torch.Generator().manual_seed(seed)
+    total = 0
+    rows_sel = torch.arange(0, num_e, 7)
+    for i, (g, t) in enumerate(zip(train_graphs, tt)):
+        out['loc_%d' % i], out['rec_%d' % i] = loc[i], rec[i]
+        _sparse_rows('f_loc_%d' % i, f_loc[i], out)
+        _sparse_rows('b_loc_%d' % i, b_loc[i], out)
+        dtf = (L - 1 - f_start[i]).unsqueeze(-1)
+        dtb = (L - 1 - b_start[i]).unsqueeze(-1)
+        a_loc, a_rec = m.ent_encoder.forward_post_ensemble_isolated(m.ent_embeds, f_rec[i][0], f_rec[i][1], dtf, b_rec[i][0], b_rec[i][1],
+                                                                     dtb, t, f_loc[i], b_loc[i])
+        out['all_loc_%d' % i], out['all_rec_%d' % i] = a_loc[rows_sel], a_rec[rows_sel]
+        for x in (loc[i], rec[i], a_loc[rows_sel], a_rec[rows_sel]):
+            total = total + (x * torch.randn(x.shape, generator=gen)).sum()
+    out['all_rows'] = rows_sel
+    out['total'] = total.item()
+    total.backward()
+    eg = m.ent_embeds.grad
+    nz = torch.nonzero(eg.abs().sum(1)).view(-1)[::5]
+    out['d_ent_sub'], out['d_ent_nz_rows'], out['d_ent_nz_vals'] = 5, nz, eg[nz]
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            out['gabs_' + k] = v.grad.double().abs().sum().item()
+            out['gsum_' + k] = v.grad.double().sum().item()
+    save("G15_post_bi", **out)
+
+    # ---- impute models: the reference's own forward() ---------------------------------------------------------------------------
+    for name, cls, module, rec_only, seed, idx, L in (("G15_impute_bi", ImputeBiDynamicRGCN, 'BiGRRGCN', True, 902, [20, 12, 3], 6),
+                                                     ("G15_impute_uni", ImputeDynamicRGCN, 'GRRGCN', True, 903, [17, 9, 2], 6),
+                                                     ("G15_impute_uni_full", ImputeDynamicRGCN, 'GRRGCN', False, 904, [15, 6], 5)):
+        out = _run_window(cls, module, rec_only, 32, 16, seed, T(idx), L, 4, 20, extra_args=dict(impute=True),
+                          tweak=_impute_weights)
+        out['impute'] = 1
+        save(name, **out)
+
+
+def _impute_weights(m):
+    """nn.Linear(1, 1) impute gates: set to fixed non-trivial values (the reference leaves them at torch's default init)."""
+    enc = m.ent_encoder
+    with torch.no_grad():
+        for nm, (w, b) in (("impute_weight", (0.3, -0.1)), ("impute_weight_forward", (0.25, -0.05)), ("impute_weight_backward", (0.4, 0.1))):
+            if hasattr(enc, nm):
+                getattr(enc, nm).weight.fill_(w)
+                getattr(enc, nm).bias.fill_(b)
+
+
+ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14, G15=gen_G15)
 
 if __name__ == "__main__":
     rh.activate()

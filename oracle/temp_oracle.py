@@ -702,6 +702,179 @@ def bi_forward_loss(model, cfg, graph_dict, t_list, times, seq_len, target_graph
     return loss, per_graph
 
 
+# --------------------------------------------------------------------------------------
+# a22: post-ensemble / impute window models (models/PostDynamicRGCN.py, models/PostBiDynamicRGCN.py)
+# The encoder dict may carry the nn.Linear(1, 1) impute gates as (weight (1,1), bias (1,)) tuples:
+#   'impute_weight' (uni, models/RRGCN.py:188-190) / 'impute_weight_forward', 'impute_weight_backward' (bi, models/BiRRGCN.py:204-207)
+# --------------------------------------------------------------------------------------
+class LocHistory(DenseHistory):
+    """hist_embeddings_loc (bsz,N,D) next to the recurrent history, both re-zeroed every position
+    (ImputeDynamicRGCN.update_time_diff_hist_embeddings, models/PostDynamicRGCN.py:33-42)."""
+
+    def __init__(self, bsz, num_ents, dim, dtype):
+        super().__init__(bsz, num_ents, dim, dtype)
+        self.loc = torch.zeros(bsz, num_ents, dim, dtype=dtype)
+
+    def update_loc(self, loc_list, first_list, second_list, graphs, cur_t):
+        loc = self.loc.new_zeros(self.bsz, self.num_ents, self.dim)
+        for i in range(len(loc_list)):
+            loc[i][graphs[i].ids] = loc_list[i]
+        self.loc = loc
+        self.update(first_list, second_list, graphs, cur_t)
+
+    def flip(self):
+        super().flip()
+        self.loc = torch.flip(self.loc, [0])
+
+
+def impute_gate(lin, dt):
+    """exp(-clamp(Linear(dt), min=0)), models/RRGCN.py:271-272 (the bi model halves it, models/BiRRGCN.py:301-302)."""
+    w, b = lin
+    return torch.exp(-torch.clamp(dt * w.view(1, 1) + b.view(1, 1), min=0))
+
+
+def rrgcn_isolated_impute(enc, cfg, e, first_prev, second_prev, dt, t, pre_loc):
+    """RRGCN.forward_isolated_impute, models/RRGCN.py:255-269 with GRRGCNLayer.forward_isolated_impute :105-116: the input of
+    the layer-2 GRU is w * (last local state) + (1 - w) * (isolated layer-2 output)."""
+    l1, l2 = enc['layer_1'], enc['layer_2']
+    te = cfg.get('use_time_embedding', False)
+    if cfg['rec_only_last_layer']:
+        y1 = rgcn_layer_isolated(e, l1['loop_weight'])
+    else:
+        y1 = rgcn_layer_isolated(e, l1['loop_weight'])
+        y1 = gru_stack(y1, _decay(l1, cfg, first_prev, dt), l1['rnn'], cfg.get('type1', False))
+        if te:
+            y1 = y1 + l1['time_embed'][int(t)]
+    w = impute_gate(enc['impute_weight'], dt)
+    x = rgcn_layer_isolated(y1, l2['loop_weight'])
+    x = w * pre_loc + (1 - w) * x
+    out = gru_stack(x, _decay(l2, cfg, second_prev, dt), l2['rnn'], cfg.get('type1', False))
+    return out + l2['time_embed'][int(t)] if te else out
+
+
+def birrgcn_isolated_impute(enc, cfg, e, f1, f2, dt_f, b1, b2, dt_b, t, f_loc, b_loc):
+    """BiRRGCN.forward_isolated_impute, models/BiRRGCN.py:320-338 with BiGRRGCNLayer.forward_isolated_impute :84-100."""
+    l1, l2 = enc['layer_1'], enc['layer_2']
+    te = cfg.get('use_time_embedding', False)
+    t1 = cfg.get('type1', False)
+    y1 = rgcn_layer_isolated(e, l1['loop_weight'])
+    if not cfg['rec_only_last_layer']:
+        y1 = gru_stack(y1, _decay(l1, cfg, f1, dt_f), l1['forward_rnn'], t1) + gru_stack(y1, _decay(l1, cfg, b1, dt_b), l1['backward_rnn'], t1)
+        if te:
+            y1 = y1 + l1['time_embed'][int(t)]
+    wf = impute_gate(enc['impute_weight_forward'], dt_f) / 2
+    wb = impute_gate(enc['impute_weight_backward'], dt_b) / 2
+    x = rgcn_layer_isolated(y1, l2['loop_weight'], None, 'relu')
+    x = wf * f_loc + wb * b_loc + (1 - wf - wb) * x
+    out = gru_stack(x, _decay(l2, cfg, f2, dt_f), l2['forward_rnn'], t1) + gru_stack(x, _decay(l2, cfg, b2, dt_b), l2['backward_rnn'], t1)
+    return out + l2['time_embed'][int(t)] if te else out
+
+
+def post_uni_pre_forward(model, cfg, graph_dict, time_batched_list, seq_len):
+    """ImputeDynamicRGCN.pre_forward, models/PostDynamicRGCN.py:58-78 (full graphs)."""
+    ent = model['ent_embeds']
+    H = LocHistory(len(time_batched_list[0]), ent.shape[0], ent.shape[1], ent.dtype)
+    for cur_t in range(seq_len - 1):
+        ts = _filter_none(time_batched_list[cur_t])
+        if len(ts) == 0:
+            continue
+        graphs = [graph_dict[t] for t in ts]
+        sizes = [g.n for g in graphs]
+        fp, sp, dt = H.get_prev(graphs, cur_t)
+        bg = batch_graphs(graphs)
+        loc, first, second = rrgcn_forward(model['ent_encoder'], cfg, bg, ent[bg.ids], fp, sp, dt, time_batched_list[cur_t], sizes, post=True)
+        H.update_loc(loc.split(sizes), first.split(sizes), second.split(sizes), graphs, cur_t)
+    return H
+
+
+def post_bi_pre_forward(model, cfg, graph_dict, time_batched_list, seq_len, forward):
+    """ImputeBiDynamicRGCN.pre_forward, models/PostBiDynamicRGCN.py:77-101."""
+    ent = model['ent_embeds']
+    H = LocHistory(len(time_batched_list[0]), ent.shape[0], ent.shape[1], ent.dtype)
+    for cur_t in range(seq_len - 1):
+        ts = _filter_none(time_batched_list[cur_t])
+        if len(ts) == 0:
+            continue
+        graphs = [graph_dict[t] for t in ts]
+        sizes = [g.n for g in graphs]
+        fp, sp, dt = H.get_prev(graphs, cur_t)
+        bg = batch_graphs(graphs)
+        loc, first, second = birrgcn_forward_one_direction(model['ent_encoder'], cfg, bg, ent[bg.ids], fp, sp, dt, forward,
+                                                           time_batched_list[cur_t], sizes, post=True)
+        H.update_loc(loc.split(sizes), first.split(sizes), second.split(sizes), graphs, cur_t)
+    if not forward:
+        H.flip()
+    return H
+
+
+def post_bi_target_embeds(model, cfg, Hf, Hb, target_graphs, target_times, seq_len):
+    """ImputeBiDynamicRGCN.get_final_graph_embeds -> get_graph_embeds_center, models/PostBiDynamicRGCN.py:53-75:
+    (local, temporal) per-graph target embeddings."""
+    ent = model['ent_embeds']
+    f1, f2, dtf = Hf.get_prev(target_graphs, seq_len - 1)
+    b1, b2, dtb = Hb.get_prev(target_graphs, seq_len - 1)
+    sizes = [g.n for g in target_graphs]
+    bg = batch_graphs(target_graphs)
+    loc, out = birrgcn_forward(model['ent_encoder'], cfg, bg, ent[bg.ids], f1, f2, dtf, b1, b2, dtb, target_times, sizes, post=True)
+    return list(loc.split(sizes)), list(out.split(sizes))
+
+
+def post_bi_all_embeds(model, cfg, Hf, Hb, i, t, seq_len):
+    """PostBiDynamicRGCN.get_all_embeds_Gt before the active rows are written over it, models/PostBiDynamicRGCN.py:182-186
+    -> BiRRGCN.forward_post_ensemble_isolated (models/BiRRGCN.py:295-318; no impute mixing unless the gates exist)."""
+    dtf = (seq_len - 1 - Hf.start[i]).unsqueeze(-1)
+    dtb = (seq_len - 1 - Hb.start[i]).unsqueeze(-1)
+    enc = model['ent_encoder']
+    loc, rec = birrgcn_isolated(enc, cfg, model['ent_embeds'], Hf.hist[i][0], Hf.hist[i][1], dtf, Hb.hist[i][0], Hb.hist[i][1], dtb, t, post=True)
+    if cfg.get('impute'):
+        wf = impute_gate(enc['impute_weight_forward'], dtf) / 2
+        wb = impute_gate(enc['impute_weight_backward'], dtb) / 2
+        loc = wf * Hf.loc[i] + wb * Hb.loc[i] + (1 - wf - wb) * loc
+    return loc, rec
+
+
+def impute_bi_forward_loss(model, cfg, graph_dict, t_list, times, seq_len, target_graphs, samples, score='complex'):
+    """ImputeBiDynamicRGCN.forward, models/PostBiDynamicRGCN.py:103-124."""
+    tf, tb = get_batch_graph_list_bi(t_list, seq_len, times)
+    Hf = post_bi_pre_forward(model, cfg, graph_dict, tf, seq_len, True)
+    Hb = post_bi_pre_forward(model, cfg, graph_dict, tb, seq_len, False)
+    _, per_graph = post_bi_target_embeds(model, cfg, Hf, Hb, target_graphs, tf[-1], seq_len)
+    fn = SCORERS[score]
+    loss = 0
+    for i, (t, emb) in enumerate(zip(tf[-1], per_graph)):
+        trip, neg_tail, neg_head = samples[i]
+        dtf = (seq_len - 1 - Hf.start[i]).unsqueeze(-1)
+        dtb = (seq_len - 1 - Hb.start[i]).unsqueeze(-1)
+        all_e = birrgcn_isolated_impute(model['ent_encoder'], cfg, model['ent_embeds'], Hf.hist[i][0], Hf.hist[i][1], dtf,
+                                        Hb.hist[i][0], Hb.hist[i][1], dtb, t, Hf.loc[i], Hb.loc[i])
+        all_e = all_e.index_copy(0, torch.as_tensor(graph_dict[t].ids), emb)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_tail, all_e, True)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_head, all_e, False)
+    return loss, per_graph
+
+
+def impute_uni_forward_loss(model, cfg, graph_dict, t_list, times, seq_len, target_graphs, samples, score='complex'):
+    """ImputeDynamicRGCN.forward, models/PostDynamicRGCN.py:80-96."""
+    tbl = get_batch_graph_list(t_list, seq_len, times)
+    H = post_uni_pre_forward(model, cfg, graph_dict, tbl, seq_len)
+    ent = model['ent_embeds']
+    fp, sp, dt = H.get_prev(target_graphs, seq_len - 1)
+    sizes = [g.n for g in target_graphs]
+    bg = batch_graphs(target_graphs)
+    _, _, second = rrgcn_forward(model['ent_encoder'], cfg, bg, ent[bg.ids], fp, sp, dt, tbl[-1], sizes, post=True)
+    per_graph = list(second.split(sizes))
+    fn = SCORERS[score]
+    loss = 0
+    for i, (t, emb) in enumerate(zip(tbl[-1], per_graph)):
+        trip, neg_tail, neg_head = samples[i]
+        dti = (seq_len - 1 - H.start[i]).unsqueeze(-1)
+        all_e = rrgcn_isolated_impute(model['ent_encoder'], cfg, ent, H.hist[i][0], H.hist[i][1], dti, t, H.loc[i])
+        all_e = all_e.index_copy(0, torch.as_tensor(graph_dict[t].ids), emb)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_tail, all_e, True)
+        loss = loss + train_link_prediction(fn, emb, model['rel_embeds'], trip, neg_head, all_e, False)
+    return loss, per_graph
+
+
 def static_forward_embeds(model, cfg, target_graphs, target_times):
     """StaticRGCN.get_per_graph_ent_embeds, baselines/StaticRGCN.py:60-89 (targets injected)."""
     ent = model['ent_embeds']

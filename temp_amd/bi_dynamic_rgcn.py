@@ -97,13 +97,15 @@ class BiDynamicRGCN(DynamicRGCN):
         if wb.program is not None:
             prog = wb.program
             want = [i for i in (wb.out_inst[0], wb.out_inst[1], wb.hist_inst[0], wb.hist_inst[1]) if i >= 0]
-            got = dict(zip(want, gru_chain(TF.gather_rows(y2, wb.chain_rows, wb.chain_inv), prog, [l2.forward_rnn, l2.backward_rnn], lam,
+            wb.last_x = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv)          # GRU input rows in chain order
+            got = dict(zip(want, gru_chain(wb.last_x, prog, [l2.forward_rnn, l2.backward_rnn], lam,
                                            isinstance(l2.forward_rnn, GRUCell), want=want)))
             out = got[wb.out_inst[0]] + got[wb.out_inst[1]]
             Hf, Hb = got.get(wb.hist_inst[0]), got.get(wb.hist_inst[1])
             return out, ((Hf, Hf), (Hb, Hb))
         if wb.visit_rows is not None:                         # distinct-snapshot rows -> visit rows
             y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))
+        wb.last_x = y2
 
         def chain(plan, rnn):
             H = None

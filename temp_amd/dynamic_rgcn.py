@@ -156,6 +156,7 @@ class DynamicRGCN(TKG_Module):
         if wb.visit_rows is not None:                 # distinct-snapshot rows -> visit rows
             y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))
         l2 = enc.layer_2
+        wb.last_x = y2                                # GRU input rows of the step (= the "local" states of the post models)
         if wb.program is not None:
             want = [wb.out_inst[0]] + ([wb.hist_inst] if wb.hist_inst >= 0 else [])
             got = gru_chain(y2, wb.program, [l2.rnn], l2.inv_temperature, isinstance(l2.rnn, GRUCell), want=want)

@@ -1,0 +1,315 @@
+"""Impute / post-ensemble window models -- the reference's models/PostDynamicRGCN.py and models/PostBiDynamicRGCN.py
+(`--impute`, `--post-ensemble`; BASELINE config 3 = BiGRRGCN --rec-only-last-layer --post-ensemble on ICEWS05-15).
+
+On top of the (Bi)DynamicRGCN window loop these models keep a THIRD history stream: the "local" layer-2 state of every
+node, i.e. the layer-2 RGCN output BEFORE the GRU (models/PostDynamicRGCN.py:33-42, models/PostBiDynamicRGCN.py:77-101), and
+the target position returns (local, temporal) embeddings (models/PostBiDynamicRGCN.py:53-75).  The all-entity pass is
+RRGCN / BiRRGCN.forward_isolated_impute (impute models) or forward_post_ensemble_isolated (post-ensemble models).
+
+Execution: with --rec-only-last-layer the batched step of the parent class is reused unchanged -- the local stream is
+simply the GRU INPUT rows of the step (one launch per RGCN layer over all visited snapshots + the persistent chain kernels);
+otherwise the reference-granular path walks the positions through forward_post_ensemble(_one_direction).  Histories are
+row maps into the last executed position (window.ChainPlan), never dense (bsz, N_ents, D) tensors.
+
+Out of scope: the frequency statistics behind PostEnsemble*'s learned score-mixing weights
+(utils/DropEdge.py, utils/frequency.py).  `PostEnsemble*.forward` takes the per-triple weights from `calc_ensemble_ratio`,
+which callers override (tests inject the weights the reference used)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import functional as TF
+from .bi_dynamic_rgcn import BiDynamicRGCN
+from .birrgcn import BiGRRGCNLayer
+from .dynamic_rgcn import DynamicRGCN
+from .rrgcn import GRRGCNLayer
+
+
+def _rows_or_zero(rows, idx_t, n, d, like):
+    return like.new_zeros(n, d) if rows is None else TF.gather_rows(rows, idx_t)
+
+
+class _PostWindowMixin:
+    """What the uni- and bidirectional post models share: slicing the local stream out of a batched run and the
+    score-level ensemble loss."""
+
+    def _chain_input_rows(self, wb, inst_id=None, step=None):
+        """GRU-input rows (= local layer-2 states) of one chain instance / step of a batched run."""
+        x = wb.last_x
+        if wb.program is not None:
+            it = wb.program.inst[inst_id]
+            return x[it.x0:it.x0 + it.n]
+        return x[step.row0:step.row0 + step.n_rows]
+
+    # -- score-level ensemble (models/PostDynamicRGCN.py:357-373, 399-406) ---------------------------------------------------
+    def calc_ensemble_ratio(self, triples, t, g):
+        raise NotImplementedError("the learned mixing weights of PostEnsemble* come from per-timestamp frequency statistics "
+                                  "(utils/DropEdge.py, utils/frequency.py), which are outside the snapshot-encoder path "
+                                  "(SURVEY section 2): override calc_ensemble_ratio or pass ensemble_weights to forward()")
+
+    def _scores(self, ent_embed, triplets, neg_samples, all_embeds_g, corrupt_tail):
+        r = self.rel_embeds[triplets[:, 1]]
+        if corrupt_tail:
+            return self.calc_score(ent_embed[triplets[:, 0]], r, all_embeds_g[neg_samples], mode='tail')
+        return self.calc_score(all_embeds_g[neg_samples], r, ent_embed[triplets[:, 2]], mode='head')
+
+    def ensemble_loss(self, loc, rec, all_loc, all_rec, triplets, neg_tail, neg_head, w_subject, w_object):
+        """loss_tail + loss_head of one target graph, models/PostDynamicRGCN.py:335-349 + combined_scores :404-406."""
+        labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=triplets.device)
+        out = 0
+        for neg, tail, w in ((neg_tail, True, w_object), (neg_head, False, w_subject)):
+            local = self._scores(loc, triplets, neg, all_loc, tail)
+            temporal = self._scores(rec, triplets, neg, all_rec, tail)
+            out = out + F.cross_entropy(w * local + (1 - w) * temporal, labels)
+        return out
+
+
+# =====================================================================================================================
+# unidirectional
+# =====================================================================================================================
+class ImputeDynamicRGCN(_PostWindowMixin, DynamicRGCN):
+    """models/PostDynamicRGCN.py:20-128."""
+
+    def _can_batch(self):
+        enc = self.ent_encoder
+        return self.use_batched_path and enc.rec_only_last_layer and isinstance(enc.layer_2, GRRGCNLayer)
+
+    # -- reference-granular path ------------------------------------------------------------------------------------------
+    def _encode_step_post(self, st, prev_first, prev_second):
+        dev = self._device()
+        ids, pidx, dt = st.tensors(dev)
+        g = st.batched()
+        g.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+        fp = self._gather_prev(prev_first, pidx, st.n_rows)
+        sp = self._gather_prev(prev_second, pidx, st.n_rows)
+        return self.ent_encoder.forward_post_ensemble(g, fp, sp, dt, st.times, st.sizes)
+
+    def _run_generic(self, wb):
+        loc = first = second = None
+        for st in wb.plan.steps:
+            loc, first, second = self._encode_step_post(st, first, second)
+        out_loc, _, out = self._encode_step_post(wb.target, first, second)
+        wb.out_loc, wb.hist_loc = out_loc, loc
+        return out, (first, second)
+
+    def _run_batched(self, wb):
+        out, hist = super()._run_batched(wb)
+        if wb.program is not None:
+            wb.out_loc = self._chain_input_rows(wb, wb.out_inst[0])
+            wb.hist_loc = self._chain_input_rows(wb, wb.hist_inst) if wb.hist_inst >= 0 else None
+        else:
+            wb.out_loc = self._chain_input_rows(wb, step=wb.target)
+            wb.hist_loc = self._chain_input_rows(wb, step=wb.plan.steps[-1]) if wb.plan.steps else None
+        return out, hist
+
+    def _fused_all_entity_ok(self, wb):
+        return False                     # the all-entity pass of these models mixes in the local history: per window, below
+
+    def _plan_loss(self, wb):
+        wb.loss_plan = None
+
+    # -- all-entity pass ---------------------------------------------------------------------------------------------------
+    def _final_prevs(self, plan, b, hist, loc):
+        dev, N, D = self._device(), self.num_ents, self.embed_size
+        row_of, dt = plan.final_all(b, plan.seq_len - 1)
+        idx = torch.from_numpy(row_of.astype(np.int32)).to(dev)
+        p1 = _rows_or_zero(hist[0], idx, N, D, self.ent_embeds)
+        p2 = p1 if hist[1] is hist[0] else _rows_or_zero(hist[1], idx, N, D, self.ent_embeds)
+        pl = _rows_or_zero(loc, idx, N, D, self.ent_embeds)
+        return p1, p2, pl, torch.from_numpy(dt).view(-1, 1).to(dev)
+
+    def get_all_embeds_Gt(self, convoluted_embeds, g, t, plan, b, hist, hist_loc=None):
+        """ImputeDynamicRGCN.get_all_embeds_Gt, models/PostDynamicRGCN.py:24-31."""
+        p1, p2, pl, dt = self._final_prevs(plan, b, hist, hist_loc)
+        all_embeds = self.ent_encoder.forward_isolated_impute(self.ent_embeds, p1, p2, dt, t, pl)
+        return all_embeds.index_copy(0, torch.from_numpy(g.gids).to(self._device()), convoluted_embeds)
+
+    def run_loss(self, wb, samples=None):
+        """ImputeDynamicRGCN.forward, models/PostDynamicRGCN.py:80-96."""
+        dev = self._device()
+        out, hist = self.run(wb)
+        per_graph = list(out.split(wb.target.sizes))
+        if samples is None:
+            samples = self.draw_samples(wb)
+        loss = 0
+        for i, (g, ent_embed) in enumerate(zip(wb.graphs, per_graph)):
+            t = wb.rows[i][-1]
+            triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
+            labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=dev)
+            all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, wb.plan, i, hist, wb.hist_loc)
+            loss = loss + self.train_link_prediction_both(ent_embed, triplets, neg_tail, neg_head, labels, all_embeds_g)
+        return loss
+
+    def encode_post(self, t_list, seq_len, train=True, target_edge_ids=None):
+        """-> (per-window local embeddings, per-window temporal embeddings, prepared batch, final histories)."""
+        wb = self.prepare(t_list, seq_len, train, target_edge_ids)
+        out, hist = self.run(wb)
+        return list(wb.out_loc.split(wb.target.sizes)), list(out.split(wb.target.sizes)), wb, hist
+
+    def evaluate(self, t_list, val=True):
+        raise NotImplementedError("evaluate() of the impute / post-ensemble models ranks with utils/post_evaluation.py, outside the "
+                                  "snapshot-encoder path; use encode_post() + get_all_embeds_Gt()")
+
+
+class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
+    """models/PostDynamicRGCN.py:131-461 minus the frequency MLP (see module docstring)."""
+
+    def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plan, b, hist, hist_loc=None):
+        """PostDynamicRGCN.get_all_embeds_Gt, models/PostDynamicRGCN.py:160-174 -> (all_loc, all_rec)."""
+        p1, p2, pl, dt = self._final_prevs(plan, b, hist, hist_loc)
+        a_loc, a_rec = self.ent_encoder.forward_post_ensemble_isolated(self.ent_embeds, p1, p2, dt, t, pl)
+        gid = torch.from_numpy(g.gids).to(self._device())
+        return a_loc.index_copy(0, gid, convoluted_loc), a_rec.index_copy(0, gid, convoluted_rec)
+
+    def run_loss(self, wb, samples=None, ensemble_weights=None):
+        """PostEnsembleDynamicRGCN.forward, models/PostDynamicRGCN.py:375-397."""
+        dev = self._device()
+        out, hist = self.run(wb)
+        recs, locs = list(out.split(wb.target.sizes)), list(wb.out_loc.split(wb.target.sizes))
+        if samples is None:
+            samples = self.draw_samples(wb)
+        loss = 0
+        for i, g in enumerate(wb.graphs):
+            t = wb.rows[i][-1]
+            triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
+            a_loc, a_rec = self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc)
+            ws, wo = ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(triplets, t, g)
+            loss = loss + self.ensemble_loss(locs[i], recs[i], a_loc, a_rec, triplets, neg_tail, neg_head, ws.to(dev), wo.to(dev))
+        return loss
+
+    def forward(self, t_list, reverse=False, target_edge_ids=None, samples=None, ensemble_weights=None):
+        wb = self.prepare(t_list, self.train_seq_len, True, target_edge_ids)
+        return self.run_loss(wb, samples, ensemble_weights)
+
+
+# =====================================================================================================================
+# bidirectional
+# =====================================================================================================================
+class ImputeBiDynamicRGCN(_PostWindowMixin, BiDynamicRGCN):
+    """models/PostBiDynamicRGCN.py:22-167."""
+
+    def _can_batch(self):
+        enc = self.ent_encoder
+        return self.use_batched_path and enc.rec_only_last_layer and isinstance(enc.layer_2, BiGRRGCNLayer)
+
+    # -- reference-granular path ------------------------------------------------------------------------------------------
+    def _pre_forward_post(self, plan, forward):
+        dev = self._device()
+        loc = first = second = None
+        for st in plan.steps:
+            ids, pidx, dt = st.tensors(dev)
+            g = st.batched()
+            g.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+            fp = self._gather_prev(first, pidx, st.n_rows)
+            sp = self._gather_prev(second, pidx, st.n_rows)
+            loc, first, second = self.ent_encoder.forward_post_ensemble_one_direction(g, fp, sp, dt, st.times, st.sizes, forward)
+        return loc, (first, second)
+
+    def _run_generic(self, wb):
+        dev = self._device()
+        plan_f, plan_b = wb.plan
+        tf, tb = wb.target, wb.target_b
+        loc_f, hf = self._pre_forward_post(plan_f, True)
+        loc_b, hb = self._pre_forward_post(plan_b, False)
+        ids, pf, dtf = tf.tensors(dev)
+        _, pb, dtb = tb.tensors(dev)
+        g = tf.batched()
+        g.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+        n = tf.n_rows
+        out_loc, out = self.ent_encoder.forward_post_ensemble(
+            g, self._gather_prev(hf[0], pf, n), self._gather_prev(hf[1], pf, n), dtf,
+            self._gather_prev(hb[0], pb, n), self._gather_prev(hb[1], pb, n), dtb, tf.times, tf.sizes)
+        wb.out_loc, wb.hist_loc = out_loc, (loc_f, loc_b)
+        return out, (hf, hb)
+
+    def _run_batched(self, wb):
+        out, hist = super()._run_batched(wb)
+        plan_f, plan_b = wb.plan
+        if wb.program is not None:
+            wb.out_loc = self._chain_input_rows(wb, wb.out_inst[0])
+            wb.hist_loc = tuple(self._chain_input_rows(wb, i) if i >= 0 else None for i in wb.hist_inst)
+        else:
+            wb.out_loc = self._chain_input_rows(wb, step=wb.target)
+            wb.hist_loc = tuple(self._chain_input_rows(wb, step=p.steps[-1]) if p.steps else None for p in (plan_f, plan_b))
+        return out, hist
+
+    def _fused_all_entity_ok(self, wb):
+        return False
+
+    def _plan_loss(self, wb):
+        wb.loss_plan = None
+
+    # -- all-entity pass ---------------------------------------------------------------------------------------------------
+    def _final_prevs(self, plans, b, hist, hist_loc):
+        dev, N, D = self._device(), self.num_ents, self.embed_size
+        out = []
+        for plan, h, loc in zip(plans, hist, hist_loc if hist_loc is not None else (None, None)):
+            row_of, dt = plan.final_all(b, plan.seq_len - 1)
+            idx = torch.from_numpy(row_of.astype(np.int32)).to(dev)
+            p1 = _rows_or_zero(h[0], idx, N, D, self.ent_embeds)
+            p2 = p1 if h[1] is h[0] else _rows_or_zero(h[1], idx, N, D, self.ent_embeds)
+            out.append((p1, p2, _rows_or_zero(loc, idx, N, D, self.ent_embeds), torch.from_numpy(dt).view(-1, 1).to(dev)))
+        return out
+
+    def get_all_embeds_Gt(self, convoluted_embeds, g, t, plans, b, hist, hist_loc=None):
+        """ImputeBiDynamicRGCN.get_all_embeds_Gt, models/PostBiDynamicRGCN.py:29-39."""
+        (f1, f2, fl, dtf), (b1, b2, bl, dtb) = self._final_prevs(plans, b, hist, hist_loc)
+        all_embeds = self.ent_encoder.forward_isolated_impute(self.ent_embeds, f1, f2, dtf, b1, b2, dtb, t, fl, bl)
+        return all_embeds.index_copy(0, torch.from_numpy(g.gids).to(self._device()), convoluted_embeds)
+
+    def run_loss(self, wb, samples=None):
+        """ImputeBiDynamicRGCN.forward, models/PostBiDynamicRGCN.py:103-124."""
+        dev = self._device()
+        out, hist = self.run(wb)
+        per_graph = list(out.split(wb.target.sizes))
+        if samples is None:
+            samples = self.draw_samples(wb)
+        loss = 0
+        for i, (g, ent_embed) in enumerate(zip(wb.graphs, per_graph)):
+            t = wb.rows[i][-1]
+            triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
+            labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=dev)
+            all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, wb.plan, i, hist, wb.hist_loc)
+            loss = loss + self.train_link_prediction_both(ent_embed, triplets, neg_tail, neg_head, labels, all_embeds_g)
+        return loss
+
+    def encode_post(self, t_list, seq_len, train=True, target_edge_ids=None):
+        """-> (per-window local embeddings, per-window temporal embeddings, prepared batch, final histories)."""
+        wb = self.prepare(t_list, seq_len, train, target_edge_ids)
+        out, hist = self.run(wb)
+        return list(wb.out_loc.split(wb.target.sizes)), list(out.split(wb.target.sizes)), wb, hist
+
+    def evaluate(self, t_list, val=True):
+        raise NotImplementedError("evaluate() of the impute / post-ensemble models ranks with utils/post_evaluation.py, outside the "
+                                  "snapshot-encoder path; use encode_post() + get_all_embeds_Gt()")
+
+
+class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
+    """models/PostBiDynamicRGCN.py:170-372 minus the frequency MLP (see module docstring) -- BASELINE config 3's model."""
+
+    def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plans, b, hist, hist_loc=None):
+        """PostBiDynamicRGCN.get_all_embeds_Gt, models/PostBiDynamicRGCN.py:176-190 -> (all_loc, all_rec)."""
+        (f1, f2, fl, dtf), (b1, b2, bl, dtb) = self._final_prevs(plans, b, hist, hist_loc)
+        a_loc, a_rec = self.ent_encoder.forward_post_ensemble_isolated(self.ent_embeds, f1, f2, dtf, b1, b2, dtb, t, fl, bl)
+        gid = torch.from_numpy(g.gids).to(self._device())
+        return a_loc.index_copy(0, gid, convoluted_loc), a_rec.index_copy(0, gid, convoluted_rec)
+
+    def run_loss(self, wb, samples=None, ensemble_weights=None):
+        """PostEnsembleBiDynamicRGCN.forward, models/PostBiDynamicRGCN.py:329-354."""
+        dev = self._device()
+        out, hist = self.run(wb)
+        recs, locs = list(out.split(wb.target.sizes)), list(wb.out_loc.split(wb.target.sizes))
+        if samples is None:
+            samples = self.draw_samples(wb)
+        loss = 0
+        for i, g in enumerate(wb.graphs):
+            t = wb.rows[i][-1]
+            triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
+            a_loc, a_rec = self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc)
+            ws, wo = ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(triplets, t, g)
+            loss = loss + self.ensemble_loss(locs[i], recs[i], a_loc, a_rec, triplets, neg_tail, neg_head, ws.to(dev), wo.to(dev))
+        return loss
+
+    def forward(self, t_list, reverse=False, target_edge_ids=None, samples=None, ensemble_weights=None):
+        wb = self.prepare(t_list, self.train_seq_len, True, target_edge_ids)
+        return self.run_loss(wb, samples, ensemble_weights)

@@ -422,3 +422,84 @@ def test_G14_self_attention_window_loss_and_grads(name):
             assert abs(v.grad.double().abs().sum().item() - want) < 2e-4 * max(want, 1e-3), (name, k, want)
             checked += 1
     assert checked >= 8, checked
+
+
+# --------------------------------------------------------------------------------------
+# a22 / config 3: post-ensemble and impute window models (G15)
+# --------------------------------------------------------------------------------------
+IMPUTE_GATES = {"impute_weight": (0.3, -0.1), "impute_weight_forward": (0.25, -0.05), "impute_weight_backward": (0.4, 0.1)}
+
+
+def _with_impute_gates(model, bi):
+    names = ("impute_weight_forward", "impute_weight_backward") if bi else ("impute_weight",)
+    for nm in names:
+        w, b = IMPUTE_GATES[nm]
+        model["ent_encoder"][nm] = (torch.full((1, 1), w), torch.full((1,), b))
+    return model
+
+
+def test_G15_post_ensemble_bi_window():
+    """Config 3's flags (BiGRRGCN, --rec-only-last-layer, --post-ensemble, L = 15): (local, temporal) target embeddings,
+    local history streams, all-entity (local, temporal) matrices and the gradients of their seeded weighted sum."""
+    z = load("G15_post_bi")
+    num_e, num_r, times, gd = slice_graphs()
+    cfg = dict(module="BiGRRGCN", n_bases=int(z["B"]), inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+    model = O.init_model(cfg, num_e, num_r, len(times), int(z["D"]), seed=int(z["seed"]))
+    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6
+    leaves = O.leaf_tensors(model)
+    for v in leaves.values():
+        v.requires_grad_(True)
+    tl = sorted([int(t) for t in z["t_list"]], reverse=True)
+    L = int(z["L"])
+    targets = [O.edge_subgraph(gd["train"][t], z["choice_%d" % i]) for i, t in enumerate(tl)]
+    tf, tb = O.get_batch_graph_list_bi(tl, L, times)
+    Hf = O.post_bi_pre_forward(model, cfg, gd["train"], tf, L, True)
+    Hb = O.post_bi_pre_forward(model, cfg, gd["train"], tb, L, False)
+    loc, rec = O.post_bi_target_embeds(model, cfg, Hf, Hb, targets, tf[-1], L)
+    rows_sel = T(z["all_rows"]).long()
+    gen = torch.Generator().manual_seed(int(z["seed"]))
+    total = 0
+    for i, t in enumerate(tl):
+        assert_close(loc[i], z["loc_%d" % i], RT, AT, "G15 loc %d" % i)
+        assert_close(rec[i], z["rec_%d" % i], RT, AT, "G15 rec %d" % i)
+        for nm, H in (("f_loc", Hf), ("b_loc", Hb)):
+            rows = T(z["%s_%d_rows" % (nm, i)]).long()
+            assert torch.equal(rows, torch.nonzero(H.loc[i].detach().abs().sum(1)).view(-1))
+            assert_close(H.loc[i][rows], z["%s_%d_vals" % (nm, i)], RT, AT, "G15 %s %d" % (nm, i))
+        a_loc, a_rec = O.post_bi_all_embeds(model, cfg, Hf, Hb, i, t, L)
+        assert_close(a_loc[rows_sel], z["all_loc_%d" % i], RT, AT, "G15 all loc")
+        assert_close(a_rec[rows_sel], z["all_rec_%d" % i], RT, AT, "G15 all rec")
+        for x in (loc[i], rec[i], a_loc[rows_sel], a_rec[rows_sel]):
+            total = total + (x * torch.randn(x.shape, generator=gen)).sum()
+    assert abs(total.item() - float(z["total"])) < 2e-5 * max(1.0, abs(float(z["total"])))
+    total.backward()
+    eg = model["ent_embeds"].grad
+    assert_close(eg[T(z["d_ent_nz_rows"]).long()], z["d_ent_nz_vals"], 1e-4, 2e-6, "G15 d_ent")
+    assert abs(eg.double().abs().sum().item() - float(z["gabs_ent_embeds"])) < 2e-4 * float(z["gabs_ent_embeds"])
+
+
+@pytest.mark.parametrize("name", ["G15_impute_bi", "G15_impute_uni", "G15_impute_uni_full"])
+def test_G15_impute_window_loss_and_grads(name):
+    z = load(name)
+    num_e, num_r, times, gd = slice_graphs()
+    bi = str(z["module"]).startswith("Bi")
+    cfg = dict(module=str(z["module"]), n_bases=int(z["B"]), inv_temperature=0.1, rec_only_last_layer=bool(z["rec_only"]),
+               use_time_embedding=False, impute=True)
+    model = O.init_model(cfg, num_e, num_r, len(times), int(z["D"]), seed=int(z["seed"]))
+    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6
+    _with_impute_gates(model, bi)
+    leaves = O.leaf_tensors(model)
+    for v in leaves.values():
+        v.requires_grad_(True)
+    tl, targets, samples = window_inputs(z, gd["train"])
+    fn = O.impute_bi_forward_loss if bi else O.impute_uni_forward_loss
+    loss, _ = fn(model, cfg, gd["train"], tl, times, int(z["L"]), targets, samples)
+    assert abs(loss.item() - float(z["loss"])) < 2e-5 * abs(float(z["loss"]))
+    loss.backward()
+    eg = model["ent_embeds"].grad
+    assert_close(eg[T(z["d_ent_nz_rows"]).long()], z["d_ent_nz_vals"], 1e-4, 2e-6, name + " d_ent")
+    assert_close(model["rel_embeds"].grad, z["d_rel"], 1e-4, 2e-6, name + " d_rel")
+    for nm in (("impute_weight_forward", "impute_weight_backward") if bi else ("impute_weight",)):
+        w, b = model["ent_encoder"][nm]
+        assert abs(w.grad.abs().sum().item() - float(z["gabs_ent_encoder.%s.weight" % nm])) < 2e-4 * max(float(z["gabs_ent_encoder.%s.weight" % nm]), 1e-3)
+        assert abs(b.grad.abs().sum().item() - float(z["gabs_ent_encoder.%s.bias" % nm])) < 2e-4 * max(float(z["gabs_ent_encoder.%s.bias" % nm]), 1e-3)

@@ -346,3 +346,22 @@ def test_static_rgcn_fused_loss_equals_per_graph_path():
     assert abs(loss1.item() - loss2.item()) < 1e-5 * max(1.0, abs(loss2.item()))
     for a, b in zip(g1, (m.ent_embeds.grad, m.rel_embeds.grad, m.ent_encoder.layer_1.weight.grad)):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+# ---- config 3: post-ensemble / impute window models (G15) ------------------------------------------------------------
+@pytest.mark.parametrize("batched", [True, False])
+def test_post_ensemble_bi_window_golden(batched):
+    from tests.window_cases import check_post_bi
+    check_post_bi(torch.device("cpu"), batched)
+
+
+@pytest.mark.parametrize("name,batched", [("G15_impute_bi", True), ("G15_impute_bi", False), ("G15_impute_uni", True),
+                                          ("G15_impute_uni", False), ("G15_impute_uni_full", False)])
+def test_impute_window_golden(name, batched):
+    from tests.window_cases import check_impute_window
+    check_impute_window(name, torch.device("cpu"), batched)
+
+
+def test_post_ensemble_loss_definition():
+    from tests.window_cases import check_post_ensemble_loss
+    check_post_ensemble_loss(torch.device("cpu"))

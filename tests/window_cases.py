@@ -296,3 +296,149 @@ def check_sa_evaluate(name, device):
         for i, (a, b) in enumerate(zip(per_graph, want)):
             assert_close(a, b, 1e-5, 2e-6, name + " eval encode")
             assert_close(all_list[i], O.sa_all_embeds(model, cfg, gd["train"], i, tt[i], b, hist, mask, td), 1e-5, 2e-6, name + " all embeds")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 3: post-ensemble / impute window models (G15)
+# ---------------------------------------------------------------------------------------------------------------------
+IMPUTE_GATES = {"impute_weight": (0.3, -0.1), "impute_weight_forward": (0.25, -0.05), "impute_weight_backward": (0.4, 0.1)}
+
+
+def build_post_model(z, device, cls, batched=True, **flags):
+    s = slice_snapshots()
+    module, rec_only, D, B, L = str(z["module"]), bool(z["rec_only"]), int(z["D"]), int(z["B"]), int(z["L"])
+    cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=False)
+    model = O.init_model(cfg, s["num_e"], s["num_r"], len(s["times"]), D, seed=int(z["seed"]))
+    assert abs(checksum(model) - float(z["param_checksum"])) < 1e-6
+    args = make_args(module=module, rec_only_last_layer=rec_only, embed_size=D, hidden_size=D, n_bases=B, train_seq_len=L,
+                     test_seq_len=L, negative_rate=int(z["neg"]), **flags)
+    m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"])
+    missing = m.load_state_dict(state_dict_from_oracle(model), strict=False)
+    assert not missing.unexpected_keys and all("impute_weight" in k for k in missing.missing_keys), missing
+    with torch.no_grad():
+        for nm, (w, b) in IMPUTE_GATES.items():
+            if hasattr(m.ent_encoder, nm):
+                getattr(m.ent_encoder, nm).weight.fill_(w)
+                getattr(m.ent_encoder, nm).bias.fill_(b)
+    m.use_batched_path = batched
+    return m.to(device)
+
+
+def check_post_bi(device, batched=True):
+    """Config 3's model at window level (G15_post_bi, recorded from the reference's ImputeBiDynamicRGCN.pre_forward /
+    get_final_graph_embeds + BiRRGCN.forward_post_ensemble_isolated): (local, temporal) target embeddings, local history
+    streams, all-entity (local, temporal) matrices, gradients of their seeded weighted sum."""
+    from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN
+    z = load("G15_post_bi")
+    m = build_post_model(z, device, PostEnsembleBiDynamicRGCN, batched, post_ensemble=True)
+    assert m._can_batch() == batched
+    edge_ids = [z["choice_%d" % i] for i in range(int(z["n_choices"]))]
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    L = int(z["L"])
+    locs, recs, wb, hist = m.encode_post(t_list, L, True, edge_ids)
+    assert wb.batched == batched and (wb.program is not None) == batched
+    rows_sel = T(z["all_rows"]).long().to(device)
+    gen = torch.Generator().manual_seed(int(z["seed"]))
+    total = 0
+    N = m.num_ents
+    for i, g in enumerate(wb.graphs):
+        assert_close(locs[i], z["loc_%d" % i], 1e-5, 2e-6, "G15 loc %d" % i)
+        assert_close(recs[i], z["rec_%d" % i], 1e-5, 2e-6, "G15 rec %d" % i)
+        # local history streams: the rows of the last executed position, scattered to entity ids
+        for nm, plan, loc in (("f_loc", wb.plan[0], wb.hist_loc[0]), ("b_loc", wb.plan[1], wb.hist_loc[1])):
+            row_of, _ = plan.final_all(i, L - 1)
+            have = np.nonzero(row_of >= 0)[0]
+            want_rows = z["%s_%d_rows" % (nm, i)]
+            vals = loc[torch.from_numpy(row_of[have]).long().to(device)] if have.size else torch.zeros(0, locs[i].shape[1])
+            nz = (vals.detach().abs().sum(1) > 0).cpu().numpy() if have.size else np.zeros(0, bool)     # a ReLU row can be all zero
+            assert np.array_equal(have[nz], want_rows), (nm, i)
+            assert_close(vals[torch.from_numpy(nz).to(vals.device)], z["%s_%d_vals" % (nm, i)], 1e-5, 2e-6, "G15 %s %d" % (nm, i))
+        t = wb.rows[i][-1]
+        full = m.graph_dict_train[t]
+        a_loc, a_rec = m.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc)
+        # the fixture holds the isolated pass BEFORE the active rows are written over it: compare the inactive rows, and the
+        # active ones against the encoder outputs they were overwritten with
+        act = torch.zeros(N, dtype=torch.bool, device=device)
+        act[torch.from_numpy(g.gids).to(device)] = True
+        keep = ~act[rows_sel]
+        assert_close(a_loc[rows_sel][keep], T(z["all_loc_%d" % i]).to(device)[keep], 1e-5, 2e-6, "G15 all loc")
+        assert_close(a_rec[rows_sel][keep], T(z["all_rec_%d" % i]).to(device)[keep], 1e-5, 2e-6, "G15 all rec")
+        assert_close(a_loc[torch.from_numpy(g.gids).to(device)], locs[i], 0, 0, "active rows")
+        iso_loc, iso_rec = m.get_all_embeds_Gt(locs[i][:0], recs[i][:0], type(g)(0, [], [], [], []), t, wb.plan, i, hist, wb.hist_loc)
+        for x, r in ((locs[i], None), (recs[i], None), (iso_loc[rows_sel], None), (iso_rec[rows_sel], None)):
+            total = total + (x * torch.randn(x.shape, generator=gen).to(device)).sum()
+    want = float(z["total"])
+    assert abs(total.item() - want) < 3e-5 * max(1.0, abs(want)), (total.item(), want)
+    total.backward()
+    eg = m.ent_embeds.grad
+    assert_close(eg[T(z["d_ent_nz_rows"]).long().to(device)], z["d_ent_nz_vals"], 1e-4, 3e-6, "G15 d_ent")
+    checked = 0
+    for k, v in m.named_parameters():
+        gk = "gabs_" + k
+        if gk in z.files and v.grad is not None:
+            w = float(z[gk])
+            assert abs(v.grad.double().abs().sum().item() - w) < 3e-4 * max(w, 1e-3), (k, w)
+            checked += 1
+    assert checked >= 9, checked
+    return m
+
+
+def check_impute_window(name, device, batched=True):
+    """ImputeDynamicRGCN / ImputeBiDynamicRGCN.forward (--impute): loss + gradients against the reference (G15_impute_*)."""
+    from temp_amd.post_dynamic_rgcn import ImputeBiDynamicRGCN, ImputeDynamicRGCN
+    z = load(name)
+    bi = str(z["module"]).startswith("Bi")
+    m = build_post_model(z, device, ImputeBiDynamicRGCN if bi else ImputeDynamicRGCN, batched, impute=True)
+    edge_ids, samples = window_inputs(z)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    loss = m(t_list, target_edge_ids=edge_ids, samples=samples)
+    want = float(z["loss"])
+    assert abs(loss.item() - want) < 3e-5 * abs(want), (name, loss.item(), want)
+    loss.backward()
+    eg = m.ent_embeds.grad
+    assert_close(eg[T(z["d_ent_nz_rows"]).long().to(device)], z["d_ent_nz_vals"], 1e-4, 3e-6, name + " d_ent")
+    assert_close(m.rel_embeds.grad, z["d_rel"], 1e-4, 3e-6, name + " d_rel")
+    checked = 0
+    for k, v in m.named_parameters():
+        gk = "gabs_" + k
+        if gk in z.files and v.grad is not None:
+            w = float(z[gk])
+            assert abs(v.grad.double().abs().sum().item() - w) < 3e-4 * max(w, 1e-3), (name, k, v.grad.double().abs().sum().item(), w)
+            checked += 1
+    assert checked >= 7, checked
+    return m
+
+
+def check_post_ensemble_loss(device):
+    """PostEnsembleBiDynamicRGCN.forward with injected mixing weights: the score-level ensemble loss equals its definition
+    (models/PostDynamicRGCN.py:399-406) evaluated with the oracle's scorers on the model's own (local, temporal) embeddings."""
+    from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN
+    z = load("G15_post_bi")
+    m = build_post_model(z, device, PostEnsembleBiDynamicRGCN, True, post_ensemble=True)
+    edge_ids = [z["choice_%d" % i] for i in range(int(z["n_choices"]))]
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    wb = m.prepare(t_list, int(z["L"]), True, edge_ids)
+    gen = torch.Generator().manual_seed(3)
+    samples, weights = [], []
+    for g in wb.graphs:
+        P = min(40, g.number_of_edges())
+        trip = torch.from_numpy(np.stack([g.src[:P], g.rel[:P], g.dst[:P]], axis=1))
+        samples.append((trip, torch.randint(0, m.num_ents, (P, 6), generator=gen), torch.randint(0, m.num_ents, (P, 6), generator=gen)))
+        weights.append((torch.rand(P, 1, generator=gen), torch.rand(P, 1, generator=gen)))
+    loss = m.run_loss(wb, samples, weights)
+    with torch.no_grad():
+        out, hist = m.run(wb)
+        recs, locs = list(out.split(wb.target.sizes)), list(wb.out_loc.split(wb.target.sizes))
+        want = 0
+        for i, g in enumerate(wb.graphs):
+            a_loc, a_rec = m.get_all_embeds_Gt(locs[i], recs[i], g, wb.rows[i][-1], wb.plan, i, hist, wb.hist_loc)
+            trip, nt, nh = (x.to(device) for x in samples[i])
+            ws, wo = (x.to(device) for x in weights[i])
+            r = m.rel_embeds[trip[:, 1]]
+            lab = torch.zeros(trip.shape[0], dtype=torch.int64, device=device)
+            st = wo * O.complex_score(locs[i][trip[:, 0]], r, a_loc[nt], "tail") + (1 - wo) * O.complex_score(recs[i][trip[:, 0]], r, a_rec[nt], "tail")
+            sh = ws * O.complex_score(a_loc[nh], r, locs[i][trip[:, 2]], "head") + (1 - ws) * O.complex_score(a_rec[nh], r, recs[i][trip[:, 2]], "head")
+            want = want + torch.nn.functional.cross_entropy(st, lab) + torch.nn.functional.cross_entropy(sh, lab)
+    assert abs(loss.item() - want.item()) < 2e-5 * abs(want.item())
+    loss.backward()
+    assert m.ent_embeds.grad.abs().sum() > 0 and m.ent_encoder.layer_2.forward_rnn.weight_hh_l0.grad.abs().sum() > 0
