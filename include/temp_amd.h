@@ -208,6 +208,11 @@ int temp_gru_bwd(int n, int d, int variant,
                  float* d_decay_wb /*nullable*/,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Fixed exponential decay as a stand-alone row scale: out[r, :] = x[r, :] * exp(-dt[r] * lambda) -- the recurrent term of the
+ * linear-recurrence layers (RRGCNLayer models/RRGCN.py:130-151, BiRRGCNLayer models/BiRRGCN.py:115-140), whose GEMM runs through
+ * temp_linear.  Self-adjoint (the backward is the same call on the gradient).  out may alias x. */
+int temp_decay_rows(int n, int d, const float* x, const float* dt, float lambda, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Window-batched recurrence.  When only the last layer is recurrent (--rec-only-last-layer,
  * models/RRGCN.py:182-187) the GRU input x of EVERY window position is known before the chain

@@ -94,6 +94,7 @@ SYMBOLS = {
     "temp_gru_bwd_workspace": (_SZ, [_I, _I, _I]),
     "temp_gru_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp,
                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_decay_rows": (_I, [_I, _I, c_vp, c_vp, _F, c_vp, c_vp]),
     "temp_gru_input_gates": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_cell_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gru_cell_bwd": (_I, [_I, _I, _I, c_vp, _SZ, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

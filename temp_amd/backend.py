@@ -243,6 +243,12 @@ class HipBackend:
         rc = self.lib.temp_gru_cell_bwd_multi(len(cells), arr, d, variant, float(lam), saved_all.shape[1] * d, _stream())
         _lib.check(rc, "temp_gru_cell_bwd_multi")
 
+    def decay_rows(self, x, dt, lam):
+        x, dt = _f32(x, "x"), _f32(dt, "dt")
+        out = torch.empty_like(x)
+        _lib.check(self.lib.temp_decay_rows(x.shape[0], x.shape[1], _ptr(x), _ptr(dt), float(lam), _ptr(out), _stream()), "temp_decay_rows")
+        return out
+
     # ---- persistent window chain (include/temp_amd.h: TempGruChain) -------------------------------
     def gru_chain_supported(self, d):
         return bool(self.lib.temp_gru_chain_supported(int(d)))

@@ -72,7 +72,8 @@ class BiGRRGCNLayer(RGCNLayer):
 
 
 class BiRRGCNLayer(RGCNLayer):
-    """Linear bidirectional recurrence, models/BiRRGCN.py:102-185 (extra GEMMs are library GEMMs)."""
+    """Linear bidirectional recurrence, models/BiRRGCN.py:102-185; the recurrent terms run on temp_decay_rows + the MFMA
+    panel GEMM (temp_linear), like everything else of the encoder."""
 
     def __init__(self, args, in_feat, out_feat, num_rels, num_bases, total_times, bias=None, activation=None,
                  self_loop=True, dropout=0.0):
@@ -99,8 +100,8 @@ class BiRRGCNLayer(RGCNLayer):
         g = g.local_var()
         lam = self.inv_temperature
         pre = self._core(g, g.ndata['h'])
-        pre = pre + torch.mm(prev_graph_embeds_forward * torch.exp(-time_diff_tensor_forward * lam), self.time_weight_forward)
-        pre = pre + torch.mm(prev_graph_embeds_backward * torch.exp(-time_diff_tensor_backward * lam), self.time_weight_backward)
+        pre = pre + TF.linear_nt(TF.decay_rows(prev_graph_embeds_forward, time_diff_tensor_forward, lam), self.time_weight_forward)
+        pre = pre + TF.linear_nt(TF.decay_rows(prev_graph_embeds_backward, time_diff_tensor_backward, lam), self.time_weight_backward)
         g.ndata['h'] = self._finish(pre)
         return g, self.get_time_embedding(time_batched_list_t, node_sizes)
 
@@ -108,7 +109,7 @@ class BiRRGCNLayer(RGCNLayer):
         g = g.local_var()
         pre = self._core(g, g.ndata['h'])
         weight = self.time_weight_forward if forward else self.time_weight_backward
-        pre = pre + torch.mm(prev_graph_embeds, weight) * torch.exp(-time_diff_tensor * self.inv_temperature)
+        pre = pre + TF.decay_rows(TF.linear_nt(prev_graph_embeds, weight), time_diff_tensor, self.inv_temperature)
         g.ndata['h'] = self._finish(pre)
         return g, self.get_time_embedding(time_batched_list_t, node_sizes)
 
@@ -116,8 +117,8 @@ class BiRRGCNLayer(RGCNLayer):
                          time_diff_tensor_backward, time):
         lam = self.inv_temperature
         pre = TF.rgcn_isolated(node_repr, self.loop_weight, None, None, self._drop())
-        pre = pre + torch.mm(prev_graph_embeds_forward * torch.exp(-time_diff_tensor_forward * lam), self.time_weight_forward)
-        pre = pre + torch.mm(prev_graph_embeds_backward * torch.exp(-time_diff_tensor_backward * lam), self.time_weight_backward)
+        pre = pre + TF.linear_nt(TF.decay_rows(prev_graph_embeds_forward, time_diff_tensor_forward, lam), self.time_weight_forward)
+        pre = pre + TF.linear_nt(TF.decay_rows(prev_graph_embeds_backward, time_diff_tensor_backward, lam), self.time_weight_backward)
         return self._finish(pre), (self.time_embed[int(time)] if self.compute_time_embedding else None)
 
 

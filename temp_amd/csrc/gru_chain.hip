@@ -162,7 +162,6 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
             stage(wB, hB);
             __builtin_amdgcn_sched_barrier(0);
           }
-          __syncthreads();    // C (of the previous position): the memory waves are done reading its products
           // lane (li, hh) owns track li and, per register quad qq, gate columns tile*32 + 8qq + 4hh .. +3
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
@@ -175,11 +174,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
             }
           }
         }
-        else __syncthreads();   // C
         __syncthreads();      // A: products of position s are in LDS
         __syncthreads();      // B: states of position s are in LDS
       }
-      __syncthreads();        // C of the last position
     } else {
       // ------------------------------------------------------------------ memory role
       const int mw = wave - 4, c4 = lane, col = 4 * c4;
@@ -200,31 +197,26 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
         }
       };
       prefetch(0);
-      __syncthreads();        // C "of position -1" (pairs with the matrix waves' first hand-over)
       for (int s = 0; s < ns; ++s) {
         const int cur = s & 1;
         const int flags = flagb[s];
+        __syncthreads();      // A
         const float* hcur = hb + (size_t)cur * CH_SLOTS * ldh;
         float* hnext = hb + (size_t)(cur ^ 1) * CH_SLOTS * ldh;
-        // Pass 0 sits on the critical path of the recurrence and touches LDS only: gates -> new states -> barrier B hands them
-        // to the matrix waves.  It leaves r, z and W_hn.h + b_hn in the LDS cells of the products it consumed; pass 1 picks
-        // them up (n = tanh(gi_n + r * hn) is one more hardware exp) and does ALL the HBM stores while the matrix waves
-        // already run the next position -- so the time the stores need to drain (33 MB per position over the chip) never
-        // holds a barrier up.  Barrier C returns the product buffer to the matrix waves.
-        __syncthreads();      // A
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
           const int slot = ps * MW + mw;
           const int e = erow[ps];
           if (e < 0 || !cact) continue;
+          const size_t row = (size_t)(e & CH_ROW_MASK);
           const bool hp = (e & CH_HAS_PREV) != 0;
-          float* ab = accb + (size_t)slot * lda + col;
           float4 ar = zero4(), az = zero4(), an = zero4(), hd = zero4();
           if (hp) {                                   // (a track without a previous state contributed zeros to the products)
+            const float* ab = accb + (size_t)slot * lda + col;
             ar = ld4(ab); az = ld4(ab + D); an = ld4(ab + 2 * D);
             hd = scale4(ld4(hcur + (size_t)slot * ldh + col), decb[s * CH_SLOTS + slot]);
           }
-          float o_h[4], o_r[4], o_z[4], o_hn[4];
+          float o_h[4], o_r[4], o_z[4], o_n[4], o_hn[4];
           const float arv[4] = {ar.x, ar.y, ar.z, ar.w}, azv[4] = {az.x, az.y, az.z, az.w}, anv[4] = {an.x, an.y, an.z, an.w};
           const float hdv[4] = {hd.x, hd.y, hd.z, hd.w};
           const float g0v[4] = {g0[ps].x, g0[ps].y, g0[ps].z, g0[ps].w}, g1v[4] = {g1[ps].x, g1[ps].y, g1[ps].z, g1[ps].w};
@@ -239,39 +231,20 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
             const float hn = anv[k] + bnv[k];
             const float ng = gate_tanh(g2v[k] + rg * hn);
             o_h[k] = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg) * ng + zg * hdv[k]) : (ng + zg * (hdv[k] - ng));
-            o_r[k] = rg; o_z[k] = zg; o_hn[k] = hn;
+            o_r[k] = rg; o_z[k] = zg; o_n[k] = ng; o_hn[k] = hn;
           }
-          st4(hnext + (size_t)slot * ldh + col, make_float4(o_h[0], o_h[1], o_h[2], o_h[3]));
-          st4(ab, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
-          st4(ab + D, make_float4(o_z[0], o_z[1], o_z[2], o_z[3]));
-          st4(ab + 2 * D, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
-        }
-        __syncthreads();      // B
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-          const int slot = ps * MW + mw;
-          const int e = erow[ps];
-          if (e < 0 || !cact) continue;
-          const size_t o = (size_t)(e & CH_ROW_MASK) * D + col;
-          const float* ab = accb + (size_t)slot * lda + col;
-          const float4 rg = ld4(ab), zg = ld4(ab + D), hn = ld4(ab + 2 * D);
-          float4 hd = zero4();                        // (the previous states stay in LDS until pass 0 of the next position)
-          if (e & CH_HAS_PREV) hd = scale4(ld4(hcur + (size_t)slot * ldh + col), decb[s * CH_SLOTS + slot]);
-          float4 ng, h4;
-#define TEMP_BLEND(c)                                                                                                    \
-          ng.c = gate_tanh(g2[ps].c + rg.c * hn.c);                                                                      \
-          h4.c = (VARIANT == TEMP_GRU_TORCH) ? ((1.f - zg.c) * ng.c + zg.c * hd.c) : (ng.c + zg.c * (hd.c - ng.c));
-          TEMP_BLEND(x) TEMP_BLEND(y) TEMP_BLEND(z) TEMP_BLEND(w)
-#undef TEMP_BLEND
+          const float4 h4 = make_float4(o_h[0], o_h[1], o_h[2], o_h[3]);
+          st4(hnext + (size_t)slot * ldh + col, h4);
+          const size_t o = row * D + col;
           if (flags & 2) st4(H + o, h4);
-          st4(saved + o, rg);
-          st4(saved + plane + o, zg);
-          st4(saved + 2 * plane + o, ng);
-          st4(saved + 3 * plane + o, hn);
+          st4(saved + o, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
+          st4(saved + plane + o, make_float4(o_z[0], o_z[1], o_z[2], o_z[3]));
+          st4(saved + 2 * plane + o, make_float4(o_n[0], o_n[1], o_n[2], o_n[3]));
+          st4(saved + 3 * plane + o, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
           st4(saved + 4 * plane + o, hd);
         }
-        __syncthreads();      // C: the products of position s may be overwritten
-        if (s + 1 < ns) prefetch(s + 1);       // in flight while the matrix waves finish position s + 1
+        if (s + 1 < ns) prefetch(s + 1);       // in flight while the matrix waves run position s + 1
+        __syncthreads();      // B
       }
     }
     __syncthreads();          // LDS is re-initialised for the next panel
@@ -409,18 +382,17 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
       };
       prefetch(ns - 1);
       for (int s = ns - 1; s >= 0; --s) {
+        const int cur = s & 1;
         // upstream gradient of the step's rows (only the positions whose states are consumed outside the chain -- the
         // target, the last history position -- have one: loaded on demand instead of holding registers for it all the time)
         const int up_sel = a.sinfo[4 * (size_t)(s0 + s) + 1], up_row0 = a.sinfo[4 * (size_t)(s0 + s) + 2];
         const float* upp = up_sel >= 0 ? ups.p[up_sel] : nullptr;
-        // critical path first: gate gradients -> LDS (the matrix waves wait for them at barrier A); the HBM stores of the
-        // same values follow after the barrier, while the matrix waves run the d_prev product
-        float4 o_r[PASSES], o_z[PASSES], o_n[PASSES], o_hn[PASSES];
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
           const int slot = ps * MW + mw;
           const int e = erow[ps];
-          if (!cact || e < 0) continue;        // idle track: whatever its LDS rows hold only reaches its own, unread, d_prev row
+          if (!cact) continue;
+          if (e < 0) continue;                 // idle track: whatever its LDS rows hold only reaches its own, unread, d_prev row
           const size_t row = (size_t)(e & CH_ROW_MASK);
           float4 gd = upp ? ld4(upp + (row - (size_t)up_row0) * D + col) : zero4();
           if (nxt[ps]) gd = add4(gd, ld4(dpb + (size_t)slot * ldz + col));
@@ -441,21 +413,13 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
           float* arow = ab + (size_t)slot * ldA + col;
           st4(arow, dr_pre); st4(arow + D, dz_pre); st4(arow + 2 * D, dhn);
           st4(gzb + (size_t)slot * ldz + col, gz);
-          o_r[ps] = dr_pre; o_z[ps] = dz_pre; o_n[ps] = dn_pre; o_hn[ps] = dhn;
-          __builtin_amdgcn_sched_barrier(0);   // one pass at a time: the next pass's inputs are already in registers
-        }
-        __syncthreads();      // A
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-          const int e = erow[ps];
-          if (!cact || e < 0) continue;
-          const size_t row = (size_t)(e & CH_ROW_MASK);
           const size_t b3 = row * 3 * D + col;
-          if (VARIANT == TEMP_GRU_TORCH) { st4(dgi + b3, o_r[ps]); st4(dgi + b3 + D, o_z[ps]); st4(dgi + b3 + 2 * D, o_n[ps]); }
-          else st4(dgi + row * D + col, o_n[ps]);
-          st4(dgh + b3, o_r[ps]); st4(dgh + b3 + D, o_z[ps]); st4(dgh + b3 + 2 * D, o_hn[ps]);
+          if (VARIANT == TEMP_GRU_TORCH) { st4(dgi + b3, dr_pre); st4(dgi + b3 + D, dz_pre); st4(dgi + b3 + 2 * D, dn_pre); }
+          else st4(dgi + row * D + col, dn_pre);
+          st4(dgh + b3, dr_pre); st4(dgh + b3 + D, dz_pre); st4(dgh + b3 + 2 * D, dhn);
         }
         if (s > 0) prefetch(s - 1);            // in flight while the matrix waves run position s
+        __syncthreads();      // A
         __syncthreads();      // B
       }
     }

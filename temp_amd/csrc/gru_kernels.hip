@@ -497,6 +497,21 @@ __global__ void __launch_bounds__(256) k_decay_grad(int n, int D, const float* _
   if (threadIdx.x == 0) { d_wb[0] = sw[0]; d_wb[1] = sb[0]; }
 }
 
+// out[r, :] = x[r, :] * exp(-dt[r] * lambda): the fixed exponential decay of a previous state as a stand-alone row scale
+// (linear recurrence of RRGCNLayer / BiRRGCNLayer, models/RRGCN.py:146, models/BiRRGCN.py:126-129).  Self-adjoint: the
+// backward is the same kernel on the gradient.  LPR lanes per row (power of two >= d / 4), one float4 per lane.
+template <int LPR>
+__global__ void __launch_bounds__(256) k_decay_rows(int n, int D, const float* __restrict__ x, const float* __restrict__ dt, float lambda,
+                                                    float* __restrict__ out) {
+  const int D4 = D >> 2;
+  const int lr = threadIdx.x & (LPR - 1), rsub = threadIdx.x / LPR;
+  constexpr int RPB = 256 / LPR;
+  for (int row = blockIdx.x * RPB + rsub; row < n; row += gridDim.x * RPB) {
+    const float dec = expf(-dt[row] * lambda);
+    for (int c4 = lr; c4 < D4; c4 += LPR) st4(out + (size_t)row * D + 4 * c4, scale4(ld4(x + (size_t)row * D + 4 * c4), dec));
+  }
+}
+
 struct GruBwdWs { float* dgi; float* dgh; float* decv; void* tn; size_t tn_bytes; void* cs; size_t cs_bytes; size_t total; };
 static GruBwdWs carve_gru(int n, int d, int variant, char* base) {
   GruBwdWs w;
@@ -652,6 +667,21 @@ int temp_gru_bwd(int n, int d, int variant, const float* x, const float* prev, c
     rc = launch_status();
   }
   return rc;
+}
+
+int temp_decay_rows(int n, int d, const float* x, const float* dt, float lambda, float* out, void* stream) {
+  if (n < 0 || d <= 0 || (n > 0 && (!x || !dt || !out))) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (n == 0) return TEMP_OK;
+  const int d4 = d / 4;
+  const int lpr = d4 <= 8 ? 8 : (d4 <= 16 ? 16 : (d4 <= 32 ? 32 : 64));
+  int gx = ceil_div(n, 256 / lpr);
+  if (gx > 4096) gx = 4096;
+  hipStream_t st = (hipStream_t)stream;
+#define TEMP_DECAY(L) TEMP_LAUNCH(K_DECAY_GRAD, (k_decay_rows<L>), dim3(gx), dim3(256), 0, st, n, d, x, dt, lambda, out)
+  if (lpr == 8) TEMP_DECAY(8); else if (lpr == 16) TEMP_DECAY(16); else if (lpr == 32) TEMP_DECAY(32); else TEMP_DECAY(64);
+#undef TEMP_DECAY
+  return launch_status();
 }
 
 /* ---- window-batched recurrence (see include/temp_amd.h) ---------------------------------------- */

@@ -82,34 +82,62 @@ def allreduce_gradients(params, world=None, average=True, group=None):
 
 
 class _AllGatherRows(torch.autograd.Function):
-    """forward : all-gather of equally padded row blocks -> rows re-ordered to the canonical layout
-    backward: scatter to the padded layout, reduce-scatter (sum) -> this rank's rows."""
+    """All-gather of UNEVEN row blocks straight into the canonical layout, and its adjoint.
+
+    The shards are contiguous ranges of the (distinct-snapshot) row space, so rank r's block lands at rows
+    [bounds[r], bounds[r+1]) of the output: no padding to the largest shard, no re-ordering gather.  Implemented as ONE group
+    of point-to-point operations (`batch_isend_irecv`: on RCCL a grouped send/recv, i.e. every rank writes its block to
+    each peer over its own xGMI link -- the links are point-to-point, so a direct all-to-all of blocks uses all 7 of them at
+    once instead of walking a ring).
+    backward: every rank holds gradient rows for ALL blocks (it consumed them in its windows of the recurrence); block q of
+    each rank is sent to rank q, which sums the pieces in rank order (deterministic)."""
 
     @staticmethod
-    def forward(ctx, local, n_max, canon_index, world, rank, group):
+    def forward(ctx, local, bounds, world, rank, group):
         d = local.shape[1]
-        pad = local.new_zeros(n_max, d)
-        pad[:local.shape[0]] = local
-        gathered = local.new_empty(world * n_max, d)
-        dist.all_gather_into_tensor(gathered, pad, group=group)
-        ctx.save_for_backward(canon_index)
-        ctx.meta = (local.shape[0], n_max, world, rank, group)
-        return gathered.index_select(0, canon_index)
+        out = local.new_empty(int(bounds[-1]), d)
+        out[bounds[rank]:bounds[rank + 1]] = local
+        ops = []
+        for q in range(world):
+            if q == rank:
+                continue
+            if bounds[q + 1] > bounds[q]:
+                ops.append(dist.P2POp(dist.irecv, out[bounds[q]:bounds[q + 1]], _global_rank(q, group), group))
+            if local.shape[0] > 0:
+                ops.append(dist.P2POp(dist.isend, local, _global_rank(q, group), group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        ctx.meta = (bounds, world, rank, group)
+        return out
 
     @staticmethod
     def backward(ctx, d_all):
-        (canon_index,) = ctx.saved_tensors
-        n_local, n_max, world, rank, group = ctx.meta
-        d = d_all.shape[1]
-        padded = d_all.new_zeros(world * n_max, d)
-        padded.index_copy_(0, canon_index, d_all.contiguous())
-        mine = d_all.new_empty(n_max, d)
-        try:
-            dist.reduce_scatter_tensor(mine, padded, group=group)
-        except (RuntimeError, NotImplementedError):          # gloo has no reduce_scatter: all-reduce + slice
-            dist.all_reduce(padded, group=group)
-            mine = padded[rank * n_max:(rank + 1) * n_max]
-        return mine[:n_local].contiguous(), None, None, None, None, None
+        bounds, world, rank, group = ctx.meta
+        d_all = d_all.contiguous()
+        lo, hi = bounds[rank], bounds[rank + 1]
+        n_local, d = hi - lo, d_all.shape[1]
+        pieces = d_all.new_empty(world, n_local, d)
+        pieces[rank] = d_all[lo:hi]
+        ops = []
+        for q in range(world):
+            if q == rank:
+                continue
+            if n_local > 0:
+                ops.append(dist.P2POp(dist.irecv, pieces[q], _global_rank(q, group), group))
+            if bounds[q + 1] > bounds[q]:
+                ops.append(dist.P2POp(dist.isend, d_all[bounds[q]:bounds[q + 1]], _global_rank(q, group), group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        mine = pieces[0]
+        for q in range(1, world):                    # fixed order: the sum does not depend on arrival order
+            mine = mine + pieces[q]
+        return mine, None, None, None, None
+
+
+def _global_rank(r, group):
+    return r if group is None else dist.get_global_rank(group, r)
 
 
 def split_visits_by_edges(edge_counts, world):
@@ -169,13 +197,7 @@ class SnapshotShardedEncoder:
         bounds = split_visits_by_edges([g.number_of_edges() for g in dgraphs], W)
         sizes = np.array([g.n for g in dgraphs], dtype=np.int64)
         canon_off = np.concatenate([[0], np.cumsum(sizes)])
-        shard_rows = [int(sizes[bounds[r]:bounds[r + 1]].sum()) for r in range(W)]
-        n_max = max(max(shard_rows), 1)
-        canon_index = np.empty(int(canon_off[-1]), dtype=np.int64)      # canonical (distinct) row -> row in the padded gather
-        for r in range(W):
-            lo, hi = bounds[r], bounds[r + 1]
-            n_r = int(canon_off[hi] - canon_off[lo])
-            canon_index[canon_off[lo]:canon_off[hi]] = r * n_max + np.arange(n_r)
+        row_bounds = [int(canon_off[b]) for b in bounds]                 # rank r owns canonical rows [row_bounds[r], row_bounds[r+1])
         # ---- this rank's RGCN shard ------------------------------------------------------------------
         from . import snapshot as S
         mine = dgraphs[bounds[R]:bounds[R + 1]]
@@ -194,7 +216,8 @@ class SnapshotShardedEncoder:
         sb = type("ShardBatch", (), {})()
         sb.g_local, sb.ids_local = g_local, torch.from_numpy(g_local.gids.astype(np.int32)).to(dev)
         sb.ids_inv = TF.gather_inverse(g_local.gids, self.model.num_ents, dev)          # static ids: table layer + deterministic gradient
-        sb.n_max, sb.canon_index = n_max, torch.from_numpy(canon_index).to(dev)
+        sb.row_bounds = row_bounds
+        sb.gather_bytes = int(canon_off[-1]) * self.model.embed_size * 4   # bytes every rank ends up holding after the all-gather
         sb.n_edge_visits_local = int(sum(g.number_of_edges() for g in mine))
         sb.n_edge_visits_global = int(sum(g.number_of_edges() for _, _, g in visits))
         # local chain program: for every plan, the sub-chain over this rank's windows
@@ -271,7 +294,7 @@ class SnapshotShardedEncoder:
         enc = m.ent_encoder
         y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table
         y2 = enc.layer_2.conv(sb.g_local, y1)
-        y2_all = _AllGatherRows.apply(y2, sb.n_max, sb.canon_index, self.world, self.rank, self.group)
+        y2_all = _AllGatherRows.apply(y2, sb.row_bounds, self.world, self.rank, self.group)
         x = TF.gather_rows(y2_all, sb.x_index32, sb.x_inv)                                   # deterministic adjoint (segment sum)
         l2 = enc.layer_2
         rnns = [l2.forward_rnn, l2.backward_rnn] if hasattr(l2, "forward_rnn") else [l2.rnn]

@@ -301,6 +301,47 @@ def linear(x, w):
     return _LinearFn.apply(x, w)
 
 
+class _LinearNTFn(torch.autograd.Function):
+    """y = x . W with W stored (in, out) -- the `time_weight` matrices of the linear-recurrence layers."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return get_backend().linear(x, w, False)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, w = ctx.saved_tensors
+        be = get_backend()
+        d_y = d_y.contiguous()
+        d_x = be.linear(d_y, w, True) if ctx.needs_input_grad[0] else None
+        d_w = be.linear_tn(x, d_y) if ctx.needs_input_grad[1] else None
+        return d_x, d_w
+
+
+def linear_nt(x, w):
+    return _LinearNTFn.apply(x.contiguous(), w)
+
+
+class _DecayRowsFn(torch.autograd.Function):
+    """x[r, :] * exp(-dt[r] * lam) (temp_decay_rows); the row scale is its own adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, dt, lam):
+        ctx.save_for_backward(dt)
+        ctx.lam = lam
+        return get_backend().decay_rows(x.contiguous(), dt.contiguous().view(-1), lam)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        (dt,) = ctx.saved_tensors
+        return get_backend().decay_rows(d_y.contiguous(), dt.contiguous().view(-1), ctx.lam), None, None
+
+
+def decay_rows(x, dt, lam):
+    return _DecayRowsFn.apply(x, dt, float(lam))
+
+
 class _HistoryAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, kv_hist, idx, decay, inverse):

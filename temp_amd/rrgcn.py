@@ -67,7 +67,8 @@ class GRRGCNLayer(RGCNLayer):
 class RRGCNLayer(RGCNLayer):
     """Linear recurrence, models/RRGCN.py:120-167:
     out = act(prop + (prev @ W_time) * exp(-dt*lam) [+bias] + loop).  The propagate + self-loop part
-    runs on the HIP layer kernel; the extra (n,D)@(D,D) term is a plain library GEMM."""
+    runs on the HIP layer kernel; the recurrent term is the MFMA panel GEMM (temp_linear) followed by the
+    row-decay kernel (temp_decay_rows) -- no library GEMM, no ATen arithmetic."""
 
     def __init__(self, args, in_feat, out_feat, num_rels, num_bases, total_times, bias=True, activation=None,
                  self_loop=True, dropout=0.0):
@@ -91,13 +92,13 @@ class RRGCNLayer(RGCNLayer):
     def forward(self, g, prev_graph_embeds, time_diff_tensor, time_batched_list_t, node_sizes):
         g = g.local_var()
         pre = self._linear_core(g, g.ndata['h'])
-        rec = torch.mm(prev_graph_embeds, self.time_weight) * torch.exp(-time_diff_tensor * self.inv_temperature)
+        rec = TF.decay_rows(TF.linear_nt(prev_graph_embeds, self.time_weight), time_diff_tensor, self.inv_temperature)
         g.ndata['h'] = self._finish(pre, rec)
         return g, self.get_time_embedding(time_batched_list_t, node_sizes)
 
     def forward_isolated(self, ent_embeds, prev_graph_embeds, time_diff_tensor, time):
         pre = TF.rgcn_isolated(ent_embeds, self.loop_weight, None, None, self._drop())
-        rec = torch.mm(prev_graph_embeds, self.time_weight) * torch.exp(-time_diff_tensor * self.inv_temperature)
+        rec = TF.decay_rows(TF.linear_nt(prev_graph_embeds, self.time_weight), time_diff_tensor, self.inv_temperature)
         return self._finish(pre, rec), (self.time_embed[int(time)] if self.compute_time_embedding else None)
 
 

@@ -245,6 +245,9 @@ class CpuTestBackend:
             self.gru_cell_bwd(saved_all, c["row0"], c["n"], c["dh_up"], c["d_prev_next"], c["next_idx"], c["dt"], lam, c["w_hh"], variant,
                               c["dgi"], c["dgh"], c["decv"], c["d_prev"])
 
+    def decay_rows(self, x, dt, lam):
+        return x.detach() * torch.exp(-dt.detach().view(-1, 1) * lam)
+
     # ---- persistent window chain: the SAME tables the HIP kernels walk (include/temp_amd.h: TempGruChain), panel by panel ----
     def gru_chain_supported(self, d):
         return d % 4 == 0
