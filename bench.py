@@ -211,6 +211,59 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
                        % (nwin, w["name"], visits, edges, dt))
 
 
+def measure_sharded(model, w, world, rank, device, steps, warmup, dist):
+    """BASELINE north_star variant (config 4): ONE global batch of bsz * world windows; its distinct snapshots are cut into
+    `world` edge-balanced shards, each rank runs the two RGCN layers on its shard, one direct all-gather over xGMI hands every
+    rank all per-snapshot node states, the recurrent chain is sharded by window, gradients are all-reduced in one bucket.
+    Eager launches (the collectives are not captured).  -> dict for the JSON line (rank 0) or None."""
+    from temp_amd import synthetic
+    from temp_amd.dist import SnapshotShardedEncoder, _AllGatherRows, allreduce_gradients
+    all_targets = [t for r in range(world) for t in synthetic.default_targets(w["num_times"], w["L"], w["bsz"], r)]
+    model.sample_rng = np.random.default_rng(2)
+    enc = SnapshotShardedEncoder(model)
+    sb = enc.prepare(all_targets, w["L"], train=True)
+    params = [p for p in model.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        enc.run(sb).sum().backward()
+        allreduce_gradients(params, world, average=False)
+
+    for _ in range(warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # the all-gather alone (forward direction), on a buffer of this rank's shard size
+    n_local = sb.row_bounds[rank + 1] - sb.row_bounds[rank]
+    y = torch.randn(n_local, w["D"], device=device)
+    for _ in range(3):
+        _AllGatherRows.apply(y, sb.row_bounds, world, rank, None)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        _AllGatherRows.apply(y, sb.row_bounds, world, rank, None)
+    torch.cuda.synchronize()
+    tg = torch.tensor([(time.perf_counter() - t1) / 10], device=device, dtype=torch.float64)
+    dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+    for p in params:
+        p.grad = None
+    return dict(value=sb.n_edge_visits_global * steps / elapsed, unit="edges/s", ms_per_step=1e3 * elapsed / steps,
+                global_windows=len(all_targets), rccl_ranks=dist.get_world_size(), launch="eager",
+                edge_visits_per_step_global=sb.n_edge_visits_global, distinct_edges_this_rank=sb.n_edge_visits_local,
+                allgather_bytes_received_per_rank=sb.gather_bytes - n_local * w["D"] * 4, allgather_ms=1e3 * float(tg.item()),
+                parallelism="distinct snapshots/%d (edge-balanced) + direct all-gather(node states) + window-sharded GRU chain + grad all-reduce" % world)
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -228,10 +281,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="S-gdelt")
     ap.add_argument("--trace-steps", type=int, default=3)
-    ap.add_argument("--shard", choices=("windows", "snapshots"), default="windows",
-                    help="N>1: 'windows' = each rank encodes its own windows (+ gradient all-reduce); 'snapshots' = snapshot "
-                         "visits of a global batch of bsz*N windows sharded across ranks with an all-gather of per-snapshot "
-                         "node states before the recurrent chain (north_star variant)")
+    ap.add_argument("--shard", choices=("both", "windows", "snapshots"), default="both",
+                    help="N>1: 'windows' = each rank encodes its own windows (+ gradient all-reduce), the reference's DDP axis, HIP-graph "
+                         "replay; 'snapshots' = the distinct snapshots of a global batch of bsz*N windows sharded across ranks with a "
+                         "direct all-gather of per-snapshot node states before the recurrent chain (BASELINE north_star, eager); "
+                         "'both' (default) = the headline `value` is the windows mode and the snapshot-sharded measurement rides along "
+                         "under `north_star_sharded`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-loop-steps", type=int, default=30,
                     help="also time this many steps of a real training loop (new batch every step: host prepare, fresh negatives, loss, "
@@ -274,6 +329,12 @@ def main():
     bi = w["module"].startswith("Bi")
     from temp_amd.dist import SnapshotShardedEncoder, allreduce_gradients
     sharded = dist is not None and a.shard == "snapshots"
+    ns_result = None
+    if dist is not None and a.shard == "both" and a.encoder == "gru" and not a.with_loss:
+        try:
+            ns_result = measure_sharded(model, w, world, rank, device, a.steps, a.warmup, dist)
+        except Exception as e:                      # never lose the headline line to the secondary measurement
+            ns_result = dict(error="%s: %s" % (type(e).__name__, e))
     targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rank)
     params = [p for p in model.parameters()]
     t0 = time.perf_counter()
@@ -449,7 +510,7 @@ def main():
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
                                else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager"),
                                train_loop=loop),
-                   roofline=roof, cpu_baseline=cpu)
+                   roofline=roof, cpu_baseline=cpu, north_star_sharded=ns_result)
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
         # that the JSON line is the LAST line of stdout
         sys.stdout.flush()

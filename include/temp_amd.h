@@ -392,6 +392,33 @@ int temp_assemble_views(int n_pieces, const int32_t* piece_desc, const int32_t* 
                         int32_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Device-side edge subsample of a resident snapshot: the training-time 50 % (target) / 80 %
+ * (--random-dropout history) random edge subset with recomputed norms of DynamicRGCN.get_batch_graph_embeds
+ * (models/DynamicRGCN.py:76-90; comp_deg_norm utils/utils.py:74-79), derived from the snapshot's resident sorted / chunked
+ * views without a host rebuild or an upload.
+ *   parent / child : packed view buffers of one snapshot with the layout of Snapshot.device_views (temp_amd/snapshot.py);
+ *                    `child` must start as a copy of `parent`.  The call rewrites, in `child`, the a / b arrays of the three
+ *                    views (kept edges moved to the front of every chunk, order preserved), their chunk_end arrays,
+ *                    in_deg, out_deg and nnorm (1 / in_deg, 0 for isolated nodes); chunk tables, partial slots and fix-up
+ *                    lists stay valid, so every temp_rgcn_* entry point runs on the child unchanged.
+ *   eid [3][E]     : original edge id of every position of the by-dst / by-src / by-rel view.
+ *   keep           : size of the subset; it is the set of the `keep` smallest values of a 64-bit counter hash of
+ *                    (seed, edge id) -- a uniformly random `keep`-subset that depends on the seed only.
+ *   keep_mask      : nullable [E] uint8 out, 1 = edge kept (original edge order).
+ *   scratch        : >= 8 bytes of device memory per job.
+ * `jobs` is a HOST array; all jobs of a batch run in three launches.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct TempSubsampleJob {
+  int32_t n_nodes, n_edges, keep;
+  uint64_t seed;
+  const int32_t* parent; int32_t* child; const int32_t* eid;
+  int32_t off_a[3], off_b[3], off_chunk_beg[3], off_chunk_end[3], off_chunk_seg[3], n_chunks[3];   /* word offsets inside a pack */
+  int32_t off_in_deg, off_out_deg, off_nnorm;
+  uint8_t* keep_mask; void* scratch;
+} TempSubsampleJob;
+int temp_subsample_views(int n_jobs, const TempSubsampleJob* jobs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Filtered negative sampling (CorruptTriples.negative_sampling / corrupt_triple, utils/CorrptTriples.py:36-85):
  *   cand[row, 0] = truth[row];   cand[row, 1..K] = uniform draws over [0, N) that are not in the row's
  *   known-true set ids[lo[row] .. hi[row])  (global entity ids, ascending within a row; lo/hi NULL = no filter).

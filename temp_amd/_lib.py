@@ -55,6 +55,15 @@ class TempGruChain(ctypes.Structure):
                 ("saved_plane", ctypes.c_size_t), ("n_rnn", ctypes.c_int32), ("packed", c_vp * CHAIN_MAX_RNN), ("b_hh", c_vp * CHAIN_MAX_RNN)]
 
 
+class TempSubsampleJob(ctypes.Structure):
+    _fields_ = [("n_nodes", ctypes.c_int32), ("n_edges", ctypes.c_int32), ("keep", ctypes.c_int32), ("seed", ctypes.c_uint64),
+                ("parent", c_vp), ("child", c_vp), ("eid", c_vp),
+                ("off_a", ctypes.c_int32 * 3), ("off_b", ctypes.c_int32 * 3), ("off_chunk_beg", ctypes.c_int32 * 3),
+                ("off_chunk_end", ctypes.c_int32 * 3), ("off_chunk_seg", ctypes.c_int32 * 3), ("n_chunks", ctypes.c_int32 * 3),
+                ("off_in_deg", ctypes.c_int32), ("off_out_deg", ctypes.c_int32), ("off_nnorm", ctypes.c_int32),
+                ("keep_mask", c_vp), ("scratch", c_vp)]
+
+
 class TempDropout(ctypes.Structure):
     _fields_ = [("p", ctypes.c_float), ("seed", ctypes.c_uint64)]
 
@@ -121,6 +130,7 @@ SYMBOLS = {
     "temp_bilinear_query_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_bilinear_query_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_assemble_views": (_I, [_I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_subsample_views": (_I, [_I, ctypes.POINTER(TempSubsampleJob), c_vp]),
     "temp_corrupt_sample": (_I, [_I, _I, _I, ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_filtered_rank": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_sa_attn_fwd": (_I, [ctypes.POINTER(TempAttn), c_vp, c_vp, c_vp, c_vp]),

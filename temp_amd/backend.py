@@ -243,6 +243,22 @@ class HipBackend:
         rc = self.lib.temp_gru_cell_bwd_multi(len(cells), arr, d, variant, float(lam), saved_all.shape[1] * d, _stream())
         _lib.check(rc, "temp_gru_cell_bwd_multi")
 
+    def subsample_views(self, jobs):
+        """jobs: list of dicts(n_nodes, n_edges, keep, seed, parent, child, eid, offs {name: [3] | int}, n_chunks [3], keep_mask,
+        scratch) -- see include/temp_amd.h: temp_subsample_views."""
+        arr = (_lib.TempSubsampleJob * len(jobs))()
+        for a, j in zip(arr, jobs):
+            a.n_nodes, a.n_edges, a.keep, a.seed = j["n_nodes"], j["n_edges"], j["keep"], int(j["seed"]) & 0xFFFFFFFFFFFFFFFF
+            a.parent, a.child = _i32(j["parent"], "parent").data_ptr(), _i32(j["child"], "child").data_ptr()
+            a.eid = _i32(j["eid"], "eid").data_ptr() if j["n_edges"] else None
+            for fld in ("off_a", "off_b", "off_chunk_beg", "off_chunk_end", "off_chunk_seg", "n_chunks"):
+                for v in range(3):
+                    getattr(a, fld)[v] = int(j[fld][v])
+            a.off_in_deg, a.off_out_deg, a.off_nnorm = int(j["off_in_deg"]), int(j["off_out_deg"]), int(j["off_nnorm"])
+            a.keep_mask = j["keep_mask"].data_ptr() if j.get("keep_mask") is not None else None
+            a.scratch = j["scratch"].data_ptr()
+        _lib.check(self.lib.temp_subsample_views(len(jobs), arr, _stream()), "temp_subsample_views")
+
     def decay_rows(self, x, dt, lam):
         x, dt = _f32(x, "x"), _f32(dt, "dt")
         out = torch.empty_like(x)

@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtemp_amd.so")
-SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip", "gru_chain.hip", "attn_kernels.hip"]
+SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip", "gru_chain.hip", "attn_kernels.hip", "store_kernels.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")] + [os.path.join(REPO, "include", "temp_amd.h")]
 OBJDIR = os.path.join(CSRC, "build")
 

@@ -55,6 +55,7 @@ class DynamicRGCN(TKG_Module):
         self.use_batched_path = True
         self.use_gru_chain = True
         self.dedup_snapshots = True
+        self.device_subsample = True          # training-time edge subsets drawn and applied on the GPU (host sampler when False)
 
     def build_model(self):
         self.ent_encoder = RRGCN(self.args, self.hidden_size, self.embed_size, self.num_rels, self.total_time)
@@ -79,6 +80,12 @@ class DynamicRGCN(TKG_Module):
         """Random edge subsample of the target snapshots with recomputed norms
         (get_batch_graph_embeds(full=False), models/DynamicRGCN.py:76-90).  `edge_ids`
         injects the kept edge ids (tests replay the reference's recorded draws)."""
+        dev = self._device()
+        if edge_ids is None and dev.type == "cuda" and self.device_subsample and S.DEVICE_STORE == "kernel" and graphs:
+            # on the device: the subgraphs' sorted views are derived from the snapshots' resident views (temp_subsample_views) --
+            # no host rebuild, no edge upload (SURVEY 8f rank 4); the draw depends only on the per-graph seed
+            seeds = self.sample_rng.integers(0, 1 << 62, size=len(graphs))
+            return S.device_subsample(graphs, [int(rate * g.number_of_edges()) for g in graphs], seeds, dev, 2 * self.num_rels, want_mask=True)
         out = []
         for i, g in enumerate(graphs):
             E = g.number_of_edges()

@@ -142,6 +142,96 @@ class Snapshot:
             self._dev[key] = dg
         return dg
 
+    def device_edge_ids(self, device):
+        """[3, E] int32 on `device`: original edge id of every position of the by-dst / by-src / by-rel view (the views are
+        STABLE sorts of the edge list by dst / src / rel), uploaded once per snapshot."""
+        key = ("eid", str(device))
+        t = self._dev.get(key)
+        if t is None:
+            eid = np.stack([np.argsort(k, kind="stable") for k in (self.dst, self.src, self.rel)]).astype(np.int32) \
+                if self.number_of_edges() else np.zeros((3, 0), np.int32)
+            t = self._dev[key] = _lib.to_device(eid, device)
+        return t
+
+
+def device_subsample(graphs, keeps, seeds, device, n_rel_rows, want_mask=False):
+    """Random edge subsets of resident snapshots, ON the device (temp_subsample_views): graph i keeps `keeps[i]` edges drawn
+    by `seeds[i]`.  -> list of SubsampledSnapshot whose resident views are derived from their parents' (one clone of the
+    parent's packed buffer + three launches for the whole list): no host sort, no edge upload."""
+    from .backend import get_backend
+    jobs, out = [], []
+    scratch = torch.zeros(max(len(graphs), 1), dtype=torch.int64, device=device)
+    for i, (g, k, seed) in enumerate(zip(graphs, keeps, seeds)):
+        dv = g.device_views(device, n_rel_rows)
+        meta = dv["_meta"]
+        child = dv["_buf"].clone()
+        off = {name: int(o) for name, o in zip(_PACK_NAMES, meta["off"])}
+        E = g.number_of_edges()
+        mask = torch.empty(E, dtype=torch.uint8, device=device) if want_mask else None
+        views = ("by_dst", "by_src", "by_rel")
+        jobs.append(dict(n_nodes=g.n, n_edges=E, keep=int(k), seed=int(seed), parent=dv["_buf"], child=child, eid=g.device_edge_ids(device),
+                         off_a=[off[(v, "a")] for v in views], off_b=[off[(v, "b")] for v in views],
+                         off_chunk_beg=[off[(v, "chunk_beg")] for v in views], off_chunk_end=[off[(v, "chunk_end")] for v in views],
+                         off_chunk_seg=[off[(v, "chunk_seg")] for v in views], n_chunks=[int(dv[v]["chunk_seg"].shape[0]) for v in views],
+                         off_in_deg=off["in_deg"], off_out_deg=off["out_deg"], off_nnorm=off["nnorm"], keep_mask=mask, scratch=scratch[i:i + 1]))
+        out.append(SubsampledSnapshot(g, int(k), child, mask, device, n_rel_rows))
+    if jobs:
+        get_backend().subsample_views(jobs)
+    return out
+
+
+class SubsampledSnapshot(Snapshot):
+    """A snapshot restricted to a random edge subset that exists on the DEVICE only: same nodes, same view layout as its
+    parent (chunk tables shared), `number_of_edges()` = size of the subset.  Host edge arrays / norms are materialised from
+    the keep mask only if something asks for them (a device -> host copy)."""
+
+    def __init__(self, parent, keep, child_buf, mask, device, n_rel_rows):
+        self.n = parent.n
+        self.gids = parent.gids
+        self.parent, self.keep, self._mask = parent, int(keep), mask
+        self.ndata = {}
+        self._dev = {}
+        self._ids_dict = None
+        self._views = {}
+        self._host = None
+        pdv = parent.device_views(device, n_rel_rows)
+        dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": child_buf}
+        pm = pdv["_meta"]
+        for name, o, n_ in zip(_PACK_NAMES, pm["off"], pm["size"]):
+            t = child_buf[int(o):int(o) + int(n_)]
+            if isinstance(name, tuple):
+                dv[name[0]][name[1]] = t
+            else:
+                dv[name] = t
+        dv["nnorm"] = dv["nnorm"].view(torch.float32)
+        m = dict(ptr=int(child_buf.data_ptr()), off=pm["off"], size=pm["size"], n_partial=pm["n_partial"], rel_chunks=pm["rel_chunks"])
+        row = pm["row"].copy()
+        row[62] = m["ptr"]
+        m["row"] = row
+        dv["_meta"] = m
+        self._dev[("views", str(device), int(n_rel_rows))] = dv
+
+    def number_of_edges(self):
+        return self.keep
+
+    def _materialise(self):
+        if self._host is None:
+            if self._mask is None:
+                raise RuntimeError("this device-side subsample was created without a keep mask (want_mask=False)")
+            idx = np.nonzero(self._mask.cpu().numpy())[0]
+            p = self.parent
+            self._host = (p.src[idx], p.dst[idx], p.rel[idx], comp_deg_norm(self.n, p.dst[idx]), idx)
+        return self._host
+
+    src = property(lambda self: self._materialise()[0])
+    dst = property(lambda self: self._materialise()[1])
+    rel = property(lambda self: self._materialise()[2])
+    nnorm = property(lambda self: self._materialise()[3])
+    edge_ids = property(lambda self: self._materialise()[4])
+
+    def local_views(self, n_rel_rows):
+        raise RuntimeError("a device-side subsample has no host views; use device_views()")
+
 
 class BatchedSnapshot(Snapshot):
     """Disjoint union of snapshots (dgl.batch, models/DynamicRGCN.py:92).  The member snapshots are kept (`parts`):
@@ -157,12 +247,18 @@ class BatchedSnapshot(Snapshot):
         self.n = int(self.node_off[-1])
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
         self.gids = cat([g.gids for g in self.parts], np.int64)
-        self.nnorm = cat([g.nnorm for g in self.parts], np.float32)
+        self._nnorm = None                       # host norms only on demand (a device-subsampled member has them on the GPU)
         self.ndata = {}
         self._dev = {}
         self._ids_dict = None
         self._views = {}
         self._edges = None
+
+    @property
+    def nnorm(self):
+        if self._nnorm is None:
+            self._nnorm = np.concatenate([g.nnorm for g in self.parts]).astype(np.float32) if self.parts else np.zeros(0, np.float32)
+        return self._nnorm
 
     def _materialise(self):
         if self._edges is None:
@@ -452,6 +548,8 @@ def union_graph_packed(snap, n_rel_rows, device):
 
 
 _VIEW_ARRAYS = ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")
+# the arrays of a snapshot's packed device buffer, in order (Snapshot.device_views)
+_PACK_NAMES = [(vn, an) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS] + ["rel_rank", "in_deg", "out_deg", "nnorm"]
 
 
 def _pack_small_union(snap, n_rel_rows, device):
@@ -493,6 +591,18 @@ class _DeviceGraph:
                 # own edge list -- the by-relation view is then the global sort this shape wants
                 self._init_from_packed(_pack_small_union(snap, n_rel_rows, device), n, E, n_rel_rows, device)
                 return
+        one = snap.parts[0] if isinstance(snap, BatchedSnapshot) and len(snap.parts) == 1 else snap
+        if isinstance(one, SubsampledSnapshot):                 # its views exist on the device only: wrap its packed buffer
+            dv = one.device_views(device, n_rel_rows)
+            m = dv["_meta"]
+            offs = {k: int(o) for k, o in zip(_PACK_NAMES, m["off"])}
+            sizes = {k: int(z) for k, z in zip(_PACK_NAMES, m["size"])}
+            counts = {}
+            for i, (vn, n_seg) in enumerate((("by_dst", n), ("by_src", n), ("by_rel", n_rel_rows))):
+                counts[vn] = dict(n_seg=int(n_seg), n_edges=int(one.parent.number_of_edges()), n_chunks=sizes[(vn, "chunk_seg")],
+                                  n_partial=int(m["n_partial"][i]), n_fix=sizes[(vn, "fix_seg")])
+            self._init_from_packed((dv["_buf"], offs, sizes, counts, None), n, E, n_rel_rows, device)
+            return
         if isinstance(snap, BatchedSnapshot) and len(snap.parts) > 1:
             views, in_deg, out_deg = union_views(snap, n_rel_rows)
         else:

@@ -245,6 +245,55 @@ class CpuTestBackend:
             self.gru_cell_bwd(saved_all, c["row0"], c["n"], c["dh_up"], c["d_prev_next"], c["next_idx"], c["dt"], lam, c["w_hh"], variant,
                               c["dgi"], c["dgh"], c["decv"], c["d_prev"])
 
+    @staticmethod
+    def subsample_keys(seed, E):
+        """numpy twin of sub_key (temp_amd/csrc/store_kernels.hip): (hash(seed, e) << 32) | e for e in [0, E)."""
+        M = np.uint64(0xFFFFFFFFFFFFFFFF)
+        with np.errstate(over="ignore"):
+            e = np.arange(E, dtype=np.uint64)
+            x = np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF) ^ (np.uint64(0x9e3779b97f4a7c15) * (e + np.uint64(1)))
+            x ^= x >> np.uint64(33)
+            x *= np.uint64(0xff51afd7ed558ccd)
+            x ^= x >> np.uint64(33)
+            x *= np.uint64(0xc4ceb9fe1a85ec53)
+            x ^= x >> np.uint64(33)
+        return ((x & np.uint64(0xffffffff00000000)) | e) & M
+
+    def subsample_views(self, jobs):
+        """Reference of temp_subsample_views on host tensors: keep the `keep` smallest keys; per chunk of every view move the
+        kept edges to the front (order preserved), shrink chunk_end, count degrees, nnorm = 1 / in_deg."""
+        for j in jobs:
+            E, k, n = j["n_edges"], j["keep"], j["n_nodes"]
+            parent, child = j["parent"].numpy(), j["child"].numpy()
+            keys = self.subsample_keys(j["seed"], E)
+            keep = np.zeros(E, dtype=bool)
+            if k > 0:
+                keep[np.argsort(keys, kind="stable")[:k]] = True
+            if j.get("keep_mask") is not None:
+                j["keep_mask"].copy_(torch.from_numpy(keep.astype(np.uint8)))
+            eid = j["eid"].numpy().reshape(3, -1) if E else np.zeros((3, 0), np.int64)
+            child[j["off_in_deg"]:j["off_in_deg"] + n] = 0
+            child[j["off_out_deg"]:j["off_out_deg"] + n] = 0
+            for v in range(3):
+                nch = j["n_chunks"][v]
+                beg = parent[j["off_chunk_beg"][v]:j["off_chunk_beg"][v] + nch]
+                end = parent[j["off_chunk_end"][v]:j["off_chunk_end"][v] + nch]
+                seg = parent[j["off_chunk_seg"][v]:j["off_chunk_seg"][v] + nch]
+                for c in range(nch):
+                    pos = np.arange(beg[c], end[c])
+                    kp = pos[keep[eid[v][pos]]]
+                    m = kp.shape[0]
+                    child[j["off_a"][v] + beg[c]:j["off_a"][v] + beg[c] + m] = parent[j["off_a"][v] + kp]
+                    child[j["off_b"][v] + beg[c]:j["off_b"][v] + beg[c] + m] = parent[j["off_b"][v] + kp]
+                    child[j["off_chunk_end"][v] + c] = beg[c] + m
+                    if v == 0:
+                        child[j["off_in_deg"] + seg[c]] += m
+                    elif v == 1:
+                        child[j["off_out_deg"] + seg[c]] += m
+            deg = child[j["off_in_deg"]:j["off_in_deg"] + n]
+            nn = np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(np.float32)
+            child[j["off_nnorm"]:j["off_nnorm"] + n] = nn.view(np.int32)
+
     def decay_rows(self, x, dt, lam):
         return x.detach() * torch.exp(-dt.detach().view(-1, 1) * lam)
 

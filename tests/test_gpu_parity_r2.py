@@ -317,3 +317,92 @@ def test_config3_icews0515_post_ensemble_step_vs_oracle_gpu():
                            ("forward_rnn.w_hh", enc.layer_2.forward_rnn.weight_hh_l0.grad, eo["layer_2"]["forward_rnn"][0]["w_hh"].grad),
                            ("backward_rnn.w_ih", enc.layer_2.backward_rnn.weight_ih_l0.grad, eo["layer_2"]["backward_rnn"][0]["w_ih"].grad)]:
         _assert_grad_close(got, ref, "config 3 d " + name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# snapshot store: device-side edge subsample + renorm (temp_subsample_views)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,E,R,rate", [(500, 7475, 20, 0.5), (60, 900, 8, 0.8), (2000, 200000, 20, 0.5), (10, 37, 4, 0.5), (5, 0, 4, 0.5),
+                                        (300, 5000, 6, 0.0), (300, 5000, 6, 1.0)])
+def test_device_subsample_kernels_bit_exact_and_layer_parity(n, E, R, rate, hip_backend):
+    """temp_subsample_views against the test backend's reference (same 64-bit counter hash): keep mask, rewritten view
+    arrays, degrees and norms bit-exact; then an RGCN layer on the device-built subgraph equals the layer on the HOST-built
+    subgraph of the same kept edges (edge_subgraph + sort + upload: the path it replaces) within fp32 round-off."""
+    from temp_amd import functional as TF
+    from temp_amd.snapshot import Snapshot, device_subsample
+    from tests.cpu_backend import CpuTestBackend
+    rng = np.random.default_rng(n + E)
+    src, dst, rel = rng.integers(0, n, E), rng.integers(0, n, E), rng.integers(0, R, E)
+    if E > 400:
+        dst[:E // 4] = rng.integers(0, 3, E // 4)
+    g = Snapshot(n, src, dst, rel, np.arange(n))
+    keep = int(rate * E)
+    sub = device_subsample([g], [keep], [99], DEV, R, want_mask=True)[0]
+    torch.cuda.synchronize()
+    TB.set_backend(CpuTestBackend())
+    try:
+        g2 = Snapshot(n, src, dst, rel, np.arange(n))
+        ref = device_subsample([g2], [keep], [99], torch.device("cpu"), R, want_mask=True)[0]
+    finally:
+        TB.set_backend(None)
+    assert torch.equal(sub._mask.cpu(), ref._mask) and int(sub._mask.sum()) == keep
+    got, want = sub.device_views(DEV, R), ref.device_views(torch.device("cpu"), R)
+    for name in ("by_dst", "by_src", "by_rel"):
+        beg, end = want[name]["chunk_beg"].numpy(), want[name]["chunk_end"].numpy()
+        assert torch.equal(got[name]["chunk_end"].cpu(), want[name]["chunk_end"])
+        live = np.zeros(E, dtype=bool)
+        for b, e in zip(beg, end):
+            live[b:e] = True
+        for arr in ("a", "b"):
+            assert np.array_equal(got[name][arr].cpu().numpy()[live], want[name][arr].numpy()[live]), (name, arr)
+    for arr in ("in_deg", "out_deg", "nnorm"):
+        assert torch.equal(got[arr].cpu(), want[arr]), arr
+    if E == 0:
+        return
+    # layer parity: device-derived views vs host-built subgraph of the same edges
+    D, B = 32, 16
+    idx = np.nonzero(sub._mask.cpu().numpy())[0]
+    host_sub = g.edge_subgraph(idx)
+    gen = torch.Generator().manual_seed(1)
+    h = torch.randn(n, D, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(R, B * (D // B) ** 2, generator=gen) * 0.3).to(DEV).requires_grad_(True)
+    lw = (torch.randn(D, D, generator=gen) * 0.1).to(DEV).requires_grad_(True)
+    outs = []
+    for graph in (sub, host_sub):
+        for t in (h, w, lw):
+            t.grad = None
+        y = TF.rgcn_layer(h, graph.device_graph(DEV, R), w, lw, None, B, None)
+        (y * y).sum().backward()
+        outs.append((y.detach().clone(), h.grad.clone(), w.grad.clone(), lw.grad.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("y", "d_h", "d_weight", "d_loop")):
+        assert_close(a, b, 2e-5, 2e-5 * max(1.0, float(b.abs().max())), "subsampled layer " + what)
+
+
+def test_training_step_with_device_subsample_gpu():
+    """A full training step of the headline model draws its 50 % target subsets on the device; the same seeds give the same
+    step, and the result equals the step on HOST-built subgraphs of the same kept edges."""
+    import bench
+    from temp_amd import synthetic
+    w = synthetic.workload("S-gdelt", seed=0)
+    model = bench.build_model(w, DEV)
+    targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:3]
+
+    def run(edge_ids=None):
+        model.sample_rng = np.random.default_rng(5)
+        for p in model.parameters():
+            p.grad = None
+        wb = model.prepare(targets, w["L"], train=True, target_edge_ids=edge_ids)
+        out = model.run(wb)[0]
+        (out * out).sum().backward()
+        return wb, out.detach().clone(), model.ent_embeds.grad.clone()
+
+    wb, out1, g1 = run()
+    from temp_amd.snapshot import SubsampledSnapshot
+    assert all(isinstance(g, SubsampledSnapshot) for g in wb.target.graphs)
+    assert all(g.number_of_edges() == int(0.5 * full.number_of_edges()) for g, full in zip(wb.target.graphs, wb.graphs))
+    _, out2, g2 = run()
+    assert torch.equal(out1, out2) and torch.equal(g1, g2)
+    ids = [g.edge_ids for g in wb.target.graphs]
+    _, out3, g3 = run(edge_ids=ids)
+    assert_close(out3, out1, 2e-5, 2e-6, "device vs host subsample: target embeddings")
+    assert_close(g3, g1, 1e-4, 1e-4 * float(g1.abs().max()), "device vs host subsample: d ent_embeds")

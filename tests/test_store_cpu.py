@@ -1,0 +1,74 @@
+"""Snapshot store, host side: device-side edge subsample semantics through the test backend's reference of
+temp_subsample_views, and the flat on-disk store."""
+import numpy as np
+import pytest
+import torch
+
+from temp_amd import backend as TB
+from temp_amd import snapshot as S
+from temp_amd.snapshot import Snapshot, comp_deg_norm, device_subsample
+from tests.cpu_backend import CpuTestBackend
+
+
+@pytest.fixture(autouse=True)
+def cpu_backend():
+    TB.set_backend(CpuTestBackend())
+    yield
+    TB.set_backend(None)
+
+
+def random_snapshot(seed, n=60, E=900, R=8, hub=True):
+    rng = np.random.default_rng(seed)
+    src, dst, rel = rng.integers(0, n, E), rng.integers(0, n, E), rng.integers(0, R, E)
+    if hub:
+        dst[:300] = rng.integers(0, 3, 300)              # segments that span several chunks
+    return Snapshot(n, src, dst, rel, np.sort(rng.choice(500, n, replace=False)))
+
+
+def check_child_against_mask(g, sub, n_rel_rows, device):
+    """The child's views hold exactly the kept edges, per chunk in the parent's order; degrees / norms are the subgraph's."""
+    keep = sub._mask.cpu().numpy().astype(bool)
+    assert keep.sum() == sub.keep == sub.number_of_edges()
+    dvp, dvc = g.device_views(device, n_rel_rows), sub.device_views(device, n_rel_rows)
+    eid = g.device_edge_ids(device).cpu().numpy()
+    for v, name in enumerate(("by_dst", "by_src", "by_rel")):
+        P = {k: t.cpu().numpy() for k, t in dvp[name].items()}
+        C = {k: t.cpu().numpy() for k, t in dvc[name].items()}
+        for k in ("chunk_seg", "chunk_beg", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt"):
+            assert np.array_equal(P[k], C[k]), (name, k)
+        for c in range(P["chunk_seg"].shape[0]):
+            pos = np.arange(P["chunk_beg"][c], P["chunk_end"][c])
+            kp = pos[keep[eid[v][pos]]]
+            assert C["chunk_end"][c] == P["chunk_beg"][c] + kp.shape[0]
+            assert np.array_equal(C["a"][P["chunk_beg"][c]:C["chunk_end"][c]], P["a"][kp])
+            assert np.array_equal(C["b"][P["chunk_beg"][c]:C["chunk_end"][c]], P["b"][kp])
+    idx = np.nonzero(keep)[0]
+    assert np.array_equal(dvc["in_deg"].cpu().numpy(), np.bincount(g.dst[idx], minlength=g.n))
+    assert np.array_equal(dvc["out_deg"].cpu().numpy(), np.bincount(g.src[idx], minlength=g.n))
+    assert np.array_equal(dvc["nnorm"].cpu().numpy(), comp_deg_norm(g.n, g.dst[idx]))
+    assert np.array_equal(sub.src, g.src[idx]) and np.array_equal(sub.nnorm, comp_deg_norm(g.n, g.dst[idx]))
+
+
+@pytest.mark.parametrize("rate", [0.5, 0.8, 0.0, 1.0])
+def test_device_subsample_reference_semantics(rate):
+    dev = torch.device("cpu")
+    graphs = [random_snapshot(1), random_snapshot(2, n=10, E=37, hub=False), random_snapshot(3, n=5, E=0, hub=False)]
+    keeps = [int(rate * g.number_of_edges()) for g in graphs]
+    subs = device_subsample(graphs, keeps, [11, 12, 13], dev, 8, want_mask=True)
+    for g, sub in zip(graphs, subs):
+        check_child_against_mask(g, sub, 8, dev)
+
+
+def test_device_subsample_is_a_uniform_k_subset():
+    """Every edge is kept with probability k / E over the seeds; two seeds give different subsets; one seed gives the same one."""
+    g = random_snapshot(4, E=400)
+    dev = torch.device("cpu")
+    hits = np.zeros(400)
+    for seed in range(200):
+        sub = device_subsample([g], [100], [seed], dev, 8, want_mask=True)[0]
+        hits += sub._mask.numpy()
+    assert abs(hits.mean() / 200 - 0.25) < 1e-9 and hits.min() > 20 and hits.max() < 85        # Binomial(200, 1/4): mean 50, sd 6
+    a = device_subsample([g], [100], [7], dev, 8, want_mask=True)[0]._mask
+    b = device_subsample([g], [100], [7], dev, 8, want_mask=True)[0]._mask
+    c = device_subsample([g], [100], [8], dev, 8, want_mask=True)[0]._mask
+    assert torch.equal(a, b) and not torch.equal(a, c)
