@@ -167,7 +167,10 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
     cores: one window (bsz=1) at a time, fwd+bwd, repeated over the rank-0 targets until at least
     `min_seconds` of CPU work has been timed."""
     from oracle import temp_oracle as O
-    nthreads = os.cpu_count() or 1                 # all host cores of the box (SURVEY 8d)
+    # Threads: measured on the MI355X box (256 hardware threads, EPYC 9575F): with all of them torch's intra-op pool turns the
+    # oracle's many small ops into 598 s per window (363 edges/s); 16 threads give 0.3 s per window (~0.67 M edges/s), the best of
+    # {1, 8, 16, 32, 64}.  `cores` reports what was used, `host_threads` what the box has.
+    nthreads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(nthreads)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     bi = w["module"].startswith("Bi")
@@ -206,7 +209,7 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
         dt = time.perf_counter() - t0
         if dt >= min_seconds or nwin >= max_windows:
             break
-    return dict(value=edges / dt, unit="edges/s", cores=nthreads, cpu_model=_cpu_model(), kind="port",
+    return dict(value=edges / dt, unit="edges/s", cores=nthreads, host_threads=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
                 sample="%d windows (bsz=1 each) of %s: %d snapshot visits, %d edge visits, full target graphs, fwd+bwd, %.1f s"
                        % (nwin, w["name"], visits, edges, dt))
 

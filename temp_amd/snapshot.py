@@ -61,6 +61,10 @@ class Snapshot:
     def number_of_edges(self):
         return int(self.src.shape[0])
 
+    def edge_extent(self):
+        """Length of this snapshot's edge arrays inside a view buffer (= number_of_edges() unless edges were dropped in place)."""
+        return self.number_of_edges()
+
     def local_var(self):
         """Shallow copy sharing topology and device views (DGL's local_var)."""
         g = self.__class__.__new__(self.__class__)
@@ -214,6 +218,9 @@ class SubsampledSnapshot(Snapshot):
     def number_of_edges(self):
         return self.keep
 
+    def edge_extent(self):
+        return self.parent.number_of_edges()     # the views keep the parent's array length; dropped positions are simply unused
+
     def _materialise(self):
         if self._host is None:
             if self._mask is None:
@@ -243,7 +250,9 @@ class BatchedSnapshot(Snapshot):
         self.parts = list(parts)
         self.node_sizes = [g.n for g in self.parts]
         self.node_off = np.concatenate([[0], np.cumsum(self.node_sizes)]).astype(np.int64)
-        self.edge_off = np.concatenate([[0], np.cumsum([g.number_of_edges() for g in self.parts])]).astype(np.int64)
+        # offsets of the members' edge ARRAYS inside the union's views (a device-subsampled member keeps its parent's length)
+        self.edge_off = np.concatenate([[0], np.cumsum([g.edge_extent() for g in self.parts])]).astype(np.int64)
+        self._n_edges = int(sum(g.number_of_edges() for g in self.parts))
         self.n = int(self.node_off[-1])
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
         self.gids = cat([g.gids for g in self.parts], np.int64)
@@ -272,6 +281,9 @@ class BatchedSnapshot(Snapshot):
     rel = property(lambda self: self._materialise()[2])
 
     def number_of_edges(self):
+        return self._n_edges
+
+    def edge_extent(self):
         return int(self.edge_off[-1])
 
 

@@ -528,6 +528,7 @@ def test_reference_default_sizes_paths_agree_gpu(module, rec_only):
     cls = BiDynamicRGCN if module.startswith("Bi") else DynamicRGCN
     torch.manual_seed(3)
     m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(DEV)
+    m.device_subsample = False          # host sampler: the CPU test backend below must draw the SAME target subsets from the same rng
     t_list = torch.tensor([s["times"][i] for i in (20, 16, 11, 2)])
     res = []
     for batched in (True, False):

@@ -224,9 +224,9 @@ def test_chain_kernels_vs_reference_and_per_position_path(d, type1, kw, want):
     finally:
         TB.set_backend(None)
     for other, name in ((cpu, "CPU reference"), (hip_steps, "per-position launches")):
-        for a, b in zip(hip_chain[0], other[0]):        # (the type-1 cell draws its weights from N(0, 1): states near +-1, products of ~14 terms)
-            assert_close(a, b, 3e-5 if type1 else 1e-5, 5e-6 if type1 else 2e-6, "states vs " + name)
-        assert_close(hip_chain[1], other[1], 1e-4, 1e-5, "d_x vs " + name)
+        for a, b in zip(hip_chain[0], other[0]):        # (the type-1 cell draws its weights from N(0, 1) like the reference's: pre-activations of +-14, saturated gates)
+            assert_close(a, b, 1e-4 if type1 else 1e-5, 2e-5 if type1 else 2e-6, "states vs " + name)
+        assert_close(hip_chain[1], other[1], 1e-4, 2e-5 * max(1.0, float(other[1].abs().max())), "d_x vs " + name)
         for a, b in zip(hip_chain[2], other[2]):
             assert_close(a, b, 1e-4, 2e-5 * max(1.0, float(b.abs().max())), "GRU parameter gradient vs " + name)
 
