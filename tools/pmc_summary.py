@@ -47,9 +47,15 @@ def main():
         base = re.sub(r"<.*$", "", k)
         fam[base][0] += v["launches"]
         fam[base][1] += v["traffic_bytes_per_launch"] * v["launches"]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else None        # encoder steps the profiled process executed
     doc = dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1 --no-graph",
                corrections="FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE raw; KiB -> bytes",
                kernels=out, families={k: dict(launches=v[0], traffic_bytes_per_launch=v[1] / v[0]) for k, v in fam.items()})
+    if steps:
+        doc["steps_in_run"] = steps
+        doc["step_traffic_bytes"] = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in out.values()) / steps
+        doc["step_fetch_bytes"] = sum(v["fetch_bytes_per_launch"] * v["launches"] for v in out.values()) / steps
+        doc["step_write_bytes_raw"] = sum(v["write_bytes_per_launch_raw"] * v["launches"] for v in out.values()) / steps
     json.dump(doc, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"]):
         print("%-44s launches %4d  fetch %9.1f MB  write(raw) %9.1f MB per launch" % (k[:44], v["launches"], v["fetch_bytes_per_launch"] / 1e6,
