@@ -100,7 +100,11 @@ class Snapshot:
         dv = self._dev.get(key)
         if dv is None:
             names = [(vn, an) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS] + ["rel_rank", "in_deg", "out_deg", "nnorm"]
-            if self._views.get(n_rel_rows) is None:
+            stored = self.stored_pack(n_rel_rows)
+            if stored is not None:                                 # precomputed in the on-disk store (temp_amd/store.py)
+                packed, sizes_np, n_partial, rel_chunks = stored
+                sizes = [int(x) for x in sizes_np]
+            elif self._views.get(n_rel_rows) is None:
                 # no host-side views cached (a freshly subsampled target graph): all three views + the pack in ONE pass of
                 # the host planner library
                 from . import _hostlib
@@ -118,7 +122,9 @@ class Snapshot:
                 packed = np.concatenate([np.ascontiguousarray(a, dtype=np.int32) for a in arrays]) if sum(sizes) else np.zeros(1, np.int32)
                 n_partial = np.array([lv[vn]["n_partial"] for vn in ("by_dst", "by_src", "by_rel")], dtype=np.int64)
                 rel_chunks = lv["rel_chunks"]
-            buf = _lib.to_device(packed, device)                  # ONE upload per snapshot
+            buf = self._dev.pop(("adopted", str(device), int(n_rel_rows)), None)      # already resident (SnapshotStore.to_device)
+            if buf is None:
+                buf = _lib.to_device(np.require(packed, requirements=['C', 'W']), device)   # ONE upload per snapshot
             dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": buf}
             off = 0
             for key_, n_ in zip(names, sizes):
@@ -145,6 +151,14 @@ class Snapshot:
             dg = _DeviceGraph(self, device, n_rel_rows)
             self._dev[key] = dg
         return dg
+
+    def stored_pack(self, n_rel_rows):
+        """(packed, sizes, n_partial, rel_chunks) when the packed views were precomputed (StoredSnapshot), else None."""
+        return None
+
+    def adopt_device_pack(self, buf, device, n_rel_rows):
+        """Hand this snapshot a device-resident copy of its packed views (a slice of a whole-store upload)."""
+        self._dev[("adopted", str(torch.device(device)), int(n_rel_rows))] = buf
 
     def device_edge_ids(self, device):
         """[3, E] int32 on `device`: original edge id of every position of the by-dst / by-src / by-rel view (the views are

@@ -72,3 +72,41 @@ def test_device_subsample_is_a_uniform_k_subset():
     b = device_subsample([g], [100], [7], dev, 8, want_mask=True)[0]._mask
     c = device_subsample([g], [100], [8], dev, 8, want_mask=True)[0]._mask
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+# ---- flat on-disk store ---------------------------------------------------------------------------------------------------
+def test_store_round_trip_and_window_golden(tmp_path):
+    """write_store -> SnapshotStore: every array identical to the text-built snapshots, the precomputed packed views identical
+    to what the planner builds at run time, and a window model constructed FROM THE STORE reproduces the reference's golden
+    loss and gradients (G10)."""
+    from temp_amd import _lib
+    from temp_amd.store import SnapshotStore, write_store
+    from tests.window_cases import check_window, slice_snapshots
+    import tests.window_cases as WC
+    s = slice_snapshots()
+    path = str(tmp_path / "icews14_slice.tsnap")
+    write_store(path, s["tr"], s["va"], s["te"], s["num_e"], s["num_r"])
+    st = SnapshotStore(path)
+    assert st.num_ents == s["num_e"] and st.num_rels == s["num_r"] and st.times == list(s["tr"].keys())
+    tr, va, te = st.graph_dicts()
+    dev = torch.device("cpu")
+    for want_d, got_d in ((s["tr"], tr), (s["va"], va), (s["te"], te)):
+        for t in st.times[::5]:
+            a, b = want_d[t], got_d[t]
+            assert a.n == b.n and np.array_equal(a.gids, b.gids) and np.array_equal(a.nnorm, b.nnorm)
+            assert np.array_equal(a.src, b.src) and np.array_equal(a.dst, b.dst) and np.array_equal(a.rel, b.rel)
+            da, db = a.device_views(dev, 2 * s["num_r"]), b.device_views(dev, 2 * s["num_r"])
+            assert torch.equal(da["_buf"], db["_buf"]) and np.array_equal(da["_meta"]["size"], db["_meta"]["size"])
+            assert np.array_equal(da["_meta"]["rel_chunks"], db["_meta"]["rel_chunks"]) and np.array_equal(da["_meta"]["n_partial"], db["_meta"]["n_partial"])
+    # whole-split residency: one upload, per-snapshot views are slices of it
+    big = st.to_device(dev)
+    dv = tr[st.times[3]].device_views(dev, 2 * s["num_r"])
+    assert dv["_buf"].data_ptr() >= big.data_ptr() and dv["_buf"].data_ptr() < big.data_ptr() + 4 * big.numel()
+    # the golden window check with the model's graph dictionaries coming from the store
+    saved = dict(WC._SLICE)
+    try:
+        WC._SLICE.update(tr=tr, va=va, te=te)
+        check_window("G10_bi_grrgcn_rol", dev)
+    finally:
+        WC._SLICE.clear()
+        WC._SLICE.update(saved)
