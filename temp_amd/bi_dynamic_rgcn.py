@@ -96,7 +96,7 @@ class BiDynamicRGCN(DynamicRGCN):
         lam, dec = l2.inv_temperature, l2.decay_spec()
         if wb.program is not None:
             prog = wb.program
-            want = [i for i in (wb.out_inst[0], wb.out_inst[1], wb.hist_inst[0], wb.hist_inst[1]) if i >= 0]
+            want = self._chain_want(wb)
             wb.last_x = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv)          # GRU input rows in chain order
             got = dict(zip(want, gru_chain(wb.last_x, prog, [l2.forward_rnn, l2.backward_rnn], lam,
                                            isinstance(l2.forward_rnn, GRUCell), want=want)))
@@ -129,6 +129,9 @@ class BiDynamicRGCN(DynamicRGCN):
         if enc.use_time_embedding:
             out = out + l2.get_time_embedding(tf.times, tf.sizes)
         return out, ((Hf, Hf), (Hb, Hb))
+
+    def _chain_want(self, wb):
+        return [i for i in (wb.out_inst[0], wb.out_inst[1], wb.hist_inst[0], wb.hist_inst[1]) if i >= 0]
 
     def _build_program(self, wb):
         """Chain program with ONE contiguous row range per direction: x rows are laid out

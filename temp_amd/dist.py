@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 from . import functional as TF
 from .gru_cell import GRUCell
-from .gru_chain import GruInstance, GruProgram, gru_chain
+from .gru_chain import GruInstance, GruProgram, gru_chain, prepare_program
 from .window import ChainPlan, Step, window_times
 
 
@@ -277,7 +277,7 @@ class SnapshotShardedEncoder:
             out_inst.append(len(inst) - 1)
         x_rows.append(t_rows)
         sb.program = GruProgram(inst)
-        sb.program.upload(dev)
+        prepare_program(sb.program, dev, m.embed_size, len(plans), out_inst)
         x_index = np.concatenate(x_rows) if x_rows else np.zeros(0, np.int64)
         sb.x_index = torch.from_numpy(x_index).to(dev)
         sb.x_index32 = sb.x_index.to(torch.int32)

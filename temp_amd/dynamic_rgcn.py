@@ -21,7 +21,7 @@ from . import _hostlib
 from . import snapshot as S
 from .rrgcn import RRGCN, GRRGCNLayer, run_rnn
 from .tkg_module import TKG_Module
-from .gru_chain import GruInstance, GruProgram, gru_chain, zero_state_program
+from .gru_chain import GruInstance, GruProgram, gru_chain, prepare_program, zero_state_program
 from .gru_cell import GRUCell
 from .window import ChainPlan, Step, concat_steps, concat_steps_dedup, window_times
 
@@ -156,6 +156,10 @@ class DynamicRGCN(TKG_Module):
         wb.out_inst = [len(inst) - 1]
         wb.hist_inst = len(inst) - 2 if len(inst) > 1 else -1
 
+    def _chain_want(self, wb):
+        """Instances whose states leave the chain: the target position and the last history position."""
+        return [wb.out_inst[0]] + ([wb.hist_inst] if wb.hist_inst >= 0 else [])
+
     def _run_batched(self, wb):
         enc, dev = self.ent_encoder, self._device()
         y1 = enc.layer_1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
@@ -165,7 +169,7 @@ class DynamicRGCN(TKG_Module):
         l2 = enc.layer_2
         wb.last_x = y2                                # GRU input rows of the step (= the "local" states of the post models)
         if wb.program is not None:
-            want = [wb.out_inst[0]] + ([wb.hist_inst] if wb.hist_inst >= 0 else [])
+            want = self._chain_want(wb)
             got = gru_chain(y2, wb.program, [l2.rnn], l2.inv_temperature, isinstance(l2.rnn, GRUCell), want=want)
             hist = got[1] if wb.hist_inst >= 0 else None
             return got[0], (hist, hist)
@@ -217,7 +221,7 @@ class DynamicRGCN(TKG_Module):
             wb.g_all.device_graph(dev, 2 * self.num_rels)
             if self._can_chain():
                 self._build_program(wb)
-                wb.program.upload(dev)
+                prepare_program(wb.program, dev, self.embed_size, len(wb.out_inst), self._chain_want(wb))
         else:
             for st in wb.steps:
                 st.batched().device_graph(dev, 2 * self.num_rels)

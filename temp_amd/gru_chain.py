@@ -329,6 +329,21 @@ class _GruChainFn(torch.autograd.Function):
         return (d_x_all, None, None, None, None, None) + tuple(grads)
 
 
+def chain_kernels_usable(d, n_rnn=1):
+    """True when gru_chain() will run a program of this width through the persistent chain kernels."""
+    be = get_backend()
+    return bool(CHAIN_KERNELS and hasattr(be, "gru_chain_fwd") and n_rnn <= _lib.CHAIN_MAX_RNN and be.gru_chain_supported(d))
+
+
+def prepare_program(prog, device, d, n_rnn, want):
+    """Host + upload half of a program, done once per prepared batch (by the prefetch thread when there is one): the chain
+    kernels' panel tables for the `want` set the run will ask for, or -- when the program goes through the per-position
+    launches -- the row maps of every instance."""
+    if chain_kernels_usable(d, n_rnn) and prog.chain_tables(device, tuple(want) if want is not None else None) is not None:
+        return
+    prog.upload(device)
+
+
 def zero_state_program(n):
     """Program of ONE cell over n rows that starts from the zero state (GRU(x, 0): the once-per-entity rows of the all-entity
     pass): hoisted input-gate GEMM + pointwise cell forward; gate gradients, d_x and d_W_ih backward -- no recurrent GEMM."""

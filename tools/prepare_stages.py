@@ -13,7 +13,7 @@ def wrap(mod, name, label=None):
     setattr(mod, name, g)
 wrap(window, "ChainPlan"); wrap(bi_dynamic_rgcn, "ChainPlan", "ChainPlan"); wrap(dynamic_rgcn, "ChainPlan", "ChainPlan")
 wrap(dynamic_rgcn, "concat_steps_dedup"); wrap(snapshot, "union_graph_packed"); wrap(snapshot, "build_view")
-wrap(functional, "gather_inverse"); wrap(sampling, "plan_batch_loss"); wrap(gru_chain.GruProgram, "upload", "program.upload")
+wrap(functional, "gather_inverse"); wrap(gru_chain.GruProgram, "chain_plan", "program.chain_plan"); wrap(gru_chain.GruProgram, "chain_tables", "program.chain_tables"); wrap(sampling, "plan_batch_loss"); wrap(gru_chain.GruProgram, "upload", "program.upload")
 wrap(dynamic_rgcn.DynamicRGCN, "sample_target_graphs"); wrap(bi_dynamic_rgcn.BiDynamicRGCN, "_build_program"); wrap(bi_dynamic_rgcn.BiDynamicRGCN, "_bi_target")
 wrap(dynamic_rgcn.DynamicRGCN, "_all_maps"); wrap(dynamic_rgcn.DynamicRGCN, "_upload"); wrap(dynamic_rgcn.DynamicRGCN, "_plan_loss")
 w = synthetic.workload(sys.argv[1] if len(sys.argv) > 1 else "S-gdelt", seed=0)
