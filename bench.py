@@ -318,6 +318,7 @@ def main():
     if world > 1 or os.environ.get("TEMP_BENCH_FORCE_DIST") == "1":       # FORCE_DIST: exercise the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from temp_amd import _lib, synthetic
