@@ -9,6 +9,7 @@
 // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
 #include "common.hpp"
 #include <type_traits>
+#include <mutex>
 #include "gemm_wres.hpp"
 
 namespace temp {
@@ -769,13 +770,47 @@ int temp_trace_end(int* kernel_ids, float* ms, int capacity, int* n_out) {
   return TEMP_OK;
 }
 
+}  // extern "C"
+
+// ---- scratch slots for the packed (bf16-split) weight matrices of gemm_bx.hpp: static device memory, one slot per stream that
+// has launched a large GEMM (at most BX_SLOTS streams; two launches on one stream are ordered, so a slot is free again when the
+// next pack kernel of that stream runs).  Nothing is allocated, freed or synchronised at run time.
+__device__ __attribute__((aligned(16))) unsigned char g_bx_slots[BX_SLOTS][BX_SLOT_BYTES];
+
+namespace temp {
+bx_u32x4* bx_scratch(hipStream_t st, size_t bytes) {
+  static std::mutex mu;
+  static hipStream_t owner[BX_SLOTS];
+  static int n_owner = 0;
+  static unsigned char* base = nullptr;
+  if (bytes > BX_SLOT_BYTES) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!base) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bx_slots)) != hipSuccess || !p) return nullptr;
+    base = (unsigned char*)p;
+  }
+  int slot = -1;
+  for (int i = 0; i < n_owner; ++i)
+    if (owner[i] == st) { slot = i; break; }
+  if (slot < 0) {
+    if (n_owner >= BX_SLOTS) return nullptr;
+    slot = n_owner;
+    owner[n_owner++] = st;
+  }
+  return reinterpret_cast<bx_u32x4*>(base + (size_t)slot * BX_SLOT_BYTES);
+}
+}  // namespace temp
+
+extern "C" {
+
 const char* temp_trace_kernel_name(int id) {
   static const char* names[] = {"k_rgcn_agg<fwd>", "k_rgcn_agg<dx>", "k_rgcn_dw", "k_fixup", "k_gemm_panel<loop_fwd>",
                                 "k_gemm_panel<loop_dx>", "k_gemm_tn", "k_reduce_slices", "k_colsum_part", "k_relu_bwd", "k_gru_fwd",
                                 "k_gru_bwd_gates", "k_gemm_panel<gru_dx>", "k_gemm_panel<gru_dprev>", "k_gather_rows",
                                 "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>", "k_gemm_panel<gru_gi>",
                                 "k_gemm_panel<linear>", "k_gather_ce", "k_sa_attn_fwd", "k_sa_attn_bwd", "k_gru_chain_fwd", "k_gru_chain_bwd",
-                                "k_gru_chain_pack"};
+                                "k_gru_chain_pack", "k_bx_pack"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 

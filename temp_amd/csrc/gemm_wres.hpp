@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "gemm_panel.hpp"
+#include "gemm_bx.hpp"
 
 namespace temp {
 
@@ -336,6 +337,16 @@ int launch_gemm_panel_multi(int kid, const PanelBatch<Epi>& batch, int count, in
   long long rows = 0;
   for (int i = 0; i < count; ++i) rows += batch.p[i].M > 0 ? batch.p[i].M : 0;
   if (rows <= 0 || N <= 0) return TEMP_OK;
+  if constexpr (!EpiIsGroup<Epi>::value) {
+    // large products run on the bf16 matrix pipe with the exact three-way operand split (gemm_bx.hpp)
+    if (bx_enabled()) {
+      int max_m = 0;
+      for (int i = 0; i < count; ++i) max_m = batch.p[i].M > max_m ? batch.p[i].M : max_m;
+      BxGeom bg;
+      int G;
+      if (bx_plan(N, K, lda, ldb, trans_b, max_m, rows, &bg, &G)) return launch_gemm_bx(kid, batch, count, bg, G, st);
+    }
+  }
   WresGeom g;
   if (!wres_disabled() && wres_plan(N, K, lda, ldb, trans_b, rows, &g)) {
     // problems with different B matrices: give every problem its own blocks instead of re-staging B per problem

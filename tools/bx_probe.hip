@@ -1,0 +1,101 @@
+// Probe: k_gemm_bx (fp32 GEMM as six bf16 MFMA products) against the fp32 MFMA kernels: time and error vs fp64.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I temp_amd/csrc -I include tools/bx_probe.hip -o tools/build/bx_probe
+#include "common.hpp"
+#include "gemm_wres.hpp"
+#include "gemm_bx.hpp"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+using namespace temp;
+int temp::trace_open(int, hipStream_t) { return -1; }
+static bx_u32x4* g_scr = nullptr;
+bx_u32x4* temp::bx_scratch(hipStream_t, size_t bytes) { if (!g_scr) (void)hipMalloc(&g_scr, BX_SLOT_BYTES); return bytes <= BX_SLOT_BYTES ? g_scr : nullptr; }
+void temp::trace_close(int, hipStream_t) {}
+
+struct EpiStoreP {
+  float* out; int ldo;
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
+  __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
+  __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const { st4(out + (size_t)row * ldo + col, acc); }
+};
+
+template <class F>
+float time_ms(F f, int iters = 20) {
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  f(); (void)hipDeviceSynchronize();
+  (void)hipEventRecord(a);
+  for (int i = 0; i < iters; ++i) f();
+  (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+  float ms; (void)hipEventElapsedTime(&ms, a, b);
+  return ms / iters;
+}
+
+static void run_case(int M, int K, int N, int trans_b, int force_g) {
+  float *A, *B, *C1, *C2;
+  (void)hipMalloc(&A, (size_t)M * K * 4); (void)hipMalloc(&B, (size_t)N * K * 4); (void)hipMalloc(&C1, (size_t)M * N * 4); (void)hipMalloc(&C2, (size_t)M * N * 4);
+  std::vector<float> ha((size_t)M * K), hb((size_t)N * K);
+  unsigned st = 12345u + M + K;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.f - 0.5f; };
+  for (auto& v : ha) v = rnd() * 2.f * expf(4.f * rnd());
+  for (auto& v : hb) v = rnd() * 0.3f;
+  (void)hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemset(C1, 0, (size_t)M * N * 4); (void)hipMemset(C2, 0, (size_t)M * N * 4);
+  const int ldb = trans_b ? K : N;
+  PanelBatch<EpiStoreP> b1, b2;
+  for (int i = 0; i < PANEL_MAXP; ++i) { b1.p[i] = PanelProblem<EpiStoreP>{0, nullptr, nullptr, nullptr, EpiStoreP{C1, N}}; b2.p[i] = b1.p[i]; }
+  b1.p[0] = PanelProblem<EpiStoreP>{M, A, nullptr, B, EpiStoreP{C1, N}};
+  b2.p[0] = PanelProblem<EpiStoreP>{M, A, nullptr, B, EpiStoreP{C2, N}};
+  WresGeom wg;
+  const bool wres = wres_plan(N, K, K, ldb, trans_b, M, &wg);
+  auto run_f32 = [&]() {
+    if (wres) launch_gemm_wres(0, b1, 1, wg, 0); else launch_gemm_stream_multi(0, b1, 1, N, K, K, ldb, trans_b, 0);
+  };
+  BxGeom bg; int G;
+  if (!bx_plan(N, K, K, ldb, trans_b, M, M, &bg, &G)) { printf("bx_plan refused\n"); return; }
+  if (force_g > 0) { G = force_g; bg.n_groups = ceil_div(bg.n_tiles, G); bg.tail_store = bg.n_tiles - (bg.n_groups - 1) * G; }
+  auto run_bx = [&]() { launch_gemm_bx(0, b2, 1, bg, G, 0); };
+  {
+    dim3 grid(8 * bg.per_xcd * bg.n_groups, 1);
+    BxPacked pk; for (int i = 0; i < PANEL_MAXP; ++i) pk.b[i] = temp::bx_scratch(0, 1);
+#define ABLG(GG, V) { auto f = [&]() { hipLaunchKernelGGL((k_gemm_bxp<GG, EpiStoreP, V>), grid, dim3(BX_THREADS), 0, 0, b2, bg, pk); }; printf("  VAR %2d: %.4f ms\n", V, time_ms(f)); }
+#define ABL(V) { if (G == 7) ABLG(7, V) else if (G == 5) ABLG(5, V) else if (G == 4) ABLG(4, V) }
+    run_bx();
+    ABL(1) ABL(4) ABL(7) ABL(2) ABL(5)
+  }
+  const float t1 = time_ms(run_f32), t2 = time_ms(run_bx);
+  const double gf = 2.0 * M * K * N / 1e9;
+  std::vector<float> c1((size_t)M * N), c2((size_t)M * N);
+  (void)hipMemcpy(c1.data(), C1, c1.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(c2.data(), C2, c2.size() * 4, hipMemcpyDeviceToHost);
+  double e1m = 0, e2m = 0, dm = 0;
+  for (int r = 0; r < 1500; ++r) {
+    const int row = r < 300 ? (r < 150 ? r : M - 1 - (r - 150)) : (int)(((long long)r * 7919) % M);
+    for (int n = 0; n < N; ++n) {
+      double ref = 0, sabs = 0;
+      for (int k = 0; k < K; ++k) {
+        const double a = ha[(size_t)row * K + k], b = trans_b ? hb[(size_t)n * K + k] : hb[(size_t)k * N + n];
+        ref += a * b; sabs += fabs(a * b);
+      }
+      const double e1 = fabs(c1[(size_t)row * N + n] - ref) / sabs, e2 = fabs(c2[(size_t)row * N + n] - ref) / sabs;
+      if (e1 > e1m) e1m = e1;
+      if (e2 > e2m) e2m = e2;
+      const double d = fabs((double)c1[(size_t)row * N + n] - c2[(size_t)row * N + n]) / sabs;
+      if (d > dm) dm = d;
+    }
+  }
+  printf("M=%6d K=%3d N=%3d tb=%d  fp32 %s %.4f ms %6.1f TF | bx G=%d x%d %.4f ms %6.1f TF (%.2fx) | err/sum|ab| fp32 %.2e bx %.2e diff %.2e\n", M, K, N,
+         trans_b, wres ? "wres" : "strm", t1, gf / t1, G, bg.n_groups, t2, gf / t2, t1 / t2, e1m, e2m, dm);
+  (void)hipFree(A); (void)hipFree(B); (void)hipFree(C1); (void)hipFree(C2);
+}
+
+int main(int argc, char** argv) {
+  const int fg = argc > 1 ? atoi(argv[1]) : 0;
+  run_case(58000, 200, 600, 1, fg);
+  run_case(58000, 600, 200, 0, fg);
+  run_case(82000, 200, 200, 0, fg);
+  run_case(82000, 200, 200, 1, fg);
+  return 0;
+}
