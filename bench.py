@@ -16,8 +16,12 @@ one bucket after backward.
 
 Extra objects on the JSON line:
   roofline      dominant kernel (largest share of traced kernel time): algorithmic bytes (or
-                flops) per step / its HIP-event time per step, against 8 TB/s HBM (or the 157.3
-                TFLOP/s fp32 MFMA peak).  Events are recorded by libtemp_amd around every launch
+                flops) per step / its HIP-event time per step, against 8 TB/s HBM or the MFMA peak
+                of the pipe the kernel runs on: 157.3 TFLOP/s fp32 MFMA, or -- for the large GEMMs,
+                which compute every fp32 product as six bf16 MFMA products of an exact three-way
+                operand split -- 2500 / 6 TFLOP/s (roofline.pipe says which; `achieved` always
+                counts the ALGORITHMIC fp32 flops).  config.fp32_mfma_ms_per_step is the same step
+                with those GEMMs on the fp32 MFMA kernels (TEMP_MFMA=f32, child process).  Events are recorded by libtemp_amd around every launch
                 on the launch stream (temp_trace_begin/end) during extra traced steps run right
                 after the timed region, so the headline number is not perturbed.
   cpu_baseline  the CPU oracle (torch restatement of the reference's op sequence, kind "port")
@@ -38,6 +42,13 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak, same guide
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guide
+# The large GEMMs (k_gemm_panel<*> = k_gemm_bx / k_gemm_bxp, k_gemm_tn = k_gemm_tn_bx) compute every fp32 product as SIX bf16 MFMA
+# products of an exact three-way operand split (temp_amd/csrc/gemm_bx.hpp; fp32-equivalent accuracy): their roof is the bf16 pipe
+# divided by six.  TEMP_MFMA=f32 in the environment keeps them on the fp32 MFMA kernels (round-1 arithmetic).
+BX_KERNELS = ("k_gemm_panel", "k_gemm_tn")
+MFMA_MODE = "f32" if os.environ.get("TEMP_MFMA", "").startswith("f") else "bf16x3"
+
 
 
 def make_args(w, module):
@@ -131,6 +142,7 @@ def algorithmic_costs(wb, D, bi, S=2):
     c["k_gru_chain_fwd"] = dict(bytes=n_gru * (3 * row + 6 * row), flops=6 * n_gru * D * D)
     c["k_gru_chain_bwd"] = dict(bytes=n_gru * (5 * row + 6 * row), flops=6 * n_gru * D * D)
     c["k_gru_chain_pack"] = dict(bytes=4 * 2 * 3 * D * D * 4, flops=0)
+    c["k_bx_pack"] = dict(bytes=(2 * D * D + 2 * 2 * 3 * D * D) * (4 + 6), flops=0)      # weights in as fp32, out as three bf16 planes
     if hasattr(wb, "idx_tgt"):                    # attention mixer over the target rows (encoder-only step)
         nq, act = int(wb.idx_tgt.shape[0]), int((wb.idx_tgt >= 0).sum().item())
         c["k_sa_attn_fwd"] = dict(bytes=nq * 4 * row + act * 2 * row, flops=4 * (act + nq) * D)
@@ -291,6 +303,8 @@ def main():
                          "'both' (default) = the headline `value` is the windows mode and the snapshot-sharded measurement rides along "
                          "under `north_star_sharded`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-mfma-compare", action="store_true",
+                    help="skip the second, short run with TEMP_MFMA=f32 (config.fp32_mfma_ms_per_step)")
     ap.add_argument("--train-loop-steps", type=int, default=30,
                     help="also time this many steps of a real training loop (new batch every step: host prepare, fresh negatives, loss, "
                          "backward, Adam, eager launches) and report it under config.train_loop, after the timed region (never the "
@@ -445,9 +459,15 @@ def main():
         cst = costs.get(dom, dict(bytes=0, flops=0))
         sec = tr[dom]["ms_per_step"] * 1e-3
         if dom.startswith(MFMA_KERNELS) and cst["flops"]:
-            ach = cst["flops"] / sec / 1e12
-            roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None)
+            ach = cst["flops"] / sec / 1e12                     # algorithmic (fp32) flops
+            if MFMA_MODE == "bf16x3" and dom.startswith(BX_KERNELS):
+                peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+                roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
+                            pipe="bf16 MFMA, six products per fp32 product (exact 3-way operand split): peak = %.0f / 6" % MFMA_BF16_PEAK_TFLOPS,
+                            executed_bf16_tflops=6.0 * ach, frac_of_fp32_mfma_peak=ach / MFMA_F32_PEAK_TFLOPS)
+            else:
+                roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, pipe="fp32 MFMA")
         else:
             ach = cst["bytes"] / sec / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
@@ -497,6 +517,23 @@ def main():
         except Exception as e:                      # an extra, never the headline
             print("bench: training-loop probe failed (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
 
+    fp32_ms = None
+    if rank == 0 and world == 1 and not sharded and MFMA_MODE == "bf16x3" and not a.no_fp32_mfma_compare:
+        # the same step with every product on the fp32 MFMA kernels, in a child process (the switch is read once per process)
+        import subprocess
+        env = dict(os.environ, TEMP_MFMA="f32")
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", str(a.warmup), "--workload", a.workload,
+               "--encoder", a.encoder, "--train-loop-steps", "0", "--trace-steps", "0", "--no-cpu-baseline", "--no-fp32-mfma-compare"]
+        if a.with_loss:
+            cmd.append("--with-loss")
+        if a.no_graph:
+            cmd.append("--no-graph")
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            fp32_ms = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+        except Exception as e:                      # an extra, never the headline
+            print("bench: fp32-MFMA comparison run failed (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
+
     if rank == 0:
         out = dict(metric="edges/sec (fwd+bwd) RGCN+%s seq_len=%d%s" % ("GRU" if a.encoder == "gru" else "self-attention", w["L"], " + link-prediction loss" if a.with_loss else ""), value=value, unit="edges/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak",
@@ -513,7 +550,11 @@ def main():
                                distinct_snapshot_nodes_per_step=getattr(wb, "n_nodes_distinct", None), targets=targets,
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
                                else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager"),
-                               train_loop=loop),
+                               train_loop=loop,
+                               mfma=("large GEMMs on the bf16 matrix pipe as six products of an exact 3-way operand split (fp32-equivalent "
+                                     "accuracy, gemm_bx.hpp); chain kernels on the fp32 MFMA pipe" if MFMA_MODE == "bf16x3"
+                                     else "fp32 MFMA everywhere (TEMP_MFMA=f32)"),
+                               fp32_mfma_ms_per_step=fp32_ms),
                    roofline=roof, cpu_baseline=cpu, north_star_sharded=ns_result)
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
         # that the JSON line is the LAST line of stdout
