@@ -325,7 +325,7 @@ struct BxPacked { const bx_u32x4* b[PANEL_MAXP]; };           // packed B of eve
 // VAR is 0 in the library; tools/bx_probe.hip instantiates ablations (bit0: no A loads, bit1: no epilogue, bit2: no B staging,
 // bit3: no MFMAs, bit4: no slab barrier)
 template <int G, class Epi, int VAR = 0>
-__global__ void __launch_bounds__(BX_THREADS, 2) k_gemm_bxp(PanelBatch<Epi> batch, BxGeom g, BxPacked packed) {
+__global__ void __launch_bounds__(BX_THREADS, (G <= 4 ? 3 : 2)) k_gemm_bxp(PanelBatch<Epi> batch, BxGeom g, BxPacked packed) {
   constexpr int PIECES = G * 192;                             // 16-byte pieces of a slab of the group
   constexpr int NPC = (PIECES + BX_THREADS - 1) / BX_THREADS;
   __shared__ __attribute__((aligned(16))) bx_u32x4 Bs[2][PIECES];

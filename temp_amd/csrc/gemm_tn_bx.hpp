@@ -173,15 +173,22 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx(int M, int Ka, int 
                 for (int p = 0; p < 3; ++p) { if constexpr (VAR & 32) wf[(pr + 1) & 1][u][p] = SM; else wf[(pr + 1) & 1][u][p] = bs[(tn * 3 + p) * 64]; }
               }
             }
-            if ((slot & 1) && (slot >> 1) < 8 && stager) chunk(Rc, slot >> 1, (s + 1) & 1, s + 1, ragged_c);
+            if constexpr (!(VAR & 128)) {
+              if ((slot & 1) && (slot >> 1) < 8 && stager) chunk(Rc, slot >> 1, (s + 1) & 1, s + 1, ragged_c);
+            } else {                                         // late placement: the last 8 MFMAs
+              constexpr int FIRST = NTW * 6 - 8;
+              if (slot >= FIRST && stager) chunk(Rc, slot - FIRST, (s + 1) & 1, s + 1, ragged_c);
+            }
             ++slot;
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
       if (stager) {
+        if constexpr (!(VAR & 128)) {
 #pragma unroll
-        for (int c = (NTW * 6) >> 1; c < 8; ++c) chunk(Rc, c, (s + 1) & 1, s + 1, ragged_c);      // narrow waves: the rest
+          for (int c = (NTW * 6) >> 1; c < 8; ++c) chunk(Rc, c, (s + 1) & 1, s + 1, ragged_c);    // narrow waves: the rest
+        }
       }
       if constexpr (!(VAR & 16)) __syncthreads();
     };

@@ -16,6 +16,7 @@
 // The matrix waves never wait on HBM: their only global loads are L2 hits on the packed weights.
 #include "common.hpp"
 #include "gru_math.hpp"
+#include "gemm_bx.hpp"
 
 namespace temp {
 
@@ -81,7 +82,9 @@ __global__ void __launch_bounds__(256) k_gru_chain_pack(int D, const float* __re
 
 // ---- forward --------------------------------------------------------------------------------------------------------
 // TPW = tiles per matrix wave (ceil(NT / 4)), MW = memory waves (4 or 8).
-template <int VARIANT, int TPW, int MW>
+// BX = 1: the products run on the bf16 matrix pipe as six products of the exact three-way operand split (gemm_bx.hpp): W_hh
+// arrives pre-split (k_bx_pack: three planes in fragment order), the state fragment is split by the matrix wave itself.
+template <int VARIANT, int TPW, int MW, int BX>
 __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, const float* __restrict__ gi, float* __restrict__ H,
                                                                   float* __restrict__ saved) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -122,6 +125,87 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
       for (int j = 0; j < TPW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      if constexpr (BX) {
+        // W_hh planes of ONE slab (16 k) in registers: [tile][lane] per plane, packed[((slab * NT + tile) * 3 + plane) * 64 + lane].
+        // The products of a slab go plane by plane -- L.ah | M.am, M.ah | H.al, H.am, H.ah (small terms first within a plane),
+        // interleaved over the wave's tiles -- so that a plane's registers are free after its last round and are refilled
+        // with the NEXT slab's plane at once: 3 to 5 rounds (TPW MFMAs each) of L2 latency cover with a single buffer.
+        const bx_u32x4* wp = reinterpret_cast<const bx_u32x4*>(R.wf);
+        const int NS = NQ >> 1;
+        bx_u32x4 wh[TPW], wm[TPW], wl[TPW];
+        auto wload = [&](bx_u32x4 (&w)[TPW], int sl, int pl) {
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) w[j] = wp[((size_t)(sl * NT + tidx[j]) * 3 + pl) * 64 + lane];
+        };
+        wload(wh, 0, 0); wload(wm, 0, 1); wload(wl, 0, 2);
+        for (int s = 0; s < ns; ++s) {
+          const int cur = s & 1;
+          const int flags = flagb[s];
+          if (flags & 1) {
+            const int e = tabb[s * CH_SLOTS + li];
+            const float decm = (e >= 0 && (e & CH_HAS_PREV)) ? decb[s * CH_SLOTS + li] : 0.f;
+            const float* hrow = hb + (size_t)cur * CH_SLOTS * ldh + li * ldh + 8 * hh;     // k = 16 slab + 8 hh .. +7 of track li
+            bx_u32x4 AH, AM, AL, NH, NM, NL;
+            {
+              const float4 r0 = scale4(ld4(hrow), decm), r1 = scale4(ld4(hrow + 4), decm);
+              unsigned h_, m_, l_;
+              bx_split_pair(r0.x, r0.y, h_, m_, l_); AH[0] = h_; AM[0] = m_; AL[0] = l_;
+              bx_split_pair(r0.z, r0.w, h_, m_, l_); AH[1] = h_; AM[1] = m_; AL[1] = l_;
+              bx_split_pair(r1.x, r1.y, h_, m_, l_); AH[2] = h_; AM[2] = m_; AL[2] = l_;
+              bx_split_pair(r1.z, r1.w, h_, m_, l_); AH[3] = h_; AM[3] = m_; AL[3] = l_;
+            }
+            for (int sl = 0; sl < NS; ++sl) {
+              const int sn = sl + 1 < NS ? sl + 1 : 0;            // past the end: slab 0 of the NEXT position (weights only)
+              const float4 n0 = scale4(ld4(hrow + 16 * sn), decm), n1 = scale4(ld4(hrow + 16 * sn + 4), decm);
+              const bx_bf16x8 ah = bx_frag(AH), am = bx_frag(AM), al = bx_frag(AL);
+              unsigned h_, m_, l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wl[j]), ah, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              wload(wl, sn, 2);
+              bx_split_pair(n0.x, n0.y, h_, m_, l_); NH[0] = h_; NM[0] = m_; NL[0] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wm[j]), am, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              bx_split_pair(n0.z, n0.w, h_, m_, l_); NH[1] = h_; NM[1] = m_; NL[1] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wm[j]), ah, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              wload(wm, sn, 1);
+              bx_split_pair(n1.x, n1.y, h_, m_, l_); NH[2] = h_; NM[2] = m_; NL[2] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wh[j]), al, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              bx_split_pair(n1.z, n1.w, h_, m_, l_); NH[3] = h_; NM[3] = m_; NL[3] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wh[j]), am, acc[j], 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wh[j]), ah, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              wload(wh, sn, 0);
+              AH = NH; AM = NM; AL = NL;
+            }
+          // lane (li, hh) owns track li and, per register quad qq, gate columns tile*32 + 8qq + 4hh .. +3
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            if (!tval[j]) continue;
+            float* dst = accb + (size_t)li * lda + tidx[j] * 32 + 4 * hh;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              st4(dst + 8 * qq, make_float4(acc[j][4 * qq], acc[j][4 * qq + 1], acc[j][4 * qq + 2], acc[j][4 * qq + 3]));
+              acc[j][4 * qq] = 0.f; acc[j][4 * qq + 1] = 0.f; acc[j][4 * qq + 2] = 0.f; acc[j][4 * qq + 3] = 0.f;
+            }
+          }
+          }
+          __syncthreads();      // A: products of position s are in LDS
+          __syncthreads();      // B: states of position s are in LDS
+        }
+      } else {
       float4 wA[TPW], wB[TPW];
       auto wload = [&](float4 (&w)[TPW], int q) {
 #pragma unroll
@@ -176,6 +260,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
         }
         __syncthreads();      // A: products of position s are in LDS
         __syncthreads();      // B: states of position s are in LDS
+      }
       }
     } else {
       // ------------------------------------------------------------------ memory role
@@ -252,7 +337,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------
-template <int VARIANT, int TPWB, int MW>
+template <int VARIANT, int TPWB, int MW, int BX>
 __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, ChainUps ups, const float* __restrict__ saved,
                                                                   float* __restrict__ dgi, float* __restrict__ dgh) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -294,6 +379,92 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
       for (int j = 0; j < TPWB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      if constexpr (BX) {
+        // W_hh planes of TWO slabs (16 k each) in registers; the planes of slab sl + 2 replace those of slab sl as soon as
+        // their last round of slab sl has issued (L after round 0, M after round 2, H after round 5): nine to eleven rounds of
+        // L2 latency cover.  NQb is a multiple of 4, so the slab count is even.
+        const bx_u32x4* wp = reinterpret_cast<const bx_u32x4*>(R.wb);
+        const int NS = NQb >> 1;
+        bx_u32x4 wh0[TPWB], wm0[TPWB], wl0[TPWB], wh1[TPWB], wm1[TPWB], wl1[TPWB];
+        auto wload = [&](bx_u32x4 (&w)[TPWB], int sl, int pl) {
+#pragma unroll
+          for (int j = 0; j < TPWB; ++j) w[j] = wp[((size_t)(sl * NTb + tidx[j]) * 3 + pl) * 64 + lane];
+        };
+        wload(wh0, 0, 0); wload(wm0, 0, 1); wload(wl0, 0, 2);
+        wload(wh1, 1, 0); wload(wm1, 1, 1); wload(wl1, 1, 2);
+        for (int s = ns - 1; s >= 0; --s) {
+          const int flags = flagb[s];
+          __syncthreads();      // A: dgh / dh*z / decay of position s are in LDS
+          if (flags & 1) {
+            const float* arow = ab + (size_t)li * ldA + 8 * hh;                 // k = 16 slab + 8 hh .. +7 of track li
+            bx_u32x4 AH, AM, AL, NH, NM, NL;
+            {
+              const float4 r0 = ld4(arow), r1 = ld4(arow + 4);
+              unsigned h_, m_, l_;
+              bx_split_pair(r0.x, r0.y, h_, m_, l_); AH[0] = h_; AM[0] = m_; AL[0] = l_;
+              bx_split_pair(r0.z, r0.w, h_, m_, l_); AH[1] = h_; AM[1] = m_; AL[1] = l_;
+              bx_split_pair(r1.x, r1.y, h_, m_, l_); AH[2] = h_; AM[2] = m_; AL[2] = l_;
+              bx_split_pair(r1.z, r1.w, h_, m_, l_); AH[3] = h_; AM[3] = m_; AL[3] = l_;
+            }
+            // one slab out of the plane registers (wh, wm, wl); `sl2` = the slab they are refilled with
+            auto slab = [&](bx_u32x4 (&wh)[TPWB], bx_u32x4 (&wm)[TPWB], bx_u32x4 (&wl)[TPWB], int sl, int sl2) {
+              const int sn = sl + 1 < NS ? sl + 1 : 0;
+              const float4 n0 = ld4(arow + 16 * sn), n1 = ld4(arow + 16 * sn + 4);
+              const bx_bf16x8 ah = bx_frag(AH), am = bx_frag(AM), al = bx_frag(AL);
+              unsigned h_, m_, l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wl[j]), ah, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              wload(wl, sl2, 2);
+              bx_split_pair(n0.x, n0.y, h_, m_, l_); NH[0] = h_; NM[0] = m_; NL[0] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wm[j]), am, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              bx_split_pair(n0.z, n0.w, h_, m_, l_); NH[1] = h_; NM[1] = m_; NL[1] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wm[j]), ah, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              wload(wm, sl2, 1);
+              bx_split_pair(n1.x, n1.y, h_, m_, l_); NH[2] = h_; NM[2] = m_; NL[2] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wh[j]), al, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              bx_split_pair(n1.z, n1.w, h_, m_, l_); NH[3] = h_; NM[3] = m_; NL[3] = l_;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wh[j]), am, acc[j], 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < TPWB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_frag(wh[j]), ah, acc[j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              wload(wh, sl2, 0);
+              AH = NH; AM = NM; AL = NL;
+            };
+            for (int sl = 0; sl < NS; sl += 2) {
+              const int a2 = sl + 2 < NS ? sl + 2 : 0, b2 = sl + 3 < NS ? sl + 3 : 1;      // wrap: the NEXT position
+              slab(wh0, wm0, wl0, sl, a2);
+              slab(wh1, wm1, wl1, sl + 1, b2);
+            }
+          const float dec = decb[s * CH_SLOTS + li];
+#pragma unroll
+          for (int j = 0; j < TPWB; ++j) {
+            if (!tval[j]) continue;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const int c = tidx[j] * 32 + 8 * qq + 4 * hh;
+              const float4 gz = ld4(gzb + (size_t)li * ldz + c);
+              st4(dpb + (size_t)li * ldz + c, make_float4((acc[j][4 * qq] + gz.x) * dec, (acc[j][4 * qq + 1] + gz.y) * dec,
+                                                           (acc[j][4 * qq + 2] + gz.z) * dec, (acc[j][4 * qq + 3] + gz.w) * dec));
+              acc[j][4 * qq] = 0.f; acc[j][4 * qq + 1] = 0.f; acc[j][4 * qq + 2] = 0.f; acc[j][4 * qq + 3] = 0.f;
+            }
+          }
+          }
+          __syncthreads();      // B: d_prev of position s is in LDS
+        }
+      } else {
       // weights: a ring of four stage buffers, i.e. three stages (3 x 8 MFMAs = 1.5 k cycles) of L2 latency cover
       float4 w0[TPWB], w1[TPWB], w2[TPWB], w3[TPWB];
       auto wload = [&](float4 (&w)[TPWB], int q) {
@@ -356,6 +527,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
           }
         }
         __syncthreads();      // B: d_prev of position s is in LDS
+      }
       }
     } else {
       // ------------------------------------------------------------------ memory role: gate gradients
@@ -437,6 +609,9 @@ static int chain_check(const TempGruChain* c) {
   return TEMP_OK;
 }
 
+// the products of the chain run on the bf16 matrix pipe (three-way split) unless TEMP_MFMA=f32 or d is not a multiple of 8
+static bool chain_bx(int d) { return bx_enabled() && d % 8 == 0; }
+
 static ChainArgs chain_args(const TempGruChain* c) {
   ChainArgs a = {};
   const ChainGeom g = chain_geom(c->d);
@@ -444,7 +619,7 @@ static ChainArgs chain_args(const TempGruChain* c) {
   a.lambda = c->lambda; a.plane = c->saved_plane;
   for (int i = 0; i < c->n_rnn; ++i) {
     a.rnn[i].wf = (const float4*)c->packed[i];
-    a.rnn[i].wb = (const float4*)c->packed[i] + (size_t)g.NT * g.NQ * 64;
+    a.rnn[i].wb = (const float4*)c->packed[i] + (chain_bx(c->d) ? (size_t)(g.NQ >> 1) * g.NT * 192 : (size_t)g.NT * g.NQ * 64);
     a.rnn[i].b_hh = c->b_hh[i];
   }
   return a;
@@ -462,8 +637,16 @@ static int chain_lds_attr(K kernel, size_t bytes, bool* done) {
 template <int VARIANT, int TPW>
 static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float* saved, hipStream_t st) {
   static bool attr = false;
-  auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4>;
+  static bool attr_bx = false;
   const size_t lds = chain_lds_fwd(a.D, a.max_steps);
+  if (chain_bx(a.D)) {
+    auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4, 1>;
+    int rc = chain_lds_attr(kernel, lds, &attr_bx);
+    if (rc) return rc;
+    TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds, st, a, gi, h, saved);
+    return launch_status();
+  }
+  auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4, 0>;
   int rc = chain_lds_attr(kernel, lds, &attr);
   if (rc) return rc;
   TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds, st, a, gi, h, saved);
@@ -473,8 +656,16 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
 template <int VARIANT, int TPWB>
 static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float* saved, float* dgi, float* dgh, hipStream_t st) {
   static bool attr = false;
-  auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8>;
+  static bool attr_bx = false;
   const size_t lds = chain_lds_bwd(a.D, a.max_steps);
+  if (chain_bx(a.D)) {
+    auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 1>;
+    int rc = chain_lds_attr(kernel, lds, &attr_bx);
+    if (rc) return rc;
+    TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds, st, a, ups, saved, dgi, dgh);
+    return launch_status();
+  }
+  auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 0>;
   int rc = chain_lds_attr(kernel, lds, &attr);
   if (rc) return rc;
   TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds, st, a, ups, saved, dgi, dgh);
@@ -495,13 +686,28 @@ int temp_gru_chain_supported(int d) {
 size_t temp_gru_chain_pack_floats(int d) {
   if (d <= 0) return 0;
   const ChainGeom g = chain_geom(d);
-  return ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64 * 4;
+  const size_t f32 = ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64 * 4;
+  // three bf16 planes in fragment order: (slabs of 16 k) x tiles x 192 sixteen-byte items, forward then backward
+  const size_t bx = ((size_t)(g.NQ >> 1) * g.NT + (size_t)(g.NQb >> 1) * g.NTb) * 192 * 4;
+  return f32 > bx ? f32 : bx;                          // either arithmetic (TEMP_MFMA) fits the caller's buffer
 }
 
 int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream) {
   if (d <= 0 || !w_hh || !packed) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
-  const size_t n4 = temp_gru_chain_pack_floats(d) / 4;
+  const ChainGeom g = chain_geom(d);
+  if (chain_bx(d)) {
+    // forward: gate column x k = W_hh as stored ([3d][d], k contiguous); backward: k = gate column, state column = W_hh as [K][N]
+    const int nsf = g.NQ >> 1, nsb = g.NQb >> 1;
+    bx_u32x4* pf = reinterpret_cast<bx_u32x4*>(packed);
+    bx_u32x4* pb = pf + (size_t)nsf * g.NT * 192;
+    TEMP_LAUNCH(K_GRU_CHAIN_PACK, (k_bx_pack<1>), dim3(ceil_div((long long)nsf * g.NT, 4)), dim3(256), 0, (hipStream_t)stream, d, 3 * d, g.NT, nsf,
+                w_hh, d, pf);
+    TEMP_LAUNCH(K_GRU_CHAIN_PACK, (k_bx_pack<0>), dim3(ceil_div((long long)nsb * g.NTb, 4)), dim3(256), 0, (hipStream_t)stream, 3 * d, d, g.NTb, nsb,
+                w_hh, d, pb);
+    return launch_status();
+  }
+  const size_t n4 = ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64;
   int gx = ceil_div((long long)n4, 256);
   if (gx > 1024) gx = 1024;
   TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_gru_chain_pack, dim3(gx), dim3(256), 0, (hipStream_t)stream, d, w_hh, (float4*)packed);

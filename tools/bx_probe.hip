@@ -63,7 +63,7 @@ static void run_case(int M, int K, int N, int trans_b, int force_g) {
 #define ABLG(GG, V) { auto f = [&]() { hipLaunchKernelGGL((k_gemm_bxp<GG, EpiStoreP, V>), grid, dim3(BX_THREADS), 0, 0, b2, bg, pk); }; printf("  VAR %2d: %.4f ms\n", V, time_ms(f)); }
 #define ABL(V) { if (G == 7) ABLG(7, V) else if (G == 5) ABLG(5, V) else if (G == 4) ABLG(4, V) }
     run_bx();
-    ABL(1) ABL(4) ABL(7) ABL(2) ABL(5)
+
   }
   const float t1 = time_ms(run_f32), t2 = time_ms(run_bx);
   const double gf = 2.0 * M * K * N / 1e9;

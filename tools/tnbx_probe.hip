@@ -48,7 +48,7 @@ static void run_case(int M, int Ka, int Nb, bool bias) {
   const float t = time_ms(run);
   if (nt == 7) {
 #define ABL(V) { auto f = [&]() { hipLaunchKernelGGL((k_gemm_tn_bx<7, V>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr); }; printf("  VAR %2d: %.4f ms\n", V, time_ms(f)); }
-    ABL(7)
+    ABL(7) ABL(128)
     { unsigned long long* dbg; (void)hipMalloc(&dbg, 32 * 8 * grid); (void)hipMemset(dbg, 0, 32 * 8 * grid);
       hipLaunchKernelGGL((k_gemm_tn_bx<7, 64>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bpart, dbg); (void)hipDeviceSynchronize();
       std::vector<unsigned long long> h(32 * grid); (void)hipMemcpy(h.data(), dbg, 32 * 8 * grid, hipMemcpyDeviceToHost);
