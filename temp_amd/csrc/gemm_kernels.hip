@@ -243,18 +243,26 @@ __global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, con
 __global__ void __launch_bounds__(256) k_reduce_slices(int n_slices, size_t elems, int width, const float* __restrict__ part,
                                                        float* __restrict__ out, int ldo) {
   // elems % 4 == 0 is guaranteed by the callers (all widths are multiples of 4): float4 lanes,
-  // 8 slice loads in flight, summed in slice order (deterministic)
+  // 16 slice loads in flight (a thread's loop is a chain of memory round trips: 48 slices = 3 of them), summed in slice order
+  // (deterministic)
   const size_t e4 = elems >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < e4; i += (size_t)gridDim.x * blockDim.x) {
     const float* p = part + (i << 2);
     float4 acc = zero4();
     int s = 0;
-    for (; s + 8 <= n_slices; s += 8) {
-      float4 v[8];
+    for (; s + 16 <= n_slices; s += 16) {
+      float4 v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld4(p + (size_t)(s + u) * elems);
+      for (int u = 0; u < 16; ++u) v[u] = ld4(p + (size_t)(s + u) * elems);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+      for (int u = 0; u < 16; ++u) acc = add4(acc, v[u]);
+    }
+    for (; s + 4 <= n_slices; s += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ld4(p + (size_t)(s + u) * elems);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = add4(acc, v[u]);
     }
     for (; s < n_slices; ++s) acc = add4(acc, ld4(p + (size_t)s * elems));
     const size_t e = i << 2;

@@ -15,6 +15,10 @@ import re
 import sys
 
 
+# rocprof kernel names -> the family names of bench.py's event trace (one trace id per call site, whichever kernel serves it)
+FAMILY_ALIAS = {"k_gemm_tn_bx": "k_gemm_tn", "k_gemm_bxp": "k_gemm_panel", "k_gemm_bx": "k_gemm_panel", "k_gemm_wres": "k_gemm_panel"}
+
+
 def short(name):
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
@@ -45,6 +49,7 @@ def main():
     fam = collections.defaultdict(lambda: [0, 0.0])           # bench.py's kernel-family names (template args dropped)
     for k, v in out.items():
         base = re.sub(r"<.*$", "", k)
+        base = FAMILY_ALIAS.get(base, base)
         fam[base][0] += v["launches"]
         fam[base][1] += v["traffic_bytes_per_launch"] * v["launches"]
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else None        # encoder steps the profiled process executed
