@@ -406,3 +406,52 @@ def test_training_step_with_device_subsample_gpu():
     _, out3, g3 = run(edge_ids=ids)
     assert_close(out3, out1, 2e-5, 2e-6, "device vs host subsample: target embeddings")
     assert_close(g3, g1, 1e-4, 1e-4 * float(g1.abs().max()), "device vs host subsample: d ent_embeds")
+
+
+# ---- split-operand GEMMs (csrc/gemm_bx.hpp, gemm_tn_bx.hpp): fp32 products as six bf16 MFMA products -------------------------
+def _wide(shape, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g) * torch.exp(3.0 * torch.rand(shape, generator=g) - 1.5) * scale
+    return x.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,trans_b", [
+    (20000, 200, 600, True),      # input gates: packed weights, 5 column groups
+    (20000, 600, 200, False),     # dx: one group of 7 tiles, 38 slabs
+    (16500, 200, 7128, True),     # score matrix against all ICEWS entities: weights beyond a scratch slot -> in-block split
+    (17000, 64, 40, False),       # narrow output (2 tiles), short K
+    (33333, 208, 132, True),      # ragged row tile, 5 tiles
+    (16384, 24, 36, False),       # K not a multiple of 16 (one and a half slabs)
+])
+def test_split_operand_gemm_vs_fp64(M, K, N, trans_b):
+    """The error of the split-operand product against fp64 stays at the level of ONE fp32 rounding per product (the fp32 MFMA
+    kernels measure 4e-7 of sum |a||b| on the same data, tools/bx_probe.hip); bar 1e-6."""
+    be = TB.get_backend()
+    a = _wide((M, K), 11, 1.0)
+    b = _wide((N, K) if trans_b else (K, N), 12, 0.2)
+    out = be.linear(a, b, trans_b)
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (1400,))]).cuda()
+    bd = b.double().t() if trans_b else b.double()
+    ref = a[rows].double() @ bd
+    sabs = a[rows].double().abs() @ bd.abs()
+    err = ((out[rows].double() - ref).abs() / sabs.clamp_min(1e-300)).max().item()
+    assert err < 1e-6, "split-operand GEMM %dx%dx%d: error %.3e of sum|a||b|" % (M, K, N, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Ka,Nb", [(58003, 600, 200), (20000, 200, 200), (17001, 600, 136), (16400, 208, 164), (30000, 72, 200)])
+def test_split_operand_weight_gradient_vs_fp64(M, Ka, Nb):
+    """out = a^T . b over M rows (k_gemm_tn_bx): ragged last slab, ragged last row block of Ka, 5 / 6 / 7 column tiles."""
+    be = TB.get_backend()
+    a = _wide((M, Ka), 21, 1.0)
+    b = _wide((M, Nb), 22, 1.0)
+    out = be.linear_tn(a, b)
+    torch.cuda.synchronize()
+    ref = a.double().t() @ b.double()
+    sabs = a.double().abs().t() @ b.double().abs()
+    err = ((out.double() - ref).abs() / sabs).max().item()
+    assert err < 2e-7, "split-operand weight gradient %d x (%d, %d): error %.3e of sum|a||b|" % (M, Ka, Nb, err)
+    out2 = be.linear_tn(a, b)
+    assert torch.equal(out, out2), "weight gradient not bitwise repeatable"
