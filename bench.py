@@ -521,7 +521,8 @@ def main():
     if rank == 0 and world == 1 and not sharded and MFMA_MODE == "bf16x3" and not a.no_fp32_mfma_compare:
         # the same step with every product on the fp32 MFMA kernels, in a child process (the switch is read once per process)
         import subprocess
-        env = dict(os.environ, TEMP_MFMA="f32")
+        env = {k: v for k, v in os.environ.items() if k not in ("TEMP_BENCH_FORCE_DIST", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+        env["TEMP_MFMA"] = "f32"                    # a plain single-process run
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", str(a.warmup), "--workload", a.workload,
                "--encoder", a.encoder, "--train-loop-steps", "0", "--trace-steps", "0", "--no-cpu-baseline", "--no-fp32-mfma-compare"]
         if a.with_loss:
