@@ -7,6 +7,7 @@
 // LPR*16-byte read.  The per-relation block-diagonal weight row is read from LDS when the whole
 // table fits in 64 KB (GDELT: 40 rows x 1600 B), else through L2.  No atomics: segments that span
 // several chunks go through ordered partial slots + a fix-up pass, so results are deterministic.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace temp {
@@ -130,6 +131,149 @@ __global__ void __launch_bounds__(1024) k_rgcn_agg(TempEdgeView v, const float* 
       if (MODE == MODE_FWD) { const float nn = nnorm[seg]; acc = scale4(acc, nn * nn); }
       float* dst = (slot < 0) ? out + (size_t)seg * D + f : partial + (size_t)slot * D + f;
       st4(dst, acc);
+    }
+  }
+}
+
+// ---- wide rows (128 < D <= 256: one edge per wave pass) --------------------------------------------------------------------
+// The kernels above spend ~45 instructions per edge (PMC / ISA count: the S-gdelt launches are bound by instruction ISSUE, not by
+// the L2 gathers): lane permutes for the edge's ids, zero-fill moves, exec-mask bookkeeping of the `ok` branches, 64-bit vector
+// address arithmetic.  With one edge per pass every per-edge quantity is wave-uniform, so it lives in SCALAR registers here:
+// v_readlane of the pre-loaded ids, scalar row base + one lane offset for the gather (no vector address math), scalar loop
+// control, no per-edge branches (full groups of four, then a scalar tail).  ~20 vector instructions per edge.
+template <int S, int MODE>
+__global__ void __launch_bounds__(1024, 8) k_rgcn_agg_s(TempEdgeView v, const float* __restrict__ feat, int ldf,
+                                                     const int32_t* __restrict__ feat_ids, const float* __restrict__ W, int n_rel_rows,
+                                                     const float* __restrict__ nnorm, int D, float* __restrict__ out,
+                                                     float* __restrict__ partial) {
+  extern __shared__ float4 Ws4[];
+  const int D4 = D >> 2;
+  stage_weights<S>(Ws4, W, n_rel_rows, D4);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const int f = lane << 2;
+  const bool active = lane < D4;
+  ItemRange it = xcd_items(v.n_chunks, wpb);
+  for (int c = it.beg + wave; c < it.end; c += it.stride) {
+    const int seg = __builtin_amdgcn_readfirstlane(v.chunk_seg[c]), beg = __builtin_amdgcn_readfirstlane(v.chunk_beg[c]);
+    const int cnt = __builtin_amdgcn_readfirstlane(v.chunk_end[c]) - beg, slot = __builtin_amdgcn_readfirstlane(v.chunk_slot[c]);
+    int a_l = 0, b_l = 0;
+    float s_l = 1.f;
+    if (lane < cnt) {
+      a_l = v.a[beg + lane];
+      b_l = v.b[beg + lane];
+      if (MODE == MODE_DX) { const float nn = nnorm[a_l]; s_l = nn * nn; }
+      if (feat_ids) a_l = feat_ids[a_l];
+    }
+    if (!active) continue;                                     // (lanes past the row keep out of the loads; readlane ignores exec)
+    float4 acc = zero4();
+    const float4* wl = Ws4 + lane;
+    auto edge = [&](int e, float4& x, int& rel, float& sc) {
+      const int row = __builtin_amdgcn_readlane(a_l, e);
+      rel = __builtin_amdgcn_readlane(b_l, e);
+      sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_l), e));
+      x = ld4(feat + (size_t)row * ldf + f);
+    };
+    auto mac = [&](const float4 x, int rel, float sc) {
+      float4 w[S];
+#pragma unroll
+      for (int j = 0; j < S; ++j) w[j] = wl[(rel * S + j) * D4];
+      block_mac<S, MODE>(acc, x, w, sc);
+    };
+    int e = 0;
+    for (; e + 4 <= cnt; e += 4) {
+      float4 x0, x1, x2, x3;
+      int r0, r1, r2, r3;
+      float c0, c1, c2, c3;
+      edge(e, x0, r0, c0); edge(e + 1, x1, r1, c1); edge(e + 2, x2, r2, c2); edge(e + 3, x3, r3, c3);
+      mac(x0, r0, c0); mac(x1, r1, c1); mac(x2, r2, c2); mac(x3, r3, c3);
+    }
+    for (; e < cnt; ++e) {
+      float4 x0;
+      int r0;
+      float c0;
+      edge(e, x0, r0, c0);
+      mac(x0, r0, c0);
+    }
+    if (MODE == MODE_FWD) { const float nn = nnorm[seg]; acc = scale4(acc, nn * nn); }
+    float* dst = (slot < 0) ? out + (size_t)seg * D + f : partial + (size_t)slot * D + f;
+    st4(dst, acc);
+  }
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* __restrict__ x, const int32_t* __restrict__ x_ids,
+                                                   const float* __restrict__ dz, const float* __restrict__ nnorm, int D,
+                                                   float* __restrict__ dW, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+  const int f = lane << 2;
+  const bool active = lane < (D >> 2);
+  const int wrow = D * S;
+  ItemRange it = xcd_items(v.n_chunks, wpb);
+  for (int c = it.beg + wave; c < it.end; c += it.stride) {
+    const int seg = __builtin_amdgcn_readfirstlane(v.chunk_seg[c]), cbeg = __builtin_amdgcn_readfirstlane(v.chunk_beg[c]);
+    const int cend = __builtin_amdgcn_readfirstlane(v.chunk_end[c]), slot = __builtin_amdgcn_readfirstlane(v.chunk_slot[c]);
+    float4 acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = zero4();
+    for (int beg = cbeg; beg < cend; beg += 64) {             // a relation chunk holds up to TEMP_CHUNK_REL edges
+      const int cnt = min(64, cend - beg);
+      int a_l = 0, b_l = 0;
+      float s_l = 0.f;
+      if (lane < cnt) {
+        a_l = v.a[beg + lane];
+        if (x_ids) a_l = x_ids[a_l];                          // x is a table, the node's row is x[x_ids[node]]
+        b_l = v.b[beg + lane];
+        const float nn = nnorm[b_l];
+        s_l = nn * nn;
+      }
+      if (!active) continue;
+      auto edge = [&](int e, float4& xx, float4& g) {
+        const int src = __builtin_amdgcn_readlane(a_l, e), dst = __builtin_amdgcn_readlane(b_l, e);
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_l), e));
+        xx = ld4(x + (size_t)src * D + f);
+        g = scale4(ld4(dz + (size_t)dst * D + f), sc);
+      };
+      auto mac = [&](const float4 xx, const float4 g) {
+        if (S == 1) {
+          acc[0].x = fmaf(xx.x, g.x, acc[0].x);
+          acc[0].y = fmaf(xx.y, g.y, acc[0].y);
+          acc[0].z = fmaf(xx.z, g.z, acc[0].z);
+          acc[0].w = fmaf(xx.w, g.w, acc[0].w);
+        } else if (S == 2) {
+          acc[0].x = fmaf(xx.x, g.x, acc[0].x);  // blk0 w00
+          acc[0].y = fmaf(xx.x, g.y, acc[0].y);  //      w01
+          acc[0].z = fmaf(xx.y, g.x, acc[0].z);  //      w10
+          acc[0].w = fmaf(xx.y, g.y, acc[0].w);  //      w11
+          acc[1].x = fmaf(xx.z, g.z, acc[1].x);  // blk1
+          acc[1].y = fmaf(xx.z, g.w, acc[1].y);
+          acc[1].z = fmaf(xx.w, g.z, acc[1].z);
+          acc[1].w = fmaf(xx.w, g.w, acc[1].w);
+        } else {
+          acc[0] = fma4(xx.x, g, acc[0]);
+          acc[1] = fma4(xx.y, g, acc[1]);
+          acc[2] = fma4(xx.z, g, acc[2]);
+          acc[3] = fma4(xx.w, g, acc[3]);
+        }
+      };
+      int e = 0;
+      for (; e + 4 <= cnt; e += 4) {
+        float4 x0, x1, x2, x3, g0, g1, g2, g3;
+        edge(e, x0, g0); edge(e + 1, x1, g1); edge(e + 2, x2, g2); edge(e + 3, x3, g3);
+        mac(x0, g0); mac(x1, g1); mac(x2, g2); mac(x3, g3);
+      }
+      for (; e < cnt; ++e) {
+        float4 x0, g0;
+        edge(e, x0, g0);
+        mac(x0, g0);
+      }
+    }
+    if (active) {
+      float* dst = ((slot < 0) ? dW + (size_t)seg * wrow : partial + (size_t)slot * wrow) + f * S;
+#pragma unroll
+      for (int j = 0; j < S; ++j) st4(dst + 4 * j, acc[j]);
     }
   }
 }
@@ -306,6 +450,11 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_generic(TempEdgeView v, const f
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// TEMP_RGCN_SCALAR=0 in the environment keeps the wide-row launches on the permute-based kernels (A/B runs)
+static bool rgcn_scalar_off() {
+  static const int v = [] { const char* e = getenv("TEMP_RGCN_SCALAR"); return (e && e[0] == '0') ? 1 : 0; }();
+  return v != 0;
+}
 static int pick_lpr(int D) {
   int q = D / 4, l = 1;
   while (l < q) l <<= 1;
@@ -333,7 +482,11 @@ static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const 
   if (wbytes <= 65536 && v.n_chunks >= 4096) {
     // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
     const int grid = 512;
-    TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, true>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
+    if (lpr == 64 && !rgcn_scalar_off())
+      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_s<S, MODE>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows,
+                  nnorm, D, out, partial);
+    else
+      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, true>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
                        lpr, out, partial);
   } else {
     int grid = (v.n_chunks + 3) / 4;
@@ -388,7 +541,11 @@ static int run_dw(const TempEdgeView& v, const float* x, const int32_t* x_ids, c
     const int lpr = pick_lpr(d_in);
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
-    if (S == 1) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<1>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, lpr, dW, partial);
+    if (lpr == 64 && !rgcn_scalar_off()) {
+      if (S == 1) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw_s<1>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, dW, partial);
+      else if (S == 2) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw_s<2>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, dW, partial);
+      else TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw_s<4>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, dW, partial);
+    } else if (S == 1) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<1>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, lpr, dW, partial);
     else if (S == 2) TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<2>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, lpr, dW, partial);
     else TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw<4>), dim3(grid), dim3(256), 0, st, v, x, x_ids, dz, nnorm, d_in, lpr, dW, partial);
   } else {
