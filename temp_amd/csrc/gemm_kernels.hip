@@ -306,7 +306,12 @@ static TnCfg tn_cfg(int M, int Ka, int Nb) {
 size_t gemm_tn_workspace(int M, int Ka, int Nb) {
   const TnCfg c0 = tn_cfg(M, Ka, Nb);
   size_t S = (size_t)c0.slices;
-  if (c0.split == 2 && c0.nbb == 1) { const size_t sb = (size_t)tn_bx_slices(M, c0.kab); if (sb > S) S = sb; }   // either kernel fits
+  if (c0.split == 2 && c0.nbb == 1) {                          // any of the kernels fits
+    size_t sb = (size_t)tn_bx_slices(M, c0.kab);
+    if (sb > S) S = sb;
+    sb = (size_t)tn_bx8_slices(M, ceil_div(Ka, 256));
+    if (sb > S) S = sb;
+  }
   return align_up(S * Ka * Nb * sizeof(float), 256) + align_up(S * Ka * sizeof(float), 256);
 }
 
@@ -332,13 +337,15 @@ int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int 
   if (bias_out && !gemm_tn_can_fuse_bias(Nb)) return TEMP_E_UNSUPPORTED;
   const TnCfg c = tn_cfg(M, Ka, Nb);
   const bool use_bx = c.split == 2 && c.nbb == 1 && tn_bx_ok(M, Ka, Nb, lda, ldb);
-  const int S = use_bx ? tn_bx_slices(M, c.kab) : c.slices;
+  const bool bx8 = use_bx && tn_bx8_ok(Ka);
+  const int kab_bx = bx8 ? ceil_div(Ka, 256) : c.kab;
+  const int S = use_bx ? (bx8 ? tn_bx8_slices(M, kab_bx) : tn_bx_slices(M, c.kab)) : c.slices;
   if (ws_bytes < gemm_tn_workspace(M, Ka, Nb) || !ws) return TEMP_E_WORKSPACE;
   int rps = ceil_div(M > 0 ? M : 1, S);
   rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
   float* part = (float*)ws;
   float* bpart = bias_out ? (float*)((char*)ws + align_up((size_t)S * Ka * Nb * sizeof(float), 256)) : nullptr;
-  if (use_bx) launch_tn_bx(M, Ka, Nb, A, lda, B, ldb, rps, c.kab, S, part, bpart, st);
+  if (use_bx) launch_tn_bx(M, Ka, Nb, A, lda, B, ldb, rps, kab_bx, S, part, bpart, st);
   else if (c.nt == 7) launch_tn<7>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
   else if (c.nt == 4) launch_tn<4>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
   else if (c.nt == 2) launch_tn<2>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);

@@ -25,8 +25,9 @@ float time_ms(F f, int iters = 20) {
 }
 
 static void run_case(int M, int Ka, int Nb, bool bias) {
-  const int kab = (Ka + 127) / 128;
-  int S = tn_bx_slices(M, kab);
+  const bool w8 = tn_bx8_ok(Ka);
+  const int kab = w8 ? (Ka + 255) / 256 : (Ka + 127) / 128;
+  int S = w8 ? tn_bx8_slices(M, kab) : tn_bx_slices(M, kab);
   int rps = (M + S - 1) / S; rps = (rps + 15) / 16 * 16;
   float *A, *B, *part, *bpart;
   (void)hipMalloc(&A, (size_t)M * Ka * 4); (void)hipMalloc(&B, (size_t)M * Nb * 4);
@@ -41,22 +42,13 @@ static void run_case(int M, int Ka, int Nb, bool bias) {
   const int nt = (Nb + 31) / 32;
   const int grid = 8 * ((S + 7) / 8) * kab;
   auto run = [&]() {
-    if (nt == 7) hipLaunchKernelGGL((k_gemm_tn_bx<7>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr);
+    if (w8 && nt == 7) hipLaunchKernelGGL((k_gemm_tn_bx8<7>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr);
+    else if (w8 && nt == 5) hipLaunchKernelGGL((k_gemm_tn_bx8<5>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr);
+    else if (nt == 7) hipLaunchKernelGGL((k_gemm_tn_bx<7>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr);
     else if (nt == 6) hipLaunchKernelGGL((k_gemm_tn_bx<6>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr);
     else hipLaunchKernelGGL((k_gemm_tn_bx<5>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr);
   };
   const float t = time_ms(run);
-  if (nt == 7) {
-#define ABL(V) { auto f = [&]() { hipLaunchKernelGGL((k_gemm_tn_bx<7, V>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr); }; printf("  VAR %2d: %.4f ms\n", V, time_ms(f)); }
-    ABL(7) ABL(128)
-    { unsigned long long* dbg; (void)hipMalloc(&dbg, 32 * 8 * grid); (void)hipMemset(dbg, 0, 32 * 8 * grid);
-      hipLaunchKernelGGL((k_gemm_tn_bx<7, 64>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bpart, dbg); (void)hipDeviceSynchronize();
-      std::vector<unsigned long long> h(32 * grid); (void)hipMemcpy(h.data(), dbg, 32 * 8 * grid, hipMemcpyDeviceToHost);
-      unsigned long long r0 = ~0ull, r1 = 0; double dsum = 0; int n = 0; double dmax = 0, dmin = 1e30, cyc = 0;
-      for (int b = 0; b < grid * 8; ++b) if (h[4 * b + 3]) { r0 = std::min(r0, h[4 * b + 1]); r1 = std::max(r1, h[4 * b + 2]); const double d = (h[4 * b + 2] - h[4 * b + 1]) / 100.0; dsum += d; ++n; dmax = std::max(dmax, d); dmin = std::min(dmin, d); cyc += (double)h[4 * b] / h[4 * b + 3]; }
-      printf("  %d active waves: loop start..end spans %.1f us; loop duration mean %.1f min %.1f max %.1f us; %.0f shader cycles / slab\n", n, (r1 - r0) / 100.0, dsum / n, dmin, dmax, cyc / n); }
-    run(); (void)hipDeviceSynchronize();
-  }
   std::vector<float> hp((size_t)S * Ka * Nb), hbp((size_t)S * Ka);
   (void)hipMemcpy(hp.data(), part, hp.size() * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(hbp.data(), bpart, hbp.size() * 4, hipMemcpyDeviceToHost);
@@ -85,5 +77,8 @@ static void run_case(int M, int Ka, int Nb, bool bias) {
 int main() {
   run_case(58000, 600, 200, true);
   run_case(82000, 200, 200, true);
+  run_case(58003, 600, 200, false);
+  run_case(20000, 600, 136, true);
+  run_case(30000, 328, 200, true);
   return 0;
 }
