@@ -141,15 +141,17 @@ __global__ void __launch_bounds__(1024) k_rgcn_agg(TempEdgeView v, const float* 
 // address arithmetic.  With one edge per pass every per-edge quantity is wave-uniform, so it lives in SCALAR registers here:
 // v_readlane of the pre-loaded ids, scalar row base + one lane offset for the gather (no vector address math), scalar loop
 // control, no per-edge branches (full groups of four, then a scalar tail).  ~20 vector instructions per edge.
-template <int S, int MODE>
+template <int S, int MODE, bool W_LDS>
 __global__ void __launch_bounds__(1024, 8) k_rgcn_agg_s(TempEdgeView v, const float* __restrict__ feat, int ldf,
                                                      const int32_t* __restrict__ feat_ids, const float* __restrict__ W, int n_rel_rows,
                                                      const float* __restrict__ nnorm, int D, float* __restrict__ out,
                                                      float* __restrict__ partial) {
   extern __shared__ float4 Ws4[];
   const int D4 = D >> 2;
-  stage_weights<S>(Ws4, W, n_rel_rows, D4);
-  __syncthreads();
+  if (W_LDS) {
+    stage_weights<S>(Ws4, W, n_rel_rows, D4);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int f = lane << 2;
@@ -177,8 +179,14 @@ __global__ void __launch_bounds__(1024, 8) k_rgcn_agg_s(TempEdgeView v, const fl
     };
     auto mac = [&](const float4 x, int rel, float sc) {
       float4 w[S];
+      if (W_LDS) {
 #pragma unroll
-      for (int j = 0; j < S; ++j) w[j] = wl[(rel * S + j) * D4];
+        for (int j = 0; j < S; ++j) w[j] = wl[(rel * S + j) * D4];
+      } else {                                                 // the relation table does not fit LDS: scalar row base, through L2
+        const float* wr = W + (size_t)rel * (D * S) + f * S;
+#pragma unroll
+        for (int j = 0; j < S; ++j) w[j] = ld4(wr + 4 * j);
+      }
       block_mac<S, MODE>(acc, x, w, sc);
     };
     int e = 0;
@@ -483,7 +491,7 @@ static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const 
     // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
     const int grid = 512;
     if (lpr == 64 && !rgcn_scalar_off())
-      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_s<S, MODE>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows,
+      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_s<S, MODE, true>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows,
                   nnorm, D, out, partial);
     else
       TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, true>), dim3(grid), dim3(1024), wbytes, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
@@ -491,7 +499,11 @@ static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const 
   } else {
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
-    TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D, lpr,
+    if (lpr == 64 && MODE == MODE_FWD && !rgcn_scalar_off())      // (measured on the S-hbm shape: the forward gains 3 %, d/dh loses 14 %)
+      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_s<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
+                  out, partial);
+    else
+      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D, lpr,
                        out, partial);
   }
 }

@@ -49,6 +49,11 @@ static void run_case(int M, int Ka, int Nb, bool bias) {
     else hipLaunchKernelGGL((k_gemm_tn_bx<5>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr);
   };
   const float t = time_ms(run);
+  if (w8 && nt == 7 && M == 58000) {
+#define ABL8(V) { auto f = [&]() { hipLaunchKernelGGL((k_gemm_tn_bx8<7, V>), dim3(grid), dim3(TNBX_THREADS), 0, 0, M, Ka, Nb, A, Ka, B, Nb, rps, kab, S, part, bias ? bpart : nullptr); }; printf("  VAR %3d: %.4f ms\n", V, time_ms(f)); }
+    ABL8(1) ABL8(4) ABL8(5) ABL8(7) ABL8(16) ABL8(20) ABL8(23) ABL8(8)
+    run(); (void)hipDeviceSynchronize();
+  }
   std::vector<float> hp((size_t)S * Ka * Nb), hbp((size_t)S * Ka);
   (void)hipMemcpy(hp.data(), part, hp.size() * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(hbp.data(), bpart, hbp.size() * 4, hipMemcpyDeviceToHost);
