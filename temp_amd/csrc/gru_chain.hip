@@ -53,7 +53,7 @@ __host__ __device__ inline ChainGeom chain_geom(int D) {
 #define CH_MAX_STEPS 64      // steps of one panel: its row table, decay factors and step flags are staged in LDS
 // `ms` = the longest panel of the launch (<= CH_MAX_STEPS)
 inline size_t chain_lds_fwd(int D, int ms) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.lda + 2 * CH_SLOTS * g.ldh + (2 * CH_SLOTS + 1) * (size_t)ms) * 4; }
-inline size_t chain_lds_bwd(int D, int ms) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.ldA + 2 * CH_SLOTS * g.ldz + (2 * CH_SLOTS + 1) * (size_t)ms) * 4; }
+inline size_t chain_lds_bwd(int D, int ms) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.ldA + 2 * CH_SLOTS * g.ldz + (2 * CH_SLOTS + 3) * (size_t)ms) * 4; }
 
 // ---- W_hh -> fragment order ---------------------------------------------------------------------------------------
 // forward  piece (tile, q, lane): float4 e -> W_hh[tile*32 + li][8q + 4hh + e]      (gate column x k)
@@ -328,8 +328,10 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
           st4(saved + 3 * plane + o, make_float4(o_hn[0], o_hn[1], o_hn[2], o_hn[3]));
           st4(saved + 4 * plane + o, hd);
         }
-        if (s + 1 < ns) prefetch(s + 1);       // in flight while the matrix waves run position s + 1
         __syncthreads();      // B
+        // issued AFTER the barrier: the 24 loads + table look-ups of a prefetch take ~4 k cycles to issue, which the matrix waves
+        // would otherwise spend waiting at B (measured with s_memtime stamps: 9 % of a position)
+        if (s + 1 < ns) prefetch(s + 1);       // in flight while the matrix waves run position s + 1
       }
     }
     __syncthreads();          // LDS is re-initialised for the next panel
@@ -352,6 +354,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
   int* tabb = (int*)(dpb + CH_SLOTS * ldz);            // [ms][32] the panel's row table
   float* decb = (float*)(tabb + CH_SLOTS * a.max_steps);   // [ms][32]
   int* flagb = (int*)(decb + CH_SLOTS * a.max_steps);  // [ms]
+  int* upb = flagb + a.max_steps;                      // [ms][2] upstream block and its first row of every step
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const size_t plane = a.plane;
 
@@ -359,6 +362,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
     const int rnn_id = a.panel[4 * p], s0 = a.panel[4 * p + 1], ns = a.panel[4 * p + 2];
     const ChainRnn R = a.rnn[rnn_id];
     for (int i = tid; i < CH_SLOTS * ldA; i += blockDim.x) ab[i] = 0.f;          // k padding of the dgh rows
+    if (tid < ns) { upb[2 * tid] = a.sinfo[4 * (size_t)(s0 + tid) + 1]; upb[2 * tid + 1] = a.sinfo[4 * (size_t)(s0 + tid) + 2]; }
     for (int i = tid; i < ns * CH_SLOTS; i += blockDim.x) {
       const int e = a.rows[(size_t)s0 * CH_SLOTS + i];
       tabb[i] = e;
@@ -557,7 +561,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
         const int cur = s & 1;
         // upstream gradient of the step's rows (only the positions whose states are consumed outside the chain -- the
         // target, the last history position -- have one: loaded on demand instead of holding registers for it all the time)
-        const int up_sel = a.sinfo[4 * (size_t)(s0 + s) + 1], up_row0 = a.sinfo[4 * (size_t)(s0 + s) + 2];
+        const int up_sel = upb[2 * s], up_row0 = upb[2 * s + 1];       // (staged in LDS: two dependent global loads per step otherwise)
         const float* upp = up_sel >= 0 ? ups.p[up_sel] : nullptr;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
@@ -590,9 +594,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
           else st4(dgi + row * D + col, dn_pre);
           st4(dgh + b3, dr_pre); st4(dgh + b3 + D, dz_pre); st4(dgh + b3 + 2 * D, dhn);
         }
-        if (s > 0) prefetch(s - 1);            // in flight while the matrix waves run position s
         __syncthreads();      // A
-        __syncthreads();      // B
+        if (s > 0) prefetch(s - 1);            // issued behind the barrier (the matrix waves start at once), in flight while they
+        __syncthreads();      // B             // run position s
       }
     }
     __syncthreads();
