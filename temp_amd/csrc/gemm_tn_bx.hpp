@@ -70,20 +70,22 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx(int M, int Ka, int 
 
   float2 R0[8], R1[8];                                        // the item of slabs s + 1, s + 2 (ring of two; a ring of three
                                                               // spills: measured slower)
-  auto fetch = [&](float2 (&R)[8], int s, auto ragged_c) {
+  // row r of the item of slab s (one 8-byte load per lane)
+  auto fetch_row = [&](float2 (&R)[8], int s, int r, auto ragged_c) {
     constexpr bool RAG = decltype(ragged_c)::value;
-    if constexpr (VAR & 1) { for (int r = 0; r < 8; ++r) R[r] = make_float2(1.f, 2.f); return; }
-    const float* sb = base + (size_t)(mbeg + s * 16) * ld;     // scalar
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if constexpr (RAG) {                                     // rows past the slice: its last row (zeroed at the split for A)
-        const int m = mbeg + s * 16 + oct * 8 + r;
-        const int mc = m < mend ? m : mend - 1;
-        R[r] = *reinterpret_cast<const float2*>(base + (size_t)(mc < 0 ? 0 : mc) * ld + (col_ok ? col : 0));
-      } else {
-        R[r] = *reinterpret_cast<const float2*>((sb + (size_t)r * ld) + voff);      // scalar row base + one lane offset
-      }
+    if constexpr (VAR & 1) { R[r] = make_float2(1.f, 2.f); return; }
+    if constexpr (RAG) {                                       // rows past the slice: its last row (zeroed at the split for A)
+      const int m = mbeg + s * 16 + oct * 8 + r;
+      const int mc = m < mend ? m : mend - 1;
+      R[r] = *reinterpret_cast<const float2*>(base + (size_t)(mc < 0 ? 0 : mc) * ld + (col_ok ? col : 0));
+    } else {
+      const float* sb = base + (size_t)(mbeg + s * 16 + r) * ld;     // scalar row base + one lane offset
+      R[r] = *reinterpret_cast<const float2*>(sb + voff);
     }
+  };
+  auto fetch = [&](float2 (&R)[8], int s, auto ragged_c) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fetch_row(R, s, r, ragged_c);
   };
   bx_u32x4 SH, SM, SL;                                         // the column being split
   // chunk c of the item: c = 0..3 element pairs (rows 2c, 2c+1) of column 0, 4..7 of column 1; after the last pair of a
@@ -133,7 +135,8 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx(int M, int Ka, int 
     // one slab: MFMAs of slab s out of buffer s & 1; the item of slab s + 1 (registers Rc) is split into the other buffer in
     // the MFMA shadows; the item of slab s + 2 is fetched into Rf (= the registers consumed one slab ago)
     auto slab = [&](float2 (&Rc)[8], float2 (&Rf)[8], int s, auto ragged_c) {
-      fetch(Rf, s + 2, ragged_c);                                        // (past the end: clamped re-reads, never used)
+      // the eight row loads of slab s + 2 are issued one by one behind the MFMAs of the even slots (issued in a burst at the top,
+      // by all eight waves at once, they kept the matrix pipe waiting); past the end: clamped re-reads, never used
       const bx_u32x4* ls = &Ls[s & 1][lane];
       const bx_bf16x8 ah = bx_frag(ls[(kt * 3) * 64]), am = bx_frag(ls[(kt * 3 + 1) * 64]), al = bx_frag(ls[(kt * 3 + 2) * 64]);
       const bx_u32x4* bs = ls + 768 + (size_t)t_beg * 192;
@@ -173,6 +176,7 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx(int M, int Ka, int 
                 for (int p = 0; p < 3; ++p) { if constexpr (VAR & 32) wf[(pr + 1) & 1][u][p] = SM; else wf[(pr + 1) & 1][u][p] = bs[(tn * 3 + p) * 64]; }
               }
             }
+            if (!(slot & 1) && (slot >> 1) < 8) fetch_row(Rf, s + 2, slot >> 1, ragged_c);
             if constexpr (!(VAR & 128)) {
               if ((slot & 1) && (slot >> 1) < 8 && stager) chunk(Rc, slot >> 1, (s + 1) & 1, s + 1, ragged_c);
             } else {                                         // late placement: the last 8 MFMAs
@@ -184,6 +188,8 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx(int M, int Ka, int 
           }
         }
       }
+#pragma unroll
+      for (int r = (NTW * 6 + 1) >> 1; r < 8; ++r) fetch_row(Rf, s + 2, r, ragged_c);      // narrow waves: the rest
       if (stager) {
         if constexpr (!(VAR & 128)) {
 #pragma unroll
@@ -285,20 +291,22 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int
 
   float2 R0[8], R1[8];                                        // the item of slabs s + 1, s + 2 (ring of two; a ring of three
                                                               // spills: measured slower)
-  auto fetch = [&](float2 (&R)[8], int s, auto ragged_c) {
+  // row r of the item of slab s (one 8-byte load per lane)
+  auto fetch_row = [&](float2 (&R)[8], int s, int r, auto ragged_c) {
     constexpr bool RAG = decltype(ragged_c)::value;
-    if constexpr (VAR & 1) { for (int r = 0; r < 8; ++r) R[r] = make_float2(1.f, 2.f); return; }
-    const float* sb = base + (size_t)(mbeg + s * 16) * ld;     // scalar
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if constexpr (RAG) {                                     // rows past the slice: its last row (zeroed at the split for A)
-        const int m = mbeg + s * 16 + oct * 8 + r;
-        const int mc = m < mend ? m : mend - 1;
-        R[r] = *reinterpret_cast<const float2*>(base + (size_t)(mc < 0 ? 0 : mc) * ld + (col_ok ? col : 0));
-      } else {
-        R[r] = *reinterpret_cast<const float2*>((sb + (size_t)r * ld) + voff);      // scalar row base + one lane offset
-      }
+    if constexpr (VAR & 1) { R[r] = make_float2(1.f, 2.f); return; }
+    if constexpr (RAG) {                                       // rows past the slice: its last row (zeroed at the split for A)
+      const int m = mbeg + s * 16 + oct * 8 + r;
+      const int mc = m < mend ? m : mend - 1;
+      R[r] = *reinterpret_cast<const float2*>(base + (size_t)(mc < 0 ? 0 : mc) * ld + (col_ok ? col : 0));
+    } else {
+      const float* sb = base + (size_t)(mbeg + s * 16 + r) * ld;     // scalar row base + one lane offset
+      R[r] = *reinterpret_cast<const float2*>(sb + voff);
     }
+  };
+  auto fetch = [&](float2 (&R)[8], int s, auto ragged_c) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fetch_row(R, s, r, ragged_c);
   };
   bx_u32x4 SH, SM, SL;                                         // the column being split
   // chunk c of the item: c = 0..3 element pairs (rows 2c, 2c+1) of column 0, 4..7 of column 1; after the last pair of a
@@ -349,7 +357,8 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int
     // one slab: MFMAs of slab s out of buffer s & 1; the item of slab s + 1 (registers Rc) is split into the other buffer in
     // the MFMA shadows; the item of slab s + 2 is fetched into Rf (= the registers consumed one slab ago)
     auto slab = [&](float2 (&Rc)[8], float2 (&Rf)[8], int s, auto ragged_c) {
-      fetch(Rf, s + 2, ragged_c);                                        // (past the end: clamped re-reads, never used)
+      // the eight row loads of slab s + 2 are issued one by one behind the MFMAs of the even slots (issued in a burst at the top,
+      // by all eight waves at once, they kept the matrix pipe waiting); past the end: clamped re-reads, never used
       const bx_u32x4* ls = &Ls[s & 1][lane];
       const bx_bf16x8 ah = bx_frag(ls[(kt * 3) * 64]), am = bx_frag(ls[(kt * 3 + 1) * 64]), al = bx_frag(ls[(kt * 3 + 2) * 64]);
       const bx_u32x4* bs = ls + 1536;
@@ -390,6 +399,7 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int
                 for (int p = 0; p < 3; ++p) { if constexpr (VAR & 32) wf[(pr + 1) & 1][u][p] = SM; else wf[(pr + 1) & 1][u][p] = bs[(tn * 3 + p) * 64]; }
               }
             }
+            if (!(slot & 1) && (slot >> 1) < 8) fetch_row(Rf, s + 2, slot >> 1, ragged_c);
             if constexpr (!(VAR & 128)) {
               if ((slot & 1) && (slot >> 1) < 8 && stager) chunk(Rc, slot >> 1, (s + 1) & 1, s + 1, ragged_c);
             } else {                                         // late placement: the last 8 MFMAs
@@ -401,6 +411,8 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int
           }
         }
       }
+#pragma unroll
+      for (int r = (NTW * 6 + 1) >> 1; r < 8; ++r) fetch_row(Rf, s + 2, r, ragged_c);      // narrow waves: the rest
       if (stager) {
         if constexpr (!(VAR & 128)) {
 #pragma unroll
