@@ -89,6 +89,19 @@ int temp_host_sample_subset(int64_t n, int64_t k, uint64_t seed, int64_t* out);
  *   seg_ptr[n_rows + 1], order[count of non-negative entries];  returns that count, or -1 on a bad argument. */
 int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, int32_t* seg_ptr, int32_t* order);
 
+/* Track / panel tables of the persistent window-chain kernels (include/temp_amd.h: TempGruChain; replaces the per-position
+ * history bookkeeping of models/DynamicRGCN.py:35-54 for the chain kernels).  Chain c = instances chain_inst[chain_off[c] ..
+ * chain_off[c+1]) in position order; instance i has inst_n[i] rows starting at row inst_h0[i] of the step's row space and uses GRU
+ * inst_rnn[i]; prev_cat[prev_off[i] + r] = row (inside the previous instance of the chain) that row r continues from, or -1
+ * (ignored for the first instance of a chain).  A row inherits the track of its predecessor, otherwise takes the lowest track
+ * no row of its instance inherits; tracks are cut into panels of T.
+ *   pass 1 (panel == NULL): counts[2] = { panels P, steps S };  pass 2: panel[P][4] = { rnn, first step, steps, 0 },
+ *   rows[S][T] = row | (has_prev << 30) or -1, any_prev[S], step_inst[S] = instance of the step (panel-major, position-minor).
+ * Returns 0, 1 = not representable (a chain mixes GRUs, or a panel has more than max_steps steps), 2 = bad argument. */
+int temp_host_chain_tracks(int n_chains, const int64_t* chain_off, const int64_t* chain_inst, const int64_t* inst_n, const int64_t* inst_h0,
+                           const int64_t* inst_rnn, const int64_t* prev_off, const int32_t* prev_cat, int T, int max_steps,
+                           int64_t* counts, int32_t* panel, int32_t* rows, uint8_t* any_prev, int64_t* step_inst);
+
 int temp_host_abi_version(void);
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ SYMBOLS = {
     "temp_host_sample_subset": (ctypes.c_int, [_I64, _I64, ctypes.c_uint64, _P]),
     "temp_host_gather_inverse": (_I64, [_I64, _P, _I64, _P, _P]),
     "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "temp_host_chain_tracks": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P]),
 }
 
 
@@ -172,3 +173,47 @@ def union_plan(meta, node_off, edge_off, n_rel_rows, piece):
     if w < 0:
         raise ValueError("temp_host_union_plan: bad argument")
     return ctl[:w], summary
+
+
+def chain_tracks(chains, inst_n, inst_h0, inst_rnn, prev_idx, tracks, max_steps):
+    """Track / panel tables of the persistent chain kernels (temp_host_chain_tracks).  chains = lists of instance ids in position
+    order; prev_idx[i] = int array (row of the previous instance or -1) or None.
+    -> None when the chains cannot run on the chain kernels, else (panel int32 [P,4], rows int32 [S,tracks], any_prev bool [S],
+       step_inst int64 [S])."""
+    n_inst = len(inst_n)
+    chain_off = np.zeros(len(chains) + 1, np.int64)
+    for c, ch in enumerate(chains):
+        chain_off[c + 1] = chain_off[c] + len(ch)
+    chain_inst = np.asarray([i for ch in chains for i in ch], dtype=np.int64) if chains else np.zeros(1, np.int64)
+    n = np.ascontiguousarray(inst_n, dtype=np.int64)
+    h0 = np.ascontiguousarray(inst_h0, dtype=np.int64)
+    rnn = np.ascontiguousarray(inst_rnn, dtype=np.int64)
+    prev_off = np.zeros(n_inst + 1, np.int64)
+    parts = []
+    for i in range(n_inst):
+        p = prev_idx[i]
+        if p is None or len(p) != n[i]:
+            p = np.full(int(n[i]), -1, np.int32)
+        parts.append(np.asarray(p, dtype=np.int32))
+        prev_off[i + 1] = prev_off[i] + n[i]
+    prev_cat = np.ascontiguousarray(np.concatenate(parts)) if parts and prev_off[-1] > 0 else np.zeros(1, np.int32)
+    counts = np.zeros(2, np.int64)
+    lib = load()
+    args = (len(chains), chain_off.ctypes.data, chain_inst.ctypes.data, n.ctypes.data, h0.ctypes.data, rnn.ctypes.data, prev_off.ctypes.data,
+            prev_cat.ctypes.data, int(tracks), int(max_steps), counts.ctypes.data)
+    rc = lib.temp_host_chain_tracks(*args, None, None, None, None)
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise ValueError("temp_host_chain_tracks: bad argument (code %d)" % rc)
+    P, S = int(counts[0]), int(counts[1])
+    if P == 0:
+        return None
+    panel = np.empty((P, 4), np.int32)
+    rows = np.empty((S, tracks), np.int32)
+    anyp = np.empty(S, np.uint8)
+    sinst = np.empty(S, np.int64)
+    rc = lib.temp_host_chain_tracks(*args, panel.ctypes.data, rows.ctypes.data, anyp.ctypes.data, sinst.ctypes.data)
+    if rc != 0:
+        raise ValueError("temp_host_chain_tracks: code %d on the fill pass" % rc)
+    return panel, rows, anyp.astype(bool), sinst

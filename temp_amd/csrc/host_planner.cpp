@@ -347,4 +347,96 @@ int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, 
   return seg_ptr[n_rows];
 }
 
+// Track / panel tables of the persistent window-chain kernels (GruProgram.chain_plan, temp_amd/gru_chain.py): every row of every
+// instance of a chain gets a TRACK -- it inherits its predecessor's (prev >= 0), otherwise takes the lowest track no row of its
+// instance inherits, new tracks when none is free -- and tracks are cut into panels of `T`; a panel's steps are the positions at
+// which it has a row (panel-major, position-minor).
+int temp_host_chain_tracks(int n_chains, const int64_t* chain_off, const int64_t* chain_inst, const int64_t* inst_n, const int64_t* inst_h0,
+                           const int64_t* inst_rnn, const int64_t* prev_off, const int32_t* prev_cat, int T, int max_steps,
+                           int64_t* counts, int32_t* panel, int32_t* rows, uint8_t* any_prev, int64_t* step_inst) {
+  if (n_chains < 0 || T <= 0 || !counts || (n_chains > 0 && (!chain_off || !chain_inst || !inst_n || !inst_h0 || !inst_rnn || !prev_off)))
+    return 2;
+  const bool fill = panel != nullptr;
+  if (fill && (!rows || !any_prev || !step_inst)) return 2;
+  int64_t P = 0, S = 0;
+  std::vector<int64_t> prev_tr, tr, free_list;
+  std::vector<uint8_t> used;
+  std::vector<int32_t> tab;                       // [K][n_pan * T]
+  for (int c = 0; c < n_chains; ++c) {
+    const int64_t* ch = chain_inst + chain_off[c];
+    const int64_t K = chain_off[c + 1] - chain_off[c];
+    if (K <= 0) continue;
+    const int64_t rnn = inst_rnn[ch[0]];
+    for (int64_t k = 0; k < K; ++k)
+      if (inst_rnn[ch[k]] != rnn) return 1;       // one GRU per chain
+    // pass A: track of every row
+    int64_t n_tracks = 0, total_rows = 0;
+    for (int64_t k = 0; k < K; ++k) total_rows += inst_n[ch[k]];
+    std::vector<int64_t> tracks((size_t)total_rows);
+    std::vector<uint8_t> has_all((size_t)total_rows);
+    int64_t base = 0;
+    prev_tr.clear();
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t i = ch[k], n = inst_n[i];
+      const int32_t* pi = (k > 0 && prev_cat) ? prev_cat + prev_off[i] : nullptr;
+      tr.assign((size_t)n, -1);
+      used.assign((size_t)n_tracks, 0);
+      for (int64_t r = 0; r < n; ++r) {
+        const bool has = pi && pi[r] >= 0;
+        has_all[(size_t)(base + r)] = has ? 1 : 0;
+        if (has) {
+          if ((size_t)pi[r] >= prev_tr.size()) return 2;
+          tr[(size_t)r] = prev_tr[(size_t)pi[r]];
+          used[(size_t)tr[(size_t)r]] = 1;
+        }
+      }
+      const int64_t nt0 = n_tracks;                // tracks that existed before this position: the free ones are reused first,
+      int64_t f = 0;                               // lowest first; rows beyond them open new tracks
+      for (int64_t r = 0; r < n; ++r) {
+        if (tr[(size_t)r] >= 0) continue;
+        while (f < nt0 && used[(size_t)f]) ++f;
+        if (f < nt0) tr[(size_t)r] = f++;
+        else tr[(size_t)r] = n_tracks++;
+      }
+      for (int64_t r = 0; r < n; ++r) tracks[(size_t)(base + r)] = tr[(size_t)r];
+      prev_tr = tr;
+      base += n;
+    }
+    if (n_tracks == 0) continue;
+    const int64_t n_pan = (n_tracks + T - 1) / T;
+    tab.assign((size_t)(K * n_pan * T), -1);
+    base = 0;
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t i = ch[k], n = inst_n[i];
+      for (int64_t r = 0; r < n; ++r)
+        tab[(size_t)(k * n_pan * T + tracks[(size_t)(base + r)])] = (int32_t)((inst_h0[i] + r) | ((int64_t)has_all[(size_t)(base + r)] << 30));
+      base += n;
+    }
+    for (int64_t p = 0; p < n_pan; ++p) {
+      int64_t cnt = 0;
+      const int64_t first = S;
+      for (int64_t k = 0; k < K; ++k) {
+        const int32_t* row = &tab[(size_t)(k * n_pan * T + p * T)];
+        bool act = false, anyp = false;
+        for (int t = 0; t < T; ++t)
+          if (row[t] >= 0) { act = true; if ((row[t] >> 30) & 1) anyp = true; }
+        if (!act) continue;
+        if (fill) {
+          for (int t = 0; t < T; ++t) rows[(size_t)S * T + t] = row[t];
+          any_prev[S] = anyp ? 1 : 0;
+          step_inst[S] = ch[k];
+        }
+        ++S; ++cnt;
+      }
+      if (cnt > max_steps) return 1;
+      if (cnt > 0) {
+        if (fill) { panel[4 * P] = (int32_t)rnn; panel[4 * P + 1] = (int32_t)first; panel[4 * P + 2] = (int32_t)cnt; panel[4 * P + 3] = 0; }
+        ++P;
+      }
+    }
+  }
+  counts[0] = P; counts[1] = S;
+  return 0;
+}
+
 }  // extern "C"

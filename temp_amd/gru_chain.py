@@ -16,7 +16,7 @@ outputs the caller adds (models/BiRRGCN.py:45).
 import numpy as np
 import torch
 
-from . import _lib
+from . import _hostlib, _lib
 from .backend import get_backend
 
 
@@ -88,6 +88,31 @@ class GruProgram:
            dict(panel [P,4], rows [S,32], any_prev [S], step_inst [S])."""
         if getattr(self, "_chain_plan", False) is not False:
             return self._chain_plan
+        self._chain_plan = self._chain_plan_host()
+        return self._chain_plan
+
+    def _chain_plan_host(self):
+        """chain_plan in the C++ planner library (temp_host_chain_tracks); bit-identical to _chain_plan_numpy."""
+        inst = self.inst
+        if not any(it.prev >= 0 and it.n > 0 for it in inst):          # at least one real recurrence step
+            return None
+        chains = []
+        for head, it0 in enumerate(inst):
+            if it0.prev >= 0:
+                continue
+            chain = [head]
+            while inst[chain[-1]].next >= 0:
+                chain.append(inst[chain[-1]].next)
+            chains.append(chain)
+        res = _hostlib.chain_tracks(chains, [it.n for it in inst], [it.h0 for it in inst], [it.rnn for it in inst],
+                                    [getattr(it, "prev_idx", None) if it.prev >= 0 else None for it in inst], _lib.CHAIN_TRACKS, _lib.CHAIN_MAX_STEPS)
+        if res is None:
+            return None
+        panel, rows, anyp, sinst = res
+        return dict(panel=panel, rows=rows, any_prev=anyp, step_inst=sinst)
+
+    def _chain_plan_numpy(self):
+        """The numpy formulation of chain_plan (kept as the cross-check of the planner library, tests/test_chain_cpu.py)."""
         inst = self.inst
         T = _lib.CHAIN_TRACKS
         panel, rows_tab, any_prev, step_inst = [], [], [], []
@@ -154,7 +179,6 @@ class GruProgram:
             pn = pn[pn[:, 2] > 0]
             plan = dict(panel=pn.astype(np.int32), rows=np.concatenate(rows_tab).astype(np.int32),
                         any_prev=np.concatenate(any_prev), step_inst=np.concatenate(step_inst).astype(np.int64))
-        self._chain_plan = plan
         return plan
 
     def chain_tables(self, device, want):

@@ -53,3 +53,19 @@ def test_chain_tables_reproduce_per_position_path(type1, want):
     assert_close(a[1], b[1], 1e-5, 1e-6, "d_x")
     for x, y in zip(a[2], b[2]):
         assert_close(x, y, 1e-4, 1e-5, "GRU parameter gradient")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_chain_tracks_planner_library_matches_numpy(seed):
+    """temp_host_chain_tracks (C++) == GruProgram._chain_plan_numpy, bit for bit: random chains with births, deaths, re-entries
+    and empty positions."""
+    from tests import chain_cases as CC
+    for kw in (dict(n_chain=2, K=6, E=90, lo=20, hi=70), dict(n_chain=3, K=9, E=40, lo=0, hi=40), dict(n_chain=1, K=15, E=300, lo=100, hi=300)):
+        prog, _ = CC.random_program(seed=seed, **kw)
+        a, b = prog._chain_plan_host(), prog._chain_plan_numpy()
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        for k in ("panel", "rows", "any_prev", "step_inst"):
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
+            assert np.array_equal(a[k], b[k]), k
