@@ -863,7 +863,65 @@ def _impute_weights(m):
                 getattr(enc, nm).bias.fill_(b)
 
 
-ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14, G15=gen_G15)
+def gen_G16():
+    """evaluate() of the impute models (models/PostDynamicRGCN.py:101-143, models/PostBiDynamicRGCN.py:126-176): the window loop
+    with the local history stream on the full train graphs, the imputed all-entity matrix (forward_isolated_impute), then the
+    standard filtered ranks (utils/evaluation.py) and classification loss.  Tie bands recorded as for G13."""
+    from models.PostBiDynamicRGCN import ImputeBiDynamicRGCN
+    from models.PostDynamicRGCN import ImputeDynamicRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    for name, cls, module, seed, idx in (("G16_eval_impute_uni", ImputeDynamicRGCN, 'GRRGCN', 711, [14, 8, 2]),
+                                         ("G16_eval_impute_bi", ImputeBiDynamicRGCN, 'BiGRRGCN', 712, [21, 12, 6])):
+        D, B, L = 32, 16, 6
+        args = rh.make_args(module=module, rec_only_last_layer=True, hidden_size=D, embed_size=D, n_bases=B,
+                            train_seq_len=L, test_seq_len=L, batch_size=4, negative_rate=20, impute=True)
+        cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+        model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
+        csum = checksum(model)
+        model['rel_embeds'] = model['rel_embeds'] * G13_REL_SCALE
+        m = cls(args, num_e, num_r, tr, va, te_g)
+        missing = m.load_state_dict(to_ref_state_dict(model), strict=False)
+        assert not missing.unexpected_keys and all("impute_weight" in k for k in missing.missing_keys), missing
+        _impute_weights(m)
+        t_list = [int(times[i]) for i in idx]
+        out = dict(module=module, rec_only=1, D=D, B=B, seed=seed, L=L, te=0, neg=20, t_list=np.array(t_list), impute=1,
+                   param_checksum=csum, rel_scale=G13_REL_SCALE, band=G13_BAND)
+        ev = m.evaluater
+        rec = dict(mode=None, graphs=[])
+        orig_single, orig_perturb, orig_sort = ev.calc_metrics_single_graph, ev.perturb_and_get_rank, ev.sort_and_rank
+
+        def single(*a, **k):
+            rec['graphs'].append(dict(head=[], tail=[]))
+            return orig_single(*a, **k)
+
+        def perturb(*a, **k):
+            rec['mode'] = k.get('mode', a[-1] if a and isinstance(a[-1], str) else 'tail')
+            return orig_perturb(*a, **k)
+
+        def sort_and_rank(score, target):
+            ts = score.gather(1, target.view(-1, 1))
+            d = (score - ts).abs()
+            d.scatter_(1, target.view(-1, 1), float('inf'))
+            rec['graphs'][-1][rec['mode']].append(((d <= G13_BAND) & (score > 1e-30)).sum(1))
+            return orig_sort(score, target)
+
+        ev.calc_metrics_single_graph, ev.perturb_and_get_rank, ev.sort_and_rank = single, perturb, sort_and_rank
+        with torch.no_grad():
+            for split, val in (("val", True), ("test", False)):
+                rec['graphs'] = []
+                ranks, loss = m.evaluate(torch.tensor(t_list), val=val)
+                nclose = torch.cat([torch.cat(g['head'] + g['tail']) for g in rec['graphs']])
+                assert nclose.shape == ranks.shape
+                out["ranks_" + split] = ranks
+                out["nclose_" + split] = nclose
+                out["loss_" + split] = float(loss)
+                print("  %s %s: %d ranks, %.1f%% outside every tie band, mean rank %.1f" %
+                      (name, split, ranks.numel(), 100.0 * (nclose == 0).float().mean().item(), ranks.float().mean().item()))
+        save(name, **out)
+
+
+ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14, G15=gen_G15, G16=gen_G16)
 
 if __name__ == "__main__":
     rh.activate()

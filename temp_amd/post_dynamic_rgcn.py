@@ -29,6 +29,30 @@ def _rows_or_zero(rows, idx_t, n, d, like):
     return like.new_zeros(n, d) if rows is None else TF.gather_rows(rows, idx_t)
 
 
+def _impute_evaluate(self, t_list, val):
+    from .evaluation import EvaluationFilter
+    if not hasattr(self, "evaluater"):
+        self.evaluater = EvaluationFilter(self.args, self.calc_score, self.graph_dict_train, self.graph_dict_val, self.graph_dict_test)
+    graph_dict = self.graph_dict_val if val else self.graph_dict_test
+    dev = self._device()
+    with torch.no_grad():
+        wb = self.prepare(t_list, self.test_seq_len, train=False)
+        out, hist = self.run(wb)
+        ranks, losses = [], []
+        for i, ent_embed in enumerate(out.split(wb.target.sizes)):
+            t = wb.rows[i][-1]
+            g = graph_dict[t]
+            if g.number_of_edges() == 0:
+                continue
+            all_embeds_g = self.get_all_embeds_Gt(ent_embed, g, t, wb.plan, i, hist, wb.hist_loc)
+            index_sample = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(dev)
+            label = torch.ones(index_sample.shape[0], device=dev)
+            ranks.append(self.evaluater.calc_metrics_single_graph(ent_embed, self.rel_embeds, all_embeds_g, index_sample, g, t))
+            losses.append(self.link_classification_loss(ent_embed, self.rel_embeds, index_sample, label))
+    ranks = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
+    return ranks, (float(torch.stack(losses).mean().item()) if losses else float("nan"))
+
+
 class _PostWindowMixin:
     """What the uni- and bidirectional post models share: slicing the local stream out of a batched run and the
     score-level ensemble loss."""
@@ -147,12 +171,19 @@ class ImputeDynamicRGCN(_PostWindowMixin, DynamicRGCN):
         return list(wb.out_loc.split(wb.target.sizes)), list(out.split(wb.target.sizes)), wb, hist
 
     def evaluate(self, t_list, val=True):
-        raise NotImplementedError("evaluate() of the impute / post-ensemble models ranks with utils/post_evaluation.py, outside the "
-                                  "snapshot-encoder path; use encode_post() + get_all_embeds_Gt()")
+        """ImputeDynamicRGCN.evaluate / calc_metrics, models/PostDynamicRGCN.py:101-143 (bidirectional:
+        models/PostBiDynamicRGCN.py:126-176): the window loop with the local history stream on the full train graphs, the
+        IMPUTED all-entity matrix, then the standard filtered ranks (temp_amd.evaluation.EvaluationFilter) and classification
+        loss of the valid (or test) triples of every target timestamp."""
+        return _impute_evaluate(self, t_list, val)
 
 
 class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
     """models/PostDynamicRGCN.py:131-461 minus the frequency MLP (see module docstring)."""
+
+    def evaluate(self, t_list, val=True):
+        raise NotImplementedError("evaluate() of the post-ensemble models mixes local and temporal scores with calc_ensemble_ratio(), which "
+                                  "the reference never defines (utils/post_evaluation.py:7-60); use encode_post() + get_all_embeds_Gt()")
 
     def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plan, b, hist, hist_loc=None):
         """PostDynamicRGCN.get_all_embeds_Gt, models/PostDynamicRGCN.py:160-174 -> (all_loc, all_rec)."""
@@ -280,12 +311,19 @@ class ImputeBiDynamicRGCN(_PostWindowMixin, BiDynamicRGCN):
         return list(wb.out_loc.split(wb.target.sizes)), list(out.split(wb.target.sizes)), wb, hist
 
     def evaluate(self, t_list, val=True):
-        raise NotImplementedError("evaluate() of the impute / post-ensemble models ranks with utils/post_evaluation.py, outside the "
-                                  "snapshot-encoder path; use encode_post() + get_all_embeds_Gt()")
+        """ImputeDynamicRGCN.evaluate / calc_metrics, models/PostDynamicRGCN.py:101-143 (bidirectional:
+        models/PostBiDynamicRGCN.py:126-176): the window loop with the local history stream on the full train graphs, the
+        IMPUTED all-entity matrix, then the standard filtered ranks (temp_amd.evaluation.EvaluationFilter) and classification
+        loss of the valid (or test) triples of every target timestamp."""
+        return _impute_evaluate(self, t_list, val)
 
 
 class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
     """models/PostBiDynamicRGCN.py:170-372 minus the frequency MLP (see module docstring) -- BASELINE config 3's model."""
+
+    def evaluate(self, t_list, val=True):
+        raise NotImplementedError("evaluate() of the post-ensemble models mixes local and temporal scores with calc_ensemble_ratio(), which "
+                                  "the reference never defines (utils/post_evaluation.py:7-60); use encode_post() + get_all_embeds_Gt()")
 
     def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plans, b, hist, hist_loc=None):
         """PostBiDynamicRGCN.get_all_embeds_Gt, models/PostBiDynamicRGCN.py:176-190 -> (all_loc, all_rec)."""

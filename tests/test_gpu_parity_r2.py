@@ -256,6 +256,12 @@ def test_impute_window_golden_gpu(name, batched):
     check_impute_window(name, DEV, batched)
 
 
+@pytest.mark.parametrize("name,batched", [("G16_eval_impute_uni", True), ("G16_eval_impute_bi", True), ("G16_eval_impute_bi", False)])
+def test_impute_evaluate_golden_gpu(name, batched):
+    from tests.window_cases import check_impute_evaluate
+    check_impute_evaluate(name, DEV, batched)
+
+
 def test_post_ensemble_loss_definition_gpu():
     from tests.window_cases import check_post_ensemble_loss
     check_post_ensemble_loss(DEV)

@@ -362,6 +362,14 @@ def test_impute_window_golden(name, batched):
     check_impute_window(name, torch.device("cpu"), batched)
 
 
+@pytest.mark.parametrize("name,batched", [("G16_eval_impute_uni", True), ("G16_eval_impute_uni", False), ("G16_eval_impute_bi", True),
+                                          ("G16_eval_impute_bi", False)])
+def test_impute_evaluate_golden(name, batched):
+    """evaluate() of the impute models (config 3) against the reference's own filtered ranks and loss."""
+    from tests.window_cases import check_impute_evaluate
+    check_impute_evaluate(name, torch.device("cpu"), batched)
+
+
 def test_post_ensemble_loss_definition():
     from tests.window_cases import check_post_ensemble_loss
     check_post_ensemble_loss(torch.device("cpu"))

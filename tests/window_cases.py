@@ -409,6 +409,29 @@ def check_impute_window(name, device, batched=True):
     return m
 
 
+def check_impute_evaluate(name, device, batched=True):
+    """evaluate() of the impute models against the reference's own ranks and loss (G16): exact wherever no competitor sits in the
+    fp32 tie band of the target, within the band population elsewhere (as check_evaluate)."""
+    from temp_amd.post_dynamic_rgcn import ImputeBiDynamicRGCN, ImputeDynamicRGCN
+    z = load(name)
+    bi = str(z["module"]).startswith("Bi")
+    m = build_post_model(z, device, ImputeBiDynamicRGCN if bi else ImputeDynamicRGCN, batched, impute=True)
+    with torch.no_grad():
+        m.rel_embeds.mul_(float(z["rel_scale"]))
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    for split, val in (("val", True), ("test", False)):
+        ranks, loss = m.evaluate(t_list, val=val)
+        want = T(z["ranks_" + split]).long()
+        nclose = T(z["nclose_" + split]).long()
+        assert ranks.shape == want.shape
+        got = ranks.cpu()
+        safe = nclose == 0
+        assert safe.float().mean().item() > 0.75, (name, split)
+        assert torch.equal(got[safe], want[safe]), (name, split, int((got[safe] != want[safe]).sum()))
+        assert bool(((got - want).abs() <= nclose).all()), (name, split)
+        assert abs(loss - float(z["loss_" + split])) < 2e-5 * max(1.0, abs(float(z["loss_" + split])))
+
+
 def check_post_ensemble_loss(device):
     """PostEnsembleBiDynamicRGCN.forward with injected mixing weights: the score-level ensemble loss equals its definition
     (models/PostDynamicRGCN.py:399-406) evaluated with the oracle's scorers on the model's own (local, temporal) embeddings."""
