@@ -921,7 +921,133 @@ def gen_G16():
         save(name, **out)
 
 
-ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14, G15=gen_G15, G16=gen_G16)
+def det_matrix(n, d, c):
+    """Deterministic pseudo-embeddings shared by the generator and the tests (no storage): x[i, j] = 0.6 sin(0.37 i + 1.3 j + c)
+    + 0.4 cos(0.011 i j + 2 c)."""
+    i = torch.arange(n, dtype=torch.float64).view(-1, 1)
+    j = torch.arange(d, dtype=torch.float64).view(1, -1)
+    return (0.6 * torch.sin(0.37 * i + 1.3 * j + c) + 0.4 * torch.cos(0.011 * i * j + 2.0 * c)).float()
+
+
+G17_REL_SCALE = float(os.environ.get('G17_REL_SCALE', '3.0'))
+
+
+def gen_G17():
+    """The post-ensemble evaluation filters (utils/post_evaluation.py): PostEvaluationFilter (embedding-level mix with four
+    weights, lines 7-60) and PostEnsembleEvaluationFilter (score-level mix, lines 63-134), called directly with deterministic
+    (local, temporal) embeddings and per-triple weights on the valid triples of one timestamp of the slice."""
+    from models.DynamicRGCN import DynamicRGCN
+    from utils.post_evaluation import PostEvaluationFilter, PostEnsembleEvaluationFilter
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    D = 16
+    for sf in ("complex", "distmult"):
+        args = rh.make_args(module='GRRGCN', rec_only_last_layer=True, hidden_size=D, embed_size=D, n_bases=8, train_seq_len=4,
+                            test_seq_len=4, score_function=sf)
+        m = DynamicRGCN(args, num_e, num_r, tr, va, te_g)
+        t = int(times[int(os.environ.get('G17_T', '15'))])
+        g = va[t]
+        n_g = g.number_of_nodes()
+        src, dst = g.edges()
+        samples = torch.stack([src, g.edata['type_s'], dst]).transpose(0, 1)
+        P = samples.shape[0]
+        loc, rec = det_matrix(n_g, D, 0.1), det_matrix(n_g, D, 0.7)
+        all_loc, all_rec = det_matrix(num_e, D, 1.3), det_matrix(num_e, D, 2.1)
+        rel = det_matrix(2 * num_r, D, 3.3) * G17_REL_SCALE    # keeps the sigmoid scores spread and unsaturated
+        w = [(0.15 + 0.7 * torch.rand(P, 1, generator=torch.Generator().manual_seed(50 + k))) for k in range(4)]
+        out = dict(score_function=sf, D=D, t=t, P=P, band=G13_BAND, rel_scale=G17_REL_SCALE)
+        for k in range(4):
+            out["w%d" % k] = w[k]
+        for cls_name, cls in (("post", PostEvaluationFilter), ("ens", PostEnsembleEvaluationFilter)):
+            ev = cls(args, m.calc_score, tr, va, te_g)
+            nclose = []
+            orig_sort = ev.sort_and_rank
+
+            def sort_and_rank(score, target):
+                ts = score.gather(1, target.view(-1, 1))
+                dd = (score - ts).abs()
+                dd.scatter_(1, target.view(-1, 1), float('inf'))
+                nclose.append(((dd <= G13_BAND) & (score > 1e-30)).sum(1))
+                return orig_sort(score, target)
+
+            ev.sort_and_rank = sort_and_rank
+            with torch.no_grad():
+                if cls_name == "post":
+                    ranks = ev.calc_metrics_single_graph(loc, rec, rel, all_loc, all_rec, samples, w[0], w[1], w[2], w[3], g, torch.tensor(t))
+                    nc = torch.cat(nclose)                   # recorded tail first, then head; ranks = [head ; tail]
+                    nc = torch.cat([nc[P:], nc[:P]])
+                else:
+                    ranks = ev.calc_metrics_single_graph(loc, rec, rel, all_loc, all_rec, w[0], w[1], samples, g, torch.tensor(t))
+                    nc = torch.cat(nclose)
+                    nc = torch.cat([nc[P:], nc[:P]])
+            assert nc.shape == ranks.shape
+            out["ranks_" + cls_name], out["nclose_" + cls_name] = ranks, nc
+            print("  G17_%s %s: %d ranks, %.1f%% outside every tie band, mean rank %.1f" %
+                  (sf, cls_name, ranks.numel(), 100.0 * (nc == 0).float().mean().item(), ranks.float().mean().item()))
+        save("G17_post_eval_" + sf, **out)
+
+
+def g18_ratio(triples, t, g):
+    """The deterministic stand-in for calc_ensemble_ratio used by G18 (the reference derives the weights from the frequency
+    tables of utils/DropEdge.py, outside the encoder path): per-triple weights as a function of the row index."""
+    i = torch.arange(triples.shape[0], dtype=torch.float32).view(-1, 1)
+    return 0.2 + 0.6 * torch.sin(0.7 * i + 0.1) ** 2, 0.25 + 0.5 * torch.cos(0.3 * i) ** 2
+
+
+def gen_G18():
+    """evaluate() of the score-level post-ensemble models (models/PostDynamicRGCN.py:367-423, models/PostBiDynamicRGCN.py:297-360)
+    with calc_ensemble_ratio replaced by g18_ratio: window loop with the local stream, (local, temporal) all-entity matrices,
+    PostEnsembleEvaluationFilter."""
+    from models.PostBiDynamicRGCN import PostEnsembleBiDynamicRGCN
+    from models.PostDynamicRGCN import PostEnsembleDynamicRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    for name, cls, module, seed, idx in (("G18_eval_post_uni", PostEnsembleDynamicRGCN, 'GRRGCN', 721, [14, 8, 2]),
+                                         ("G18_eval_post_bi", PostEnsembleBiDynamicRGCN, 'BiGRRGCN', 722, [21, 12, 6])):
+        D, B, L = 32, 16, 6
+        args = rh.make_args(module=module, rec_only_last_layer=True, hidden_size=D, embed_size=D, n_bases=B,
+                            train_seq_len=L, test_seq_len=L, batch_size=4, negative_rate=20, post_ensemble=True)
+        cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+        model = O.init_model(cfg, num_e, num_r, len(tr), D, seed=seed)
+        csum = checksum(model)
+        model['rel_embeds'] = model['rel_embeds'] * G13_REL_SCALE
+        m = cls(args, num_e, num_r, tr, va, te_g)
+        missing = m.load_state_dict(to_ref_state_dict(model), strict=False)
+        assert not missing.unexpected_keys and all("_linear" in k for k in missing.missing_keys), missing
+        m.calc_ensemble_ratio = g18_ratio
+        t_list = [int(times[i]) for i in idx]
+        out = dict(module=module, rec_only=1, D=D, B=B, seed=seed, L=L, te=0, neg=20, t_list=np.array(t_list), post_ensemble=1,
+                   param_checksum=csum, rel_scale=G13_REL_SCALE, band=G13_BAND)
+        ev = m.evaluater
+        rec = dict(graphs=[])
+        orig_single, orig_sort = ev.calc_metrics_single_graph, ev.sort_and_rank
+
+        def single(*a, **k):
+            rec['graphs'].append([])
+            return orig_single(*a, **k)
+
+        def sort_and_rank(score, target):
+            ts = score.gather(1, target.view(-1, 1))
+            d = (score - ts).abs()
+            d.scatter_(1, target.view(-1, 1), float('inf'))
+            rec['graphs'][-1].append(((d <= G13_BAND) & (score > 1e-30)).sum(1))
+            return orig_sort(score, target)
+
+        ev.calc_metrics_single_graph, ev.sort_and_rank = single, sort_and_rank
+        with torch.no_grad():
+            for split, val in (("val", True), ("test", False)):
+                rec['graphs'] = []
+                ranks, _ = m.evaluate(torch.tensor(t_list), val=val)
+                # per graph the filter ranks tails first, then heads; ranks = [head ranks ; tail ranks]
+                nclose = torch.cat([torch.cat([g[1], g[0]]) for g in rec['graphs']])
+                assert nclose.shape == ranks.shape
+                out["ranks_" + split], out["nclose_" + split] = ranks, nclose
+                print("  %s %s: %d ranks, %.1f%% outside every tie band, mean rank %.1f" %
+                      (name, split, ranks.numel(), 100.0 * (nclose == 0).float().mean().item(), ranks.float().mean().item()))
+        save(name, **out)
+
+
+ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14, G15=gen_G15, G16=gen_G16, G17=gen_G17, G18=gen_G18)
 
 if __name__ == "__main__":
     rh.activate()

@@ -111,6 +111,95 @@ class EvaluationFilter:
             return torch.cat([out["head"], out["tail"]])
 
 
+def _w_col(w, P, like):
+    """Per-triple mixing weight as a (P, 1) column (the reference passes (P, 1) tensors; scalars and (P,) vectors broadcast)."""
+    w = torch.as_tensor(w, dtype=like.dtype, device=like.device)
+    if w.dim() == 0:
+        return w.view(1, 1).expand(P, 1)
+    return w.reshape(P, 1)
+
+
+class _MixedRankFilter(EvaluationFilter):
+    """Shared part of the two post-ensemble filters: for one corruption mode, the score matrix of the mixed (local, temporal)
+    representation, then the filtered rank (the filter list replaces the reference's -10e6 overwrite, as in the base class)."""
+
+    def _score_matrix(self, known, r, all_embeds, mode, eval_bz):
+        name = getattr(self.args, "score_function", None)
+        P, num_ent = known.shape[0], all_embeds.shape[0]
+        if name in ("distmult", "complex") and num_ent % 4 == 0 and all_embeds.shape[1] % 4 == 0:
+            q = S.bilinear_query(name, known, r, mode).contiguous()
+            return get_backend().linear(q, all_embeds.contiguous(), True)
+        rows = []
+        for a in range(0, P, eval_bz):
+            b = min(P, a + eval_bz)
+            rows.append(self.calc_score(known[a:b], r[a:b], all_embeds, mode="tail") if mode == "tail"
+                        else self.calc_score(all_embeds, r[a:b], known[a:b], mode="head"))
+        return torch.cat(rows)
+
+    def _rank(self, score, mode, samples, graph, time, num_ent, dev):
+        target, ptr, ids = self._mode_inputs(mode, samples, graph, time, num_ent, dev)
+        return get_backend().filtered_rank(_pad4(score), target, ptr, ids)
+
+
+class PostEnsembleEvaluationFilter(_MixedRankFilter):
+    """utils/post_evaluation.py:63-134: SCORE-level ensemble.  score = w * score(local) + (1 - w) * score(temporal), per triple
+    (the reference masks each score matrix before mixing; both masked values are -10e6, so filtering after the mix is the
+    same).  As in the reference, the object-corruption ranks use `weight_subject`, the subject-corruption ranks `weight_object`."""
+
+    def calc_metrics_single_graph(self, ent_embed_local, ent_embed_temporal, rel_enc_mean, all_embeds_g_local, all_embeds_g_temporal,
+                                  weight_subject, weight_object, samples, graph, time, eval_bz=100):
+        with torch.no_grad():
+            dev, num_ent, time, P = all_embeds_g_local.device, all_embeds_g_local.shape[0], int(time), samples.shape[0]
+            if P == 0:
+                return torch.zeros(0, dtype=torch.int64, device=dev)
+            r = rel_enc_mean[samples[:, 1]]
+            out = {}
+            for mode, w in (("head", weight_object), ("tail", weight_subject)):
+                sel = samples[:, 0] if mode == "tail" else samples[:, 2]
+                s_loc = self._score_matrix(ent_embed_local[sel], r, all_embeds_g_local, mode, eval_bz)
+                s_tmp = self._score_matrix(ent_embed_temporal[sel], r, all_embeds_g_temporal, mode, eval_bz)
+                wc = _w_col(w, P, s_loc)
+                out[mode] = self._rank(wc * s_loc + (1 - wc) * s_tmp, mode, samples, graph, time, num_ent, dev)
+            return torch.cat([out["head"], out["tail"]])
+
+
+class PostEvaluationFilter(_MixedRankFilter):
+    """utils/post_evaluation.py:7-60: EMBEDDING-level ensemble with four per-triple weights.  The known entity is mixed as
+    w * local + (1 - w) * temporal; every candidate likewise with the other weight.  distmult / complex are linear in the
+    candidate, so the candidate mix is applied to the two score matrices instead of materialising (P, N_ents, D) candidates;
+    any other scorer takes the reference's literal route."""
+
+    def calc_metrics_single_graph(self, ent_embed_loc, ent_embed_rec, rel_enc_means, all_embeds_g_loc, all_embeds_g_rec, samples,
+                                  weight_subject_query_subject_embed, weight_subject_query_object_embed,
+                                  weight_object_query_subject_embed, weight_object_query_object_embed, graph, time, eval_bz=100):
+        with torch.no_grad():
+            dev, num_ent, time, P = all_embeds_g_loc.device, all_embeds_g_loc.shape[0], int(time), samples.shape[0]
+            if P == 0:
+                return torch.zeros(0, dtype=torch.int64, device=dev)
+            r = rel_enc_means[samples[:, 1]]
+            name = getattr(self.args, "score_function", None)
+            out = {}
+            for mode, w_s, w_o in (("head", weight_subject_query_subject_embed, weight_subject_query_object_embed),
+                                   ("tail", weight_object_query_subject_embed, weight_object_query_object_embed)):
+                ws, wo = _w_col(w_s, P, ent_embed_loc), _w_col(w_o, P, ent_embed_loc)
+                sel = samples[:, 0] if mode == "tail" else samples[:, 2]
+                w_known, w_cand = (ws, wo) if mode == "tail" else (wo, ws)     # tail: subject known; head: object known
+                known = w_known * ent_embed_loc[sel] + (1 - w_known) * ent_embed_rec[sel]
+                if name in ("distmult", "complex"):
+                    score = w_cand * self._score_matrix(known, r, all_embeds_g_loc, mode, eval_bz) \
+                        + (1 - w_cand) * self._score_matrix(known, r, all_embeds_g_rec, mode, eval_bz)
+                else:
+                    rows = []
+                    for a in range(0, P, eval_bz):
+                        b = min(P, a + eval_bz)
+                        cand = w_cand[a:b].unsqueeze(-1) * all_embeds_g_loc.unsqueeze(0) + (1 - w_cand[a:b]).unsqueeze(-1) * all_embeds_g_rec.unsqueeze(0)
+                        rows.append(self.calc_score(known[a:b], r[a:b], cand, mode="tail") if mode == "tail"
+                                    else self.calc_score(cand, r[a:b], known[a:b], mode="head"))
+                    score = torch.cat(rows)
+                out[mode] = self._rank(score, mode, samples, graph, time, num_ent, dev)
+            return torch.cat([out["head"], out["tail"]])
+
+
 def _pad4(score):
     """Score rows padded to a multiple of 4 columns with -inf (sigmoid 0 at ids above every target: never ahead)."""
     n = score.shape[1]

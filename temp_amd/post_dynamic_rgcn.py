@@ -53,6 +53,30 @@ def _impute_evaluate(self, t_list, val):
     return ranks, (float(torch.stack(losses).mean().item()) if losses else float("nan"))
 
 
+def _post_ensemble_evaluate(self, t_list, val):
+    from .evaluation import PostEnsembleEvaluationFilter
+    if not isinstance(getattr(self, "evaluater", None), PostEnsembleEvaluationFilter):
+        self.evaluater = PostEnsembleEvaluationFilter(self.args, self.calc_score, self.graph_dict_train, self.graph_dict_val, self.graph_dict_test)
+    graph_dict = self.graph_dict_val if val else self.graph_dict_test
+    dev = self._device()
+    with torch.no_grad():
+        wb = self.prepare(t_list, self.test_seq_len, train=False)
+        out, hist = self.run(wb)
+        ranks = []
+        for i, (loc, rec) in enumerate(zip(wb.out_loc.split(wb.target.sizes), out.split(wb.target.sizes))):
+            t = wb.rows[i][-1]
+            g = graph_dict[t]
+            if g.number_of_edges() == 0:
+                continue
+            all_loc, all_rec = self.get_all_embeds_Gt(loc, rec, g, t, wb.plan, i, hist, wb.hist_loc)
+            index_sample = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(dev)
+            w_subject, w_object = self.calc_ensemble_ratio(index_sample, t, g)
+            ranks.append(self.evaluater.calc_metrics_single_graph(loc, rec, self.rel_embeds, all_loc, all_rec, w_subject, w_object,
+                                                                  index_sample, g, t))
+    ranks = torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=dev)
+    return ranks, float("nan")
+
+
 class _PostWindowMixin:
     """What the uni- and bidirectional post models share: slicing the local stream out of a batched run and the
     score-level ensemble loss."""
@@ -182,8 +206,12 @@ class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
     """models/PostDynamicRGCN.py:131-461 minus the frequency MLP (see module docstring)."""
 
     def evaluate(self, t_list, val=True):
-        raise NotImplementedError("evaluate() of the post-ensemble models mixes local and temporal scores with calc_ensemble_ratio(), which "
-                                  "the reference never defines (utils/post_evaluation.py:7-60); use encode_post() + get_all_embeds_Gt()")
+        """PostEnsemble(Bi)DynamicRGCN.evaluate / calc_metrics (models/PostDynamicRGCN.py:367-423, models/PostBiDynamicRGCN.py:297-360):
+        window loop with the local stream on the full train graphs, (local, temporal) all-entity matrices, score-level ensemble
+        ranks (PostEnsembleEvaluationFilter).  The mixing weights come from calc_ensemble_ratio(index_sample, t, g), which the
+        caller supplies (the reference derives them from the frequency tables of utils/DropEdge.py).  As in the reference no
+        classification loss is computed (nan)."""
+        return _post_ensemble_evaluate(self, t_list, val)
 
     def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plan, b, hist, hist_loc=None):
         """PostDynamicRGCN.get_all_embeds_Gt, models/PostDynamicRGCN.py:160-174 -> (all_loc, all_rec)."""
@@ -322,8 +350,12 @@ class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
     """models/PostBiDynamicRGCN.py:170-372 minus the frequency MLP (see module docstring) -- BASELINE config 3's model."""
 
     def evaluate(self, t_list, val=True):
-        raise NotImplementedError("evaluate() of the post-ensemble models mixes local and temporal scores with calc_ensemble_ratio(), which "
-                                  "the reference never defines (utils/post_evaluation.py:7-60); use encode_post() + get_all_embeds_Gt()")
+        """PostEnsemble(Bi)DynamicRGCN.evaluate / calc_metrics (models/PostDynamicRGCN.py:367-423, models/PostBiDynamicRGCN.py:297-360):
+        window loop with the local stream on the full train graphs, (local, temporal) all-entity matrices, score-level ensemble
+        ranks (PostEnsembleEvaluationFilter).  The mixing weights come from calc_ensemble_ratio(index_sample, t, g), which the
+        caller supplies (the reference derives them from the frequency tables of utils/DropEdge.py).  As in the reference no
+        classification loss is computed (nan)."""
+        return _post_ensemble_evaluate(self, t_list, val)
 
     def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plans, b, hist, hist_loc=None):
         """PostBiDynamicRGCN.get_all_embeds_Gt, models/PostBiDynamicRGCN.py:176-190 -> (all_loc, all_rec)."""

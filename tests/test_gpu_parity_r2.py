@@ -461,3 +461,15 @@ def test_split_operand_weight_gradient_vs_fp64(M, Ka, Nb):
     assert err < 2e-7, "split-operand weight gradient %d x (%d, %d): error %.3e of sum|a||b|" % (M, Ka, Nb, err)
     out2 = be.linear_tn(a, b)
     assert torch.equal(out, out2), "weight gradient not bitwise repeatable"
+
+
+@pytest.mark.parametrize("name", ["G17_post_eval_complex", "G17_post_eval_distmult"])
+def test_post_evaluation_filters_golden_gpu(name):
+    from tests.window_cases import check_post_eval_filters
+    check_post_eval_filters(name, DEV)
+
+
+@pytest.mark.parametrize("name,batched", [("G18_eval_post_uni", True), ("G18_eval_post_bi", True), ("G18_eval_post_bi", False)])
+def test_post_ensemble_evaluate_golden_gpu(name, batched):
+    from tests.window_cases import check_post_ensemble_evaluate
+    check_post_ensemble_evaluate(name, DEV, batched)

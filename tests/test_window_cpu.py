@@ -373,3 +373,16 @@ def test_impute_evaluate_golden(name, batched):
 def test_post_ensemble_loss_definition():
     from tests.window_cases import check_post_ensemble_loss
     check_post_ensemble_loss(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", ["G17_post_eval_complex", "G17_post_eval_distmult"])
+def test_post_evaluation_filters_golden(name):
+    """utils/post_evaluation.py: embedding-level and score-level ensemble ranking against the reference's own ranks."""
+    from tests.window_cases import check_post_eval_filters
+    check_post_eval_filters(name, torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name,batched", [("G18_eval_post_uni", True), ("G18_eval_post_uni", False), ("G18_eval_post_bi", True), ("G18_eval_post_bi", False)])
+def test_post_ensemble_evaluate_golden(name, batched):
+    from tests.window_cases import check_post_ensemble_evaluate
+    check_post_ensemble_evaluate(name, torch.device("cpu"), batched)

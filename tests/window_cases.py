@@ -432,6 +432,71 @@ def check_impute_evaluate(name, device, batched=True):
         assert abs(loss - float(z["loss_" + split])) < 2e-5 * max(1.0, abs(float(z["loss_" + split])))
 
 
+def det_matrix(n, d, c):
+    """oracle/gen_golden.py:det_matrix (the deterministic pseudo-embeddings of G17)."""
+    i = torch.arange(n, dtype=torch.float64).view(-1, 1)
+    j = torch.arange(d, dtype=torch.float64).view(1, -1)
+    return (0.6 * torch.sin(0.37 * i + 1.3 * j + c) + 0.4 * torch.cos(0.011 * i * j + 2.0 * c)).float()
+
+
+def check_post_eval_filters(name, device):
+    """PostEvaluationFilter / PostEnsembleEvaluationFilter (utils/post_evaluation.py) against the reference's own ranks (G17):
+    exact outside the fp32 tie bands, within the band population inside."""
+    from temp_amd.evaluation import PostEnsembleEvaluationFilter, PostEvaluationFilter
+    z = load(name)
+    s = slice_snapshots()
+    D, t, P = int(z["D"]), int(z["t"]), int(z["P"])
+    args = make_args(module='GRRGCN', rec_only_last_layer=True, embed_size=D, hidden_size=D, n_bases=8, train_seq_len=4, test_seq_len=4,
+                     score_function=str(z["score_function"]))
+    m = DynamicRGCN(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+    g = s["va"][t]
+    samples = torch.from_numpy(np.stack([g.src, g.rel, g.dst], axis=1)).to(device)
+    assert samples.shape[0] == P
+    loc, rec = det_matrix(g.n, D, 0.1).to(device), det_matrix(g.n, D, 0.7).to(device)
+    all_loc, all_rec = det_matrix(s["num_e"], D, 1.3).to(device), det_matrix(s["num_e"], D, 2.1).to(device)
+    rel = (det_matrix(2 * s["num_r"], D, 3.3) * float(z["rel_scale"])).to(device)
+    w = [T(z["w%d" % k]).to(device) for k in range(4)]
+    post = PostEvaluationFilter(args, m.calc_score, s["tr"], s["va"], s["te"])
+    ens = PostEnsembleEvaluationFilter(args, m.calc_score, s["tr"], s["va"], s["te"])
+    got = dict(post=post.calc_metrics_single_graph(loc, rec, rel, all_loc, all_rec, samples, w[0], w[1], w[2], w[3], g, t),
+               ens=ens.calc_metrics_single_graph(loc, rec, rel, all_loc, all_rec, w[0], w[1], samples, g, t))
+    for k, ranks in got.items():
+        want, nclose = T(z["ranks_" + k]).long(), T(z["nclose_" + k]).long()
+        r = ranks.cpu()
+        assert r.shape == want.shape
+        safe = nclose == 0
+        assert safe.float().mean().item() > 0.85, (name, k)
+        assert torch.equal(r[safe], want[safe]), (name, k, int((r[safe] != want[safe]).sum()))
+        assert bool(((r - want).abs() <= nclose).all()), (name, k)
+
+
+def g18_ratio(triples, t, g):
+    """oracle/gen_golden.py:g18_ratio (deterministic stand-in for calc_ensemble_ratio)."""
+    i = torch.arange(triples.shape[0], dtype=torch.float32, device=triples.device).view(-1, 1)
+    return 0.2 + 0.6 * torch.sin(0.7 * i + 0.1) ** 2, 0.25 + 0.5 * torch.cos(0.3 * i) ** 2
+
+
+def check_post_ensemble_evaluate(name, device, batched=True):
+    """evaluate() of the score-level post-ensemble models with an injected calc_ensemble_ratio, against the reference's ranks (G18)."""
+    from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN, PostEnsembleDynamicRGCN
+    z = load(name)
+    bi = str(z["module"]).startswith("Bi")
+    m = build_post_model(z, device, PostEnsembleBiDynamicRGCN if bi else PostEnsembleDynamicRGCN, batched, post_ensemble=True)
+    with torch.no_grad():
+        m.rel_embeds.mul_(float(z["rel_scale"]))
+    m.calc_ensemble_ratio = g18_ratio
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    for split, val in (("val", True), ("test", False)):
+        ranks, _ = m.evaluate(t_list, val=val)
+        want, nclose = T(z["ranks_" + split]).long(), T(z["nclose_" + split]).long()
+        got = ranks.cpu()
+        assert got.shape == want.shape
+        safe = nclose == 0
+        assert safe.float().mean().item() > 0.85, (name, split)
+        assert torch.equal(got[safe], want[safe]), (name, split, int((got[safe] != want[safe]).sum()))
+        assert bool(((got - want).abs() <= nclose).all()), (name, split)
+
+
 def check_post_ensemble_loss(device):
     """PostEnsembleBiDynamicRGCN.forward with injected mixing weights: the score-level ensemble loss equals its definition
     (models/PostDynamicRGCN.py:399-406) evaluated with the oracle's scorers on the model's own (local, temporal) embeddings."""
