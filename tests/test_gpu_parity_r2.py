@@ -68,13 +68,17 @@ def _upstream(sizes, D, seed):
     return [torch.randn(n, D, generator=g) for n in sizes]
 
 
-@pytest.mark.parametrize("workload,n_windows", [("S-gdelt", 3), ("S-icews0515", 3)])
-def test_full_size_windows_vs_oracle_gpu(workload, n_windows):
+@pytest.mark.parametrize("workload,n_windows,dim", [("S-gdelt", 3, None), ("S-icews0515", 3, None), ("S-gdelt", 2, 128), ("S-gdelt", 2, 64)])
+def test_full_size_windows_vs_oracle_gpu(workload, n_windows, dim):
     """BASELINE's headline shape: full windows of the S-gdelt (and the ICEWS05-15-shaped) workload through the batched HIP
-    step (distinct snapshots once, table layer, one GRU chain program) against the oracle (0.3 s per window on the CPU)."""
+    step (distinct snapshots once, table layer, one GRU chain program) against the oracle (0.3 s per window on the CPU).
+    dim = 128 / 64: the reference's shipped grid (embed = n_bases, 1 x 1 blocks): other tile counts of every MFMA kernel, the
+    permute-based edge kernels, the fp32 weight-gradient kernel."""
     import bench
     from temp_amd import synthetic
     w = synthetic.workload(workload, seed=0)
+    if dim is not None:
+        w["D"], w["B"] = dim, dim
     model = bench.build_model(w, DEV)
     targets = sorted(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:n_windows], reverse=True)
     L, D = w["L"], w["D"]
