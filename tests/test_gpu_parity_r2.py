@@ -477,3 +477,26 @@ def test_post_evaluation_filters_golden_gpu(name):
 def test_post_ensemble_evaluate_golden_gpu(name, batched):
     from tests.window_cases import check_post_ensemble_evaluate
     check_post_ensemble_evaluate(name, DEV, batched)
+
+
+def test_rgcn_layer_row_gather_in_large_gemm_gpu():
+    """temp_rgcn_fwd with feature ids at a size that takes the split-operand GEMM (>= 16 K rows): the self-loop product gathers
+    its rows through a_idx inside the kernel; result = the same layer on the explicitly gathered rows.  Nodes without in-edges
+    (row mask) included."""
+    from temp_amd.snapshot import Snapshot
+    be = TB.get_backend()
+    rng = np.random.default_rng(5)
+    n, E, R2, D, B, n_table = 20000, 120000, 40, 200, 100, 700
+    src, dst = rng.integers(0, n, E), rng.integers(0, n - 500, E)          # the last 500 nodes have no in-edges
+    g = Snapshot(n, src, dst, rng.integers(0, R2, E), np.arange(n))
+    dg = g.device_graph(DEV, R2)
+    gen = torch.Generator().manual_seed(3)
+    table = torch.randn(n_table, D, generator=gen).cuda()
+    ids = torch.from_numpy(rng.integers(0, n_table, n).astype(np.int32)).cuda()
+    weight = (torch.randn(R2, B * 4, generator=gen) * 0.3).cuda()
+    loop_w = (torch.randn(D, D, generator=gen) * 0.1).cuda()
+    bias = (torch.randn(D, generator=gen) * 0.1).cuda()
+    got = be.rgcn_fwd(dg, table, ids, weight, loop_w, bias, B, 1)
+    want = be.rgcn_fwd(dg, table[ids.long()].contiguous(), None, weight, loop_w, bias, B, 1)
+    assert_close(got, want, 1e-6, 1e-6, "rgcn layer with gathered rows")
+    assert float(got[-500:].abs().max()) > 0          # isolated nodes still get act(bias)-type rows, identical in both
