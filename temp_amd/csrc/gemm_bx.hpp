@@ -254,22 +254,36 @@ __global__ void __launch_bounds__(BX_THREADS, 2) k_gemm_bx(PanelBatch<Epi> batch
 
   const bool row_ok = row < M;
   const typename Epi::RowCtx rc = epi.row_ctx(row_ok ? row : 0);
+  // Epilogue in groups of up to four tiles: ALL the epilogue's own loads of a group (the addend of the self-loop layer: 16
+  // float4 per lane) are issued before its first store.  `out` may alias the addend, so the compiler cannot hoist a load
+  // above a store itself, and tile by tile every tile paid its own memory round trip (cold inputs: up to 7 x ~2 us per
+  // block).  A lane reads and writes only its own elements, each read before its write.
+  constexpr int EG = 4;
 #pragma unroll
-  for (int t = 0; t < G; ++t) {
-    if (t < t_store) continue;
-    float4 pre[4];
-    bool ok[4];
+  for (int t0e = 0; t0e < G; t0e += EG) {
+    float4 pre[EG][4];
+    bool ok[EG][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = n0 + t * 32 + 8 * q + 4 * hh;
-      ok[q] = row_ok && col < N;
-      pre[q] = epi.pre4(rc, ok[q] ? row : 0, ok[q] ? col : 0);
+    for (int u = 0; u < EG; ++u) {
+      const int t = t0e + u;
+      if (t >= G) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + t * 32 + 8 * q + 4 * hh;
+        ok[u][q] = row_ok && col < N && t >= t_store;
+        pre[u][q] = epi.pre4(rc, ok[u][q] ? row : 0, ok[u][q] ? col : 0);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = n0 + t * 32 + 8 * q + 4 * hh;
-      if constexpr (VAR & 2) { if (acc[t][4 * q] == 12345.678f) epi.fin4(rc, row, col, zero4(), pre[q]); continue; }
-      if (ok[q]) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), pre[q]);
+    for (int u = 0; u < EG; ++u) {
+      const int t = t0e + u;
+      if (t >= G) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + t * 32 + 8 * q + 4 * hh;
+        if constexpr (VAR & 2) { if (acc[t][4 * q] == 12345.678f) epi.fin4(rc, row, col, zero4(), pre[u][q]); continue; }
+        if (ok[u][q]) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), pre[u][q]);
+      }
     }
   }
 }
@@ -480,22 +494,36 @@ __global__ void __launch_bounds__(BX_THREADS, (G <= 4 ? 3 : 2)) k_gemm_bxp(Panel
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   }
   const typename Epi::RowCtx rc = epi.row_ctx(row_ok ? row : 0);
+  // Epilogue in groups of up to four tiles: ALL the epilogue's own loads of a group (the addend of the self-loop layer: 16
+  // float4 per lane) are issued before its first store.  `out` may alias the addend, so the compiler cannot hoist a load
+  // above a store itself, and tile by tile every tile paid its own memory round trip (cold inputs: up to 7 x ~2 us per
+  // block).  A lane reads and writes only its own elements, each read before its write.
+  constexpr int EG = 4;
 #pragma unroll
-  for (int t = 0; t < G; ++t) {
-    if (t < t_store) continue;
-    float4 pre[4];
-    bool ok[4];
+  for (int t0e = 0; t0e < G; t0e += EG) {
+    float4 pre[EG][4];
+    bool ok[EG][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = n0 + t * 32 + 8 * q + 4 * hh;
-      ok[q] = row_ok && col < N;
-      pre[q] = epi.pre4(rc, ok[q] ? row : 0, ok[q] ? col : 0);
+    for (int u = 0; u < EG; ++u) {
+      const int t = t0e + u;
+      if (t >= G) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + t * 32 + 8 * q + 4 * hh;
+        ok[u][q] = row_ok && col < N && t >= t_store;
+        pre[u][q] = epi.pre4(rc, ok[u][q] ? row : 0, ok[u][q] ? col : 0);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = n0 + t * 32 + 8 * q + 4 * hh;
-      if constexpr (VAR & 2) { if (acc[t][4 * q] == 12345.678f) epi.fin4(rc, row, col, zero4(), pre[q]); continue; }
-      if (ok[q]) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), pre[q]);
+    for (int u = 0; u < EG; ++u) {
+      const int t = t0e + u;
+      if (t >= G) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + t * 32 + 8 * q + 4 * hh;
+        if constexpr (VAR & 2) { if (acc[t][4 * q] == 12345.678f) epi.fin4(rc, row, col, zero4(), pre[u][q]); continue; }
+        if (ok[u][q]) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), pre[u][q]);
+      }
     }
   }
 }
