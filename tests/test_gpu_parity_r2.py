@@ -500,3 +500,26 @@ def test_rgcn_layer_row_gather_in_large_gemm_gpu():
     want = be.rgcn_fwd(dg, table[ids.long()].contiguous(), None, weight, loop_w, bias, B, 1)
     assert_close(got, want, 1e-6, 1e-6, "rgcn layer with gathered rows")
     assert float(got[-500:].abs().max()) > 0          # isolated nodes still get act(bias)-type rows, identical in both
+
+
+def test_split_operand_gemm_scratch_slots_per_stream_gpu():
+    """The packed weights of the split-operand GEMM live in one scratch slot PER STREAM (gemm_kernels.hip: bx_scratch): launches
+    issued concurrently on many streams -- more streams than slots, so the last ones take the kernel that splits the weights
+    itself -- each give the result of the same product run alone."""
+    be = TB.get_backend()
+    M, K, N = 20000, 200, 200
+    a = _wide((M, K), 31, 1.0)
+    ws = [_wide((N, K), 40 + i, 0.2) for i in range(11)]
+    alone = [be.linear(a, w, True) for w in ws]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in ws]
+    outs = [None] * len(ws)
+    for rep in range(3):
+        for i, (w, st) in enumerate(zip(ws, streams)):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs[i] = be.linear(a, w, True)
+        torch.cuda.synchronize()
+        for i in range(len(ws)):
+            # (the in-block-split fallback of the streams beyond the slot count sums the same products in the same order)
+            assert torch.equal(outs[i], alone[i]) or float((outs[i] - alone[i]).abs().max()) < 1e-5 * float(alone[i].abs().max()), (rep, i)
