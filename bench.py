@@ -389,7 +389,7 @@ def main():
     # The window batch is static, so the whole forward+backward of a step (~130 launches) is captured
     # once into a HIP graph and replayed: no host launch overhead between the small per-position kernels.
     # The gradient all-reduce stays outside the graph.
-    graph = None
+    graph = graph_grads = None
     if not a.no_graph and not sharded:
         try:
             side = torch.cuda.Stream()
@@ -406,6 +406,7 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # RCCL's watchdog thread polls events meanwhile
                 run().sum().backward()
+            graph_grads = [p.grad for p in params]                  # the tensors every replay writes
             torch.cuda.synchronize()
         except Exception as e:                      # capture is an optimisation only
             print("bench: HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
@@ -416,7 +417,7 @@ def main():
             return step_eager()
         graph.replay()
         if dist is not None:
-            allreduce_gradients(params, world, average=True)
+            allreduce_gradients(params, world, average=True, grads=graph_grads)
 
     for _ in range(a.warmup):
         step()

@@ -46,30 +46,43 @@ class GradBucket:
             self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         return self.flat
 
-    def allreduce(self, world=None, average=True, group=None):
+    def allreduce(self, world=None, average=True, group=None, grads=None):
+        """Few launches whatever the number of parameters: ONE multi-tensor copy of the gradients into the flat buffer, the
+        collective (averaging inside it where the backend can: RCCL), and NO copy back -- each parameter's `.grad` becomes
+        its span of the flat buffer (a later in-place accumulation into `.grad` then lands in the buffer, and the next
+        call's copy of such a span onto itself is skipped).  `grads` (one tensor or None per parameter) replaces the
+        `.grad`s as the source: a replayed HIP graph writes the gradient tensors of its CAPTURE, whatever `.grad` points to."""
         if world is None:
             world = dist.get_world_size(group)
         if world == 1 or not self.params:
             return
         flat = self._buffer()
-        for p, (a, b) in zip(self.params, self.spans):
-            if p.grad is None:
-                flat[a:b].zero_()
-            else:
-                flat[a:b].copy_(p.grad.reshape(-1))
-        dist.all_reduce(flat, group=group)
-        if average:
+        views = [flat[a:b].view_as(p) for p, (a, b) in zip(self.params, self.spans)]
+        src, dst, missing = [], [], []
+        for i, (p, v) in enumerate(zip(self.params, views)):
+            g = p.grad if grads is None else grads[i]
+            if g is None:
+                missing.append(v)
+            elif g.data_ptr() != v.data_ptr() or not g.is_contiguous():
+                src.append(g if g.dtype == flat.dtype else g.to(flat.dtype))
+                dst.append(v)
+        if missing:
+            torch._foreach_zero_(missing)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        fused_avg = average and dist.get_backend(group) == "nccl"
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM, group=group)
+        if average and not fused_avg:
             flat.div_(world)
-        for p, (a, b) in zip(self.params, self.spans):
-            if p.grad is None:
-                p.grad = flat[a:b].view_as(p).clone()
-            else:
-                p.grad.copy_(flat[a:b].view_as(p))
+        for p, v in zip(self.params, views):
+            p.grad = v
 
 
-def allreduce_gradients(params, world=None, average=True, group=None):
+def allreduce_gradients(params, world=None, average=True, group=None, grads=None):
     """One flat bucket for all parameter gradients (about 2.5 M floats at D=200 on ICEWS14); the bucket (layout + buffer) is
     built once per parameter list and kept on its first parameter."""
+    if grads is not None:
+        grads = [g for p, g in zip(params, grads) if p.requires_grad]
     params = [p for p in params if p.requires_grad]
     if not params:
         return
@@ -78,7 +91,7 @@ def allreduce_gradients(params, world=None, average=True, group=None):
     if bucket is None or bucket[0] != key:
         bucket = (key, GradBucket(params))
         params[0]._temp_grad_bucket = bucket
-    bucket[1].allreduce(world, average, group)
+    bucket[1].allreduce(world, average, group, grads)
 
 
 class _AllGatherRows(torch.autograd.Function):

@@ -118,3 +118,55 @@ def test_split_visits_by_edges():
     assert b[0] == 0 and b[-1] == 7 and all(x <= y for x, y in zip(b, b[1:]))
     assert split_visits_by_edges([], 3) == [0, 0, 0, 0]
     assert split_visits_by_edges([5], 2)[-1] == 1
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from temp_amd.dist import allreduce_gradients
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+        g = [torch.full((3, 4), 1.0 + rank), torch.full((5,), 10.0 * (rank + 1)), torch.full((2, 2), -1.0 - rank)]
+        ps[0].grad = g[0].clone()
+        ps[1].grad = g[1].clone() if rank == 0 else None          # rank 1 has no gradient for this parameter: zeros join the sum
+        ps[2].grad = g[2].clone()
+        allreduce_gradients(ps, world, average=True)
+        first = [p.grad.clone() for p in ps]
+        # the gradients now live in the bucket: an in-place accumulation (no zero_grad between two backward passes) must be seen
+        # by the next call, and a parameter whose .grad was replaced must be picked up again
+        ps[0].grad += 1.0 + rank
+        ps[2].grad = torch.full((2, 2), 7.0 * (rank + 1))
+        allreduce_gradients(ps, world, average=False)
+        second = [p.grad.clone() for p in ps]
+        # explicit sources (a replayed graph's capture tensors) win over .grad
+        src = [torch.full((3, 4), 2.0), None, torch.full((2, 2), 3.0 * (rank + 1))]
+        allreduce_gradients(ps, world, average=False, grads=src)
+        third = [p.grad.clone() for p in ps]
+        q.put((rank, [t.numpy() for t in first], [t.numpy() for t in second], [t.numpy() for t in third]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_bucket_semantics():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, first, second, third in results:
+        np.testing.assert_allclose(first[0], np.full((3, 4), 1.5))            # (1 + 2) / 2
+        np.testing.assert_allclose(first[1], np.full((5,), 5.0))              # (10 + 0) / 2
+        np.testing.assert_allclose(first[2], np.full((2, 2), -1.5))
+        np.testing.assert_allclose(second[0], np.full((3, 4), 1.5 + 1 + 1.5 + 2))   # both ranks' (average + own increment), summed
+        np.testing.assert_allclose(second[1], np.full((5,), 10.0))            # the averaged span of both ranks, summed
+        np.testing.assert_allclose(second[2], np.full((2, 2), 21.0))
+        np.testing.assert_allclose(third[0], np.full((3, 4), 4.0))
+        np.testing.assert_allclose(third[1], np.zeros(5))
+        np.testing.assert_allclose(third[2], np.full((2, 2), 9.0))

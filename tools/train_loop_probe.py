@@ -43,6 +43,25 @@ for depth, label in ((2, "prefetch depth 2"), (0, "inline prepare"), (2, "prefet
     dt = time.perf_counter() - t0
     print("%-18s %d steps: %.2f ms/step wall, %.1f M edge visits/s (loss %.4f)" % (label, n, 1e3 * dt / n, edges / dt / 1e6, float(loss)))
 
+if os.environ.get("PROBE_SPLIT"):                # host time of the two halves on their own (no overlap, device drained between)
+    wbs, tp = [], 0.0
+    for b in batches[5:25]:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wbs.append(model.prepare(b, w["L"], True))
+        tp += time.perf_counter() - t0
+    tl = 0.0
+    for wb in wbs:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = model.run_loss(wb)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        tl += time.perf_counter() - t0                 # launch code only: the device runs behind
+    torch.cuda.synchronize()
+    print("host only: prepare %.2f ms/batch, loss + backward + Adam launch code %.2f ms/step" % (1e3 * tp / len(wbs), 1e3 * tl / len(wbs)))
+
 if os.environ.get("PROBE_PROFILE"):
     import cProfile
     import pstats
@@ -57,7 +76,7 @@ if os.environ.get("PROBE_PROFILE"):
         opt.step()
     torch.cuda.synchronize()
     pr.disable()
-    st = pstats.Stats(pr).sort_stats("cumulative")
+    st = pstats.Stats(pr).sort_stats(os.environ.get("PROBE_SORT", "cumulative"))
     st.print_stats(int(os.environ.get("PROBE_TOP", "45")))
     if os.environ.get("PROBE_CALLERS"):
         st.print_callers(os.environ["PROBE_CALLERS"])
