@@ -97,6 +97,8 @@ int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, 
  * no row of its instance inherits; tracks are cut into panels of T.
  *   pass 1 (panel == NULL): counts[2] = { panels P, steps S };  pass 2: panel[P][4] = { rnn, first step, steps, 0 },
  *   rows[S][T] = row | (has_prev << 30) or -1, any_prev[S], step_inst[S] = instance of the step (panel-major, position-minor).
+ *   Pass 1 keeps its tables in thread-local storage; a pass 2 from the same thread with the very same argument pointers (the
+ *   usual size-then-fill sequence, inputs untouched in between) copies them out instead of planning again.
  * Returns 0, 1 = not representable (a chain mixes GRUs, or a panel has more than max_steps steps), 2 = bad argument. */
 int temp_host_chain_tracks(int n_chains, const int64_t* chain_off, const int64_t* chain_inst, const int64_t* inst_n, const int64_t* inst_h0,
                            const int64_t* inst_rnn, const int64_t* prev_off, const int32_t* prev_cat, int T, int max_steps,

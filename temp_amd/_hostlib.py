@@ -175,7 +175,7 @@ def union_plan(meta, node_off, edge_off, n_rel_rows, piece):
     return ctl[:w], summary
 
 
-def chain_tracks(chains, inst_n, inst_h0, inst_rnn, prev_idx, tracks, max_steps):
+def chain_tracks(chains, inst_n, inst_h0, inst_rnn, prev_idx, tracks, max_steps, reuse_sizing_pass=True):
     """Track / panel tables of the persistent chain kernels (temp_host_chain_tracks).  chains = lists of instance ids in position
     order; prev_idx[i] = int array (row of the previous instance or -1) or None.
     -> None when the chains cannot run on the chain kernels, else (panel int32 [P,4], rows int32 [S,tracks], any_prev bool [S],
@@ -213,6 +213,9 @@ def chain_tracks(chains, inst_n, inst_h0, inst_rnn, prev_idx, tracks, max_steps)
     rows = np.empty((S, tracks), np.int32)
     anyp = np.empty(S, np.uint8)
     sinst = np.empty(S, np.int64)
+    if not reuse_sizing_pass:                    # other argument pointers: the library plans again instead of copying pass 1's tables
+        counts2 = np.zeros(2, np.int64)
+        args = args[:-1] + (counts2.ctypes.data,)
     rc = lib.temp_host_chain_tracks(*args, panel.ctypes.data, rows.ctypes.data, anyp.ctypes.data, sinst.ctypes.data)
     if rc != 0:
         raise ValueError("temp_host_chain_tracks: code %d on the fill pass" % rc)

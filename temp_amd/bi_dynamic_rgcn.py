@@ -133,6 +133,9 @@ class BiDynamicRGCN(DynamicRGCN):
     def _chain_want(self, wb):
         return [i for i in (wb.out_inst[0], wb.out_inst[1], wb.hist_inst[0], wb.hist_inst[1]) if i >= 0]
 
+    def _visit_rows_on_device(self):
+        return not self._can_chain()              # the chain program gathers by its own row list (chain_rows, _build_program)
+
     def _build_program(self, wb):
         """Chain program with ONE contiguous row range per direction: x rows are laid out
         [forward history | target | backward history | target (second copy)] and the instances follow the
@@ -145,7 +148,7 @@ class BiDynamicRGCN(DynamicRGCN):
         nb = sum(st.n_rows for st in plan_b.steps)
         nt = tf.n_rows
         total = nf + nb + nt
-        base = wb.visit_rows.cpu().numpy().astype(np.int64) if wb.visit_rows is not None else np.arange(total, dtype=np.int64)
+        base = wb.visit_rows_host.astype(np.int64) if wb.visit_rows_host is not None else np.arange(total, dtype=np.int64)
         assert base.shape[0] == total and tf.row0 == nf + nb
         f_rows = base[:nf]
         b_rows = base[nf:nf + nb]

@@ -147,6 +147,9 @@ class DynamicRGCN(TKG_Module):
         l2 = enc.layer_2
         return (self.use_gru_chain and l2.decay_spec() is None and not enc.use_time_embedding and getattr(l2, "num_layers", 1) == 1)
 
+    def _visit_rows_on_device(self):
+        return True
+
     def _build_program(self, wb):
         inst = []
         for k, st in enumerate(wb.steps):
@@ -208,12 +211,14 @@ class DynamicRGCN(TKG_Module):
 
     def _upload(self, wb, dev):
         wb.program = None
-        wb.visit_rows = None
+        wb.visit_rows = wb.visit_rows_host = None
         if wb.batched:
             if self.dedup_snapshots:
                 wb.g_all, vr, wb.total_rows = concat_steps_dedup(wb.steps)
-                wb.visit_rows = _lib.to_device(vr, dev) if vr is not None else None
-                wb.visit_inv = TF.gather_inverse(vr, int(wb.g_all.n), dev) if vr is not None else None
+                wb.visit_rows_host = vr                  # the device copy + its inverse only where `run` gathers by them
+                on_dev = vr is not None and self._visit_rows_on_device()
+                wb.visit_rows = _lib.to_device(vr, dev) if on_dev else None
+                wb.visit_inv = TF.gather_inverse(vr, int(wb.g_all.n), dev) if on_dev else None
             else:
                 wb.g_all, wb.total_rows = concat_steps(wb.steps)
             wb.ids_all = _lib.to_device(wb.g_all.gids.astype(np.int32), dev)

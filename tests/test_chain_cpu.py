@@ -69,3 +69,18 @@ def test_chain_tracks_planner_library_matches_numpy(seed):
         for k in ("panel", "rows", "any_prev", "step_inst"):
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
             assert np.array_equal(a[k], b[k]), k
+        # the fill pass planning on its own (no tables kept from the sizing pass) gives the same arrays
+        from temp_amd import _hostlib, _lib
+        inst = prog.inst
+        chains = []
+        for head, it0 in enumerate(inst):
+            if it0.prev < 0:
+                chain = [head]
+                while inst[chain[-1]].next >= 0:
+                    chain.append(inst[chain[-1]].next)
+                chains.append(chain)
+        c = _hostlib.chain_tracks(chains, [it.n for it in inst], [it.h0 for it in inst], [it.rnn for it in inst],
+                                  [getattr(it, "prev_idx", None) if it.prev >= 0 else None for it in inst], _lib.CHAIN_TRACKS,
+                                  _lib.CHAIN_MAX_STEPS, reuse_sizing_pass=False)
+        for k, v in zip(("panel", "rows", "any_prev", "step_inst"), c):
+            assert np.array_equal(a[k], v), k
