@@ -77,9 +77,11 @@ def build_model(w, device, encoder="gru"):
 
 def train_loop(model, w, steps):
     """Wall time of a training loop in which EVERY step is a new window batch (what main.py's trainer does): host-side
-    prepare, fresh negative samples (one kernel launch), link-prediction loss, backward, Adam; eager launches.  Reported next
-    to the headline (which replays one resident batch as a HIP graph), never as the headline."""
+    prepare, fresh negative samples (one kernel launch), link-prediction loss, backward, Adam; eager launches.  Timed twice:
+    batches prepared by the background prefetcher (temp_amd.prefetch.BatchPrefetcher, the loop the package documents) and
+    prepared inline.  Reported next to the headline (which replays one resident batch as a HIP graph), never as the headline."""
     from temp_amd import synthetic
+    from temp_amd.prefetch import BatchPrefetcher
     from temp_amd.sampling import CorruptTriples
     if not hasattr(model, "corrupter"):
         model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
@@ -87,22 +89,28 @@ def train_loop(model, w, steps):
     batches = [synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 1000 + r) for r in range(steps + 5)]
     for b in batches:                       # the first visit of a snapshot builds and uploads its cached views: once per run
         model.prepare(b, w["L"], True)
-    edges, t0 = 0, None
-    for i, b in enumerate(batches):
-        if i == 5:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        wb = model.prepare(b, w["L"], True)
-        loss = model.run_loss(wb)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        if i >= 5:
-            edges += wb.n_edge_visits
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return dict(ms_per_step=1e3 * dt / steps, edges_per_s=edges / dt, steps=steps,
-                what="new batch every step: host prepare + negatives + loss + backward + Adam, eager launches (host-bound)")
+
+    def timed(source):
+        edges, t0 = 0, None
+        for i, wb in enumerate(source):
+            if i == 5:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            loss = model.run_loss(wb)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            if i >= 5:
+                edges += wb.n_edge_visits
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return 1e3 * dt / steps, edges / dt
+
+    inline_ms, inline_eps = timed(model.prepare(b, w["L"], True) for b in batches)
+    pre_ms, pre_eps = timed(BatchPrefetcher(model, batches, seq_len=w["L"], depth=2))
+    return dict(ms_per_step=pre_ms, edges_per_s=pre_eps, inline_prepare_ms_per_step=inline_ms, inline_prepare_edges_per_s=inline_eps, steps=steps,
+                what="new batch every step: host prepare (background prefetcher; inline_* = prepared inline) + negatives + loss + backward "
+                     "+ Adam, eager launches (host-bound)")
 
 
 def algorithmic_costs(wb, D, bi, S=2):
