@@ -173,6 +173,19 @@ def check(rc, what):
         raise TempAmdError("%s failed: %s (code %d)" % (what, msg, rc))
 
 
+# Resident, shared device objects (a snapshot's views, the true-set store) are created on first use by whichever thread gets
+# there -- with several prefetch workers, each under its own HIP stream.  Creation is serialised by this lock and `publish()`
+# drains the creating stream BEFORE the object becomes visible, so that any other stream may read it without an event.
+create_lock = threading.RLock()
+
+
+def publish(device):
+    import torch as _torch
+    device = _torch.device(device)
+    if device.type == "cuda":
+        _torch.cuda.current_stream(device).synchronize()
+
+
 _STAGE_BYTES = 32 << 20
 _stage = threading.local()
 

@@ -310,9 +310,10 @@ class DynamicRGCN(TKG_Module):
             return
         from .sampling import TrueSetStore, plan_batch_loss
         dev = self._device()
-        store = getattr(self, "_true_store", None)
-        if store is None or store.device != dev:
-            store = self._true_store = TrueSetStore(self.graph_dict_train, self.num_ents, dev)
+        with _lib.create_lock:
+            store = getattr(self, "_true_store", None)
+            if store is None or store.device != dev:
+                store = self._true_store = TrueSetStore(self.graph_dict_train, self.num_ents, dev)
         sizes = self._target_sizes(wb)
         offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
         wb.loss_plan = plan_batch_loss(store, [r[-1] for r in wb.rows], wb.graphs, offs, self.args.num_pos_facts, self.sample_rng,

@@ -1,42 +1,86 @@
 """Host-side pipeline for training loops: window batches are *prepared* (plan, row maps, union of the cached
-snapshot views, uploads -- temp_amd.dynamic_rgcn.DynamicRGCN.prepare) by a background thread a few steps ahead of
-the GPU, so the ~30 ms of host work per batch overlaps the previous steps instead of preceding each one.
+snapshot views, uploads -- temp_amd.dynamic_rgcn.DynamicRGCN.prepare) by background threads a few steps ahead of
+the GPU, so the host work per batch overlaps the previous steps instead of preceding each one.
 
-    for wb in BatchPrefetcher(model, batches, seq_len=model.train_seq_len):
+    for wb in BatchPrefetcher(model, batches, seq_len=model.train_seq_len, workers=2):
         loss = model.run_loss(wb)
         ...
 
 The reference builds its batched DGL graphs inline at the top of every forward (models/DynamicRGCN.py:76-94);
-this replaces that with a bounded queue.  numpy releases the GIL in the sorting / concatenation calls that
-dominate `prepare`, so one thread is enough.
+this replaces that with a bounded, ordered pipeline.  About half of `prepare` runs inside the C++ planner library with
+the GIL released; the rest shares the GIL with the training loop's launch code, so ONE worker delivers a batch every
+(its own time + the main thread's share of the GIL); a second worker takes that off the critical path.
 """
 import collections
-import queue
 import threading
 
+import numpy as np
 import torch
 
 
 class BatchPrefetcher:
-    """On a GPU the worker prepares under its OWN HIP stream: the (pageable, hence synchronous) uploads and the small device
-    sorts of `prepare` then queue behind each other only, not behind the training step's kernels on the main stream -- on the
-    shared stream every one of the ~100 small copies of a batch would wait for the step in flight.  The consumer's stream waits
-    for the batch's `ready` event; a consumed batch is kept alive until the main stream has passed it, so the caching
-    allocator cannot hand its memory (allocated on the worker's stream) to the next batch while kernels still read it."""
+    """Yields the prepared batches IN ORDER.
 
-    def __init__(self, model, batches, seq_len=None, train=True, depth=2):
+    On a GPU every worker prepares under its OWN HIP stream: the uploads and the small device kernels of `prepare` then
+    queue behind each other only, not behind the training step's kernels on the main stream.  The consumer's stream waits
+    for the batch's `ready` event; a consumed batch is kept alive until the main stream has passed it, so the caching
+    allocator cannot hand its memory (allocated on a worker's stream) to a later batch while kernels still read it.  Shared
+    resident objects created on first use (a snapshot's views, the true-set store) are published only after the creating
+    stream has drained (temp_amd._lib.publish), so another worker's stream may read them without an event.
+
+    workers > 1 (or batch_seeds=True): batch i is prepared with its own random generator, seeded from `model.sample_rng`
+    in batch order when the batch is handed to a worker -- the subsets drawn for a batch, and hence the whole run, do not
+    depend on which worker took it or when.  With one worker and batch_seeds=False the model's generator is used directly,
+    exactly as by an inline `model.prepare`."""
+
+    def __init__(self, model, batches, seq_len=None, train=True, depth=2, workers=1, batch_seeds=None):
         self.model, self.batches, self.train = model, batches, train
         self.seq_len = seq_len if seq_len is not None else model.train_seq_len
-        self.q = queue.Queue(maxsize=max(1, depth))
-        self.thread = None
+        self.workers = max(1, int(workers))
+        self.batch_seeds = (self.workers > 1) if batch_seeds is None else bool(batch_seeds)
+        if self.workers > 1 and not self.batch_seeds:
+            raise ValueError("several workers need per-batch seeds (batch_seeds=True)")
+        self.window = max(1, depth) + self.workers - 1          # batches handed out and not yet consumed
+        self.threads = []
         dev = next(model.parameters()).device
         self.device = dev if dev.type == "cuda" else None
         self._inflight = collections.deque()
 
+    # ---- workers ---------------------------------------------------------------------------------------------
+    def _take(self):
+        """Next (index, batch, seed) in batch order, or None when the source is exhausted / the run is stopping."""
+        with self._src_lock:
+            if self._stop:
+                return None
+            try:
+                t_list = next(self._src)
+            except StopIteration:
+                return None
+            except BaseException as e:                          # an error of the batch source surfaces at this position
+                i = self._n_taken
+                self._n_taken += 1
+                self._stop = True
+                return (i, e, None)
+            i = self._n_taken
+            self._n_taken += 1
+            seed = int(self.model.sample_rng.integers(1 << 62)) if self.batch_seeds else None
+            return (i, t_list, seed)
+
     def _work(self):
-        try:
-            stream = torch.cuda.Stream(self.device) if self.device is not None else None
-            for t_list in self.batches:
+        from .tkg_module import TKG_Module
+        stream = torch.cuda.Stream(self.device) if self.device is not None else None
+        while True:
+            self._slots.acquire()
+            job = self._take()
+            if job is None:
+                self._slots.release()
+                break
+            i, t_list, seed = job
+            try:
+                if isinstance(t_list, BaseException):
+                    raise t_list
+                if seed is not None:
+                    TKG_Module._rng_override.rng = np.random.default_rng(seed)
                 if stream is None:
                     wb = self.model.prepare(t_list, self.seq_len, self.train)
                 else:
@@ -44,11 +88,19 @@ class BatchPrefetcher:
                         wb = self.model.prepare(t_list, self.seq_len, self.train)
                         wb.ready = torch.cuda.Event()
                         wb.ready.record(stream)
-                self.q.put(("ok", wb))
-        except BaseException as e:          # surfaced in the consumer
-            self.q.put(("err", e))
-            return
-        self.q.put(("end", None))
+                res = ("ok", wb)
+            except BaseException as e:                          # surfaced in the consumer, at this batch's position
+                res = ("err", e)
+                with self._src_lock:
+                    self._stop = True
+            finally:
+                TKG_Module._rng_override.rng = None
+            with self._cv:
+                self._done[i] = res
+                self._cv.notify_all()
+        with self._cv:
+            self._live -= 1
+            self._cv.notify_all()
 
     def _retire(self, wb):
         """Called when the consumer is done issuing work for `wb`."""
@@ -60,22 +112,38 @@ class BatchPrefetcher:
         while self._inflight and self._inflight[0][0].query():
             self._inflight.popleft()
 
+    # ---- consumer --------------------------------------------------------------------------------------------
     def __iter__(self):
         import sys
         old_interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(old_interval, 2e-4))        # both threads issue many short calls: hand the GIL over quickly
+        sys.setswitchinterval(min(old_interval, 2e-4))        # all threads issue many short calls: hand the GIL over quickly
         try:
             yield from self._iterate()
         finally:
+            with self._src_lock:
+                self._stop = True
+            for _ in self.threads:                              # wake workers blocked on the window
+                self._slots.release()
             sys.setswitchinterval(old_interval)
 
     def _iterate(self):
-        self.thread = threading.Thread(target=self._work, daemon=True)
-        self.thread.start()
+        self._src = iter(self.batches)
+        self._src_lock = threading.Lock()
+        self._cv = threading.Condition()
+        self._slots = threading.Semaphore(self.window)
+        self._done, self._n_taken, self._stop, self._live = {}, 0, False, self.workers
+        self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.workers)]
+        for th in self.threads:
+            th.start()
+        i = 0
         while True:
-            kind, item = self.q.get()
-            if kind == "end":
-                break
+            with self._cv:
+                while i not in self._done and self._live > 0:
+                    self._cv.wait()
+                if i not in self._done:                         # every worker has ended and batch i was never taken: the end
+                    break
+                kind, item = self._done.pop(i)
+            self._slots.release()
             if kind == "err":
                 raise item
             if getattr(item, "ready", None) is not None:
@@ -83,7 +151,9 @@ class BatchPrefetcher:
             yield item
             self._retire(item)
             item = None
-        self.thread.join()
+            i += 1
+        for th in self.threads:
+            th.join()
         if self.device is not None:
             torch.cuda.current_stream(self.device).synchronize()
         self._inflight.clear()

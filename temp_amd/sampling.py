@@ -139,21 +139,30 @@ class TrueSetStore:
     def snapshot(self, t):
         s = self._snap.get(t)
         if s is None:
-            g, N = self.graphs[t], self.N
-            gid = g.gids.astype(np.int64)
-            src, rel, dst = g.src.astype(np.int64), g.rel.astype(np.int64), g.dst.astype(np.int64)
-            R = int(rel.max()) + 1 if rel.shape[0] else 1
-            pt, ph = src * R + rel, dst * R + rel
-            kt = np.unique(pt * N + gid[dst]) if rel.shape[0] else np.zeros(0, np.int64)
-            kh = np.unique(ph * N + gid[src]) if rel.shape[0] else np.zeros(0, np.int64)
-            base = self._append(np.concatenate([kt % N, kh % N]).astype(np.int32))
-            off_h = base + kt.shape[0]
-            s = self._snap[t] = dict(
-                tail_lo=(base + np.searchsorted(kt, pt * N)).astype(np.int32), tail_hi=(base + np.searchsorted(kt, (pt + 1) * N)).astype(np.int32),
-                head_lo=(off_h + np.searchsorted(kh, ph * N)).astype(np.int32), head_hi=(off_h + np.searchsorted(kh, (ph + 1) * N)).astype(np.int32))
-            # addresses of the per-edge arrays for the host planner (the arrays live as long as the snapshot / this store)
-            s["ptrs"] = np.array([g.src.ctypes.data, g.rel.ctypes.data, g.dst.ctypes.data, g.gids.ctypes.data, s["tail_lo"].ctypes.data,
-                                  s["tail_hi"].ctypes.data, s["head_lo"].ctypes.data, s["head_hi"].ctypes.data], dtype=np.int64)
+            with _lib.create_lock:
+                s = self._snap.get(t)
+                if s is None:
+                    s = self._build_snapshot(t)
+                    _lib.publish(self.device)            # the appended slice has landed before any other stream can be told of it
+                    self._snap[t] = s
+        return s
+
+    def _build_snapshot(self, t):
+        g, N = self.graphs[t], self.N
+        gid = g.gids.astype(np.int64)
+        src, rel, dst = g.src.astype(np.int64), g.rel.astype(np.int64), g.dst.astype(np.int64)
+        R = int(rel.max()) + 1 if rel.shape[0] else 1
+        pt, ph = src * R + rel, dst * R + rel
+        kt = np.unique(pt * N + gid[dst]) if rel.shape[0] else np.zeros(0, np.int64)
+        kh = np.unique(ph * N + gid[src]) if rel.shape[0] else np.zeros(0, np.int64)
+        base = self._append(np.concatenate([kt % N, kh % N]).astype(np.int32))
+        off_h = base + kt.shape[0]
+        s = dict(
+            tail_lo=(base + np.searchsorted(kt, pt * N)).astype(np.int32), tail_hi=(base + np.searchsorted(kt, (pt + 1) * N)).astype(np.int32),
+            head_lo=(off_h + np.searchsorted(kh, ph * N)).astype(np.int32), head_hi=(off_h + np.searchsorted(kh, (ph + 1) * N)).astype(np.int32))
+        # addresses of the per-edge arrays for the host planner (the arrays live as long as the snapshot / this store)
+        s["ptrs"] = np.array([g.src.ctypes.data, g.rel.ctypes.data, g.dst.ctypes.data, g.gids.ctypes.data, s["tail_lo"].ctypes.data,
+                              s["tail_hi"].ctypes.data, s["head_lo"].ctypes.data, s["head_hi"].ctypes.data], dtype=np.int64)
         return s
 
 

@@ -99,57 +99,68 @@ class Snapshot:
         key = ("views", str(device), int(n_rel_rows))
         dv = self._dev.get(key)
         if dv is None:
-            names = [(vn, an) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS] + ["rel_rank", "in_deg", "out_deg", "nnorm"]
-            stored = self.stored_pack(n_rel_rows)
-            if stored is not None:                                 # precomputed in the on-disk store (temp_amd/store.py)
-                packed, sizes_np, n_partial, rel_chunks = stored
-                sizes = [int(x) for x in sizes_np]
-            elif self._views.get(n_rel_rows) is None:
-                # no host-side views cached (a freshly subsampled target graph): all three views + the pack in ONE pass of
-                # the host planner library
-                from . import _hostlib
-                packed, sizes_np, n_partial, rel_chunks = _hostlib.snapshot_pack(self.n, self.src, self.dst, self.rel, self.nnorm, n_rel_rows,
-                                                                                 _lib.CHUNK, _lib.CHUNK_REL)
-                sizes = [int(x) for x in sizes_np]
+            with _lib.create_lock:
+                dv = self._dev.get(key)
+                if dv is None:
+                    dv = self._dev[key] = self._build_device_views(device, n_rel_rows)
+        return dv
+
+    def _build_device_views(self, device, n_rel_rows):
+        names = [(vn, an) for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS] + ["rel_rank", "in_deg", "out_deg", "nnorm"]
+        stored = self.stored_pack(n_rel_rows)
+        if stored is not None:                                 # precomputed in the on-disk store (temp_amd/store.py)
+            packed, sizes_np, n_partial, rel_chunks = stored
+            sizes = [int(x) for x in sizes_np]
+        elif self._views.get(n_rel_rows) is None:
+            # no host-side views cached (a freshly subsampled target graph): all three views + the pack in ONE pass of
+            # the host planner library
+            from . import _hostlib
+            packed, sizes_np, n_partial, rel_chunks = _hostlib.snapshot_pack(self.n, self.src, self.dst, self.rel, self.nnorm, n_rel_rows,
+                                                                             _lib.CHUNK, _lib.CHUNK_REL)
+            sizes = [int(x) for x in sizes_np]
+        else:
+            lv = self.local_views(n_rel_rows)
+            seg = lv["by_rel"]["chunk_seg"].astype(np.int64)
+            first = np.cumsum(lv["rel_chunks"]) - lv["rel_chunks"]
+            arrays = [lv[vn][an] for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS]
+            arrays += [np.arange(seg.shape[0], dtype=np.int64) - first[seg],        # rank of a chunk inside its relation
+                       lv["in_deg"], lv["out_deg"], np.ascontiguousarray(self.nnorm, dtype=np.float32).view(np.int32)]   # float bits ride along
+            sizes = [int(a.shape[0]) for a in arrays]
+            packed = np.concatenate([np.ascontiguousarray(a, dtype=np.int32) for a in arrays]) if sum(sizes) else np.zeros(1, np.int32)
+            n_partial = np.array([lv[vn]["n_partial"] for vn in ("by_dst", "by_src", "by_rel")], dtype=np.int64)
+            rel_chunks = lv["rel_chunks"]
+        buf = self._dev.pop(("adopted", str(device), int(n_rel_rows)), None)      # already resident (SnapshotStore.to_device)
+        if buf is None:
+            buf = _lib.to_device(np.require(packed, requirements=['C', 'W']), device)   # ONE upload per snapshot
+        dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": buf}
+        off = 0
+        for key_, n_ in zip(names, sizes):
+            t = buf[off:off + n_]
+            off += n_
+            if isinstance(key_, tuple):
+                dv[key_[0]][key_[1]] = t
             else:
-                lv = self.local_views(n_rel_rows)
-                seg = lv["by_rel"]["chunk_seg"].astype(np.int64)
-                first = np.cumsum(lv["rel_chunks"]) - lv["rel_chunks"]
-                arrays = [lv[vn][an] for vn in ("by_dst", "by_src", "by_rel") for an in _VIEW_ARRAYS]
-                arrays += [np.arange(seg.shape[0], dtype=np.int64) - first[seg],        # rank of a chunk inside its relation
-                           lv["in_deg"], lv["out_deg"], np.ascontiguousarray(self.nnorm, dtype=np.float32).view(np.int32)]   # float bits ride along
-                sizes = [int(a.shape[0]) for a in arrays]
-                packed = np.concatenate([np.ascontiguousarray(a, dtype=np.int32) for a in arrays]) if sum(sizes) else np.zeros(1, np.int32)
-                n_partial = np.array([lv[vn]["n_partial"] for vn in ("by_dst", "by_src", "by_rel")], dtype=np.int64)
-                rel_chunks = lv["rel_chunks"]
-            buf = self._dev.pop(("adopted", str(device), int(n_rel_rows)), None)      # already resident (SnapshotStore.to_device)
-            if buf is None:
-                buf = _lib.to_device(np.require(packed, requirements=['C', 'W']), device)   # ONE upload per snapshot
-            dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": buf}
-            off = 0
-            for key_, n_ in zip(names, sizes):
-                t = buf[off:off + n_]
-                off += n_
-                if isinstance(key_, tuple):
-                    dv[key_[0]][key_[1]] = t
-                else:
-                    dv[key_] = t
-            dv["nnorm"] = dv["nnorm"].view(torch.float32)
-            offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
-            dv["_meta"] = dict(ptr=int(buf.data_ptr()), off=offs.astype(np.int64), size=np.asarray(sizes, dtype=np.int64),
-                               n_partial=np.asarray(n_partial, dtype=np.int64), rel_chunks=np.asarray(rel_chunks, dtype=np.int64))
-            m = dv["_meta"]                                      # one int64 row for the host planner (temp_host_union_plan)
-            m["row"] = np.concatenate([m["size"], m["off"], [m["ptr"]], m["n_partial"], m["rel_chunks"][:n_rel_rows],
-                                       np.zeros(max(0, n_rel_rows - m["rel_chunks"].shape[0]), np.int64)]).astype(np.int64)
-            self._dev[key] = dv
+                dv[key_] = t
+        dv["nnorm"] = dv["nnorm"].view(torch.float32)
+        offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+        dv["_meta"] = dict(ptr=int(buf.data_ptr()), off=offs.astype(np.int64), size=np.asarray(sizes, dtype=np.int64),
+                           n_partial=np.asarray(n_partial, dtype=np.int64), rel_chunks=np.asarray(rel_chunks, dtype=np.int64))
+        m = dv["_meta"]                                      # one int64 row for the host planner (temp_host_union_plan)
+        m["row"] = np.concatenate([m["size"], m["off"], [m["ptr"]], m["n_partial"], m["rel_chunks"][:n_rel_rows],
+                                   np.zeros(max(0, n_rel_rows - m["rel_chunks"].shape[0]), np.int64)]).astype(np.int64)
+        _lib.publish(device)
         return dv
 
     def device_graph(self, device, n_rel_rows):
         key = (str(device), int(n_rel_rows))
         dg = self._dev.get(key)
         if dg is None:
-            dg = _DeviceGraph(self, device, n_rel_rows)
-            self._dev[key] = dg
+            with _lib.create_lock:
+                dg = self._dev.get(key)
+                if dg is None:
+                    dg = _DeviceGraph(self, device, n_rel_rows)
+                    _lib.publish(device)
+                    self._dev[key] = dg
         return dg
 
     def stored_pack(self, n_rel_rows):
@@ -166,9 +177,14 @@ class Snapshot:
         key = ("eid", str(device))
         t = self._dev.get(key)
         if t is None:
-            eid = np.stack([np.argsort(k, kind="stable") for k in (self.dst, self.src, self.rel)]).astype(np.int32) \
-                if self.number_of_edges() else np.zeros((3, 0), np.int32)
-            t = self._dev[key] = _lib.to_device(eid, device)
+            with _lib.create_lock:
+                t = self._dev.get(key)
+                if t is None:
+                    eid = np.stack([np.argsort(k, kind="stable") for k in (self.dst, self.src, self.rel)]).astype(np.int32) \
+                        if self.number_of_edges() else np.zeros((3, 0), np.int32)
+                    t = _lib.to_device(eid, device)
+                    _lib.publish(device)
+                    self._dev[key] = t
         return t
 
 

@@ -3,6 +3,8 @@
 harness, not part of the hot path; the hooks a harness calls -- training_step, validation_step,
 configure_optimizers -- are kept and need no Lightning import).
 """
+import threading
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -34,6 +36,20 @@ class TKG_Module(nn.Module):
             self.corrupter = CorruptTriples(self.args, graph_dict_train)
             if evaluater_type is not None:
                 self.evaluater = evaluater_type(args, self.calc_score, graph_dict_train, graph_dict_val, graph_dict_test)
+
+    # `sample_rng` draws the training-time edge / positive subsets inside `prepare`.  A prefetch worker that prepares batches
+    # out of order (temp_amd.prefetch.BatchPrefetcher with several workers) installs a generator of its own for the batch it
+    # is working on -- seeded, in batch order, from the model's -- so that a run does not depend on the workers' timing.
+    _rng_override = threading.local()
+
+    @property
+    def sample_rng(self):
+        o = getattr(TKG_Module._rng_override, "rng", None)
+        return o if o is not None else self._sample_rng
+
+    @sample_rng.setter
+    def sample_rng(self, rng):
+        self._sample_rng = rng
 
     def build_model(self):
         raise NotImplementedError

@@ -523,3 +523,38 @@ def test_split_operand_gemm_scratch_slots_per_stream_gpu():
         for i in range(len(ws)):
             # (the in-block-split fallback of the streams beyond the slot count sums the same products in the same order)
             assert torch.equal(outs[i], alone[i]) or float((outs[i] - alone[i]).abs().max()) < 1e-5 * float(alone[i].abs().max()), (rep, i)
+
+
+@pytest.mark.gpu
+def test_prefetch_workers_training_run_reproducible_gpu():
+    """A training run (new batch every step, device subsample, fresh negatives, loss, backward, Adam) with batches prepared by
+    THREE prefetch workers -- first, on cold snapshot caches, so the shared resident objects (snapshot views, edge-id tables,
+    true-set slices) are created under several workers and HIP streams -- gives bit for bit the loss sequence of the run with one
+    worker: per-batch seeds make the draws independent of worker timing, first-use creation is published only after its stream
+    has drained, and every kernel on the path is deterministic."""
+    import bench
+    from temp_amd import synthetic
+    from temp_amd.prefetch import BatchPrefetcher
+    from temp_amd.sampling import CorruptTriples
+    w = synthetic.workload("S-gdelt", seed=3)              # its own snapshot objects: nothing is resident yet
+    steps = 24
+    batches = [synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 50 + r) for r in range(steps)]
+
+    def run(workers):
+        model = bench.build_model(w, DEV)
+        model.sample_rng = np.random.default_rng(2)
+        model.seed_rng = np.random.default_rng(3)
+        model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        for wb in BatchPrefetcher(model, batches, seq_len=w["L"], depth=2, workers=workers, batch_seeds=True):
+            loss = model.run_loss(wb)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        return torch.stack(losses).cpu()
+
+    cold3, warm1, warm2 = run(3), run(1), run(2)
+    assert torch.isfinite(cold3).all()
+    assert torch.equal(cold3, warm1) and torch.equal(warm2, warm1)

@@ -118,6 +118,26 @@ def test_batch_prefetcher_yields_prepared_batches_in_order():
         list(BatchPrefetcher(m, boom(), seq_len=int(z["L"])))
 
 
+def test_batch_prefetcher_workers_same_batches_as_one_worker():
+    """Two workers prepare out of order; the batches come out in order and -- per-batch seeds -- with the same random
+    subsets (target edge subsample, positives) as one worker draws."""
+    from temp_amd.prefetch import BatchPrefetcher
+    from tests.window_cases import build_window_model
+    z = load("G10_bi_grrgcn_rol")
+    batches = [[20, 15, 9], [18, 4], [7], [19, 12], [16, 3, 5], [11]]
+    runs = []
+    for workers in (1, 2, 3):
+        m = build_window_model(z, torch.device("cpu"))
+        m.sample_rng = np.random.default_rng(11)
+        got = list(BatchPrefetcher(m, batches, seq_len=int(z["L"]), depth=1, workers=workers, batch_seeds=True))
+        assert [wb.rows[0][-1] for wb in got] == [b[0] for b in batches]
+        runs.append([(wb.n_edge_visits, [(g.src.tolist(), g.rel.tolist(), g.dst.tolist()) for g in wb.target.graphs],
+                      [t.tolist() for t in wb.loss_plan["triples"]] if wb.loss_plan else None) for wb in got])
+    assert runs[0] == runs[1] == runs[2]
+    with pytest.raises(ValueError):
+        BatchPrefetcher(m, batches, workers=2, batch_seeds=False)
+
+
 def test_device_negative_sampler_filters_true_triples():
     """DeviceCorruptTriples (torch ops on the model's device; here the CPU device) keeps the reference sampler's
     contract: column 0 = the true entity (global id), no sampled candidate forms a true triple of the snapshot."""

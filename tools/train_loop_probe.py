@@ -80,3 +80,20 @@ if os.environ.get("PROBE_PROFILE"):
     st.print_stats(int(os.environ.get("PROBE_TOP", "45")))
     if os.environ.get("PROBE_CALLERS"):
         st.print_callers(os.environ["PROBE_CALLERS"])
+
+if os.environ.get("PROBE_PROFILE_MAIN"):          # the training thread's launch code alone, on prepared batches
+    import cProfile
+    import pstats
+    wbs = [model.prepare(b, w["L"], True) for b in batches[5:25]]
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for wb in wbs:
+        loss = model.run_loss(wb)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr).sort_stats(os.environ.get("PROBE_SORT", "cumulative"))
+    st.print_stats(int(os.environ.get("PROBE_TOP", "45")))
