@@ -199,19 +199,47 @@ def device_subsample(graphs, keeps, seeds, device, n_rel_rows, want_mask=False):
         dv = g.device_views(device, n_rel_rows)
         meta = dv["_meta"]
         child = dv["_buf"].clone()
-        off = {name: int(o) for name, o in zip(_PACK_NAMES, meta["off"])}
         E = g.number_of_edges()
         mask = torch.empty(E, dtype=torch.uint8, device=device) if want_mask else None
-        views = ("by_dst", "by_src", "by_rel")
-        jobs.append(dict(n_nodes=g.n, n_edges=E, keep=int(k), seed=int(seed), parent=dv["_buf"], child=child, eid=g.device_edge_ids(device),
-                         off_a=[off[(v, "a")] for v in views], off_b=[off[(v, "b")] for v in views],
-                         off_chunk_beg=[off[(v, "chunk_beg")] for v in views], off_chunk_end=[off[(v, "chunk_end")] for v in views],
-                         off_chunk_seg=[off[(v, "chunk_seg")] for v in views], n_chunks=[int(dv[v]["chunk_seg"].shape[0]) for v in views],
-                         off_in_deg=off["in_deg"], off_out_deg=off["out_deg"], off_nnorm=off["nnorm"], keep_mask=mask, scratch=scratch[i:i + 1]))
+        static = meta.get("subsample_job")                   # the parent's part of the job: offsets inside its packed buffer
+        if static is None:
+            off = {name: int(o) for name, o in zip(_PACK_NAMES, meta["off"])}
+            views = ("by_dst", "by_src", "by_rel")
+            static = meta["subsample_job"] = dict(
+                n_nodes=g.n, n_edges=E, parent=dv["_buf"], eid=g.device_edge_ids(device),
+                off_a=[off[(v, "a")] for v in views], off_b=[off[(v, "b")] for v in views],
+                off_chunk_beg=[off[(v, "chunk_beg")] for v in views], off_chunk_end=[off[(v, "chunk_end")] for v in views],
+                off_chunk_seg=[off[(v, "chunk_seg")] for v in views], n_chunks=[int(dv[v]["chunk_seg"].shape[0]) for v in views],
+                off_in_deg=off["in_deg"], off_out_deg=off["out_deg"], off_nnorm=off["nnorm"])
+        jobs.append(dict(static, keep=int(k), seed=int(seed), child=child, keep_mask=mask, scratch=scratch[i:i + 1]))
         out.append(SubsampledSnapshot(g, int(k), child, mask, device, n_rel_rows))
     if jobs:
         get_backend().subsample_views(jobs)
     return out
+
+
+class _PackedViews(dict):
+    """device_views() of a snapshot whose packed buffer already sits on the device: `_buf` / `_meta` are there from the start,
+    the per-array slices (by_dst / by_src / by_rel -> array, rel_rank, in_deg, out_deg, nnorm) are cut on first access."""
+
+    def __init__(self, buf, parent_meta):
+        super().__init__(_buf=buf)
+        self._pm = parent_meta
+
+    def __missing__(self, key):
+        if self._pm is None:
+            raise KeyError(key)
+        buf, pm, self._pm = dict.__getitem__(self, "_buf"), self._pm, None
+        for vn in ("by_dst", "by_src", "by_rel"):
+            dict.__setitem__(self, vn, {})
+        for name, o, n_ in zip(_PACK_NAMES, pm["off"], pm["size"]):
+            t = buf[int(o):int(o) + int(n_)]
+            if isinstance(name, tuple):
+                dict.__getitem__(self, name[0])[name[1]] = t
+            else:
+                dict.__setitem__(self, name, t)
+        dict.__setitem__(self, "nnorm", dict.__getitem__(self, "nnorm").view(torch.float32))
+        return self[key]
 
 
 class SubsampledSnapshot(Snapshot):
@@ -229,15 +257,8 @@ class SubsampledSnapshot(Snapshot):
         self._views = {}
         self._host = None
         pdv = parent.device_views(device, n_rel_rows)
-        dv = {"by_dst": {}, "by_src": {}, "by_rel": {}, "_buf": child_buf}
         pm = pdv["_meta"]
-        for name, o, n_ in zip(_PACK_NAMES, pm["off"], pm["size"]):
-            t = child_buf[int(o):int(o) + int(n_)]
-            if isinstance(name, tuple):
-                dv[name[0]][name[1]] = t
-            else:
-                dv[name] = t
-        dv["nnorm"] = dv["nnorm"].view(torch.float32)
+        dv = _PackedViews(child_buf, pm)              # the per-array tensors only if something indexes them (the union does not)
         m = dict(ptr=int(child_buf.data_ptr()), off=pm["off"], size=pm["size"], n_partial=pm["n_partial"], rel_chunks=pm["rel_chunks"])
         row = pm["row"].copy()
         row[62] = m["ptr"]
