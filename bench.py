@@ -107,9 +107,9 @@ def train_loop(model, w, steps):
         return 1e3 * dt / steps, edges / dt
 
     inline_ms, inline_eps = timed(model.prepare(b, w["L"], True) for b in batches)
-    pre_ms, pre_eps = timed(BatchPrefetcher(model, batches, seq_len=w["L"], depth=2))
+    pre_ms, pre_eps = timed(BatchPrefetcher(model, batches, seq_len=w["L"], depth=2, workers=2))
     return dict(ms_per_step=pre_ms, edges_per_s=pre_eps, inline_prepare_ms_per_step=inline_ms, inline_prepare_edges_per_s=inline_eps, steps=steps,
-                what="new batch every step: host prepare (background prefetcher; inline_* = prepared inline) + negatives + loss + backward "
+                what="new batch every step: host prepare (background prefetcher, 2 workers; inline_* = prepared inline) + negatives + loss + backward "
                      "+ Adam, eager launches (host-bound)")
 
 

@@ -50,7 +50,8 @@ def run(workers, warm):
 
 
 ref = None
-for k, workers in enumerate((3, 1, 2, 3, 1, 2, 3)):
+order = [int(x) for x in os.environ.get("PROBE_WORKERS", "3,1,2,3,1,2,3").split(",")]
+for k, workers in enumerate(order):
     losses, ms, meps = run(workers, warm=k > 0)
     same = "" if ref is None else ("  losses identical to the first run" if losses == ref else "  LOSSES DIFFER from the first run")
     ref = ref or losses
