@@ -16,6 +16,8 @@ from temp_amd import synthetic  # noqa: E402
 from temp_amd.prefetch import BatchPrefetcher  # noqa: E402
 from temp_amd.sampling import CorruptTriples  # noqa: E402
 
+if os.environ.get("PROBE_SWITCH_INTERVAL"):
+    sys.setswitchinterval(float(os.environ["PROBE_SWITCH_INTERVAL"]))
 name = sys.argv[1] if len(sys.argv) > 1 else "S-gdelt"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 dev = torch.device("cuda:0")
