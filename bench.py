@@ -85,22 +85,23 @@ def train_loop(model, w, steps):
     from temp_amd.sampling import CorruptTriples
     if not hasattr(model, "corrupter"):
         model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    batches = [synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 1000 + r) for r in range(steps + 5)]
+    WARM = 10                               # untimed steps at the head of each loop (worker threads, their streams and pinned rings start here)
+    opt = model.configure_optimizers()      # the reference trainer's: Adam(lr, weight_decay=1e-4), models/TKG_Module.py:154-160
+    batches = [synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 1000 + r) for r in range(steps + WARM)]
     for b in batches:                       # the first visit of a snapshot builds and uploads its cached views: once per run
         model.prepare(b, w["L"], True)
 
     def timed(source):
         edges, t0 = 0, None
         for i, wb in enumerate(source):
-            if i == 5:
+            if i == WARM:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             loss = model.run_loss(wb)
             opt.zero_grad(set_to_none=True)
             loss.backward()
             opt.step()
-            if i >= 5:
+            if i >= WARM:
                 edges += wb.n_edge_visits
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -313,7 +314,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mfma-compare", action="store_true",
                     help="skip the second, short run with TEMP_MFMA=f32 (config.fp32_mfma_ms_per_step)")
-    ap.add_argument("--train-loop-steps", type=int, default=30,
+    ap.add_argument("--train-loop-steps", type=int, default=100,
                     help="also time this many steps of a real training loop (new batch every step: host prepare, fresh negatives, loss, "
                          "backward, Adam, eager launches) and report it under config.train_loop, after the timed region (never the "
                          "headline); pass 0 when profiling, so that a rocprofv3 summary holds the headline step's kernels only")
