@@ -61,6 +61,17 @@ if os.environ.get("PROBE_SPLIT"):                # host time of the two halves o
         tl += time.perf_counter() - t0                 # launch code only: the device runs behind
     torch.cuda.synchronize()
     print("host only: prepare %.2f ms/batch, loss + backward + Adam launch code %.2f ms/step" % (1e3 * tp / len(wbs), 1e3 * tl / len(wbs)))
+    for rep in range(2):                            # prepared batches, no prepare in the loop: the device time of a training step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for wb in wbs:
+            loss = model.run_loss(wb)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        td = time.perf_counter() - t0
+    print("prepared batches only (device-bound if above the launch code's time): %.2f ms/step" % (1e3 * td / len(wbs)))
 
 if os.environ.get("PROBE_PROFILE"):
     import cProfile
