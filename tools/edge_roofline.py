@@ -26,8 +26,9 @@ def main():
     ap.add_argument("--log2-nodes", type=int, default=20)
     ap.add_argument("--log2-edges", type=int, default=24)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--relations", type=int, default=230, help="20: the relation weights fit LDS (the S-gdelt kernels on the HBM-sized graph)")
     a = ap.parse_args()
-    n, E, R, D, B = 1 << a.log2_nodes, 1 << a.log2_edges, 230, 200, 100
+    n, E, R, D, B = 1 << a.log2_nodes, 1 << a.log2_edges, a.relations, 200, 100
     dev = torch.device("cuda:0")
     t0 = time.time()
     g = synthetic.make_snapshots(n, R, E, n, 1, seed=0)[0]
