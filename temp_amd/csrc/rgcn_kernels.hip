@@ -325,31 +325,68 @@ __global__ void __launch_bounds__(256) k_rgcn_agg_generic(TempEdgeView v, const 
   }
 }
 
-// out[seg] = sum of its partial slots, in slot order (deterministic).  One wave per (fix entry,
-// 256-float column block); lanes own float4s; the slot walk is unrolled for memory-level parallelism.
-__global__ void __launch_bounds__(256) k_fixup(int n_fix, const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ fix_slot,
-                                               const int32_t* __restrict__ fix_cnt, const float* __restrict__ partial, int width,
-                                               float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+// out[seg] = sum of its partial slots, in a fixed order (deterministic).  One wave per (fix entry, 256-float column block);
+// lanes own float4s; the slot walk is unrolled for memory-level parallelism.  A segment with more than LONG partial rows
+// (a hub of an HBM-sized snapshot has tens of thousands: one wave would walk them for a millisecond while the chip idles) is
+// walked by ALL waves of its block, each over a contiguous share of the slots, and the shares are added in wave order.
+// <WAVES, IPB, LONG>: waves per block, items a block takes per round (one per wave, IPB <= WAVES), partial rows from which an
+// entry counts as long.  Many entries (the node views: thousands of hubs with a few partial rows each): <4, 4, 256>.  Few entries
+// (the by-relation view of the weight gradient: one entry per relation, hundreds to thousands of partial rows each -- ten
+// 4-wave blocks walked them for 40 us on an idle chip): <16, 1, 32>, one block of 16 waves per entry.
+__device__ __forceinline__ float4 fixup_walk(const float* __restrict__ p, int s, int end, int width) {
+  float4 acc = zero4();
+  for (; s + 8 <= end; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4(p + (size_t)(s + u) * width);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+  }
+  for (; s < end; ++s) acc = add4(acc, ld4(p + (size_t)s * width));
+  return acc;
+}
+
+template <int WAVES, int IPB, int LONG>
+__global__ void __launch_bounds__(WAVES * 64) k_fixup(int n_fix, const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ fix_slot,
+                                                      const int32_t* __restrict__ fix_cnt, const float* __restrict__ partial, int width,
+                                                      float* __restrict__ out) {
+  __shared__ long long long_item[IPB];
+  __shared__ float4 share[WAVES][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cblocks = (width + 255) >> 8;
   const long long items = (long long)n_fix * cblocks;
-  for (long long it = (long long)blockIdx.x * wpb + wave; it < items; it += (long long)gridDim.x * wpb) {
-    const int i = (int)(it / cblocks), cb = (int)(it - (long long)i * cblocks);
-    const int f = (cb << 8) + (lane << 2);
-    if (f >= width) continue;
-    const int seg = fix_seg[i], s0 = fix_slot[i], cnt = fix_cnt[i];
-    const float* p = partial + (size_t)s0 * width + f;
-    float4 acc = zero4();
-    int s = 0;
-    for (; s + 8 <= cnt; s += 8) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld4(p + (size_t)(s + u) * width);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+  const long long rounds = (items + (long long)gridDim.x * IPB - 1) / ((long long)gridDim.x * IPB);
+  for (long long r = 0; r < rounds; ++r) {                       // block-uniform
+    const long long it = (r * gridDim.x + blockIdx.x) * IPB + wave;
+    long long mine = -1;
+    if (wave < IPB && it < items) {
+      const int i = (int)(it / cblocks), cb = (int)(it - (long long)i * cblocks);
+      const int f = (cb << 8) + (lane << 2);
+      const int seg = fix_seg[i], s0 = fix_slot[i], cnt = fix_cnt[i];          // (one round trip for the three)
+      if (cnt > LONG) mine = it;                                // left to the whole block below
+      else if (f < width) st4(out + (size_t)seg * width + f, fixup_walk(partial + (size_t)s0 * width + f, 0, cnt, width));
     }
-    for (; s < cnt; ++s) acc = add4(acc, ld4(p + (size_t)s * width));
-    st4(out + (size_t)seg * width + f, acc);
+    if (wave < IPB && lane == 0) long_item[wave] = mine;
+    if (!__syncthreads_or(mine >= 0)) continue;                 // (block-uniform) no long entry in this round: nothing is shared
+    for (int w = 0; w < IPB; ++w) {
+      const long long lt = long_item[w];                        // block-uniform
+      if (lt < 0) continue;
+      const int i = (int)(lt / cblocks), cb = (int)(lt - (long long)i * cblocks);
+      const int f = (cb << 8) + (lane << 2);
+      const int seg = fix_seg[i], slot0 = fix_slot[i], cnt = fix_cnt[i];
+      const int per = (cnt + WAVES - 1) / WAVES;
+      const int s0 = min(cnt, wave * per), s1 = min(cnt, s0 + per);
+      share[wave][lane] = f < width ? fixup_walk(partial + (size_t)slot0 * width + f, s0, s1, width) : zero4();
+      __syncthreads();
+      if (wave == 0 && f < width) {
+        float4 acc = share[0][lane];
+#pragma unroll
+        for (int u = 1; u < WAVES; ++u) acc = add4(acc, share[u][lane]);
+        st4(out + (size_t)seg * width + f, acc);
+      }
+      __syncthreads();
+    }
+    __syncthreads();                                            // long_item is rewritten by the next round
   }
 }
 
@@ -511,8 +548,13 @@ static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const 
 static void launch_fixup(const TempEdgeView& v, const float* partial, int width, float* out, hipStream_t st) {
   if (v.n_fix <= 0) return;
   long long items = (long long)v.n_fix * ((width + 255) / 256);
-  int grid = (int)((items + 3) / 4 > 4096 ? 4096 : (items + 3) / 4);
-  TEMP_LAUNCH(K_FIXUP, k_fixup, dim3(grid), dim3(256), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
+  if (items <= 1024) {                                          // few entries: one 16-wave block each
+    TEMP_LAUNCH(K_FIXUP, (k_fixup<16, 1, 32>), dim3((int)items), dim3(16 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
+    return;
+  }
+  const long long blocks = (items + 3) / 4;
+  int grid = (int)(blocks > 4096 ? 4096 : blocks);
+  TEMP_LAUNCH(K_FIXUP, (k_fixup<4, 4, 256>), dim3(grid), dim3(4 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
 }
 
 // forward / dx aggregation into `out` rows of segments that have edges (others untouched)
