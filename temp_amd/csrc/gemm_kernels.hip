@@ -432,34 +432,44 @@ template <int LPR>
 __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
                                                           const int32_t* __restrict__ order, const float4* __restrict__ src,
                                                           const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
-  constexpr int G = 64 / LPR;
+  // A wave takes FOUR consecutive segments at a time and walks them in lockstep: the three dependent round trips of a segment
+  // (seg_ptr -> order -> row) are then shared by four segments instead of paid by each (the gather adjoints have 1-2 rows per
+  // segment: the walk is all latency).
+  constexpr int G = 64 / LPR, U = 4;
   const int lane = threadIdx.x & 63, grp = lane / LPR, lr = lane - grp * LPR;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const bool col_ok = lr < d4;
-  for (int s = wave; s < n_seg; s += nwaves) {
-    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
-    float4 acc = zero4();
-    int j = beg + grp;
-    for (; j + 3 * G < end; j += 4 * G) {
-      const int r0 = order[j], r1 = order[j + G], r2 = order[j + 2 * G], r3 = order[j + 3 * G];
-      const bool m0 = !row_mask || row_mask[r0] > 0, m1 = !row_mask || row_mask[r1] > 0, m2 = !row_mask || row_mask[r2] > 0,
-                 m3 = !row_mask || row_mask[r3] > 0;          // masked rows were never written by their producer
-      float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4();
-      if (col_ok) {
-        if (m0) v0 = src[(size_t)r0 * d4 + lr];
-        if (m1) v1 = src[(size_t)r1 * d4 + lr];
-        if (m2) v2 = src[(size_t)r2 * d4 + lr];
-        if (m3) v3 = src[(size_t)r3 * d4 + lr];
-      }
-      acc = add4(add4(acc, v0), add4(v1, add4(v2, v3)));
+  for (int s0 = wave * U; s0 < n_seg; s0 += nwaves * U) {
+    int beg[U], len[U], maxlen = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = s0 + u < n_seg;
+      beg[u] = ok ? seg_ptr[s0 + u] : 0;
+      len[u] = ok ? seg_ptr[s0 + u + 1] - beg[u] : 0;
+      maxlen = max(maxlen, len[u]);
     }
-    for (; j < end; j += G) {
-      const int r = order[j];
-      if (col_ok && (!row_mask || row_mask[r] > 0)) acc = add4(acc, src[(size_t)r * d4 + lr]);
+    float4 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = zero4();
+    for (int k = grp; k < maxlen; k += G) {
+      int r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) r[u] = k < len[u] ? order[beg[u] + k] : -1;
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v[u] = zero4();
+        if (r[u] >= 0 && col_ok && (!row_mask || row_mask[r[u]] > 0)) v[u] = src[(size_t)r[u] * d4 + lr];   // masked rows were never written
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = add4(acc[u], v[u]);
     }
 #pragma unroll
-    for (int m = LPR; m < 64; m <<= 1) acc = add4(acc, shfl_xor4(acc, m));
-    if (grp == 0 && col_ok) out[(size_t)s * d4 + lr] = acc;
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int m = LPR; m < 64; m <<= 1) acc[u] = add4(acc[u], shfl_xor4(acc[u], m));
+      if (grp == 0 && col_ok && s0 + u < n_seg) out[(size_t)(s0 + u) * d4 + lr] = acc[u];
+    }
   }
 }
 
@@ -925,20 +935,24 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
 namespace temp {
 // Long segments (a hot table: hundreds of gathered rows per table row): one BLOCK per segment, its 4 waves take every
 // 4th row with 8 row loads in flight each, partial sums meet in LDS in a fixed order.
-__global__ void __launch_bounds__(256) k_segment_sum_rows_blk(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
-                                                              const int32_t* __restrict__ order, const float4* __restrict__ src,
-                                                              const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
-  __shared__ float4 red[4][64];
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_segment_sum_rows_blk(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
+                                                                     const int32_t* __restrict__ order, const float4* __restrict__ src,
+                                                                     const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
+  // one block per segment: wave w takes rows w, w + WAVES, ... eight at a time; the waves' sums are added in wave order.
+  // WAVES = 16 for segments of a hundred rows and more (500 entities gathered 82 000 times: 164 rows each -- four waves walk
+  // them in five dependent round trips of order[] -> row, sixteen in two)
+  __shared__ float4 red[WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool col_ok = lane < d4;
   for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
     const int beg = seg_ptr[s], end = seg_ptr[s + 1];
     float4 acc = zero4();
-    for (int j0 = beg + wave; j0 < end; j0 += 32) {
+    for (int j0 = beg + wave; j0 < end; j0 += 8 * WAVES) {
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int j = j0 + 4 * u;
+        const int j = j0 + WAVES * u;
         v[u] = zero4();
         if (j < end && col_ok) {
           const int r = order[j];
@@ -950,7 +964,12 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows_blk(int n_seg, int d4,
     }
     red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && col_ok) out[(size_t)s * d4 + lane] = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
+    if (wave == 0 && col_ok) {
+      float4 t = red[0][lane];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) t = add4(t, red[w][lane]);
+      out[(size_t)s * d4 + lane] = t;
+    }
     __syncthreads();
   }
 }
@@ -1018,11 +1037,15 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
     return launch_status();
   }
   if (n_rows_hint > 32LL * n_seg && d4 <= 64) {
-    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk, dim3(n_seg < 4096 ? n_seg : 4096), dim3(256), 0, st, n_seg, d4, seg_ptr, order,
-                (const float4*)src, row_mask, (float4*)out);
+    if (n_rows_hint >= 96LL * n_seg)
+      TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk<16>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(16 * 64), 0, st, n_seg, d4, seg_ptr, order,
+                  (const float4*)src, row_mask, (float4*)out);
+    else
+      TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk<4>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(4 * 64), 0, st, n_seg, d4, seg_ptr, order,
+                  (const float4*)src, row_mask, (float4*)out);
     return launch_status();
   }
-  int grid = ceil_div(n_seg, 4);
+  int grid = ceil_div(n_seg, 16);                               // four segments per wave at a time, four waves per block
   if (grid > 2048) grid = 2048;
 #define TEMP_SEGSUM(L) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)out)
   if (d4 <= 8) TEMP_SEGSUM(8); else if (d4 <= 16) TEMP_SEGSUM(16); else if (d4 <= 32) TEMP_SEGSUM(32); else TEMP_SEGSUM(64);
