@@ -296,7 +296,7 @@ static TnCfg tn_cfg(int M, int Ka, int Nb) {
   c.nt = ntiles >= 5 ? 7 : (ntiles >= 3 ? 4 : (ntiles == 2 ? 2 : 1));
   c.nbb = ceil_div(ntiles, c.nt);
   long long s = 256 / ((long long)c.kab * c.nbb);     // ~ one 7/8-wave block per CU
-  const long long max_s = (M + 127) / 128;            // at least 128 rows per slice
+  const long long max_s = M < 2048 ? (M + 31) / 32 : (M + 127) / 128;   // at least 128 rows per slice (32 for a tiny M: the launch is all latency)
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   c.slices = (int)s;
