@@ -432,6 +432,42 @@ template <int LPR>
 __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
                                                           const int32_t* __restrict__ order, const float4* __restrict__ src,
                                                           const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, grp = lane / LPR, lr = lane - grp * LPR;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const bool col_ok = lr < d4;
+  for (int s = wave; s < n_seg; s += nwaves) {
+    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+    float4 acc = zero4();
+    int j = beg + grp;
+    for (; j + 3 * G < end; j += 4 * G) {
+      const int r0 = order[j], r1 = order[j + G], r2 = order[j + 2 * G], r3 = order[j + 3 * G];
+      const bool m0 = !row_mask || row_mask[r0] > 0, m1 = !row_mask || row_mask[r1] > 0, m2 = !row_mask || row_mask[r2] > 0,
+                 m3 = !row_mask || row_mask[r3] > 0;          // masked rows were never written by their producer
+      float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4();
+      if (col_ok) {
+        if (m0) v0 = src[(size_t)r0 * d4 + lr];
+        if (m1) v1 = src[(size_t)r1 * d4 + lr];
+        if (m2) v2 = src[(size_t)r2 * d4 + lr];
+        if (m3) v3 = src[(size_t)r3 * d4 + lr];
+      }
+      acc = add4(add4(acc, v0), add4(v1, add4(v2, v3)));
+    }
+    for (; j < end; j += G) {
+      const int r = order[j];
+      if (col_ok && (!row_mask || row_mask[r] > 0)) acc = add4(acc, src[(size_t)r * d4 + lr]);
+    }
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) acc = add4(acc, shfl_xor4(acc, m));
+    if (grp == 0 && col_ok) out[(size_t)s * d4 + lr] = acc;
+  }
+}
+
+// The same for segments of one or two rows (the adjoint of a gather whose rows are mostly distinct).
+template <int LPR>
+__global__ void __launch_bounds__(256) k_segment_sum_rows_short(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
+                                                          const int32_t* __restrict__ order, const float4* __restrict__ src,
+                                                          const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
   // A wave takes FOUR consecutive segments at a time and walks them in lockstep: the three dependent round trips of a segment
   // (seg_ptr -> order -> row) are then shared by four segments instead of paid by each (the gather adjoints have 1-2 rows per
   // segment: the walk is all latency).
@@ -1045,9 +1081,16 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
                   (const float4*)src, row_mask, (float4*)out);
     return launch_status();
   }
-  int grid = ceil_div(n_seg, 16);                               // four segments per wave at a time, four waves per block
+  const bool short_segs = n_rows_hint > 0 && n_rows_hint <= 2LL * n_seg;      // four segments per wave in lockstep
+  int grid = ceil_div(n_seg, short_segs ? 16 : 4);
   if (grid > 2048) grid = 2048;
-#define TEMP_SEGSUM(L) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)out)
+#define TEMP_SEGSUM(L)                                                                                                                      \
+  do {                                                                                                                                      \
+    if (short_segs) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows_short<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order,      \
+                                (const float4*)src, row_mask, (float4*)out);                                                                \
+    else TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src,   \
+                     row_mask, (float4*)out);                                                                                               \
+  } while (0)
   if (d4 <= 8) TEMP_SEGSUM(8); else if (d4 <= 16) TEMP_SEGSUM(16); else if (d4 <= 32) TEMP_SEGSUM(32); else TEMP_SEGSUM(64);
 #undef TEMP_SEGSUM
   return launch_status();
