@@ -12,9 +12,15 @@ model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 import resource
 t0 = time.perf_counter()
-for i in range(3000):
-    b = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], i)
-    wb = model.prepare(b, w["L"], True)
+workers = int(os.environ.get("PROBE_WORKERS", "0"))          # 0: prepare inline; N: temp_amd.prefetch.BatchPrefetcher with N workers
+steps = int(os.environ.get("PROBE_STEPS", "3000"))
+batches = (synthetic.default_targets(w["num_times"], w["L"], w["bsz"], i) for i in range(steps))
+if workers:
+    from temp_amd.prefetch import BatchPrefetcher
+    source = BatchPrefetcher(model, batches, seq_len=w["L"], depth=2, workers=workers, batch_seeds=True)
+else:
+    source = (model.prepare(b, w["L"], True) for b in batches)
+for i, wb in enumerate(source):
     loss = model.run_loss(wb); opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
     if i % 500 == 499:
         torch.cuda.synchronize()
