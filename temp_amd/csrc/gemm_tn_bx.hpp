@@ -481,7 +481,7 @@ inline int tn_bx8_slices(int M, int kab8) {
   int per_xcd = 32 / kab8;
   if (per_xcd < 1) per_xcd = 1;
   int S = 8 * per_xcd;
-  const int max_s = (M + 255) / 256;
+  const int max_s = M < 16384 ? (M + 127) / 128 : (M + 255) / 256;   // at least 256 rows per slice (128 for a small M: 48 blocks leave the chip idle)
   if (S > max_s) S = max_s;
   return S < 1 ? 1 : S;
 }
