@@ -367,7 +367,13 @@ __global__ void __launch_bounds__(256) k_colsum_part(int rows, int cols, const f
   const int r0 = blockIdx.y * CS_RPB, r1 = min(rows, r0 + CS_RPB);
   float acc = 0.f;
   if (c < cols)
-    for (int r = r0 + w; r < r1; r += 4) acc += X[(size_t)r * ldx + c];
+    for (int r = r0 + w; r < r1; r += 32) {                    // eight row loads in flight per lane (one at a time was all latency)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r + 4 * u < r1 ? X[(size_t)(r + 4 * u) * ldx + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
   red[w][threadIdx.x & 63] = acc;
   __syncthreads();
   if (w == 0 && c < cols) part[(size_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
