@@ -537,7 +537,8 @@ inline bool bx_enabled() {
 // Scratch slot for the packed weights of one launch on `st` (gemm_kernels.hip): nullptr when `bytes` exceed a slot or every
 // slot belongs to another stream -- the caller then uses the kernel that splits B itself.
 bx_u32x4* bx_scratch(hipStream_t st, size_t bytes);
-#define BX_SLOT_BYTES (3u << 20)
+#define BX_SLOT_BYTES (16u << 20)                            // a slot: packed weights (up to BX_PACK_MAX_BYTES) or k-slice partials
+#define BX_PACK_MAX_BYTES (3u << 20)
 #define BX_SLOTS 8
 
 inline size_t bx_packed_bytes(int N, int K) { return (size_t)ceil_div(K, 16) * ceil_div(N, 32) * 192 * 16; }
@@ -580,7 +581,7 @@ static inline void launch_bx_g(int kid, const PanelBatch<Epi>& batch, int count,
       if (batch.p[j].B == batch.p[i].B) { which[i] = which[j]; break; }
     if (which[i] < 0) which[i] = n_distinct++;
   }
-  bx_u32x4* slot = bx_scratch(st, pbytes * n_distinct);
+  bx_u32x4* slot = pbytes * n_distinct <= BX_PACK_MAX_BYTES ? bx_scratch(st, pbytes * n_distinct) : nullptr;
   if (slot) {
     BxPacked pk;
     const int n_slabs = ceil_div(g.K, 16);

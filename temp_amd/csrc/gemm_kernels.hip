@@ -1120,6 +1120,19 @@ struct EpiPlainStore {
   __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const { st4(out + (size_t)row * ldo + col, acc); }
 };
 
+// Partial product of one k-slice (k_gemm_panel with K split over the blocks, gemm_panel.hpp): slice s of the launch writes
+// part[s * slice_elems + row * ldo + col]; k_reduce_slices adds the slices in order.
+struct EpiPartialStore {
+  static constexpr int k_split_tag = 1;
+  float* part; int ldo; size_t slice_elems; int kc, col_blocks;
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
+  __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
+  __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const {
+    st4(part + (size_t)(blockIdx.y / col_blocks) * slice_elems + (size_t)row * ldo + col, acc);
+  }
+};
+
 // C^T written: out[col * ldo + row].  A lane of the weights-resident kernel owns one row and four consecutive columns, so for a
 // fixed column the 32 lanes of a half-wave write 32 consecutive floats: coalesced 128-B segments.
 struct EpiPlainStoreT {
@@ -1182,6 +1195,46 @@ int temp_linear_multi(int count, const TempLinearProblem* probs, int N, int K, i
     if (probs[i].M < 0 || !probs[i].B || (probs[i].M > 0 && (!probs[i].A || !probs[i].C))) return TEMP_E_BADARG;
   for (int i0 = 0; i0 < count; i0 += PANEL_MAXP) {
     const int n = count - i0 < PANEL_MAXP ? count - i0 : PANEL_MAXP;
+    // Few rows against a long K (d_q = d_scores . all_entities: ~200 rows x 10 000 entities x D per window): the row panels
+    // x column tiles are a few dozen blocks, each walking all of K -- 330 us on an idle chip.  K is cut into slices, every
+    // (panel, tile, slice) is a block, the slices' partial products land in a scratch slot of the library and are summed in order.
+    if (!trans_b && K >= 4096 && N <= 256 && ldc == N && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0) {
+      long long panels = 0, rows = 0;
+      int max_m = 0;
+      for (int i = 0; i < n; ++i) {
+        const int M = probs[i0 + i].M;
+        panels += ceil_div(M, 128); rows += M; max_m = M > max_m ? M : max_m;
+      }
+      const int ntiles = ceil_div(N, 32);
+      int S = (int)(768 / (panels * ntiles > 0 ? panels * ntiles : 1));
+      if (S > K / 320) S = K / 320;
+      const long long cap = (long long)BX_SLOT_BYTES / ((rows > 0 ? rows : 1) * ldc * (long long)sizeof(float));
+      if (S > cap) S = (int)cap;
+      if (S >= 2) {
+        const int kc = ceil_div(ceil_div(K, S), GEMM_KC) * GEMM_KC;
+        S = ceil_div(K, kc);
+        float* scratch = (float*)bx_scratch((hipStream_t)stream, (size_t)S * rows * ldc * sizeof(float));
+        if (S >= 2 && scratch) {
+          PanelBatch<EpiPartialStore> pb;
+          float* part[PANEL_MAXP];
+          size_t off = 0;
+          for (int i = 0; i < PANEL_MAXP; ++i) {
+            const TempLinearProblem& q = probs[i0 + (i < n ? i : 0)];
+            const int M = i < n ? q.M : 0;
+            part[i] = scratch + off;
+            pb.p[i] = PanelProblem<EpiPartialStore>{M, q.A, nullptr, q.B, EpiPartialStore{part[i], ldc, (size_t)M * ldc, kc, ntiles}};
+            off += (size_t)S * M * ldc;
+          }
+          TEMP_LAUNCH(K_GEMM_LINEAR, (k_gemm_panel<1, EpiPartialStore>), dim3(ceil_div(max_m, 128), ntiles * S, n), dim3(256), 0,
+                      (hipStream_t)stream, pb, N, K, lda, ldb, trans_b, 0);
+          for (int i = 0; i < n; ++i)
+            if (probs[i0 + i].M > 0)
+              reduce_slices(S, (size_t)probs[i0 + i].M * ldc, ldc, part[i], probs[i0 + i].C, ldc, (hipStream_t)stream);
+          if (launch_status() != TEMP_OK) return TEMP_E_LAUNCH;
+          continue;
+        }
+      }
+    }
     PanelBatch<EpiPlainStore> batch;
     for (int i = 0; i < PANEL_MAXP; ++i) {
       const TempLinearProblem& q = probs[i0 + (i < n ? i : 0)];

@@ -88,6 +88,13 @@ struct PanelProblem { int M; const float* A; const int32_t* a_idx; const float* 
 template <class Epi>
 struct PanelBatch { PanelProblem<Epi> p[PANEL_MAXP]; };
 
+// An epilogue that declares `k_split_tag` splits K over the blocks: blockIdx.y = k-slice * col_blocks + column block, the slice
+// covers k in [slice * kc, slice * kc + kc) and the epilogue stores the slice's partial product (epi.kc, epi.col_blocks).
+template <class E, class = void>
+struct EpiKSplit { static constexpr bool value = false; };
+template <class E>
+struct EpiKSplit<E, decltype((void)E::k_split_tag)> { static constexpr bool value = true; };
+
 template <int NT, class Epi>
 __global__ void __launch_bounds__(256) k_gemm_panel(PanelBatch<Epi> batch, int N, int K, int lda, int ldb, int trans_b, int n_base) {
   constexpr int LDS_B = PanelCfg<NT>::LDS_B, NV = PanelCfg<NT>::NV, NQ = GEMM_KC / 8;
@@ -102,7 +109,15 @@ __global__ void __launch_bounds__(256) k_gemm_panel(PanelBatch<Epi> batch, int N
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hh = lane >> 5, li = lane & 31;
   const int m0 = (blockIdx.x * 4 + wave) * 32;
-  const int n0 = n_base + blockIdx.y * PanelCfg<NT>::BN;
+  int col_block = blockIdx.y;
+  if constexpr (EpiKSplit<Epi>::value) {                      // this block's k-slice: shift the operands, shorten K
+    const int ks = blockIdx.y / epi.col_blocks, kb = ks * epi.kc;
+    col_block -= ks * epi.col_blocks;
+    A += kb;
+    B += trans_b ? (size_t)kb : (size_t)kb * ldb;
+    K = min(K - kb, epi.kc);
+  }
+  const int n0 = n_base + col_block * PanelCfg<NT>::BN;
   const int arow = m0 + li;
   long arow_src = -1;
   if (arow < M) arow_src = a_idx ? (long)a_idx[arow] : (long)arow;

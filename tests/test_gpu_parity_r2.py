@@ -558,3 +558,30 @@ def test_prefetch_workers_training_run_reproducible_gpu():
     cold3, warm1, warm2 = run(3), run(1), run(2)
     assert torch.isfinite(cold3).all()
     assert torch.equal(cold3, warm1) and torch.equal(warm2, warm1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ms,K,N", [
+    ([184, 120, 0, 200, 184, 96], 10488, 200),     # ICEWS05-15-like d_q = d_scores . all_entities: split over K, two launches
+    ([300], 7128, 200),                            # one problem, three row panels
+    ([184, 184, 184, 184], 4100, 136),             # K barely above the threshold, narrow output, ragged last chunk
+])
+def test_linear_multi_long_k_vs_fp64(hip_backend, Ms, K, N):
+    """temp_linear_multi with few rows against a long K runs with K cut into slices (partial products in a scratch slot of the
+    library, summed in slice order); every problem against fp64, and twice bit for bit the same."""
+    g = torch.Generator().manual_seed(7)
+    a = [torch.randn(m, K, generator=g).cuda() for m in Ms]
+    b = [(torch.randn(K, N, generator=g) * 0.3).cuda() for _ in Ms]
+    out = torch.full((sum(Ms), N), float("nan"), device="cuda")
+    hip_backend.linear_multi(a, b, False, out)
+    again = torch.full_like(out, float("nan"))
+    hip_backend.linear_multi(a, b, False, again)
+    assert torch.equal(out, again)
+    r = 0
+    for ai, bi in zip(a, b):
+        want = (ai.double() @ bi.double())
+        scale = (ai.double().abs() @ bi.double().abs())
+        got = out[r:r + ai.shape[0]].double()
+        assert torch.isfinite(got).all()
+        assert float(((got - want).abs() / scale.clamp_min(1e-30)).max()) < 2e-6 if ai.shape[0] else True
+        r += ai.shape[0]
