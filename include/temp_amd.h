@@ -346,6 +346,13 @@ int temp_linear_multi(int count, const TempLinearProblem* probs, int N, int K, i
 size_t temp_linear_tn_workspace(int M, int Ka, int Nb);
 int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, float* out, int ldo,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* Several weight-gradient-shaped products in one launch sequence (the per-window d_all_b = d_scores_b^T . q_b of the loss,
+ * models/TKG_Module.py:202-213 differentiated): C_i[Ka,Nb] = A_i[M_i,Ka]^T . B_i[M_i,Nb], same Ka, Nb and leading dimensions,
+ * C_i contiguous (ldc == Nb).  Small M_i run as ONE launch (up to 8 problems, problem index in the grid); shapes of the large-M
+ * kernels fall back to one temp_linear_tn per problem.  `probs` is a HOST array; deterministic. */
+size_t temp_linear_tn_multi_workspace(int count, int max_m, int Ka, int Nb);
+int temp_linear_tn_multi(int count, const TempLinearProblem* probs, int Ka, int Nb, int lda, int ldb, int ldc, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Link-prediction loss (TKG_Module.train_link_prediction, models/TKG_Module.py:202-213;

@@ -124,6 +124,8 @@ SYMBOLS = {
     "temp_linear_t": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, _I, c_vp, _I, c_vp]),
     "temp_linear_multi": (_I, [_I, ctypes.POINTER(TempLinearProblem), _I, _I, _I, _I, _I, _I, c_vp]),
     "temp_linear_tn_workspace": (_SZ, [_I, _I, _I]),
+    "temp_linear_tn_multi_workspace": (_SZ, [_I, _I, _I, _I]),
+    "temp_linear_tn_multi": (_I, [_I, ctypes.POINTER(TempLinearProblem), _I, _I, _I, _I, _I, c_vp, _SZ, c_vp]),
     "temp_linear_tn": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, c_vp, _I, c_vp, _SZ, c_vp]),
     "temp_gather_ce_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gather_ce_bwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp]),

@@ -402,6 +402,25 @@ class HipBackend:
         _lib.check(rc, "temp_linear_tn")
         return out
 
+    def linear_tn_multi(self, a_list, b_list, out_list):
+        """out_i[Ka,Nb] = a_i[M_i,Ka]^T . b_i[M_i,Nb] for every problem i (contiguous (Ka, Nb) outputs): one launch for small M_i."""
+        Ka, Nb = a_list[0].shape[1], b_list[0].shape[1]
+        arr = (_lib.TempLinearProblem * len(a_list))()
+        keep, max_m = [], 0
+        for i, (a, b, o) in enumerate(zip(a_list, b_list, out_list)):
+            a, b = _f32(a, "a"), _f32(b, "b")
+            keep.append((a, b))
+            if a.shape[1] != Ka or b.shape[1] != Nb or a.shape[0] != b.shape[0]:
+                raise ValueError("linear_tn_multi: problems must share Ka and Nb")
+            if o.shape != (Ka, Nb) or not o.is_contiguous() or o.dtype != torch.float32:
+                raise ValueError("linear_tn_multi: outputs must be contiguous float32 (Ka, Nb) matrices")
+            arr[i].M, arr[i].A, arr[i].B, arr[i].C = a.shape[0], a.data_ptr(), b.data_ptr(), o.data_ptr()
+            max_m = max(max_m, a.shape[0])
+        ws = self._ws(self.lib.temp_linear_tn_multi_workspace(len(a_list), max_m, Ka, Nb), a_list[0].device)
+        rc = self.lib.temp_linear_tn_multi(len(a_list), arr, Ka, Nb, Ka, Nb, Nb, _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_linear_tn_multi")
+        return out_list
+
     def gather_ce_fwd(self, scores, cand):
         scores, cand = _f32(scores, "scores"), _i32(cand, "cand")
         P, N = scores.shape

@@ -101,10 +101,10 @@ int mask_rows(int n, int d, const float* src, float* dst, const DropSpec& drop, 
 // SPLIT = 2: the block's WPB waves are KT = WPB/2 row tiles x 2 column halves (wave w and w + KT share a row tile and,
 // by the hardware's cyclic wave -> SIMD placement, a SIMD): for NT = 7 a SIMD runs a 4-tile and a 3-tile wave, i.e.
 // 7 tiles on every SIMD, where 7 full-width waves load the four SIMDs 2 : 2 : 2 : 1.
-template <int NT, int WPB, int SPLIT = 1>
-__global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
-                                                      const float* __restrict__ B, int ldb, int rows_per_slice, int nb_base,
-                                                      float* __restrict__ part, float* __restrict__ bias_part) {
+template <int NT, int WPB, int SPLIT>
+__device__ __forceinline__ void tn_body(int M, int Ka, int Nb, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                        int rows_per_slice, int nb_base, float* __restrict__ part, float* __restrict__ bias_part,
+                                        const int slice) {
   constexpr int KT = WPB / SPLIT, NT_LO = (NT + SPLIT - 1) / SPLIT;
   constexpr int T = WPB * 64, BK = KT * 32, BN = NT * 32;
   constexpr int NVA = (TN_MC * BK / 4 + T - 1) / T;          // = 2
@@ -118,7 +118,6 @@ __global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, con
   const int t_beg = part_id * NT_LO;                         // first column tile of this wave
   const int ka0 = ka_blk + kt * 32;
   const int nb0 = nb_base + blockIdx.y * BN;
-  const int slice = blockIdx.z;
   const int mbeg = slice * rows_per_slice, mend = min(M, mbeg + rows_per_slice);
   const bool wave_on = ka0 < Ka;
   f32x16 acc[NT_LO];
@@ -240,6 +239,23 @@ __global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, con
   }
 }
 
+template <int NT, int WPB, int SPLIT = 1>
+__global__ void __launch_bounds__(WPB * 64) k_gemm_tn(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ B, int ldb, int rows_per_slice, int nb_base,
+                                                      float* __restrict__ part, float* __restrict__ bias_part) {
+  tn_body<NT, WPB, SPLIT>(M, Ka, Nb, A, lda, B, ldb, rows_per_slice, nb_base, part, bias_part, blockIdx.z);
+}
+
+// Several products of one shape class in ONE launch (the per-window d_all = d_scores^T . q of the loss: eight launches of a few
+// dozen row blocks each were latency chains on an idle chip): blockIdx.z = problem * slices + slice.
+#define TN_MAXP 8
+struct TnBatch { int M[TN_MAXP]; const float* A[TN_MAXP]; const float* B[TN_MAXP]; float* part[TN_MAXP]; };
+template <int NT, int WPB, int SPLIT = 1>
+__global__ void __launch_bounds__(WPB * 64) k_gemm_tn_multi(TnBatch b, int Ka, int Nb, int lda, int ldb, int rows_per_slice, int slices) {
+  const int prob = blockIdx.z / slices, slice = blockIdx.z - prob * slices;
+  tn_body<NT, WPB, SPLIT>(b.M[prob], Ka, Nb, b.A[prob], lda, b.B[prob], ldb, rows_per_slice, 0, b.part[prob], nullptr, slice);
+}
+
 __global__ void __launch_bounds__(256) k_reduce_slices(int n_slices, size_t elems, int width, const float* __restrict__ part,
                                                        float* __restrict__ out, int ldo) {
   // elems % 4 == 0 is guaranteed by the callers (all widths are multiples of 4): float4 lanes,
@@ -352,6 +368,51 @@ int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int 
   else launch_tn<1>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
   reduce_slices(S, (size_t)Ka * Nb, Nb, part, out, ldo, st);
   if (bias_out) reduce_slices(S, (size_t)Ka, Ka, bpart, bias_out, Ka, st);
+  return launch_status();
+}
+
+// count <= TN_MAXP products out_i[Ka,Nb] = A_i[M_i,Ka]^T . B_i[M_i,Nb] (same Ka, Nb, leading dimensions) in one launch of the
+// fp32 kernel; with one slice per problem the blocks write out_i directly (ldo == Nb), else partials + one reduction per problem.
+// Returns TEMP_E_UNSUPPORTED for shapes it does not take (the caller then loops over gemm_tn).
+size_t gemm_tn_multi_workspace(int count, int max_m, int Ka, int Nb) {
+  const TnCfg c = tn_cfg(max_m, Ka, Nb);
+  long long s = 256 / ((long long)c.kab * c.nbb * (count > 0 ? count : 1));
+  if (s > c.slices) s = c.slices;
+  if (s < 1) s = 1;
+  return s > 1 ? align_up((size_t)count * s * Ka * Nb * sizeof(float), 256) : 0;
+}
+int gemm_tn_multi(int count, const int* Ms, int Ka, int Nb, const float* const* As, int lda, const float* const* Bs, int ldb, float* const* outs,
+                  int ldo, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (count <= 0 || count > TN_MAXP || Ka <= 0 || Nb <= 0) return TEMP_E_UNSUPPORTED;
+  if (Ka % 4 || Nb % 4 || lda % 4 || ldb % 4 || ldo != Nb) return TEMP_E_UNSUPPORTED;
+  int max_m = 0;
+  for (int i = 0; i < count; ++i) max_m = Ms[i] > max_m ? Ms[i] : max_m;
+  if (max_m <= 0) return TEMP_E_UNSUPPORTED;
+  const TnCfg c = tn_cfg(max_m, Ka, Nb);
+  if (c.split == 2 && c.nbb == 1 && tn_bx_ok(max_m, Ka, Nb, lda, ldb)) return TEMP_E_UNSUPPORTED;   // large M: the split-operand kernels
+  if (!(c.split == 2 && c.nt == 7) && !(c.split == 1 && (c.nt == 7 || c.nt == 4 || c.nt == 2 || c.nt == 1))) return TEMP_E_UNSUPPORTED;
+  if ((long long)max_m * (lda > ldb ? lda : ldb) >= (1ll << 31)) return TEMP_E_UNSUPPORTED;
+  long long s = 256 / ((long long)c.kab * c.nbb * count);
+  if (s > c.slices) s = c.slices;
+  if (s < 1) s = 1;
+  const int S = (int)s;
+  if (S > 1 && (!ws || ws_bytes < gemm_tn_multi_workspace(count, max_m, Ka, Nb))) return TEMP_E_WORKSPACE;
+  int rps = ceil_div(max_m, S);
+  rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
+  TnBatch b;
+  for (int i = 0; i < TN_MAXP; ++i) {
+    const int k = i < count ? i : 0;
+    b.M[i] = i < count ? Ms[k] : 0; b.A[i] = As[k]; b.B[i] = Bs[k];
+    b.part[i] = S > 1 ? (float*)ws + (size_t)k * S * Ka * Nb : outs[k];
+  }
+  dim3 grid(c.kab, c.nbb, S * count);
+#define TEMP_TN_MULTI(NT_, W_, SP_) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_multi<NT_, W_, SP_>), grid, dim3(W_ * 64), 0, st, b, Ka, Nb, lda, ldb, rps, S)
+  if (c.split == 2) TEMP_TN_MULTI(7, 8, 2);
+  else if (c.wpb == 7) { if (c.nt == 7) TEMP_TN_MULTI(7, 7, 1); else if (c.nt == 4) TEMP_TN_MULTI(4, 7, 1); else if (c.nt == 2) TEMP_TN_MULTI(2, 7, 1); else TEMP_TN_MULTI(1, 7, 1); }
+  else { if (c.nt == 7) TEMP_TN_MULTI(7, 8, 1); else if (c.nt == 4) TEMP_TN_MULTI(4, 8, 1); else if (c.nt == 2) TEMP_TN_MULTI(2, 8, 1); else TEMP_TN_MULTI(1, 8, 1); }
+#undef TEMP_TN_MULTI
+  if (S > 1)
+    for (int i = 0; i < count; ++i) reduce_slices(S, (size_t)Ka * Nb, Nb, (float*)ws + (size_t)i * S * Ka * Nb, outs[i], ldo, st);
   return launch_status();
 }
 
@@ -1217,19 +1278,27 @@ int temp_linear_multi(int count, const TempLinearProblem* probs, int N, int K, i
         if (S >= 2 && scratch) {
           PanelBatch<EpiPartialStore> pb;
           float* part[PANEL_MAXP];
+          // outputs that follow each other in memory (the row blocks of one matrix): slices of the WHOLE row range, one reduction
+          bool adjacent = true;
+          for (int i = 1; i < n; ++i) adjacent = adjacent && probs[i0 + i].C == probs[i0 + i - 1].C + (size_t)probs[i0 + i - 1].M * ldc;
           size_t off = 0;
           for (int i = 0; i < PANEL_MAXP; ++i) {
             const TempLinearProblem& q = probs[i0 + (i < n ? i : 0)];
             const int M = i < n ? q.M : 0;
             part[i] = scratch + off;
-            pb.p[i] = PanelProblem<EpiPartialStore>{M, q.A, nullptr, q.B, EpiPartialStore{part[i], ldc, (size_t)M * ldc, kc, ntiles}};
-            off += (size_t)S * M * ldc;
+            pb.p[i] = PanelProblem<EpiPartialStore>{M, q.A, nullptr, q.B,
+                                                    EpiPartialStore{part[i], ldc, adjacent ? (size_t)rows * ldc : (size_t)M * ldc, kc, ntiles}};
+            off += adjacent ? (size_t)M * ldc : (size_t)S * M * ldc;
           }
           TEMP_LAUNCH(K_GEMM_LINEAR, (k_gemm_panel<1, EpiPartialStore>), dim3(ceil_div(max_m, 128), ntiles * S, n), dim3(256), 0,
                       (hipStream_t)stream, pb, N, K, lda, ldb, trans_b, 0);
-          for (int i = 0; i < n; ++i)
-            if (probs[i0 + i].M > 0)
-              reduce_slices(S, (size_t)probs[i0 + i].M * ldc, ldc, part[i], probs[i0 + i].C, ldc, (hipStream_t)stream);
+          if (adjacent) {
+            reduce_slices(S, (size_t)rows * ldc, ldc, scratch, probs[i0].C, ldc, (hipStream_t)stream);
+          } else {
+            for (int i = 0; i < n; ++i)
+              if (probs[i0 + i].M > 0)
+                reduce_slices(S, (size_t)probs[i0 + i].M * ldc, ldc, part[i], probs[i0 + i].C, ldc, (hipStream_t)stream);
+          }
           if (launch_status() != TEMP_OK) return TEMP_E_LAUNCH;
           continue;
         }
@@ -1253,6 +1322,45 @@ int temp_linear_tn(int M, int Ka, int Nb, const float* A, int lda, const float* 
   if (M < 0 || Ka <= 0 || Nb <= 0 || !out || (M > 0 && (!A || !B))) return TEMP_E_BADARG;
   if (!workspace || workspace_bytes < temp_linear_tn_workspace(M, Ka, Nb)) return TEMP_E_WORKSPACE;
   return gemm_tn(M, Ka, Nb, A, lda, B, ldb, out, ldo, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t temp_linear_tn_multi_workspace(int count, int max_m, int Ka, int Nb) {
+  if (count <= 0 || max_m < 0 || Ka <= 0 || Nb <= 0) return 0;
+  size_t w = gemm_tn_workspace(max_m, Ka, Nb) + 256;                 // the per-problem loop it falls back to
+  for (int i0 = 0; i0 < count; i0 += TN_MAXP) {
+    const size_t m = gemm_tn_multi_workspace(count - i0 < TN_MAXP ? count - i0 : TN_MAXP, max_m, Ka, Nb) + 256;
+    if (m > w) w = m;
+  }
+  return w;
+}
+
+int temp_linear_tn_multi(int count, const TempLinearProblem* probs, int Ka, int Nb, int lda, int ldb, int ldc, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (count < 0 || Ka <= 0 || Nb <= 0 || (count > 0 && !probs)) return TEMP_E_BADARG;
+  int max_m = 0;
+  for (int i = 0; i < count; ++i) {
+    if (probs[i].M < 0 || !probs[i].C || (probs[i].M > 0 && (!probs[i].A || !probs[i].B))) return TEMP_E_BADARG;
+    if (probs[i].M > max_m) max_m = probs[i].M;
+  }
+  if (count == 0) return TEMP_OK;
+  if (!workspace || workspace_bytes < temp_linear_tn_multi_workspace(count, max_m, Ka, Nb)) return TEMP_E_WORKSPACE;
+  for (int i0 = 0; i0 < count; i0 += TN_MAXP) {
+    const int n = count - i0 < TN_MAXP ? count - i0 : TN_MAXP;
+    int Ms[TN_MAXP];
+    const float *As[TN_MAXP], *Bs[TN_MAXP];
+    float* Cs[TN_MAXP];
+    for (int i = 0; i < n; ++i) { Ms[i] = probs[i0 + i].M; As[i] = probs[i0 + i].A; Bs[i] = probs[i0 + i].B; Cs[i] = probs[i0 + i].C; }
+    int rc = gemm_tn_multi(n, Ms, Ka, Nb, As, lda, Bs, ldb, Cs, ldc, workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc == TEMP_E_UNSUPPORTED) {                                  // shapes of the split-operand kernels etc.: one product at a time
+      for (int i = 0; i < n; ++i) {
+        rc = gemm_tn(Ms[i], Ka, Nb, As[i], lda, Bs[i], ldb, Cs[i], ldc, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc != TEMP_OK) return rc;
+      }
+    } else if (rc != TEMP_OK) {
+      return rc;
+    }
+  }
+  return TEMP_OK;
 }
 
 int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* cand, float* loss_rows, float* lse_rows, void* stream) {

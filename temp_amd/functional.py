@@ -252,8 +252,12 @@ class _BatchedLinkPredictionFn(torch.autograd.Function):
                 d_big[b * N:(b + 1) * N].copy_(be.linear(dst, q[a0:a1], False))               # d_all = d_scores^T . q
         else:
             be.linear_multi([d_scores[a0:a1] for _, a0, a1 in live], [big[b * N:(b + 1) * N] for b, _, _ in live], False, d_q)
-            for b, a0, a1 in live:
-                be.linear_tn(d_scores[a0:a1], q[a0:a1], out=d_big[b * N:(b + 1) * N])
+            if hasattr(be, "linear_tn_multi"):                                                # d_all_b = d_scores_b^T . q_b, one launch
+                be.linear_tn_multi([d_scores[a0:a1] for _, a0, a1 in live], [q[a0:a1] for _, a0, a1 in live],
+                                   [d_big[b * N:(b + 1) * N] for b, _, _ in live])
+            else:
+                for b, a0, a1 in live:
+                    be.linear_tn(d_scores[a0:a1], q[a0:a1], out=d_big[b * N:(b + 1) * N])
         dk, dr = be.bilinear_query_bwd(ctx.kind, ent_rows, inp["known"], rel, inp["rel"], inp["is_tail"], d_q)
         d_ent = be.segment_sum_rows(dk, inp["known_inv"][0], inp["known_inv"][1], ent_rows.shape[0])
         d_rel = be.segment_sum_rows(dr, inp["rel_inv"][0], inp["rel_inv"][1], rel.shape[0])

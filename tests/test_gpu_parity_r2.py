@@ -577,11 +577,48 @@ def test_linear_multi_long_k_vs_fp64(hip_backend, Ms, K, N):
     again = torch.full_like(out, float("nan"))
     hip_backend.linear_multi(a, b, False, again)
     assert torch.equal(out, again)
-    r = 0
-    for ai, bi in zip(a, b):
-        want = (ai.double() @ bi.double())
-        scale = (ai.double().abs() @ bi.double().abs())
-        got = out[r:r + ai.shape[0]].double()
-        assert torch.isfinite(got).all()
-        assert float(((got - want).abs() / scale.clamp_min(1e-30)).max()) < 2e-6 if ai.shape[0] else True
-        r += ai.shape[0]
+    # outputs that do NOT follow each other in memory (problems given in reverse order): per-problem reductions
+    rev = torch.full_like(out, float("nan"))
+    from temp_amd import _lib as L
+    import ctypes
+    arr = (L.TempLinearProblem * len(Ms))()
+    starts = [sum(Ms[:i]) for i in range(len(Ms))]
+    for j, i in enumerate(reversed(range(len(Ms)))):
+        arr[j].M, arr[j].A, arr[j].B, arr[j].C = Ms[i], a[i].data_ptr(), b[i].data_ptr(), rev.data_ptr() + starts[i] * N * 4
+    L.check(hip_backend.lib.temp_linear_multi(len(Ms), arr, N, K, K, N, 0, N, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "multi")
+    torch.cuda.synchronize()                    # (the launches group the problems differently: other slice cuts, so not bit-equal to `out`)
+    for res in (out, rev):
+        r = 0
+        for ai, bi in zip(a, b):
+            want = (ai.double() @ bi.double())
+            scale = (ai.double().abs() @ bi.double().abs())
+            got = res[r:r + ai.shape[0]].double()
+            assert torch.isfinite(got).all()
+            assert float(((got - want).abs() / scale.clamp_min(1e-30)).max()) < 2e-6 if ai.shape[0] else True
+            r += ai.shape[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ms,Ka,Nb", [
+    ([184, 120, 0, 200, 184, 96, 184, 150], 7128, 200),     # ICEWS-like d_all_b = d_scores_b^T . q_b: eight windows, one launch, direct write
+    ([400, 400, 380], 500, 200),                             # few row blocks: slices + one reduction per problem
+    ([6000, 6000], 500, 200),                                # rows of the split-operand kernels: falls back to one product at a time
+    ([64] * 11, 232, 40),                                    # more problems than one launch takes, narrow output
+])
+def test_linear_tn_multi_vs_fp64(hip_backend, Ms, Ka, Nb):
+    g = torch.Generator().manual_seed(11)
+    a = [torch.randn(m, Ka, generator=g).cuda() for m in Ms]
+    b = [torch.randn(m, Nb, generator=g).cuda() for m in Ms]
+    outs = [torch.full((Ka, Nb), float("nan"), device="cuda") for _ in Ms]
+    hip_backend.linear_tn_multi(a, b, outs)
+    again = [torch.full((Ka, Nb), float("nan"), device="cuda") for _ in Ms]
+    hip_backend.linear_tn_multi(a, b, again)
+    for ai, bi, o, o2 in zip(a, b, outs, again):
+        assert torch.equal(o, o2)
+        want = ai.double().t() @ bi.double()
+        scale = ai.double().abs().t() @ bi.double().abs()
+        assert torch.isfinite(o).all()
+        if ai.shape[0]:
+            assert float(((o.double() - want).abs() / scale.clamp_min(1e-30)).max()) < 2e-6
+        else:
+            assert float(o.abs().max()) == 0.0
