@@ -374,12 +374,26 @@ int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int 
 // count <= TN_MAXP products out_i[Ka,Nb] = A_i[M_i,Ka]^T . B_i[M_i,Nb] (same Ka, Nb, leading dimensions) in one launch of the
 // fp32 kernel; with one slice per problem the blocks write out_i directly (ldo == Nb), else partials + one reduction per problem.
 // Returns TEMP_E_UNSUPPORTED for shapes it does not take (the caller then loops over gemm_tn).
+// slices per problem of the split-operand multi launch: enough blocks for the chip over all problems, a multiple of 8 (XCD mapping)
+static int tn_bx8_multi_slices(int count, int max_m, int kab8) {
+  int S = ceil_div(256, (count > 0 ? count : 1) * kab8);
+  S = (S + 7) / 8 * 8;
+  const int cap = tn_bx8_slices(max_m, kab8);
+  if (S > cap) S = cap;
+  return S < 1 ? 1 : S;
+}
+
 size_t gemm_tn_multi_workspace(int count, int max_m, int Ka, int Nb) {
   const TnCfg c = tn_cfg(max_m, Ka, Nb);
   long long s = 256 / ((long long)c.kab * c.nbb * (count > 0 ? count : 1));
   if (s > c.slices) s = c.slices;
   if (s < 1) s = 1;
-  return s > 1 ? align_up((size_t)count * s * Ka * Nb * sizeof(float), 256) : 0;
+  size_t w = s > 1 ? align_up((size_t)count * s * Ka * Nb * sizeof(float), 256) : 0;
+  if (tn_bx8_ok(Ka)) {                                          // the split-operand kernel's launch (large M)
+    const size_t wb = align_up((size_t)count * tn_bx8_multi_slices(count, max_m, ceil_div(Ka, 256)) * Ka * Nb * sizeof(float), 256);
+    if (wb > w) w = wb;
+  }
+  return w;
 }
 int gemm_tn_multi(int count, const int* Ms, int Ka, int Nb, const float* const* As, int lda, const float* const* Bs, int ldb, float* const* outs,
                   int ldo, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -389,7 +403,24 @@ int gemm_tn_multi(int count, const int* Ms, int Ka, int Nb, const float* const* 
   for (int i = 0; i < count; ++i) max_m = Ms[i] > max_m ? Ms[i] : max_m;
   if (max_m <= 0) return TEMP_E_UNSUPPORTED;
   const TnCfg c = tn_cfg(max_m, Ka, Nb);
-  if (c.split == 2 && c.nbb == 1 && tn_bx_ok(max_m, Ka, Nb, lda, ldb)) return TEMP_E_UNSUPPORTED;   // large M: the split-operand kernels
+  if (c.split == 2 && c.nbb == 1 && tn_bx_ok(max_m, Ka, Nb, lda, ldb)) {                             // large M: the split-operand kernel
+    if (!tn_bx8_ok(Ka)) return TEMP_E_UNSUPPORTED;
+    const int kab8 = ceil_div(Ka, 256), S = tn_bx8_multi_slices(count, max_m, kab8);
+    if (!ws || ws_bytes < gemm_tn_multi_workspace(count, max_m, Ka, Nb)) return TEMP_E_WORKSPACE;
+    int rps = ceil_div(max_m, S);
+    rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
+    TnBxBatch b;
+    for (int i = 0; i < 8; ++i) {
+      const int k = i < count ? i : 0;
+      b.M[i] = i < count ? Ms[k] : 0; b.A[i] = As[k]; b.B[i] = Bs[k]; b.part[i] = (float*)ws + (size_t)k * S * Ka * Nb;
+    }
+    const int bpp = 8 * ceil_div(S, 8) * kab8, nt = ceil_div(Nb, 32);
+    if (nt == 7) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<7>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
+    else if (nt == 6) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<6>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
+    else TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<5>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
+    for (int i = 0; i < count; ++i) reduce_slices(S, (size_t)Ka * Nb, Nb, (float*)ws + (size_t)i * S * Ka * Nb, outs[i], ldo, st);
+    return launch_status();
+  }
   if (!(c.split == 2 && c.nt == 7) && !(c.split == 1 && (c.nt == 7 || c.nt == 4 || c.nt == 2 || c.nt == 1))) return TEMP_E_UNSUPPORTED;
   if ((long long)max_m * (lda > ldb ? lda : ldb) >= (1ll << 31)) return TEMP_E_UNSUPPORTED;
   long long s = 256 / ((long long)c.kab * c.nbb * count);

@@ -242,17 +242,16 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx(int M, int Ka, int 
 // accumulator registers), so an element of B is split once per 256 rows of Ka instead of once per 128 and every wave both
 // stages (one 8 x 2 item per thread) and multiplies -- 2.4 instead of 8 VALU instructions per MFMA on the staging waves.
 // VAR as above.
-template <int NT, int VAR = 0>
-__global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
-                                                             const float* __restrict__ B, int ldb, int rows_per_slice, int kab,
-                                                             int n_slices, float* __restrict__ part, float* __restrict__ bias_part,
-                                                             unsigned long long* dbg = nullptr) {
+template <int NT, int VAR>
+__device__ __forceinline__ void tn_bx8_body(int M, int Ka, int Nb, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                            int rows_per_slice, int kab, int n_slices, float* __restrict__ part,
+                                            float* __restrict__ bias_part, unsigned long long* dbg, const int block_id) {
   constexpr int ITEMS_A = 128 * 2, ITEMS_B = NT * 16 * 2, ITEMS = ITEMS_A + ITEMS_B;   // (column pair, m-octet)
   constexpr int LDS_ITEMS = (8 + NT) * 192;                   // 16-byte fragment items of a slab: A tiles, then B tiles
   static_assert(ITEMS <= TNBX_THREADS, "one staging item per thread");
   __shared__ __attribute__((aligned(16))) bx_u32x4 Ls[2][LDS_ITEMS];
   // blocks b, b + 8, ... share an XCD: the kab row blocks of an m-slice are neighbours there
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int xcd = block_id & 7, q = block_id >> 3;
   const int kb = q % kab, slice = (q / kab) * 8 + xcd;
   if (slice >= n_slices) return;                              // uniform
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: wave-level branches below)
@@ -437,7 +436,7 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int
     if constexpr (VAR & 64) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
       if ((threadIdx.x & 63) == 0) {
-        unsigned long long* o = dbg + 4 * (blockIdx.x * 8 + wave);
+        unsigned long long* o = dbg + 4 * (block_id * 8 + wave);
         o[0] = t1 - clk_t0; o[1] = clk_r0; o[2] = r1; o[3] = (unsigned long long)nslabs;
       }
     }
@@ -458,6 +457,25 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int
     }
   };
   run(std::integral_constant<int, NT>());
+}
+
+template <int NT, int VAR = 0>
+__global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int Nb, const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ B, int ldb, int rows_per_slice, int kab,
+                                                             int n_slices, float* __restrict__ part, float* __restrict__ bias_part,
+                                                             unsigned long long* dbg = nullptr) {
+  tn_bx8_body<NT, VAR>(M, Ka, Nb, A, lda, B, ldb, rows_per_slice, kab, n_slices, part, bias_part, dbg, (int)blockIdx.x);
+}
+
+// Several products of one shape class in ONE launch (gemm_kernels.hip: gemm_tn_multi): blocks_per_problem (a multiple of 8, so a
+// block's XCD is the same as in a launch of its own) consecutive blocks per problem.
+struct TnBxBatch { int M[8]; const float* A[8]; const float* B[8]; float* part[8]; };
+template <int NT>
+__global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8_multi(TnBxBatch b, int Ka, int Nb, int lda, int ldb, int rows_per_slice, int kab,
+                                                                   int n_slices, int blocks_per_problem) {
+  const int prob = blockIdx.x / blocks_per_problem;
+  tn_bx8_body<NT, 0>(b.M[prob], Ka, Nb, b.A[prob], lda, b.B[prob], ldb, rows_per_slice, kab, n_slices, b.part[prob], nullptr, nullptr,
+                     (int)blockIdx.x - prob * blocks_per_problem);
 }
 
 // shapes this kernel takes: one column block of 5..7 tiles (the split-2 configuration of tn_cfg), even pairs
