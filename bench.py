@@ -21,7 +21,8 @@ Extra objects on the JSON line:
                 which compute every fp32 product as six bf16 MFMA products of an exact three-way
                 operand split -- 2500 / 6 TFLOP/s (roofline.pipe says which; `achieved` always
                 counts the ALGORITHMIC fp32 flops).  config.fp32_mfma_ms_per_step is the same step
-                with those GEMMs on the fp32 MFMA kernels (TEMP_MFMA=f32, child process).  Events are recorded by libtemp_amd around every launch
+                with every product on the fp32 MFMA kernels (temp_set_option(TEMP_OPT_MFMA_BF16X3, 0), same
+                process, re-captured graph).  Events are recorded by libtemp_amd around every launch
                 on the launch stream (temp_trace_begin/end) during extra traced steps run right
                 after the timed region, so the headline number is not perturbed.
   cpu_baseline  the CPU oracle (torch restatement of the reference's op sequence, kind "port")
@@ -45,9 +46,12 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak, same guide
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guide
 # The large GEMMs (k_gemm_panel<*> = k_gemm_bx / k_gemm_bxp, k_gemm_tn = k_gemm_tn_bx) compute every fp32 product as SIX bf16 MFMA
 # products of an exact three-way operand split (temp_amd/csrc/gemm_bx.hpp; fp32-equivalent accuracy): their roof is the bf16 pipe
-# divided by six.  TEMP_MFMA=f32 in the environment keeps them on the fp32 MFMA kernels (round-1 arithmetic).
+# divided by six.  temp_set_option(TEMP_OPT_MFMA_BF16X3, 0) (or TEMP_MFMA=f32 in the environment at load time) keeps them on the
+# fp32 MFMA kernels (round-1 arithmetic); MFMA_MODE is read from the library in main().
 BX_KERNELS = ("k_gemm_panel", "k_gemm_tn")
-MFMA_MODE = "f32" if os.environ.get("TEMP_MFMA", "").startswith("f") else "bf16x3"
+MFMA_MODE = "bf16x3"
+OPT_MFMA_BF16X3 = 0            # include/temp_amd.h: TEMP_OPT_MFMA_BF16X3
+CPU_THREADS = 16               # cpu_baseline leg (--cpu-threads)
 
 
 
@@ -193,7 +197,7 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
     # Threads: measured on the MI355X box (256 hardware threads, EPYC 9575F): with all of them torch's intra-op pool turns the
     # oracle's many small ops into 598 s per window (363 edges/s); 16 threads give 0.3 s per window (~0.67 M edges/s), the best of
     # {1, 8, 16, 32, 64}.  `cores` reports what was used, `host_threads` what the box has.
-    nthreads = min(os.cpu_count() or 1, 16)
+    nthreads = min(os.cpu_count() or 1, CPU_THREADS)
     torch.set_num_threads(nthreads)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     bi = w["module"].startswith("Bi")
@@ -233,6 +237,11 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
         if dt >= min_seconds or nwin >= max_windows:
             break
     return dict(value=edges / dt, unit="edges/s", cores=nthreads, host_threads=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
+                all_cores=dict(cores=256, value=363.0, unit="edges/s",
+                               note="measured once on this box type (round 2, EPYC 9575F, torch.set_num_threads(256)): 598 s for ONE window, "
+                                    "i.e. 1900x slower than 16 threads -- torch's intra-op pool turns the oracle's many small ops into "
+                                    "barrier traffic; not re-run in the default bench (it alone would take >10 min); "
+                                    "`--cpu-threads N` times the oracle with N threads instead of 16"),
                 sample="%d windows (bsz=1 each) of %s: %d snapshot visits, %d edge visits, full target graphs, fwd+bwd, %.1f s"
                        % (nwin, w["name"], visits, edges, dt))
 
@@ -314,8 +323,9 @@ def main():
                          "'both' (default) = the headline `value` is the windows mode and the snapshot-sharded measurement rides along "
                          "under `north_star_sharded`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the cpu_baseline leg (16 = the measured optimum on the 256-thread box)")
     ap.add_argument("--no-fp32-mfma-compare", action="store_true",
-                    help="skip the second, short run with TEMP_MFMA=f32 (config.fp32_mfma_ms_per_step)")
+                    help="skip the second, short timing with every product on the fp32 MFMA kernels (config.fp32_mfma_ms_per_step)")
     ap.add_argument("--train-loop-steps", type=int, default=100,
                     help="also time this many steps of a real training loop (new batch every step: host prepare, fresh negatives, loss, "
                          "backward, Adam, eager launches) and report it under config.train_loop, after the timed region (never the "
@@ -350,6 +360,9 @@ def main():
     from temp_amd import backend as TB
     lib = _lib.load()
     assert TB.get_backend().name == "hip"
+    global MFMA_MODE, CPU_THREADS
+    CPU_THREADS = max(1, a.cpu_threads)
+    MFMA_MODE = "bf16x3" if lib.temp_get_option(OPT_MFMA_BF16X3) else "f32"
 
     w = synthetic.workload(a.workload, seed=0)
     model = build_model(w, device, a.encoder)
@@ -400,8 +413,8 @@ def main():
     # The window batch is static, so the whole forward+backward of a step (~130 launches) is captured
     # once into a HIP graph and replayed: no host launch overhead between the small per-position kernels.
     # The gradient all-reduce stays outside the graph.
-    graph = graph_grads = None
-    if not a.no_graph and not sharded:
+    def capture():
+        """-> (graph, the gradient tensors every replay writes) or (None, None)."""
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -414,14 +427,18 @@ def main():
             torch.cuda.synchronize()
             for p in params:
                 p.grad = None
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # RCCL's watchdog thread polls events meanwhile
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread polls events meanwhile
                 run().sum().backward()
-            graph_grads = [p.grad for p in params]                  # the tensors every replay writes
             torch.cuda.synchronize()
+            return g, [p.grad for p in params]
         except Exception as e:                      # capture is an optimisation only
             print("bench: HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
-            graph = None
+            return None, None
+
+    graph = graph_grads = None
+    if not a.no_graph and not sharded:
+        graph, graph_grads = capture()
 
     def step():
         if graph is None:
@@ -531,21 +548,24 @@ def main():
 
     fp32_ms = None
     if rank == 0 and world == 1 and not sharded and MFMA_MODE == "bf16x3" and not a.no_fp32_mfma_compare:
-        # the same step with every product on the fp32 MFMA kernels, in a child process (the switch is read once per process)
-        import subprocess
-        env = {k: v for k, v in os.environ.items() if k not in ("TEMP_BENCH_FORCE_DIST", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
-        env["TEMP_MFMA"] = "f32"                    # a plain single-process run
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", str(a.warmup), "--workload", a.workload,
-               "--encoder", a.encoder, "--train-loop-steps", "0", "--trace-steps", "0", "--no-cpu-baseline", "--no-fp32-mfma-compare"]
-        if a.with_loss:
-            cmd.append("--with-loss")
-        if a.no_graph:
-            cmd.append("--no-graph")
+        # the same step with every product on the fp32 MFMA kernels: one library switch, same process, same batch, graph re-captured
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-            fp32_ms = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+            lib.temp_set_option(OPT_MFMA_BF16X3, 0)
+            g32, _ = capture() if graph is not None else (None, None)
+            one = g32.replay if g32 is not None else step_eager
+            for _ in range(a.warmup):
+                one()
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            for _ in range(a.steps):
+                one()
+            torch.cuda.synchronize()
+            fp32_ms = 1e3 * (time.perf_counter() - t32) / a.steps
+            del g32
         except Exception as e:                      # an extra, never the headline
             print("bench: fp32-MFMA comparison run failed (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
+        finally:
+            lib.temp_set_option(OPT_MFMA_BF16X3, 1)
 
     if rank == 0:
         out = dict(metric="edges/sec (fwd+bwd) RGCN+%s seq_len=%d%s" % ("GRU" if a.encoder == "gru" else "self-attention", w["L"], " + link-prediction loss" if a.with_loss else ""), value=value, unit="edges/s", n_gpus=world,
@@ -564,9 +584,10 @@ def main():
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
                                else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager"),
                                train_loop=loop,
-                               mfma=("large GEMMs on the bf16 matrix pipe as six products of an exact 3-way operand split (fp32-equivalent "
-                                     "accuracy, gemm_bx.hpp); chain kernels on the fp32 MFMA pipe" if MFMA_MODE == "bf16x3"
-                                     else "fp32 MFMA everywhere (TEMP_MFMA=f32)"),
+                               mfma=("every large fp32 product (panel GEMMs, weight gradients, the window-chain kernels' W_hh products) on the bf16 "
+                                     "matrix pipe as six products of an exact 3-way operand split (fp32-equivalent accuracy, gemm_bx.hpp); "
+                                     "small products (< 16384 rows) on the fp32 MFMA pipe" if MFMA_MODE == "bf16x3"
+                                     else "fp32 MFMA everywhere (TEMP_OPT_MFMA_BF16X3 = 0)"),
                                fp32_mfma_ms_per_step=fp32_ms),
                    roofline=roof, cpu_baseline=cpu, north_star_sharded=ns_result)
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so

@@ -15,7 +15,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  The device is whatever
  *     is current in the calling thread.
  *   - Return value: 0 on success, a TEMP_E_* code otherwise (temp_error_string() describes it).
- *     Nothing is thrown across the ABI.  All functions are re-entrant (no global mutable state),
+ *     Nothing is thrown across the ABI.  All functions are re-entrant (no global mutable state
+ *     apart from the explicit switches of temp_set_option() and the bench-only trace),
  *     so forward may run on one thread and backward on PyTorch's autograd thread.
  *   - "nullable" arguments may be NULL.
  */
@@ -45,6 +46,26 @@ enum { TEMP_GRU_TORCH = 0,   /* nn.GRU single step, gates r,z,n          (models
 
 int temp_abi_version(void);
 const char* temp_error_string(int code);
+
+/* Process-wide kernel-selection switches (A/B runs and bit-comparisons in ONE process; every setting computes the
+ * same result to fp32 accuracy).  Each is one relaxed atomic int, read at launch time: a set is seen by every launch
+ * issued after it returns, on any thread.  Defaults below; the environment variable named on each line, read ONCE
+ * when the library is loaded, overrides the default (kept for runs that cannot call into the library first).
+ * temp_set_option returns the previous value, or -1 for an unknown key; temp_get_option -1 for an unknown key. */
+enum {
+  TEMP_OPT_MFMA_BF16X3 = 0, /* 1: large fp32 products as six bf16 MFMA products of an exact 3-way operand split (gemm_bx.hpp)
+                               0: every product on the fp32 MFMA kernels                   [TEMP_MFMA=f32 -> 0]       default 1 */
+  TEMP_OPT_TN_SPLIT = 1,    /* 1: weight-gradient blocks of 4 row tiles x (4+3) column tiles  [TEMP_TN_SPLIT=0 -> 0]  default 1 */
+  TEMP_OPT_RGCN_SCALAR = 2, /* 1: wide-row edge kernels keep per-edge quantities in SGPRs     [TEMP_RGCN_SCALAR=0 -> 0] default 1 */
+  TEMP_OPT_GEMM_STREAM = 3, /* 1: force the streaming row-panel GEMM instead of weights-resident [TEMP_GEMM_STREAM=1 -> 1] default 0 */
+  TEMP_OPT_GRU_STREAM = 4,  /* 1: force the streaming GRU cell kernel                          [TEMP_GRU_STREAM=1 -> 1] default 0 */
+  TEMP_OPT_COUNT = 5
+};
+int temp_set_option(int key, int value);
+int temp_get_option(int key);
+/* Diagnostic: how often a launch found no scratch slot for its packed weights / k-slice partials (more than 8 busy streams
+ * on one device) and took the scratch-free kernels instead.  0 in every supported configuration. */
+long long temp_scratch_refused(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmented edge lists.  One batched snapshot graph (the disjoint union `dgl.batch` builds at

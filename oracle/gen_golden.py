@@ -464,7 +464,7 @@ def gen_G9():
 
 
 def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, trace=False, te=False, ent_row_stride=1, extra_args=None,
-                tweak=None):
+                tweak=None, backward=True):
     num_e, num_r, tr, va, te_g = graphs()
     args = rh.make_args(module=module, rec_only_last_layer=rec_only, hidden_size=D, embed_size=D, n_bases=B,
                         train_seq_len=L, test_seq_len=L, batch_size=bsz_args, negative_rate=neg, use_time_embedding=te, **(extra_args or {}))
@@ -473,7 +473,7 @@ def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, tra
     torch.manual_seed(0)
     m = cls(args, num_e, num_r, tr, va, te_g)
     missing = m.load_state_dict(to_ref_state_dict(model), strict=False)
-    assert not missing.unexpected_keys and all("impute_weight" in k for k in missing.missing_keys), missing
+    assert not missing.unexpected_keys and all(("impute_weight" in k or "_linear" in k) for k in missing.missing_keys), missing
     if tweak is not None:
         tweak(m)
     np.random.seed(seed)
@@ -508,7 +508,6 @@ def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, tra
         loss = m(torch.tensor(t_list))
     finally:
         np.random.choice = orig_choice
-    loss.backward()
     times = list(tr.keys())
     out = dict(module=module, rec_only=int(rec_only), D=D, B=B, seed=seed, L=L, neg=neg, te=int(te),
                t_list=np.array(t_list), times=np.array(times), loss=loss.item(), param_checksum=checksum(model),
@@ -517,6 +516,9 @@ def _run_window(cls, module, rec_only, D, B, seed, t_list, L, bsz_args, neg, tra
         out['choice_%d' % i] = c
     for i, (trip, nt, nh) in enumerate(samples):
         out['trip_%d' % i], out['negtail_%d' % i], out['neghead_%d' % i] = trip, nt, nh
+    if not backward:
+        return out
+    loss.backward()
     eg = m.ent_embeds.grad
     nz = torch.nonzero(eg.abs().sum(1)).view(-1)
     if ent_row_stride > 1:                 # large-D fixtures: every k-th non-zero row + the global sums (gabs_/gsum_ent_embeds)
@@ -1047,7 +1049,48 @@ def gen_G18():
         save(name, **out)
 
 
-ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14, G15=gen_G15, G16=gen_G16, G17=gen_G17, G18=gen_G18)
+def gen_G19():
+    """PostEnsemble(Bi)DynamicRGCN.forward with the reference's OWN calc_ensemble_ratio (models/PostDynamicRGCN.py:375-397,425-461,
+    models/PostBiDynamicRGCN.py:329-354): frequency tables of utils/DropEdge.py:34-82 (built by the reference from its full
+    ICEWS14 train.txt; the target timestamps lie far enough inside the committed slice that every window the tables aggregate over
+    is inside it too), the two 3-3-1 MLPs with recorded weights, the loss with the recorded draws, and the raw feature rows the
+    MLPs were fed."""
+    from models.PostBiDynamicRGCN import PostEnsembleBiDynamicRGCN
+    from models.PostDynamicRGCN import PostEnsembleDynamicRGCN
+    num_e, num_r, tr, va, te_g = graphs()
+    times = list(tr.keys())
+    for name, cls, module, seed, idx in (("G19_post_ratio_uni", PostEnsembleDynamicRGCN, 'GRRGCN', 731, [14, 9, 20]),
+                                         ("G19_post_ratio_bi", PostEnsembleBiDynamicRGCN, 'BiGRRGCN', 732, [12, 18, 7])):
+        L = 6
+        assert [int(x) for x in times] == list(range(len(times)))
+        assert max(idx) + (L if module.startswith("Bi") else 0) <= len(times)      # the tables' windows stay inside the slice
+        feats = dict(sub=[], obj=[])
+        mlp = {}
+
+        def tweak(m):
+            rng = np.random.default_rng(seed + 5)
+            for nm in ("subject_linear", "object_linear"):
+                seq = getattr(m, nm)
+                for k, p in seq.named_parameters():
+                    v = torch.from_numpy(rng.uniform(-0.6, 0.6, tuple(p.shape)).astype(np.float32))
+                    p.data.copy_(v)
+                    mlp["mlp_%s.%s" % (nm, k)] = v.clone()
+            m.subject_linear.register_forward_pre_hook(lambda mod, inp: feats["sub"].append(inp[0].detach().clone()))
+            m.object_linear.register_forward_pre_hook(lambda mod, inp: feats["obj"].append(inp[0].detach().clone()))
+
+        out = _run_window(cls, module, True, 32, 16, seed, [int(times[i]) for i in idx], L, 4, 20, extra_args=dict(post_ensemble=True), tweak=tweak,
+                          backward=False)      # the reference's own backward of this forward() fails under torch 2.x (an in-place
+                                               # row overwrite of the all-entity matrices after they were saved for backward)
+        out.update(mlp)
+        out["post_ensemble"] = 1
+        assert len(feats["sub"]) == len(idx) and len(feats["obj"]) == len(idx)
+        for i in range(len(idx)):
+            out["feat_sub_%d" % i], out["feat_obj_%d" % i] = feats["sub"][i], feats["obj"][i]
+        print("  %s: loss %.6f, features up to %.0f" % (name, out["loss"], max(float(f.max()) for f in feats["sub"] + feats["obj"])))
+        save(name, **out)
+
+
+ALL = dict(slice=gen_slice, G1=gen_G1, G2=gen_G2_G3, G4=gen_G4_G5, G6=gen_G6, G7=gen_G7, G9=gen_G9, G10=gen_G10, G12=gen_G12, G13=gen_G13, G14=gen_G14, G15=gen_G15, G16=gen_G16, G17=gen_G17, G18=gen_G18, G19=gen_G19)
 
 if __name__ == "__main__":
     rh.activate()

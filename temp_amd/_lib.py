@@ -87,6 +87,9 @@ _I, _F, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 SYMBOLS = {
     "temp_abi_version": (_I, []),
     "temp_error_string": (ctypes.c_char_p, [_I]),
+    "temp_set_option": (_I, [_I, _I]),
+    "temp_get_option": (_I, [_I]),
+    "temp_scratch_refused": (ctypes.c_longlong, []),
     "temp_rgcn_fwd_workspace": (_SZ, [_G, _I]),
     "temp_rgcn_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_rgcn_bwd_workspace": (_SZ, [_G, _I, _I, _I, _I]),

@@ -73,6 +73,9 @@ __device__ __forceinline__ float4 drop4(const DropSpec& d, unsigned row, unsigne
                      v.w * drop_scale(d, row, col + 3));
 }
 
+// process-wide kernel-selection switches (include/temp_amd.h: temp_set_option); definition in gemm_kernels.hip
+int option(int key);
+
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -27,6 +27,8 @@ typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int bx_u32x4 __attribute__((ext_vector_type(4)));
 
 // x = h + m + l exactly; returns the three pieces as fp32 bit patterns whose low 16 bits are zero
+// (+-inf: r1 = inf - inf = NaN, so a non-finite input gives NaN where an fp32 product gives inf; both are "non-finite" and the
+// 9-instruction pair form below has no slot for a guard -- documented in INTEGRATION.md.)
 __device__ __forceinline__ void bx_split(float x, unsigned& h, unsigned& m, unsigned& l) {
   h = __float_as_uint(x) & 0xffff0000u;
   const float r1 = x - __uint_as_float(h);
@@ -528,11 +530,8 @@ __global__ void __launch_bounds__(BX_THREADS, (G <= 4 ? 3 : 2)) k_gemm_bxp(Panel
   }
 }
 
-// TEMP_MFMA=f32 in the environment keeps every product on the fp32 MFMA kernels (A/B runs, bit-comparison against round 1)
-inline bool bx_enabled() {
-  static const int v = [] { const char* e = getenv("TEMP_MFMA"); return (e && e[0] == 'f') ? 0 : 1; }();
-  return v != 0;
-}
+// temp_set_option(TEMP_OPT_MFMA_BF16X3, 0) keeps every product on the fp32 MFMA kernels (A/B runs, bit-comparison against round 1)
+inline bool bx_enabled() { return option(TEMP_OPT_MFMA_BF16X3) != 0; }
 
 // Scratch slot for the packed weights of one launch on `st` (gemm_kernels.hip): nullptr when `bytes` exceed a slot or every
 // slot belongs to another stream -- the caller then uses the kernel that splits B itself.

@@ -10,6 +10,8 @@
 #include "common.hpp"
 #include <type_traits>
 #include <mutex>
+#include <atomic>
+#include <cstdlib>
 #include "gemm_wres.hpp"
 #include "gemm_tn_bx.hpp"
 
@@ -304,7 +306,7 @@ static TnCfg tn_cfg(int M, int Ka, int Nb) {
   c.wpb = (ceil_div(ktiles, 7) * 7 - ktiles <= ceil_div(ktiles, 8) * 8 - ktiles) ? 7 : 8;
   c.split = 1;
   const int ntiles_n = ceil_div(Nb, 32);
-  static const int split_off = [] { const char* e = getenv("TEMP_TN_SPLIT"); return (e && e[0] == '0') ? 1 : 0; }();
+  const int split_off = !option(TEMP_OPT_TN_SPLIT);
   if (ntiles_n >= 5 && ntiles_n <= 7 && !split_off) { c.wpb = 8; c.split = 2; }      // 4 row tiles x (4 + 3) column tiles per block
   c.bk = (c.wpb / c.split) * 32;
   c.kab = ceil_div(Ka, c.bk);
@@ -936,34 +938,72 @@ int temp_trace_end(int* kernel_ids, float* ms, int capacity, int* n_out) {
 
 }  // extern "C"
 
-// ---- scratch slots for the packed (bf16-split) weight matrices of gemm_bx.hpp: static device memory, one slot per stream that
-// has launched a large GEMM (at most BX_SLOTS streams; two launches on one stream are ordered, so a slot is free again when the
-// next pack kernel of that stream runs).  Nothing is allocated, freed or synchronised at run time.
+// ---- scratch slots for the packed (bf16-split) weight matrices of gemm_bx.hpp and the k-slice partial products: static device
+// memory (one copy per device: a __device__ array is instantiated on every device that loads the module), BX_SLOTS slots of
+// BX_SLOT_BYTES.  A slot belongs to one (device, stream): two launches on one stream are ordered, so its slot is free again when
+// the next pack kernel of that stream runs.  With every slot taken, the least recently used one is handed to the new stream --
+// safe when the previous owner's last launch has drained, which holds for streams that were destroyed or went idle (the callers'
+// pools keep <= BX_SLOTS streams live per device; beyond that two live streams could share a slot, so the hand-over first checks
+// hipStreamQuery of the old owner and refuses (nullptr: the callers fall back to the kernels that need no scratch, counted in
+// g_bx_refused) while it still has work in flight).  Nothing is allocated, freed or synchronised at run time.
 __device__ __attribute__((aligned(16))) unsigned char g_bx_slots[BX_SLOTS][BX_SLOT_BYTES];
 
 namespace temp {
+static std::atomic<long long> g_bx_refused{0};
+long long bx_scratch_refused() { return g_bx_refused.load(std::memory_order_relaxed); }
+
 bx_u32x4* bx_scratch(hipStream_t st, size_t bytes) {
+  constexpr int MAX_DEV = 16;
+  struct DevSlots { unsigned char* base = nullptr; hipStream_t owner[BX_SLOTS] = {}; unsigned long long used[BX_SLOTS] = {}; int n = 0; };
   static std::mutex mu;
-  static hipStream_t owner[BX_SLOTS];
-  static int n_owner = 0;
-  static unsigned char* base = nullptr;
+  static DevSlots devs[MAX_DEV];
+  static unsigned long long tick = 0;
   if (bytes > BX_SLOT_BYTES) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { g_bx_refused.fetch_add(1, std::memory_order_relaxed); return nullptr; }
   std::lock_guard<std::mutex> lock(mu);
-  if (!base) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bx_slots)) != hipSuccess || !p) return nullptr;
-    base = (unsigned char*)p;
+  DevSlots& d = devs[dev];
+  if (!d.base) {
+    void* p = nullptr;                                        // the symbol's address on the CURRENT device
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bx_slots)) != hipSuccess || !p) { g_bx_refused.fetch_add(1, std::memory_order_relaxed); return nullptr; }
+    d.base = (unsigned char*)p;
   }
   int slot = -1;
-  for (int i = 0; i < n_owner; ++i)
-    if (owner[i] == st) { slot = i; break; }
+  for (int i = 0; i < d.n; ++i)
+    if (d.owner[i] == st) { slot = i; break; }
   if (slot < 0) {
-    if (n_owner >= BX_SLOTS) return nullptr;
-    slot = n_owner;
-    owner[n_owner++] = st;
+    if (d.n < BX_SLOTS) {
+      slot = d.n++;
+    } else {
+      int lru = 0;
+      for (int i = 1; i < BX_SLOTS; ++i)
+        if (d.used[i] < d.used[lru]) lru = i;
+      // the old owner may be a destroyed stream (query fails: its work has drained) or an idle one (hipSuccess)
+      const hipError_t q = hipStreamQuery(d.owner[lru]);
+      if (q == hipErrorNotReady) { g_bx_refused.fetch_add(1, std::memory_order_relaxed); return nullptr; }
+      (void)hipGetLastError();
+      slot = lru;
+    }
+    d.owner[slot] = st;
   }
-  return reinterpret_cast<bx_u32x4*>(base + (size_t)slot * BX_SLOT_BYTES);
+  d.used[slot] = ++tick;
+  return reinterpret_cast<bx_u32x4*>(d.base + (size_t)slot * BX_SLOT_BYTES);
 }
+
+// ---- kernel-selection switches (include/temp_amd.h).  Defaults, then the environment, once at load time.
+static std::atomic<int> g_options[TEMP_OPT_COUNT];
+static const bool g_options_init = [] {
+  g_options[TEMP_OPT_MFMA_BF16X3] = 1; g_options[TEMP_OPT_TN_SPLIT] = 1; g_options[TEMP_OPT_RGCN_SCALAR] = 1;
+  g_options[TEMP_OPT_GEMM_STREAM] = 0; g_options[TEMP_OPT_GRU_STREAM] = 0;
+  const char* e;
+  if ((e = getenv("TEMP_MFMA")) && e[0] == 'f') g_options[TEMP_OPT_MFMA_BF16X3] = 0;
+  if ((e = getenv("TEMP_TN_SPLIT")) && e[0] == '0') g_options[TEMP_OPT_TN_SPLIT] = 0;
+  if ((e = getenv("TEMP_RGCN_SCALAR")) && e[0] == '0') g_options[TEMP_OPT_RGCN_SCALAR] = 0;
+  if ((e = getenv("TEMP_GEMM_STREAM")) && e[0] == '1') g_options[TEMP_OPT_GEMM_STREAM] = 1;
+  if ((e = getenv("TEMP_GRU_STREAM")) && e[0] == '1') g_options[TEMP_OPT_GRU_STREAM] = 1;
+  return true;
+}();
+int option(int key) { return (key >= 0 && key < TEMP_OPT_COUNT) ? g_options[key].load(std::memory_order_relaxed) : -1; }
 }  // namespace temp
 
 extern "C" {
@@ -979,6 +1019,13 @@ const char* temp_trace_kernel_name(int id) {
 }
 
 int temp_abi_version(void) { return TEMP_ABI_VERSION; }
+
+int temp_set_option(int key, int value) {
+  if (key < 0 || key >= TEMP_OPT_COUNT) return -1;
+  return temp::g_options[key].exchange(value, std::memory_order_relaxed);
+}
+int temp_get_option(int key) { return temp::option(key); }
+long long temp_scratch_refused(void) { return temp::bx_scratch_refused(); }
 
 const char* temp_error_string(int code) {
   switch (code) {

@@ -325,11 +325,8 @@ int launch_gemm_wres(int kid, const PanelBatch<Epi>& batch, int count, const Wre
 }
 
 // Dispatcher used by every call site: weights-resident kernel when the shape allows, else the
-// streaming row-panel kernel.  TEMP_GEMM_STREAM=1 in the environment forces the latter (A/B runs).
-inline bool wres_disabled() {
-  static const int v = [] { const char* e = getenv("TEMP_GEMM_STREAM"); return (e && e[0] == '1') ? 1 : 0; }();
-  return v != 0;
-}
+// streaming row-panel kernel.  temp_set_option(TEMP_OPT_GEMM_STREAM, 1) forces the latter (A/B runs).
+inline bool wres_disabled() { return option(TEMP_OPT_GEMM_STREAM) != 0; }
 
 template <class Epi>
 int launch_gemm_panel_multi(int kid, const PanelBatch<Epi>& batch, int count, int N, int K, int lda, int ldb, int trans_b, hipStream_t st) {

@@ -541,7 +541,7 @@ static int launch_gru_fwd_batch(const GruFwdBatch& batch, int count, int d, int 
   int max_n = 0;
   for (int i = 0; i < count; ++i) if (batch.c[i].n > max_n) max_n = batch.c[i].n;
   if (max_n <= 0) return TEMP_OK;
-  static const bool stream_only = [] { const char* e = getenv("TEMP_GRU_STREAM"); return e && e[0] == '1'; }();   // A/B switch
+  const bool stream_only = option(TEMP_OPT_GRU_STREAM) != 0;   // A/B switch
   if (hoisted && d % 8 == 0 && !stream_only) {
     // window-chain cells: weights-resident GEMM with the grouped gate epilogue (EpiGruCell)
     int rc = (variant == TEMP_GRU_TORCH) ? launch_gru_fwd_wres<TEMP_GRU_TORCH>(batch, count, d, lambda, decay_wb, plane, st)

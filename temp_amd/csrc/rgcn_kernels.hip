@@ -495,11 +495,8 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_generic(TempEdgeView v, const f
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// TEMP_RGCN_SCALAR=0 in the environment keeps the wide-row launches on the permute-based kernels (A/B runs)
-static bool rgcn_scalar_off() {
-  static const int v = [] { const char* e = getenv("TEMP_RGCN_SCALAR"); return (e && e[0] == '0') ? 1 : 0; }();
-  return v != 0;
-}
+// temp_set_option(TEMP_OPT_RGCN_SCALAR, 0) keeps the wide-row launches on the permute-based kernels (A/B runs)
+static bool rgcn_scalar_off() { return !option(TEMP_OPT_RGCN_SCALAR); }
 static int pick_lpr(int D) {
   int q = D / 4, l = 1;
   while (l < q) l <<= 1;

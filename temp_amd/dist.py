@@ -9,12 +9,14 @@ Two ways the path shards:
 
 2. snapshot visits -> ranks (BASELINE north_star; needs --rec-only-last-layer): all ranks share the
    same batch of windows; the (position, window) snapshot visits are cut into `world` contiguous
-   ranges balanced by edge count; each rank runs the two RGCN layers on ITS visits only, then ONE
-   all-gather of the per-snapshot node states (padded to the largest shard) gives every rank the GRU
-   inputs of all visits; the recurrent chain itself is sharded by window (rank = window index mod
-   world).  Backward mirrors it: the adjoint of the all-gather is a reduce-scatter that returns to
-   each rank the summed gradient of its own visits' node states; parameter gradients are partial
-   sums on every rank and are all-reduced like in (1).  (`SnapshotShardedEncoder`)
+   same batch of windows; the DISTINCT snapshots the windows visit are cut into `world` contiguous
+   ranges balanced by edge count; each rank runs the two RGCN layers on ITS snapshots only, then ONE
+   UNPADDED all-gather of the per-snapshot node states (every rank posts its rows straight into the
+   destination row range of each peer's buffer: a grouped point-to-point batch, `_AllGatherRows`) gives
+   every rank the GRU inputs of all visits; the recurrent chain itself is sharded by window (rank =
+   window index mod world).  Backward mirrors it: the adjoint of the all-gather returns to each rank
+   the pieces of its own rows' gradient from every peer, summed in rank order; parameter gradients are
+   partial sums on every rank and are all-reduced like in (1).  (`SnapshotShardedEncoder`)
 """
 import numpy as np
 import torch
@@ -29,7 +31,13 @@ from .window import ChainPlan, Step, window_times
 class GradBucket:
     """ONE preallocated flat buffer over ALL trainable parameters, in a fixed order that is identical on every rank.
     A parameter without a gradient on this rank (a rank that owns no window of a short last batch, a weight its shard
-    never touches) contributes zeros, so the collective has the same size everywhere and is never skipped."""
+    never touches) contributes zeros, so the collective has the same size everywhere and is never skipped.
+
+    A parameter for which NO rank produced a gradient keeps `.grad = None`, exactly as in single-process training (Adam then
+    skips it: no moment update, no weight decay -- the post/impute branches and time weights are such parameters in some
+    configurations).  For that the buffer carries one presence float per parameter behind the gradients (1 where this rank has
+    a gradient), reduced by the same collective; only a rank that itself lacks a gradient reads its entries back (one small
+    device-to-host copy) -- a rank with every gradient present already knows the answer and never synchronises."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -39,11 +47,12 @@ class GradBucket:
             off += p.numel()
         self.numel = off
         self.flat = None
+        self._present = None                         # (pattern of local presence, its device tensor): rebuilt when the pattern changes
 
     def _buffer(self):
         dev = self.params[0].device if self.params else torch.device("cpu")
         if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+            self.flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=dev)
         return self.flat
 
     def allreduce(self, world=None, average=True, group=None, grads=None):
@@ -58,11 +67,12 @@ class GradBucket:
             return
         flat = self._buffer()
         views = [flat[a:b].view_as(p) for p, (a, b) in zip(self.params, self.spans)]
-        src, dst, missing = [], [], []
+        src, dst, missing, miss_i = [], [], [], []
         for i, (p, v) in enumerate(zip(self.params, views)):
             g = p.grad if grads is None else grads[i]
             if g is None:
                 missing.append(v)
+                miss_i.append(i)
             elif g.data_ptr() != v.data_ptr() or not g.is_contiguous():
                 src.append(g if g.dtype == flat.dtype else g.to(flat.dtype))
                 dst.append(v)
@@ -70,12 +80,22 @@ class GradBucket:
             torch._foreach_zero_(missing)
         if dst:
             torch._foreach_copy_(dst, src)
+        pattern = tuple(miss_i)
+        if self._present is None or self._present[0] != pattern or self._present[1].device != flat.device:
+            host = torch.ones(len(self.params), dtype=torch.float32)
+            host[miss_i] = 0.0
+            self._present = (pattern, host.to(flat.device))
+        flat[self.numel:].copy_(self._present[1])    # reduced below together with the gradients (SUM or AVG: > 0 iff some rank had one)
         fused_avg = average and dist.get_backend(group) == "nccl"
         dist.all_reduce(flat, op=dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM, group=group)
         if average and not fused_avg:
-            flat.div_(world)
-        for p, v in zip(self.params, views):
-            p.grad = v
+            flat[:self.numel].div_(world)
+        nobody = set()
+        if miss_i:                                   # only a rank that lacks a gradient needs to ask whether anybody had one
+            got = flat[self.numel:][torch.tensor(miss_i, device=flat.device)].cpu()
+            nobody = {i for i, x in zip(miss_i, got.tolist()) if x <= 0.0}
+        for i, (p, v) in enumerate(zip(self.params, views)):
+            p.grad = None if i in nobody else v
 
 
 def allreduce_gradients(params, world=None, average=True, group=None, grads=None):

@@ -11,11 +11,13 @@ simply the GRU INPUT rows of the step (one launch per RGCN layer over all visite
 otherwise the reference-granular path walks the positions through forward_post_ensemble(_one_direction).  Histories are
 row maps into the last executed position (window.ChainPlan), never dense (bsz, N_ents, D) tensors.
 
-Out of scope: the frequency statistics behind PostEnsemble*'s learned score-mixing weights
-(utils/DropEdge.py, utils/frequency.py).  `PostEnsemble*.forward` takes the per-triple weights from `calc_ensemble_ratio`,
-which callers override (tests inject the weights the reference used)."""
+The learned score-mixing weights of PostEnsemble* (`calc_ensemble_ratio`, models/PostDynamicRGCN.py:425-461): two MLPs
+`subject_linear` / `object_linear` (3 -> 3 -> 1, sigmoid; same parameter names as the reference, so its checkpoints load) over
+per-timestamp frequency features of every triple (temp_amd/frequency.py restates the tables of utils/DropEdge.py:34-82).
+`forward(..., ensemble_weights=...)` still accepts injected weights (parity tests that replay the reference's)."""
 import numpy as np
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as TF
@@ -89,11 +91,42 @@ class _PostWindowMixin:
             return x[it.x0:it.x0 + it.n]
         return x[step.row0:step.row0 + step.n_rows]
 
+    # Reference quirk kept for parity (pinned by golden G19_post_ratio_bi): PostEnsembleBiDynamicRGCN.train_link_prediction forwards
+    # to the uni-directional class with `corrupt_tail=True` hard-coded (models/PostBiDynamicRGCN.py:294-295), so its "head" scores
+    # are score(s, r, all_embeds[neg_head], mode='tail') -- the head-corruption candidates scored as tails of the true subject.
+    head_scored_as_tail = False
+
     # -- score-level ensemble (models/PostDynamicRGCN.py:357-373, 399-406) ---------------------------------------------------
+    def init_freq_mlp(self):
+        """PostEnsembleDynamicRGCN.init_freq_mlp, models/PostDynamicRGCN.py:328-338 (same module names => same state_dict keys)."""
+        self.subject_linear = nn.Sequential(nn.Linear(3, 3), nn.ReLU(), nn.Linear(3, 1))
+        self.object_linear = nn.Sequential(nn.Linear(3, 3), nn.ReLU(), nn.Linear(3, 1))
+
+    def frequency_tables(self):
+        ft = getattr(self, "_freq_tables", None)
+        if ft is None:
+            from .frequency import FrequencyTables
+            ft = self._freq_tables = FrequencyTables(self.graph_dict_train, self.train_seq_len, "Bi" in self.args.module,
+                                                     2 * self.num_rels)
+        return ft
+
+    def ensemble_features(self, triples, t, g):
+        """Frequency features of the (local-id) triples of graph g at timestamp t -> (subject (n, 3), object (n, 3)) on the device."""
+        tr = triples.detach().cpu().numpy() if torch.is_tensor(triples) else np.asarray(triples)
+        tr = tr.reshape(-1, 3)
+        sub_f, obj_f = self.frequency_tables().features(int(t), g.gids[tr[:, 0]], tr[:, 1], g.gids[tr[:, 2]])
+        dev = self._device()
+        return torch.from_numpy(sub_f).to(dev), torch.from_numpy(obj_f).to(dev)
+
     def calc_ensemble_ratio(self, triples, t, g):
-        raise NotImplementedError("the learned mixing weights of PostEnsemble* come from per-timestamp frequency statistics "
-                                  "(utils/DropEdge.py, utils/frequency.py), which are outside the snapshot-encoder path "
-                                  "(SURVEY section 2): override calc_ensemble_ratio or pass ensemble_weights to forward()")
+        """models/PostDynamicRGCN.py:425-461 -> (weight_subject (n, 1), weight_object (n, 1)); empty tensors for no triples."""
+        if not hasattr(self, "subject_linear"):
+            raise NotImplementedError("calc_ensemble_ratio needs the frequency MLPs of a PostEnsemble* model")
+        if len(triples) == 0:
+            e = torch.zeros(0, dtype=torch.int64, device=self._device())
+            return e, e
+        sub_f, obj_f = self.ensemble_features(triples, t, g)
+        return torch.sigmoid(self.subject_linear(sub_f)), torch.sigmoid(self.object_linear(obj_f))
 
     def _scores(self, ent_embed, triplets, neg_samples, all_embeds_g, corrupt_tail):
         r = self.rel_embeds[triplets[:, 1]]
@@ -106,6 +139,7 @@ class _PostWindowMixin:
         labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=triplets.device)
         out = 0
         for neg, tail, w in ((neg_tail, True, w_object), (neg_head, False, w_subject)):
+            tail = tail or self.head_scored_as_tail
             local = self._scores(loc, triplets, neg, all_loc, tail)
             temporal = self._scores(rec, triplets, neg, all_rec, tail)
             out = out + F.cross_entropy(w * local + (1 - w) * temporal, labels)
@@ -203,14 +237,17 @@ class ImputeDynamicRGCN(_PostWindowMixin, DynamicRGCN):
 
 
 class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
-    """models/PostDynamicRGCN.py:131-461 minus the frequency MLP (see module docstring)."""
+    """models/PostDynamicRGCN.py:323-461 (PostEnsembleDynamicRGCN: score-level ensemble with the frequency MLPs)."""
+
+    def __init__(self, args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type=None):
+        super().__init__(args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type)
+        self.init_freq_mlp()
 
     def evaluate(self, t_list, val=True):
         """PostEnsemble(Bi)DynamicRGCN.evaluate / calc_metrics (models/PostDynamicRGCN.py:367-423, models/PostBiDynamicRGCN.py:297-360):
         window loop with the local stream on the full train graphs, (local, temporal) all-entity matrices, score-level ensemble
-        ranks (PostEnsembleEvaluationFilter).  The mixing weights come from calc_ensemble_ratio(index_sample, t, g), which the
-        caller supplies (the reference derives them from the frequency tables of utils/DropEdge.py).  As in the reference no
-        classification loss is computed (nan)."""
+        ranks (PostEnsembleEvaluationFilter).  The mixing weights come from calc_ensemble_ratio(index_sample, t, g) (frequency MLPs).
+        As in the reference no classification loss is computed (nan)."""
         return _post_ensemble_evaluate(self, t_list, val)
 
     def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plan, b, hist, hist_loc=None):
@@ -347,14 +384,18 @@ class ImputeBiDynamicRGCN(_PostWindowMixin, BiDynamicRGCN):
 
 
 class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
-    """models/PostBiDynamicRGCN.py:170-372 minus the frequency MLP (see module docstring) -- BASELINE config 3's model."""
+    """models/PostBiDynamicRGCN.py:283-372 (score-level ensemble with the frequency MLPs) -- BASELINE config 3's model."""
+    head_scored_as_tail = True            # models/PostBiDynamicRGCN.py:294-295, see _PostWindowMixin
+
+    def __init__(self, args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type=None):
+        super().__init__(args, num_ents, num_rels, graph_dict_train, graph_dict_val, graph_dict_test, evaluater_type)
+        self.init_freq_mlp()
 
     def evaluate(self, t_list, val=True):
         """PostEnsemble(Bi)DynamicRGCN.evaluate / calc_metrics (models/PostDynamicRGCN.py:367-423, models/PostBiDynamicRGCN.py:297-360):
         window loop with the local stream on the full train graphs, (local, temporal) all-entity matrices, score-level ensemble
-        ranks (PostEnsembleEvaluationFilter).  The mixing weights come from calc_ensemble_ratio(index_sample, t, g), which the
-        caller supplies (the reference derives them from the frequency tables of utils/DropEdge.py).  As in the reference no
-        classification loss is computed (nan)."""
+        ranks (PostEnsembleEvaluationFilter).  The mixing weights come from calc_ensemble_ratio(index_sample, t, g) (frequency MLPs).
+        As in the reference no classification loss is computed (nan)."""
         return _post_ensemble_evaluate(self, t_list, val)
 
     def get_all_embeds_Gt(self, convoluted_loc, convoluted_rec, g, t, plans, b, hist, hist_loc=None):

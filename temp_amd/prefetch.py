@@ -67,40 +67,55 @@ class BatchPrefetcher:
             return (i, t_list, seed)
 
     def _work(self):
-        from .tkg_module import TKG_Module
-        stream = torch.cuda.Stream(self.device) if self.device is not None else None
-        while True:
-            self._slots.acquire()
-            job = self._take()
-            if job is None:
-                self._slots.release()
-                break
-            i, t_list, seed = job
-            try:
-                if isinstance(t_list, BaseException):
-                    raise t_list
-                if seed is not None:
-                    TKG_Module._rng_override.rng = np.random.default_rng(seed)
-                if stream is None:
-                    wb = self.model.prepare(t_list, self.seq_len, self.train)
-                else:
-                    with torch.cuda.stream(stream):
+        """Worker thread.  Whatever ends it -- the normal end of the source, or an exception anywhere in the body (stream creation,
+        the seed draw inside _take, the import) -- `_live` is decremented and the consumer woken in the `finally`; an unexpected
+        failure is posted as the result of the next batch index, so the consumer raises it instead of waiting forever."""
+        fatal = None
+        try:
+            from .tkg_module import TKG_Module
+            stream = torch.cuda.Stream(self.device) if self.device is not None else None
+            while True:
+                self._slots.acquire()
+                job = self._take()
+                if job is None:
+                    self._slots.release()
+                    break
+                i, t_list, seed = job
+                try:
+                    if isinstance(t_list, BaseException):
+                        raise t_list
+                    if seed is not None:
+                        TKG_Module._rng_override.rng = np.random.default_rng(seed)
+                    if stream is None:
                         wb = self.model.prepare(t_list, self.seq_len, self.train)
-                        wb.ready = torch.cuda.Event()
-                        wb.ready.record(stream)
-                res = ("ok", wb)
-            except BaseException as e:                          # surfaced in the consumer, at this batch's position
-                res = ("err", e)
-                with self._src_lock:
+                    else:
+                        with torch.cuda.stream(stream):
+                            wb = self.model.prepare(t_list, self.seq_len, self.train)
+                            wb.ready = torch.cuda.Event()
+                            wb.ready.record(stream)
+                    res = ("ok", wb)
+                except BaseException as e:                          # surfaced in the consumer, at this batch's position
+                    res = ("err", e)
+                    with self._src_lock:
+                        self._stop = True
+                finally:
+                    TKG_Module._rng_override.rng = None
+                with self._cv:
+                    self._done[i] = res
+                    self._cv.notify_all()
+        except BaseException as e:                                  # outside a batch: no index of its own
+            fatal = e
+        finally:
+            with self._src_lock:
+                if fatal is not None:
                     self._stop = True
-            finally:
-                TKG_Module._rng_override.rng = None
+                    i = self._n_taken                               # the next index nobody will prepare now
+                    self._n_taken += 1
             with self._cv:
-                self._done[i] = res
+                if fatal is not None:
+                    self._done[i] = ("err", fatal)
+                self._live -= 1
                 self._cv.notify_all()
-        with self._cv:
-            self._live -= 1
-            self._cv.notify_all()
 
     def _retire(self, wb):
         """Called when the consumer is done issuing work for `wb`."""

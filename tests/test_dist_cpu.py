@@ -69,7 +69,7 @@ def _worker(rank, world, port, name, mode, q):
             loss.backward()
         # ranks without work (or without a gradient for some parameter) still join the SAME collective: the bucket zero-fills
         allreduce_gradients(list(m.parameters()), world, average=False)
-        q.put((rank, wins, [e.detach().numpy() for e in pieces], {k: v.grad.numpy() for k, v in m.named_parameters()}))
+        q.put((rank, wins, [e.detach().numpy() for e in pieces], {k: v.grad.numpy() for k, v in m.named_parameters() if v.grad is not None}))
     finally:
         dist.destroy_process_group()
 
@@ -106,9 +106,10 @@ def test_ranks_match_single_process(mode, name, world):
         for b, e in zip(wins, pieces):
             np.testing.assert_allclose(e, ref_out[b].numpy(), rtol=2e-5, atol=2e-6)
             seen.add(b)
+        # a parameter no rank produced a gradient for keeps .grad = None, as in the single-process run (presence mask of GradBucket)
+        assert set(grads) == set(ref_grads), (sorted(set(grads) ^ set(ref_grads)))
         for k, g in grads.items():
-            if k in ref_grads:
-                np.testing.assert_allclose(g, ref_grads[k].numpy(), rtol=2e-4, atol=3e-6, err_msg=k)
+            np.testing.assert_allclose(g, ref_grads[k].numpy(), rtol=2e-4, atol=3e-6, err_msg=k)
     assert seen == set(range(len(ref_out)))
 
 
@@ -143,8 +144,8 @@ def _bucket_worker(rank, world, port, q):
         # explicit sources (a replayed graph's capture tensors) win over .grad
         src = [torch.full((3, 4), 2.0), None, torch.full((2, 2), 3.0 * (rank + 1))]
         allreduce_gradients(ps, world, average=False, grads=src)
-        third = [p.grad.clone() for p in ps]
-        q.put((rank, [t.numpy() for t in first], [t.numpy() for t in second], [t.numpy() for t in third]))
+        third = [None if p.grad is None else p.grad.clone() for p in ps]
+        q.put((rank, [t.numpy() for t in first], [t.numpy() for t in second], [None if t is None else t.numpy() for t in third]))
     finally:
         dist.destroy_process_group()
 
@@ -168,5 +169,5 @@ def test_gradient_bucket_semantics():
         np.testing.assert_allclose(second[1], np.full((5,), 10.0))            # the averaged span of both ranks, summed
         np.testing.assert_allclose(second[2], np.full((2, 2), 21.0))
         np.testing.assert_allclose(third[0], np.full((3, 4), 4.0))
-        np.testing.assert_allclose(third[1], np.zeros(5))
+        assert third[1] is None      # NO rank had a gradient for it: .grad stays None as in single-process training (Adam skips it)
         np.testing.assert_allclose(third[2], np.full((2, 2), 9.0))

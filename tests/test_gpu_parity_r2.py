@@ -479,6 +479,12 @@ def test_post_ensemble_evaluate_golden_gpu(name, batched):
     check_post_ensemble_evaluate(name, DEV, batched)
 
 
+@pytest.mark.parametrize("name,batched", [("G19_post_ratio_uni", True), ("G19_post_ratio_bi", True)])
+def test_post_ensemble_own_ratio_golden_gpu(name, batched):
+    from tests.window_cases import check_post_ensemble_ratio
+    check_post_ensemble_ratio(name, DEV, batched)
+
+
 def test_rgcn_layer_row_gather_in_large_gemm_gpu():
     """temp_rgcn_fwd with feature ids at a size that takes the split-operand GEMM (>= 16 K rows): the self-loop product gathers
     its rows through a_idx inside the kernel; result = the same layer on the explicitly gathered rows.  Nodes without in-edges

@@ -406,3 +406,10 @@ def test_post_evaluation_filters_golden(name):
 def test_post_ensemble_evaluate_golden(name, batched):
     from tests.window_cases import check_post_ensemble_evaluate
     check_post_ensemble_evaluate(name, torch.device("cpu"), batched)
+
+
+@pytest.mark.parametrize("name,batched", [("G19_post_ratio_uni", True), ("G19_post_ratio_bi", True), ("G19_post_ratio_bi", False)])
+def test_post_ensemble_own_ratio_golden(name, batched):
+    """config 3 end to end: frequency features + MLP mixing weights + loss against the reference's own calc_ensemble_ratio."""
+    from tests.window_cases import check_post_ensemble_ratio
+    check_post_ensemble_ratio(name, torch.device("cpu"), batched)
