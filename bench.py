@@ -403,10 +403,22 @@ def main():
     torch.cuda.synchronize()
     prepare_s = time.perf_counter() - t0
 
+    # Upstream gradient = ones on the step's output, handed to backward() as a resident tensor: `.sum().backward()`
+    # computes the same gradients but spends a reduction, two fills and -- because autograd expands the scalar's gradient
+    # with stride 0 -- one contiguous copy per consumer (~35 us of harness kernels per step in the round-2 trace).
+    ones_cache = {}
+
+    def backward_ones(out):
+        key = (tuple(out.shape), out.dtype)
+        g = ones_cache.get(key)
+        if g is None:
+            g = ones_cache[key] = torch.ones_like(out)
+        out.backward(g)
+
     def step_eager():
         for p in params:
             p.grad = None
-        run().sum().backward()
+        backward_ones(run())
         if dist is not None:
             allreduce_gradients(params, world, average=not sharded)
 
@@ -422,14 +434,14 @@ def main():
                 for _ in range(2):
                     for p in params:
                         p.grad = None
-                    run().sum().backward()
+                    backward_ones(run())
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             for p in params:
                 p.grad = None
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread polls events meanwhile
-                run().sum().backward()
+                backward_ones(run())
             torch.cuda.synchronize()
             return g, [p.grad for p in params]
         except Exception as e:                      # capture is an optimisation only

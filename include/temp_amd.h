@@ -59,13 +59,22 @@ enum {
   TEMP_OPT_RGCN_SCALAR = 2, /* 1: wide-row edge kernels keep per-edge quantities in SGPRs     [TEMP_RGCN_SCALAR=0 -> 0] default 1 */
   TEMP_OPT_GEMM_STREAM = 3, /* 1: force the streaming row-panel GEMM instead of weights-resident [TEMP_GEMM_STREAM=1 -> 1] default 0 */
   TEMP_OPT_GRU_STREAM = 4,  /* 1: force the streaming GRU cell kernel                          [TEMP_GRU_STREAM=1 -> 1] default 0 */
-  TEMP_OPT_COUNT = 5
+  TEMP_OPT_RGCN_TILE = 5,   /* 1: aggregation and d/dh stage a member snapshot's rows in LDS when the graph carries member tables
+                               2: the weight-gradient kernel too (slower at the measured shapes)
+                               0: always gather through L2 (bit-identical results)             [TEMP_RGCN_TILE=0 -> 0]  default 1 */
+  TEMP_OPT_DEBUG = 6,       /* development ablations inside instrumented kernels; 0 (off) in every product run          default 0 */
+  TEMP_OPT_COUNT = 7
 };
 int temp_set_option(int key, int value);
 int temp_get_option(int key);
 /* Diagnostic: how often a launch found no scratch slot for its packed weights / k-slice partials (more than 8 busy streams
  * on one device) and took the scratch-free kernels instead.  0 in every supported configuration. */
 long long temp_scratch_refused(void);
+/* Diagnostic: edge-kernel launches (aggregation, d/dh, d/dweight) that took the LDS-tiled path (TempMembers present, member fits). */
+long long temp_tile_launches(void);
+/* Development only: a device buffer of `words` int64 into which instrumented kernels write cycle-counter stamps (NULL: off).
+ * Not used by the product path or the tests. */
+void temp_set_debug_buffer(void* device_ptr, size_t words);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmented edge lists.  One batched snapshot graph (the disjoint union `dgl.batch` builds at
@@ -113,6 +122,23 @@ typedef struct TempEdgeView {
   const int32_t* fix_cnt;   /* [n_fix] number of slots                                             */
 } TempEdgeView;
 
+/* Optional member tables of a batched graph (the disjoint union `dgl.batch` builds, models/DynamicRGCN.py:92): the union's
+ * nodes, the edge arrays of every view and the chunk lists of every view are MEMBER-MAJOR (member m owns the node rows
+ * [node_off[m], node_off[m+1]), positions [edge_off[m], edge_off[m+1]) of every view's a/b arrays and chunks
+ * [chunk_off[v][m], chunk_off[v][m+1]) of view v = 0 by_dst, 1 by_src, 2 by_rel; no edge crosses members).  With them the edge
+ * kernels run one workgroup per (member, feature slice) with the member's rows staged in LDS (block-diagonal relation weights
+ * make feature slices independent) instead of gathering rows through L2 -- same chunks, same summation order, bit-identical
+ * results.  n_members == 0 (or a member too large for LDS): the kernels gather from global memory as before. */
+typedef struct TempMembers {
+  int32_t n_members;
+  int32_t max_nodes;        /* largest member: nodes                                               */
+  int32_t max_edges;        /*                 edge-array positions (edge_off[m+1] - edge_off[m])  */
+  int32_t max_chunks[3];    /*                 chunks in the by_dst / by_src / by_rel view         */
+  const int32_t* node_off;  /* [n_members + 1]  device                                             */
+  const int32_t* edge_off;  /* [n_members + 1]  device                                             */
+  const int32_t* chunk_off; /* [3][n_members + 1] device                                           */
+} TempMembers;
+
 typedef struct TempGraph {
   int32_t n_nodes;          /* sum of nodes over the batched snapshots                             */
   int32_t n_edges;
@@ -122,6 +148,7 @@ typedef struct TempGraph {
   TempEdgeView by_dst;
   TempEdgeView by_src;      /* needed by temp_rgcn_bwd only                                        */
   TempEdgeView by_rel;      /* needed by temp_rgcn_bwd only; n_seg = number of weight rows (2R)    */
+  TempMembers members;      /* optional (n_members = 0: absent)                                    */
 } TempGraph;
 
 /* ------------------------------------------------------------------------------------------------

@@ -27,9 +27,18 @@ class TempEdgeView(ctypes.Structure):
                 ("fix_seg", c_vp), ("fix_slot", c_vp), ("fix_cnt", c_vp)]
 
 
+class TempMembers(ctypes.Structure):
+    _fields_ = [("n_members", ctypes.c_int32), ("max_nodes", ctypes.c_int32), ("max_edges", ctypes.c_int32),
+                ("max_chunks", ctypes.c_int32 * 3), ("node_off", c_vp), ("edge_off", c_vp), ("chunk_off", c_vp)]
+
+
 class TempGraph(ctypes.Structure):
     _fields_ = [("n_nodes", ctypes.c_int32), ("n_edges", ctypes.c_int32), ("nnorm", c_vp), ("in_deg", c_vp),
-                ("out_deg", c_vp), ("by_dst", TempEdgeView), ("by_src", TempEdgeView), ("by_rel", TempEdgeView)]
+                ("out_deg", c_vp), ("by_dst", TempEdgeView), ("by_src", TempEdgeView), ("by_rel", TempEdgeView),
+                ("members", TempMembers)]
+
+
+OPT_MFMA_BF16X3, OPT_TN_SPLIT, OPT_RGCN_SCALAR, OPT_GEMM_STREAM, OPT_GRU_STREAM, OPT_RGCN_TILE, OPT_DEBUG = range(7)
 
 
 class TempGruCellFwd(ctypes.Structure):
@@ -90,6 +99,8 @@ SYMBOLS = {
     "temp_set_option": (_I, [_I, _I]),
     "temp_get_option": (_I, [_I]),
     "temp_scratch_refused": (ctypes.c_longlong, []),
+    "temp_tile_launches": (ctypes.c_longlong, []),
+    "temp_set_debug_buffer": (None, [c_vp, _SZ]),
     "temp_rgcn_fwd_workspace": (_SZ, [_G, _I]),
     "temp_rgcn_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_rgcn_bwd_workspace": (_SZ, [_G, _I, _I, _I, _I]),

@@ -8,6 +8,7 @@
 // table fits in 64 KB (GDELT: 40 rows x 1600 B), else through L2.  No atomics: segments that span
 // several chunks go through ordered partial slots + a fix-up pass, so results are deterministic.
 #include <stdlib.h>
+#include <atomic>
 #include "common.hpp"
 
 namespace temp {
@@ -286,6 +287,10 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* 
   }
 }
 
+}  // namespace temp
+#include "rgcn_tile.hpp"
+namespace temp {
+
 // Generic (any si, so) scalar-lane variant; slow, for shapes outside the fast path.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rgcn_agg_generic(TempEdgeView v, const float* __restrict__ feat, int ldf,
@@ -509,6 +514,7 @@ static bool fast_shape(int d_in, int d_out, int num_bases, int* S) {
   *S = s;
   return true;
 }
+static const TempMembers* members_of(const TempGraph* g) { return g->members.n_members > 0 ? &g->members : nullptr; }
 static bool view_ok(const TempEdgeView& v) {
   if (v.n_chunks < 0 || v.n_edges < 0 || v.n_partial < 0 || v.n_fix < 0) return false;
   if (v.n_chunks > 0 && (!v.a || !v.b || !v.chunk_seg || !v.chunk_beg || !v.chunk_end || !v.chunk_slot)) return false;
@@ -516,11 +522,50 @@ static bool view_ok(const TempEdgeView& v) {
   return true;
 }
 
+static bool rgcn_tile_on() { return option(TEMP_OPT_RGCN_TILE) != 0; }
+static std::atomic<long long*> g_debug_buf{nullptr};         // development only (temp_set_debug_buffer)
+static std::atomic<size_t> g_debug_words{0};
+static std::atomic<long long> g_tile_launches{0};           // diagnostic (temp_tile_launches): edge-kernel launches that took the LDS-tiled path
+
+// dynamic LDS beyond 64 KB must be granted per kernel function
+template <class K>
+static bool tile_grant_lds(K kernel, int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+
+template <int S, int MODE, class BT>
+static bool launch_agg_tile(const TempEdgeView& v, const TileArgs& t, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
+                            const float* nnorm, int D, float* out, float* partial, hipStream_t st) {
+  static const bool granted = tile_grant_lds(k_rgcn_agg_t<S, MODE, BT>, TILE_LDS_MAX);
+  if (!granted) { (void)hipGetLastError(); return false; }
+  const int grid = 8 * ceil_div(t.n_members, 8) * t.n_slices;
+  TileArgs tp = t;
+  if (g_debug_words.load() >= (size_t)grid * 8) tp.prof = g_debug_buf.load();
+  if constexpr (S == 2 && MODE == MODE_FWD && sizeof(BT) == 1) {          // development ablations (TEMP_OPT_DEBUG), never set by the product
+    const int var = option(TEMP_OPT_DEBUG);
+#define TILE_VAR(V) if (var == V) { static const bool ok = tile_grant_lds(k_rgcn_agg_t<S, MODE, BT, V>, TILE_LDS_MAX); (void)ok; \
+    TEMP_LAUNCH(K_RGCN_AGG_FWD, (k_rgcn_agg_t<S, MODE, BT, V>), dim3(grid), dim3(TILE_THREADS), t.lds_bytes, st, v, tp, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial); return true; }
+    TILE_VAR(1) TILE_VAR(2) TILE_VAR(3) TILE_VAR(4) TILE_VAR(7) TILE_VAR(8)
+#undef TILE_VAR
+  }
+  TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_t<S, MODE, BT>), dim3(grid), dim3(TILE_THREADS), t.lds_bytes, st, v, tp, feat, ldf, ids,
+              W, n_rel_rows, nnorm, D, out, partial);
+  g_tile_launches.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+
 template <int S, int MODE>
-static void launch_agg(const TempEdgeView& v, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
+static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
                        const float* nnorm, int D, float* out, float* partial, hipStream_t st) {
   const int lpr = pick_lpr(D);
   const size_t wbytes = (size_t)n_rel_rows * D * S * sizeof(float);
+  TileArgs ta;
+  if (mb && rgcn_tile_on() && n_rel_rows <= 65535 && v.n_partial < 0xffffff &&
+      tile_plan(*mb, view, D, S, 0, n_rel_rows, n_rel_rows <= 256 ? 1 : 2, &ta)) {
+    const bool ok = n_rel_rows <= 256 ? launch_agg_tile<S, MODE, unsigned char>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st)
+                                      : launch_agg_tile<S, MODE, unsigned short>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st);
+    if (ok) return;
+  }
   if (wbytes <= 65536 && v.n_chunks >= 4096) {
     // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
     const int grid = 512;
@@ -555,15 +600,15 @@ static void launch_fixup(const TempEdgeView& v, const float* partial, int width,
 }
 
 // forward / dx aggregation into `out` rows of segments that have edges (others untouched)
-static int run_agg(int mode, const TempEdgeView& v, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
+static int run_agg(int mode, const TempEdgeView& v, const TempMembers* mb, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
                    const float* nnorm, int d_in, int d_out, int num_bases, float* out, float* partial, hipStream_t st) {
   if (v.n_chunks == 0) return TEMP_OK;
   int S = 0;
   const int wres = (mode == MODE_FWD) ? d_out : d_in;
   if (fast_shape(d_in, d_out, num_bases, &S)) {
 #define TEMP_AGG(SS)                                                                                   \
-  if (mode == MODE_FWD) launch_agg<SS, MODE_FWD>(v, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st); \
-  else launch_agg<SS, MODE_DX>(v, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st);
+  if (mode == MODE_FWD) launch_agg<SS, MODE_FWD>(v, mb, 0, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st); \
+  else launch_agg<SS, MODE_DX>(v, mb, 1, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st);
     if (S == 1) { TEMP_AGG(1) } else if (S == 2) { TEMP_AGG(2) } else { TEMP_AGG(4) }
 #undef TEMP_AGG
   } else {
@@ -581,14 +626,33 @@ static int run_agg(int mode, const TempEdgeView& v, const float* feat, int ldf, 
   return launch_status();
 }
 
-static int run_dw(const TempEdgeView& v, const float* x, const int32_t* x_ids, const float* dz, const float* nnorm, int d_in, int d_out, int num_bases,
+template <int S>
+static bool launch_dw_tile(const TempEdgeView& v, const TileArgs& t, const float* x, const int32_t* x_ids, const float* dz, const float* nnorm, int D,
+                           float* dW, float* partial, hipStream_t st) {
+  static const bool granted = tile_grant_lds(k_rgcn_dw_t<S>, TILE_LDS_MAX);
+  if (!granted) { (void)hipGetLastError(); return false; }
+  const int grid = 8 * ceil_div(t.n_members, 8) * t.n_slices;
+  TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw_t<S>), dim3(grid), dim3(TILE_THREADS), t.lds_bytes, st, v, t, x, x_ids, dz, nnorm, D, dW, partial);
+  g_tile_launches.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+
+static int run_dw(const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz, const float* nnorm, int d_in, int d_out, int num_bases,
                   int n_rel_rows, float* dW, float* partial, hipStream_t st) {
   const int si = d_in / num_bases, so = d_out / num_bases;
   const size_t wrow = (size_t)num_bases * si * so;
   if (hipMemsetAsync(dW, 0, (size_t)n_rel_rows * wrow * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
   if (v.n_chunks == 0) return TEMP_OK;
   int S = 0;
-  if (fast_shape(d_in, d_out, num_bases, &S)) {
+  TileArgs ta;
+  // (measured at the S-gdelt shape: with TWO row sets in LDS the slices get narrow -- 7-8 of a walker's 16 lanes work -- and the
+  // tiled weight-gradient kernel is slower than the L2-gather kernel, 151 against 110-120 us: only TEMP_OPT_RGCN_TILE = 2 takes it)
+  if (fast_shape(d_in, d_out, num_bases, &S) && mb && option(TEMP_OPT_RGCN_TILE) >= 2 && n_rel_rows <= 65535 && v.n_partial < 0xffffff &&
+      tile_plan(*mb, 2, d_in, S, 1, 0, 2, &ta) &&
+      (S == 1 ? launch_dw_tile<1>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st)
+              : S == 2 ? launch_dw_tile<2>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st) : launch_dw_tile<4>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st))) {
+    // LDS-tiled (rgcn_tile.hpp)
+  } else if (fast_shape(d_in, d_out, num_bases, &S)) {
     const int lpr = pick_lpr(d_in);
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
@@ -656,6 +720,9 @@ using namespace temp;
 
 extern "C" {
 
+long long temp_tile_launches(void) { return g_tile_launches.load(std::memory_order_relaxed); }
+void temp_set_debug_buffer(void* device_ptr, size_t words) { g_debug_buf.store((long long*)device_ptr); g_debug_words.store(device_ptr ? words : 0); }
+
 size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out) {
   if (!g || n_table < 0) return 0;
   return align_up((size_t)g->by_dst.n_partial * d_out * sizeof(float), 256) + align_up((size_t)n_table * d_out * sizeof(float), 256) + 256;
@@ -676,7 +743,7 @@ int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* i
   int rc = gemm_add_bias_act(K_GEMM_ISO, n_table, d_out, d_in, table, d_in, nullptr, loop_w, d_out, 0, nullptr, 0, nullptr, nullptr, TEMP_ACT_NONE,
                              t_loop, d_out, st);
   if (rc) return rc;
-  rc = run_agg(MODE_FWD, g->by_dst, table, d_in, ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
+  rc = run_agg(MODE_FWD, g->by_dst, members_of(g), table, d_in, ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
   if (rc) return rc;
   int grid = ceil_div((long long)g->n_nodes * (d_out / 4), 256);
   if (grid > 4096) grid = 4096;
@@ -721,7 +788,7 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
   }
   // aggregation part of d_h per node row, then everything that is linear in the gathered rows is summed per table row FIRST:
   //   d_table = segsum(out_deg > 0 ? d_h : 0) + segsum(dz) . loop_w^T        d_loop_w = table^T . segsum(dz)
-  rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, w.d_h, w.part_dx, st);
+  rc = run_agg(MODE_DX, g->by_src, members_of(g), dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, w.d_h, w.part_dx, st);
   if (rc) return rc;
   rc = segment_sum_rows(n_table, d_in, inv_ptr, inv_order, w.d_h, g->out_deg, d_table, st, g->n_nodes);
   if (rc) return rc;
@@ -737,7 +804,7 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, n_table, d_in, d_out, w.seg_dz, d_out, nullptr, loop_w, d_out, 1, d_table, d_in, nullptr, nullptr,
                          TEMP_ACT_NONE, d_table, d_in, st);
   if (rc) return rc;
-  rc = run_dw(g->by_rel, table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+  rc = run_dw(g->by_rel, members_of(g), table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
   if (rc) return rc;
   rc = gemm_tn(n_table, d_in, d_out, table, d_in, w.seg_dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
   if (rc) return rc;
@@ -764,7 +831,7 @@ int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids, int 
   if (g->n_nodes == 0) return TEMP_OK;
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  int rc = run_agg(MODE_FWD, g->by_dst, h, d_in, h_ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
+  int rc = run_agg(MODE_FWD, g->by_dst, members_of(g), h, d_in, h_ids, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, out, partial, st);
   if (rc) return rc;
   // out = act( (in_deg>0 ? out : 0) + bias + h . loop_w )       (MFMA fp32 GEMM, fused epilogue)
   const DropSpec ds = drop_spec(drop);
@@ -833,7 +900,7 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
     dz = w.dz;
   }
   // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
-  rc = run_agg(MODE_DX, g->by_src, dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
+  rc = run_agg(MODE_DX, g->by_src, members_of(g), dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
   if (rc) return rc;
   const DropSpec ds = drop_spec(drop);
   const float* dzm = dz;                       // gradient of the (dropped-out) self-loop message
@@ -845,7 +912,7 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dzm, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
                          d_h, d_in, st);
   if (rc) return rc;
-  rc = run_dw(g->by_rel, h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+  rc = run_dw(g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
   if (rc) return rc;
   rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dzm, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
   if (rc) return rc;

@@ -1,0 +1,358 @@
+// LDS-tiled edge kernels for batched graphs of SMALL member snapshots (GDELT-shaped: hundreds of nodes, thousands of edges per
+// snapshot; models/RGCN.py:91-104 and its autograd).
+//
+// The block-diagonal relation weights make the feature columns of a layer independent in groups of `so` (<= 4) columns, and no
+// edge of a batched graph crosses its member snapshots.  So a workgroup takes ONE (member snapshot, slice of <= 16 float4
+// columns): it stages the member's rows of that slice (500 nodes x 13 float4 = 104 KB), the slice of the relation weight table
+// (17 KB), the member's edge ids as 16-/8-bit local indices (22 KB) and its chunk list, sorted by length (5 KB) in the CU's 160 KB
+// of LDS, and then every gather of the aggregation is an LDS read instead of an L2 round trip (the L2-gather kernels above moved
+// ~9 TB/s through L2 at a third of its peak and were bound by that latency).
+//
+// Lane layout: a wave holds four "walkers" of 16 lanes (the four lane groups in which the LDS serves a 16-byte read, see
+// tile_lane); a walker owns one chunk (<= 64 edges of one destination, or <= 128 of one relation) and walks its edges in order, one
+// float4 column per lane: exactly the per-chunk accumulation order of k_rgcn_agg_s / k_rgcn_dw_s, so results are BIT-IDENTICAL
+// to those kernels (same chunk partials, same fix-up pass).  Chunk lengths are Zipf-distributed (a hub's chunks are full, most
+// chunks hold a handful of edges): the block counting-sorts its chunks by length (LDS integer atomics: which chunk lands where
+// inside a bucket varies, no result depends on it) and waves pull groups of four neighbouring chunks from a block-local queue, so
+// the walkers of a wave finish together and waves balance dynamically.
+//
+// Per-edge scalars disappear: the d/dh kernel's nnorm[dst]^2 and the weight-gradient kernel's nnorm[dst]^2 are folded into the
+// staged rows (the same single fp32 product the per-edge form computes).
+#pragma once
+#include "common.hpp"
+
+namespace temp {
+
+#define TILE_LMAX 128                                        // longest chunk (TEMP_CHUNK_REL)
+#define TILE_MISC_INTS (2 * (TILE_LMAX + 2) + 2)             // histogram, cursors, queue head
+#define TILE_LDS_MAX (160 * 1024)                            // LDS of a CU: one workgroup takes what it needs of it
+#define TILE_THREADS 1024
+
+struct TileArgs {
+  const int32_t* node_off;                                   // member tables (device), chunk_off of THIS view
+  const int32_t* edge_off;
+  const int32_t* chunk_off;
+  int n_members;
+  int fs4, n_slices;                                         // float4 columns of the widest slice (= LDS row stride), slices per row
+  int off_x, off_g, off_w, off_ea, off_eb, off_cm, off_misc; // LDS byte offsets
+  int lds_bytes;
+  long long* prof;                                           // development only (temp_set_debug_buffer): 8 cycle stamps per block
+};
+#define TILE_STAMP(k) do { if (t.prof && threadIdx.x == 0) t.prof[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+
+// LDS plan for a launch: the fewest slices (widest rows, <= 16 float4) whose staging fits one CU's LDS.
+// rows2: the weight-gradient kernel stages two row sets (x and dz); w_rows: rows of the relation table (0: none staged).
+inline bool tile_plan(const TempMembers& mb, int view, int D, int S, int rows2, int w_rows, int b_bytes, TileArgs* t) {
+  if (mb.n_members <= 0 || !mb.node_off || !mb.edge_off || !mb.chunk_off) return false;
+  if (mb.max_nodes <= 0 || mb.max_nodes > 65535 || mb.max_edges > 65535 || mb.max_chunks[view] > 65535) return false;
+  const int D4 = D >> 2;
+  for (int ns = ceil_div(D4, 16); ns <= D4; ++ns) {
+    const int fs4 = ceil_div(D4, ns);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += align_up(bytes, 16); return (int)at; };
+    t->off_x = take((size_t)mb.max_nodes * fs4 * 16);
+    t->off_g = rows2 ? take((size_t)mb.max_nodes * fs4 * 16) : 0;
+    t->off_w = w_rows ? take((size_t)w_rows * S * fs4 * 16) : 0;
+    t->off_ea = take((size_t)mb.max_edges * 2 + 16);
+    t->off_eb = take((size_t)mb.max_edges * b_bytes + 16);
+    t->off_cm = take((size_t)mb.max_chunks[view] * 8);
+    t->off_misc = take((size_t)TILE_MISC_INTS * 4);
+    if (off > TILE_LDS_MAX) continue;
+    t->lds_bytes = (int)off;
+    t->fs4 = fs4;
+    t->n_slices = ns;
+    t->n_members = mb.n_members;
+    t->node_off = mb.node_off;
+    t->edge_off = mb.edge_off;
+    t->chunk_off = mb.chunk_off + (size_t)view * (mb.n_members + 1);
+    t->prof = nullptr;
+    return true;
+  }
+  return false;
+}
+
+struct TileBlock {
+  int m, slice, n0, nm, e0, em, c0, nc, f4_0, nf4;
+};
+
+__device__ __forceinline__ bool tile_block(const TileArgs& t, int D4, TileBlock& b) {
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // the slices of one member run on one XCD (they share its rows' lines)
+  b.m = xcd + 8 * (local / t.n_slices);
+  b.slice = local % t.n_slices;
+  if (b.m >= t.n_members) return false;
+  b.n0 = t.node_off[b.m]; b.nm = t.node_off[b.m + 1] - b.n0;
+  b.e0 = t.edge_off[b.m]; b.em = t.edge_off[b.m + 1] - b.e0;
+  b.c0 = t.chunk_off[b.m]; b.nc = t.chunk_off[b.m + 1] - b.c0;
+  b.f4_0 = (b.slice * D4) / t.n_slices;                      // even slices: widths differ by at most one float4
+  b.nf4 = ((b.slice + 1) * D4) / t.n_slices - b.f4_0;
+  return true;
+}
+
+// A wave's four WALKERS are the four 16-lane groups in which the LDS serves a ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19,
+// 28-31} and the same + 32: one LDS cycle per group when its lanes hit distinct banks).  The lanes of a walker read one
+// CONTIGUOUS run of <= 256 bytes (its <= 16 float4 of one staged row): every bank at most once, whatever the row -- so the random
+// row gathers of the aggregation run at the full 256 B/clk of the LDS.  (With walkers of consecutive lanes several rows share a
+// group and their bank ranges overlap at random: measured 2.3x slower.)  -> walker 0..3, column 0..15 of the lane.
+__device__ __forceinline__ void tile_lane(int lane, int& g, int& lr) {
+  const int l = lane & 31;
+  int grp, idx;
+  if (l < 4) { grp = 0; idx = l; }
+  else if (l < 12) { grp = 1; idx = l - 4; }
+  else if (l < 16) { grp = 0; idx = l - 8; }
+  else if (l < 20) { grp = 1; idx = l - 8; }
+  else if (l < 28) { grp = 0; idx = l - 12; }
+  else { grp = 1; idx = l - 16; }
+  g = (lane >> 5) * 2 + grp;
+  lr = idx;
+}
+
+// rows of one slice -> LDS (row i of the member at Xs[i * fs4 + lr]); `ids` (nullable) maps node -> table row; SCALE: x nnorm[node]^2
+template <bool SCALE>
+__device__ __forceinline__ void tile_stage_rows(float4* Xs, const TileArgs& t, const TileBlock& b, const float* __restrict__ src, int ld,
+                                                const int32_t* __restrict__ ids, const float* __restrict__ nnorm) {
+  const int w = b.nf4, rstep = blockDim.x / w;                // consecutive threads read consecutive float4 of a row
+  const int r0 = threadIdx.x / w, lr = threadIdx.x - r0 * w;
+  if (r0 >= rstep) return;
+  const float* base = src + (size_t)(b.f4_0 + lr) * 4;
+  const int fs4 = t.fs4;
+  constexpr int U = 8;                                       // rows in flight per thread (every batch predicated: a member has few passes)
+  for (int i = r0; i < b.nm; i += U * rstep) {
+    int row[U];
+    float4 x[U];
+    float nn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int node = b.n0 + min(i + u * rstep, b.nm - 1);  // past the end: the last row again (not stored)
+      row[u] = ids ? ids[node] : node;
+      nn[u] = SCALE ? nnorm[node] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = ld4(base + (size_t)row[u] * ld);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i + u * rstep < b.nm) Xs[(i + u * rstep) * fs4 + lr] = SCALE ? scale4(x[u], nn[u] * nn[u]) : x[u];
+  }
+}
+
+// the member's edge ids of a view as local 16-bit (a) and BT-sized (b) indices; a_sub / b_sub: what to subtract (node offset or 0)
+template <class BT>
+__device__ __forceinline__ void tile_stage_edges(unsigned short* Ea, BT* Eb, const TempEdgeView& v, const TileBlock& b, int a_sub, int b_sub) {
+  const int nthr = blockDim.x;
+  constexpr int U = 8;
+  for (int i = threadIdx.x; i < b.em; i += U * nthr) {
+    int a[U], bb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = b.e0 + min(i + u * nthr, b.em - 1);
+      a[u] = v.a[e];
+      bb[u] = v.b[e];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i + u * nthr < b.em) { Ea[i + u * nthr] = (unsigned short)(a[u] - a_sub); Eb[i + u * nthr] = (BT)(bb[u] - b_sub); }
+  }
+}
+
+// Chunk list of the member, counting-sorted by length (longest first) into cm[]:
+//   .x = first edge (relative to the member's edge range) | segment (relative to seg_sub) << 16      .y = partial slot (0xffffff: none) | length << 24
+// misc: [0, LMAX+2) histogram, [LMAX+2, 2 LMAX+4) cursors, then the queue head.  Must be zero on entry (and the zeroing visible:
+// a barrier before the call); ends with a barrier.  The chunk arrays are read once (a thread keeps up to two chunks in registers).
+__device__ __forceinline__ void tile_sort_chunks(uint2* cm, int* misc, const TempEdgeView& v, const TileBlock& b, int seg_sub) {
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  int* hist = misc;
+  int* cur = misc + TILE_LMAX + 2;
+  uint2 keep[2];
+  int klen[2] = {-1, -1};
+  for (int i = tid, u = 0; i < b.nc; i += nthr, ++u) {
+    const int beg = v.chunk_beg[b.c0 + i], len = min(max(v.chunk_end[b.c0 + i] - beg, 0), TILE_LMAX);
+    atomicAdd(&hist[TILE_LMAX - len], 1);
+    if (u < 2) {
+      const int seg = v.chunk_seg[b.c0 + i], slot = v.chunk_slot[b.c0 + i];
+      keep[u] = make_uint2((unsigned)(beg - b.e0) | ((unsigned)(seg - seg_sub) << 16), ((unsigned)slot & 0xffffffu) | ((unsigned)len << 24));
+      klen[u] = len;
+    }
+  }
+  __syncthreads();
+  if (tid <= TILE_LMAX) {
+    int s = 0;
+    for (int q = 0; q < tid; ++q) s += hist[q];
+    cur[tid] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (klen[u] >= 0) cm[atomicAdd(&cur[TILE_LMAX - klen[u]], 1)] = keep[u];
+  for (int i = tid + 2 * nthr; i < b.nc; i += nthr) {         // (members with more than 2 x 1024 chunks: re-read)
+    const int beg = v.chunk_beg[b.c0 + i], len = min(max(v.chunk_end[b.c0 + i] - beg, 0), TILE_LMAX);
+    const int seg = v.chunk_seg[b.c0 + i], slot = v.chunk_slot[b.c0 + i];
+    cm[atomicAdd(&cur[TILE_LMAX - len], 1)] = make_uint2((unsigned)(beg - b.e0) | ((unsigned)(seg - seg_sub) << 16), ((unsigned)slot & 0xffffffu) | ((unsigned)len << 24));
+  }
+  __syncthreads();
+}
+
+// Forward aggregation (view = by-dst: a = src node, b = relation; result x nnorm[seg]^2) and d/dh (view = by-src: a = dst node,
+// b = relation; rows pre-scaled by nnorm[dst]^2, transposed blocks).  BT: storage of the relation ids in LDS.
+// VAR (development ablations, 0 in the product path): 1 no row reads, 2 no weight reads, 4 no edge-id reads, 8 walkers = consecutive lanes
+template <int S, int MODE, class BT, int VAR = 0>
+__global__ void __launch_bounds__(TILE_THREADS) k_rgcn_agg_t(TempEdgeView v, TileArgs t, const float* __restrict__ feat, int ldf,
+                                                             const int32_t* __restrict__ feat_ids, const float* __restrict__ W, int n_rel_rows,
+                                                             const float* __restrict__ nnorm, int D, float* __restrict__ out,
+                                                             float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+  float4* Xs = reinterpret_cast<float4*>(tile_lds + t.off_x);
+  float4* Ws = reinterpret_cast<float4*>(tile_lds + t.off_w);
+  unsigned short* Ea = reinterpret_cast<unsigned short*>(tile_lds + t.off_ea);
+  BT* Eb = reinterpret_cast<BT*>(tile_lds + t.off_eb);
+  uint2* cm = reinterpret_cast<uint2*>(tile_lds + t.off_cm);
+  int* misc = reinterpret_cast<int*>(tile_lds + t.off_misc);
+  const int D4 = D >> 2;
+  TileBlock b;
+  if (!tile_block(t, D4, b)) return;
+  const int tid = threadIdx.x, nthr = blockDim.x, fs4 = t.fs4;
+  TILE_STAMP(0);
+  for (int i = tid; i < TILE_MISC_INTS; i += nthr) misc[i] = 0;
+  if (MODE == MODE_DX) tile_stage_rows<true>(Xs, t, b, feat, ldf, feat_ids, nnorm);
+  else tile_stage_rows<false>(Xs, t, b, feat, ldf, feat_ids, nnorm);
+  TILE_STAMP(1);
+  {  // weight slice: Ws[(r * S + j) * fs4 + lr] = W4[r * D4 * S + (f4_0 + lr) * S + j]
+    const float4* W4 = reinterpret_cast<const float4*>(W);
+    const int total = n_rel_rows * S * fs4;
+    for (int q = tid; q < total; q += nthr) {
+      const int rj = q / fs4, lr = q - rj * fs4;
+      const int r = rj / S, j = rj - r * S;
+      if (lr < b.nf4) Ws[q] = W4[(size_t)r * D4 * S + (size_t)(b.f4_0 + lr) * S + j];
+    }
+  }
+  TILE_STAMP(2);
+  tile_stage_edges<BT>(Ea, Eb, v, b, b.n0, 0);
+  TILE_STAMP(3);
+  __syncthreads();                                            // misc zeroed
+  TILE_STAMP(4);
+  tile_sort_chunks(cm, misc, v, b, b.n0);
+  TILE_STAMP(5);
+
+  const int lane = tid & 63;
+  int g, lr;
+  tile_lane(lane, g, lr);
+  if (VAR & 8) { g = lane >> 4; lr = lane & 15; }
+  const bool lane_ok = lr < b.nf4;
+  int* queue = misc + 2 * (TILE_LMAX + 2);
+  // byte addressing with 24-bit multiplies (full-rate v_mad_u32_u24; a 32-bit v_mul_lo_u32 issues at a quarter of that)
+  const unsigned char* xl = reinterpret_cast<const unsigned char*>(Xs + lr);
+  const unsigned char* wl = reinterpret_cast<const unsigned char*>(Ws + lr);
+  const unsigned xrow = (unsigned)fs4 * 16u, wrow_b = (unsigned)(S * fs4) * 16u;
+  for (;;) {
+    int task = 0;
+    if (lane == 0) task = atomicAdd(queue, 1);
+    task = __builtin_amdgcn_readfirstlane(task);
+    const int k = task * 4 + g;
+    if (task * 4 >= b.nc) break;
+    const bool has = lane_ok && k < b.nc;
+    const uint2 mt = has ? cm[k] : make_uint2(0u, 0xffffffu);
+    const int beg = mt.x & 0xffffu, segl = mt.x >> 16, len = mt.y >> 24;
+    const unsigned slot = mt.y & 0xffffffu;
+    float nn = 0.f;
+    if (MODE == MODE_FWD && has) nn = nnorm[b.n0 + segl];      // in flight during the walk
+    float4 acc = zero4();
+    const unsigned short* ea = Ea + beg;
+    const BT* eb = Eb + beg;
+    for (int j = 0; j < len; ++j) {                           // (per-walker trip count: the chunks of a task are neighbours in the sort)
+      const unsigned src = (VAR & 4) ? (unsigned)(j & 7) : (unsigned)ea[j], rel = (VAR & 4) ? (unsigned)(j & 3) : (unsigned)eb[j];
+      const float4 x = (VAR & 1) ? make_float4((float)src, 1.f, 2.f, 3.f) : *reinterpret_cast<const float4*>(xl + __umul24(src, xrow));
+      const unsigned char* wr = wl + __umul24(rel, wrow_b);
+      float4 w[S];
+#pragma unroll
+      for (int q = 0; q < S; ++q) w[q] = (VAR & 2) ? make_float4((float)rel, 1.f, 0.5f, (float)q) : *reinterpret_cast<const float4*>(wr + q * xrow);
+      block_mac<S, MODE>(acc, x, w, 1.f);
+    }
+    if (has) {
+      if (MODE == MODE_FWD) acc = scale4(acc, nn * nn);
+      float* dst = (slot == 0xffffffu) ? out + (size_t)(b.n0 + segl) * D : partial + (size_t)slot * D;
+      st4(dst + (b.f4_0 + lr) * 4, acc);
+    }
+  }
+  TILE_STAMP(6);
+  if (t.prof) { __syncthreads(); TILE_STAMP(7); }
+}
+
+// d/dweight (view = by-rel: a = src node, b = dst node, segment = relation row): x rows and dz rows (pre-scaled by nnorm[dst]^2)
+// staged; a walker accumulates the S x S outer products of its blocks over one relation chunk.
+template <int S>
+__global__ void __launch_bounds__(TILE_THREADS) k_rgcn_dw_t(TempEdgeView v, TileArgs t, const float* __restrict__ x, const int32_t* __restrict__ x_ids,
+                                                            const float* __restrict__ dz, const float* __restrict__ nnorm, int D,
+                                                            float* __restrict__ dW, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+  float4* Xs = reinterpret_cast<float4*>(tile_lds + t.off_x);
+  float4* Gs = reinterpret_cast<float4*>(tile_lds + t.off_g);
+  unsigned short* Ea = reinterpret_cast<unsigned short*>(tile_lds + t.off_ea);
+  unsigned short* Eb = reinterpret_cast<unsigned short*>(tile_lds + t.off_eb);
+  uint2* cm = reinterpret_cast<uint2*>(tile_lds + t.off_cm);
+  int* misc = reinterpret_cast<int*>(tile_lds + t.off_misc);
+  const int D4 = D >> 2;
+  TileBlock b;
+  if (!tile_block(t, D4, b)) return;
+  const int tid = threadIdx.x, nthr = blockDim.x, fs4 = t.fs4;
+  for (int i = tid; i < TILE_MISC_INTS; i += nthr) misc[i] = 0;
+  tile_stage_rows<false>(Xs, t, b, x, D, x_ids, nnorm);
+  tile_stage_rows<true>(Gs, t, b, dz, D, nullptr, nnorm);
+  tile_stage_edges<unsigned short>(Ea, Eb, v, b, b.n0, b.n0);
+  __syncthreads();
+  tile_sort_chunks(cm, misc, v, b, 0);
+
+  const int lane = tid & 63;
+  int g, lr;
+  tile_lane(lane, g, lr);
+  const bool lane_ok = lr < b.nf4;
+  int* queue = misc + 2 * (TILE_LMAX + 2);
+  const unsigned char* xl = reinterpret_cast<const unsigned char*>(Xs + lr);
+  const unsigned char* gl = reinterpret_cast<const unsigned char*>(Gs + lr);
+  const unsigned xrow = (unsigned)fs4 * 16u;
+  const int wrow = D * S;
+  for (;;) {
+    int task = 0;
+    if (lane == 0) task = atomicAdd(queue, 1);
+    task = __builtin_amdgcn_readfirstlane(task);
+    const int k = task * 4 + g;
+    if (task * 4 >= b.nc) break;
+    const bool has = lane_ok && k < b.nc;
+    const uint2 mt = has ? cm[k] : make_uint2(0u, 0xffffffu);
+    const int beg = mt.x & 0xffffu, seg = mt.x >> 16, len = mt.y >> 24;
+    const unsigned slot = mt.y & 0xffffffu;
+    float4 acc[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) acc[q] = zero4();
+    const unsigned short* ea = Ea + beg;
+    const unsigned short* eb = Eb + beg;
+    for (int j = 0; j < len; ++j) {
+      const float4 xx = *reinterpret_cast<const float4*>(xl + __umul24((unsigned)ea[j], xrow));
+      const float4 gg = *reinterpret_cast<const float4*>(gl + __umul24((unsigned)eb[j], xrow));
+      if (S == 1) {
+        acc[0].x = fmaf(xx.x, gg.x, acc[0].x);
+        acc[0].y = fmaf(xx.y, gg.y, acc[0].y);
+        acc[0].z = fmaf(xx.z, gg.z, acc[0].z);
+        acc[0].w = fmaf(xx.w, gg.w, acc[0].w);
+      } else if (S == 2) {
+        acc[0].x = fmaf(xx.x, gg.x, acc[0].x);
+        acc[0].y = fmaf(xx.x, gg.y, acc[0].y);
+        acc[0].z = fmaf(xx.y, gg.x, acc[0].z);
+        acc[0].w = fmaf(xx.y, gg.y, acc[0].w);
+        acc[S > 1 ? 1 : 0].x = fmaf(xx.z, gg.z, acc[S > 1 ? 1 : 0].x);
+        acc[S > 1 ? 1 : 0].y = fmaf(xx.z, gg.w, acc[S > 1 ? 1 : 0].y);
+        acc[S > 1 ? 1 : 0].z = fmaf(xx.w, gg.z, acc[S > 1 ? 1 : 0].z);
+        acc[S > 1 ? 1 : 0].w = fmaf(xx.w, gg.w, acc[S > 1 ? 1 : 0].w);
+      } else {
+        acc[0] = fma4(xx.x, gg, acc[0]);
+        acc[S > 1 ? 1 : 0] = fma4(xx.y, gg, acc[S > 1 ? 1 : 0]);
+        acc[S > 2 ? 2 : 0] = fma4(xx.z, gg, acc[S > 2 ? 2 : 0]);
+        acc[S > 3 ? 3 : 0] = fma4(xx.w, gg, acc[S > 3 ? 3 : 0]);
+      }
+    }
+    if (has) {
+      float* dst = ((slot == 0xffffffu) ? dW + (size_t)seg * wrow : partial + (size_t)slot * wrow) + (size_t)(b.f4_0 + lr) * 4 * S;
+#pragma unroll
+      for (int q = 0; q < S; ++q) st4(dst + 4 * q, acc[q]);
+    }
+  }
+}
+
+}  // namespace temp

@@ -584,7 +584,8 @@ def union_graph_packed(snap, n_rel_rows, device):
             m = g._dev[key] = g.device_views(device, n_rel_rows)["_meta"]
         metas.append(m)
     from . import _hostlib
-    ctl, sm = _hostlib.union_plan(np.stack([m["row"] for m in metas]), snap.node_off[:-1], snap.edge_off[:-1], n_rel_rows, _lib.ASSEMBLE_PIECE)
+    rows = np.stack([m["row"] for m in metas])
+    ctl, sm = _hostlib.union_plan(rows, snap.node_off[:-1], snap.edge_off[:-1], n_rel_rows, _lib.ASSEMBLE_PIECE)
     n_desc, npc, nfix, tail0 = (int(x) for x in sm[:4])
     out_base, totals = sm[4:32], sm[35:62]
     names = ["in_deg", "out_deg", "nnorm"] + [(vn, an) for vn in ("by_dst", "by_src") for an in _VIEW_ARRAYS] + \
@@ -607,6 +608,16 @@ def union_graph_packed(snap, n_rel_rows, device):
     for i, vn in enumerate(("by_dst", "by_src")):
         counts[vn] = dict(n_seg=int(snap.n), n_edges=E, n_chunks=sizes[(vn, "chunk_seg")], n_partial=int(sm[65 + i]), n_fix=sizes[(vn, "fix_seg")])
     counts["by_rel"] = dict(n_seg=int(n_rel_rows), n_edges=E, n_chunks=sizes[("by_rel", "chunk_seg")], n_partial=int(sm[67]), n_fix=nfix)
+    # member tables (include/temp_amd.h: TempMembers): every view of the union is member-major, so the edge kernels can take one
+    # workgroup per (member, feature slice) with the member's rows staged in LDS
+    M = len(metas)
+    nck = rows[:, [_COL[("by_dst", "chunk_seg")], _COL[("by_src", "chunk_seg")], _COL[("by_rel", "chunk_seg")]]].T      # (3, M) chunks per member
+    tab = np.zeros((5, M + 1), dtype=np.int32)
+    tab[0], tab[1] = snap.node_off, snap.edge_off
+    tab[2:, 1:] = np.cumsum(nck, axis=1)
+    members = dict(n_members=M, max_nodes=int(max(snap.node_sizes)) if M else 0, max_edges=int(np.diff(snap.edge_off).max()) if M else 0,
+                   max_chunks=[int(x) for x in nck.max(axis=1)] if M else [0, 0, 0], table=_lib.to_device(tab.reshape(-1), device))
+    counts["_members"] = members
     return ints, offs, sizes, counts, ctl_dev
 
 
@@ -743,6 +754,15 @@ class _DeviceGraph:
         g.n_nodes, g.n_edges = n, E
         g.nnorm, g.in_deg, g.out_deg = base + 4 * offs["nnorm"], base + 4 * offs["in_deg"], base + 4 * offs["out_deg"]
         self.views = {}
+        members = counts.pop("_members", None) if isinstance(counts, dict) else None
+        if members is not None and members["n_members"] > 0:
+            self._members = members                      # keeps the device table alive
+            mb, M = g.members, members["n_members"]
+            mb.n_members, mb.max_nodes, mb.max_edges = M, members["max_nodes"], members["max_edges"]
+            for i in range(3):
+                mb.max_chunks[i] = members["max_chunks"][i]
+            tb = members["table"].data_ptr()
+            mb.node_off, mb.edge_off, mb.chunk_off = tb, tb + 4 * (M + 1), tb + 8 * (M + 1)
         for vn, cnt in counts.items():
             ev = getattr(g, vn)
             for fld, val in cnt.items():

@@ -485,6 +485,72 @@ def test_post_ensemble_own_ratio_golden_gpu(name, batched):
     check_post_ensemble_ratio(name, DEV, batched)
 
 
+@pytest.mark.parametrize("D,B", [(200, 100), (64, 16), (32, 32)])
+def test_tiled_edge_kernels_bit_identical_gpu(D, B, hip_backend):
+    """LDS-tiled edge kernels (csrc/rgcn_tile.hpp: one workgroup per (member snapshot, feature slice), rows staged in LDS) against
+    the L2-gather kernels on the same batched graph: same chunks, same per-chunk order => BIT-identical aggregation, d/dh and
+    d/dweight at D = 200 (1e-6 for narrow rows, whose gather kernels use another order), for the plain layer and the table
+    layer, with a device-subsampled member in the batch.  The member tables of the
+    union are checked against its chunk arrays first."""
+    from temp_amd import _lib, snapshot as S, synthetic
+    lib = _lib.load()
+    w = synthetic.workload("S-gdelt", seed=0)
+    parts = [w["snapshots"][t] for t in (3, 40, 7, 103, 12, 200, 77, 5, 300)]
+    R2 = 2 * w["num_rels"]
+    sub = S.device_subsample([parts[2]], [parts[2].number_of_edges() // 2], [1234], DEV, R2)[0]
+    parts[2] = sub
+    g = S.batch(parts)
+    dg = g.device_graph(DEV, R2)
+    mb = dg.c.members
+    M = len(parts)
+    assert mb.n_members == M and mb.max_nodes == max(p.n for p in parts)
+    tab = dg._members["table"].cpu().numpy().reshape(5, M + 1)
+    assert np.array_equal(tab[0], g.node_off) and np.array_equal(tab[1], g.edge_off)
+    for vi, vn in enumerate(("by_dst", "by_src", "by_rel")):
+        seg, beg, end = (dg.view_tensor(vn, k).cpu().numpy() for k in ("chunk_seg", "chunk_beg", "chunk_end"))
+        co = tab[2 + vi]
+        assert co[0] == 0 and co[-1] == seg.shape[0] and mb.max_chunks[vi] == int(np.diff(co).max())
+        for m in range(M):
+            sl = slice(co[m], co[m + 1])
+            assert (beg[sl] >= tab[1][m]).all() and (end[sl] <= tab[1][m + 1]).all(), (vn, m)
+            if vn != "by_rel":
+                assert (seg[sl] >= tab[0][m]).all() and (seg[sl] < tab[0][m + 1]).all(), (vn, m)
+    rng = np.random.default_rng(5)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(DEV)
+    n, s_ = g.n, D // B
+    h, wt, lw, b, gy = f(n, D), f(R2, B * s_ * s_) * 0.5, f(D, D) * 0.2, f(D), f(n, D)
+    table = f(w["num_ents"], D)
+    ids = torch.from_numpy(g.gids.astype(np.int32)).to(DEV)
+    from temp_amd import functional as TF
+    inv = TF.gather_inverse(g.gids, w["num_ents"], DEV)
+
+    def run():
+        out = hip_backend.rgcn_fwd(dg, h, None, wt, lw, b, B, 1)
+        grads = hip_backend.rgcn_bwd(dg, h, out, gy, wt, lw, True, B, 1)
+        tout = hip_backend.rgcn_table_fwd(dg, table, ids, wt, lw, None, B, 0)
+        tgrads = hip_backend.rgcn_table_bwd(dg, table, ids, inv, tout, gy, wt, lw, False, B, 0)
+        torch.cuda.synchronize()
+        return [out] + [x for x in grads if x is not None] + [tout] + [x for x in tgrads if x is not None]
+
+    prev = lib.temp_set_option(_lib.OPT_RGCN_TILE, 2)         # 2: the weight-gradient kernel tiled too (default 1: aggregation and d/dh)
+    n0 = lib.temp_tile_launches()
+    tiled = run()
+    assert lib.temp_tile_launches() - n0 == 6, "the LDS-tiled kernels were not launched"
+    lib.temp_set_option(_lib.OPT_RGCN_TILE, 0)
+    try:
+        n1 = lib.temp_tile_launches()
+        gathered = run()
+        assert lib.temp_tile_launches() == n1
+    finally:
+        lib.temp_set_option(_lib.OPT_RGCN_TILE, prev)
+    assert len(tiled) == len(gathered)
+    for i, (a, c) in enumerate(zip(tiled, gathered)):
+        if D > 128:          # the gather path runs the one-edge-per-pass kernels here: the SAME per-chunk order as the tiled walkers
+            assert torch.equal(a, c), (i, float((a - c).abs().max()))
+        else:                # narrow rows: the gather kernels sum several edges per pass and reduce across lanes (another order)
+            assert_close(a, c, 2e-6, 2e-6 * max(1.0, float(c.abs().max())), "tiled vs gathered %d" % i)
+
+
 def test_rgcn_layer_row_gather_in_large_gemm_gpu():
     """temp_rgcn_fwd with feature ids at a size that takes the split-operand GEMM (>= 16 K rows): the self-loop product gathers
     its rows through a_idx inside the kernel; result = the same layer on the explicitly gathered rows.  Nodes without in-edges

@@ -1,0 +1,10 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+( timeout 600 python -m pytest tests/test_gpu_parity_r2.py -x -q -k "tiled_edge" ) > gpurun_out/tile_test.log 2>&1
+tail -15 gpurun_out/tile_test.log
+python bench.py --steps 20 --warmup 5 --kernel-table --train-loop-steps 0 --no-cpu-baseline --no-fp32-mfma-compare > gpurun_out/bench_2.json 2> gpurun_out/bench_2.err
+grep -v Warning gpurun_out/bench_2.err | head -40
+python -c "
+import json
+d=json.loads(open('gpurun_out/bench_2.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
+timeout 120 tools/build/bx_probe 4 > gpurun_out/bx_probe_g4.log 2>&1; tail -12 gpurun_out/bx_probe_g4.log
