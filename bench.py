@@ -246,57 +246,147 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
                        % (nwin, w["name"], visits, edges, dt))
 
 
-def measure_sharded(model, w, world, rank, device, steps, warmup, dist):
+def measure_sharded(model, w, world, rank, device, steps, warmup, dist, graphs=True):
     """BASELINE north_star variant (config 4): ONE global batch of bsz * world windows; its distinct snapshots are cut into
     `world` edge-balanced shards, each rank runs the two RGCN layers on its shard, one direct all-gather over xGMI hands every
     rank all per-snapshot node states, the recurrent chain is sharded by window, gradients are all-reduced in one bucket.
-    Eager launches (the collectives are not captured).  -> dict for the JSON line (rank 0) or None."""
+    Everything except the collectives is replayed from three HIP graphs (temp_amd.dist.ShardedStep).
+    -> dict for the JSON line (rank 0) or None."""
     from temp_amd import synthetic
-    from temp_amd.dist import SnapshotShardedEncoder, _AllGatherRows, allreduce_gradients
+    from temp_amd.dist import ShardedStep, SnapshotShardedEncoder, allgather_rows
     all_targets = [t for r in range(world) for t in synthetic.default_targets(w["num_times"], w["L"], w["bsz"], r)]
     model.sample_rng = np.random.default_rng(2)
     enc = SnapshotShardedEncoder(model)
     sb = enc.prepare(all_targets, w["L"], train=True)
     params = [p for p in model.parameters()]
-
-    def step():
-        for p in params:
-            p.grad = None
-        enc.run(sb).sum().backward()
-        allreduce_gradients(params, world, average=False)
+    st = ShardedStep(enc, sb, params, graphs=graphs, average=False, force_allreduce=True)    # (force: a single forced rank still calls RCCL)
 
     for _ in range(warmup):
-        step()
+        st.step()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        st.step()
     dist.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    # the all-gather alone (forward direction), on a buffer of this rank's shard size
+    # the all-gather alone (forward direction) on this step's buffers
     n_local = sb.row_bounds[rank + 1] - sb.row_bounds[rank]
     y = torch.randn(n_local, w["D"], device=device)
     for _ in range(3):
-        _AllGatherRows.apply(y, sb.row_bounds, world, rank, None)
+        allgather_rows(y, st.y2_all, sb.row_bounds, world, rank, None)
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(10):
-        _AllGatherRows.apply(y, sb.row_bounds, world, rank, None)
+        allgather_rows(y, st.y2_all, sb.row_bounds, world, rank, None)
     torch.cuda.synchronize()
     tg = torch.tensor([(time.perf_counter() - t1) / 10], device=device, dtype=torch.float64)
     dist.all_reduce(tg, op=dist.ReduceOp.MAX)
     for p in params:
         p.grad = None
-    return dict(value=sb.n_edge_visits_global * steps / elapsed, unit="edges/s", ms_per_step=1e3 * elapsed / steps,
-                global_windows=len(all_targets), rccl_ranks=dist.get_world_size(), launch="eager",
+    ms = 1e3 * elapsed / steps
+    recv = sb.gather_bytes - n_local * w["D"] * 4
+    # per-rank step roofline with SURVEY 8d's byte model, de-dup aware: this rank's RGCN bytes on ITS distinct snapshots + the GRU
+    # bytes of ITS windows' node visits + the exchanged rows once in, once out
+    D = w["D"]
+    n_gru = int(sb.program.n_total)
+    rank_bytes = sb.n_edge_visits_local * 2 * (12 * D + 24) + n_local * 2 * (20 * D + 16) + n_gru * (32 * D + 4)
+    ag_ms = 1e3 * float(tg.item())
+    return dict(value=sb.n_edge_visits_global * steps / elapsed, unit="edges/s", ms_per_step=ms,
+                global_windows=len(all_targets), rccl_ranks=dist.get_world_size(), launch=("3 hip graphs + eager collectives" if st.graphs is not None else "eager"),
                 edge_visits_per_step_global=sb.n_edge_visits_global, distinct_edges_this_rank=sb.n_edge_visits_local,
-                allgather_bytes_received_per_rank=sb.gather_bytes - n_local * w["D"] * 4, allgather_ms=1e3 * float(tg.item()),
+                allgather_bytes_received_per_rank=recv, allgather_ms=ag_ms,
+                allgather_gbps_per_rank=(recv / (ag_ms * 1e-3) / 1e9) if ag_ms > 0 and recv > 0 else None,
+                per_rank_roofline=dict(bound="hbm", algorithmic_bytes=rank_bytes, achieved=rank_bytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                                       unit="GB/s", frac=rank_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
                 parallelism="distinct snapshots/%d (edge-balanced) + direct all-gather(node states) + window-sharded GRU chain + grad all-reduce" % world)
+
+
+def shbm_main(a, lib, device):
+    """`--workload S-hbm`: the edge kernels in the HBM regime the BASELINE metric is named after.  A full 15-position
+    window at this shape (2^20 nodes, 2^24 edges per snapshot: 23 GB per node-state tensor x ~20 live tensors) does not fit one
+    GPU, so a step here is ONE RGCN layer, forward + backward, over ONE snapshot whose 839-MB node matrix is far beyond the 256-MB
+    Infinity Cache.  `value` = edges processed per second (fwd + bwd of the layer); `roofline` = the forward aggregation kernel's
+    ALGORITHMIC bytes (E (row + 8) + n row) over its HIP-event time against 8 TB/s, with the rocprofv3 PMC traffic of the same
+    command (profiles/pmc_traffic_shbm*.json: FETCH_SIZE / WRITE_SIZE passes) beside it -- where the byte model exceeds the peak
+    (Zipf hub rows are cache hits) `frac_from_counters` is the honest fraction."""
+    from temp_amd import _lib, synthetic
+    from temp_amd import backend as TB
+    n, E, R, D, B = 1 << a.shbm_log2_nodes, 1 << a.shbm_log2_edges, a.shbm_relations, 200, 100
+    t0 = time.perf_counter()
+    g = synthetic.make_snapshots(n, R, E, n, 1, seed=0)[0]
+    dg = g.device_graph(device, 2 * R)
+    prep = time.perf_counter() - t0
+    be = TB.get_backend()
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    S = D // B
+    w = (torch.rand(2 * R, B * S * S, generator=gen) - 0.5).to(device)
+    lw = ((torch.rand(D, D, generator=gen) - 0.5) * 0.2).to(device)
+    h = torch.randn(n, D, device=device)
+    gy = torch.randn(n, D, device=device)
+
+    def step():
+        out = be.rgcn_fwd(dg, h, None, w, lw, None, B, 1)
+        be.rgcn_bwd(dg, h, out, gy, w, lw, False, B, 1)
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tr = traced_steps(step, max(a.trace_steps, 1), lib) if a.trace_steps > 0 else {}
+    row = 4 * D
+    alg = {"k_rgcn_agg<fwd>": E * (row + 8) + n * row, "k_rgcn_agg<dx>": E * (row + 12) + n * row, "k_rgcn_dw": E * (2 * row + 12),
+           "k_gemm_panel<loop_fwd>": 3 * n * row, "k_gemm_panel<loop_dx>": 3 * n * row, "k_relu_bwd": 3 * n * row}
+    pmc_path = os.path.join(REPO, "profiles", "pmc_traffic_shbm%s.json" % ("" if R == 230 else "_rel%d" % R))
+    per_kernel = json.load(open(pmc_path)).get("kernels", {}) if os.path.exists(pmc_path) else {}
+
+    def traffic_of(trace_name):
+        """HBM-side bytes per launch (PMC) of the kernel behind a trace id: k_rgcn_agg*<S, MODE, ...> with MODE 0 = fwd, 1 = d/dh."""
+        import re
+        for k, v in per_kernel.items():
+            m = re.match(r"(k_rgcn_agg\w*)<\s*\d+\s*,\s*(\d)", k)
+            if m and trace_name == ("k_rgcn_agg<fwd>" if m.group(2) == "0" else "k_rgcn_agg<dx>"):
+                return v["traffic_bytes_per_launch"]
+            if trace_name == "k_rgcn_dw" and k.startswith("k_rgcn_dw"):
+                return v["traffic_bytes_per_launch"]
+        return None
+
+    kernels = {}
+    for k, v in sorted(tr.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+        e = dict(launches_per_step=v["launches_per_step"], avg_ms=v["avg_ms"])
+        if k in alg:
+            e["algorithmic_bytes"] = alg[k]
+            e["algorithmic_GBps"] = alg[k] / (v["avg_ms"] * 1e-3) / 1e9
+            e["frac_of_8TBps_algorithmic"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
+        tb = traffic_of(k)
+        if tb is not None:
+            e["traffic_bytes"] = tb
+            e["frac_of_8TBps_from_counters"] = tb / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        kernels[k] = e
+    roof = None
+    dom = "k_rgcn_agg<fwd>"
+    if dom in tr:
+        ach = alg[dom] / (tr[dom]["avg_ms"] * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic_of(dom),
+                    avg_launch_ms=tr[dom]["avg_ms"], algorithmic_per_launch=alg[dom])
+        if roof["traffic"] is not None:
+            roof["traffic_unit"] = "bytes/launch (rocprofv3 PMC, %s)" % os.path.relpath(pmc_path, REPO)
+            roof["frac_from_counters"] = roof["traffic"] / (tr[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out = dict(metric="edges/sec (fwd+bwd) of ONE RGCN layer over one S-hbm snapshot (edge kernels, HBM regime)", value=E * a.steps / elapsed, unit="edges/s",
+               n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic",
+               config=dict(workload="S-hbm", nodes=n, edges=E, relations=R, embed=D, n_bases=B, host_prepare_s=prep,
+                           what="one RGCN layer fwd+bwd on one snapshot; a 15-position window of this shape does not fit one GPU"),
+               roofline=roof, kernels=kernels, cpu_baseline=None)
+    print(json.dumps(out), flush=True)
 
 
 def _cpu_model():
@@ -338,6 +428,9 @@ def main():
                     help="gru: the headline RGCN+GRU window models; attention: SelfAttentionRGCN / BiSelfAttentionRGCN (config 5, "
                          "secondary measurement: no cpu_baseline leg)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the step as a captured HIP graph")
+    ap.add_argument("--shbm-relations", type=int, default=230, help="--workload S-hbm: relations (230 = SURVEY's, 20 = GDELT's: the weight table then fits LDS)")
+    ap.add_argument("--shbm-log2-nodes", type=int, default=20)
+    ap.add_argument("--shbm-log2-edges", type=int, default=24)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -364,6 +457,12 @@ def main():
     CPU_THREADS = max(1, a.cpu_threads)
     MFMA_MODE = "bf16x3" if lib.temp_get_option(OPT_MFMA_BF16X3) else "f32"
 
+    if a.workload == "S-hbm":
+        if rank == 0:
+            shbm_main(a, lib, device)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     w = synthetic.workload(a.workload, seed=0)
     model = build_model(w, device, a.encoder)
     if a.encoder == "attention":
@@ -374,7 +473,7 @@ def main():
     ns_result = None
     if dist is not None and a.shard == "both" and a.encoder == "gru" and not a.with_loss:
         try:
-            ns_result = measure_sharded(model, w, world, rank, device, a.steps, a.warmup, dist)
+            ns_result = measure_sharded(model, w, world, rank, device, a.steps, a.warmup, dist, graphs=not a.no_graph)
         except Exception as e:                      # never lose the headline line to the secondary measurement
             ns_result = dict(error="%s: %s" % (type(e).__name__, e))
     targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rank)
@@ -389,6 +488,8 @@ def main():
         wb.n_edge_visits = wb.n_edge_visits_global / world       # per-rank share of the global step
         wb.n_node_visits = 0
         run = lambda: enc.run(wb)
+        from temp_amd.dist import ShardedStep
+        sharded_step = ShardedStep(enc, wb, params, graphs=not a.no_graph, average=False, force_allreduce=True)
     else:
         model.sample_rng = np.random.default_rng(2 + rank)
         wb = model.prepare(targets, w["L"], train=True)
@@ -453,6 +554,8 @@ def main():
         graph, graph_grads = capture()
 
     def step():
+        if sharded:
+            return sharded_step.step()
         if graph is None:
             return step_eager()
         graph.replay()
@@ -594,7 +697,10 @@ def main():
                                distinct_snapshot_edges_per_step=getattr(wb, "n_edges_distinct", None),
                                distinct_snapshot_nodes_per_step=getattr(wb, "n_nodes_distinct", None), targets=targets,
                                parallelism=("snapshot-visits/%d+allgather(node states)+grad-allreduce" % world) if sharded
-                               else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s, launch=("hip-graph replay" if graph is not None else "eager"),
+                               else ("dp%d(windows)+grad-allreduce" % world), host_prepare_s=prepare_s,
+                               launch=(("3 hip graphs + eager collectives" if sharded_step.graphs is not None else "eager") if sharded
+                                       else ("hip-graph replay" if graph is not None else "eager")),
+                               rccl_ranks=(dist.get_world_size() if dist is not None else 0),
                                train_loop=loop,
                                mfma=("every large fp32 product (panel GEMMs, weight gradients, the window-chain kernels' W_hh products) on the bf16 "
                                      "matrix pipe as six products of an exact 3-way operand split (fp32-equivalent accuracy, gemm_bx.hpp); "

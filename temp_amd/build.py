@@ -15,6 +15,9 @@ LIB = os.path.join(PKG, "libtemp_amd.so")
 SOURCES = ["rgcn_kernels.hip", "gemm_kernels.hip", "gru_kernels.hip", "gru_chain.hip", "attn_kernels.hip", "store_kernels.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")] + [os.path.join(REPO, "include", "temp_amd.h")]
 OBJDIR = os.path.join(CSRC, "build")
+# per-source flags (none at present; -fno-slp-vectorize on rgcn_kernels.hip -- v_fmac_f32 pairs instead of v_pk_fma_f32 in the
+# edge kernels -- measured neutral with tools/tile_phases.py)
+EXTRA_FLAGS = {}
 
 
 def _newer(deps, target):
@@ -36,7 +39,7 @@ def build(force=False, verbose=True):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer([src] + HEADERS, obj):
-            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            cmd = [hipcc] + flags + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print("[temp_amd.build] " + " ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))

@@ -55,7 +55,7 @@ class GradBucket:
             self.flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=dev)
         return self.flat
 
-    def allreduce(self, world=None, average=True, group=None, grads=None):
+    def allreduce(self, world=None, average=True, group=None, grads=None, force=False):
         """Few launches whatever the number of parameters: ONE multi-tensor copy of the gradients into the flat buffer, the
         collective (averaging inside it where the backend can: RCCL), and NO copy back -- each parameter's `.grad` becomes
         its span of the flat buffer (a later in-place accumulation into `.grad` then lands in the buffer, and the next
@@ -63,7 +63,7 @@ class GradBucket:
         `.grad`s as the source: a replayed HIP graph writes the gradient tensors of its CAPTURE, whatever `.grad` points to."""
         if world is None:
             world = dist.get_world_size(group)
-        if world == 1 or not self.params:
+        if (world == 1 and not force) or not self.params:    # force: run the collective on a single rank too (exercises the RCCL path)
             return
         flat = self._buffer()
         views = [flat[a:b].view_as(p) for p, (a, b) in zip(self.params, self.spans)]
@@ -98,7 +98,7 @@ class GradBucket:
             p.grad = None if i in nobody else v
 
 
-def allreduce_gradients(params, world=None, average=True, group=None, grads=None):
+def allreduce_gradients(params, world=None, average=True, group=None, grads=None, force=False):
     """One flat bucket for all parameter gradients (about 2.5 M floats at D=200 on ICEWS14); the bucket (layout + buffer) is
     built once per parameter list and kept on its first parameter."""
     if grads is not None:
@@ -111,7 +111,49 @@ def allreduce_gradients(params, world=None, average=True, group=None, grads=None
     if bucket is None or bucket[0] != key:
         bucket = (key, GradBucket(params))
         params[0]._temp_grad_bucket = bucket
-    bucket[1].allreduce(world, average, group, grads)
+    bucket[1].allreduce(world, average, group, grads, force)
+
+
+def allgather_rows(local, out, bounds, world, rank, group=None):
+    """out[bounds[q]:bounds[q+1]] <- rank q's `local` rows, for every q, as ONE grouped point-to-point batch (see _AllGatherRows).
+    `out` is caller-owned (a static buffer when the surrounding compute is replayed from HIP graphs).  On RCCL `req.wait()` orders
+    the CURRENT STREAM behind the transfers (the host does not block); on gloo it blocks the host, which is what a CPU run needs."""
+    out[bounds[rank]:bounds[rank + 1]] = local
+    ops = []
+    for q in range(world):
+        if q == rank:
+            continue
+        if bounds[q + 1] > bounds[q]:
+            ops.append(dist.P2POp(dist.irecv, out[bounds[q]:bounds[q + 1]], _global_rank(q, group), group))
+        if local.shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, local, _global_rank(q, group), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def allgather_rows_adjoint(d_all, pieces, bounds, world, rank, group=None):
+    """Adjoint of allgather_rows: block q of every rank's `d_all` goes to rank q, which sums the pieces in RANK ORDER
+    (deterministic).  `pieces` is a caller-owned (world, n_local, d) buffer.  -> (n_local, d)"""
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n_local = hi - lo
+    pieces[rank] = d_all[lo:hi]
+    ops = []
+    for q in range(world):
+        if q == rank:
+            continue
+        if n_local > 0:
+            ops.append(dist.P2POp(dist.irecv, pieces[q], _global_rank(q, group), group))
+        if bounds[q + 1] > bounds[q]:
+            ops.append(dist.P2POp(dist.isend, d_all[bounds[q]:bounds[q + 1]], _global_rank(q, group), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    mine = pieces[0]
+    for q in range(1, world):                        # fixed order: the sum does not depend on arrival order
+        mine = mine + pieces[q]
+    return mine
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -127,20 +169,7 @@ class _AllGatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, local, bounds, world, rank, group):
-        d = local.shape[1]
-        out = local.new_empty(int(bounds[-1]), d)
-        out[bounds[rank]:bounds[rank + 1]] = local
-        ops = []
-        for q in range(world):
-            if q == rank:
-                continue
-            if bounds[q + 1] > bounds[q]:
-                ops.append(dist.P2POp(dist.irecv, out[bounds[q]:bounds[q + 1]], _global_rank(q, group), group))
-            if local.shape[0] > 0:
-                ops.append(dist.P2POp(dist.isend, local, _global_rank(q, group), group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        out = allgather_rows(local, local.new_empty(int(bounds[-1]), local.shape[1]), bounds, world, rank, group)
         ctx.meta = (bounds, world, rank, group)
         return out
 
@@ -148,25 +177,8 @@ class _AllGatherRows(torch.autograd.Function):
     def backward(ctx, d_all):
         bounds, world, rank, group = ctx.meta
         d_all = d_all.contiguous()
-        lo, hi = bounds[rank], bounds[rank + 1]
-        n_local, d = hi - lo, d_all.shape[1]
-        pieces = d_all.new_empty(world, n_local, d)
-        pieces[rank] = d_all[lo:hi]
-        ops = []
-        for q in range(world):
-            if q == rank:
-                continue
-            if n_local > 0:
-                ops.append(dist.P2POp(dist.irecv, pieces[q], _global_rank(q, group), group))
-            if bounds[q + 1] > bounds[q]:
-                ops.append(dist.P2POp(dist.isend, d_all[bounds[q]:bounds[q + 1]], _global_rank(q, group), group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        mine = pieces[0]
-        for q in range(1, world):                    # fixed order: the sum does not depend on arrival order
-            mine = mine + pieces[q]
-        return mine, None, None, None, None
+        pieces = d_all.new_empty(world, bounds[rank + 1] - bounds[rank], d_all.shape[1])
+        return allgather_rows_adjoint(d_all, pieces, bounds, world, rank, group), None, None, None, None
 
 
 def _global_rank(r, group):
@@ -319,20 +331,141 @@ class SnapshotShardedEncoder:
         return sb
 
     # ---------------------------------------------------------------------------------------------
-    def run(self, sb):
-        """-> (target-position embeddings of THIS rank's windows, concatenated, forward order).  A rank that owns no window
-        (bsz < world) gets a (0, D) tensor that is still attached to the graph: EVERY rank must run backward on (a function
-        of) its output -- `out.sum()` is enough -- because the adjoint of the all-gather is a collective."""
+    # The step in three compute parts around the two exchanges (ShardedStep replays each part as ONE HIP graph):
+    def local_layers(self, sb):
+        """Part 1: the two RGCN layers on this rank's snapshots -> y2 (n_local, D), attached to the autograd graph."""
         m = self.model
         enc = m.ent_encoder
         y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table (DESIGN 3b)
-        y2 = enc.layer_2.conv(sb.g_local, y1)
-        y2_all = _AllGatherRows.apply(y2, sb.row_bounds, self.world, self.rank, self.group)
+        return enc.layer_2.conv(sb.g_local, y1)
+
+    def chain_on_gathered(self, sb, y2_all):
+        """Part 2: GRU inputs of this rank's windows out of the gathered node states + the window-sharded recurrence
+        -> target-position embeddings of this rank's windows."""
+        l2 = self.model.ent_encoder.layer_2
         x = TF.gather_rows(y2_all, sb.x_index32, sb.x_inv)                                   # deterministic adjoint (segment sum)
-        l2 = enc.layer_2
         rnns = [l2.forward_rnn, l2.backward_rnn] if hasattr(l2, "forward_rnn") else [l2.rnn]
         pieces = gru_chain(x, sb.program, rnns, l2.inv_temperature, isinstance(rnns[0], GRUCell), want=list(sb.out_inst))
         out = None
         for piece in pieces:                          # only the target-position states are consumed (no full-size gradient buffers)
             out = piece if out is None else out + piece
         return out
+
+    def run(self, sb):
+        """-> (target-position embeddings of THIS rank's windows, concatenated, forward order).  A rank that owns no window
+        (bsz < world) gets a (0, D) tensor that is still attached to the graph: EVERY rank must run backward on (a function
+        of) its output -- `out.sum()` is enough -- because the adjoint of the all-gather is a collective."""
+        y2 = self.local_layers(sb)
+        y2_all = _AllGatherRows.apply(y2, sb.row_bounds, self.world, self.rank, self.group)
+        return self.chain_on_gathered(sb, y2_all)
+
+
+class ShardedStep:
+    """One forward+backward of the snapshot-sharded encoder on a STATIC batch with everything except the collectives replayed
+    from HIP graphs (BASELINE north_star):
+
+        graph A   RGCN layers on this rank's snapshots                      -> y2 (n_local, D)
+        exchange  unpadded all-gather of the node states (grouped P2P over xGMI, RCCL's stream)
+        graph B   row gather + window-sharded GRU chain, forward AND backward -> out, d(gathered states), GRU gradients
+        exchange  the adjoint: every rank's piece of MY rows' gradient, summed in rank order
+        graph C   backward of the RGCN layers                               -> layer / embedding gradients
+        all-reduce of the flat gradient bucket (GradBucket, averaging inside the collective on RCCL)
+
+    The three graphs share one memory pool (graph C consumes what graph A saved for backward); the buffers the exchanges
+    read and write are static.  `upstream`: the gradient on `out` (default ones).  With graphs=False the same three
+    parts run eagerly (CPU / gloo tests, and the reference the graphed run is compared with: bit-identical)."""
+
+    def __init__(self, enc, sb, params, graphs=True, average=False, force_allreduce=False):
+        self.enc, self.sb, self.params, self.average = enc, sb, [p for p in params if p.requires_grad], average
+        self.force_allreduce = force_allreduce
+        self.world, self.rank, self.group = enc.world, enc.rank, enc.group
+        dev = enc.model._device()
+        d = enc.model.embed_size
+        b = sb.row_bounds
+        self.n_local = b[self.rank + 1] - b[self.rank]
+        self.y2_all = torch.zeros(int(b[-1]), d, dtype=torch.float32, device=dev)           # static exchange buffers
+        self.pieces = torch.zeros(self.world, self.n_local, d, dtype=torch.float32, device=dev)
+        self.d_local = torch.zeros(self.n_local, d, dtype=torch.float32, device=dev)
+        self.out = None
+        self.graphs = None
+        if graphs and dev.type == "cuda":
+            self._capture()
+
+    # -- the three parts (they communicate through attributes so that a capture and an eager call are the same code) ------
+    def _part_a(self):
+        self.y2 = self.enc.local_layers(self.sb)
+
+    def _part_b(self):
+        leaf = self.y2_all.detach().requires_grad_(True)
+        self.out = self.enc.chain_on_gathered(self.sb, leaf)
+        up = getattr(self, "_ones", None)
+        if up is None or up.shape != self.out.shape:
+            up = self._ones = torch.ones_like(self.out)
+        self.out.backward(up)
+        self.d_all = leaf.grad if leaf.grad is not None else torch.zeros_like(self.y2_all)
+
+    def _part_c(self):
+        self.y2.backward(self.d_local)
+
+    def _exchange_fwd(self):
+        allgather_rows(self.y2.detach(), self.y2_all, self.sb.row_bounds, self.world, self.rank, self.group)
+
+    def _exchange_bwd(self):
+        self.d_local.copy_(allgather_rows_adjoint(self.d_all, self.pieces, self.sb.row_bounds, self.world, self.rank, self.group))
+
+    def _eager(self):
+        for p in self.params:
+            p.grad = None
+        self._part_a()
+        self._exchange_fwd()
+        self._part_b()
+        self._exchange_bwd()
+        self._part_c()
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up off the capture stream (allocator, lazy module state)
+            for _ in range(2):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in self.params:
+            p.grad = None
+        # Nothing may keep an autograd graph of these parameters alive across the capture: a parameter's AccumulateGrad node
+        # survives as long as a graph references it and keeps the stream it was created on -- with a node left over from an
+        # EAGER backward on the default stream, graph C's backward would touch the default stream inside the capture (HIP aborts
+        # the process).  The warm-up's own references go here; callers must drop theirs (outputs of earlier steps) first.
+        self.y2 = self.out = self.d_all = None
+        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            self._part_a()
+        self._exchange_fwd()
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            self._part_b()
+        self._exchange_bwd()
+        with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode="thread_local"):
+            self._part_c()
+        torch.cuda.synchronize()
+        self.graphs = (ga, gb, gc)
+        self.grads = [p.grad for p in self.params]    # the tensors every replay writes
+
+    def step(self, allreduce=True):
+        """-> target-position embeddings of this rank's windows; the parameters' .grad hold this rank's (or, after the
+        all-reduce, the job's) gradients."""
+        if self.graphs is None:
+            self._eager()
+            grads = None
+        else:
+            ga, gb, gc = self.graphs
+            ga.replay()
+            self._exchange_fwd()
+            gb.replay()
+            self._exchange_bwd()
+            gc.replay()
+            grads = self.grads
+            for p, g in zip(self.params, grads):
+                p.grad = g
+        if allreduce:
+            allreduce_gradients(self.params, self.world, average=self.average, group=self.group, grads=grads, force=self.force_allreduce)
+        return self.out

@@ -9,6 +9,7 @@ recorded outputs.
   * temp_amd.scores and the folded-query kernels vs G9_scores.npz (recorded from utils/scores.py).
 Tolerance: 1e-5 relative fp32 with a small absolute floor on outputs; gradients that sum over ~10^5 rows get 1e-4."""
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -42,16 +43,18 @@ def _oracle_model(model, w, module, te=False):
     return om, cfg, gd
 
 
-def _assert_grad_close(got, ref, what, rtol=1e-4, atol_frac=2e-5, max_bad=0.03, frob=1e-2):
+def _assert_grad_close(got, ref, what, rtol=1e-4, atol_frac=2e-5, max_bad=1e-4, frob=1e-4, frob_clean=6e-6):
     """Gradient check that tolerates ReLU-kink flips.  Layer 2 of these encoders ends in a ReLU over ~10^7 pre-activations
     per step; a handful of them lie within fp32 rounding of 0, where the fp32 HIP path and the fp64 oracle legitimately take
     different sides (measured with tools/attn_grad_probe.py: ONE flipped element moves d h_bias by 1.6e-2 and 2 of the 16 000
     entries of d layer_2.weight by 5 % of their maximum, while d q/k/v_linear, which do not pass through the kink, agree
     to 1e-6).  Each flip touches few gradient entries, so a tensor passes when EITHER its relative Frobenius error is below
-    2e-4 (fp32 round-off of sums over ~6e4 rows, no flip in its path) OR at least 97 % of its entries are within
-    (rtol, atol_frac * max|ref|) elementwise and the whole tensor within `frob` in Frobenius norm.  A wrong kernel fails
-    both by orders of magnitude; the small-size golden tests (no flips at that size) pin the same kernels to 1e-5
-    elementwise."""
+    `frob_clean` (fp32 round-off of sums over ~6e4 rows, no flip in its path) OR at most `max_bad` of its entries are outside
+    (rtol, atol_frac * max|ref|) elementwise and the whole tensor within `frob` in Frobenius norm.
+    Thresholds = measured x 3 (round 3, all 87 full-size checks of the suite printed with `pytest -s`, gpurun_out/grad_stats.txt):
+    every tensor had 0.0000 % of its entries out of tolerance and a relative Frobenius error between 2.4e-7 and 1.9e-6 -- no
+    flip occurs with the committed seeds, so the flip branch (max_bad = 0.01 %, frob = 1e-4) is head-room, not slack in use.
+    A wrong scale on 2 % of the rows of a gradient fails both branches by orders of magnitude."""
     g = got.detach().cpu().double()
     r = ref.detach().cpu().double()
     assert g.shape == r.shape, what
@@ -59,7 +62,12 @@ def _assert_grad_close(got, ref, what, rtol=1e-4, atol_frac=2e-5, max_bad=0.03, 
     tol = atol_frac * float(r.abs().max()) + rtol * r.abs()
     bad = float((err > tol).double().mean())
     rel_f = float(err.norm() / r.norm().clamp_min(1e-30))
-    assert rel_f <= 2e-4 or (bad <= max_bad and rel_f <= frob), "%s: %.2f%% of the entries out of tolerance, relative Frobenius error %.2e" % (what, 100 * bad, rel_f)
+    GRAD_STATS.append((what, bad, rel_f))
+    print("grad-check %-48s out-of-tolerance %.4f%%  relative Frobenius error %.2e" % (what, 100 * bad, rel_f))
+    assert rel_f <= frob_clean or (bad <= max_bad and rel_f <= frob), "%s: %.2f%% of the entries out of tolerance, relative Frobenius error %.2e" % (what, 100 * bad, rel_f)
+
+
+GRAD_STATS = []     # (what, fraction out of tolerance, relative Frobenius error) of every full-size gradient check of the session (-s prints them)
 
 
 def _upstream(sizes, D, seed):
@@ -117,6 +125,69 @@ def test_full_size_windows_vs_oracle_gpu(workload, n_windows, dim):
     for name, got, ref in checks:
         assert got is not None and ref is not None, name
         _assert_grad_close(got, ref, "%s d %s" % (workload, name))
+
+
+@pytest.mark.parametrize("workload,n_windows", [("S-icews14", 3), ("S-gdelt", 2)])
+def test_full_size_training_loss_vs_oracle_gpu(workload, n_windows):
+    """A full-size TRAINING step with the ComplEx link-prediction loss against the oracle in fp64 -- BASELINE config 2 at its own
+    size (S-icews14: uni-directional GRRGCN, L = 8, D = 200, 7 128 entities, 460 relation rows; models/DynamicRGCN.py:176-194,
+    models/TKG_Module.py:202-213, utils/scores.py:27-44) and the headline S-gdelt BiGRRGCN step (models/BiDynamicRGCN.py:123-144):
+    50 % target-edge subsample (fixed draw), negatives with the truth in column 0 (fixed draw), all-entity pass, fused loss node.
+    Loss to 2e-5 relative, target embeddings to 1e-5, every parameter gradient by _assert_grad_close."""
+    import bench
+    from temp_amd import synthetic
+    w = synthetic.workload(workload, seed=0)
+    model = bench.build_model(w, DEV)
+    bi = w["module"].startswith("Bi")
+    targets = sorted(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:n_windows], reverse=True)
+    L, N = w["L"], w["num_ents"]
+    rng = np.random.default_rng(11)
+    edge_ids, samples = [], []
+    NEG = 60
+    for t in targets:
+        g = w["snapshots"][t]
+        E = g.number_of_edges()
+        edge_ids.append(np.sort(rng.choice(E, E // 2, replace=False)))
+        P = min(E, 400)
+        pos = rng.choice(E, P, replace=False)
+        trip = torch.from_numpy(np.stack([g.src[pos], g.rel[pos], g.dst[pos]], axis=1)).long()
+        nt = torch.from_numpy(rng.integers(0, N, (P, 1 + NEG)))
+        nh = torch.from_numpy(rng.integers(0, N, (P, 1 + NEG)))
+        nt[:, 0] = torch.from_numpy(g.gids[g.dst[pos]])
+        nh[:, 0] = torch.from_numpy(g.gids[g.src[pos]])
+        samples.append((trip, nt, nh))
+    # ---- HIP path: the model's own forward() with the draws injected ------------------------------------------------------------
+    loss = model(torch.tensor(targets), target_edge_ids=edge_ids, samples=samples)
+    loss.backward()
+    torch.cuda.synchronize()
+    # ---- oracle, fp64 -----------------------------------------------------------------------------------------------------------
+    om, cfg, gd = _oracle_model(model, w, w["module"])
+    times = sorted(gd.keys())
+    leaves = O.leaf_tensors(om)
+    for v in leaves.values():
+        v.requires_grad_(True)
+    tgt = [O.edge_subgraph(gd[t], torch.from_numpy(e)) for t, e in zip(targets, edge_ids)]
+    fn = O.bi_forward_loss if bi else O.uni_forward_loss
+    want, _ = fn(om, cfg, gd, targets, times, L, tgt, samples, score="complex")
+    want.backward()
+    print("full-size %s training loss: HIP %.7f  oracle(fp64) %.7f  rel diff %.2e" % (workload, loss.item(), want.item(), abs(loss.item() - want.item()) / abs(want.item())))
+    assert abs(loss.item() - want.item()) <= 2e-5 * abs(want.item()), (loss.item(), want.item())
+    enc = model.ent_encoder
+    l2o = om["ent_encoder"]["layer_2"]
+    checks = [("ent_embeds", model.ent_embeds.grad, om["ent_embeds"].grad), ("rel_embeds", model.rel_embeds.grad, om["rel_embeds"].grad),
+              ("layer_1.weight", enc.layer_1.weight.grad, om["ent_encoder"]["layer_1"]["weight"].grad),
+              ("layer_1.loop_weight", enc.layer_1.loop_weight.grad, om["ent_encoder"]["layer_1"]["loop_weight"].grad),
+              ("layer_2.weight", enc.layer_2.weight.grad, l2o["weight"].grad),
+              ("layer_2.loop_weight", enc.layer_2.loop_weight.grad, l2o["loop_weight"].grad)]
+    for name in (("forward_rnn", "backward_rnn") if bi else ("rnn",)):
+        rnn, q = getattr(enc.layer_2, name), l2o[name][0]
+        checks += [("%s.w_hh" % name, rnn.weight_hh_l0.grad, q["w_hh"].grad), ("%s.w_ih" % name, rnn.weight_ih_l0.grad, q["w_ih"].grad),
+                   ("%s.b_hh" % name, rnn.bias_hh_l0.grad, q["b_hh"].grad), ("%s.b_ih" % name, rnn.bias_ih_l0.grad, q["b_ih"].grad)]
+    for name, got, ref in checks:
+        assert got is not None and ref is not None, name
+        # measured: 0 entries out of tolerance, relative Frobenius error 5e-7 .. 1.9e-6 (no ReLU-kink flip reaches a gradient
+        # through the loss at these sizes) -> thresholds = measured x 3
+        _assert_grad_close(got, ref, "%s+loss d %s" % (workload, name), max_bad=0.0, frob=6e-6, frob_clean=6e-6)
 
 
 @pytest.mark.parametrize("workload,n_windows", [("S-gdelt", 2)])
@@ -483,6 +554,59 @@ def test_post_ensemble_evaluate_golden_gpu(name, batched):
 def test_post_ensemble_own_ratio_golden_gpu(name, batched):
     from tests.window_cases import check_post_ensemble_ratio
     check_post_ensemble_ratio(name, DEV, batched)
+
+
+def test_sharded_step_rccl_single_rank_gpu():
+    """BASELINE north_star mode on the RCCL backend with ONE rank (two ranks cannot share a GPU): SnapshotShardedEncoder +
+    ShardedStep (three HIP graphs around the two exchanges) + GradBucket with ReduceOp.AVG through nccl.
+      * the graph-replayed step is BIT-identical to the same three parts run eagerly (outputs and every gradient);
+      * against the unsharded batched step of the same windows: target embeddings and gradients equal to rounding (measured
+        1.5e-7 on the embeddings: the sharded program groups the chain rows by rank-local window, so row panels -- and with
+        them the order of a few sums -- differ)."""
+    import torch.distributed as dist
+    from tests.test_dist_cpu import _free_port
+    import bench
+    from temp_amd import synthetic
+    from temp_amd.dist import ShardedStep, SnapshotShardedEncoder
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        w = synthetic.workload("S-gdelt", seed=0)
+        model = bench.build_model(w, DEV)
+        targets = synthetic.default_targets(w["num_times"], w["L"], 3, 0)
+        params = [p for p in model.parameters()]
+        model.sample_rng = np.random.default_rng(2)
+        wb = model.prepare(targets, w["L"], train=True)
+        ref_out = model.run(wb)[0]
+        ref_out.backward(torch.ones_like(ref_out))
+        ref_grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        ref_out = ref_out.detach().clone()                           # (no reference to the eager step's autograd graph may survive:
+        del wb                                                       #  see ShardedStep._capture)
+        for p in params:
+            p.grad = None
+        model.sample_rng = np.random.default_rng(2)                  # same target subsample
+        enc = SnapshotShardedEncoder(model)
+        sb = enc.prepare(targets, w["L"], train=True)
+        res = {}
+        for name, graphs in (("eager", False), ("graphs", True)):
+            st = ShardedStep(enc, sb, params, graphs=graphs, average=True, force_allreduce=True)
+            assert (st.graphs is not None) == graphs
+            for _ in range(2):                                       # a replayed graph must reproduce itself
+                out = st.step()
+            torch.cuda.synchronize()
+            res[name] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+            del st, out
+            for p in params:
+                p.grad = None
+        assert torch.equal(res["eager"][0], res["graphs"][0])
+        assert set(res["eager"][1]) == set(res["graphs"][1]) == set(ref_grads)
+        for k, g in res["eager"][1].items():
+            assert torch.equal(g, res["graphs"][1][k]), k
+        assert_close(res["graphs"][0], ref_out, 2e-6, 5e-7, "sharded vs unsharded target embeddings")
+        for k, g in res["graphs"][1].items():
+            assert_close(g, ref_grads[k], 2e-5, 2e-6 * max(1.0, float(ref_grads[k].abs().max())), "sharded vs unsharded " + k)
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("D,B", [(200, 100), (64, 16), (32, 32)])
