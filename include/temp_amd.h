@@ -11,7 +11,9 @@
  * Conventions
  *   - All arithmetic is fp32; all indices are int32; all matrices are dense row-major.
  *   - Every pointer is a DEVICE pointer unless stated otherwise.  The caller owns every buffer,
- *     including workspaces; the library never allocates, frees or synchronises.
+ *     including workspaces; the library never allocates or frees device memory and never synchronises
+ *     (temp_rgcn_bwd / temp_rgcn_table_bwd order one side-stream branch against the caller's stream with two
+ *     events, TEMP_OPT_OVERLAP: all of its work is complete, in stream order, when the call's last launch is).
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  The device is whatever
  *     is current in the calling thread.
  *   - Return value: 0 on success, a TEMP_E_* code otherwise (temp_error_string() describes it).
@@ -63,7 +65,11 @@ enum {
                                2: the weight-gradient kernel too (slower at the measured shapes)
                                0: always gather through L2 (bit-identical results)             [TEMP_RGCN_TILE=0 -> 0]  default 1 */
   TEMP_OPT_DEBUG = 6,       /* development ablations inside instrumented kernels; 0 (off) in every product run          default 0 */
-  TEMP_OPT_COUNT = 7
+  TEMP_OPT_OVERLAP = 7,     /* 1: a layer's backward launches the relation-weight gradient on a library-owned side stream (fork /
+                               join events on the caller's stream: a parallel branch under HIP-graph capture) so that it overlaps
+                               the d/dh aggregation and the self-loop products; 0: everything on the caller's stream
+                                                                                               [TEMP_OVERLAP=0 -> 0]    default 1 */
+  TEMP_OPT_COUNT = 8
 };
 int temp_set_option(int key, int value);
 int temp_get_option(int key);

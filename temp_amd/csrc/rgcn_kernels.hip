@@ -9,6 +9,7 @@
 // several chunks go through ordered partial slots + a fix-up pass, so results are deterministic.
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 #include "common.hpp"
 
 namespace temp {
@@ -690,6 +691,42 @@ __global__ void __launch_bounds__(256) k_loop_gather_epi(int n, int d4, const in
   }
 }
 
+// ---- side stream for the weight-gradient edge kernel ---------------------------------------------------------------------------
+// In a layer's backward the relation-weight gradient (k_rgcn_dw + its fix-up: an L2-gather kernel of small blocks, ~110 us at the
+// S-gdelt shape) depends only on dz, like the d/dh aggregation, the self-loop product and the loop-weight gradient -- kernels
+// bound by LDS or by the matrix pipe.  It is launched on a per-device side stream between a fork event and a join event, so it
+// fills the CUs' spare wave slots under those kernels instead of queueing behind them.  Same kernels, same results.  The events
+// are ordinary stream dependencies: inside a HIP-graph capture they become a parallel branch of the graph.  The stream and the two
+// events are created once per device, on first use (never inside a capture: every captured step is preceded by warm-up runs);
+// nothing is synchronised.  One backward at a time per device (autograd's device thread).  temp_set_option(TEMP_OPT_OVERLAP, 0): off.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; };
+static SideStream* side_stream() {
+  static std::mutex mu;
+  static SideStream pool[16];
+  if (!option(TEMP_OPT_OVERLAP)) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SideStream& p = pool[dev];
+  if (!p.tried) {
+    p.tried = true;
+    p.ok = hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&p.join, hipEventDisableTiming) == hipSuccess;
+    if (!p.ok) (void)hipGetLastError();
+  }
+  return p.ok ? &p : nullptr;
+}
+// run_dw on the side stream, forked from `st`; the caller joins with side_join() after its own launches
+static int dw_forked(SideStream* ss, hipStream_t st, const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz,
+                     const float* nnorm, int d_in, int d_out, int num_bases, int n_rel_rows, float* dW, float* partial) {
+  if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return TEMP_E_LAUNCH;
+  const int rc = run_dw(v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, ss->s);
+  if (hipEventRecord(ss->join, ss->s) != hipSuccess) return TEMP_E_LAUNCH;
+  return rc;
+}
+static int side_join(SideStream* ss, hipStream_t st) { return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? TEMP_OK : TEMP_E_LAUNCH; }
+
 struct TableBwdWs {
   float *dz, *dzm, *d_h, *part_dx, *part_dw, *seg_dz;
   void *tn, *cs;
@@ -786,6 +823,11 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
     if (rc) return rc;
     dz = w.dz;
   }
+  SideStream* ss = side_stream();                // relation-weight gradient beside the rest of the backward (see SideStream)
+  if (ss) {
+    rc = dw_forked(ss, st, g->by_rel, members_of(g), table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw);
+    if (rc) return rc;
+  }
   // aggregation part of d_h per node row, then everything that is linear in the gathered rows is summed per table row FIRST:
   //   d_table = segsum(out_deg > 0 ? d_h : 0) + segsum(dz) . loop_w^T        d_loop_w = table^T . segsum(dz)
   rc = run_agg(MODE_DX, g->by_src, members_of(g), dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, w.d_h, w.part_dx, st);
@@ -804,15 +846,17 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, n_table, d_in, d_out, w.seg_dz, d_out, nullptr, loop_w, d_out, 1, d_table, d_in, nullptr, nullptr,
                          TEMP_ACT_NONE, d_table, d_in, st);
   if (rc) return rc;
-  rc = run_dw(g->by_rel, members_of(g), table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
-  if (rc) return rc;
+  if (!ss) {
+    rc = run_dw(g->by_rel, members_of(g), table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+    if (rc) return rc;
+  }
   rc = gemm_tn(n_table, d_in, d_out, table, d_in, w.seg_dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
   if (rc) return rc;
   if (has_bias) {
     rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
     if (rc) return rc;
   }
-  return TEMP_OK;
+  return ss ? side_join(ss, st) : TEMP_OK;
 }
 
 size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out) {
@@ -899,6 +943,11 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
     if (rc) return rc;
     dz = w.dz;
   }
+  SideStream* ss = side_stream();                // relation-weight gradient beside the rest of the backward (see SideStream)
+  if (ss) {
+    rc = dw_forked(ss, st, g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw);
+    if (rc) return rc;
+  }
   // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
   rc = run_agg(MODE_DX, g->by_src, members_of(g), dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
   if (rc) return rc;
@@ -912,15 +961,17 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dzm, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
                          d_h, d_in, st);
   if (rc) return rc;
-  rc = run_dw(g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
-  if (rc) return rc;
+  if (!ss) {
+    rc = run_dw(g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+    if (rc) return rc;
+  }
   rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dzm, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
   if (rc) return rc;
   if (has_bias) {
     rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
     if (rc) return rc;
   }
-  return TEMP_OK;
+  return ss ? side_join(ss, st) : TEMP_OK;
 }
 
 }  // extern "C"
