@@ -69,7 +69,10 @@ enum {
                                join events on the caller's stream: a parallel branch under HIP-graph capture) so that it overlaps
                                the d/dh aggregation and the self-loop products; 0: everything on the caller's stream
                                                                                                [TEMP_OVERLAP=0 -> 0]    default 1 */
-  TEMP_OPT_COUNT = 8
+  TEMP_OPT_GEMM_RESIDENT = 8, /* 1: large fp32 products with K <= 208 keep the packed weights of four column tiles resident in LDS and
+                               stream row panels through them (gemm_bxr.hpp); 0: one row tile per block, weights staged per slab
+                                                                                               [TEMP_GEMM_RESIDENT=0 -> 0] default 1 */
+  TEMP_OPT_COUNT = 9
 };
 int temp_set_option(int key, int value);
 int temp_get_option(int key);

@@ -38,7 +38,7 @@ class TempGraph(ctypes.Structure):
                 ("members", TempMembers)]
 
 
-OPT_MFMA_BF16X3, OPT_TN_SPLIT, OPT_RGCN_SCALAR, OPT_GEMM_STREAM, OPT_GRU_STREAM, OPT_RGCN_TILE, OPT_DEBUG, OPT_OVERLAP = range(8)
+OPT_MFMA_BF16X3, OPT_TN_SPLIT, OPT_RGCN_SCALAR, OPT_GEMM_STREAM, OPT_GRU_STREAM, OPT_RGCN_TILE, OPT_DEBUG, OPT_OVERLAP, OPT_GEMM_RESIDENT = range(9)
 
 
 class TempGruCellFwd(ctypes.Structure):

@@ -568,10 +568,14 @@ inline bool bx_plan(int N, int K, int lda, int ldb, int trans_b, int max_m, long
   return true;
 }
 
-template <int G, class Epi>
-static inline void launch_bx_g(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st) {
-  dim3 grid(8 * g.per_xcd * g.n_groups, count);
-  // pack the weight matrices of the batch (problems that share B share the pack) into this stream's scratch slot
+}  // namespace temp
+#include "gemm_bxr.hpp"
+namespace temp {
+
+// Pack the weight matrices of the batch (problems that share B share the pack) into this stream's scratch slot.
+// -> false when no slot is free or the packs do not fit one (the caller then uses the kernel that splits B itself).
+template <class Epi>
+static inline bool bx_pack_batch(const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st, BxPacked* pk) {
   const size_t pbytes = bx_packed_bytes(g.N, g.K);
   int n_distinct = 0, which[PANEL_MAXP];
   for (int i = 0; i < count; ++i) {
@@ -581,37 +585,62 @@ static inline void launch_bx_g(int kid, const PanelBatch<Epi>& batch, int count,
     if (which[i] < 0) which[i] = n_distinct++;
   }
   bx_u32x4* slot = pbytes * n_distinct <= BX_PACK_MAX_BYTES ? bx_scratch(st, pbytes * n_distinct) : nullptr;
-  if (slot) {
-    BxPacked pk;
-    const int n_slabs = ceil_div(g.K, 16);
-    int done = 0;
-    for (int i = 0; i < PANEL_MAXP; ++i) pk.b[i] = slot;
-    for (int i = 0; i < count; ++i) {
-      bx_u32x4* dst = slot + (size_t)which[i] * (pbytes / 16);
-      pk.b[i] = dst;
-      if (which[i] < done) continue;
-      ++done;
-      const dim3 pgrid(ceil_div((long long)n_slabs * g.n_tiles, 4));
-      if (g.trans_b) TEMP_LAUNCH(K_BX_PACK, (k_bx_pack<1>), pgrid, dim3(256), 0, st, g.K, g.N, g.n_tiles, n_slabs, batch.p[i].B, g.ldb, dst);
-      else TEMP_LAUNCH(K_BX_PACK, (k_bx_pack<0>), pgrid, dim3(256), 0, st, g.K, g.N, g.n_tiles, n_slabs, batch.p[i].B, g.ldb, dst);
-    }
-    TEMP_LAUNCH(kid, (k_gemm_bxp<G, Epi>), grid, dim3(BX_THREADS), 0, st, batch, g, pk);
+  if (!slot) return false;
+  const int n_slabs = ceil_div(g.K, 16);
+  int done = 0;
+  for (int i = 0; i < PANEL_MAXP; ++i) pk->b[i] = slot;
+  for (int i = 0; i < count; ++i) {
+    bx_u32x4* dst = slot + (size_t)which[i] * (pbytes / 16);
+    pk->b[i] = dst;
+    if (which[i] < done) continue;
+    ++done;
+    const dim3 pgrid(ceil_div((long long)n_slabs * g.n_tiles, 4));
+    if (g.trans_b) TEMP_LAUNCH(K_BX_PACK, (k_bx_pack<1>), pgrid, dim3(256), 0, st, g.K, g.N, g.n_tiles, n_slabs, batch.p[i].B, g.ldb, dst);
+    else TEMP_LAUNCH(K_BX_PACK, (k_bx_pack<0>), pgrid, dim3(256), 0, st, g.K, g.N, g.n_tiles, n_slabs, batch.p[i].B, g.ldb, dst);
+  }
+  return true;
+}
+
+template <int G, class Epi>
+static inline void launch_bx_g(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st, const BxPacked* pk) {
+  dim3 grid(8 * g.per_xcd * g.n_groups, count);
+  if (pk) {
+    TEMP_LAUNCH(kid, (k_gemm_bxp<G, Epi>), grid, dim3(BX_THREADS), 0, st, batch, g, *pk);
     return;
   }
   if (g.trans_b) TEMP_LAUNCH(kid, (k_gemm_bx<G, 1, Epi>), grid, dim3(BX_THREADS), 0, st, batch, g);
   else TEMP_LAUNCH(kid, (k_gemm_bx<G, 0, Epi>), grid, dim3(BX_THREADS), 0, st, batch, g);
 }
 
+// weights-resident kernel (gemm_bxr.hpp) for short K; temp_set_option(TEMP_OPT_GEMM_RESIDENT, 0): always the slab-staged kernels
+template <class Epi>
+static inline bool launch_bxr(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st, const BxPacked& pk) {
+  if (!option(TEMP_OPT_GEMM_RESIDENT) || g.K > BXR_MAX_SLABS * 16 || g.K < 48) return false;
+  int max_m = 0;
+  for (int i = 0; i < count; ++i) max_m = batch.p[i].M > max_m ? batch.p[i].M : max_m;
+  BxrGeom rg;
+  if (!bxr_plan(g.N, g.K, g.lda, max_m, &rg)) return false;
+  static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bxr<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, BXR_LDS_BYTES) == hipSuccess;
+  if (!granted) { (void)hipGetLastError(); return false; }
+  const size_t lds = (size_t)rg.n_slabs * BXR_G * 192 * 16;
+  TEMP_LAUNCH(kid, (k_gemm_bxr<Epi>), dim3(256, count), dim3(BXR_WAVES * 64), lds, st, batch, rg, pk);
+  return true;
+}
+
 template <class Epi>
 int launch_gemm_bx(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, int G, hipStream_t st) {
+  BxPacked pk;
+  const bool packed = bx_pack_batch(batch, count, g, st, &pk);
+  if (packed && launch_bxr(kid, batch, count, g, st, pk)) return launch_status();
+  const BxPacked* pp = packed ? &pk : nullptr;
   switch (G) {
-    case 1: launch_bx_g<1, Epi>(kid, batch, count, g, st); break;
-    case 2: launch_bx_g<2, Epi>(kid, batch, count, g, st); break;
-    case 3: launch_bx_g<3, Epi>(kid, batch, count, g, st); break;
-    case 4: launch_bx_g<4, Epi>(kid, batch, count, g, st); break;
-    case 5: launch_bx_g<5, Epi>(kid, batch, count, g, st); break;
-    case 6: launch_bx_g<6, Epi>(kid, batch, count, g, st); break;
-    default: launch_bx_g<7, Epi>(kid, batch, count, g, st); break;
+    case 1: launch_bx_g<1, Epi>(kid, batch, count, g, st, pp); break;
+    case 2: launch_bx_g<2, Epi>(kid, batch, count, g, st, pp); break;
+    case 3: launch_bx_g<3, Epi>(kid, batch, count, g, st, pp); break;
+    case 4: launch_bx_g<4, Epi>(kid, batch, count, g, st, pp); break;
+    case 5: launch_bx_g<5, Epi>(kid, batch, count, g, st, pp); break;
+    case 6: launch_bx_g<6, Epi>(kid, batch, count, g, st, pp); break;
+    default: launch_bx_g<7, Epi>(kid, batch, count, g, st, pp); break;
   }
   return launch_status();
 }

@@ -49,6 +49,9 @@ struct EpiAddBiasAct {
   }
 };
 
+template <>
+struct EpiAccInit<EpiAddBiasAct> { static constexpr bool value = true; };   // fin4 = store(act(acc + pre)): gemm_bxr.hpp starts the accumulators at pre
+
 // Same epilogue with dropout of the product term (the self-loop message in training mode): a separate type, so the
 // common no-dropout instantiations carry neither the extra kernel arguments nor the hash code.
 struct EpiAddBiasActDrop : EpiAddBiasAct {
@@ -994,7 +997,7 @@ bx_u32x4* bx_scratch(hipStream_t st, size_t bytes) {
 static std::atomic<int> g_options[TEMP_OPT_COUNT];
 static const bool g_options_init = [] {
   g_options[TEMP_OPT_MFMA_BF16X3] = 1; g_options[TEMP_OPT_TN_SPLIT] = 1; g_options[TEMP_OPT_RGCN_SCALAR] = 1;
-  g_options[TEMP_OPT_GEMM_STREAM] = 0; g_options[TEMP_OPT_GRU_STREAM] = 0; g_options[TEMP_OPT_RGCN_TILE] = 1; g_options[TEMP_OPT_DEBUG] = 0; g_options[TEMP_OPT_OVERLAP] = 1;
+  g_options[TEMP_OPT_GEMM_STREAM] = 0; g_options[TEMP_OPT_GRU_STREAM] = 0; g_options[TEMP_OPT_RGCN_TILE] = 1; g_options[TEMP_OPT_DEBUG] = 0; g_options[TEMP_OPT_OVERLAP] = 1; g_options[TEMP_OPT_GEMM_RESIDENT] = 1;
   const char* e;
   if ((e = getenv("TEMP_MFMA")) && e[0] == 'f') g_options[TEMP_OPT_MFMA_BF16X3] = 0;
   if ((e = getenv("TEMP_TN_SPLIT")) && e[0] == '0') g_options[TEMP_OPT_TN_SPLIT] = 0;
@@ -1003,6 +1006,7 @@ static const bool g_options_init = [] {
   if ((e = getenv("TEMP_GRU_STREAM")) && e[0] == '1') g_options[TEMP_OPT_GRU_STREAM] = 1;
   if ((e = getenv("TEMP_RGCN_TILE")) && e[0] == '0') g_options[TEMP_OPT_RGCN_TILE] = 0;
   if ((e = getenv("TEMP_OVERLAP")) && e[0] == '0') g_options[TEMP_OPT_OVERLAP] = 0;
+  if ((e = getenv("TEMP_GEMM_RESIDENT")) && e[0] == '0') g_options[TEMP_OPT_GEMM_RESIDENT] = 0;
   return true;
 }();
 int option(int key) { return (key >= 0 && key < TEMP_OPT_COUNT) ? g_options[key].load(std::memory_order_relaxed) : -1; }
