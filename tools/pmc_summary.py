@@ -16,7 +16,7 @@ import sys
 
 
 # rocprof kernel names -> the family names of bench.py's event trace (one trace id per call site, whichever kernel serves it)
-FAMILY_ALIAS = {"k_gemm_tn_bx": "k_gemm_tn", "k_gemm_tn_bx8": "k_gemm_tn", "k_rgcn_agg_s": "k_rgcn_agg", "k_rgcn_dw_s": "k_rgcn_dw", "k_gemm_bxp": "k_gemm_panel", "k_gemm_bx": "k_gemm_panel", "k_gemm_wres": "k_gemm_panel"}
+FAMILY_ALIAS = {"k_gemm_tn_bx": "k_gemm_tn", "k_gemm_tn_bx8": "k_gemm_tn", "k_rgcn_agg_s": "k_rgcn_agg", "k_rgcn_dw_s": "k_rgcn_dw", "k_gemm_bxp": "k_gemm_panel", "k_gemm_bx": "k_gemm_panel", "k_gemm_wres": "k_gemm_panel", "k_gemm_bxr": "k_gemm_panel", "k_rgcn_agg_t": "k_rgcn_agg"}
 
 
 def short(name):
