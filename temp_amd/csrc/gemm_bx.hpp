@@ -615,14 +615,14 @@ static inline void launch_bx_g(int kid, const PanelBatch<Epi>& batch, int count,
 // weights-resident kernel (gemm_bxr.hpp) for short K; temp_set_option(TEMP_OPT_GEMM_RESIDENT, 0): always the slab-staged kernels
 template <class Epi>
 static inline bool launch_bxr(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st, const BxPacked& pk) {
-  if (!option(TEMP_OPT_GEMM_RESIDENT) || g.K > BXR_MAX_SLABS * 16 || g.K < 48) return false;
+  if (!option(TEMP_OPT_GEMM_RESIDENT) || g.K > BXR_MAX_SLABS * 16 || g.K < 72) return false;
   int max_m = 0;
   for (int i = 0; i < count; ++i) max_m = batch.p[i].M > max_m ? batch.p[i].M : max_m;
   BxrGeom rg;
   if (!bxr_plan(g.N, g.K, g.lda, max_m, &rg)) return false;
   static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bxr<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, BXR_LDS_BYTES) == hipSuccess;
   if (!granted) { (void)hipGetLastError(); return false; }
-  const size_t lds = (size_t)rg.n_slabs * BXR_G * 192 * 16;
+  const size_t lds = (size_t)rg.n_slabs * BXR_G * 192 * 16 + BXR_BIAS_BYTES;
   TEMP_LAUNCH(kid, (k_gemm_bxr<Epi>), dim3(256, count), dim3(BXR_WAVES * 64), lds, st, batch, rg, pk);
   return true;
 }

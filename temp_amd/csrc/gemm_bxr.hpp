@@ -19,10 +19,15 @@
 
 namespace temp {
 
+#ifdef BXR_PROBE
+__device__ unsigned long long g_bxr_stamp[256 * 8 * 4];
+#endif
+
 #define BXR_G 4                                              // column tiles resident per workgroup
 #define BXR_WAVES 8
 #define BXR_MAX_SLABS 13
-#define BXR_LDS_BYTES (BXR_MAX_SLABS * BXR_G * 192 * 16)     // 159 744
+#define BXR_BIAS_BYTES (BXR_G * 32 * 4)                      // the group's bias columns behind the planes
+#define BXR_LDS_BYTES (BXR_MAX_SLABS * BXR_G * 192 * 16 + BXR_BIAS_BYTES)   // 159 744 + 512 of the CU's 163 840
 
 struct BxrGeom {
   int N, K, lda, n_tiles, n_slabs, n_groups;
@@ -31,7 +36,7 @@ struct BxrGeom {
 };
 
 inline bool bxr_plan(int N, int K, int lda, int max_m, BxrGeom* g) {
-  if (K % 8 || lda % 4 || N % 4 || K < 48 || K > BXR_MAX_SLABS * 16) return false;   // >= 3 slabs: the A stream runs three slabs ahead
+  if (K % 8 || lda % 4 || N % 4 || K < 72 || K > BXR_MAX_SLABS * 16) return false;   // >= 5 slabs: the A stream runs four slabs ahead
   g->N = N; g->K = K; g->lda = lda;
   g->n_tiles = ceil_div(N, 32);
   g->n_slabs = ceil_div(K, 16);
@@ -65,10 +70,27 @@ inline bool bxr_plan(int N, int K, int lda, int max_m, BxrGeom* g) {
 // tiles) and fin4 gets a zero `pre`.  (Explicit specialisations only: a derived epilogue does not inherit it.)
 template <class E>
 struct EpiAccInit { static constexpr bool value = false; };
+// An epilogue that declares `k_raw_pre` (has_addend / raw4 / bias1, RowCtx::add, > 0 = keep) has  pre4 = (add ? raw4 : 0) + bias  taken apart:
+// the raw loads of a panel are issued back to back, the mask select follows them, the bias comes from LDS (staged once per block).
+// pre4 itself branches on kernel-uniform pointers per quad, and the compiler serialises its loads: 32 dependent round trips per
+// panel, two thirds of the first version's run time.
+template <class E, class = void>
+struct EpiRawPre { static constexpr bool value = false; };
+template <class E>
+struct EpiRawPre<E, decltype((void)E::k_raw_pre)> { static constexpr bool value = true; };
 
 // One wave, GT resident column tiles: the panels [p_lo + first, p_hi) step `stride` of problem `pb`.
-template <int GT, class Epi>
-__device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrGeom& g, const bx_u32x4* __restrict__ Bl, int t0, int first, int p_hi, int stride) {
+//
+// The A stream is a ring of FOUR raw register stages with static names (the slab loop is unrolled by four; stage = flat slab
+// index mod 4): body f issues the loads of flat slab f + 4 into the stage whose content it no longer needs and splits slab f + 1
+// for the next body, so a load has three slab bodies (~2 300 MFMA cycles of this wave alone) before its first use.  The first
+// version rotated three stages through register copies (r1 <- r2 <- r3): a copy of an in-flight load makes the wave wait for
+// it, so every load was waited for at the end of the body that issued it -- one slab of cover against an HBM latency of 2-3 --
+// and the matrix pipe idled two thirds of the time (86-112 us per launch at the S-gdelt shapes).  The operand fragments
+// alternate between two named sets for the same reason (no AH <- NH copies).  The flat sequence runs over panel boundaries:
+// the next panel's first slabs are in flight during this one's epilogue.
+template <int GT, class Epi, int VAR = 0>
+__device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrGeom& g, const bx_u32x4* __restrict__ Bl, const float* __restrict__ bias_l, int t0, int first, int p_hi, int stride) {
   const int M = pb.M, N = g.N, K = g.K, NS = g.n_slabs;
   const float* __restrict__ A = pb.A;
   const int32_t* __restrict__ a_idx = pb.a_idx;
@@ -79,87 +101,122 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
   const int kclamp = K - 8;                                   // last octet that may be read
   if (first >= p_hi) return;
 
-  auto row_ptr = [&](int panel, long& a_src) {
+  auto row_src = [&](int panel) {                            // source row of this lane in `panel` (-1: past M, or a gathered zero row)
     const int row = panel * 32 + li;
-    a_src = -1;
-    if (panel < p_hi && row < M) a_src = a_idx ? (long)a_idx[row] : (long)row;
-    return A + (size_t)(a_src >= 0 ? a_src : 0) * g.lda + 8 * hh;   // rows past M / gathered zero rows compute on row 0
+    int a_src = -1;
+    if (panel < p_hi && row < M) a_src = a_idx ? a_idx[row] : row;
+    return a_src;                                             // (kept as the loaded word: a widening here would wait for the load)
+  };
+  auto src_ptr = [&](int a_src) {                            // rows past M / gathered zero rows compute on row 0
+    return A + (size_t)(a_src >= 0 ? a_src : 0) * g.lda + 8 * hh;
   };
   auto fetch_a = [&](float4 (&a)[2], const float* aptr, int s) {
     const int k = 16 * s + 8 * hh;
     const float* p = aptr + (k <= kclamp ? 16 * s : kclamp - 8 * hh);   // past K: a valid octet again (meets the zero padding of B)
+    if constexpr (VAR & 1) { a[0] = make_float4(1.f, 2.f, 3.f, (float)s); a[1] = a[0]; return; }
     a[0] = ld4(p);
     a[1] = ld4(p + 4);
   };
 
-  constexpr bool INIT = EpiAccInit<Epi>::value;
+  constexpr bool INIT = EpiAccInit<Epi>::value, RAW = EpiRawPre<Epi>::value;
+  static_assert(!INIT || RAW, "an accumulator-start epilogue supplies the raw-load interface");
   f32x16 acc[GT];
-  auto acc_start = [&](int panel) {                           // accumulators of a panel: zero, or the epilogue's addend (INIT)
+  auto acc_start = [&](int panel, const typename Epi::RowCtx& rc) {   // accumulators of a panel: zero, or the epilogue's addend (INIT)
     const int row = panel * 32 + li;
     const bool row_ok = panel < p_hi && row < M;
-    typename Epi::RowCtx rc;
-    if constexpr (INIT) rc = epi.row_ctx(row_ok ? row : 0);
-#pragma unroll
-    for (int t = 0; t < GT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = zero4();
-        if constexpr (INIT) {
-          const int col = n0 + t * 32 + 8 * q + 4 * hh;
-          const bool ok = row_ok && col < N;
-          v = epi.pre4(rc, ok ? row : 0, ok ? col : 0);
-        }
-        acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
-      }
-  };
-  acc_start(first);
-
-  // ---- A stream: slab s of the current panel is split one slab ahead (NH/NM/NL), its raw octets arrive three slabs ahead.  The
-  // flat sequence (panel, slab) runs over panel boundaries: the next panel's first slabs are in flight during this one's epilogue.
-  long src_cur, src_nxt;
-  const float* ptr_cur = row_ptr(first, src_cur);
-  const float* ptr_nxt = row_ptr(first + stride, src_nxt);
-  float4 r1[2], r2[2], r3[2];                                 // raw A of flat slabs +1, +2, +3
-  bx_u32x4 AH, AM, AL, NH, NM, NL;
-  {
-    float4 r0[2];
-    fetch_a(r0, ptr_cur, 0);
-    fetch_a(r1, NS > 1 ? ptr_cur : ptr_nxt, NS > 1 ? 1 : 0);
-    fetch_a(r2, NS > 2 ? ptr_cur : ptr_nxt, NS > 2 ? 2 : (NS > 1 ? 0 : 1));
-    bx_split8(r0[0], r0[1], AH, AM, AL);
-  }
-  if (src_cur < 0) { AH = bx_u32x4{0, 0, 0, 0}; AM = AH; AL = AH; }     // a gathered zero row (or a row past M): zero operand
-  auto chunk = [&](int c, bool zero_row) {                    // element pair c of the NEXT slab's fragment
-    const float4 f = r1[c >> 1];
-    unsigned h, m, l;
-    bx_split_pair((c & 1) ? f.z : f.x, (c & 1) ? f.w : f.y, h, m, l);
-    NH[c] = zero_row ? 0u : h; NM[c] = zero_row ? 0u : m; NL[c] = zero_row ? 0u : l;
-  };
-
-  for (int panel = first; panel < p_hi; panel += stride) {
-    const int row = panel * 32 + li;
-    const bool row_ok = row < M;
-    const typename Epi::RowCtx rc = epi.row_ctx(row_ok ? row : 0);
-    float4 pre[INIT ? 1 : GT][4];
-    for (int s = 0; s < NS; ++s) {
-      const bool zr = (s + 1 < NS) ? (src_cur < 0) : (src_nxt < 0);   // the row the NEXT flat slab belongs to: a zero row?
-      // flat slab s + 3: this panel's or the next one's
-      {
-        const int f = s + 3;
-        const bool here = f < NS;
-        fetch_a(r3, here ? ptr_cur : ptr_nxt, here ? f : f - NS);
-      }
-      if (!INIT && s == NS - 2) {                             // the epilogue's own loads: behind the last slabs of the panel
+    bool loaded = false;
+    if constexpr (INIT) {
+      if (!(VAR & 2) && epi.has_addend()) {                   // (kernel-uniform)
+        loaded = true;
 #pragma unroll
         for (int t = 0; t < GT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int col = n0 + t * 32 + 8 * q + 4 * hh;
             const bool ok = row_ok && col < N;
-            pre[t][q] = epi.pre4(rc, ok ? row : 0, ok ? col : 0);
+            const float4 v = epi.raw4(ok ? row : 0, ok ? col : 0);
+            acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
+          }
+        // Wait for them HERE (vmcnt(0): one exposed latency per panel, covered by the SIMD's other wave).  Left to the compiler, the
+        // waits land in front of the slab body's MFMAs, where they must also hold on the path that comes from the previous body --
+        // with the counter in order that makes every body wait for all but its newest A load, i.e. no prefetch at all.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (__builtin_amdgcn_ballot_w64(!(rc.add > 0)) != 0) {      // a masked row in this panel: its addend is zero
+#pragma unroll
+          for (int t = 0; t < GT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = rc.add > 0 ? acc[t][r] : 0.f;
+        }
+      }
+    }
+    if (!loaded) {
+#pragma unroll
+      for (int t = 0; t < GT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
+  };
+  int panel = first, s = 0;
+  bool row_ok = panel * 32 + li < M;
+  typename Epi::RowCtx rc = epi.row_ctx(row_ok ? panel * 32 + li : 0);
+  acc_start(first, rc);
+
+  // ---- fetch cursor: (panel pointer, slab) of the next flat slab to load; it runs at most one panel ahead, and wraps into the next panel
+  // only after the panel advance below has set src_nxt (NS >= 5)
+  int src_cur = row_src(first), src_nxt = row_src(first + stride);    // (a gather index is loaded here and first used at the
+  const float* fptr = src_ptr(src_cur);                                //  cursor's wrap, NS - 4 bodies later: no wait for it)
+  int fs = 0;
+  auto fetch_next = [&](float4 (&a)[2]) {
+    fetch_a(a, fptr, fs);
+    if (++fs == NS) { fs = 0; fptr = src_ptr(src_nxt); }
+  };
+  float4 R[4][2];                                             // raw A of flat slabs f .. f + 3 (stage = flat index mod 4)
+  bx_u32x4 F[2][3];                                           // operand fragments (h, m, l) of the current / the next flat slab
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fetch_next(R[j]);
+  bx_split8(R[0][0], R[0][1], F[0][0], F[0][1], F[0][2]);
+  if (src_cur < 0) { F[0][0] = bx_u32x4{0, 0, 0, 0}; F[0][1] = F[0][0]; F[0][2] = F[0][0]; }   // a gathered zero row (or past M)
+
+  float4 pre[INIT ? 1 : GT][4];
+  typename Epi::RowCtx rc_next = rc;                          // the next panel's row context (its mask load), fetched two slabs early
+  bool row_masked = false;                                    // (kernel-uniform; without a row mask the context is the same for every row)
+  if constexpr (RAW) row_masked = epi.has_row_mask();
+  for (;;) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                             // flat slab f with f mod 4 == j
+      const int row = panel * 32 + li;
+      const bool zr = (s + 1 < NS) ? (src_cur < 0) : (src_nxt < 0);   // the row the NEXT flat slab belongs to: a zero row?
+      fetch_next(R[j]);                                       // flat slab f + 4 (stage j held slab f: split by the previous body)
+      if constexpr (RAW) {
+        if (s == NS - 2 && row_masked) {
+          const int nrow = (panel + stride) * 32 + li;
+          rc_next = epi.row_ctx(panel + stride < p_hi && nrow < M ? nrow : 0);
+        }
+      }
+      if (!INIT && s == NS - 2) {                             // the epilogue's own loads: behind the last slabs of the panel
+        bool raw_loads = false;
+        if constexpr (RAW) raw_loads = epi.has_addend();      // (kernel-uniform)
+#pragma unroll
+        for (int t = 0; t < GT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = n0 + t * 32 + 8 * q + 4 * hh;
+            const bool ok = row_ok && col < N;
+            if constexpr (RAW) pre[t][q] = raw_loads ? epi.raw4(ok ? row : 0, ok ? col : 0) : zero4();
+            else pre[t][q] = epi.pre4(rc, ok ? row : 0, ok ? col : 0);
           }
       }
-      const bx_bf16x8 ah = bx_frag(AH), am = bx_frag(AM), al = bx_frag(AL);
+      bx_u32x4 (&CF)[3] = F[j & 1];
+      bx_u32x4 (&NF)[3] = F[(j + 1) & 1];
+      const float4 (&rn)[2] = R[(j + 1) & 3];
+      auto chunk = [&](int c) {                               // element pair c of the NEXT slab's fragment
+        const float4 f = rn[c >> 1];
+        unsigned h, m, l;
+        if constexpr (VAR & 8) { h = __float_as_uint(f.x); m = __float_as_uint(f.y); l = __float_as_uint(f.z); }
+        else bx_split_pair((c & 1) ? f.z : f.x, (c & 1) ? f.w : f.y, h, m, l);
+        NF[0][c] = zr ? 0u : h; NF[1][c] = zr ? 0u : m; NF[2][c] = zr ? 0u : l;
+      };
+      const bx_bf16x8 ah = bx_frag(CF[0]), am = bx_frag(CF[1]), al = bx_frag(CF[2]);
       const bx_u32x4* bs = Bl + (size_t)s * (BXR_G * 192) + lane;
       // Tiles in PAIRS (the products of tile t alternate with those of tile t + 1: an MFMA never waits for the accumulator of the
       // one just issued), plane by plane -- L.ah | M.am, M.ah | H.al, H.am, H.ah (small terms first within a plane; the order of the
@@ -179,53 +236,67 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
       for (int pr = 0; pr < NP; ++pr) {
         const bool two = 2 * pr + 1 < GT;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int jj = 0; jj < 6; ++jj) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) continue;
             const int t = 2 * pr + u;
             const bx_bf16x8 wh = bx_frag(wf[u][0]), wm = bx_frag(wf[u][1]), wl = bx_frag(wf[u][2]);
-            if (j == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc[t], 0, 0, 0);
-            if (j == 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, acc[t], 0, 0, 0);
-            if (j == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc[t], 0, 0, 0);
-            if (j == 3) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc[t], 0, 0, 0);
-            if (j == 4) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc[t], 0, 0, 0);
-            if (j == 5) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc[t], 0, 0, 0);
+            if (jj == 0 && !(VAR & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc[t], 0, 0, 0);
+            if (jj == 1 && !(VAR & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, acc[t], 0, 0, 0);
+            if (jj == 2 && !(VAR & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc[t], 0, 0, 0);
+            if (jj == 3 && !(VAR & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc[t], 0, 0, 0);
+            if (jj == 4 && !(VAR & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc[t], 0, 0, 0);
+            if (jj == 5 && !(VAR & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc[t], 0, 0, 0);
             const int tn = 2 * (pr + 1) + u;                  // the same tile slot of the next pair: its planes as they fall free
             if (pr + 1 < NP && tn < GT) {
-              if (j == 0) wf[u][2] = bs[(tn * 3 + 2) * 64];
-              if (j == 2) wf[u][1] = bs[(tn * 3 + 1) * 64];
-              if (j == 5) wf[u][0] = bs[(tn * 3 + 0) * 64];
+              if (jj == 0) wf[u][2] = bs[(tn * 3 + 2) * 64];
+              if (jj == 2) wf[u][1] = bs[(tn * 3 + 1) * 64];
+              if (jj == 5) wf[u][0] = bs[(tn * 3 + 0) * 64];
             }
-            if ((slot & 1) && (slot >> 1) < 4) chunk(slot >> 1, zr);
+            if ((slot & 1) && (slot >> 1) < 4) chunk(slot >> 1);
             ++slot;
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
 #pragma unroll
-      for (int c = (GT * 6) >> 1; c < 4; ++c) chunk(c, zr);     // narrow groups: what found no slot behind an MFMA
-      AH = NH; AM = NM; AL = NL;
-      r1[0] = r2[0]; r1[1] = r2[1];
-      r2[0] = r3[0]; r2[1] = r3[1];
-    }
-    // ---- epilogue of the panel (its own loads are in `pre`, or were the accumulators' start values), then the next panel's start
+      for (int c = (GT * 6) >> 1; c < 4; ++c) chunk(c);        // narrow groups: what found no slot behind an MFMA
+      // the next body is another basic block (the panel-end branch below): without a use here the compiler SINKS the split of the
+      // next fragment out of the MFMA shadow into the top of that block
+      asm volatile("" : "+v"(NF[0]), "+v"(NF[1]), "+v"(NF[2]));
+
+      if (++s == NS) {
+        // ---- epilogue of the panel (its own loads are in `pre`, or were the accumulators' start values), then the next panel's start
 #pragma unroll
-    for (int t = 0; t < GT; ++t)
+        for (int t = 0; t < GT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = n0 + t * 32 + 8 * q + 4 * hh;
-        if (row_ok && col < N) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]),
-                                        INIT ? zero4() : pre[INIT ? 0 : t][q]);
+          for (int q = 0; q < 4; ++q) {
+            const int col = n0 + t * 32 + 8 * q + 4 * hh;
+            float4 p = INIT ? zero4() : pre[INIT ? 0 : t][q];
+            if constexpr (RAW) {
+              if constexpr (!INIT) p = rc.add > 0 ? p : zero4();
+              p = add4(p, *reinterpret_cast<const float4*>(bias_l + t * 32 + 8 * q + 4 * hh));
+            }
+            if (row_ok && col < N && !(VAR & 2)) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), p);
+          }
+        panel += stride;
+        if (panel >= p_hi) return;
+        s = 0;
+        row_ok = panel * 32 + li < M;
+        rc = rc_next;
+        src_cur = src_nxt;                                    // (the fetch cursor crossed into this panel NS - 4 bodies ago and
+        src_nxt = row_src(panel + stride);                    //  holds its pointer; it wraps to src_nxt's after this update: NS >= 5)
+        acc_start(panel, rc);                                 // (after the index load: the compiler waits for that one at the block's
+                                                              //  end, and the wait inside acc_start then covers it)
       }
-    acc_start(panel + stride);
-    ptr_cur = ptr_nxt;
-    src_cur = src_nxt;
-    ptr_nxt = row_ptr(panel + 2 * stride, src_nxt);
+    }
   }
 }
 
-template <class Epi>
+// VAR is 0 in the library; tools/bxr_probe.hip instantiates ablations (bit0: no A loads, bit1: no epilogue traffic, bit2: no MFMAs,
+// bit3: no operand split) and, with BXR_PROBE defined, s_memtime stamps per wave
+template <class Epi, int VAR = 0>
 __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> batch, BxrGeom g, BxPacked packed) {
   extern __shared__ __attribute__((aligned(16))) bx_u32x4 bxr_lds[];
   const PanelProblem<Epi>& pb = batch.p[blockIdx.y];
@@ -236,22 +307,58 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
   const int n_panels = (pb.M + 31) >> 5;
   const int p_lo = xcd * g.per_xcd, p_hi = min(n_panels, p_lo + g.per_xcd);
   if (p_lo >= p_hi) return;                                   // (uniform) nothing for this XCD in this problem
-  // ---- the group's planes of B for all of K: slab s = gt * 192 consecutive 16-byte pieces of the packed matrix
+  // ---- the group's planes of B for all of K: slab s = gt * 192 consecutive 16-byte pieces of the packed matrix (<= 2 per thread);
+  // four slabs = up to eight loads in flight per thread (a load-wait-store loop of 20 dependent L2 round trips cost ~25 us)
   {
     const bx_u32x4* __restrict__ src = packed.b[blockIdx.y] + (size_t)t0 * 192;
-    const int per = gt * 192, total = g.n_slabs * per;
-    for (int i = threadIdx.x; i < total; i += BXR_WAVES * 64) {
-      const int s = i / per, r = i - s * per;
-      bxr_lds[s * (BXR_G * 192) + r] = src[(size_t)s * g.n_tiles * 192 + r];
+    const int per = gt * 192, NS = g.n_slabs;
+    const size_t sstride = (size_t)g.n_tiles * 192;
+    const int r0 = min((int)threadIdx.x, per - 1), r1 = min((int)threadIdx.x + BXR_WAVES * 64, per - 1);
+    const bool ok0 = (int)threadIdx.x < per, ok1 = (int)threadIdx.x + BXR_WAVES * 64 < per;
+    for (int s0 = 0; s0 < NS; s0 += 4) {
+      bx_u32x4 v[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bx_u32x4* p = src + (size_t)min(s0 + u, NS - 1) * sstride;
+        v[u][0] = p[r0];
+        v[u][1] = p[r1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < NS) {
+          bx_u32x4* d = bxr_lds + (s0 + u) * (BXR_G * 192);
+          if (ok0) d[r0] = v[u][0];
+          if (ok1) d[r1] = v[u][1];
+        }
+    }
+  }
+#ifdef BXR_PROBE
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+  float* bias_l = reinterpret_cast<float*>(bxr_lds + g.n_slabs * (BXR_G * 192));
+  if constexpr (EpiRawPre<Epi>::value) {
+    if (threadIdx.x < BXR_G * 32) {
+      const int col = t0 * 32 + (int)threadIdx.x;
+      bias_l[threadIdx.x] = col < g.N ? pb.epi.bias1(col) : 0.f;
     }
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6;
   const int first = p_lo + rank * BXR_WAVES + wave, stride = nslots * BXR_WAVES;
-  if (gt == 4) bxr_wave<4, Epi>(pb, g, bxr_lds, t0, first, p_hi, stride);
-  else if (gt == 3) bxr_wave<3, Epi>(pb, g, bxr_lds, t0, first, p_hi, stride);
-  else if (gt == 2) bxr_wave<2, Epi>(pb, g, bxr_lds, t0, first, p_hi, stride);
-  else bxr_wave<1, Epi>(pb, g, bxr_lds, t0, first, p_hi, stride);
+#ifdef BXR_PROBE
+  const unsigned long long t_staged = __builtin_amdgcn_s_memtime();
+#endif
+  if (gt == 4) bxr_wave<4, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
+  else if (gt == 3) bxr_wave<3, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
+  else if (gt == 2) bxr_wave<2, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
+  else bxr_wave<1, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
+#ifdef BXR_PROBE
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* o = g_bxr_stamp + ((size_t)blockIdx.x * BXR_WAVES + wave) * 4;
+    o[0] = t_start; o[1] = t_staged; o[2] = __builtin_amdgcn_s_memtime();
+    o[3] = ((unsigned long long)gt << 32) | (unsigned)(first < p_hi ? (p_hi - first + stride - 1) / stride : 0);
+  }
+#endif
 }
 
 }  // namespace temp

@@ -26,10 +26,10 @@ namespace temp {
 // ---------------------------------------------------------------------------------------------
 struct EpiAddBiasAct {
   const float* addend; int ld_add; const int32_t* row_mask; const float* bias; int act; float* out; int ldo;
-  struct RowCtx { bool add; };
+  struct RowCtx { int add; };              // (an int: a one-byte struct travelled through scratch memory in gemm_bxr.hpp)
   __device__ __forceinline__ RowCtx row_ctx(int row) const {
     RowCtx c;
-    c.add = addend && (!row_mask || row_mask[row] > 0);
+    c.add = !addend ? 0 : (row_mask ? row_mask[row] : 1);   // the raw mask word (tested as > 0 where it is used: no wait for the load here)
     return c;
   }
   // pre4(): branch-free float4 loads (row/col clamped by the caller); fin4(): arithmetic + float4 store
@@ -37,7 +37,7 @@ struct EpiAddBiasAct {
     float4 a = zero4();
     if (addend) {                                   // kernel-uniform
       const float4 v = ld4(addend + (size_t)row * ld_add + col);
-      a = c.add ? v : zero4();
+      a = c.add > 0 ? v : zero4();
     }
     if (bias) a = add4(a, ld4(bias + col));
     return a;
@@ -47,6 +47,13 @@ struct EpiAddBiasAct {
     if (act == TEMP_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     st4(out + (size_t)row * ldo + col, v);
   }
+  // gemm_bxr.hpp (EpiRawPre): pre4 = (c.add ? raw4 : 0) + bias, taken apart so that a wave can issue all sixteen raw loads of a
+  // panel back to back and apply the row mask and the bias (staged in LDS once per block) afterwards
+  static constexpr int k_raw_pre = 1;
+  __device__ __forceinline__ bool has_addend() const { return addend != nullptr; }
+  __device__ __forceinline__ bool has_row_mask() const { return addend && row_mask; }   // else row_ctx() is the same for every row
+  __device__ __forceinline__ float4 raw4(int row, int col) const { return ld4(addend + (size_t)row * ld_add + col); }
+  __device__ __forceinline__ float bias1(int col) const { return bias ? bias[col] : 0.f; }
 };
 
 template <>
