@@ -21,6 +21,7 @@ namespace temp {
 
 #ifdef BXR_PROBE
 __device__ unsigned long long g_bxr_stamp[256 * 8 * 4];
+__device__ unsigned long long g_bxr_epi[256 * 8];
 #endif
 
 #define BXR_G 4                                              // column tiles resident per workgroup
@@ -114,6 +115,13 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
     const int k = 16 * s + 8 * hh;
     const float* p = aptr + (k <= kclamp ? 16 * s : kclamp - 8 * hh);   // past K: a valid octet again (meets the zero padding of B)
     if constexpr (VAR & 1) { a[0] = make_float4(1.f, 2.f, 3.f, (float)s); a[1] = a[0]; return; }
+    if constexpr (VAR & 16) {                                 // (probe) same bytes, row-contiguous: 4 lanes x 16 B per row and instruction
+      const float* q = aptr - 8 * hh + ((lane >> 2) - li) * (long)g.lda + 16 * min(s, NS - 2) + 4 * (lane & 3);
+      if (q < A) q = A + 4 * (lane & 3);
+      a[0] = ld4(q);
+      a[1] = ld4(q + 16 * (long)g.lda);
+      return;
+    }
     a[0] = ld4(p);
     a[1] = ld4(p + 4);
   };
@@ -126,7 +134,7 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
     const bool row_ok = panel < p_hi && row < M;
     bool loaded = false;
     if constexpr (INIT) {
-      if (!(VAR & 2) && epi.has_addend()) {                   // (kernel-uniform)
+      if (!(VAR & (2 | 128)) && epi.has_addend()) {           // (kernel-uniform; probe bit 128: no addend loads)
         loaded = true;
 #pragma unroll
         for (int t = 0; t < GT; ++t)
@@ -134,7 +142,12 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
           for (int q = 0; q < 4; ++q) {
             const int col = n0 + t * 32 + 8 * q + 4 * hh;
             const bool ok = row_ok && col < N;
-            const float4 v = epi.raw4(ok ? row : 0, ok ? col : 0);
+            float4 v;
+            if constexpr (VAR & 32) {                         // (probe) same bytes, 8 lanes x 16 B per row and instruction
+              const int prow = min(panel * 32 + 8 * q + (lane >> 3), M - 1);
+              v = epi.raw4(prow, min(n0 + t * 32, N - 32) + 4 * (lane & 7));
+            } else
+              v = epi.raw4(ok ? row : 0, ok ? col : 0);
             acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
           }
         // Wait for them HERE (vmcnt(0): one exposed latency per panel, covered by the SIMD's other wave).  Left to the compiler, the
@@ -267,6 +280,9 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
       asm volatile("" : "+v"(NF[0]), "+v"(NF[1]), "+v"(NF[2]));
 
       if (++s == NS) {
+#ifdef BXR_PROBE
+        const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- epilogue of the panel (its own loads are in `pre`, or were the accumulators' start values), then the next panel's start
 #pragma unroll
         for (int t = 0; t < GT; ++t)
@@ -278,6 +294,11 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
               if constexpr (!INIT) p = rc.add > 0 ? p : zero4();
               p = add4(p, *reinterpret_cast<const float4*>(bias_l + t * 32 + 8 * q + 4 * hh));
             }
+            if constexpr (VAR & 32) {
+              const int prow = min(panel * 32 + 8 * q + (lane >> 3), M - 1);
+              epi.fin4(rc, prow, min(n0 + t * 32, N - 32) + 4 * (lane & 7), make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), p);
+            } else
+            if ((VAR & 64) && acc[t][4 * q] != 1.2345e30f) continue;      // (probe) no stores, accumulators stay live
             if (row_ok && col < N && !(VAR & 2)) epi.fin4(rc, row, col, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), p);
           }
         panel += stride;
@@ -289,6 +310,9 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
         src_nxt = row_src(panel + stride);                    //  holds its pointer; it wraps to src_nxt's after this update: NS >= 5)
         acc_start(panel, rc);                                 // (after the index load: the compiler waits for that one at the block's
                                                               //  end, and the wait inside acc_start then covers it)
+#ifdef BXR_PROBE
+        if (lane == 0) g_bxr_epi[(size_t)blockIdx.x * BXR_WAVES + (threadIdx.x >> 6)] += __builtin_amdgcn_s_memtime() - te0;
+#endif
       }
     }
   }
