@@ -54,6 +54,42 @@ __device__ __forceinline__ ItemRange xcd_items(int n_items, int per_block) {
   return r;
 }
 
+// The same split for a chunk list whose chunks differ in length by orders of magnitude (ONE large graph with power-law degrees: the
+// hubs' full chunks sit at the front of a dst- or src-sorted view -- on the S-hbm shape the first eighth of the chunk list holds
+// 57 % of the edges, so with equal chunk COUNTS one XCD worked while seven waited): XCD x owns the chunks whose first edge lies in
+// the x-th eighth of the EDGE range.  chunk_beg is non-decreasing (also in device-subsampled views, whose chunks keep their start);
+// the two boundaries cost ~20 dependent loads per block, so only lists of >= XCD_BALANCE_MIN chunks take this path.
+#define XCD_BALANCE_MIN (1 << 18)
+__device__ __forceinline__ int chunk_lower_bound(const int32_t* __restrict__ chunk_beg, int n, int edge) {
+  int lo = 0, hi = n;                                         // first chunk with chunk_beg >= edge
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_beg[mid] < edge) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ void xcd_chunk_range(int n_chunks, int n_edges, const int32_t* __restrict__ chunk_beg, int xcd, int& c_lo, int& c_hi) {
+  if (n_chunks < XCD_BALANCE_MIN) {
+    const int per = (n_chunks + 7) >> 3;
+    c_lo = xcd * per;
+    c_hi = min(n_chunks, c_lo + per);
+    return;
+  }
+  const int e_lo = (int)(((long long)n_edges * xcd) >> 3), e_hi = (int)(((long long)n_edges * (xcd + 1)) >> 3);
+  c_lo = xcd == 0 ? 0 : chunk_lower_bound(chunk_beg, n_chunks, e_lo);
+  c_hi = xcd == 7 ? n_chunks : chunk_lower_bound(chunk_beg, n_chunks, e_hi);
+}
+__device__ __forceinline__ ItemRange xcd_chunks(int n_chunks, int n_edges, const int32_t* __restrict__ chunk_beg, int per_block) {
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  int c_lo, c_hi;
+  xcd_chunk_range(n_chunks, n_edges, chunk_beg, xcd, c_lo, c_hi);
+  ItemRange r;
+  r.beg = c_lo + lb * per_block;
+  r.end = c_hi;
+  r.stride = bpx * per_block;
+  return r;
+}
+
 // Self-loop dropout (include/temp_amd.h: TempDropout): keep-scale of element (row, col), a counter-based hash so the
 // backward pass regenerates the forward mask.
 struct DropSpec { float p; float inv_keep; unsigned long long seed; };

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(1024) k_rgcn_agg(TempEdgeView v, const float* 
   const int lr = lane & (lpr - 1), gi = lane / lpr, epw = 64 / lpr;
   const int f = lr << 2;
   const bool active = f < D;
-  ItemRange it = xcd_items(v.n_chunks, wpb);
+  ItemRange it = xcd_chunks(v.n_chunks, v.n_edges, v.chunk_beg, wpb);
   for (int c = it.beg + wave; c < it.end; c += it.stride) {
     const int seg = v.chunk_seg[c], beg = v.chunk_beg[c], cnt = v.chunk_end[c] - beg, slot = v.chunk_slot[c];
     int a_l = 0, b_l = 0;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(1024, 8) k_rgcn_agg_s(TempEdgeView v, const fl
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
   const int f = lane << 2;
   const bool active = lane < D4;
-  ItemRange it = xcd_items(v.n_chunks, wpb);
+  ItemRange it = xcd_chunks(v.n_chunks, v.n_edges, v.chunk_beg, wpb);
   for (int c = it.beg + wave; c < it.end; c += it.stride) {
     const int seg = __builtin_amdgcn_readfirstlane(v.chunk_seg[c]), beg = __builtin_amdgcn_readfirstlane(v.chunk_beg[c]);
     const int cnt = __builtin_amdgcn_readfirstlane(v.chunk_end[c]) - beg, slot = __builtin_amdgcn_readfirstlane(v.chunk_slot[c]);
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* 
   const int f = lane << 2;
   const bool active = lane < (D >> 2);
   const int wrow = D * S;
-  ItemRange it = xcd_items(v.n_chunks, wpb);
+  ItemRange it = xcd_chunks(v.n_chunks, v.n_edges, v.chunk_beg, wpb);
   for (int c = it.beg + wave; c < it.end; c += it.stride) {
     const int seg = __builtin_amdgcn_readfirstlane(v.chunk_seg[c]), cbeg = __builtin_amdgcn_readfirstlane(v.chunk_beg[c]);
     const int cend = __builtin_amdgcn_readfirstlane(v.chunk_end[c]), slot = __builtin_amdgcn_readfirstlane(v.chunk_slot[c]);
@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* 
 
 }  // namespace temp
 #include "rgcn_tile.hpp"
+#include "rgcn_slice.hpp"
 namespace temp {
 
 // Generic (any si, so) scalar-lane variant; slow, for shapes outside the fast path.
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256) k_rgcn_dw(TempEdgeView v, const float* __
   const int f = lr << 2;
   const bool active = f < D;
   const int wrow = D * S;
-  ItemRange it = xcd_items(v.n_chunks, wpb);
+  ItemRange it = xcd_chunks(v.n_chunks, v.n_edges, v.chunk_beg, wpb);
   for (int c = it.beg + wave; c < it.end; c += it.stride) {
     const int seg = v.chunk_seg[c], cbeg = v.chunk_beg[c], cend = v.chunk_end[c], slot = v.chunk_slot[c];
     float4 acc[S];
@@ -526,6 +527,7 @@ static bool view_ok(const TempEdgeView& v) {
 static bool rgcn_tile_on() { return option(TEMP_OPT_RGCN_TILE) != 0; }
 static std::atomic<long long*> g_debug_buf{nullptr};         // development only (temp_set_debug_buffer)
 static std::atomic<size_t> g_debug_words{0};
+static std::atomic<long long> g_slice_launches{0};          // diagnostic (temp_slice_launches): launches of the feature-sliced kernels (rgcn_slice.hpp)
 static std::atomic<long long> g_tile_launches{0};           // diagnostic (temp_tile_launches): edge-kernel launches that took the LDS-tiled path
 
 // dynamic LDS beyond 64 KB must be granted per kernel function
@@ -567,6 +569,18 @@ static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, c
                                       : launch_agg_tile<S, MODE, unsigned short>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st);
     if (ok) return;
   }
+  SliceArgs sa;
+  if (wbytes > 65536 && lpr == 64 && option(TEMP_OPT_RGCN_SLICE) && v.n_edges >= (1 << 21) && slice_plan(D, S, n_rel_rows, &sa)) {
+    // large graph, table beyond LDS: one feature slice of the WHOLE table per persistent block (rgcn_slice.hpp)
+    static const bool granted = tile_grant_lds(k_rgcn_agg_f<S, MODE>, SLICE_LDS_MAX);
+    if (granted) {
+      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_f<S, MODE>), dim3(256), dim3(SLICE_THREADS), sa.lds_bytes, st, v, sa, feat, ldf, ids,
+                  W, n_rel_rows, nnorm, D, out, partial);
+      g_slice_launches.fetch_add(1, std::memory_order_relaxed);
+      return;
+    }
+    (void)hipGetLastError();
+  }
   if (wbytes <= 65536 && v.n_chunks >= 4096) {
     // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
     const int grid = 512;
@@ -579,7 +593,7 @@ static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, c
   } else {
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
-    if (lpr == 64 && MODE == MODE_FWD && !rgcn_scalar_off())      // (measured on the S-hbm shape: the forward gains 3 %, d/dh loses 14 %)
+    if (lpr == 64 && MODE == MODE_FWD && !rgcn_scalar_off())      // (measured on the S-hbm shape: the forward gains 3 %, d/dh loses 14 %: 3.32 against 2.91 ms)
       TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_s<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
                   out, partial);
     else
@@ -758,6 +772,7 @@ using namespace temp;
 extern "C" {
 
 long long temp_tile_launches(void) { return g_tile_launches.load(std::memory_order_relaxed); }
+long long temp_slice_launches(void) { return g_slice_launches.load(std::memory_order_relaxed); }
 void temp_set_debug_buffer(void* device_ptr, size_t words) { g_debug_buf.store((long long*)device_ptr); g_debug_words.store(device_ptr ? words : 0); }
 
 size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out) {

@@ -675,6 +675,55 @@ def test_tiled_edge_kernels_bit_identical_gpu(D, B, hip_backend):
             assert_close(a, c, 2e-6, 2e-6 * max(1.0, float(c.abs().max())), "tiled vs gathered %d" % i)
 
 
+@pytest.mark.parametrize("with_ids", [False, True])
+def test_sliced_edge_kernels_bit_identical_gpu(with_ids, hip_backend):
+    """Feature-sliced aggregation / d/dh (csrc/rgcn_slice.hpp: one slice of the WHOLE relation table in LDS per persistent block,
+    for large graphs whose table does not fit LDS) against the kernels that read the table through L2: same chunks, same
+    per-chunk order => BIT-identical layer output and gradients.  2^17 nodes, 2^21 edges, 2 x 230 relation rows, D = 200; with
+    and without the table layer's row ids (models/RGCN.py:91-104)."""
+    from temp_amd import _lib, synthetic
+    lib = _lib.load()
+    n, E, R, D, B = 1 << 17, 1 << 21, 230, 200, 100
+    g = synthetic.make_snapshots(n, R, E, n, 1, seed=3)[0]
+    dg = g.device_graph(DEV, 2 * R)
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    s_ = D // B
+    wt = (torch.rand(2 * R, B * s_ * s_, generator=gen) - 0.5).to(DEV)
+    lw = ((torch.rand(D, D, generator=gen) - 0.5) * 0.2).to(DEV)
+    h = torch.randn(n, D, generator=gen).to(DEV)
+    gy = torch.randn(n, D, generator=gen).to(DEV)
+    n_tab = 5000
+    table = torch.randn(n_tab, D, generator=gen).to(DEV)
+    ids_np = np.random.default_rng(6).integers(0, n_tab, n)
+    ids = torch.from_numpy(ids_np.astype(np.int32)).to(DEV)
+    from temp_amd import functional as TF
+    inv = TF.gather_inverse(ids_np, n_tab, DEV)
+
+    def run():
+        if with_ids:
+            out = hip_backend.rgcn_table_fwd(dg, table, ids, wt, lw, None, B, 0)
+            grads = hip_backend.rgcn_table_bwd(dg, table, ids, inv, out, gy, wt, lw, False, B, 0)
+        else:
+            out = hip_backend.rgcn_fwd(dg, h, None, wt, lw, None, B, 1)
+            grads = hip_backend.rgcn_bwd(dg, h, out, gy, wt, lw, False, B, 1)
+        torch.cuda.synchronize()
+        return [out] + [x for x in grads if x is not None]
+
+    prev = lib.temp_set_option(_lib.OPT_RGCN_SLICE, 1)
+    try:
+        n0 = lib.temp_slice_launches()
+        sliced = run()
+        assert lib.temp_slice_launches() - n0 == 2, "the feature-sliced kernels were not launched"
+        lib.temp_set_option(_lib.OPT_RGCN_SLICE, 0)
+        n1 = lib.temp_slice_launches()
+        through_l2 = run()
+        assert lib.temp_slice_launches() == n1
+    finally:
+        lib.temp_set_option(_lib.OPT_RGCN_SLICE, prev)
+    for i, (a, c) in enumerate(zip(sliced, through_l2)):
+        assert torch.equal(a, c), (i, float((a - c).abs().max()))
+
+
 def test_rgcn_layer_row_gather_in_large_gemm_gpu():
     """temp_rgcn_fwd with feature ids at a size that takes the split-operand GEMM (>= 16 K rows): the self-loop product gathers
     its rows through a_idx inside the kernel; result = the same layer on the explicitly gathered rows.  Nodes without in-edges
