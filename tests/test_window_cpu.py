@@ -1,6 +1,8 @@
 """Window-level host logic on CPU (test-only backend): plan building, compact history with the
 reference's F8 semantics, None-padded windows, bi-directional flip, batched == reference-granular,
 loss + gradients against the golden vectors recorded from the reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -61,7 +63,13 @@ def test_plan_matches_dense_history_semantics():
         assert np.array_equal(a, hist_mark[b]) and np.array_equal(d, L - 1 - start[b])
 
 
-@pytest.mark.parametrize("name", ["G10_uni_grrgcn", "G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol", "G10_bi_grrgcn", "G10_bi_grrgcn_rol_d200"])
+# (G10_bi_grrgcn_rol_d200 -- the headline model at D = 200, L = 15 -- takes five minutes through the test-only CPU backend; the
+#  same golden pins the oracle in test_oracle_golden.py and the HIP path in test_gpu_parity.py, so here it runs on request only)
+_WINDOW_GOLDENS = ["G10_uni_grrgcn", "G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol", "G10_bi_grrgcn"] + \
+    (["G10_bi_grrgcn_rol_d200"] if os.environ.get("TEMP_FULL_CPU_TESTS") else [])
+
+
+@pytest.mark.parametrize("name", _WINDOW_GOLDENS)
 def test_window_loss_and_grads_golden(name):
     check_window(name, torch.device("cpu"))
 
