@@ -74,7 +74,7 @@ enum {
                                                                                                [TEMP_GEMM_RESIDENT=0 -> 0] default 1 */
   TEMP_OPT_RGCN_SLICE = 9,  /* 1: on a large graph (>= 2^21 edges) whose relation table does not fit LDS, aggregation and d/dh run one
                                feature slice of the WHOLE table per persistent block (rgcn_slice.hpp; bit-identical results).
-                               Measured SLOWER than reading the table through L2 on the S-hbm shape (3.40 against 2.79 ms: five
+                               Measured SLOWER than reading the table through L2 on the S-hbm shape (3.03 against 2.75 ms: five
                                times the chunk visits, each a chain of dependent loads), hence off by default
                                                                                                [TEMP_RGCN_SLICE=1 -> 1] default 0 */
   TEMP_OPT_COUNT = 10

@@ -16,12 +16,15 @@
 // handed round with ds_bpermute; eight row gathers are in flight per walker.
 //
 // STATUS (round 3): correct (bit-identical, tests/test_gpu_parity_r2.py::test_sliced_edge_kernels_bit_identical_gpu) but SLOWER
-// than the kernels that read the table through L2 -- forward 3.40 against 2.79 ms on S-hbm -- and therefore opt-in
+// than the kernels that read the table through L2 -- forward 3.03 against 2.75 ms on S-hbm -- and therefore opt-in
 // (TEMP_OPT_RGCN_SLICE).  Every chunk is visited once per slice, and a visit is a chain of dependent loads (chunk record -> ids
 // [-> nnorm] -> rows) with the row loads of one round waited for before the next round is issued: a walker keeps ~8 gathers of
 // 160 bytes in flight a third of the time, where the chip needs ~8 per walker ALL the time (8 TB/s x 2.5 us / 256 CUs / 64
 // walkers).  What it needs: the walker's chunks as one contiguous edge stream with the ids two windows and the rows one round
-// ahead of the products.
+// ahead of the products -- tried (contiguous chunk range per walker, prefetched id / record windows, two alternating sets of
+// eight gathers): bit-identical, but 4.6 ms: with loads inside the data-dependent chunk-retire path the compiler cannot count
+// outstanding loads and drains them all (s_waitcnt vmcnt(0)) at the top of every window and at every record-window switch, so
+// the prefetch never overlaps; it needs hand-placed wait counts (inline assembly) or the records delivered through LDS.
 #pragma once
 #include "rgcn_tile.hpp"
 
@@ -113,7 +116,8 @@ __global__ void __launch_bounds__(SLICE_THREADS) k_rgcn_agg_f(TempEdgeView v, Sl
           const int row = __shfl(a_l, src_lane);
           rel[u] = __shfl(b_l, src_lane);
           sc[u] = __shfl(s_l, src_lane);
-          x[u] = (lane_ok && e0 + u < n16) ? ld4(fcol + (size_t)row * ldf) : zero4();
+          x[u] = ld4(fcol + (size_t)row * ldf);             // (unconditional: a select on the loaded value makes the wave wait for every
+                                                              //  gather before it issues the next; idle lanes / edges read a valid row and are not used)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
