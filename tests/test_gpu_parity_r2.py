@@ -724,6 +724,36 @@ def test_sliced_edge_kernels_bit_identical_gpu(with_ids, hip_backend):
         assert torch.equal(a, c), (i, float((a - c).abs().max()))
 
 
+def test_rgcn_layer_large_power_law_graph_gpu(hip_backend):
+    """One large graph with power-law degrees (2^19 nodes, 2^21 edges, dst / src ~ Zipf): its by-dst and by-src chunk lists are
+    long enough (>= 2^18 chunks) for the XCD split by EDGES (csrc/common.hpp: xcd_chunk_range -- the hubs' full chunks sit at the
+    front of the list), which no other test reaches.  Layer output and every gradient against the test backend's restatement."""
+    from temp_amd import synthetic
+    from tests.cpu_backend import CpuTestBackend
+    n, E, R, D, B = 1 << 19, 1 << 21, 20, 8, 4
+    g = synthetic.make_snapshots(n, R, E, n, 1, seed=11)[0]
+    dg = g.device_graph(DEV, 2 * R)
+    for view in ("by_dst", "by_src"):
+        assert dg.view_tensor(view, "chunk_seg").shape[0] >= 1 << 18, view
+    rng = np.random.default_rng(12)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    s_ = D // B
+    h, w, lw, gy = f(n, D), f(2 * R, B * s_ * s_) * 0.5, f(D, D) * 0.2, f(n, D)
+    cpu = CpuTestBackend()
+    dg_c = g.device_graph(torch.device("cpu"), 2 * R)
+    want = cpu.rgcn_fwd(dg_c, h, None, w, lw, None, B, 1)
+    wd = cpu.rgcn_bwd(dg_c, h, want, gy, w, lw, False, B, 1)
+    got = hip_backend.rgcn_fwd(dg, h.to(DEV), None, w.to(DEV), lw.to(DEV), None, B, 1)
+    gd = hip_backend.rgcn_bwd(dg, h.to(DEV), got, gy.to(DEV), w.to(DEV), lw.to(DEV), False, B, 1)
+    # absolute floors relative to the largest entry: a hub row sums ~10^5 terms (|d_h| reaches ~100 where typical entries are ~0.1),
+    # and the two paths add them in different orders
+    assert_close(got, want, 1e-5, 1e-6 * max(1.0, float(want.abs().max())), "rgcn_fwd on the large power-law graph")
+    assert_close(gd[0], wd[0], 1e-5, 1e-6 * max(1.0, float(wd[0].abs().max())), "d_h")
+    # weight gradients: fp32 sums over 2^19 rows / 2^21 edges on both sides (eps x sqrt(n) = 4e-5 of the largest entry)
+    assert_close(gd[1], wd[1], 2e-5, 4e-5 * max(1.0, float(wd[1].abs().max())), "d_weight")
+    assert_close(gd[2], wd[2], 2e-5, 4e-5 * max(1.0, float(wd[2].abs().max())), "d_loop")
+
+
 def test_rgcn_layer_row_gather_in_large_gemm_gpu():
     """temp_rgcn_fwd with feature ids at a size that takes the split-operand GEMM (>= 16 K rows): the self-loop product gathers
     its rows through a_idx inside the kernel; result = the same layer on the explicitly gathered rows.  Nodes without in-edges
