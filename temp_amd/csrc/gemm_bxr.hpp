@@ -372,10 +372,25 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
 #ifdef BXR_PROBE
   const unsigned long long t_staged = __builtin_amdgcn_s_memtime();
 #endif
-  if (gt == 4) bxr_wave<4, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
-  else if (gt == 3) bxr_wave<3, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
-  else if (gt == 2) bxr_wave<2, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
-  else bxr_wave<1, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_hi, stride);
+  // Whole rounds of panels go to the waves with all gt tiles each; the LAST, partial round (r < stride panels) is cut into r x gt
+  // single-tile units dealt round the waves: with 2.2 panels per wave (the self-loop products of the step) every wave used to
+  // wait for the few that ran a third panel -- 12 tile-panels on the critical path against an average of 8.8; now 8 + 1.
+  // (only where a wave gets at most ONE unit: a unit pays a pipeline fill, an epilogue and a full operand split for six MFMAs per
+  //  slab, three of them cost more than the panel they replace -- measured on the input-gate shape, +5 %)
+  const int n_x = p_hi - p_lo;
+  int q_full = n_x / stride, n_units = (n_x - q_full * stride) * gt;
+  if (n_units > stride) { q_full = (n_x + stride - 1) / stride; n_units = 0; }
+  const int p_full = min(p_hi, p_lo + q_full * stride);
+  if (q_full > 0) {
+    if (gt == 4) bxr_wave<4, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_full, stride);
+    else if (gt == 3) bxr_wave<3, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_full, stride);
+    else if (gt == 2) bxr_wave<2, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_full, stride);
+    else bxr_wave<1, Epi, VAR>(pb, g, bxr_lds, bias_l, t0, first, p_full, stride);
+  }
+  for (int u = rank * BXR_WAVES + wave; u < n_units; u += stride) {
+    const int panel = p_full + u / gt, ti = u - (u / gt) * gt;
+    bxr_wave<1, Epi, VAR>(pb, g, bxr_lds + ti * 192, bias_l + ti * 32, t0 + ti, panel, panel + 1, 1);
+  }
 #ifdef BXR_PROBE
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* o = g_bxr_stamp + ((size_t)blockIdx.x * BXR_WAVES + wave) * 4;
