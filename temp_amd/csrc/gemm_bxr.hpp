@@ -34,6 +34,7 @@ struct BxrGeom {
   int N, K, lda, n_tiles, n_slabs, n_groups;
   int per_xcd;                                               // 32-row panels per XCD (of the largest problem)
   unsigned char slot_group[32], slot_rank[32], group_slots[8];
+  unsigned char group_t0[8], group_nt[8];                    // first column tile and tile count (<= BXR_G) of every group
 };
 
 inline bool bxr_plan(int N, int K, int lda, int max_m, BxrGeom* g) {
@@ -59,7 +60,8 @@ inline bool bxr_plan(int N, int K, int lda, int max_m, BxrGeom* g) {
     --left;
   }
   int s = 0;
-  for (int j = 0; j < g->n_groups; ++j) {
+  for (int j = 0, t = 0; j < g->n_groups; ++j) {
+    g->group_t0[j] = (unsigned char)t; g->group_nt[j] = (unsigned char)tiles[j]; t += tiles[j];
     g->group_slots[j] = (unsigned char)slots[j];
     for (int r = 0; r < slots[j]; ++r, ++s) { g->slot_group[s] = (unsigned char)j; g->slot_rank[s] = (unsigned char)r; }
   }
@@ -326,8 +328,8 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
   const PanelProblem<Epi>& pb = batch.p[blockIdx.y];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int grp = g.slot_group[slot], rank = g.slot_rank[slot], nslots = g.group_slots[grp];
-  const int t0 = grp * BXR_G;
-  const int gt = min(BXR_G, g.n_tiles - t0);
+  const int t0 = g.group_t0[grp];
+  const int gt = g.group_nt[grp];
   const int n_panels = (pb.M + 31) >> 5;
   const int p_lo = xcd * g.per_xcd, p_hi = min(n_panels, p_lo + g.per_xcd);
   if (p_lo >= p_hi) return;                                   // (uniform) nothing for this XCD in this problem

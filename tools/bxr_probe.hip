@@ -98,6 +98,19 @@ static void run_case(int M, int K, int N) {
   const double mfma = (double)ceil_div(M, 32) * rg.n_tiles * rg.n_slabs * 6 * 32 / 1024.0;
   printf(", %d panels per XCD; MFMA issue bound %.0f cycles per SIMD\n", rg.per_xcd, mfma);
   run_var<0>(b, rg, pk, true);
+  if (rg.n_tiles == 19) {                                     // alternative split for the input-gate shape: (4,3,3,3,3,3) tiles on (7,5,5,5,5,5) slots
+    BxrGeom r2 = rg;
+    const int tl[6] = {4, 3, 3, 3, 3, 3}, sl[6] = {7, 5, 5, 5, 5, 5};
+    r2.n_groups = 6;
+    int sidx = 0, t = 0;
+    for (int j = 0; j < 6; ++j) {
+      r2.group_t0[j] = (unsigned char)t; r2.group_nt[j] = (unsigned char)tl[j]; t += tl[j];
+      r2.group_slots[j] = (unsigned char)sl[j];
+      for (int r = 0; r < sl[j]; ++r, ++sidx) { r2.slot_group[sidx] = (unsigned char)j; r2.slot_rank[sidx] = (unsigned char)r; }
+    }
+    printf("  alternative split (4,3,3,3,3,3) x (7,5,5,5,5,5) [measured: 136.8 against 137.9 us, no gain]:\n");
+    run_var<0>(b, r2, pk, false);
+  }
   run_var<64>(b, rg, pk, true);
   run_var<128>(b, rg, pk, true);
   run_var<192>(b, rg, pk, true);
