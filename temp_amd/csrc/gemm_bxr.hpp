@@ -22,6 +22,7 @@ namespace temp {
 #ifdef BXR_PROBE
 __device__ unsigned long long g_bxr_stamp[256 * 8 * 4];
 __device__ unsigned long long g_bxr_epi[256 * 8];
+__device__ unsigned long long g_bxr_rt[256 * 8 * 2];       // s_memrealtime (100 MHz) at the wave's start and end: shader clock = cycles / time
 #endif
 
 #define BXR_G 4                                              // column tiles resident per workgroup
@@ -360,6 +361,7 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
   }
 #ifdef BXR_PROBE
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
 #endif
   float* bias_l = reinterpret_cast<float*>(bxr_lds + g.n_slabs * (BXR_G * 192));
   if constexpr (EpiRawPre<Epi>::value) {
@@ -397,6 +399,8 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* o = g_bxr_stamp + ((size_t)blockIdx.x * BXR_WAVES + wave) * 4;
     o[0] = t_start; o[1] = t_staged; o[2] = __builtin_amdgcn_s_memtime();
+    g_bxr_rt[((size_t)blockIdx.x * BXR_WAVES + wave) * 2] = rt_start;
+    g_bxr_rt[((size_t)blockIdx.x * BXR_WAVES + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
     o[3] = ((unsigned long long)gt << 32) | (unsigned)(first < p_hi ? (p_hi - first + stride - 1) / stride : 0);
   }
 #endif

@@ -55,6 +55,13 @@ static float run_var(const PanelBatch<EpiAddP>& b, const BxrGeom& rg, const BxPa
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_bxr_stamp), h.size() * 8);
     (void)hipMemcpyFromSymbol(he.data(), HIP_SYMBOL(g_bxr_epi), he.size() * 8);
     { std::vector<unsigned long long> z(256 * 8, 0); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bxr_epi), z.data(), z.size() * 8); }
+    {
+      std::vector<unsigned long long> rt(256 * 8 * 2);
+      (void)hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(g_bxr_rt), rt.size() * 8);
+      double cyc = 0, ns = 0;
+      for (int i = 0; i < 2048; ++i) { if (h[4 * i + 3] == 0) continue; cyc += (double)(h[4 * i + 2] - h[4 * i]); ns += 10.0 * (double)(rt[2 * i + 1] - rt[2 * i]); }
+      printf("    s_memtime ticks per ns of s_memrealtime (100 MHz) over the waves' lifetimes: %.3f (= GHz if s_memtime is the shader clock)\n", cyc / ns);
+    }
     unsigned long long t0 = ~0ull, t1 = 0;
     for (int i = 0; i < 2048; ++i) { if (h[4 * i + 3] == 0) continue; t0 = std::min(t0, h[4 * i]); t1 = std::max(t1, h[4 * i + 2]); }
     printf("    kernel span %llu ticks\n", t1 - t0);
