@@ -564,7 +564,7 @@ static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, c
   const size_t wbytes = (size_t)n_rel_rows * D * S * sizeof(float);
   TileArgs ta;
   if (mb && rgcn_tile_on() && n_rel_rows <= 65535 && v.n_partial < 0xffffff &&
-      tile_plan(*mb, view, D, S, 0, n_rel_rows, n_rel_rows <= 256 ? 1 : 2, &ta)) {
+      tile_plan(*mb, view, D, S, 0, n_rel_rows, 0, &ta)) {
     const bool ok = n_rel_rows <= 256 ? launch_agg_tile<S, MODE, unsigned char>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st)
                                       : launch_agg_tile<S, MODE, unsigned short>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st);
     if (ok) return;

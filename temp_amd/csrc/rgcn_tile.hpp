@@ -50,11 +50,17 @@ inline bool tile_plan(const TempMembers& mb, int view, int D, int S, int rows2, 
     const int fs4 = ceil_div(D4, ns);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += align_up(bytes, 16); return (int)at; };
-    t->off_x = take((size_t)mb.max_nodes * fs4 * 16);
+    t->off_x = take(((size_t)mb.max_nodes + (b_bytes == 0 ? 1 : 0)) * fs4 * 16);   // (+ the zero row of the packed walk)
     t->off_g = rows2 ? take((size_t)mb.max_nodes * fs4 * 16) : 0;
     t->off_w = w_rows ? take((size_t)w_rows * S * fs4 * 16) : 0;
-    t->off_ea = take((size_t)mb.max_edges * 2 + 16);
-    t->off_eb = take((size_t)mb.max_edges * b_bytes + 16);
+    if (b_bytes == 0) {                                       // aggregation / d-dh: ONE packed word per edge (tile_stage_edges_packed)
+      if (((size_t)mb.max_nodes + 1) * fs4 * 16 > 131071 || (size_t)w_rows * S * fs4 > 32767) continue;   // 17 + 15 bits of the word
+      t->off_ea = take((size_t)mb.max_edges * 4 + 64);        // (+ a group of padding words: the walk reads one group ahead)
+      t->off_eb = t->off_ea;
+    } else {
+      t->off_ea = take((size_t)mb.max_edges * 2 + 16);
+      t->off_eb = take((size_t)mb.max_edges * b_bytes + 16);
+    }
     t->off_cm = take((size_t)mb.max_chunks[view] * 8);
     t->off_misc = take((size_t)TILE_MISC_INTS * 4);
     if (off > TILE_LDS_MAX) continue;
@@ -153,10 +159,51 @@ __device__ __forceinline__ void tile_stage_edges(unsigned short* Ea, BT* Eb, con
   }
 }
 
+// The aggregation / d-dh walk keeps ONE word per edge holding both LDS offsets, ready to use --
+// bits 0-16: BYTE offset of the edge's staged row  (a_local * fs4 * 16), bits 17-31: weight offset  b * S * fs4  in units of 16
+// bytes (Ws + that = the relation's block rows).  The walk was bound by instruction ISSUE, not by the LDS (4 waves per SIMD x ~22
+// instructions per edge step: 47 k cycles per block against 26 k of LDS reads): two id reads, two clamps, two 24-bit multiplies
+// and their address adds per edge became one read, a mask and a shift (k_rgcn_agg_t builds the words while staging).
+
 // Chunk list of the member, counting-sorted by length (longest first) into cm[]:
 //   .x = first edge (relative to the member's edge range) | segment (relative to seg_sub) << 16      .y = partial slot (0xffffff: none) | length << 24
 // misc: [0, LMAX+2) histogram, [LMAX+2, 2 LMAX+4) cursors, then the queue head.  Must be zero on entry (and the zeroing visible:
 // a barrier before the call); ends with a barrier.  The chunk arrays are read once (a thread keeps up to two chunks in registers).
+// Workgroup barrier that waits for this wave's LDS operations only: __syncthreads() also waits for every outstanding GLOBAL load
+// (s_waitcnt vmcnt(0)), which would end the overlap of the staging loads with the chunk sort.  Only where the data handed over
+// lives in LDS.
+__device__ __forceinline__ void tile_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The same sort with the thread's FIRST chunk record already in registers (loaded by the caller ahead of its other staging loads;
+// `crec` = {first edge, end, segment, slot}, valid when tid < b.nc) and LDS-only barriers: no wait on the caller's loads in flight.
+__device__ __forceinline__ void tile_sort_chunks_pre(uint2* cm, int* misc, const TempEdgeView& v, const TileBlock& b, int seg_sub, const int (&crec)[4]) {
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  int* hist = misc;
+  int* cur = misc + TILE_LMAX + 2;
+  const bool mine = tid < b.nc;
+  const int len0 = min(max(crec[1] - crec[0], 0), TILE_LMAX);
+  if (mine) atomicAdd(&hist[TILE_LMAX - len0], 1);
+  for (int i = tid + nthr; i < b.nc; i += nthr) {             // (members with more than 1024 chunks)
+    const int beg = v.chunk_beg[b.c0 + i], len = min(max(v.chunk_end[b.c0 + i] - beg, 0), TILE_LMAX);
+    atomicAdd(&hist[TILE_LMAX - len], 1);
+  }
+  tile_barrier_lds();
+  if (tid <= TILE_LMAX) {
+    int s = 0;
+    for (int q = 0; q < tid; ++q) s += hist[q];
+    cur[tid] = s;
+  }
+  tile_barrier_lds();
+  if (mine)
+    cm[atomicAdd(&cur[TILE_LMAX - len0], 1)] = make_uint2((unsigned)(crec[0] - b.e0) | ((unsigned)(crec[2] - seg_sub) << 16), ((unsigned)crec[3] & 0xffffffu) | ((unsigned)len0 << 24));
+  for (int i = tid + nthr; i < b.nc; i += nthr) {
+    const int beg = v.chunk_beg[b.c0 + i], len = min(max(v.chunk_end[b.c0 + i] - beg, 0), TILE_LMAX);
+    const int seg = v.chunk_seg[b.c0 + i], slot = v.chunk_slot[b.c0 + i];
+    cm[atomicAdd(&cur[TILE_LMAX - len], 1)] = make_uint2((unsigned)(beg - b.e0) | ((unsigned)(seg - seg_sub) << 16), ((unsigned)slot & 0xffffffu) | ((unsigned)len << 24));
+  }
+  tile_barrier_lds();
+}
+
 __device__ __forceinline__ void tile_sort_chunks(uint2* cm, int* misc, const TempEdgeView& v, const TileBlock& b, int seg_sub) {
   const int nthr = blockDim.x, tid = threadIdx.x;
   int* hist = misc;
@@ -201,8 +248,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_rgcn_agg_t(TempEdgeView v, Til
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
   float4* Xs = reinterpret_cast<float4*>(tile_lds + t.off_x);
   float4* Ws = reinterpret_cast<float4*>(tile_lds + t.off_w);
-  unsigned short* Ea = reinterpret_cast<unsigned short*>(tile_lds + t.off_ea);
-  BT* Eb = reinterpret_cast<BT*>(tile_lds + t.off_eb);
+  unsigned* Ep = reinterpret_cast<unsigned*>(tile_lds + t.off_ea);
   uint2* cm = reinterpret_cast<uint2*>(tile_lds + t.off_cm);
   int* misc = reinterpret_cast<int*>(tile_lds + t.off_misc);
   const int D4 = D >> 2;
@@ -210,25 +256,87 @@ __global__ void __launch_bounds__(TILE_THREADS) k_rgcn_agg_t(TempEdgeView v, Til
   if (!tile_block(t, D4, b)) return;
   const int tid = threadIdx.x, nthr = blockDim.x, fs4 = t.fs4;
   TILE_STAMP(0);
+  // ---- staging.  The FIRST batch of every stream -- eight rows, one weight item, eight edges per thread: all of a GDELT-sized
+  // member but half of its edges -- is requested before anything waits, and the chunk sort (global loads of the chunk records,
+  // LDS atomics, three barriers) runs while those loads are in flight: one memory round trip where the four phases used to pay
+  // one each (rows 9.5 k + weights 3.2 k + edges 2.8 k + sort 4.9 k cycles of a 57 k-cycle block).
   for (int i = tid; i < TILE_MISC_INTS; i += nthr) misc[i] = 0;
-  if (MODE == MODE_DX) tile_stage_rows<true>(Xs, t, b, feat, ldf, feat_ids, nnorm);
-  else tile_stage_rows<false>(Xs, t, b, feat, ldf, feat_ids, nnorm);
+  int crec[4];                                                // this thread's chunk record FIRST: the sort waits for it, and the
+  {                                                           // load counter is in order -- what is requested behind it stays in flight
+    const int ci = b.c0 + min(tid, max(b.nc - 1, 0));
+    crec[0] = v.chunk_beg[ci]; crec[1] = v.chunk_end[ci]; crec[2] = v.chunk_seg[ci]; crec[3] = v.chunk_slot[ci];
+  }
+  constexpr int RU = 8;
+  const int rw = b.nf4, rstep = nthr / rw;
+  const int rr0 = min(tid / rw, rstep - 1), rlr = tid - (tid / rw) * rw;
+  const bool rower = tid / rw < rstep;                        // (the last few threads repeat the last row group's loads and store nothing)
+  const float* rbase = feat + (size_t)(b.f4_0 + rlr) * 4;
+  float4 rx[RU];
+  float rnn[RU];
+  {
+    int row[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int node = b.n0 + min(rr0 + u * rstep, b.nm - 1);  // past the end: the last row again (not stored)
+      row[u] = feat_ids ? feat_ids[node] : node;
+      rnn[u] = (MODE == MODE_DX) ? nnorm[node] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) rx[u] = ld4(rbase + (size_t)row[u] * ldf);
+  }
+  const float4* W4 = reinterpret_cast<const float4*>(W);
+  const int w_total = n_rel_rows * S * fs4;
+  auto w_src = [&](int q, bool& ok) {                          // Ws[(r * S + j) * fs4 + lr] = W4[r * D4 * S + (f4_0 + lr) * S + j]
+    const int rj = q / fs4, lr = q - rj * fs4;
+    const int r = rj / S, j = rj - r * S;
+    ok = q < w_total && lr < b.nf4;
+    return W4 + (ok ? (size_t)r * D4 * S + (size_t)(b.f4_0 + lr) * S + j : 0);
+  };
+  bool w_ok0;
+  const float4 w0 = *w_src(tid, w_ok0);
+  constexpr int EU = 8;
+  int ea0[EU], eb0[EU];
+#pragma unroll
+  for (int u = 0; u < EU; ++u) {
+    const int e = b.e0 + min(tid + u * nthr, max(b.em - 1, 0));
+    ea0[u] = v.a[e];
+    eb0[u] = v.b[e];
+  }
   TILE_STAMP(1);
-  {  // weight slice: Ws[(r * S + j) * fs4 + lr] = W4[r * D4 * S + (f4_0 + lr) * S + j]
-    const float4* W4 = reinterpret_cast<const float4*>(W);
-    const int total = n_rel_rows * S * fs4;
-    for (int q = tid; q < total; q += nthr) {
-      const int rj = q / fs4, lr = q - rj * fs4;
-      const int r = rj / S, j = rj - r * S;
-      if (lr < b.nf4) Ws[q] = W4[(size_t)r * D4 * S + (size_t)(b.f4_0 + lr) * S + j];
+  tile_barrier_lds();                                         // misc zeroed
+  TILE_STAMP(2);
+  tile_sort_chunks_pre(cm, misc, v, b, b.n0, crec);
+  TILE_STAMP(3);
+  // ---- commit the first batches, then whatever a larger member has beyond them
+  if (rower) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (rr0 + u * rstep < b.nm) Xs[(rr0 + u * rstep) * fs4 + rlr] = (MODE == MODE_DX) ? scale4(rx[u], rnn[u] * rnn[u]) : rx[u];
+    for (int i = rr0 + RU * rstep; i < b.nm; i += rstep) {
+      const int node = b.n0 + i;
+      const int row = feat_ids ? feat_ids[node] : node;
+      const float4 x = ld4(rbase + (size_t)row * ldf);
+      if (MODE == MODE_DX) { const float nn = nnorm[node]; Xs[i * fs4 + rlr] = scale4(x, nn * nn); }
+      else Xs[i * fs4 + rlr] = x;
     }
   }
-  TILE_STAMP(2);
-  tile_stage_edges<BT>(Ea, Eb, v, b, b.n0, 0);
-  TILE_STAMP(3);
-  __syncthreads();                                            // misc zeroed
+  for (int i = tid; i < fs4; i += nthr) Xs[b.nm * fs4 + i] = zero4();          // the null edge's row
+  if (w_ok0) Ws[tid] = w0;
+  for (int q = tid + nthr; q < w_total; q += nthr) {
+    bool ok;
+    const float4* p = w_src(q, ok);
+    if (ok) Ws[q] = *p;
+  }
+  {
+    const unsigned row_b = (unsigned)fs4 << 4, wrow16 = (unsigned)(S * fs4);
+#pragma unroll
+    for (int u = 0; u < EU; ++u)
+      if (tid + u * nthr < b.em) Ep[tid + u * nthr] = (unsigned)(ea0[u] - b.n0) * row_b | ((unsigned)eb0[u] * wrow16) << 17;
+    for (int i = tid + EU * nthr; i < b.em; i += nthr) Ep[i] = (unsigned)(v.a[b.e0 + i] - b.n0) * row_b | ((unsigned)v.b[b.e0 + i] * wrow16) << 17;
+    if (tid < 8) Ep[b.em + tid] = 0u;                         // the walk reads one group ahead
+  }
   TILE_STAMP(4);
-  tile_sort_chunks(cm, misc, v, b, b.n0);
+  __syncthreads();
   TILE_STAMP(5);
 
   const int lane = tid & 63;
@@ -254,39 +362,31 @@ __global__ void __launch_bounds__(TILE_THREADS) k_rgcn_agg_t(TempEdgeView v, Til
     float nn = 0.f;
     if (MODE == MODE_FWD && has) nn = nnorm[b.n0 + segl];      // in flight during the walk
     float4 acc = zero4();
-    const unsigned short* ea = Ea + beg;
-    const BT* eb = Eb + beg;
-    // Groups of four edges: the twelve row / weight reads of a group are issued back to back (independent LDS reads: one latency
-    // per group, not two dependent ones per edge -- the walk was bound by that chain: 49.7 k cycles per block against 20.9 k with
-    // the ids taken from registers, tools/tile_phases.py), and the ids of the NEXT group are requested before this group's
-    // products.  Edges are accumulated in order, one at a time: the same sums as before.
+    // Groups of four edges: the four packed id words of the NEXT group are requested (two ds_read2_b32: no clamp, the array is
+    // padded) before this group's twelve row / weight reads and products; an edge's two LDS addresses are a mask / shift of its
+    // word + the lane's base.  Edges are accumulated in order, one at a time: the same sums as the gather kernels.
     constexpr int U = 4;
-    unsigned sid[U], rid[U];
-    const int last = len > 0 ? len - 1 : 0;
+    const unsigned* ep = Ep + beg;
+    const unsigned null_word = (unsigned)b.nm * xrow;         // the zero row behind the member's rows, weights of relation 0: adds +0
+    unsigned idw[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int jj = min(u, last);
-      sid[u] = (VAR & 4) ? (unsigned)(jj & 7) : (unsigned)ea[jj];
-      rid[u] = (VAR & 4) ? (unsigned)(jj & 3) : (unsigned)eb[jj];
-    }
+    for (int u = 0; u < U; ++u) idw[u] = ep[u];
     for (int j = 0; j < len; j += U) {                        // (per-walker trip count: the chunks of a task are neighbours in the sort)
       float4 x[U], w[U][S];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        x[u] = (VAR & 1) ? make_float4((float)sid[u], 1.f, 2.f, 3.f) : *reinterpret_cast<const float4*>(xl + __umul24(sid[u], xrow));
-        const unsigned char* wr = wl + __umul24(rid[u], wrow_b);
+        // past the chunk's end: the null edge instead of a predicate on the products (one select here against four there)
+        const unsigned word = (j + u < len) ? idw[u] : null_word;
+        const unsigned xo = word & 0x1ffffu, wo = word >> 17;
+        x[u] = (VAR & 1) ? make_float4((float)xo, 1.f, 2.f, 3.f) : *reinterpret_cast<const float4*>(xl + xo);
 #pragma unroll
-        for (int q = 0; q < S; ++q) w[u][q] = (VAR & 2) ? make_float4((float)rid[u], 1.f, 0.5f, (float)q) : *reinterpret_cast<const float4*>(wr + q * xrow);
+        for (int q = 0; q < S; ++q)
+          w[u][q] = (VAR & 2) ? make_float4((float)wo, 1.f, 0.5f, (float)q) : *reinterpret_cast<const float4*>(wl + q * xrow + (wo << 4));
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int jj = min(j + U + u, last);
-        sid[u] = (VAR & 4) ? (unsigned)(jj & 7) : (unsigned)ea[jj];
-        rid[u] = (VAR & 4) ? (unsigned)(jj & 3) : (unsigned)eb[jj];
-      }
+      for (int u = 0; u < U; ++u) idw[u] = ep[j + U + u];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (j + u < len) block_mac<S, MODE>(acc, x[u], w[u], 1.f);
+      for (int u = 0; u < U; ++u) block_mac<S, MODE>(acc, x[u], w[u], 1.f);
     }
     if (has) {
       if (MODE == MODE_FWD) acc = scale4(acc, nn * nn);

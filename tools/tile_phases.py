@@ -31,7 +31,7 @@ for rep, var in enumerate([0, 0, 1, 2, 3, 4, 7, 8]):
     st = buf.cpu().numpy().reshape(-1, 8)
     st = st[st[:, 0] != 0]
     d = np.diff(st, axis=1).astype(np.float64)
-    names = ["rows", "weights", "edges", "barrier", "sort", "main", "tail-barrier"]
+    names = ["issue loads", "barrier", "sort", "commit", "barrier", "main", "tail-barrier"]
     print("VAR %d" % var, end=" ")
     print("rep %d: %d blocks, layer fwd %.1f us; launch span %.0f ticks" % (rep, st.shape[0], 1e3 * ev0.elapsed_time(ev1), st[:, 7].max() - st[:, 0].min()))
     for k, nm in enumerate(names):
