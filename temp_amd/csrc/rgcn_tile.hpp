@@ -20,6 +20,7 @@
 // staged rows (the same single fp32 product the per-edge form computes).
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 namespace temp {
 
@@ -371,22 +372,28 @@ __global__ void __launch_bounds__(TILE_THREADS) k_rgcn_agg_t(TempEdgeView v, Til
     unsigned idw[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) idw[u] = ep[u];
-    for (int j = 0; j < len; j += U) {                        // (per-walker trip count: the chunks of a task are neighbours in the sort)
+    auto group = [&](int j, auto full_c) {                      // four edges; FULL: all four inside the chunk for every walker
+      constexpr bool FULL = decltype(full_c)::value;
       float4 x[U], w[U][S];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // past the chunk's end: the null edge instead of a predicate on the products (one select here against four there)
-        const unsigned word = (j + u < len) ? idw[u] : null_word;
-        const unsigned xo = word & 0x1ffffu, wo = word >> 17;
+        const unsigned word = (FULL || j + u < len) ? idw[u] : null_word;
+        const unsigned xo = word & 0x1ffffu, wo = __builtin_amdgcn_ubfe(word, 17, 15) << 4;
         x[u] = (VAR & 1) ? make_float4((float)xo, 1.f, 2.f, 3.f) : *reinterpret_cast<const float4*>(xl + xo);
 #pragma unroll
         for (int q = 0; q < S; ++q)
-          w[u][q] = (VAR & 2) ? make_float4((float)wo, 1.f, 0.5f, (float)q) : *reinterpret_cast<const float4*>(wl + q * xrow + (wo << 4));
+          w[u][q] = (VAR & 2) ? make_float4((float)wo, 1.f, 0.5f, (float)q) : *reinterpret_cast<const float4*>(wl + wo + q * xrow);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) idw[u] = ep[j + U + u];
 #pragma unroll
       for (int u = 0; u < U; ++u) block_mac<S, MODE>(acc, x[u], w[u], 1.f);
+    };
+    for (int j = 0; j < len; j += U) {                        // (per-walker trip count: the chunks of a task are neighbours in the sort)
+      // every active walker of the wave has a whole group left: no selects (wave-uniform branch)
+      if (__builtin_amdgcn_ballot_w64(j + U > len) == 0) group(j, std::true_type());
+      else group(j, std::false_type());
     }
     if (has) {
       if (MODE == MODE_FWD) acc = scale4(acc, nn * nn);
