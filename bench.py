@@ -44,7 +44,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak, same guide
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guide
-# The large GEMMs (k_gemm_panel<*> = k_gemm_bx / k_gemm_bxp, k_gemm_tn = k_gemm_tn_bx) compute every fp32 product as SIX bf16 MFMA
+# The large GEMMs (k_gemm_panel<*> = k_gemm_bxr / k_gemm_bxp / k_gemm_bx, k_gemm_tn = k_gemm_tn_bx8 / k_gemm_tn_bx) compute every fp32 product as SIX bf16 MFMA
 # products of an exact three-way operand split (temp_amd/csrc/gemm_bx.hpp; fp32-equivalent accuracy): their roof is the bf16 pipe
 # divided by six.  temp_set_option(TEMP_OPT_MFMA_BF16X3, 0) (or TEMP_MFMA=f32 in the environment at load time) keeps them on the
 # fp32 MFMA kernels (round-1 arithmetic); MFMA_MODE is read from the library in main().
@@ -409,7 +409,7 @@ def main():
     ap.add_argument("--shard", choices=("both", "windows", "snapshots"), default="both",
                     help="N>1: 'windows' = each rank encodes its own windows (+ gradient all-reduce), the reference's DDP axis, HIP-graph "
                          "replay; 'snapshots' = the distinct snapshots of a global batch of bsz*N windows sharded across ranks with a "
-                         "direct all-gather of per-snapshot node states before the recurrent chain (BASELINE north_star, eager); "
+                         "direct all-gather of per-snapshot node states before the recurrent chain (BASELINE north_star; three HIP graphs around the two exchanges); "
                          "'both' (default) = the headline `value` is the windows mode and the snapshot-sharded measurement rides along "
                          "under `north_star_sharded`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
