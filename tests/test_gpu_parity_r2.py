@@ -836,6 +836,34 @@ def test_prefetch_workers_training_run_reproducible_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,trans_b", [
+    (82000, 200, 200, True),      # the self-loop product of the step: two column groups, a last partial round cut into single-tile units
+    (58000, 200, 600, True),      # the input gates: five column groups, partial rounds both as units and as whole panels
+    (16384, 72, 8, False),        # smallest K the weights-resident kernel takes (five slabs), one narrow tile
+    (20001, 208, 100, False),     # K = 13 full slabs, ragged M (last panel one row), four tiles = one group
+    (33000, 136, 328, True),      # K not a multiple of 16 (ragged last slab), 11 tiles = three groups
+    (17000, 64, 200, False),      # K below the weights-resident range: the slab-staged kernel (same contract)
+])
+def test_large_linear_weights_resident_vs_fp64(hip_backend, M, K, N, trans_b):
+    """temp_linear at >= 16 K rows (csrc/gemm_bxr.hpp: packed weights resident in LDS, panels streamed by single waves, the last
+    partial round of panels as single-tile units) against fp64: every output element within 2e-6 of sum |a||b| (the error of the
+    six-product split is one fp32 rounding per product), for shapes that exercise every branch of the work split."""
+    g = torch.Generator().manual_seed(M + K + N)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()     # rows of very different magnitude
+    b = (torch.randn(N, K, generator=g) * 0.3).cuda() if trans_b else (torch.randn(K, N, generator=g) * 0.3).cuda()
+    got = hip_backend.linear(a, b, trans_b)
+    again = hip_backend.linear(a, b, trans_b)
+    assert torch.equal(got, again)
+    bd = b.double().t() if trans_b else b.double()
+    rows = torch.cat([torch.arange(0, 4096), torch.arange(M - 4096, M), torch.randint(0, M, (8192,), generator=g)]).cuda()
+    want = a[rows].double() @ bd
+    scale = a[rows].double().abs() @ bd.abs()
+    err = ((got[rows].double() - want).abs() / scale.clamp_min(1e-30)).max()
+    assert torch.isfinite(got).all()
+    assert float(err) < 2e-6, float(err)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Ms,K,N", [
     ([184, 120, 0, 200, 184, 96], 10488, 200),     # ICEWS05-15-like d_q = d_scores . all_entities: split over K, two launches
     ([300], 7128, 200),                            # one problem, three row panels
