@@ -724,6 +724,47 @@ def test_sliced_edge_kernels_bit_identical_gpu(with_ids, hip_backend):
         assert torch.equal(a, c), (i, float((a - c).abs().max()))
 
 
+def test_tiled_edge_kernels_large_members_gpu(hip_backend):
+    """The LDS-tiled aggregation / d-dh on members LARGER than GDELT's (1 100 nodes, 15 000 edges, > 1 024 chunks per view: the
+    staging paths beyond a thread's first chunk record / first eight edges, narrower feature slices): bit-identical to the gather
+    kernels at D = 200, for the plain layer and the table layer."""
+    from temp_amd import _lib, snapshot as S, synthetic
+    lib = _lib.load()
+    R, D, B, n_ents = 20, 200, 100, 1400
+    snaps = synthetic.make_snapshots(n_ents, R, 15000, 1100, 3, seed=21)
+    g = S.batch([snaps[t] for t in range(3)])
+    dg = g.device_graph(DEV, 2 * R)
+    assert dg.c.members.n_members == 3 and max(dg.c.members.max_chunks[:2]) > 1024
+    rng = np.random.default_rng(22)
+    f = lambda *s_: torch.from_numpy(rng.standard_normal(s_).astype(np.float32)).to(DEV)
+    s2 = D // B
+    h, wt, lw, b, gy = f(g.n, D), f(2 * R, B * s2 * s2) * 0.5, f(D, D) * 0.2, f(D), f(g.n, D)
+    table = f(n_ents, D)
+    ids = torch.from_numpy(g.gids.astype(np.int32)).to(DEV)
+    from temp_amd import functional as TF
+    inv = TF.gather_inverse(g.gids, n_ents, DEV)
+
+    def run():
+        out = hip_backend.rgcn_fwd(dg, h, None, wt, lw, b, B, 1)
+        grads = hip_backend.rgcn_bwd(dg, h, out, gy, wt, lw, True, B, 1)
+        tout = hip_backend.rgcn_table_fwd(dg, table, ids, wt, lw, None, B, 0)
+        tgrads = hip_backend.rgcn_table_bwd(dg, table, ids, inv, tout, gy, wt, lw, False, B, 0)
+        torch.cuda.synchronize()
+        return [out] + [x for x in grads if x is not None] + [tout] + [x for x in tgrads if x is not None]
+
+    prev = lib.temp_set_option(_lib.OPT_RGCN_TILE, 1)
+    try:
+        n0 = lib.temp_tile_launches()
+        tiled = run()
+        assert lib.temp_tile_launches() - n0 == 4, "the LDS-tiled kernels were not launched"
+        lib.temp_set_option(_lib.OPT_RGCN_TILE, 0)
+        gathered = run()
+    finally:
+        lib.temp_set_option(_lib.OPT_RGCN_TILE, prev)
+    for i, (a, c) in enumerate(zip(tiled, gathered)):
+        assert torch.equal(a, c), (i, float((a - c).abs().max()))
+
+
 def test_rgcn_layer_large_power_law_graph_gpu(hip_backend):
     """One large graph with power-law degrees (2^19 nodes, 2^21 edges, dst / src ~ Zipf): its by-dst and by-src chunk lists are
     long enough (>= 2^18 chunks) for the XCD split by EDGES (csrc/common.hpp: xcd_chunk_range -- the hubs' full chunks sit at the
