@@ -296,6 +296,11 @@ int temp_decay_rows(int n, int d, const float* x, const float* dt, float lambda,
  * Fixed decay only (learnable decay uses temp_gru_fwd / temp_gru_bwd).
  * ---------------------------------------------------------------------------------------------- */
 int temp_gru_input_gates(int n, int d, int variant, const float* x, const float* w_ih, const float* b_ih, float* gi, void* stream);
+/* The same for `count` (row block, weight set) pairs of one width in as few launches as possible (four problems each): the input
+ * gates of both directions of a bidirectional window chain (models/BiRRGCN.py:206-221: forward_rnn and backward_rnn).  Results
+ * are bit-identical to `count` calls of temp_gru_input_gates. */
+int temp_gru_input_gates_multi(int count, const int* ns, int d, int variant, const float* const* xs, const float* const* w_ihs,
+                               const float* const* b_ihs, float* const* gis, void* stream);
 int temp_gru_cell_fwd(int n, int d, int variant, const float* gi, const float* prev, const int32_t* prev_idx /*nullable*/,
                       const float* dt, float lambda, const float* w_hh, const float* b_hh,
                       float* h_out, float* saved, size_t saved_plane, void* stream);

@@ -120,6 +120,7 @@ SYMBOLS = {
                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_decay_rows": (_I, [_I, _I, c_vp, c_vp, _F, c_vp, c_vp]),
     "temp_gru_input_gates": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_input_gates_multi": (_I, [_I, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_cell_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gru_cell_bwd": (_I, [_I, _I, _I, c_vp, _SZ, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_cell_fwd_multi": (_I, [_I, ctypes.POINTER(TempGruCellFwd), _I, _I, _F, _SZ, c_vp]),

@@ -196,6 +196,20 @@ class HipBackend:
         rc = self.lib.temp_gru_input_gates(x.shape[0], x.shape[1], variant, _ptr(x), _ptr(w_ih), _ptr(b_ih), _ptr(out), _stream())
         _lib.check(rc, "temp_gru_input_gates")
 
+    def gru_input_gates_multi(self, xs, w_ihs, b_ihs, variant, outs):
+        """gi_i = x_i . W_ih_i^T + b_ih_i for every (row block, weight set) pair in one launch per four problems
+        (include/temp_amd.h: temp_gru_input_gates_multi)."""
+        k = len(xs)
+        xs = [_f32(x, "x") for x in xs]
+        w_ihs, b_ihs = [_f32(w, "w_ih") for w in w_ihs], [_f32(b, "b_ih") for b in b_ihs]
+        d = xs[0].shape[1]
+        for x, w, o in zip(xs, w_ihs, outs):
+            assert x.shape[1] == d and o.is_contiguous() and o.shape == (x.shape[0], w.shape[0]) and w.shape == w_ihs[0].shape
+        arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+        ns = (ctypes.c_int * k)(*[x.shape[0] for x in xs])
+        rc = self.lib.temp_gru_input_gates_multi(k, ns, d, variant, arr(xs), arr(w_ihs), arr(b_ihs), arr(outs), _stream())
+        _lib.check(rc, "temp_gru_input_gates_multi")
+
     def gru_cell_fwd(self, gi, prev, prev_idx, dt, lam, w_hh, b_hh, variant, h_out, saved_all, row0):
         """h_out (n,d) and rows [row0, row0+n) of every plane of saved_all (5, N, d) are written."""
         n, d = h_out.shape

@@ -81,6 +81,18 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
   return launch_gemm_panel(kid, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi, st);
 }
 
+int gemm_bias_multi(int kid, int count, const int* Ms, int N, int K, const float* const* As, int lda, const float* const* Bs, int ldb,
+                    const float* const* biases, float* const* outs, int ldo, hipStream_t st) {
+  if (count <= 0 || count > PANEL_MAXP) return TEMP_E_BADARG;
+  PanelBatch<EpiAddBiasAct> batch;
+  for (int i = 0; i < PANEL_MAXP; ++i) {
+    const int k = i < count ? i : 0;
+    const EpiAddBiasAct epi{nullptr, 0, nullptr, biases[k], TEMP_ACT_NONE, outs[k], ldo};
+    batch.p[i] = PanelProblem<EpiAddBiasAct>{i < count ? Ms[k] : 0, As[k], nullptr, Bs[k], epi};
+  }
+  return launch_gemm_panel_multi(kid, batch, count, N, K, lda, ldb, 1, st);
+}
+
 __global__ void __launch_bounds__(256) k_mask_rows(size_t n4, int d4, const float4* __restrict__ src, float4* __restrict__ dst, DropSpec drop) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const unsigned row = (unsigned)(i / (unsigned)d4), c4 = (unsigned)(i - (size_t)row * d4);

@@ -263,9 +263,13 @@ class _GruChainFn(torch.autograd.Function):
         if CHAIN_KERNELS and hasattr(be, "gru_chain_fwd") and n_rnn <= _lib.CHAIN_MAX_RNN and be.gru_chain_supported(d):
             tabs = prog.chain_tables(dev, want)
         gi = torch.empty(N, G, dtype=torch.float32, device=dev)
-        for g in prog.groups:
-            w_ih, _, b_ih, _ = W[g["rnn"]]
-            be.gru_input_gates(x_all[g["x0"]:g["x1"]], w_ih, b_ih, variant, gi[g["h0"]:g["h1"]])
+        if len(prog.groups) > 1 and hasattr(be, "gru_input_gates_multi"):    # both directions' input gates in one launch
+            be.gru_input_gates_multi([x_all[g["x0"]:g["x1"]] for g in prog.groups], [W[g["rnn"]][0] for g in prog.groups],
+                                     [W[g["rnn"]][2] for g in prog.groups], variant, [gi[g["h0"]:g["h1"]] for g in prog.groups])
+        else:
+            for g in prog.groups:
+                w_ih, _, b_ih, _ = W[g["rnn"]]
+                be.gru_input_gates(x_all[g["x0"]:g["x1"]], w_ih, b_ih, variant, gi[g["h0"]:g["h1"]])
         H = torch.empty(N, d, dtype=torch.float32, device=dev)
         saved = torch.empty(5, N, d, dtype=torch.float32, device=dev)
         packs = None
