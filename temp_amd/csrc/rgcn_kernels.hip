@@ -353,10 +353,13 @@ __device__ __forceinline__ float4 fixup_walk(const float* __restrict__ p, int s,
   return acc;
 }
 
-template <int WAVES, int IPB, int LONG>
+constexpr int FIX_PART = 256, FIX_LIST = 2, FIX_LIST_CAP = 4096, FIX_SPLIT_MIN = 1 << 15;
+// SPLIT: an entry with more than `huge` partial rows is not summed here; its index is appended to the list in `ctl` and
+// k_fixup_split sums it with many blocks (the append order varies from run to run, the sums do not: see there).
+template <int WAVES, int IPB, int LONG, bool SPLIT = false>
 __global__ void __launch_bounds__(WAVES * 64) k_fixup(int n_fix, const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ fix_slot,
                                                       const int32_t* __restrict__ fix_cnt, const float* __restrict__ partial, int width,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, unsigned* __restrict__ ctl = nullptr, int huge = 0) {
   __shared__ long long long_item[IPB];
   __shared__ float4 share[WAVES][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -370,7 +373,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_fixup(int n_fix, const int32_t* 
       const int i = (int)(it / cblocks), cb = (int)(it - (long long)i * cblocks);
       const int f = (cb << 8) + (lane << 2);
       const int seg = fix_seg[i], s0 = fix_slot[i], cnt = fix_cnt[i];          // (one round trip for the three)
-      if (cnt > LONG) mine = it;                                // left to the whole block below
+      if (SPLIT && cnt > huge) {                                // left to k_fixup_split (once per entry: by its first column block)
+        if (cb == 0 && lane == 0) ctl[FIX_LIST + atomicAdd(ctl, 1u)] = (unsigned)i;
+      } else if (cnt > LONG) mine = it;                         // left to the whole block below
       else if (f < width) st4(out + (size_t)seg * width + f, fixup_walk(partial + (size_t)s0 * width + f, 0, cnt, width));
     }
     if (wave < IPB && lane == 0) long_item[wave] = mine;
@@ -394,6 +399,69 @@ __global__ void __launch_bounds__(WAVES * 64) k_fixup(int n_fix, const int32_t* 
       __syncthreads();
     }
     __syncthreads();                                            // long_item is rewritten by the next round
+  }
+}
+
+// Second level of the fix-up for entries with thousands of partial rows (a hub of an HBM-sized snapshot: 18 000; a relation of
+// a 20-relation graph of that size: 3 300 rows of the weight gradient) -- one block, however wide, walks such an entry for
+// hundreds of microseconds while the chip idles.  The listed entries are cut into parts of FIX_PART rows; (entry, part) pairs are
+// dealt to all blocks; a part's sum goes to its scratch row; the block that finishes an entry's LAST outstanding part (a ticket
+// per entry) adds the entry's part rows IN PART ORDER.  Which block that is, and the order of the list, vary from run to run; the
+// sum of a part and the order of the final addition do not, so the result is deterministic.
+// ctl words: [0] listed entries, [1] unused, [FIX_LIST + j] entry index, [FIX_LIST + cap + j * cblocks + cb] ticket of list position j,
+// column block cb.
+__host__ __device__ inline int fix_huge(int n_partial) { const int h = (n_partial + FIX_LIST_CAP - 2) / (FIX_LIST_CAP - 1); return h > 2048 ? h : 2048; }
+inline int fix_list_cap(int n_partial) { return n_partial / fix_huge(n_partial) + 1; }          // (every listed entry has > huge rows)
+inline size_t fix_ctl_bytes(int n_partial, size_t width) { return align_up((size_t)(FIX_LIST + (1 + (width + 255) / 256) * fix_list_cap(n_partial)) * sizeof(unsigned), 256); }
+inline size_t fix_scratch_rows(int n_partial) { return (size_t)n_partial / FIX_PART + fix_list_cap(n_partial); }
+// bytes of a view's partial region: the slots, then (large views only) control words + part rows of the split fix-up
+inline size_t partial_bytes(int n_partial, size_t width) {
+  size_t b = align_up((size_t)n_partial * width * sizeof(float), 256);
+  if (n_partial >= FIX_SPLIT_MIN) b += fix_ctl_bytes(n_partial, width) + align_up(fix_scratch_rows(n_partial) * width * sizeof(float), 256);
+  return b;
+}
+
+__global__ void __launch_bounds__(256) k_fixup_split(const int32_t* __restrict__ fix_seg, const int32_t* __restrict__ fix_slot,
+                                                     const int32_t* __restrict__ fix_cnt, const float* __restrict__ partial, int width,
+                                                     float* __restrict__ out, unsigned* __restrict__ ctl, int cap, float* __restrict__ scratch) {
+  __shared__ int pre[FIX_LIST_CAP + 1];
+  __shared__ float4 share[4][64];
+  __shared__ int last_flag;
+  const int n_h = (int)ctl[0];
+  if (n_h == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cblocks = (width + 255) >> 8;
+  // parts of every listed entry, then their exclusive prefix (one thread: at most a few thousand short additions)
+  for (int j = tid; j < n_h; j += blockDim.x) pre[j + 1] = (fix_cnt[ctl[FIX_LIST + j]] + FIX_PART - 1) / FIX_PART;
+  __syncthreads();
+  if (tid == 0) { pre[0] = 0; int run = 0; for (int j = 1; j <= n_h; ++j) { run += pre[j]; pre[j] = run; } }
+  __syncthreads();
+  const int total = pre[n_h] * cblocks;
+  unsigned* ticket = ctl + FIX_LIST + cap;
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {                      // block-uniform
+    const int pw = w / cblocks, cb = w - pw * cblocks;
+    int lo = 0, hi = n_h;                                                    // list position j with pre[j] <= pw < pre[j + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= pw) lo = mid; else hi = mid; }
+    const int j = lo, part = pw - pre[j], parts = pre[j + 1] - pre[j];
+    const int i = (int)ctl[FIX_LIST + j];
+    const int seg = fix_seg[i], slot0 = fix_slot[i], cnt = fix_cnt[i];
+    const int f = (cb << 8) + (lane << 2);
+    const int p0 = part * FIX_PART, p1 = min(cnt, p0 + FIX_PART);
+    const int per = (p1 - p0 + 3) >> 2;
+    const int s0 = min(p1, p0 + wave * per), s1 = min(p1, s0 + per);
+    share[wave][lane] = f < width ? fixup_walk(partial + (size_t)slot0 * width + f, s0, s1, width) : zero4();
+    __syncthreads();
+    if (wave == 0 && f < width)
+      st4(scratch + (size_t)(pre[j] + part) * width + f, add4(add4(share[0][lane], share[1][lane]), add4(share[2][lane], share[3][lane])));
+    __threadfence();                                                         // the part row is visible chip-wide before the ticket moves
+    __syncthreads();
+    if (tid == 0) last_flag = atomicAdd(&ticket[j * cblocks + cb], 1u) == (unsigned)(parts - 1);
+    __syncthreads();
+    if (last_flag) {                                                         // block-uniform: every part row of (entry, cb) is written
+      __threadfence();
+      if (wave == 0 && f < width) st4(out + (size_t)seg * width + f, fixup_walk(scratch + (size_t)pre[j] * width + f, 0, parts, width));
+    }
+    __syncthreads();
   }
 }
 
@@ -605,13 +673,31 @@ static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, c
 static void launch_fixup(const TempEdgeView& v, const float* partial, int width, float* out, hipStream_t st) {
   if (v.n_fix <= 0) return;
   long long items = (long long)v.n_fix * ((width + 255) / 256);
-  if (items <= 1024) {                                          // few entries: one 16-wave block each
-    TEMP_LAUNCH(K_FIXUP, (k_fixup<16, 1, 32>), dim3((int)items), dim3(16 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
-    return;
+  // large views: entries beyond `huge` rows are listed by the first pass and summed by k_fixup_split (partial_bytes() reserved
+  // the control words and the part rows behind the slots)
+  const bool split = v.n_partial >= FIX_SPLIT_MIN && option(TEMP_OPT_DEBUG) != 100;     // (100: single-level walk, for A/B tests)
+  unsigned* ctl = nullptr;
+  float* scratch = nullptr;
+  int huge = 0, cap = 0;
+  if (split) {
+    ctl = (unsigned*)((char*)partial + align_up((size_t)v.n_partial * width * sizeof(float), 256));
+    scratch = (float*)((char*)ctl + fix_ctl_bytes(v.n_partial, width));
+    huge = fix_huge(v.n_partial);
+    cap = fix_list_cap(v.n_partial);
+    (void)hipMemsetAsync(ctl, 0, fix_ctl_bytes(v.n_partial, width), st);
   }
-  const long long blocks = (items + 3) / 4;
-  int grid = (int)(blocks > 4096 ? 4096 : blocks);
-  TEMP_LAUNCH(K_FIXUP, (k_fixup<4, 4, 256>), dim3(grid), dim3(4 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out);
+  if (items <= 1024) {                                          // few entries: one 16-wave block each
+    if (split) TEMP_LAUNCH(K_FIXUP, (k_fixup<16, 1, 32, true>), dim3((int)items), dim3(16 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out, ctl, huge);
+    else TEMP_LAUNCH(K_FIXUP, (k_fixup<16, 1, 32>), dim3((int)items), dim3(16 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out, ctl, huge);
+  } else {
+    const long long blocks = (items + 3) / 4;
+    int grid = (int)(blocks > 4096 ? 4096 : blocks);
+    if (split) TEMP_LAUNCH(K_FIXUP, (k_fixup<4, 4, 256, true>), dim3(grid), dim3(4 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out, ctl, huge);
+    else TEMP_LAUNCH(K_FIXUP, (k_fixup<4, 4, 256>), dim3(grid), dim3(4 * 64), 0, st, v.n_fix, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out, ctl, huge);
+  }
+  if (split) {
+    TEMP_LAUNCH(K_FIXUP, k_fixup_split, dim3(1024), dim3(256), 0, st, v.fix_seg, v.fix_slot, v.fix_cnt, partial, width, out, ctl, cap, scratch);
+  }
 }
 
 // forward / dx aggregation into `out` rows of segments that have edges (others untouched)
@@ -754,8 +840,8 @@ static TableBwdWs carve_table_bwd(const TempGraph* g, int n_table, int d_in, int
   w.dz = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
   w.dzm = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
   w.d_h = (float*)take((size_t)g->n_nodes * d_in * sizeof(float));
-  w.part_dx = (float*)take((size_t)g->by_src.n_partial * d_in * sizeof(float));
-  w.part_dw = (float*)take((size_t)g->by_rel.n_partial * wrow * sizeof(float));
+  w.part_dx = (float*)take(partial_bytes(g->by_src.n_partial, d_in));
+  w.part_dw = (float*)take(partial_bytes(g->by_rel.n_partial, wrow));
   w.seg_dz = (float*)take((size_t)n_table * d_out * sizeof(float));
   w.tn_bytes = gemm_tn_workspace(n_table, d_in, d_out);
   w.tn = take(w.tn_bytes);
@@ -777,7 +863,7 @@ void temp_set_debug_buffer(void* device_ptr, size_t words) { g_debug_buf.store((
 
 size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out) {
   if (!g || n_table < 0) return 0;
-  return align_up((size_t)g->by_dst.n_partial * d_out * sizeof(float), 256) + align_up((size_t)n_table * d_out * sizeof(float), 256) + 256;
+  return partial_bytes(g->by_dst.n_partial, d_out) + align_up((size_t)n_table * d_out * sizeof(float), 256) + 256;
 }
 
 int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* ids, int n_table, int d_in, int d_out, int num_bases,
@@ -791,7 +877,7 @@ int temp_rgcn_table_fwd(const TempGraph* g, const float* table, const int32_t* i
   if (g->n_nodes == 0) return TEMP_OK;
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  float* t_loop = (float*)((char*)workspace + align_up((size_t)g->by_dst.n_partial * d_out * sizeof(float), 256));
+  float* t_loop = (float*)((char*)workspace + partial_bytes(g->by_dst.n_partial, d_out));
   int rc = gemm_add_bias_act(K_GEMM_ISO, n_table, d_out, d_in, table, d_in, nullptr, loop_w, d_out, 0, nullptr, 0, nullptr, nullptr, TEMP_ACT_NONE,
                              t_loop, d_out, st);
   if (rc) return rc;
@@ -876,7 +962,7 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
 
 size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out) {
   if (!g) return 0;
-  return align_up((size_t)g->by_dst.n_partial * d_out * sizeof(float), 256) + 256;
+  return partial_bytes(g->by_dst.n_partial, d_out) + 256;
 }
 
 int temp_rgcn_fwd(const TempGraph* g, const float* h, const int32_t* h_ids, int d_in, int d_out, int num_bases, int n_rel_rows,
@@ -915,8 +1001,8 @@ static BwdWs carve_bwd(const TempGraph* g, int d_in, int d_out, int num_bases, c
   const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
   w.dz = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
   w.dzm = (float*)take((size_t)g->n_nodes * d_out * sizeof(float));
-  w.part_dx = (float*)take((size_t)g->by_src.n_partial * d_in * sizeof(float));
-  w.part_dw = (float*)take((size_t)g->by_rel.n_partial * wrow * sizeof(float));
+  w.part_dx = (float*)take(partial_bytes(g->by_src.n_partial, d_in));
+  w.part_dw = (float*)take(partial_bytes(g->by_rel.n_partial, wrow));
   w.tn_bytes = gemm_tn_workspace(g->n_nodes, d_in, d_out);
   w.tn = take(w.tn_bytes);
   w.cs_bytes = colsum_workspace(g->n_nodes, d_out);

@@ -765,6 +765,52 @@ def test_tiled_edge_kernels_large_members_gpu(hip_backend):
         assert torch.equal(a, c), (i, float((a - c).abs().max()))
 
 
+@pytest.mark.gpu
+def test_split_fixup_large_hubs_gpu(hip_backend):
+    """Two-level fix-up (csrc/rgcn_kernels.hip: k_fixup_split) on a graph whose hubs and relations have thousands of partial rows
+    (2^15 nodes, 5.2 M Zipf edges, 4 relation rows, D = 200: the top destination carries ~7 500 partial rows, every relation
+    ~10 000 rows of the 400-wide weight gradient, i.e. two column blocks): entries beyond 2 048 rows are listed by the first pass and
+    summed by (entry, part) pairs over all blocks.  The list order and the finishing block vary from run to run, the result must not:
+    two runs are BIT-identical; against the single-level walk (TEMP_OPT_DEBUG = 100) the sums agree to fp32 reassociation."""
+    from temp_amd import _lib, synthetic
+    lib = _lib.load()
+    n, E, R, D, B = 1 << 15, 5 << 20, 2, 200, 100
+    g = synthetic.make_snapshots(n, R, E, n, 1, seed=21)[0]
+    dg = g.device_graph(DEV, 2 * R)
+    assert dg.views["by_dst"]["n_partial"] >= 1 << 15 and dg.views["by_src"]["n_partial"] >= 1 << 15 and dg.views["by_rel"]["n_partial"] >= 1 << 15
+    for view in ("by_dst", "by_src", "by_rel"):
+        assert int(dg.view_tensor(view, "fix_cnt").max()) > 4096, view
+    gen = torch.Generator(device="cpu").manual_seed(22)
+    s_ = D // B
+    wt = (torch.rand(2 * R, B * s_ * s_, generator=gen) - 0.5).to(DEV)
+    lw = ((torch.rand(D, D, generator=gen) - 0.5) * 0.2).to(DEV)
+    h = torch.randn(n, D, generator=gen).to(DEV)
+    gy = torch.randn(n, D, generator=gen).to(DEV)
+
+    def run():
+        out = hip_backend.rgcn_fwd(dg, h, None, wt, lw, None, B, 1)
+        grads = hip_backend.rgcn_bwd(dg, h, out, gy, wt, lw, False, B, 1)
+        torch.cuda.synchronize()
+        return [out] + [x for x in grads if x is not None]
+
+    prev = lib.temp_set_option(_lib.OPT_DEBUG, 0)
+    try:
+        a = run()
+        b = run()
+        lib.temp_set_option(_lib.OPT_DEBUG, 100)
+        c = run()
+    finally:
+        lib.temp_set_option(_lib.OPT_DEBUG, prev)
+    for i, (x, y, z) in enumerate(zip(a, b, c)):
+        assert torch.isfinite(x).all()
+        assert torch.equal(x, y), ("split fix-up not repeatable", i)
+        tol = 2e-5 * max(1.0, float(z.abs().max()))
+        assert float((x - z).abs().max()) <= tol, (i, float((x - z).abs().max()), tol)
+    # the weight gradient IS a fix-up output (the layer output adds the self-loop term on top: 1-ulp differences of a hub's small
+    # mean vanish there): different association => different bits, or the split pass did not run
+    assert not torch.equal(a[2], c[2]), "the split fix-up did not run (identical bits to the single-level walk)"
+
+
 def test_rgcn_layer_large_power_law_graph_gpu(hip_backend):
     """One large graph with power-law degrees (2^19 nodes, 2^21 edges, dst / src ~ Zipf): its by-dst and by-src chunk lists are
     long enough (>= 2^18 chunks) for the XCD split by EDGES (csrc/common.hpp: xcd_chunk_range -- the hubs' full chunks sit at the
