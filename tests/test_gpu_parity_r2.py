@@ -766,6 +766,41 @@ def test_tiled_edge_kernels_large_members_gpu(hip_backend):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("rows", [(61000, 60500), (20000, 300), (700, 90), (5, 33000, 17, 4100)])
+def test_gru_input_gates_multi_gpu(rows, variant, hip_backend):
+    """temp_gru_input_gates_multi (the input gates of both directions of the window chain -- up to four (row block, weight set)
+    pairs per launch) against one temp_gru_input_gates call per pair: the same kernels on the same rows => BIT-identical; and
+    against fp64 (x . W_ih^T + b_ih, models/GRU_cell.py / torch.nn.GRU's input half).  Row counts on both sides of the
+    16 384-row switch to the split-operand kernels, ragged last panels, tiny problems next to large ones."""
+    from temp_amd import _lib
+    D = 200
+    G = 3 * D if variant == _lib.GRU_TORCH else D
+    gen = torch.Generator(device="cpu").manual_seed(31 + len(rows) + variant)
+    xs = [torch.randn(n, D, generator=gen).to(DEV) for n in rows]
+    ws = [((torch.rand(G, D, generator=gen) - 0.5) * 0.3).to(DEV) for _ in rows]
+    bs = [((torch.rand(G, generator=gen) - 0.5) * 0.3).to(DEV) for _ in rows]
+    single = [torch.empty(n, G, device=DEV) for n in rows]
+    for x, w, b, o in zip(xs, ws, bs, single):
+        hip_backend.gru_input_gates(x, w, b, variant, o)
+    multi = [torch.full((n, G), float("nan"), device=DEV) for n in rows]
+    hip_backend.gru_input_gates_multi(xs, ws, bs, variant, multi)
+    torch.cuda.synchronize()
+    # the launch picks its kernels by the rows of ALL its problems (>= 16 384: the split-operand kernels), a single call by its
+    # own rows: bit-identical when both sides make the same choice
+    same_route = min(rows) >= 16384 or sum(rows) < 16384
+    for k, (x, w, b, a, c) in enumerate(zip(xs, ws, bs, single, multi)):
+        assert torch.isfinite(c).all()
+        if same_route:
+            assert torch.equal(a, c), (k, float((a - c).abs().max()))
+        want = x.double() @ w.double().t() + b.double()
+        scale = x.abs().double() @ w.abs().double().t() + b.abs().double()
+        for got in (a, c):
+            err = ((got.double() - want).abs() / scale.clamp_min(1e-30)).max()
+            assert float(err) < 2e-6, (k, float(err))
+
+
+@pytest.mark.gpu
 def test_split_fixup_large_hubs_gpu(hip_backend):
     """Two-level fix-up (csrc/rgcn_kernels.hip: k_fixup_split) on a graph whose hubs and relations have thousands of partial rows
     (2^15 nodes, 5.2 M Zipf edges, 4 relation rows, D = 200: the top destination carries ~7 500 partial rows, every relation
