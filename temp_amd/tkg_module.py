@@ -68,7 +68,12 @@ class TKG_Module(nn.Module):
         return torch.mean(1.0 / r), torch.mean((ranks <= 1).float()), torch.mean((ranks <= 3).float()), torch.mean((ranks <= 10).float())
 
     def configure_optimizers(self):
-        return torch.optim.Adam(self.parameters(), lr=self.args.lr, weight_decay=0.0001)
+        """models/TKG_Module.py:154-160: Adam(lr, weight_decay = 1e-4).  On the GPU torch's fused implementation of the same
+        update (one launch over all parameters instead of ten multi-tensor ones: 0.6 ms less host time and 0.3 ms less device
+        time per S-gdelt training step, tools/adam_probe.py)."""
+        params = list(self.parameters())
+        fused = bool(params) and all(p.is_cuda and p.dtype == torch.float32 for p in params)
+        return torch.optim.Adam(params, lr=self.args.lr, weight_decay=0.0001, fused=fused)
 
     # -- loss (models/TKG_Module.py:202-221) ----------------------------------------------------------
     def train_link_prediction(self, ent_embed, triplets, neg_samples, labels, all_embeds_g, corrupt_tail=True):

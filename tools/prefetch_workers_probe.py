@@ -33,7 +33,7 @@ def run(workers, warm):
     model.sample_rng = np.random.default_rng(2)
     model.seed_rng = np.random.default_rng(3)
     model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = model.configure_optimizers()
     losses, t0, edges = [], None, 0
     for i, wb in enumerate(BatchPrefetcher(model, batches, seq_len=w["L"], depth=2, workers=workers, batch_seeds=True)):
         if i == 5:

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 model = bench.build_model(w, dev)
 model.sample_rng = np.random.default_rng(2)
 model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = model.configure_optimizers()
 wbs = [model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], r), w["L"], True) for r in range(12)]
 def step(wb):
     loss = model.run_loss(wb); opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
