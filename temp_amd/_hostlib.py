@@ -79,6 +79,11 @@ def build_view(seg, a, b, n_seg, chunk):
     return res
 
 
+# data addresses of long-lived arrays (a snapshot's gids are looked up ~250 times per window batch; `.ctypes` builds a helper
+# object per access)
+_ADDR = {}
+
+
 def chain_plan(bsz, num_ents, positions, n_win, gid_arrays):
     """Row maps of one window chain (see temp_host_chain_plan).  gid_arrays[s][j] = int64 gids of window j at executed step s.
     -> (prev_idx int32 [total], next_idx int32 [total], dt [total], row_of [bsz, num_ents], last [bsz, num_ents])"""
@@ -87,7 +92,12 @@ def chain_plan(bsz, num_ents, positions, n_win, gid_arrays):
     lens = np.zeros(max(n_steps * bsz, 1), np.int64)
     for s, arrs in enumerate(gid_arrays):
         for j, g in enumerate(arrs):
-            ptrs[s * bsz + j] = g.ctypes.data
+            a = _ADDR.get(id(g))                     # (array, address): the entry keeps the array alive, so its id stays its own
+            if a is None or a[0] is not g:
+                if len(_ADDR) > 65536:
+                    _ADDR.clear()
+                a = _ADDR[id(g)] = (g, g.ctypes.data)
+            ptrs[s * bsz + j] = a[1]
             lens[s * bsz + j] = g.shape[0]
     total = int(lens.sum())
     prev_idx = np.empty(max(total, 1), np.int32)

@@ -41,21 +41,30 @@ def window_times(t_list, seq_len, times, ascending=False):
 
 class Step:
     """One executed window position: the graphs of the windows active there, batched."""
-    __slots__ = ("p", "windows", "graphs", "times", "sizes", "offsets", "n_rows", "ids", "prev_idx", "next_idx", "dt", "graph",
+    __slots__ = ("p", "windows", "graphs", "times", "sizes", "n_rows", "_ids", "prev_idx", "next_idx", "dt", "graph",
                  "row0", "dev")
 
     def __init__(self, p, windows, graphs, times):
         self.p, self.windows, self.graphs, self.times = p, windows, graphs, times
         self.sizes = [g.n for g in graphs]
-        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
-        self.n_rows = int(self.offsets[-1])
-        self.ids = np.concatenate([g.gids for g in graphs]) if graphs else np.zeros(0, np.int64)
+        self.n_rows = sum(self.sizes)
+        self._ids = None             # concatenated global ids: only the per-position path (tensors()) reads them
         self.prev_idx = None
         self.next_idx = None         # inverse of the next executed step's prev_idx (filled by ChainPlan for history steps)
         self.dt = None
         self.graph = None            # batched Snapshot (built lazily)
         self.row0 = 0                # first row inside an all-visits batch (fast path)
         self.dev = {}
+
+    @property
+    def ids(self):
+        if self._ids is None:
+            self._ids = np.concatenate([g.gids for g in self.graphs]) if self.graphs else np.zeros(0, np.int64)
+        return self._ids
+
+    @property
+    def offsets(self):
+        return np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
 
     def batched(self):
         if self.graph is None:

@@ -23,4 +23,4 @@ print("issue %.2f ms/step (host), drained after another %.2f ms" % (1e3 * (t1 - 
 pr = cProfile.Profile(); pr.enable()
 for wb in wbs[2:]: step(wb)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "tottime").print_stats(28)
+pstats.Stats(pr).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "tottime").print_stats(int(sys.argv[3]) if len(sys.argv) > 3 else 28)
