@@ -212,7 +212,9 @@ def to_device(host, device):
     """Host tensor / numpy array -> `device`.  On a GPU the bytes are staged in a per-thread pinned ring buffer and the
     copy is stream-ordered (non_blocking): no host-side wait per upload.  A pageable copy blocks the calling thread until
     the stream reaches it -- tens of microseconds each even when idle, and a window batch has dozens of small index vectors.
-    The ring is recycled after a device synchronize (once per 32 MB of uploads)."""
+    The ring has two halves: when one is full, an event is recorded on every stream that carried copies out of it, and the
+    half is written again only after those events (a full cycle later: they have long passed).  A device-wide synchronize at
+    that point made the host wait for the training step in flight once every few batches."""
     import numpy as _np
     import torch as _torch
     t = _torch.from_numpy(_np.ascontiguousarray(host)) if isinstance(host, _np.ndarray) else host
@@ -220,17 +222,33 @@ def to_device(host, device):
     nbytes = t.numel() * t.element_size()
     if device.type != "cuda" or nbytes == 0 or t.is_cuda or nbytes > _STAGE_BYTES // 4 or not t.is_contiguous():
         return t.to(device)
-    buf = getattr(_stage, "buf", None)
+    st = _stage
+    buf = getattr(st, "buf", None)
+    half_bytes = _STAGE_BYTES // 2
     if buf is None:
-        buf = _stage.buf = _torch.empty(_STAGE_BYTES, dtype=_torch.uint8, pin_memory=True)
-        _stage.np = buf.numpy()
-        _stage.off = 0
-    if _stage.off + nbytes > _STAGE_BYTES:
-        _torch.cuda.synchronize(device)              # every copy staged in the ring has landed, whatever stream carried it
-        _stage.off = 0
-    off = _stage.off
-    _stage.off += (nbytes + 255) & ~255
-    _stage.np[off:off + nbytes] = t.numpy().reshape(-1).view(_np.uint8)      # plain single-threaded memcpy
+        buf = st.buf = _torch.empty(_STAGE_BYTES, dtype=_torch.uint8, pin_memory=True)
+        st.np = buf.numpy()
+        st.off, st.half = 0, 0
+        st.streams = {}                      # streams that carried copies out of the current half
+        st.events = [[], []]                 # per half: events behind its last copies
+    if st.off + nbytes > (st.half + 1) * half_bytes:
+        evs = []
+        for s in st.streams.values():
+            ev = _torch.cuda.Event()
+            ev.record(s)
+            evs.append(ev)
+        st.events[st.half] = evs
+        st.streams = {}
+        st.half ^= 1
+        st.off = st.half * half_bytes
+        for ev in st.events[st.half]:
+            ev.synchronize()
+        st.events[st.half] = []
+    off = st.off
+    st.off += (nbytes + 255) & ~255
+    st.np[off:off + nbytes] = t.numpy().reshape(-1).view(_np.uint8)      # plain single-threaded memcpy
     out = _torch.empty(t.shape, dtype=t.dtype, device=device)
     out.copy_(buf[off:off + nbytes].view(t.dtype).view(t.shape), non_blocking=True)
+    cur = _torch.cuda.current_stream(device)
+    st.streams[cur.cuda_stream] = cur
     return out

@@ -159,7 +159,12 @@ class Snapshot:
                 dg = self._dev.get(key)
                 if dg is None:
                     dg = _DeviceGraph(self, device, n_rel_rows)
-                    _lib.publish(device)
+                    # a resident snapshot is shared by every batch (and worker stream) that visits it: visible only once its uploads
+                    # have landed.  The union of ONE batch (BatchedSnapshot, built per prepare) is read by that batch alone, on
+                    # the stream that built it or behind the batch's `ready` event -- draining the stream here made every inline
+                    # prepare wait for the previous training step's kernels (the host then never ran ahead of the device)
+                    if not isinstance(self, BatchedSnapshot):
+                        _lib.publish(device)
                     self._dev[key] = dg
         return dg
 
