@@ -27,7 +27,7 @@ namespace temp {
 
 struct ChainRnn { const float4* wf; const float4* wb; const float* b_hh; };
 struct ChainArgs {
-  int D, n_panels, max_steps;
+  int D, n_panels, max_steps, dbg;
   const int32_t* panel; const int32_t* rows; const int32_t* sinfo;
   const float* dt;
   float lambda;
@@ -603,6 +603,17 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
   }
 }
 
+}  // namespace temp
+#include "gru_chain2.hpp"
+namespace temp {
+
+// The pipelined kernels (gru_chain2.hpp) serve every width whose LDS layout fits with the longest panel the tables allow, so the
+// choice -- and with it the packed order of W_hh -- depends on d alone.
+static bool chain2_ok(int d) {
+  return option(TEMP_OPT_CHAIN_PIPELINE) != 0 && d % 8 == 0 && d <= 32 * CH2_NCX && chain2_lds_fwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT &&
+         chain2_lds_bwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && ceil_div(chain2_geom(d).NT, 4) <= 6 && ceil_div(chain2_geom(d).NTb, 4) <= 2;
+}
+
 static int chain_check(const TempGruChain* c) {
   if (!c || c->d <= 0 || c->n_panels < 0 || c->n_steps < 0 || c->n_rnn <= 0 || c->n_rnn > TEMP_CHAIN_MAX_RNN) return TEMP_E_BADARG;
   if (c->variant != TEMP_GRU_TORCH && c->variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
@@ -620,9 +631,10 @@ static ChainArgs chain_args(const TempGruChain* c) {
   ChainArgs a = {};
   const ChainGeom g = chain_geom(c->d);
   a.D = c->d; a.n_panels = c->n_panels; a.max_steps = c->max_steps; a.panel = c->panel; a.rows = c->rows; a.sinfo = c->sinfo; a.dt = c->dt;
-  a.lambda = c->lambda; a.plane = c->saved_plane;
+  a.lambda = c->lambda; a.plane = c->saved_plane; a.dbg = option(TEMP_OPT_DEBUG) >> 8;      // development ablations of the pipelined kernels (tools/chain_probe.py); 0 in every product run
   for (int i = 0; i < c->n_rnn; ++i) {
     a.rnn[i].wf = (const float4*)c->packed[i];
+    // (the pipelined kernels' forward planes are the same k_bx_pack<1> layout: (NQ >> 1) == chain2_geom(d).NS)
     a.rnn[i].wb = (const float4*)c->packed[i] + (chain_bx(c->d) ? (size_t)(g.NQ >> 1) * g.NT * 192 : (size_t)g.NT * g.NQ * 64);
     a.rnn[i].b_hh = c->b_hh[i];
   }
@@ -643,6 +655,14 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
   static bool attr = false;
   static bool attr_bx = false;
   const size_t lds = chain_lds_fwd(a.D, a.max_steps);
+  if (chain_bx(a.D) && chain2_ok(a.D)) {
+    static bool attr2 = false;
+    auto kernel = k_gru_chain_fwd2<VARIANT, TPW>;
+    int rc = chain_lds_attr(kernel, 0, &attr2);
+    if (rc) return rc;
+    TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), chain2_lds_fwd(a.D, a.max_steps), st, a, gi, h, saved);
+    return launch_status();
+  }
   if (chain_bx(a.D)) {
     auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4, 1>;
     int rc = chain_lds_attr(kernel, lds, &attr_bx);
@@ -662,6 +682,14 @@ static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float
   static bool attr = false;
   static bool attr_bx = false;
   const size_t lds = chain_lds_bwd(a.D, a.max_steps);
+  if (chain_bx(a.D) && chain2_ok(a.D)) {
+    static bool attr2 = false;
+    auto kernel = k_gru_chain_bwd2<VARIANT, TPWB>;
+    int rc = chain_lds_attr(kernel, 0, &attr2);
+    if (rc) return rc;
+    TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), chain2_lds_bwd(a.D, a.max_steps), st, a, ups, saved, dgi, dgh);
+    return launch_status();
+  }
   if (chain_bx(a.D)) {
     auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 1>;
     int rc = chain_lds_attr(kernel, lds, &attr_bx);
@@ -682,6 +710,12 @@ using namespace temp;
 
 extern "C" {
 
+int temp_gru_chain_timeouts(void) {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_chain2_timeouts), sizeof(int)) != hipSuccess) return -1;
+  return v;
+}
+
 int temp_gru_chain_supported(int d) {
   if (d <= 0 || d % 4) return 0;
   return chain_lds_fwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && chain_lds_bwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && chain_geom(d).NT <= 24 && chain_geom(d).NTb <= 8;
@@ -692,14 +726,25 @@ size_t temp_gru_chain_pack_floats(int d) {
   const ChainGeom g = chain_geom(d);
   const size_t f32 = ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64 * 4;
   // three bf16 planes in fragment order: (slabs of 16 k) x tiles x 192 sixteen-byte items, forward then backward
-  const size_t bx = ((size_t)(g.NQ >> 1) * g.NT + (size_t)(g.NQb >> 1) * g.NTb) * 192 * 4;
-  return f32 > bx ? f32 : bx;                          // either arithmetic (TEMP_MFMA) fits the caller's buffer
+  size_t bx = ((size_t)(g.NQ >> 1) * g.NT + (size_t)(g.NQb >> 1) * g.NTb) * 192 * 4;
+  if (d % 8 == 0 && d <= 32 * CH2_NCX) {               // pipelined kernels: backward planes in chunk-major k' order
+    const Chain2Geom g2 = chain2_geom(d);
+    const size_t b2 = ((size_t)g2.NS * g2.NT + (size_t)g2.NSb * g2.NTb) * 192 * 4;
+    bx = b2 > bx ? b2 : bx;
+  }
+  return f32 > bx ? f32 : bx;                          // either arithmetic (TEMP_MFMA) and either kernel set fits the caller's buffer
 }
 
 int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream) {
   if (d <= 0 || !w_hh || !packed) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
   const ChainGeom g = chain_geom(d);
+  if (chain_bx(d) && chain2_ok(d)) {                   // both operand orders of the pipelined kernels in one launch
+    const Chain2Geom g2 = chain2_geom(d);
+    TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_chain2_pack, dim3(ceil_div((long long)g2.NS * g2.NT + (long long)g2.NSb * g2.NTb, 4)), dim3(256), 0,
+                (hipStream_t)stream, d, w_hh, reinterpret_cast<bx_u32x4*>(packed));
+    return launch_status();
+  }
   if (chain_bx(d)) {
     // forward: gate column x k = W_hh as stored ([3d][d], k contiguous); backward: k = gate column, state column = W_hh as [K][N]
     const int nsf = g.NQ >> 1, nsb = g.NQb >> 1;

@@ -290,7 +290,6 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* 
 
 }  // namespace temp
 #include "rgcn_tile.hpp"
-#include "rgcn_slice.hpp"
 namespace temp {
 
 // Generic (any si, so) scalar-lane variant; slow, for shapes outside the fast path.
@@ -595,7 +594,6 @@ static bool view_ok(const TempEdgeView& v) {
 static bool rgcn_tile_on() { return option(TEMP_OPT_RGCN_TILE) != 0; }
 static std::atomic<long long*> g_debug_buf{nullptr};         // development only (temp_set_debug_buffer)
 static std::atomic<size_t> g_debug_words{0};
-static std::atomic<long long> g_slice_launches{0};          // diagnostic (temp_slice_launches): launches of the feature-sliced kernels (rgcn_slice.hpp)
 static std::atomic<long long> g_tile_launches{0};           // diagnostic (temp_tile_launches): edge-kernel launches that took the LDS-tiled path
 
 // dynamic LDS beyond 64 KB must be granted per kernel function
@@ -636,18 +634,6 @@ static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, c
     const bool ok = n_rel_rows <= 256 ? launch_agg_tile<S, MODE, unsigned char>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st)
                                       : launch_agg_tile<S, MODE, unsigned short>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st);
     if (ok) return;
-  }
-  SliceArgs sa;
-  if (wbytes > 65536 && lpr == 64 && option(TEMP_OPT_RGCN_SLICE) && v.n_edges >= (1 << 21) && slice_plan(D, S, n_rel_rows, &sa)) {
-    // large graph, table beyond LDS: one feature slice of the WHOLE table per persistent block (rgcn_slice.hpp)
-    static const bool granted = tile_grant_lds(k_rgcn_agg_f<S, MODE>, SLICE_LDS_MAX);
-    if (granted) {
-      TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_f<S, MODE>), dim3(256), dim3(SLICE_THREADS), sa.lds_bytes, st, v, sa, feat, ldf, ids,
-                  W, n_rel_rows, nnorm, D, out, partial);
-      g_slice_launches.fetch_add(1, std::memory_order_relaxed);
-      return;
-    }
-    (void)hipGetLastError();
   }
   if (wbytes <= 65536 && v.n_chunks >= 4096) {
     // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
@@ -858,7 +844,6 @@ using namespace temp;
 extern "C" {
 
 long long temp_tile_launches(void) { return g_tile_launches.load(std::memory_order_relaxed); }
-long long temp_slice_launches(void) { return g_slice_launches.load(std::memory_order_relaxed); }
 void temp_set_debug_buffer(void* device_ptr, size_t words) { g_debug_buf.store((long long*)device_ptr); g_debug_words.store(device_ptr ? words : 0); }
 
 size_t temp_rgcn_table_fwd_workspace(const TempGraph* g, int n_table, int d_out) {

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     lib = _lib.load()
-    assert lib.temp_abi_version() == 1
+    assert lib.temp_abi_version() == 2
     assert lib.temp_error_string(0) == b"ok"
     assert b"workspace" in lib.temp_error_string(3)
     assert lib.temp_trace_kernel_name(0).startswith(b"k_rgcn_agg")
