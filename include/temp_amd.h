@@ -72,10 +72,7 @@ enum {
   TEMP_OPT_GEMM_RESIDENT = 8, /* 1: large fp32 products with K <= 208 keep the packed weights of four column tiles resident in LDS and
                                stream row panels through them (gemm_bxr.hpp); 0: one row tile per block, weights staged per slab
                                                                                                [TEMP_GEMM_RESIDENT=0 -> 0] default 1 */
-  TEMP_OPT_CHAIN_PIPELINE = 9, /* 1: window-chain kernels that overlap product and gate phases inside a position (gru_chain2.hpp,
-                               d % 8 == 0, d <= 200); 0: the two-phase kernels of round 3 (same results to fp32 accuracy)
-                                                                                               [TEMP_CHAIN_PIPELINE=0 -> 0] default 1 */
-  TEMP_OPT_COUNT = 10
+  TEMP_OPT_COUNT = 9
 };
 int temp_set_option(int key, int value);
 int temp_get_option(int key);
@@ -84,9 +81,6 @@ int temp_get_option(int key);
 long long temp_scratch_refused(void);
 /* Diagnostic: edge-kernel launches (aggregation, d/dh, d/dweight) that took the LDS-tiled path (TempMembers present, member fits). */
 long long temp_tile_launches(void);
-/* Diagnostic: hand-over waits inside the pipelined window-chain kernels that gave up (bounded spins).  0 unless the kernels are
- * broken; reads a device symbol (synchronises): tests only. */
-int temp_gru_chain_timeouts(void);
 /* Development only: a device buffer of `words` int64 into which instrumented kernels write cycle-counter stamps (NULL: off).
  * Not used by the product path or the tests. */
 void temp_set_debug_buffer(void* device_ptr, size_t words);

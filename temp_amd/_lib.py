@@ -39,7 +39,7 @@ class TempGraph(ctypes.Structure):
 
 
 ABI_VERSION = 2            # include/temp_amd.h: TEMP_ABI_VERSION (2: TempGraph.members, chain pipeline option)
-OPT_MFMA_BF16X3, OPT_TN_SPLIT, OPT_RGCN_SCALAR, OPT_GEMM_STREAM, OPT_GRU_STREAM, OPT_RGCN_TILE, OPT_DEBUG, OPT_OVERLAP, OPT_GEMM_RESIDENT, OPT_CHAIN_PIPELINE = range(10)
+OPT_MFMA_BF16X3, OPT_TN_SPLIT, OPT_RGCN_SCALAR, OPT_GEMM_STREAM, OPT_GRU_STREAM, OPT_RGCN_TILE, OPT_DEBUG, OPT_OVERLAP, OPT_GEMM_RESIDENT = range(9)
 
 
 class TempGruCellFwd(ctypes.Structure):
@@ -101,7 +101,6 @@ SYMBOLS = {
     "temp_get_option": (_I, [_I]),
     "temp_scratch_refused": (ctypes.c_longlong, []),
     "temp_tile_launches": (ctypes.c_longlong, []),
-    "temp_gru_chain_timeouts": (_I, []),
     "temp_set_debug_buffer": (None, [c_vp, _SZ]),
     "temp_rgcn_fwd_workspace": (_SZ, [_G, _I]),
     "temp_rgcn_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp, c_vp]),

@@ -1016,7 +1016,7 @@ bx_u32x4* bx_scratch(hipStream_t st, size_t bytes) {
 static std::atomic<int> g_options[TEMP_OPT_COUNT];
 static const bool g_options_init = [] {
   g_options[TEMP_OPT_MFMA_BF16X3] = 1; g_options[TEMP_OPT_TN_SPLIT] = 1; g_options[TEMP_OPT_RGCN_SCALAR] = 1;
-  g_options[TEMP_OPT_GEMM_STREAM] = 0; g_options[TEMP_OPT_GRU_STREAM] = 0; g_options[TEMP_OPT_RGCN_TILE] = 1; g_options[TEMP_OPT_DEBUG] = 0; g_options[TEMP_OPT_OVERLAP] = 1; g_options[TEMP_OPT_GEMM_RESIDENT] = 1; g_options[TEMP_OPT_CHAIN_PIPELINE] = 1;
+  g_options[TEMP_OPT_GEMM_STREAM] = 0; g_options[TEMP_OPT_GRU_STREAM] = 0; g_options[TEMP_OPT_RGCN_TILE] = 1; g_options[TEMP_OPT_DEBUG] = 0; g_options[TEMP_OPT_OVERLAP] = 1; g_options[TEMP_OPT_GEMM_RESIDENT] = 1;
   const char* e;
   if ((e = getenv("TEMP_MFMA")) && e[0] == 'f') g_options[TEMP_OPT_MFMA_BF16X3] = 0;
   if ((e = getenv("TEMP_TN_SPLIT")) && e[0] == '0') g_options[TEMP_OPT_TN_SPLIT] = 0;
@@ -1026,7 +1026,6 @@ static const bool g_options_init = [] {
   if ((e = getenv("TEMP_RGCN_TILE")) && e[0] == '0') g_options[TEMP_OPT_RGCN_TILE] = 0;
   if ((e = getenv("TEMP_OVERLAP")) && e[0] == '0') g_options[TEMP_OPT_OVERLAP] = 0;
   if ((e = getenv("TEMP_GEMM_RESIDENT")) && e[0] == '0') g_options[TEMP_OPT_GEMM_RESIDENT] = 0;
-  if ((e = getenv("TEMP_CHAIN_PIPELINE")) && e[0] == '0') g_options[TEMP_OPT_CHAIN_PIPELINE] = 0;
   if ((e = getenv("TEMP_DEBUG"))) g_options[TEMP_OPT_DEBUG] = atoi(e);
   return true;
 }();

@@ -137,7 +137,11 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
 #pragma unroll
           for (int j = 0; j < TPW; ++j) w[j] = wp[((size_t)(sl * NT + tidx[j]) * 3 + pl) * 64 + lane];
         };
-        wload(wh, 0, 0); wload(wm, 0, 1); wload(wl, 0, 2);
+        // Every CU of an XCD walks the same 720 KB of planes; started at the same slab they ask the same L2 lines at the same
+        // time.  The walk of a block starts at its own slab (k order of a sum is free; fixed per block, so results stay
+        // bit-repeatable).
+        const int rot = (a.dbg & 64) ? 0 : (int)(blockIdx.x >> 3) % NS;
+        wload(wh, rot, 0); wload(wm, rot, 1); wload(wl, rot, 2);
         for (int s = 0; s < ns; ++s) {
           const int cur = s & 1;
           const int flags = flagb[s];
@@ -147,15 +151,15 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
             const float* hrow = hb + (size_t)cur * CH_SLOTS * ldh + li * ldh + 8 * hh;     // k = 16 slab + 8 hh .. +7 of track li
             bx_u32x4 AH, AM, AL, NH, NM, NL;
             {
-              const float4 r0 = scale4(ld4(hrow), decm), r1 = scale4(ld4(hrow + 4), decm);
+              const float4 r0 = scale4(ld4(hrow + 16 * rot), decm), r1 = scale4(ld4(hrow + 16 * rot + 4), decm);
               unsigned h_, m_, l_;
               bx_split_pair(r0.x, r0.y, h_, m_, l_); AH[0] = h_; AM[0] = m_; AL[0] = l_;
               bx_split_pair(r0.z, r0.w, h_, m_, l_); AH[1] = h_; AM[1] = m_; AL[1] = l_;
               bx_split_pair(r1.x, r1.y, h_, m_, l_); AH[2] = h_; AM[2] = m_; AL[2] = l_;
               bx_split_pair(r1.z, r1.w, h_, m_, l_); AH[3] = h_; AM[3] = m_; AL[3] = l_;
             }
-            for (int sl = 0; sl < NS; ++sl) {
-              const int sn = sl + 1 < NS ? sl + 1 : 0;            // past the end: slab 0 of the NEXT position (weights only)
+            for (int j = 0, sl = rot; j < NS; ++j) {
+              const int sn = sl + 1 < NS ? sl + 1 : 0;            // (after the last slab of the walk: the first one of the NEXT position, weights only)
               const float4 n0 = scale4(ld4(hrow + 16 * sn), decm), n1 = scale4(ld4(hrow + 16 * sn + 4), decm);
               const bx_bf16x8 ah = bx_frag(AH), am = bx_frag(AM), al = bx_frag(AL);
               unsigned h_, m_, l_;
@@ -189,6 +193,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
               __builtin_amdgcn_sched_barrier(0);
               wload(wh, sn, 0);
               AH = NH; AM = NM; AL = NL;
+              sl = sn;
             }
           // lane (li, hh) owns track li and, per register quad qq, gate columns tile*32 + 8qq + 4hh .. +3
 #pragma unroll
@@ -394,8 +399,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
 #pragma unroll
           for (int j = 0; j < TPWB; ++j) w[j] = wp[((size_t)(sl * NTb + tidx[j]) * 3 + pl) * 64 + lane];
         };
-        wload(wh0, 0, 0); wload(wm0, 0, 1); wload(wl0, 0, 2);
-        wload(wh1, 1, 0); wload(wm1, 1, 1); wload(wl1, 1, 2);
+        const int rot = (a.dbg & 64) ? 0 : 2 * ((int)(blockIdx.x >> 3) % (NS >> 1));     // per-block start of the slab walk (see the forward kernel)
+        wload(wh0, rot, 0); wload(wm0, rot, 1); wload(wl0, rot, 2);
+        wload(wh1, rot + 1, 0); wload(wm1, rot + 1, 1); wload(wl1, rot + 1, 2);
         for (int s = ns - 1; s >= 0; --s) {
           const int flags = flagb[s];
           __syncthreads();      // A: dgh / dh*z / decay of position s are in LDS
@@ -403,7 +409,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
             const float* arow = ab + (size_t)li * ldA + 8 * hh;                 // k = 16 slab + 8 hh .. +7 of track li
             bx_u32x4 AH, AM, AL, NH, NM, NL;
             {
-              const float4 r0 = ld4(arow), r1 = ld4(arow + 4);
+              const float4 r0 = ld4(arow + 16 * rot), r1 = ld4(arow + 16 * rot + 4);
               unsigned h_, m_, l_;
               bx_split_pair(r0.x, r0.y, h_, m_, l_); AH[0] = h_; AM[0] = m_; AL[0] = l_;
               bx_split_pair(r0.z, r0.w, h_, m_, l_); AH[1] = h_; AM[1] = m_; AL[1] = l_;
@@ -447,10 +453,11 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
               wload(wh, sl2, 0);
               AH = NH; AM = NM; AL = NL;
             };
-            for (int sl = 0; sl < NS; sl += 2) {
-              const int a2 = sl + 2 < NS ? sl + 2 : 0, b2 = sl + 3 < NS ? sl + 3 : 1;      // wrap: the NEXT position
+            for (int j = 0, sl = rot; j < NS; j += 2) {
+              const int a2 = sl + 2 < NS ? sl + 2 : 0, b2 = a2 + 1;          // (after the walk's last pair: the first pair of the NEXT position)
               slab(wh0, wm0, wl0, sl, a2);
               slab(wh1, wm1, wl1, sl + 1, b2);
+              sl = a2;
             }
           const float dec = decb[s * CH_SLOTS + li];
 #pragma unroll
@@ -603,17 +610,6 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
   }
 }
 
-}  // namespace temp
-#include "gru_chain2.hpp"
-namespace temp {
-
-// The pipelined kernels (gru_chain2.hpp) serve every width whose LDS layout fits with the longest panel the tables allow, so the
-// choice -- and with it the packed order of W_hh -- depends on d alone.
-static bool chain2_ok(int d) {
-  return option(TEMP_OPT_CHAIN_PIPELINE) != 0 && d % 8 == 0 && d <= 32 * CH2_NCX && chain2_lds_fwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT &&
-         chain2_lds_bwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && ceil_div(chain2_geom(d).NT, 4) <= 6 && ceil_div(chain2_geom(d).NTb, 4) <= 2;
-}
-
 static int chain_check(const TempGruChain* c) {
   if (!c || c->d <= 0 || c->n_panels < 0 || c->n_steps < 0 || c->n_rnn <= 0 || c->n_rnn > TEMP_CHAIN_MAX_RNN) return TEMP_E_BADARG;
   if (c->variant != TEMP_GRU_TORCH && c->variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
@@ -631,10 +627,9 @@ static ChainArgs chain_args(const TempGruChain* c) {
   ChainArgs a = {};
   const ChainGeom g = chain_geom(c->d);
   a.D = c->d; a.n_panels = c->n_panels; a.max_steps = c->max_steps; a.panel = c->panel; a.rows = c->rows; a.sinfo = c->sinfo; a.dt = c->dt;
-  a.lambda = c->lambda; a.plane = c->saved_plane; a.dbg = option(TEMP_OPT_DEBUG) >> 8;      // development ablations of the pipelined kernels (tools/chain_probe.py); 0 in every product run
+  a.lambda = c->lambda; a.plane = c->saved_plane; a.dbg = option(TEMP_OPT_DEBUG) >> 8;      // development A/B switches (bit 6: no per-block rotation of the slab walk); 0 in every product run
   for (int i = 0; i < c->n_rnn; ++i) {
     a.rnn[i].wf = (const float4*)c->packed[i];
-    // (the pipelined kernels' forward planes are the same k_bx_pack<1> layout: (NQ >> 1) == chain2_geom(d).NS)
     a.rnn[i].wb = (const float4*)c->packed[i] + (chain_bx(c->d) ? (size_t)(g.NQ >> 1) * g.NT * 192 : (size_t)g.NT * g.NQ * 64);
     a.rnn[i].b_hh = c->b_hh[i];
   }
@@ -655,14 +650,6 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
   static bool attr = false;
   static bool attr_bx = false;
   const size_t lds = chain_lds_fwd(a.D, a.max_steps);
-  if (chain_bx(a.D) && chain2_ok(a.D)) {
-    static bool attr2 = false;
-    auto kernel = k_gru_chain_fwd2<VARIANT, TPW>;
-    int rc = chain_lds_attr(kernel, 0, &attr2);
-    if (rc) return rc;
-    TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), chain2_lds_fwd(a.D, a.max_steps), st, a, gi, h, saved);
-    return launch_status();
-  }
   if (chain_bx(a.D)) {
     auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4, 1>;
     int rc = chain_lds_attr(kernel, lds, &attr_bx);
@@ -682,14 +669,6 @@ static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float
   static bool attr = false;
   static bool attr_bx = false;
   const size_t lds = chain_lds_bwd(a.D, a.max_steps);
-  if (chain_bx(a.D) && chain2_ok(a.D)) {
-    static bool attr2 = false;
-    auto kernel = k_gru_chain_bwd2<VARIANT, TPWB>;
-    int rc = chain_lds_attr(kernel, 0, &attr2);
-    if (rc) return rc;
-    TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), chain2_lds_bwd(a.D, a.max_steps), st, a, ups, saved, dgi, dgh);
-    return launch_status();
-  }
   if (chain_bx(a.D)) {
     auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 1>;
     int rc = chain_lds_attr(kernel, lds, &attr_bx);
@@ -710,12 +689,6 @@ using namespace temp;
 
 extern "C" {
 
-int temp_gru_chain_timeouts(void) {
-  int v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_chain2_timeouts), sizeof(int)) != hipSuccess) return -1;
-  return v;
-}
-
 int temp_gru_chain_supported(int d) {
   if (d <= 0 || d % 4) return 0;
   return chain_lds_fwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && chain_lds_bwd(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && chain_geom(d).NT <= 24 && chain_geom(d).NTb <= 8;
@@ -726,25 +699,14 @@ size_t temp_gru_chain_pack_floats(int d) {
   const ChainGeom g = chain_geom(d);
   const size_t f32 = ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64 * 4;
   // three bf16 planes in fragment order: (slabs of 16 k) x tiles x 192 sixteen-byte items, forward then backward
-  size_t bx = ((size_t)(g.NQ >> 1) * g.NT + (size_t)(g.NQb >> 1) * g.NTb) * 192 * 4;
-  if (d % 8 == 0 && d <= 32 * CH2_NCX) {               // pipelined kernels: backward planes in chunk-major k' order
-    const Chain2Geom g2 = chain2_geom(d);
-    const size_t b2 = ((size_t)g2.NS * g2.NT + (size_t)g2.NSb * g2.NTb) * 192 * 4;
-    bx = b2 > bx ? b2 : bx;
-  }
-  return f32 > bx ? f32 : bx;                          // either arithmetic (TEMP_MFMA) and either kernel set fits the caller's buffer
+  const size_t bx = ((size_t)(g.NQ >> 1) * g.NT + (size_t)(g.NQb >> 1) * g.NTb) * 192 * 4;
+  return f32 > bx ? f32 : bx;                          // either arithmetic (TEMP_MFMA) fits the caller's buffer
 }
 
 int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream) {
   if (d <= 0 || !w_hh || !packed) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
   const ChainGeom g = chain_geom(d);
-  if (chain_bx(d) && chain2_ok(d)) {                   // both operand orders of the pipelined kernels in one launch
-    const Chain2Geom g2 = chain2_geom(d);
-    TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_chain2_pack, dim3(ceil_div((long long)g2.NS * g2.NT + (long long)g2.NSb * g2.NTb, 4)), dim3(256), 0,
-                (hipStream_t)stream, d, w_hh, reinterpret_cast<bx_u32x4*>(packed));
-    return launch_status();
-  }
   if (chain_bx(d)) {
     // forward: gate column x k = W_hh as stored ([3d][d], k contiguous); backward: k = gate column, state column = W_hh as [K][N]
     const int nsf = g.NQ >> 1, nsb = g.NQb >> 1;
