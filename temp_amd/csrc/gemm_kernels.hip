@@ -976,7 +976,7 @@ long long bx_scratch_refused() { return g_bx_refused.load(std::memory_order_rela
 
 bx_u32x4* bx_scratch(hipStream_t st, size_t bytes) {
   constexpr int MAX_DEV = 16;
-  struct DevSlots { unsigned char* base = nullptr; hipStream_t owner[BX_SLOTS] = {}; unsigned long long used[BX_SLOTS] = {}; int n = 0; };
+  struct DevSlots { unsigned char* base = nullptr; hipStream_t owner[BX_SLOTS] = {}; unsigned long long used[BX_SLOTS] = {}; bool pinned[BX_SLOTS] = {}; int n = 0; };
   static std::mutex mu;
   static DevSlots devs[MAX_DEV];
   static unsigned long long tick = 0;
@@ -997,9 +997,13 @@ bx_u32x4* bx_scratch(hipStream_t st, size_t bytes) {
     if (d.n < BX_SLOTS) {
       slot = d.n++;
     } else {
-      int lru = 0;
-      for (int i = 1; i < BX_SLOTS; ++i)
-        if (d.used[i] < d.used[lru]) lru = i;
+      // Recycle the least recently used slot whose owner has drained -- but never one that was handed out under a HIP-graph
+      // capture: the captured graph has the slot's address baked in and may be replayed at any time, on any stream, while its
+      // capture stream sits idle.  (hipStreamQuery on a capturing stream would also invalidate that capture.)
+      int lru = -1;
+      for (int i = 0; i < BX_SLOTS; ++i)
+        if (!d.pinned[i] && (lru < 0 || d.used[i] < d.used[lru])) lru = i;
+      if (lru < 0) { g_bx_refused.fetch_add(1, std::memory_order_relaxed); return nullptr; }
       // the old owner may be a destroyed stream (query fails: its work has drained) or an idle one (hipSuccess)
       const hipError_t q = hipStreamQuery(d.owner[lru]);
       if (q == hipErrorNotReady) { g_bx_refused.fetch_add(1, std::memory_order_relaxed); return nullptr; }
@@ -1007,6 +1011,11 @@ bx_u32x4* bx_scratch(hipStream_t st, size_t bytes) {
       slot = lru;
     }
     d.owner[slot] = st;
+  }
+  if (!d.pinned[slot]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) d.pinned[slot] = true;
+    else (void)hipGetLastError();
   }
   d.used[slot] = ++tick;
   return reinterpret_cast<bx_u32x4*>(d.base + (size_t)slot * BX_SLOT_BYTES);

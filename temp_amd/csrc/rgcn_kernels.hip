@@ -784,34 +784,81 @@ __global__ void __launch_bounds__(256) k_loop_gather_epi(int n, int d4, const in
 // fills the CUs' spare wave slots under those kernels instead of queueing behind them.  Same kernels, same results.  The events
 // are ordinary stream dependencies: inside a HIP-graph capture they become a parallel branch of the graph.  The stream and the two
 // events are created once per device, on first use (never inside a capture: every captured step is preceded by warm-up runs);
-// nothing is synchronised.  One backward at a time per device (autograd's device thread).  temp_set_option(TEMP_OPT_OVERLAP, 0): off.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; };
-static SideStream* side_stream() {
-  static std::mutex mu;
-  static SideStream pool[16];
+// nothing is synchronised.  temp_set_option(TEMP_OPT_OVERLAP, 0): off.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  hipStream_t owner = nullptr;                   // caller stream this entry last served (an entry is re-used by the same stream)
+  int dev = -1;
+  bool ok = false, tried = false;
+  std::atomic_flag busy = ATOMIC_FLAG_INIT;      // held for the duration of ONE backward call
+};
+// A small pool per process: an entry (side stream + its two events) serves one backward call at a time.  Two host threads that
+// run backward passes concurrently (different caller streams, or even the same one) never share events; when every entry is
+// busy the call simply runs the weight gradient in-stream.
+#define SIDE_POOL 16
+static SideStream* side_acquire(hipStream_t st) {
+  static SideStream pool[SIDE_POOL];
+  static std::mutex mu;                          // guards creation only
   if (!option(TEMP_OPT_OVERLAP)) return nullptr;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  SideStream& p = pool[dev];
-  if (!p.tried) {
-    p.tried = true;
-    p.ok = hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&p.join, hipEventDisableTiming) == hipSuccess;
-    if (!p.ok) (void)hipGetLastError();
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+  // first choice: the entry this (device, stream) used before -- a captured graph then sees the same side stream on every capture
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < SIDE_POOL; ++i) {
+      SideStream& p = pool[i];
+      const bool mine = p.tried && p.ok && p.dev == dev && p.owner == st;
+      const bool fresh = !p.tried;
+      const bool any = p.tried && p.ok && p.dev == dev;
+      if (!(pass == 0 ? mine : (fresh || any))) continue;
+      if (p.busy.test_and_set(std::memory_order_acquire)) continue;
+      if (!p.tried) {
+        std::lock_guard<std::mutex> lock(mu);
+        p.tried = true;
+        p.dev = dev;
+        p.ok = hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&p.join, hipEventDisableTiming) == hipSuccess;
+        if (!p.ok) (void)hipGetLastError();
+      }
+      if (p.ok && p.dev == dev) { p.owner = st; return &p; }
+      p.busy.clear(std::memory_order_release);
+    }
   }
-  return p.ok ? &p : nullptr;
+  return nullptr;
 }
-// run_dw on the side stream, forked from `st`; the caller joins with side_join() after its own launches
-static int dw_forked(SideStream* ss, hipStream_t st, const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz,
+// One backward call's use of a side stream: whatever path leaves the call, a branch that was forked is joined back into the
+// caller's stream (an un-joined branch would invalidate a HIP-graph capture and leave d_weight in flight behind the return)
+// and the entry is released.
+struct SideScope {
+  SideStream* ss;
+  hipStream_t st;
+  bool forked = false;
+  SideScope(hipStream_t stream) : ss(side_acquire(stream)), st(stream) {}
+  SideScope(const SideScope&) = delete;
+  SideScope& operator=(const SideScope&) = delete;
+  int join() {                                   // explicit join on the regular path: its status is the call's status
+    if (!ss || !forked) return TEMP_OK;
+    forked = false;
+    return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? TEMP_OK : TEMP_E_LAUNCH;
+  }
+  ~SideScope() {
+    if (!ss) return;
+    if (forked) (void)hipStreamWaitEvent(st, ss->join, 0);
+    ss->busy.clear(std::memory_order_release);
+  }
+};
+// run_dw on the side stream, forked from the caller's stream; joined by SideScope
+static int dw_forked(SideScope& sc, const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz,
                      const float* nnorm, int d_in, int d_out, int num_bases, int n_rel_rows, float* dW, float* partial) {
-  if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return TEMP_E_LAUNCH;
+  SideStream* ss = sc.ss;
+  if (hipEventRecord(ss->fork, sc.st) != hipSuccess) return TEMP_E_LAUNCH;
+  if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return TEMP_E_LAUNCH;
+  sc.forked = true;                              // from here on the side stream depends on the caller's: it must be joined
   const int rc = run_dw(v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, ss->s);
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return TEMP_E_LAUNCH;
   return rc;
 }
-static int side_join(SideStream* ss, hipStream_t st) { return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? TEMP_OK : TEMP_E_LAUNCH; }
 
 struct TableBwdWs {
   float *dz, *dzm, *d_h, *part_dx, *part_dw, *seg_dz;
@@ -909,9 +956,10 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
     if (rc) return rc;
     dz = w.dz;
   }
-  SideStream* ss = side_stream();                // relation-weight gradient beside the rest of the backward (see SideStream)
+  SideScope side(st);                            // relation-weight gradient beside the rest of the backward (see SideStream)
+  SideStream* ss = side.ss;
   if (ss) {
-    rc = dw_forked(ss, st, g->by_rel, members_of(g), table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw);
+    rc = dw_forked(side, g->by_rel, members_of(g), table, ids, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw);
     if (rc) return rc;
   }
   // aggregation part of d_h per node row, then everything that is linear in the gathered rows is summed per table row FIRST:
@@ -942,7 +990,7 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
     rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
     if (rc) return rc;
   }
-  return ss ? side_join(ss, st) : TEMP_OK;
+  return side.join();
 }
 
 size_t temp_rgcn_fwd_workspace(const TempGraph* g, int d_out) {
@@ -1029,9 +1077,10 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
     if (rc) return rc;
     dz = w.dz;
   }
-  SideStream* ss = side_stream();                // relation-weight gradient beside the rest of the backward (see SideStream)
+  SideScope side(st);                            // relation-weight gradient beside the rest of the backward (see SideStream)
+  SideStream* ss = side.ss;
   if (ss) {
-    rc = dw_forked(ss, st, g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw);
+    rc = dw_forked(side, g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw);
     if (rc) return rc;
   }
   // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
@@ -1057,7 +1106,7 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
     rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
     if (rc) return rc;
   }
-  return ss ? side_join(ss, st) : TEMP_OK;
+  return side.join();
 }
 
 }  // extern "C"

@@ -90,6 +90,9 @@ __device__ __forceinline__ bool tile_block(const TileArgs& t, int D4, TileBlock&
   b.n0 = t.node_off[b.m]; b.nm = t.node_off[b.m + 1] - b.n0;
   b.e0 = t.edge_off[b.m]; b.em = t.edge_off[b.m + 1] - b.e0;
   b.c0 = t.chunk_off[b.m]; b.nc = t.chunk_off[b.m + 1] - b.c0;
+  // an EMPTY member (a timestamp with no train facts: no nodes, or nodes without edges) has nothing to aggregate -- rows without
+  // in-edges are never read from the aggregation output -- and its clamped staging indices would point before / past the views
+  if (b.nm <= 0 || b.nc <= 0 || b.em <= 0) return false;
   b.f4_0 = (b.slice * D4) / t.n_slices;                      // even slices: widths differ by at most one float4
   b.nf4 = ((b.slice + 1) * D4) / t.n_slices - b.f4_0;
   return true;

@@ -63,7 +63,11 @@ class BatchPrefetcher:
                 return (i, e, None)
             i = self._n_taken
             self._n_taken += 1
-            seed = int(self.model.sample_rng.integers(1 << 62)) if self.batch_seeds else None
+            try:
+                seed = int(self.model.sample_rng.integers(1 << 62)) if self.batch_seeds else None
+            except BaseException as e:                          # index i is already consumed: the error is THIS batch's result
+                self._stop = True
+                return (i, e, None)
             return (i, t_list, seed)
 
     def _work(self):
@@ -157,6 +161,9 @@ class BatchPrefetcher:
                 while i not in self._done and self._live > 0:
                     self._cv.wait()
                 if i not in self._done:                         # every worker has ended and batch i was never taken: the end
+                    pending = [v for _, v in sorted(self._done.items()) if v[0] == "err"]
+                    if pending:                                 # (an error posted past the end must not be swallowed as "no more data")
+                        raise pending[0][1]
                     break
                 kind, item = self._done.pop(i)
             self._slots.release()
