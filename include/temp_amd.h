@@ -363,6 +363,9 @@ typedef struct TempGruChain {
 int temp_gru_chain_supported(int d);
 size_t temp_gru_chain_pack_floats(int d);                                   /* floats of one packed W_hh */
 int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream);
+/* count <= TEMP_CHAIN_MAX_RNN matrices in one launch (w_hh / packed: HOST arrays of device pointers; each packed[i] holds
+ * temp_gru_chain_pack_floats(d) floats) */
+int temp_gru_chain_pack_multi(int count, int d, const float* const* w_hh, float* const* packed, void* stream);
 int temp_gru_chain_fwd(const TempGruChain* c, const float* gi, float* h_out, float* saved, void* stream);
 int temp_gru_chain_bwd(const TempGruChain* c, const float* saved, int n_up, const float* const* up /* HOST array of device pointers */,
                        float* dgi, float* dgh, void* stream);
@@ -386,6 +389,12 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
 size_t temp_segment_sum_rows_workspace(int n_seg, int n_rows, int d);
 int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the adjoint of a ReLU folded in: out[s][c] = relu_of[s][c] > 0 ? sum : 0, where relu_of [n_seg, d] is the
+ * POST-activation table the gather read (y = relu(z) => y > 0 <=> z > 0).  For a gather that is the only consumer of an
+ * RGCN layer's ReLU output (models/BiRRGCN.py:202-203 -> the GRU input rows), the layer's backward then takes the gradient as
+ * already masked (act = TEMP_ACT_NONE) and the (n, d) mask pass of its own disappears. */
+int temp_segment_sum_rows_relu(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const float* relu_of,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plain fp32 MFMA GEMMs (the extra (n,D)@(D,D) terms of the linear-recurrence layers,

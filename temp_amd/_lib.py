@@ -130,12 +130,14 @@ SYMBOLS = {
     "temp_gru_chain_supported": (_I, [_I]),
     "temp_gru_chain_pack_floats": (_SZ, [_I]),
     "temp_gru_chain_pack": (_I, [_I, c_vp, c_vp, c_vp]),
+    "temp_gru_chain_pack_multi": (_I, [_I, _I, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp]),
     "temp_gru_chain_fwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_chain_bwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_segment_sum_rows_workspace": (_SZ, [_I, _I, _I]),
     "temp_segment_sum_rows": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_segment_sum_rows_relu": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_linear": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, _I, c_vp, _I, c_vp]),
     "temp_linear_t": (_I, [_I, _I, _I, c_vp, _I, c_vp, _I, _I, c_vp, _I, c_vp]),
     "temp_linear_multi": (_I, [_I, ctypes.POINTER(TempLinearProblem), _I, _I, _I, _I, _I, _I, c_vp]),

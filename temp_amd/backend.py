@@ -298,6 +298,17 @@ class HipBackend:
         _lib.check(self.lib.temp_gru_chain_pack(d, _ptr(w_hh), _ptr(out), _stream()), "temp_gru_chain_pack")
         return out
 
+    def gru_chain_pack_multi(self, w_hhs):
+        """gru_chain_pack of several GRUs' W_hh (same width) in ONE launch -> list of packed tensors (views of one buffer)."""
+        w_hhs = [_f32(w, "w_hh") for w in w_hhs]
+        d = w_hhs[0].shape[1]
+        n = self.lib.temp_gru_chain_pack_floats(d)
+        buf = torch.empty(len(w_hhs), n, dtype=torch.float32, device=w_hhs[0].device)
+        src = (ctypes.c_void_p * len(w_hhs))(*[w.data_ptr() for w in w_hhs])
+        dst = (ctypes.c_void_p * len(w_hhs))(*[buf[i].data_ptr() for i in range(len(w_hhs))])
+        _lib.check(self.lib.temp_gru_chain_pack_multi(len(w_hhs), d, src, dst, _stream()), "temp_gru_chain_pack_multi")
+        return [buf[i] for i in range(len(w_hhs))]
+
     def _chain_desc(self, tabs, d, variant, lam, plane, packs, b_hhs):
         c = _lib.TempGruChain()
         c.d, c.variant, c.n_panels, c.n_steps, c.max_steps = d, variant, tabs["n_panels"], tabs["n_steps"], tabs["max_steps"]
@@ -555,16 +566,24 @@ class HipBackend:
         _lib.check(rc, "temp_scatter_add_rows")
         return table
 
-    def segment_sum_rows(self, src, seg_ptr, order, n_seg):
-        """out[s] = sum of src[order[seg_ptr[s]:seg_ptr[s+1]]] (deterministic adjoint of a static gather)."""
+    def segment_sum_rows(self, src, seg_ptr, order, n_seg, relu_of=None):
+        """out[s] = sum of src[order[seg_ptr[s]:seg_ptr[s+1]]] (deterministic adjoint of a static gather); with relu_of
+        [n_seg, d] (the post-ReLU table the gather read): zero where relu_of <= 0 (that ReLU's adjoint, same kernel)."""
         src, seg_ptr, order = _f32(src, "src"), _i32(seg_ptr, "seg_ptr"), _i32(order, "order")
         if src.shape[0] == 0 or order.shape[0] == 0:
             return torch.zeros(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
         out = torch.empty(n_seg, src.shape[1], dtype=torch.float32, device=src.device)
         nb = self.lib.temp_segment_sum_rows_workspace(n_seg, order.shape[0], src.shape[1])
         ws = self._ws(nb, src.device) if nb else None
-        rc = self.lib.temp_segment_sum_rows(n_seg, order.shape[0], src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(out),
-                                            _ptr(ws), nb, _stream())
+        if relu_of is not None:
+            relu_of = _f32(relu_of, "relu_of")
+            if tuple(relu_of.shape) != (n_seg, src.shape[1]):
+                raise _lib.TempAmdError("relu_of must be [n_seg, d]")
+            rc = self.lib.temp_segment_sum_rows_relu(n_seg, order.shape[0], src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(relu_of),
+                                                     _ptr(out), _ptr(ws), nb, _stream())
+        else:
+            rc = self.lib.temp_segment_sum_rows(n_seg, order.shape[0], src.shape[1], _ptr(seg_ptr), _ptr(order), _ptr(src), _ptr(out),
+                                                _ptr(ws), nb, _stream())
         _lib.check(rc, "temp_segment_sum_rows")
         return out
 

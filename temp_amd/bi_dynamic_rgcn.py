@@ -91,18 +91,23 @@ class BiDynamicRGCN(DynamicRGCN):
         plan_f, plan_b = wb.plan
         tf, tb = wb.target, wb.target_b
         y1 = enc.layer_1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
-        y2 = enc.layer_2.conv(wb.g_all, y1)                   # ReLU fused (models/BiRRGCN.py:202-203)
         l2 = enc.layer_2
         lam, dec = l2.inv_temperature, l2.decay_spec()
         if wb.program is not None:
             prog = wb.program
             want = self._chain_want(wb)
-            wb.last_x = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv)          # GRU input rows in chain order
+            # y2 = relu(.) (models/BiRRGCN.py:202-203) is read by ONE consumer here, the gather into chain order: the ReLU's
+            # adjoint rides in that gather's backward (one pass less over the (n, d) gradient)
+            fold = l2.relu_fused() and wb.chain_inv is not None
+            y2 = l2.conv(wb.g_all, y1, grad_premasked=fold)
+            fold = fold and TF.relu_gather_supported(y2, wb.chain_inv)
+            wb.last_x = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv, relu_table=fold)          # GRU input rows in chain order
             got = dict(zip(want, gru_chain(wb.last_x, prog, [l2.forward_rnn, l2.backward_rnn], lam,
                                            isinstance(l2.forward_rnn, GRUCell), want=want)))
             out = got[wb.out_inst[0]] + got[wb.out_inst[1]]
             Hf, Hb = got.get(wb.hist_inst[0]), got.get(wb.hist_inst[1])
             return out, ((Hf, Hf), (Hb, Hb))
+        y2 = l2.conv(wb.g_all, y1)                            # ReLU fused (models/BiRRGCN.py:202-203)
         if wb.visit_rows is not None:                         # distinct-snapshot rows -> visit rows
             y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))
         wb.last_x = y2

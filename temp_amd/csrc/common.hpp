@@ -36,6 +36,10 @@ __device__ __forceinline__ float4 shfl4(float4 v, int src) {
 __device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
   return make_float4(__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m), __shfl_xor(v.w, m));
 }
+// y = relu(z) was the forward: pass the gradient where y > 0 (the ReLU adjoint folded into the producer of the gradient)
+__device__ __forceinline__ float4 relu_gate4(float4 y, float4 g) {
+  return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // Persistent, XCD-aware work partition: block b is observed to run on XCD b % 8 (each XCD has its
@@ -164,7 +168,8 @@ int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int 
             float* out, int ldo, void* ws, size_t ws_bytes, hipStream_t st, float* bias_out = nullptr);
 
 // out = sum over n_slices of part[s] (each `elems` floats, elems % 4 == 0), in slice order
-void reduce_slices(int n_slices, size_t elems, int width, const float* part, float* out, int ldo, hipStream_t st);
+void reduce_slices(int n_slices, size_t elems, int width, const float* part, float* out, int ldo, hipStream_t st, size_t elems2 = 0,
+                   const float* part2 = nullptr, float* out2 = nullptr);    // (elems2 > 0: a second, flat array in the same launch)
 
 // out[n_cols] = sum over rows of X[rows, n_cols]
 size_t colsum_workspace(int rows, int cols);
@@ -172,7 +177,10 @@ int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, si
 
 // out[s] = sum_{j in [seg_ptr[s], seg_ptr[s+1])} src[order[j]]  (rows with row_mask[row] <= 0 skipped; row_mask nullable)
 int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
-                     hipStream_t st, long long n_rows_hint, void* ws = nullptr, size_t ws_bytes = 0);
+                     hipStream_t st, long long n_rows_hint, void* ws = nullptr, size_t ws_bytes = 0, const float* relu_src = nullptr);
+// two sources (a masked by mask_a, b unmasked) over the same segmentation; one launch for hot tables, else two single-source calls
+int segment_sum_rows2(int n_seg, const int32_t* seg_ptr, const int32_t* order, int d_a, const float* src_a, const int32_t* mask_a, float* out_a,
+                      int d_b, const float* src_b, float* out_b, hipStream_t st, long long n_rows_hint);
 size_t segment_sum_rows_workspace(int n_seg, long long n_rows, int d);   // n_rows_hint = length of `order` (picks the long-segment kernel)
 
 // dz = (y > 0) ? dy : 0

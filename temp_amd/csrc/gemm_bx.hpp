@@ -323,6 +323,47 @@ __global__ void __launch_bounds__(256) k_bx_pack(int K, int N, int n_tiles, int 
   d[0] = H; d[64] = Mi; d[128] = L;
 }
 
+// Several packs in ONE launch (the weights of both directions' input-gate products, both GRUs' W_hh in both operand orders: a
+// step packs ten matrices, each launch a few microseconds of latency on an idle chip).
+#define BX_PACK_JOBS 8
+struct BxPackJob { const float* B; bx_u32x4* out; int K, N, n_tiles, n_slabs, ldb, trans, unit0; };
+struct BxPackJobs { BxPackJob j[BX_PACK_JOBS]; int count, total_units; };
+static __global__ void __launch_bounds__(256) k_bx_pack_multi(BxPackJobs jobs) {
+  const int lane = threadIdx.x & 63, hh = lane >> 5, li = lane & 31;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= jobs.total_units) return;
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < BX_PACK_JOBS; ++i)
+    if (i < jobs.count && unit >= jobs.j[i].unit0) ji = i;
+  const BxPackJob& jb = jobs.j[ji];
+  const int st = unit - jb.unit0;
+  const int s = st / jb.n_tiles, t = st - s * jb.n_tiles;
+  const int k = 16 * s + 8 * hh, n = 32 * t + li;
+  float4 v0 = zero4(), v1 = zero4();
+  if (n < jb.N && k < jb.K) {                                // K % 8 == 0: the octet is entirely in or out
+    if (jb.trans) {
+      const float* p = jb.B + (size_t)n * jb.ldb + k;
+      v0 = ld4(p); v1 = ld4(p + 4);
+    } else {
+      const float* p = jb.B + (size_t)k * jb.ldb + n;
+      const size_t l = (size_t)jb.ldb;
+      v0 = make_float4(p[0], p[l], p[2 * l], p[3 * l]);
+      v1 = make_float4(p[4 * l], p[5 * l], p[6 * l], p[7 * l]);
+    }
+  }
+  bx_u32x4 H, Mi, L;
+  bx_split8(v0, v1, H, Mi, L);
+  bx_u32x4* d = jb.out + (size_t)st * 192 + lane;
+  d[0] = H; d[64] = Mi; d[128] = L;
+}
+inline void bx_pack_jobs_add(BxPackJobs& jobs, const float* B, bx_u32x4* out, int K, int N, int ldb, int trans) {
+  BxPackJob& j = jobs.j[jobs.count++];
+  j.B = B; j.out = out; j.K = K; j.N = N; j.n_tiles = ceil_div(N, 32); j.n_slabs = ceil_div(K, 16); j.ldb = ldb; j.trans = trans;
+  j.unit0 = jobs.total_units;
+  jobs.total_units += j.n_tiles * j.n_slabs;
+}
+
 typedef float bx_f2 __attribute__((ext_vector_type(2)));
 // one element pair of an A fragment: 9 VALU instructions (2 and, packed subtract, 2 and, packed subtract, 3 byte permutes)
 __device__ __forceinline__ void bx_split_pair(float x0, float x1, unsigned& H, unsigned& M, unsigned& L) {
@@ -588,16 +629,19 @@ static inline bool bx_pack_batch(const PanelBatch<Epi>& batch, int count, const 
   if (!slot) return false;
   const int n_slabs = ceil_div(g.K, 16);
   int done = 0;
+  BxPackJobs jobs = {};
   for (int i = 0; i < PANEL_MAXP; ++i) pk->b[i] = slot;
   for (int i = 0; i < count; ++i) {
     bx_u32x4* dst = slot + (size_t)which[i] * (pbytes / 16);
     pk->b[i] = dst;
     if (which[i] < done) continue;
     ++done;
+    if (n_distinct > 1 && n_distinct <= BX_PACK_JOBS) { bx_pack_jobs_add(jobs, batch.p[i].B, dst, g.K, g.N, g.ldb, g.trans_b); continue; }
     const dim3 pgrid(ceil_div((long long)n_slabs * g.n_tiles, 4));
     if (g.trans_b) TEMP_LAUNCH(K_BX_PACK, (k_bx_pack<1>), pgrid, dim3(256), 0, st, g.K, g.N, g.n_tiles, n_slabs, batch.p[i].B, g.ldb, dst);
     else TEMP_LAUNCH(K_BX_PACK, (k_bx_pack<0>), pgrid, dim3(256), 0, st, g.K, g.N, g.n_tiles, n_slabs, batch.p[i].B, g.ldb, dst);
   }
+  if (jobs.count) TEMP_LAUNCH(K_BX_PACK, k_bx_pack_multi, dim3(ceil_div(jobs.total_units, 4)), dim3(256), 0, st, jobs);   // all distinct weights of the batch in one launch
   return true;
 }
 

@@ -280,42 +280,50 @@ __global__ void __launch_bounds__(WPB * 64) k_gemm_tn_multi(TnBatch b, int Ka, i
   tn_body<NT, WPB, SPLIT>(b.M[prob], Ka, Nb, b.A[prob], lda, b.B[prob], ldb, rows_per_slice, 0, b.part[prob], nullptr, slice);
 }
 
+// out = sum over n_slices of part[s] (slice stride `elems`), optionally a SECOND, flat array in the same launch (the bias partials
+// of a weight-gradient product: one launch per product instead of two)
 __global__ void __launch_bounds__(256) k_reduce_slices(int n_slices, size_t elems, int width, const float* __restrict__ part,
-                                                       float* __restrict__ out, int ldo) {
+                                                       float* __restrict__ out, int ldo, size_t elems2, const float* __restrict__ part2,
+                                                       float* __restrict__ out2) {
   // elems % 4 == 0 is guaranteed by the callers (all widths are multiples of 4): float4 lanes,
   // 16 slice loads in flight (a thread's loop is a chain of memory round trips: 48 slices = 3 of them), summed in slice order
   // (deterministic)
-  const size_t e4 = elems >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < e4; i += (size_t)gridDim.x * blockDim.x) {
-    const float* p = part + (i << 2);
+  const size_t e4 = elems >> 2, e4b = elems2 >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < e4 + e4b; i += (size_t)gridDim.x * blockDim.x) {
+    const bool second = i >= e4;
+    const size_t stride = second ? elems2 : elems;
+    const size_t ii = second ? i - e4 : i;
+    const float* p = (second ? part2 : part) + (ii << 2);
     float4 acc = zero4();
     int s = 0;
     for (; s + 16 <= n_slices; s += 16) {
       float4 v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = ld4(p + (size_t)(s + u) * elems);
+      for (int u = 0; u < 16; ++u) v[u] = ld4(p + (size_t)(s + u) * stride);
 #pragma unroll
       for (int u = 0; u < 16; ++u) acc = add4(acc, v[u]);
     }
     for (; s + 4 <= n_slices; s += 4) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = ld4(p + (size_t)(s + u) * elems);
+      for (int u = 0; u < 4; ++u) v[u] = ld4(p + (size_t)(s + u) * stride);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = add4(acc, v[u]);
     }
-    for (; s < n_slices; ++s) acc = add4(acc, ld4(p + (size_t)s * elems));
-    const size_t e = i << 2;
+    for (; s < n_slices; ++s) acc = add4(acc, ld4(p + (size_t)s * stride));
+    const size_t e = ii << 2;
+    if (second) { st4(out2 + e, acc); continue; }
     const size_t r = e / width, c = e - r * width;
     st4(out + r * ldo + c, acc);
   }
 }
 
-void reduce_slices(int n_slices, size_t elems, int width, const float* part, float* out, int ldo, hipStream_t st) {
-  int rg = ceil_div((long long)elems / 4, 256);
+void reduce_slices(int n_slices, size_t elems, int width, const float* part, float* out, int ldo, hipStream_t st, size_t elems2, const float* part2,
+                   float* out2) {
+  int rg = ceil_div((long long)(elems + elems2) / 4, 256);
   if (rg > 2048) rg = 2048;
   if (rg < 1) rg = 1;
-  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, n_slices, elems, width, part, out, ldo);
+  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(rg), dim3(256), 0, st, n_slices, elems, width, part, out, ldo, elems2, part2, out2);
 }
 
 struct TnCfg { int wpb, bk, kab, nt, nbb, slices, split; };
@@ -390,8 +398,7 @@ int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int 
   else if (c.nt == 4) launch_tn<4>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
   else if (c.nt == 2) launch_tn<2>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
   else launch_tn<1>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
-  reduce_slices(S, (size_t)Ka * Nb, Nb, part, out, ldo, st);
-  if (bias_out) reduce_slices(S, (size_t)Ka, Ka, bpart, bias_out, Ka, st);
+  reduce_slices(S, (size_t)Ka * Nb, Nb, part, out, ldo, st, bias_out ? (size_t)Ka : 0, bpart, bias_out);      // weights + bias partials in one launch
   return launch_status();
 }
 
@@ -503,7 +510,8 @@ int colsum(int rows, int cols, const float* X, int ldx, float* out, void* ws, si
   const int nb = ceil_div(rows > 0 ? rows : 1, CS_RPB);
   if (!ws || ws_bytes < (size_t)nb * cols * sizeof(float)) return TEMP_E_WORKSPACE;
   TEMP_LAUNCH(K_COLSUM, k_colsum_part, dim3(ceil_div(cols, 64), nb), dim3(256), 0, st, rows, cols, X, ldx, (float*)ws);
-  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(ceil_div(cols / 4, 256)), dim3(256), 0, st, nb, (size_t)cols, cols, (const float*)ws, out, cols);
+  TEMP_LAUNCH(K_REDUCE_SLICES, k_reduce_slices, dim3(ceil_div(cols / 4, 256)), dim3(256), 0, st, nb, (size_t)cols, cols, (const float*)ws, out, cols, (size_t)0,
+              (const float*)nullptr, (float*)nullptr);
   return launch_status();
 }
 
@@ -553,7 +561,8 @@ __global__ void __launch_bounds__(256) k_scatter_add_rows(int n, int d, const fl
 template <int LPR>
 __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
                                                           const int32_t* __restrict__ order, const float4* __restrict__ src,
-                                                          const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
+                                                          const int32_t* __restrict__ row_mask, const float4* __restrict__ relu_of,
+                                                          float4* __restrict__ out) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63, grp = lane / LPR, lr = lane - grp * LPR;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -581,7 +590,7 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, con
     }
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) acc = add4(acc, shfl_xor4(acc, m));
-    if (grp == 0 && col_ok) out[(size_t)s * d4 + lr] = acc;
+    if (grp == 0 && col_ok) out[(size_t)s * d4 + lr] = relu_of ? relu_gate4(relu_of[(size_t)s * d4 + lr], acc) : acc;
   }
 }
 
@@ -589,7 +598,8 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(int n_seg, int d4, con
 template <int LPR>
 __global__ void __launch_bounds__(256) k_segment_sum_rows_short(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
                                                           const int32_t* __restrict__ order, const float4* __restrict__ src,
-                                                          const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
+                                                          const int32_t* __restrict__ row_mask, const float4* __restrict__ relu_of,
+                                                          float4* __restrict__ out) {
   // A wave takes FOUR consecutive segments at a time and walks them in lockstep: the three dependent round trips of a segment
   // (seg_ptr -> order -> row) are then shared by four segments instead of paid by each (the gather adjoints have 1-2 rows per
   // segment: the walk is all latency).
@@ -626,7 +636,8 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows_short(int n_seg, int d
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int m = LPR; m < 64; m <<= 1) acc[u] = add4(acc[u], shfl_xor4(acc[u], m));
-      if (grp == 0 && col_ok && s0 + u < n_seg) out[(size_t)(s0 + u) * d4 + lr] = acc[u];
+      if (grp == 0 && col_ok && s0 + u < n_seg)
+        out[(size_t)(s0 + u) * d4 + lr] = relu_of ? relu_gate4(relu_of[(size_t)(s0 + u) * d4 + lr], acc[u]) : acc[u];
     }
   }
 }
@@ -1154,7 +1165,8 @@ namespace temp {
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_segment_sum_rows_blk(int n_seg, int d4, const int32_t* __restrict__ seg_ptr,
                                                                      const int32_t* __restrict__ order, const float4* __restrict__ src,
-                                                                     const int32_t* __restrict__ row_mask, float4* __restrict__ out) {
+                                                                     const int32_t* __restrict__ row_mask, const float4* __restrict__ relu_of,
+                                                                     float4* __restrict__ out) {
   // one block per segment: wave w takes rows w, w + WAVES, ... eight at a time; the waves' sums are added in wave order.
   // WAVES = 16 for segments of a hundred rows and more (500 entities gathered 82 000 times: 164 rows each -- four waves walk
   // them in five dependent round trips of order[] -> row, sixteen in two)
@@ -1184,10 +1196,66 @@ __global__ void __launch_bounds__(WAVES * 64) k_segment_sum_rows_blk(int n_seg, 
       float4 t = red[0][lane];
 #pragma unroll
       for (int w = 1; w < WAVES; ++w) t = add4(t, red[w][lane]);
-      out[(size_t)s * d4 + lane] = t;
+      out[(size_t)s * d4 + lane] = relu_of ? relu_gate4(relu_of[(size_t)s * d4 + lane], t) : t;
     }
     __syncthreads();
   }
+}
+
+// Two sources over the SAME segmentation in one launch (the table layer's backward sums the aggregation part of d_h and dz per
+// table row: same inverse map, one walk of order[] instead of two; a stays masked by row_mask as in the single-source kernels).
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_segment_sum_rows_blk2(int n_seg, int d4a, int d4b, const int32_t* __restrict__ seg_ptr,
+                                                                      const int32_t* __restrict__ order, const float4* __restrict__ src_a,
+                                                                      const int32_t* __restrict__ mask_a, const float4* __restrict__ src_b,
+                                                                      float4* __restrict__ out_a, float4* __restrict__ out_b) {
+  __shared__ float4 red[2][WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool a_ok = lane < d4a, b_ok = lane < d4b;
+  for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
+    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+    float4 acc_a = zero4(), acc_b = zero4();
+    for (int j0 = beg + wave; j0 < end; j0 += 4 * WAVES) {
+      float4 va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + WAVES * u;
+        va[u] = zero4(); vb[u] = zero4();
+        if (j < end) {
+          const int r = order[j];
+          if (a_ok && (!mask_a || mask_a[r] > 0)) va[u] = src_a[(size_t)r * d4a + lane];
+          if (b_ok) vb[u] = src_b[(size_t)r * d4b + lane];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc_a = add4(acc_a, va[u]); acc_b = add4(acc_b, vb[u]); }
+    }
+    red[0][wave][lane] = acc_a;
+    red[1][wave][lane] = acc_b;
+    __syncthreads();
+    if (wave < 2) {
+      const bool ok = wave == 0 ? a_ok : b_ok;
+      if (ok) {
+        float4 t = red[wave][0][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t = add4(t, red[wave][w][lane]);
+        if (wave == 0) out_a[(size_t)s * d4a + lane] = t; else out_b[(size_t)s * d4b + lane] = t;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int segment_sum_rows2(int n_seg, const int32_t* seg_ptr, const int32_t* order, int d_a, const float* src_a, const int32_t* mask_a, float* out_a,
+                      int d_b, const float* src_b, float* out_b, hipStream_t st, long long n_rows_hint) {
+  if (d_a % 4 == 0 && d_b % 4 == 0 && d_a <= 256 && d_b <= 256 && n_rows_hint >= 96LL * n_seg) {
+    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk2<16>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(16 * 64), 0, st, n_seg, d_a / 4, d_b / 4, seg_ptr, order,
+                (const float4*)src_a, mask_a, (const float4*)src_b, (float4*)out_a, (float4*)out_b);
+    return launch_status();
+  }
+  int rc = segment_sum_rows(n_seg, d_a, seg_ptr, order, src_a, mask_a, out_a, st, n_rows_hint);
+  if (rc) return rc;
+  return segment_sum_rows(n_seg, d_b, seg_ptr, order, src_b, nullptr, out_b, st, n_rows_hint);
 }
 
 // Very long segments (a 40-row relation table gathered 48 000 times by the loss): every segment is cut into S equal
@@ -1222,13 +1290,14 @@ __global__ void __launch_bounds__(256) k_segment_sum_part(int S, int d4, const i
   if (wave == 0 && col_ok) part[((size_t)s * S + p) * d4 + lane] = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
 }
 
-__global__ void __launch_bounds__(256) k_segment_sum_fin(int n_seg, int S, int d4, const float4* __restrict__ part, float4* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_segment_sum_fin(int n_seg, int S, int d4, const float4* __restrict__ part, const float4* __restrict__ relu_of,
+                                                         float4* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n_seg * d4) return;
   const size_t s = i / d4, c = i - s * d4;
   float4 acc = zero4();
   for (int p = 0; p < S; ++p) acc = add4(acc, part[(s * S + p) * d4 + c]);
-  out[i] = acc;
+  out[i] = relu_of ? relu_gate4(relu_of[i], acc) : acc;
 }
 
 static int segsum_splits(int n_seg, long long n_rows) {
@@ -1244,21 +1313,22 @@ size_t segment_sum_rows_workspace(int n_seg, long long n_rows, int d) {
 }
 
 int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
-                     hipStream_t st, long long n_rows_hint, void* ws, size_t ws_bytes) {
+                     hipStream_t st, long long n_rows_hint, void* ws, size_t ws_bytes, const float* relu_src) {
   const int d4 = d / 4;
+  const float4* relu_of = (const float4*)relu_src;           // out = (relu_src > 0) ? sum : 0, element by element (nullable)
   const int S = segsum_splits(n_seg, n_rows_hint);
   if (S > 1 && d4 <= 64 && ws && ws_bytes >= segment_sum_rows_workspace(n_seg, n_rows_hint, d)) {
     TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_part, dim3(S, n_seg), dim3(256), 0, st, S, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)ws);
-    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_fin, dim3(ceil_div((long long)n_seg * d4, 256)), dim3(256), 0, st, n_seg, S, d4, (const float4*)ws, (float4*)out);
+    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_fin, dim3(ceil_div((long long)n_seg * d4, 256)), dim3(256), 0, st, n_seg, S, d4, (const float4*)ws, relu_of, (float4*)out);
     return launch_status();
   }
   if (n_rows_hint > 32LL * n_seg && d4 <= 64) {
     if (n_rows_hint >= 96LL * n_seg)
       TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk<16>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(16 * 64), 0, st, n_seg, d4, seg_ptr, order,
-                  (const float4*)src, row_mask, (float4*)out);
+                  (const float4*)src, row_mask, relu_of, (float4*)out);
     else
       TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk<4>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(4 * 64), 0, st, n_seg, d4, seg_ptr, order,
-                  (const float4*)src, row_mask, (float4*)out);
+                  (const float4*)src, row_mask, relu_of, (float4*)out);
     return launch_status();
   }
   const bool short_segs = n_rows_hint > 0 && n_rows_hint <= 2LL * n_seg;      // four segments per wave in lockstep
@@ -1267,9 +1337,9 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
 #define TEMP_SEGSUM(L)                                                                                                                      \
   do {                                                                                                                                      \
     if (short_segs) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows_short<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order,      \
-                                (const float4*)src, row_mask, (float4*)out);                                                                \
+                                (const float4*)src, row_mask, relu_of, (float4*)out);                                                       \
     else TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src,   \
-                     row_mask, (float4*)out);                                                                                               \
+                     row_mask, relu_of, (float4*)out);                                                                                      \
   } while (0)
   if (d4 <= 8) TEMP_SEGSUM(8); else if (d4 <= 16) TEMP_SEGSUM(16); else if (d4 <= 32) TEMP_SEGSUM(32); else TEMP_SEGSUM(64);
 #undef TEMP_SEGSUM
@@ -1284,6 +1354,12 @@ int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, 
                           void* workspace, size_t workspace_bytes, void* stream) {
   if (n_seg < 0 || d <= 0 || (n_seg > 0 && (!seg_ptr || !src || !out))) return TEMP_E_BADARG;
   return segment_sum_rows(n_seg, d, seg_ptr, order, src, nullptr, out, (hipStream_t)stream, n_rows, workspace, workspace_bytes);
+}
+
+int temp_segment_sum_rows_relu(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const float* relu_of,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_seg < 0 || d <= 0 || (n_seg > 0 && (!seg_ptr || !src || !out || !relu_of))) return TEMP_E_BADARG;
+  return segment_sum_rows(n_seg, d, seg_ptr, order, src, nullptr, out, (hipStream_t)stream, n_rows, workspace, workspace_bytes, relu_of);
 }
 
 struct EpiPlainStore {

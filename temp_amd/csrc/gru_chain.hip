@@ -725,6 +725,25 @@ int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream) {
   return launch_status();
 }
 
+int temp_gru_chain_pack_multi(int count, int d, const float* const* w_hh, float* const* packed, void* stream) {
+  if (count <= 0 || count > TEMP_CHAIN_MAX_RNN || d <= 0 || !w_hh || !packed) return TEMP_E_BADARG;
+  for (int i = 0; i < count; ++i) if (!w_hh[i] || !packed[i]) return TEMP_E_BADARG;
+  if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (!chain_bx(d) || 2 * count > BX_PACK_JOBS) {
+    for (int i = 0; i < count; ++i) { const int rc = temp_gru_chain_pack(d, w_hh[i], packed[i], stream); if (rc) return rc; }
+    return TEMP_OK;
+  }
+  const ChainGeom g = chain_geom(d);
+  BxPackJobs jobs = {};
+  for (int i = 0; i < count; ++i) {                           // forward planes (W_hh as stored: [3d][d], k contiguous), then backward planes (W_hh as [K][N])
+    bx_u32x4* pf = reinterpret_cast<bx_u32x4*>(packed[i]);
+    bx_pack_jobs_add(jobs, w_hh[i], pf, d, 3 * d, d, 1);
+    bx_pack_jobs_add(jobs, w_hh[i], pf + (size_t)(g.NQ >> 1) * g.NT * 192, 3 * d, d, d, 0);
+  }
+  TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_bx_pack_multi, dim3(ceil_div(jobs.total_units, 4)), dim3(256), 0, (hipStream_t)stream, jobs);
+  return launch_status();
+}
+
 int temp_gru_chain_fwd(const TempGruChain* c, const float* gi, float* h_out, float* saved, void* stream) {
   int rc = chain_check(c);
   if (rc) return rc;

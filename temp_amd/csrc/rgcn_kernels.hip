@@ -966,8 +966,6 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
   //   d_table = segsum(out_deg > 0 ? d_h : 0) + segsum(dz) . loop_w^T        d_loop_w = table^T . segsum(dz)
   rc = run_agg(MODE_DX, g->by_src, members_of(g), dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, w.d_h, w.part_dx, st);
   if (rc) return rc;
-  rc = segment_sum_rows(n_table, d_in, inv_ptr, inv_order, w.d_h, g->out_deg, d_table, st, g->n_nodes);
-  if (rc) return rc;
   const DropSpec ds = drop_spec(drop);
   const float* dzm = dz;                       // gradient of the (dropped-out) self-loop message
   if (ds.p > 0.f) {
@@ -975,7 +973,7 @@ int temp_rgcn_table_bwd(const TempGraph* g, const float* table, const int32_t* i
     if (rc) return rc;
     dzm = w.dzm;
   }
-  rc = segment_sum_rows(n_table, d_out, inv_ptr, inv_order, dzm, nullptr, w.seg_dz, st, g->n_nodes);
+  rc = segment_sum_rows2(n_table, inv_ptr, inv_order, d_in, w.d_h, g->out_deg, d_table, d_out, dzm, w.seg_dz, st, g->n_nodes);
   if (rc) return rc;
   rc = gemm_add_bias_act(K_GEMM_LOOP_DX, n_table, d_in, d_out, w.seg_dz, d_out, nullptr, loop_w, d_out, 1, d_table, d_in, nullptr, nullptr,
                          TEMP_ACT_NONE, d_table, d_in, st);

@@ -18,11 +18,14 @@ ACTS = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU}
 
 class _RGCNLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, weight, loop_w, bias, dg, num_bases, act, drop):
+    def forward(ctx, h, weight, loop_w, bias, dg, num_bases, act, drop, grad_premasked):
         be = get_backend()
         out = be.rgcn_fwd(dg, h, None, weight, loop_w, bias, num_bases, act, drop)
         ctx.save_for_backward(h, weight, loop_w, out)
-        ctx.dg, ctx.num_bases, ctx.act, ctx.has_bias, ctx.drop = dg, num_bases, act, bias is not None, drop
+        ctx.dg, ctx.num_bases, ctx.has_bias, ctx.drop = dg, num_bases, bias is not None, drop
+        # grad_premasked: the ONLY consumer of `out` folds the activation's adjoint into the gradient it returns
+        # (gather_rows(..., relu_table=True)), so the backward kernels take d_out as the pre-activation gradient
+        ctx.act = _lib.ACT_NONE if grad_premasked else act
         return out
 
     @staticmethod
@@ -30,13 +33,13 @@ class _RGCNLayerFn(torch.autograd.Function):
         h, weight, loop_w, out = ctx.saved_tensors
         d_h, d_w, d_loop, d_bias = get_backend().rgcn_bwd(ctx.dg, h, out, d_out.contiguous(), weight, loop_w, ctx.has_bias,
                                                           ctx.num_bases, ctx.act, ctx.drop)
-        return d_h, d_w, d_loop, d_bias, None, None, None, None
+        return d_h, d_w, d_loop, d_bias, None, None, None, None, None
 
 
-def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None, drop=None):
+def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None, drop=None, grad_premasked=False):
     """out = act(nnorm^2 * sum_in h_u BD(W_r) [+bias] + dropout(h W_loop)) on a device graph `dg`.
     drop = (p, seed) or None: dropout of the self-loop message (models/RGCN.py:57-59), mask = hash(seed, row, col)."""
-    return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act], drop)
+    return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act], drop, bool(grad_premasked and act == "relu"))
 
 
 class _RGCNTableLayerFn(torch.autograd.Function):
@@ -122,28 +125,42 @@ def gru_step(x, prev, dt, w_ih, w_hh, b_ih, b_hh, lam, decay=None, prev_idx=None
 
 class _GatherRowsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, idx, inverse):
-        ctx.save_for_backward(idx)
+    def forward(ctx, table, idx, inverse, relu_table):
         ctx.rows = table.shape[0]
         ctx.inverse = inverse
+        ctx.relu_table = relu_table
+        ctx.save_for_backward(idx, table.detach()) if relu_table else ctx.save_for_backward(idx)
         return get_backend().gather_rows(table, idx)
 
     @staticmethod
     def backward(ctx, d_out):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
         be = get_backend()
+        if ctx.relu_table:                                # (only offered with an inverse: see gather_rows)
+            seg_ptr, order = ctx.inverse
+            return be.segment_sum_rows(d_out.contiguous(), seg_ptr, order, ctx.rows, relu_of=ctx.saved_tensors[1]), None, None, None
         if ctx.inverse is not None and d_out.shape[1] % 4 == 0 and d_out.shape[1] <= 256:
             seg_ptr, order = ctx.inverse
-            return be.segment_sum_rows(d_out.contiguous(), seg_ptr, order, ctx.rows), None, None
+            return be.segment_sum_rows(d_out.contiguous(), seg_ptr, order, ctx.rows), None, None, None
         d_table = torch.zeros(ctx.rows, d_out.shape[1], dtype=d_out.dtype, device=d_out.device)
         be.scatter_add_rows(d_out.contiguous(), idx, d_table)
-        return d_table, None, None
+        return d_table, None, None, None
 
 
-def gather_rows(table, idx, inverse=None):
+def relu_gather_supported(table, inverse):
+    """True when gather_rows(table, ., inverse, relu_table=True) is available for this table."""
+    return inverse is not None and table.shape[1] % 4 == 0 and table.shape[1] <= 256
+
+
+def gather_rows(table, idx, inverse=None, relu_table=False):
     """out[i] = table[idx[i]] (idx int32, -1 => zero row).  Backward: atomic scatter-add, or -- when the caller
-    supplies `inverse` = gather_inverse(idx, rows) for a static index list -- a deterministic segment sum."""
-    return _GatherRowsFn.apply(table, idx, inverse)
+    supplies `inverse` = gather_inverse(idx, rows) for a static index list -- a deterministic segment sum.
+    relu_table=True: `table` is the ReLU output of the layer before and this gather is its ONLY consumer: the backward returns
+    the gradient with that ReLU's adjoint already applied (zero where table <= 0), in the same kernel; the producing layer must
+    then run its own backward with grad_premasked=True (rgcn_layer)."""
+    if relu_table and not relu_gather_supported(table, inverse):
+        raise ValueError("relu_table needs a static inverse and a width the segment-sum kernels take")
+    return _GatherRowsFn.apply(table, idx, inverse, bool(relu_table))
 
 
 def gather_inverse(idx_np, n_rows, device):

@@ -274,7 +274,8 @@ class _GruChainFn(torch.autograd.Function):
         saved = torch.empty(5, N, d, dtype=torch.float32, device=dev)
         packs = None
         if tabs is not None:
-            packs = [be.gru_chain_pack(W[r][1]) for r in range(n_rnn)]
+            packs = be.gru_chain_pack_multi([W[r][1] for r in range(n_rnn)]) if hasattr(be, "gru_chain_pack_multi") else \
+                [be.gru_chain_pack(W[r][1]) for r in range(n_rnn)]
             be.gru_chain_fwd(tabs, gi, lam, variant, packs, [W[r][3] for r in range(n_rnn)], H, saved)
         else:
             tens = prog.upload(dev)

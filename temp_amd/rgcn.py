@@ -67,11 +67,17 @@ class RGCNLayer(nn.Module):
     def _bias(self):
         return self.h_bias if self.bias else None
 
-    def conv(self, g, h):
-        """The fused layer on node features `h` of graph `g` (models/RGCN.py:53-70)."""
+    def conv(self, g, h, grad_premasked=False):
+        """The fused layer on node features `h` of graph `g` (models/RGCN.py:53-70).  grad_premasked: see TF.rgcn_layer (only
+        meaningful for a fused ReLU; the caller guarantees the single masking consumer)."""
         dg = g.device_graph(h.device, self.num_rels)
-        out = TF.rgcn_layer(h, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act, self._drop())
+        out = TF.rgcn_layer(h, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act, self._drop(),
+                            grad_premasked=grad_premasked and self._post_act is None)
         return self._post_act(out) if self._post_act is not None else out
+
+    def relu_fused(self):
+        """True when this layer's activation is the ReLU the kernels fuse (its adjoint can move into the consumer's backward)."""
+        return self._act == "relu" and self._post_act is None
 
     def conv_table(self, g, table, ids, inverse):
         """conv(g, table[ids]) for a layer fed straight from an embedding table (layer 1: h = ent_embeds[id],

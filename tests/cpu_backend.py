@@ -514,11 +514,12 @@ class CpuTestBackend:
         i = idx.long()
         return table.detach()[i.clamp(min=0)] * (i >= 0).to(table.dtype).view(-1, 1)
 
-    def segment_sum_rows(self, src, seg_ptr, order, n_seg):
+    def segment_sum_rows(self, src, seg_ptr, order, n_seg, relu_of=None):
         out = torch.zeros(n_seg, src.shape[1], dtype=src.dtype)
         cnt = (seg_ptr[1:] - seg_ptr[:-1]).long()
         seg = torch.repeat_interleave(torch.arange(n_seg), cnt)
-        return out.index_add_(0, seg, src.detach()[order.long()])
+        out.index_add_(0, seg, src.detach()[order.long()])
+        return out if relu_of is None else out * (relu_of.detach() > 0).to(out.dtype)
 
     def scatter_add_rows(self, src, idx, table):
         i = idx.long()

@@ -29,7 +29,7 @@ def hip_backend():
 
 def test_library_loaded_is_in_tree():
     lib = _lib.load()
-    assert lib.temp_abi_version() == 1
+    assert lib.temp_abi_version() == 2
     assert _lib.LIB_PATH.endswith("temp_amd/libtemp_amd.so")
 
 
