@@ -15,6 +15,10 @@ windows (weak scaling, the reference's DDP axis) and the parameter gradients are
 one bucket after backward.
 
 Extra objects on the JSON line:
+  extra         short secondary measurements of the same process (never the headline): the step with the link-prediction loss,
+                the self-attention encoder (config 5), the snapshot-sharded north-star step on one RCCL rank, and the FULL
+                window in the HBM regime (S-hbm-window: bi L=15 bsz=1 over 2^18-node / 2^22-edge snapshots, 230 relations --
+                the regime BASELINE's "% HBM roofline" is named after; its own roofline object uses SURVEY 8d's byte model)
   roofline      dominant kernel (largest share of traced kernel time): algorithmic bytes (or
                 flops) per step / its HIP-event time per step, against 8 TB/s HBM or the MFMA peak
                 of the pipe the kernel runs on: 157.3 TFLOP/s fp32 MFMA, or -- for the large GEMMs,
@@ -48,7 +52,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guid
 # products of an exact three-way operand split (temp_amd/csrc/gemm_bx.hpp; fp32-equivalent accuracy): their roof is the bf16 pipe
 # divided by six.  temp_set_option(TEMP_OPT_MFMA_BF16X3, 0) (or TEMP_MFMA=f32 in the environment at load time) keeps them on the
 # fp32 MFMA kernels (round-1 arithmetic); MFMA_MODE is read from the library in main().
-BX_KERNELS = ("k_gemm_panel", "k_gemm_tn")
+BX_KERNELS = ("k_gemm_panel", "k_gemm_tn_bx")          # (k_gemm_tn itself is the fp32 MFMA kernel of the small products)
 MFMA_MODE = "bf16x3"
 OPT_MFMA_BF16X3 = 0            # include/temp_amd.h: TEMP_OPT_MFMA_BF16X3
 CPU_THREADS = 16               # cpu_baseline leg (--cpu-threads)
@@ -144,7 +148,11 @@ def algorithmic_costs(wb, D, bi, S=2):
     c["k_gemm_panel<loop_fwd>"] = dict(bytes=n * 3 * row, flops=2 * n * D * D)
     c["k_gemm_panel<loop_dx>"] = dict(bytes=n * 3 * row + nt * 3 * row, flops=2 * (n + nt) * D * D)
     c["k_gemm_panel<isolated>"] = dict(bytes=nt * 3 * row, flops=2 * nt * D * D)
-    c["k_gemm_tn"] = dict(bytes=(n + nt) * 2 * row + n_gru * (2 * row + 6 * row), flops=2 * (n + nt) * D * D + 2 * 2 * n_gru * 3 * D * D)
+    # weight gradients, one entry per KERNEL (trace ids follow the kernels since round 4): the four 3d x d products of the two GRUs
+    # (k_gemm_tn_bx8: d_W_ih = dgi^T x, d_W_hh = dgh^T hdec), layer 2's loop weight (k_gemm_tn_bx), the table layer's (k_gemm_tn)
+    c["k_gemm_tn_bx8"] = dict(bytes=n_gru * (2 * row + 6 * row), flops=2 * 2 * n_gru * 3 * D * D)
+    c["k_gemm_tn_bx"] = dict(bytes=n * 2 * row, flops=2 * n * D * D)
+    c["k_gemm_tn"] = dict(bytes=nt * 2 * row, flops=2 * nt * D * D)
     c["k_relu_bwd"] = dict(bytes=n * 3 * row, flops=0)
     c["k_gru_fwd"] = dict(bytes=n_gru * (row + 3 * row + row + 5 * row + 8), flops=6 * n_gru * D * D)   # hoisted: h-phase only
     c["k_gemm_panel<gru_gi>"] = dict(bytes=n_gru * (row + 3 * row), flops=2 * n_gru * 3 * D * D)
@@ -167,7 +175,7 @@ def algorithmic_costs(wb, D, bi, S=2):
     return c
 
 
-MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd", "k_gru_chain_fwd", "k_gru_chain_bwd")
+MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd", "k_gru_chain_fwd", "k_gru_chain_bwd")   # (prefixes)
 
 
 def traced_steps(step_fn, n_steps, lib):
@@ -189,61 +197,125 @@ def traced_steps(step_fn, n_steps, lib):
     return {k: dict(launches_per_step=v[0] / n_steps, ms_per_step=v[1] / n_steps, avg_ms=v[1] / v[0]) for k, v in agg.items()}
 
 
-def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_windows=64):
-    """The oracle (port of the reference's op sequence, dense re-zeroed history kept) on the host
-    cores: one window (bsz=1) at a time, fwd+bwd, repeated over the rank-0 targets until at least
-    `min_seconds` of CPU work has been timed."""
+def _oracle_batch_runner(om, cfg, w, gd, seed=7):
+    """-> run(t_list): one oracle step (forward + backward, upstream gradient = ones) over ONE batch of windows with the
+    target graphs cut to a random 50 % of their edges and re-normalised, as the training step does (models/DynamicRGCN.py:76-90)
+    -> (edge visits, snapshot visits)."""
     from oracle import temp_oracle as O
-    # Threads: measured on the MI355X box (256 hardware threads, EPYC 9575F): with all of them torch's intra-op pool turns the
-    # oracle's many small ops into 598 s per window (363 edges/s); 16 threads give 0.3 s per window (~0.67 M edges/s), the best of
-    # {1, 8, 16, 32, 64}.  `cores` reports what was used, `host_threads` what the box has.
-    nthreads = min(os.cpu_count() or 1, CPU_THREADS)
-    torch.set_num_threads(nthreads)
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     bi = w["module"].startswith("Bi")
-    cfg = dict(module=w["module"], n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
-    om = O.model_from_state_dict(sd, cfg)
-    gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
     times = sorted(gd.keys())
     L = w["L"]
     leaves = list(O.leaf_tensors(om).values())
     for v in leaves:
         v.requires_grad_(True)
+    rng = np.random.default_rng(seed)
 
-    def run(t):
+    def half(g):
+        E = g.num_edges
+        return O.edge_subgraph(g, np.sort(rng.choice(E, size=E // 2, replace=False))) if E > 1 else g
+
+    def run(t_list):
         for v in leaves:
             v.grad = None
+        tgt = [half(gd[t]) for t in t_list]
         if bi:
-            tf, tb = O.get_batch_graph_list_bi([t], L, times)
+            tf, tb = O.get_batch_graph_list_bi(list(t_list), L, times)
             Hf = O.bi_pre_forward(om, cfg, gd, tf, L, True)
             Hb = O.bi_pre_forward(om, cfg, gd, tb, L, False)
-            out = O.bi_target_embeds(om, cfg, Hf, Hb, [gd[t]], tf[-1], L)
-            visits = [x for col in tf[:-1] + tb[:-1] for x in col if x is not None] + [t]
+            out = O.bi_target_embeds(om, cfg, Hf, Hb, tgt, tf[-1], L)
+            hist = [x for col in tf[:-1] + tb[:-1] for x in col if x is not None]
         else:
-            tf = O.get_batch_graph_list([t], L, times)
+            tf = O.get_batch_graph_list(list(t_list), L, times)
             H = O.uni_pre_forward(om, cfg, gd, tf, L)
-            out = O.uni_target_embeds(om, cfg, H, [gd[t]], tf[-1], L)
-            visits = [x for col in tf for x in col if x is not None]
+            out = O.uni_target_embeds(om, cfg, H, tgt, tf[-1], L)
+            hist = [x for col in tf[:-1] for x in col if x is not None]
         sum(o.sum() for o in out).backward()
-        return sum(gd[x].num_edges for x in visits), len(visits)
+        return sum(gd[x].num_edges for x in hist) + sum(g.num_edges for g in tgt), len(hist) + len(tgt)
 
-    run(device_targets[0])                          # warm-up (allocator, thread pool)
-    edges = visits = nwin = 0
+    return run
+
+
+def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_batches=16):
+    """The oracle (port of the reference's op sequence, dense re-zeroed history kept) on the host cores, on the SAME batch the
+    GPU step encodes: the rank-0 targets as ONE batch of bsz windows, target graphs at 50 % of their edges, fwd+bwd, repeated
+    until at least `min_seconds` of CPU work has been timed.  `all_cores` is a second, bounded measurement with every hardware
+    thread of the box (one window, in a child process with a timeout: torch's intra-op pool makes the oracle's many small ops
+    slower, not faster, beyond ~16 threads)."""
+    from oracle import temp_oracle as O
+    nthreads = min(os.cpu_count() or 1, CPU_THREADS)
+    torch.set_num_threads(nthreads)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = dict(module=w["module"], n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+    om = O.model_from_state_dict(sd, cfg)
+    gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
+    run = _oracle_batch_runner(om, cfg, w, gd)
+    run(device_targets[:1])                         # warm-up (allocator, thread pool)
+    edges = visits = nb = 0
     t0 = time.perf_counter()
     while True:
-        e, v = run(device_targets[nwin % len(device_targets)])
-        edges, visits, nwin = edges + e, visits + v, nwin + 1
+        e, v = run(device_targets)
+        edges, visits, nb = edges + e, visits + v, nb + 1
         dt = time.perf_counter() - t0
-        if dt >= min_seconds or nwin >= max_windows:
+        if dt >= min_seconds or nb >= max_batches:
             break
     return dict(value=edges / dt, unit="edges/s", cores=nthreads, host_threads=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
-                all_cores=dict(cores=256, value=363.0, unit="edges/s",
-                               note="measured once on this box type (round 2, EPYC 9575F, torch.set_num_threads(256)): 598 s for ONE window, "
-                                    "i.e. 1900x slower than 16 threads -- torch's intra-op pool turns the oracle's many small ops into "
-                                    "barrier traffic; not re-run in the default bench (it alone would take >10 min); "
-                                    "`--cpu-threads N` times the oracle with N threads instead of 16"),
-                sample="%d windows (bsz=1 each) of %s: %d snapshot visits, %d edge visits, full target graphs, fwd+bwd, %.1f s"
-                       % (nwin, w["name"], visits, edges, dt))
+                all_cores=cpu_all_cores_probe(w),
+                sample="%d batches of %d windows of %s (the step's own targets, target graphs at 50 %% of their edges): %d snapshot visits, "
+                       "%d edge visits, fwd+bwd, %.1f s" % (nb, len(device_targets), w["name"], visits, edges, dt))
+
+
+def cpu_probe_main(a):
+    """Child process of cpu_all_cores_probe: ONE window (bsz = 1) of the workload through the oracle with a.cpu_threads torch
+    threads; prints one JSON line.  Needs no GPU (oracle-initialised parameters of the same shapes: timing only)."""
+    from oracle import temp_oracle as O
+    from temp_amd import synthetic
+    torch.set_num_threads(max(1, a.cpu_threads))
+    w = synthetic.workload(a.workload, seed=0)
+    cfg = dict(module=w["module"], n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+    om = O.init_model(cfg, w["num_ents"], w["num_rels"], w["num_times"], w["D"], seed=1)
+    gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
+    run = _oracle_batch_runner(om, cfg, w, gd)
+    t = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:1]
+    print(json.dumps(dict(stage="ready", edges_per_window=None)), flush=True)
+    t0 = time.perf_counter()
+    e, v = run(t)
+    dt = time.perf_counter() - t0
+    print(json.dumps(dict(stage="done", seconds=dt, edges=e, visits=v, threads=torch.get_num_threads())), flush=True)
+
+
+def cpu_all_cores_probe(w, timeout_s=45.0):
+    """The oracle with torch.set_num_threads(os.cpu_count()) on ONE window, measured NOW in a child process that is stopped
+    after `timeout_s` (round 2 measured 598 s per window with 256 threads: the probe then reports the bound it established)."""
+    import subprocess
+    n = os.cpu_count() or 1
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-probe", "--cpu-threads", str(n), "--workload", w["name"]]
+    env = dict(os.environ, OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n))
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+    except OSError as e:
+        return dict(cores=n, value=None, note="probe not started: %s" % e)
+    ready_at, done = None, None
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.kill()                                    # exactly the child started above
+        out, _ = p.communicate()
+    for line in (out or "").splitlines():
+        try:
+            d = json.loads(line)
+        except ValueError:
+            continue
+        if d.get("stage") == "done":
+            done = d
+    wall = time.perf_counter() - t0
+    N, R, E, nn, T, D, B, L, bsz, module = __import__("temp_amd.synthetic", fromlist=["WORKLOADS"]).WORKLOADS[w["name"]]
+    per_window = E * ((2 * L - 1) if module.startswith("Bi") else L)
+    if done is not None:
+        return dict(cores=n, value=done["edges"] / done["seconds"], unit="edges/s", seconds=done["seconds"], sample="1 window (bsz 1), full target graph halved, fwd+bwd")
+    return dict(cores=n, value=None, unit="edges/s", timed_out_after_s=round(wall, 1), value_upper_bound=per_window / max(wall, 1e-9),
+                note="ONE window did not finish within the time limit with every hardware thread (torch's intra-op pool turns the oracle's "
+                     "many small ops into barrier traffic); value_upper_bound = edge visits of a full window / the time allowed, incl. start-up")
 
 
 def measure_sharded(model, w, world, rank, device, steps, warmup, dist, graphs=True):
@@ -307,10 +379,10 @@ def measure_sharded(model, w, world, rank, device, steps, warmup, dist, graphs=T
 
 
 def shbm_main(a, lib, device):
-    """`--workload S-hbm`: the edge kernels in the HBM regime the BASELINE metric is named after.  A full 15-position
-    window at this shape (2^20 nodes, 2^24 edges per snapshot: 23 GB per node-state tensor x ~20 live tensors) does not fit one
-    GPU, so a step here is ONE RGCN layer, forward + backward, over ONE snapshot whose 839-MB node matrix is far beyond the 256-MB
-    Infinity Cache.  `value` = edges processed per second (fwd + bwd of the layer); `roofline` = the forward aggregation kernel's
+    """`--workload S-hbm`: the edge kernels ALONE at SURVEY 8d's full S-hbm snapshot size (2^20 nodes, 2^24 edges): ONE RGCN layer,
+    forward + backward, over ONE snapshot whose 839-MB node matrix is far beyond the 256-MB Infinity Cache.  (The whole window path
+    in this regime -- both layers, the GRU chain, every weight gradient -- is `--workload S-hbm-window` / `extra.hbm_window` at
+    2^18 nodes / 2^22 edges per snapshot; the full-size window would hold 29 x ~17 node-row tensors of 839 MB = ~410 GB.)  `value` = edges processed per second (fwd + bwd of the layer); `roofline` = the forward aggregation kernel's
     ALGORITHMIC bytes (E (row + 8) + n row) over its HIP-event time against 8 TB/s, with the rocprofv3 PMC traffic of the same
     command (profiles/pmc_traffic_shbm*.json: FETCH_SIZE / WRITE_SIZE passes) beside it -- where the byte model exceeds the peak
     (Zipf hub rows are cache hits) `frac_from_counters` is the honest fraction."""
@@ -384,9 +456,174 @@ def shbm_main(a, lib, device):
                n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32", data="synthetic",
                config=dict(workload="S-hbm", nodes=n, edges=E, relations=R, embed=D, n_bases=B, host_prepare_s=prep,
-                           what="one RGCN layer fwd+bwd on one snapshot; a 15-position window of this shape does not fit one GPU"),
+                           what="one RGCN layer fwd+bwd on one snapshot (the full window in this regime: --workload S-hbm-window)"),
                roofline=roof, kernels=kernels, cpu_baseline=None)
     print(json.dumps(out), flush=True)
+
+
+class GraphStep:
+    """One forward+backward of `run()` with upstream gradient = ones, captured once into a HIP graph and replayed (eager when the
+    capture fails or graph=False).  `grads` = the gradient tensors every replay writes."""
+
+    def __init__(self, run, params, graph=True):
+        self.run, self.params = run, params
+        self._ones = {}
+        self.graph = self.grads = None
+        if graph:
+            self._capture()
+
+    def _backward_ones(self, out):
+        # handed to backward() as a resident tensor: `.sum().backward()` computes the same gradients but spends a reduction, two
+        # fills and -- because autograd expands the scalar's gradient with stride 0 -- one contiguous copy per consumer
+        key = (tuple(out.shape), out.dtype)
+        g = self._ones.get(key)
+        if g is None:
+            g = self._ones[key] = torch.ones_like(out)
+        out.backward(g)
+
+    def eager(self):
+        for p in self.params:
+            p.grad = None
+        self._backward_ones(self.run())
+
+    def _capture(self):
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.eager()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for p in self.params:
+                p.grad = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread polls events meanwhile
+                self._backward_ones(self.run())
+            torch.cuda.synchronize()
+            self.graph, self.grads = g, [p.grad for p in self.params]
+        except Exception as e:                      # capture is an optimisation only
+            print("bench: HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            self.graph = self.grads = None
+
+    def __call__(self):
+        if self.graph is None:
+            return self.eager()
+        self.graph.replay()
+
+    def time(self, steps, warmup):
+        for _ in range(warmup):
+            self()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def extra_measurements(a, w, model, wb, targets, device, lib):
+    """Secondary measurements of the default run (rank 0, one GPU), each a short object; a failure is reported in its object and
+    never costs the headline line."""
+    from temp_amd import synthetic
+    out = {}
+    steps, warm = max(20, min(a.steps, 100)), 5
+    params = [p for p in model.parameters()]
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:
+            out[name] = dict(error="%s: %s" % (type(e).__name__, e))
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+
+    def with_loss():
+        from temp_amd.sampling import CorruptTriples
+        model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
+        fixed = [tuple(x.to(device) for x in smp) for smp in model.draw_samples(wb)]
+        st = GraphStep(lambda: model.run_loss(wb, fixed), params, graph=not a.no_graph)
+        ms = st.time(steps, warm)
+        return dict(what="encoder + all-entity pass + ComplEx scores + cross-entropy, negative_rate 500, fixed negatives", ms_per_step=ms,
+                    edges_per_s=wb.n_edge_visits / (ms * 1e-3), launch="hip-graph replay" if st.graph is not None else "eager", steps=steps)
+
+    def attention():
+        m2 = build_model(w, device, "attention")
+        m2.sample_rng = np.random.default_rng(2)
+        wb2 = m2.prepare(targets, w["L"], train=True)
+        st = GraphStep(lambda: m2.run(wb2)[0], [p for p in m2.parameters()], graph=not a.no_graph)
+        ms = st.time(steps, warm)
+        return dict(what="BiSelfAttentionRGCN (config 5), same windows", ms_per_step=ms, edges_per_s=wb2.n_edge_visits / (ms * 1e-3),
+                    launch="hip-graph replay" if st.graph is not None else "eager", steps=steps)
+
+    def sharded():
+        import torch.distributed as dist
+        own = not dist.is_initialized()
+        if own:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        try:
+            r = measure_sharded(model, w, 1, 0, device, steps, warm, dist, graphs=not a.no_graph)
+        finally:
+            if own:
+                dist.destroy_process_group()
+        return dict(what="north-star snapshot-sharded step on ONE RCCL rank (three HIP graphs around the two exchanges + grad all-reduce)",
+                    ms_per_step=r["ms_per_step"], edges_per_s=r["value"], launch=r["launch"], rccl_ranks=r["rccl_ranks"], steps=steps)
+
+    guarded("with_loss", with_loss)
+    guarded("attention", attention)
+    guarded("sharded_1rank", sharded)
+    if a.hbm_window_log2_nodes > 0:
+        guarded("hbm_window", lambda: hbm_window(a, device, lib))
+    return out
+
+
+def hbm_window(a, device, lib):
+    """The WHOLE hot path in the HBM regime (BASELINE.md section 3, S-hbm row scaled to one GPU): BiGRRGCN, L = 15, bsz = 1 --
+    29 snapshot visits of 2^k nodes / 2^(k+4) edges each (k = 18: a 210-MB node matrix per visit, ~100 GB of activations, far beyond
+    the 256-MB Infinity Cache), 230 relations, through the same batched step as the headline (two RGCN layers over the union graph,
+    input-gate GEMM, window-chain kernels, all weight gradients).  roofline = SURVEY 8d's per-visit byte model against 8 TB/s."""
+    from temp_amd import synthetic
+    k = a.hbm_window_log2_nodes
+    N, E, R, D, B, L = 1 << k, 1 << (k + 4), a.shbm_relations, 200, 100, 15
+    t0 = time.perf_counter()
+    snaps = synthetic.make_snapshots(N, R, E, N, 2 * L - 1, seed=0)
+    w = dict(name="S-hbm-window", num_ents=N, num_rels=R, edges_per_snap=E, nodes_per_snap=N, num_times=2 * L - 1, D=D, B=B, L=L, bsz=1,
+             module="BiGRRGCN", snapshots=snaps)
+    gen_s = time.perf_counter() - t0
+    model = build_model(w, device)
+    model.sample_rng = np.random.default_rng(2)
+    t0 = time.perf_counter()
+    wb = model.prepare([L - 1], L, train=True)
+    torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t0
+    params = [p for p in model.parameters()]
+    st = GraphStep(lambda: model.run(wb)[0], params, graph=False)      # (a 0.2-s step: launch overhead is nothing here)
+    steps = max(2, a.hbm_window_steps)
+    ms = st.time(steps, 1)
+    tr = traced_steps(st.eager, 1, lib)
+    total = sum(v["ms_per_step"] for v in tr.values())
+    top = sorted(tr.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8]
+    n_over_e = wb.n_node_visits / max(wb.n_edge_visits, 1)
+    bpe = 2 * (12 * D + 24) + n_over_e * (2 * (20 * D + 16) + 32 * D + 4)
+    ach = wb.n_edge_visits * bpe / (ms * 1e-3) / 1e9
+    mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    edge_visits, node_visits = int(wb.n_edge_visits), int(wb.n_node_visits)
+    pmc_path = os.path.join(REPO, "profiles", "r04_pmc_traffic_hbm_window.json")
+    traffic = json.load(open(pmc_path)).get("step_traffic_bytes") if os.path.exists(pmc_path) else None
+    del st, wb, model, snaps
+    torch.cuda.empty_cache()
+    return dict(what="BiGRRGCN --rec-only-last-layer, L=15, bsz=1, one full bi window (29 snapshot visits), encoder fwd+bwd, eager launches",
+                nodes_per_snapshot=N, edges_per_snapshot=E, relations=R, embed=D, edge_visits_per_step=edge_visits, node_visits_per_step=node_visits, ms_per_step=ms,
+                edges_per_s=ach * 1e9 / bpe, steps=steps,
+                roofline=dict(bound="hbm", model="SURVEY 8d: 4848 + 14436 (n/E) bytes per snapshot-edge visit", bytes_per_edge_visit=bpe,
+                              achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                              traffic=traffic, traffic_source=("static: profiles/r04_pmc_traffic_hbm_window.json (rocprofv3 --pmc passes of this "
+                                                               "workload, bytes per step)" if traffic else None),
+                              frac_from_counters=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None),
+                kernels={k_: dict(ms=v["ms_per_step"], launches=v["launches_per_step"], share=v["ms_per_step"] / total) for k_, v in top},
+                traced_kernel_ms=total, peak_memory_gib=mem, host_generate_s=gen_s, host_prepare_s=prep_s)
 
 
 def _cpu_model():
@@ -402,8 +639,8 @@ def _cpu_model():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (0.5 s of replays at the headline shape: boxes differ by a few per cent)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="S-gdelt")
     ap.add_argument("--trace-steps", type=int, default=3)
     ap.add_argument("--shard", choices=("both", "windows", "snapshots"), default="both",
@@ -431,7 +668,14 @@ def main():
     ap.add_argument("--shbm-relations", type=int, default=230, help="--workload S-hbm: relations (230 = SURVEY's, 20 = GDELT's: the weight table then fits LDS)")
     ap.add_argument("--shbm-log2-nodes", type=int, default=20)
     ap.add_argument("--shbm-log2-edges", type=int, default=24)
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (`extra`: loss, attention, sharded on one rank, HBM-regime window)")
+    ap.add_argument("--hbm-window-log2-nodes", type=int, default=18,
+                    help="extra.hbm_window: nodes per snapshot = 2^k, edges = 2^(k+4), bi L=15 bsz=1 (0: skip; 18 needs ~110 GB of HBM and ~1 min of host planning)")
+    ap.add_argument("--hbm-window-steps", type=int, default=3)
+    ap.add_argument("--cpu-probe", action="store_true", help="(internal) child process of the all-cores CPU probe: no GPU")
     a = ap.parse_args()
+    if a.cpu_probe:
+        return cpu_probe_main(a)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -457,6 +701,16 @@ def main():
     CPU_THREADS = max(1, a.cpu_threads)
     MFMA_MODE = "bf16x3" if lib.temp_get_option(OPT_MFMA_BF16X3) else "f32"
 
+    if a.workload == "S-hbm-window":                 # the HBM-regime window on its own (profiling runs): same object as extra.hbm_window
+        if rank == 0:
+            r = hbm_window(a, device, lib)
+            print(json.dumps(dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=15, one full bi window in the HBM regime", value=r["edges_per_s"], unit="edges/s",
+                                  n_gpus=1, steps=r["steps"], warmup=1, ms_per_step=r["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None,
+                                  dtype="f32", data="synthetic", config=dict(workload="S-hbm-window", **{k: r[k] for k in ("nodes_per_snapshot", "edges_per_snapshot", "relations", "embed", "edge_visits_per_step", "what")}),
+                                  roofline=r["roofline"], kernels=r["kernels"], cpu_baseline=None, detail=r)), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if a.workload == "S-hbm":
         if rank == 0:
             shbm_main(a, lib, device)
@@ -504,54 +758,22 @@ def main():
     torch.cuda.synchronize()
     prepare_s = time.perf_counter() - t0
 
-    # Upstream gradient = ones on the step's output, handed to backward() as a resident tensor: `.sum().backward()`
-    # computes the same gradients but spends a reduction, two fills and -- because autograd expands the scalar's gradient
-    # with stride 0 -- one contiguous copy per consumer (~35 us of harness kernels per step in the round-2 trace).
-    ones_cache = {}
-
-    def backward_ones(out):
-        key = (tuple(out.shape), out.dtype)
-        g = ones_cache.get(key)
-        if g is None:
-            g = ones_cache[key] = torch.ones_like(out)
-        out.backward(g)
+    # The window batch is static, so the whole forward+backward of a step is captured once into a HIP graph and replayed
+    # (GraphStep); the gradient all-reduce stays outside the graph.
+    gs = None
+    if not sharded:
+        gs = GraphStep(run, params, graph=not a.no_graph)
+    graph, graph_grads = (gs.graph, gs.grads) if gs is not None else (None, None)
+    step_eager_local = gs.eager if gs is not None else None
 
     def step_eager():
-        for p in params:
-            p.grad = None
-        backward_ones(run())
+        step_eager_local()
         if dist is not None:
             allreduce_gradients(params, world, average=not sharded)
 
-    # The window batch is static, so the whole forward+backward of a step (~130 launches) is captured
-    # once into a HIP graph and replayed: no host launch overhead between the small per-position kernels.
-    # The gradient all-reduce stays outside the graph.
     def capture():
-        """-> (graph, the gradient tensors every replay writes) or (None, None)."""
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    for p in params:
-                        p.grad = None
-                    backward_ones(run())
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            for p in params:
-                p.grad = None
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread polls events meanwhile
-                backward_ones(run())
-            torch.cuda.synchronize()
-            return g, [p.grad for p in params]
-        except Exception as e:                      # capture is an optimisation only
-            print("bench: HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
-            return None, None
-
-    graph = graph_grads = None
-    if not a.no_graph and not sharded:
-        graph, graph_grads = capture()
+        g2 = GraphStep(run, params, graph=True)
+        return g2.graph, g2.grads
 
     def step():
         if sharded:
@@ -615,15 +837,18 @@ def main():
         else:
             ach = cst["bytes"] / sec / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
-        # HBM-side bytes per launch of the dominant kernel: measured separately with rocprofv3 --pmc
-        # (FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py) on this same workload and committed
-        # under profiles/ -- counters cannot be collected from inside this process.
-        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and a.workload == "S-gdelt" and a.encoder == "gru" and not a.with_loss:
-            fam = json.load(open(pmc_path)).get("families", {}).get(dom.split("<")[0])
-            if fam:
-                roof["traffic"] = fam["traffic_bytes_per_launch"]
-                roof["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)"
+        # HBM-side bytes per launch of the dominant kernel: measured separately with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in their
+        # own passes, tools/pmc_summary.py) on this same workload and committed under profiles/ -- counters cannot be collected from
+        # inside this process, so this is a STATIC number and says so.
+        pmc_path = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
+        pmc = json.load(open(pmc_path)) if (os.path.exists(pmc_path) and a.workload == "S-gdelt" and a.encoder == "gru" and not a.with_loss) else None
+        if pmc:
+            hits = [v for k, v in pmc.get("kernels", {}).items() if k == dom or k.startswith(dom + "<")]
+            if hits:
+                n_l = sum(h["launches"] for h in hits)
+                roof["traffic"] = sum(h["traffic_bytes_per_launch"] * h["launches"] for h in hits) / max(n_l, 1)
+                roof["traffic_unit"] = "bytes/launch"
+                roof["traffic_source"] = "static: profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)"
                 roof["algorithmic_per_launch"] = cst["flops" if roof["bound"] == "mfma" else "bytes"] / max(tr[dom]["launches_per_step"], 1e-9)
         roof.update(avg_launch_ms=tr[dom]["avg_ms"], launches_per_step=tr[dom]["launches_per_step"],
                     share_of_kernel_time=tr[dom]["ms_per_step"] / total_ms, traced_kernel_ms_per_step=total_ms)
@@ -647,13 +872,27 @@ def main():
         roof["step_frac_of_hbm"] = bytes_dedup * steps_per_s / (HBM_PEAK_GBS * 1e9)
         roof["step_algorithmic_flops"] = flops_step
         roof["step_frac_of_mfma"] = flops_step * steps_per_s / (MFMA_F32_PEAK_TFLOPS * 1e12)
-        if os.path.exists(pmc_path) and a.workload == "S-gdelt" and a.encoder == "gru" and not a.with_loss:
-            tot = json.load(open(pmc_path)).get("step_traffic_bytes")
-            if tot:
-                roof["step_traffic_bytes"] = tot
-                roof["step_traffic_over_algorithmic"] = tot / bytes_dedup
+        if pmc and pmc.get("step_traffic_bytes"):
+            roof["step_traffic_bytes"] = pmc["step_traffic_bytes"]
+            roof["step_traffic_over_algorithmic"] = pmc["step_traffic_bytes"] / bytes_dedup
+            roof["step_traffic_source"] = "static: profiles/r04_pmc_traffic.json"
+    # a longer replay of the same graph when the timed region was short (the driver's 20 steps are 50 ms: box-to-box noise is larger
+    # than the 1-3 % steps a round works on); reported beside the headline, never instead of it
+    long_ms = None
+    if rank == 0 and world == 1 and not sharded and a.steps < 200:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for _ in range(400):
+            step()
+        torch.cuda.synchronize()
+        long_ms = 1e3 * (time.perf_counter() - tl) / 400
     if rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(model, w, targets)
+    extra = None
+    if rank == 0 and world == 1 and not sharded and not a.no_extras and a.workload == "S-gdelt" and a.encoder == "gru" and not a.with_loss:
+        extra = extra_measurements(a, w, model, wb, targets, device, lib)
     loop = None
     if rank == 0 and world == 1 and a.train_loop_steps > 0 and not sharded:
         try:
@@ -668,14 +907,15 @@ def main():
             lib.temp_set_option(OPT_MFMA_BF16X3, 0)
             g32, _ = capture() if graph is not None else (None, None)
             one = g32.replay if g32 is not None else step_eager
-            for _ in range(a.warmup):
+            n32 = min(a.steps, 50)
+            for _ in range(min(a.warmup, 5)):
                 one()
             torch.cuda.synchronize()
             t32 = time.perf_counter()
-            for _ in range(a.steps):
+            for _ in range(n32):
                 one()
             torch.cuda.synchronize()
-            fp32_ms = 1e3 * (time.perf_counter() - t32) / a.steps
+            fp32_ms = 1e3 * (time.perf_counter() - t32) / n32
             del g32
         except Exception as e:                      # an extra, never the headline
             print("bench: fp32-MFMA comparison run failed (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
@@ -706,8 +946,8 @@ def main():
                                      "matrix pipe as six products of an exact 3-way operand split (fp32-equivalent accuracy, gemm_bx.hpp); "
                                      "small products (< 16384 rows) on the fp32 MFMA pipe" if MFMA_MODE == "bf16x3"
                                      else "fp32 MFMA everywhere (TEMP_OPT_MFMA_BF16X3 = 0)"),
-                               fp32_mfma_ms_per_step=fp32_ms),
-                   roofline=roof, cpu_baseline=cpu, north_star_sharded=ns_result)
+                               fp32_mfma_ms_per_step=fp32_ms, ms_per_step_400_replays=long_ms),
+                   roofline=roof, cpu_baseline=cpu, north_star_sharded=ns_result, extra=extra)
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
         # that the JSON line is the LAST line of stdout
         sys.stdout.flush()

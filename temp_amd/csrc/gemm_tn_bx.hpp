@@ -509,10 +509,10 @@ static inline void launch_tn_bx_nt(int M, int Ka, int Nb, const float* A, int ld
                                    float* part, float* bpart, hipStream_t st) {
   const int grid = 8 * ceil_div(S, 8) * kab;
   if (tn_bx8_ok(Ka)) {                                         // kab = row blocks of 256 here
-    TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8<NT>), dim3(grid), dim3(TNBX_THREADS), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, kab, S, part, bpart);
+    TEMP_LAUNCH(K_GEMM_TN_BX8, (k_gemm_tn_bx8<NT>), dim3(grid), dim3(TNBX_THREADS), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, kab, S, part, bpart);
     return;
   }
-  TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx<NT>), dim3(grid), dim3(TNBX_THREADS), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, kab, S, part, bpart);
+  TEMP_LAUNCH(K_GEMM_TN_BX, (k_gemm_tn_bx<NT>), dim3(grid), dim3(TNBX_THREADS), 0, st, M, Ka, Nb, A, lda, B, ldb, rps, kab, S, part, bpart);
 }
 
 inline void launch_tn_bx(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb, int rps, int kab, int S, float* part,
