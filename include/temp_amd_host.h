@@ -24,6 +24,8 @@ extern "C" {
  *   fix_seg/slot/cnt         one entry per multi-chunk segment (capacity E): segment, first slot, number of chunks
  *   counts[3]                n_chunks, n_partial (chunks that go through slots), n_fix */
 int temp_host_build_view(int64_t E, const int64_t* seg, const int64_t* a, const int64_t* b, int64_t n_seg, int64_t chunk,
+                         int sort_b /* 1: a segment's edges in ascending b (ties: input order) -- the by-dst / by-src views, b = relation;
+                                       0: input order -- the by-relation view */,
                          int64_t* order, int32_t* a_out, int32_t* b_out,
                          int32_t* chunk_seg, int32_t* chunk_beg, int32_t* chunk_end, int32_t* chunk_slot,
                          int32_t* fix_seg, int32_t* fix_slot, int32_t* fix_cnt, int64_t* counts);

@@ -17,7 +17,7 @@ _P = ctypes.c_void_p
 _I64 = ctypes.c_int64
 SYMBOLS = {
     "temp_host_abi_version": (ctypes.c_int, []),
-    "temp_host_build_view": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "temp_host_build_view": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "temp_host_plan_loss": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, ctypes.c_int, _I64, _P, _P, _P]),
     "temp_host_snapshot_pack": (_I64, [_I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "temp_host_union_plan": (_I64, [_I64, _I64, _P, _P, _P, _I64, _P, _I64, _P]),
@@ -46,7 +46,7 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.temp_host_abi_version() != 1:
+        if lib.temp_host_abi_version() != 2:
             raise RuntimeError("libtemp_host.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -56,7 +56,7 @@ def _i64(x):
     return np.ascontiguousarray(x, dtype=np.int64)
 
 
-def build_view(seg, a, b, n_seg, chunk):
+def build_view(seg, a, b, n_seg, chunk, sort_b=False):
     """Sorted / chunked edge view of one snapshot (see temp_host_build_view) -> dict in the layout snapshot.py uses."""
     seg, a, b = _i64(seg), _i64(a), _i64(b)
     E = int(seg.shape[0])
@@ -64,7 +64,7 @@ def build_view(seg, a, b, n_seg, chunk):
     order = np.empty(cap, np.int64)
     out = {k: np.empty(cap, np.int32) for k in ("a", "b", "chunk_seg", "chunk_beg", "chunk_end", "chunk_slot", "fix_seg", "fix_slot", "fix_cnt")}
     counts = np.zeros(3, np.int64)
-    rc = load().temp_host_build_view(E, seg.ctypes.data, a.ctypes.data, b.ctypes.data, int(n_seg), int(chunk), order.ctypes.data,
+    rc = load().temp_host_build_view(E, seg.ctypes.data, a.ctypes.data, b.ctypes.data, int(n_seg), int(chunk), int(bool(sort_b)), order.ctypes.data,
                                      out["a"].ctypes.data, out["b"].ctypes.data, out["chunk_seg"].ctypes.data, out["chunk_beg"].ctypes.data,
                                      out["chunk_end"].ctypes.data, out["chunk_slot"].ctypes.data, out["fix_seg"].ctypes.data,
                                      out["fix_slot"].ctypes.data, out["fix_cnt"].ctypes.data, counts.ctypes.data)

@@ -6,23 +6,51 @@
 
 extern "C" {
 
-int temp_host_abi_version(void) { return 1; }
+int temp_host_abi_version(void) { return 2; }
 
-int temp_host_build_view(int64_t E, const int64_t* seg, const int64_t* a, const int64_t* b, int64_t n_seg, int64_t chunk,
+}  // extern "C"
+
+// Edge ids sorted by (seg, b) when sort_b (else by seg alone), ties in input order: two stable counting sorts.  The by-destination
+// and by-source views list a segment's edges in RELATION order (b = relation there), so the chunks of a hub are runs of one
+// relation: the edge kernels then read a run's block weights once (rgcn_kernels.hip, relation runs).  Any order inside a
+// segment is a valid view; this one is fixed by the input alone, so results stay deterministic.
+static bool sorted_edge_order(int64_t E, const int64_t* seg, const int64_t* b, int64_t n_seg, bool sort_b, std::vector<int64_t>& ptr,
+                              std::vector<int64_t>& order) {
+  ptr.assign((size_t)n_seg + 1, 0);
+  for (int64_t e = 0; e < E; ++e) {
+    if (seg[e] < 0 || seg[e] >= n_seg) return false;
+    ++ptr[(size_t)seg[e] + 1];
+  }
+  for (int64_t s = 0; s < n_seg; ++s) ptr[(size_t)s + 1] += ptr[(size_t)s];
+  order.resize((size_t)E);
+  std::vector<int64_t> first;
+  if (sort_b && E > 0) {
+    int64_t nb = 0;
+    for (int64_t e = 0; e < E; ++e) { if (b[e] < 0) return false; nb = b[e] + 1 > nb ? b[e] + 1 : nb; }
+    std::vector<int64_t> bp((size_t)nb + 1, 0);
+    for (int64_t e = 0; e < E; ++e) ++bp[(size_t)b[e] + 1];
+    for (int64_t k = 0; k < nb; ++k) bp[(size_t)k + 1] += bp[(size_t)k];
+    first.resize((size_t)E);
+    for (int64_t e = 0; e < E; ++e) first[(size_t)bp[(size_t)b[e]]++] = e;
+  }
+  std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+  for (int64_t i = 0; i < E; ++i) {
+    const int64_t e = first.empty() ? i : first[(size_t)i];
+    order[(size_t)cur[(size_t)seg[e]]++] = e;
+  }
+  return true;
+}
+
+extern "C" {
+
+int temp_host_build_view(int64_t E, const int64_t* seg, const int64_t* a, const int64_t* b, int64_t n_seg, int64_t chunk, int sort_b,
                          int64_t* order, int32_t* a_out, int32_t* b_out,
                          int32_t* chunk_seg, int32_t* chunk_beg, int32_t* chunk_end, int32_t* chunk_slot,
                          int32_t* fix_seg, int32_t* fix_slot, int32_t* fix_cnt, int64_t* counts) {
   if (E < 0 || n_seg < 0 || chunk <= 0 || !counts || (E > 0 && (!seg || !a || !b || !order || !a_out || !b_out))) return 1;
-  std::vector<int64_t> ptr((size_t)n_seg + 1, 0);
-  for (int64_t e = 0; e < E; ++e) {
-    if (seg[e] < 0 || seg[e] >= n_seg) return 2;
-    ++ptr[(size_t)seg[e] + 1];
-  }
-  for (int64_t s = 0; s < n_seg; ++s) ptr[(size_t)s + 1] += ptr[(size_t)s];
-  {                                                    // counting sort: stable, edges keep their order inside a segment
-    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
-    for (int64_t e = 0; e < E; ++e) order[cur[(size_t)seg[e]]++] = e;
-  }
+  std::vector<int64_t> ptr, ord;
+  if (!sorted_edge_order(E, seg, b, n_seg, sort_b != 0, ptr, ord)) return 2;
+  for (int64_t i = 0; i < E; ++i) order[i] = ord[(size_t)i];
   for (int64_t i = 0; i < E; ++i) { a_out[i] = (int32_t)a[order[i]]; b_out[i] = (int32_t)b[order[i]]; }
   int64_t n_chunks = 0, n_partial = 0, n_fix = 0;
   for (int64_t s = 0; s < n_seg; ++s) {
@@ -140,16 +168,12 @@ int temp_host_plan_loss(int n_graphs, const int64_t* graph_ptrs, const int64_t* 
 
 // one view written compactly at `out`; returns entries written (or -1), fills sizes[9], *n_partial, optionally per-segment
 // chunk counts and per-chunk ranks (by-relation view)
-static int64_t pack_view(int64_t E, const int64_t* seg, const int64_t* a, const int64_t* b, int64_t n_seg, int64_t chunk, int32_t* out,
+static int64_t pack_view(int64_t E, const int64_t* seg, const int64_t* a, const int64_t* b, int64_t n_seg, int64_t chunk, bool sort_b, int32_t* out,
                          int64_t* sizes, int64_t* n_partial, int32_t* seg_count /* nullable [n_seg] */, int64_t* seg_chunks /* nullable [n_seg] */,
                          std::vector<int32_t>* rank /* nullable */) {
-  std::vector<int64_t> ptr((size_t)n_seg + 1, 0);
-  for (int64_t e = 0; e < E; ++e) {
-    if (seg[e] < 0 || seg[e] >= n_seg) return -1;
-    ++ptr[(size_t)seg[e] + 1];
-  }
-  if (seg_count) for (int64_t s = 0; s < n_seg; ++s) seg_count[s] = (int32_t)ptr[(size_t)s + 1];
-  for (int64_t s = 0; s < n_seg; ++s) ptr[(size_t)s + 1] += ptr[(size_t)s];
+  std::vector<int64_t> ptr, ord;
+  if (!sorted_edge_order(E, seg, b, n_seg, sort_b, ptr, ord)) return -1;
+  if (seg_count) for (int64_t s = 0; s < n_seg; ++s) seg_count[s] = (int32_t)(ptr[(size_t)s + 1] - ptr[(size_t)s]);
   int64_t n_chunks = 0, n_fix = 0;
   for (int64_t s = 0; s < n_seg; ++s) {
     const int64_t nch = (ptr[(size_t)s + 1] - ptr[(size_t)s] + chunk - 1) / chunk;
@@ -166,10 +190,7 @@ static int64_t pack_view(int64_t E, const int64_t* seg, const int64_t* a, const 
   int32_t* f_seg = c_slot + n_chunks;
   int32_t* f_slot = f_seg + n_fix;
   int32_t* f_cnt = f_slot + n_fix;
-  {
-    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
-    for (int64_t e = 0; e < E; ++e) { const int64_t p = cur[(size_t)seg[e]]++; a_o[p] = (int32_t)a[e]; b_o[p] = (int32_t)b[e]; }
-  }
+  for (int64_t p = 0; p < E; ++p) { const int64_t e = ord[(size_t)p]; a_o[p] = (int32_t)a[e]; b_o[p] = (int32_t)b[e]; }
   if (rank) rank->resize((size_t)n_chunks);
   int64_t c = 0, part = 0, f = 0;
   for (int64_t s = 0; s < n_seg; ++s) {
@@ -196,13 +217,13 @@ int64_t temp_host_snapshot_pack(int64_t n, int64_t E, const int64_t* src, const 
       (E > 0 && (!src || !dst || !rel)) || (n > 0 && !nnorm)) return -1;
   std::vector<int32_t> in_deg((size_t)n), out_deg((size_t)n), rank;
   int64_t off = 0;
-  int64_t w = pack_view(E, dst, src, rel, n, chunk, packed + off, sizes, n_partial, in_deg.data(), nullptr, nullptr);
+  int64_t w = pack_view(E, dst, src, rel, n, chunk, true, packed + off, sizes, n_partial, in_deg.data(), nullptr, nullptr);
   if (w < 0) return -1;
   off += w;
-  w = pack_view(E, src, dst, rel, n, chunk, packed + off, sizes + 9, n_partial + 1, out_deg.data(), nullptr, nullptr);
+  w = pack_view(E, src, dst, rel, n, chunk, true, packed + off, sizes + 9, n_partial + 1, out_deg.data(), nullptr, nullptr);
   if (w < 0) return -1;
   off += w;
-  w = pack_view(E, rel, src, dst, n_rel_rows, chunk_rel, packed + off, sizes + 18, n_partial + 2, nullptr, rel_chunks, &rank);
+  w = pack_view(E, rel, src, dst, n_rel_rows, chunk_rel, false, packed + off, sizes + 18, n_partial + 2, nullptr, rel_chunks, &rank);
   if (w < 0) return -1;
   off += w;
   for (size_t i = 0; i < rank.size(); ++i) packed[off + (int64_t)i] = rank[i];

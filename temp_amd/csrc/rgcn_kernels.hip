@@ -170,9 +170,53 @@ __global__ void __launch_bounds__(1024, 8) k_rgcn_agg_s(TempEdgeView v, const fl
       if (MODE == MODE_DX) { const float nn = nnorm[a_l]; s_l = nn * nn; }
       if (feat_ids) a_l = feat_ids[a_l];
     }
+    // Relation runs (table beyond LDS only).  The views list a segment's edges in relation order (host planner), so a HUB's chunks
+    // are a few long runs of one relation each -- with power-law degrees half of all edges sit in such chunks.  A run needs its
+    // 1.6 KB of block weights ONCE (they were read through L2 per edge: twice the bytes of the row itself, and what bounded the
+    // 230-relation case), and by linearity its rows are summed first and multiplied once.
+    unsigned long long starts = 0ull;
+    // (only for tables beyond LDS, n_rel_rows * D * S * 4 > 64 KB: small tables keep the per-edge sums of the LDS-resident kernels)
+    if (!W_LDS && (size_t)n_rel_rows * D * S * sizeof(float) > 65536) {
+      const int prev = __shfl_up(b_l, 1);
+      starts = __builtin_amdgcn_ballot_w64(lane < cnt && (lane == 0 || b_l != prev));
+    }
     if (!active) continue;                                     // (lanes past the row keep out of the loads; readlane ignores exec)
     float4 acc = zero4();
     const float4* wl = Ws4 + lane;
+    if (!W_LDS && starts != 0ull && 2 * __builtin_popcountll(starts) <= cnt) {  // runs of two and more on average: the run walk
+      int e = 0;
+      while (e < cnt) {
+        const unsigned long long later = e < 63 ? (starts >> (e + 1)) << (e + 1) : 0ull;
+        const int end = later ? __builtin_ctzll(later) : cnt;
+        const int rel = __builtin_amdgcn_readlane(b_l, e);
+        const float* wr = W + (size_t)rel * (D * S) + f * S;
+        float4 w[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) w[j] = ld4(wr + 4 * j);
+        float4 xs = zero4();
+        auto row = [&](int i) {
+          const int r = __builtin_amdgcn_readlane(a_l, i);
+          return ld4(feat + (size_t)r * ldf + f);
+        };
+        auto scale = [&](int i) { return MODE == MODE_DX ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_l), i)) : 1.f; };
+        int i = e;
+        for (; i + 4 <= end; i += 4) {
+          const float4 x0 = row(i), x1 = row(i + 1), x2 = row(i + 2), x3 = row(i + 3);
+          if (MODE == MODE_DX) { xs = fma4(scale(i), x0, xs); xs = fma4(scale(i + 1), x1, xs); xs = fma4(scale(i + 2), x2, xs); xs = fma4(scale(i + 3), x3, xs); }
+          else xs = add4(add4(xs, x0), add4(add4(x1, x2), x3));
+        }
+        for (; i < end; ++i) {
+          const float4 x0 = row(i);
+          if (MODE == MODE_DX) xs = fma4(scale(i), x0, xs); else xs = add4(xs, x0);
+        }
+        block_mac<S, MODE>(acc, xs, w, 1.f);
+        e = end;
+      }
+      if (MODE == MODE_FWD) { const float nn = nnorm[seg]; acc = scale4(acc, nn * nn); }
+      float* dst = (slot < 0) ? out + (size_t)seg * D + f : partial + (size_t)slot * D + f;
+      st4(dst, acc);
+      continue;
+    }
     auto edge = [&](int e, float4& x, int& rel, float& sc) {
       const int row = __builtin_amdgcn_readlane(a_l, e);
       rel = __builtin_amdgcn_readlane(b_l, e);

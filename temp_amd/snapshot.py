@@ -86,7 +86,8 @@ class Snapshot:
             E = self.number_of_edges()
             if E and (self.rel.min() < 0 or self.rel.max() >= n_rel_rows):
                 raise ValueError("relation id outside [0, %d)" % n_rel_rows)
-            v = dict(by_dst=build_view(self.dst, self.src, self.rel, self.n), by_src=build_view(self.src, self.dst, self.rel, self.n),
+            # (a node's edges in relation order: the chunks of a hub are runs of one relation -- see host_planner.cpp)
+            v = dict(by_dst=build_view(self.dst, self.src, self.rel, self.n, sort_b=True), by_src=build_view(self.src, self.dst, self.rel, self.n, sort_b=True),
                      by_rel=build_view(self.rel, self.src, self.dst, n_rel_rows, chunk=_lib.CHUNK_REL),
                      in_deg=np.bincount(self.dst, minlength=self.n).astype(np.int32),
                      out_deg=np.bincount(self.src, minlength=self.n).astype(np.int32))
@@ -177,15 +178,15 @@ class Snapshot:
         self._dev[("adopted", str(torch.device(device)), int(n_rel_rows))] = buf
 
     def device_edge_ids(self, device):
-        """[3, E] int32 on `device`: original edge id of every position of the by-dst / by-src / by-rel view (the views are
-        STABLE sorts of the edge list by dst / src / rel), uploaded once per snapshot."""
+        """[3, E] int32 on `device`: original edge id of every position of the by-dst / by-src / by-rel view (stable sorts of the
+        edge list by (dst, rel) / (src, rel) / rel), uploaded once per snapshot."""
         key = ("eid", str(device))
         t = self._dev.get(key)
         if t is None:
             with _lib.create_lock:
                 t = self._dev.get(key)
                 if t is None:
-                    eid = np.stack([np.argsort(k, kind="stable") for k in (self.dst, self.src, self.rel)]).astype(np.int32) \
+                    eid = np.stack([np.lexsort((self.rel, self.dst)), np.lexsort((self.rel, self.src)), np.argsort(self.rel, kind="stable")]).astype(np.int32) \
                         if self.number_of_edges() else np.zeros((3, 0), np.int32)
                     t = _lib.to_device(eid, device)
                     _lib.publish(device)
@@ -348,12 +349,12 @@ def batch(snapshots):
     return BatchedSnapshot(snapshots)
 
 
-def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK):
-    """Sort edges by `seg` (stable) and cut every segment into chunks of <= `chunk` edges.
+def build_view(seg, a, b, n_seg, chunk=_lib.CHUNK, sort_b=False):
+    """Sort edges by `seg` (stable; sort_b: by (seg, b)) and cut every segment into chunks of <= `chunk` edges.
     Returns a dict of int32 numpy arrays + counts (layout of TempEdgeView).  One counting-sort pass in the host
     planner library (temp_host_build_view); tests/host_reference.py holds the numpy formulation it is checked against."""
     from . import _hostlib
-    return _hostlib.build_view(seg, a, b, n_seg, chunk)
+    return _hostlib.build_view(seg, a, b, n_seg, chunk, sort_b)
 
 
 def build_view_tiled(seg, a, b, n_seg, tile, chunk=_lib.CHUNK):

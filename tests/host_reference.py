@@ -2,11 +2,14 @@
 import numpy as np
 
 
-def build_view_numpy(seg, a, b, n_seg, chunk):
-    """Sort edges by `seg` (stable) and cut every segment into chunks of <= `chunk` edges.
+def build_view_numpy(seg, a, b, n_seg, chunk, sort_b=False):
+    """Sort edges by `seg` (stable; sort_b: by (seg, b), ties in input order) and cut every segment into chunks of <= `chunk` edges.
     Returns a dict of int32 numpy arrays + counts (layout of TempEdgeView)."""
     seg = np.asarray(seg, dtype=np.int64)
-    order = np.argsort(seg.astype(np.uint16) if n_seg <= 65536 else seg, kind="stable")     # 16-bit keys: numpy radix-sorts them
+    if sort_b:
+        order = np.lexsort((np.asarray(b, dtype=np.int64), seg))
+    else:
+        order = np.argsort(seg.astype(np.uint16) if n_seg <= 65536 else seg, kind="stable")     # 16-bit keys: numpy radix-sorts them
     seg_s = seg[order]
     counts = np.bincount(seg_s, minlength=n_seg).astype(np.int64)
     ptr = np.concatenate([[0], np.cumsum(counts)])

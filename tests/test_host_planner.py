@@ -19,19 +19,26 @@ def test_host_library_exports_every_declared_symbol():
     assert names == sorted(_hostlib.SYMBOLS) and len(names) == 9
     for n in names:
         assert hasattr(lib, n)
-    assert lib.temp_host_abi_version() == 1
+    assert lib.temp_host_abi_version() == 2
 
 
 @pytest.mark.parametrize("E,n_seg,chunk,hub", [(0, 5, 64, False), (1, 1, 64, False), (7475, 500, 64, True), (3737, 40, 128, False),
                                               (1000, 3, 7, True), (50, 5000, 64, False), (4096, 1, 64, False)])
-def test_build_view_matches_numpy(E, n_seg, chunk, hub):
+@pytest.mark.parametrize("sort_b", [False, True])
+def test_build_view_matches_numpy(E, n_seg, chunk, hub, sort_b):
     rng = np.random.default_rng(E + n_seg)
     seg = rng.integers(0, n_seg, E)
     if hub and E:
         seg[: E // 2] = rng.integers(0, min(2, n_seg), E // 2)          # segments spanning many chunks
     a, b = rng.integers(0, 1000, E), rng.integers(0, 77, E)
-    got = _hostlib.build_view(seg, a, b, n_seg, chunk)
-    want = build_view_numpy(seg, a, b, n_seg, chunk)
+    got = _hostlib.build_view(seg, a, b, n_seg, chunk, sort_b)
+    want = build_view_numpy(seg, a, b, n_seg, chunk, sort_b)
+    if sort_b and E:                                      # a segment's edges in ascending b, ties in input order
+        s_sorted, b_sorted = seg[got["order"]], b[got["order"]]
+        same = s_sorted[1:] == s_sorted[:-1]
+        assert (b_sorted[1:][same] >= b_sorted[:-1][same]).all()
+        tie = same & (b_sorted[1:] == b_sorted[:-1])
+        assert (got["order"][1:][tie] > got["order"][:-1][tie]).all()
     assert set(got) == set(want)
     for k, v in want.items():
         if isinstance(v, np.ndarray):
