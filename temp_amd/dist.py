@@ -114,11 +114,32 @@ def allreduce_gradients(params, world=None, average=True, group=None, grads=None
     bucket[1].allreduce(world, average, group, grads, force)
 
 
+# Test switch: with ONE rank there is no peer, so the exchange below would issue no point-to-point operation at all (RCCL
+# refuses two ranks on one GPU: "Duplicate GPU detected").  LOOPBACK_P2P = True makes the rank its own peer: its block travels
+# through `batch_isend_irecv` (a grouped ncclSend / ncclRecv to itself) instead of the local copy, forward and adjoint, so the
+# RCCL point-to-point path, its stream ordering and its place between the HIP graphs run on a one-GPU box.  P2P_BATCHES counts
+# the batches issued.
+LOOPBACK_P2P = False
+P2P_BATCHES = 0
+
+
+def _self_exchange(dst, src, rank, group):
+    global P2P_BATCHES
+    ops = [dist.P2POp(dist.irecv, dst, _global_rank(rank, group), group), dist.P2POp(dist.isend, src, _global_rank(rank, group), group)]
+    P2P_BATCHES += 1
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
 def allgather_rows(local, out, bounds, world, rank, group=None):
     """out[bounds[q]:bounds[q+1]] <- rank q's `local` rows, for every q, as ONE grouped point-to-point batch (see _AllGatherRows).
     `out` is caller-owned (a static buffer when the surrounding compute is replayed from HIP graphs).  On RCCL `req.wait()` orders
     the CURRENT STREAM behind the transfers (the host does not block); on gloo it blocks the host, which is what a CPU run needs."""
-    out[bounds[rank]:bounds[rank + 1]] = local
+    global P2P_BATCHES
+    if LOOPBACK_P2P and local.shape[0] > 0:
+        _self_exchange(out[bounds[rank]:bounds[rank + 1]], local.contiguous(), rank, group)
+    else:
+        out[bounds[rank]:bounds[rank + 1]] = local
     ops = []
     for q in range(world):
         if q == rank:
@@ -128,6 +149,7 @@ def allgather_rows(local, out, bounds, world, rank, group=None):
         if local.shape[0] > 0:
             ops.append(dist.P2POp(dist.isend, local, _global_rank(q, group), group))
     if ops:
+        P2P_BATCHES += 1
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return out
@@ -138,7 +160,11 @@ def allgather_rows_adjoint(d_all, pieces, bounds, world, rank, group=None):
     (deterministic).  `pieces` is a caller-owned (world, n_local, d) buffer.  -> (n_local, d)"""
     lo, hi = bounds[rank], bounds[rank + 1]
     n_local = hi - lo
-    pieces[rank] = d_all[lo:hi]
+    global P2P_BATCHES
+    if LOOPBACK_P2P and n_local > 0:
+        _self_exchange(pieces[rank], d_all[lo:hi], rank, group)
+    else:
+        pieces[rank] = d_all[lo:hi]
     ops = []
     for q in range(world):
         if q == rank:
@@ -148,6 +174,7 @@ def allgather_rows_adjoint(d_all, pieces, bounds, world, rank, group=None):
         if bounds[q + 1] > bounds[q]:
             ops.append(dist.P2POp(dist.isend, d_all[bounds[q]:bounds[q + 1]], _global_rank(q, group), group))
     if ops:
+        P2P_BATCHES += 1
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     mine = pieces[0]

@@ -557,7 +557,8 @@ def test_post_ensemble_own_ratio_golden_gpu(name, batched):
 
 
 def test_sharded_step_rccl_single_rank_gpu():
-    """BASELINE north_star mode on the RCCL backend with ONE rank (two ranks cannot share a GPU): SnapshotShardedEncoder +
+    """BASELINE north_star mode on the RCCL backend with ONE rank (two ranks cannot share a GPU: RCCL answers "Duplicate GPU
+    detected", tools/p2p_probe.py) -- with the rank as its own peer for the point-to-point exchange: SnapshotShardedEncoder +
     ShardedStep (three HIP graphs around the two exchanges) + GradBucket with ReduceOp.AVG through nccl.
       * the graph-replayed step is BIT-identical to the same three parts run eagerly (outputs and every gradient);
       * against the unsharded batched step of the same windows: target embeddings and gradients equal to rounding (measured
@@ -588,20 +589,31 @@ def test_sharded_step_rccl_single_rank_gpu():
         enc = SnapshotShardedEncoder(model)
         sb = enc.prepare(targets, w["L"], train=True)
         res = {}
-        for name, graphs in (("eager", False), ("graphs", True)):
-            st = ShardedStep(enc, sb, params, graphs=graphs, average=True, force_allreduce=True)
-            assert (st.graphs is not None) == graphs
-            for _ in range(2):                                       # a replayed graph must reproduce itself
-                out = st.step()
-            torch.cuda.synchronize()
+        from temp_amd import dist as TD
+        # "loopback": the rank is its own peer -- its node-state block and the mirrored gradient block go through RCCL's grouped
+        # send / recv (batch_isend_irecv) between the HIP graphs instead of a local copy: the point-to-point path of the exchange
+        # on a one-GPU box (two ranks cannot share a GPU: "Duplicate GPU detected")
+        for name, graphs, loop in (("eager", False, False), ("graphs", True, False), ("loopback", True, True)):
+            TD.LOOPBACK_P2P = loop
+            n0 = TD.P2P_BATCHES
+            try:
+                st = ShardedStep(enc, sb, params, graphs=graphs, average=True, force_allreduce=True)
+                assert (st.graphs is not None) == graphs
+                for _ in range(2):                                       # a replayed graph must reproduce itself
+                    out = st.step()
+                torch.cuda.synchronize()
+            finally:
+                TD.LOOPBACK_P2P = False
+            assert (TD.P2P_BATCHES - n0 >= 4) == loop, "forward + adjoint exchange of two steps = four RCCL point-to-point batches"
             res[name] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
             del st, out
             for p in params:
                 p.grad = None
-        assert torch.equal(res["eager"][0], res["graphs"][0])
-        assert set(res["eager"][1]) == set(res["graphs"][1]) == set(ref_grads)
+        assert torch.equal(res["eager"][0], res["graphs"][0]) and torch.equal(res["loopback"][0], res["graphs"][0])
+        assert set(res["eager"][1]) == set(res["graphs"][1]) == set(res["loopback"][1]) == set(ref_grads)
         for k, g in res["eager"][1].items():
             assert torch.equal(g, res["graphs"][1][k]), k
+            assert torch.equal(res["loopback"][1][k], res["graphs"][1][k]), "loopback " + k
         assert_close(res["graphs"][0], ref_out, 2e-6, 5e-7, "sharded vs unsharded target embeddings")
         for k, g in res["graphs"][1].items():
             assert_close(g, ref_grads[k], 2e-5, 2e-6 * max(1.0, float(ref_grads[k].abs().max())), "sharded vs unsharded " + k)
