@@ -146,6 +146,9 @@ typedef struct TempMembers {
   const int32_t* node_off;  /* [n_members + 1]  device                                             */
   const int32_t* edge_off;  /* [n_members + 1]  device                                             */
   const int32_t* chunk_off; /* [3][n_members + 1] device                                           */
+  const int32_t* fix_off;   /* [2][n_members + 1] device, nullable: first fix-up entry of every member in the by_dst / by_src
+                               view (their fix_* lists are member-major).  Present: the LDS-tiled aggregation / d-dh kernels sum
+                               a member's multi-chunk segments themselves, after their walk (one launch less per view). */
 } TempMembers;
 
 typedef struct TempGraph {

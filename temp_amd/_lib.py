@@ -29,7 +29,7 @@ class TempEdgeView(ctypes.Structure):
 
 class TempMembers(ctypes.Structure):
     _fields_ = [("n_members", ctypes.c_int32), ("max_nodes", ctypes.c_int32), ("max_edges", ctypes.c_int32),
-                ("max_chunks", ctypes.c_int32 * 3), ("node_off", c_vp), ("edge_off", c_vp), ("chunk_off", c_vp)]
+                ("max_chunks", ctypes.c_int32 * 3), ("node_off", c_vp), ("edge_off", c_vp), ("chunk_off", c_vp), ("fix_off", c_vp)]
 
 
 class TempGraph(ctypes.Structure):

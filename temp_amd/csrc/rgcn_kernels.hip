@@ -332,6 +332,20 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* 
   }
 }
 
+// ordered sum of `end - s` partial rows (column `p`), eight loads in flight: THE summation order of every fix-up
+__device__ __forceinline__ float4 fixup_walk(const float* __restrict__ p, int s, int end, int width) {
+  float4 acc = zero4();
+  for (; s + 8 <= end; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4(p + (size_t)(s + u) * width);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+  }
+  for (; s < end; ++s) acc = add4(acc, ld4(p + (size_t)s * width));
+  return acc;
+}
+
 }  // namespace temp
 #include "rgcn_tile.hpp"
 namespace temp {
@@ -383,19 +397,6 @@ __global__ void __launch_bounds__(256) k_rgcn_agg_generic(TempEdgeView v, const 
 // entry counts as long.  Many entries (the node views: thousands of hubs with a few partial rows each): <4, 4, 256>.  Few entries
 // (the by-relation view of the weight gradient: one entry per relation, hundreds to thousands of partial rows each -- ten
 // 4-wave blocks walked them for 40 us on an idle chip): <16, 1, 32>, one block of 16 waves per entry.
-__device__ __forceinline__ float4 fixup_walk(const float* __restrict__ p, int s, int end, int width) {
-  float4 acc = zero4();
-  for (; s + 8 <= end; s += 8) {
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld4(p + (size_t)(s + u) * width);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
-  }
-  for (; s < end; ++s) acc = add4(acc, ld4(p + (size_t)s * width));
-  return acc;
-}
-
 constexpr int FIX_PART = 256, FIX_LIST = 2, FIX_LIST_CAP = 4096, FIX_SPLIT_MIN = 1 << 15;
 // SPLIT: an entry with more than `huge` partial rows is not summed here; its index is appended to the list in `ctl` and
 // k_fixup_split sums it with many blocks (the append order varies from run to run, the sums do not: see there).
@@ -668,7 +669,7 @@ static bool launch_agg_tile(const TempEdgeView& v, const TileArgs& t, const floa
 }
 
 template <int S, int MODE>
-static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
+static bool launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, const float* feat, int ldf, const int32_t* ids, const float* W, int n_rel_rows,
                        const float* nnorm, int D, float* out, float* partial, hipStream_t st) {
   const int lpr = pick_lpr(D);
   const size_t wbytes = (size_t)n_rel_rows * D * S * sizeof(float);
@@ -677,7 +678,7 @@ static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, c
       tile_plan(*mb, view, D, S, 0, n_rel_rows, 0, &ta)) {
     const bool ok = n_rel_rows <= 256 ? launch_agg_tile<S, MODE, unsigned char>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st)
                                       : launch_agg_tile<S, MODE, unsigned short>(v, ta, feat, ldf, ids, W, n_rel_rows, nnorm, D, out, partial, st);
-    if (ok) return;
+    if (ok) return ta.fix_off != nullptr;                     // (the tiled kernels then summed the multi-chunk segments themselves)
   }
   if (wbytes <= 65536 && v.n_chunks >= 4096) {
     // whole relation table in LDS; 1024-thread persistent blocks, 2 per CU (2 x 64 KB of 160 KB)
@@ -691,13 +692,17 @@ static void launch_agg(const TempEdgeView& v, const TempMembers* mb, int view, c
   } else {
     int grid = (v.n_chunks + 3) / 4;
     grid = grid < 8 ? 8 : (grid > 2048 ? 2048 : (grid + 7) / 8 * 8);
-    if (lpr == 64 && MODE == MODE_FWD && !rgcn_scalar_off())      // (measured on the S-hbm shape: the forward gains 3 %, d/dh loses 14 %: 3.32 against 2.91 ms)
+    // (measured on the S-hbm shape before the relation runs: the forward gains 3 %, d/dh loses 14 %: 3.32 against 2.91 ms; with a
+    // table beyond LDS the scalar kernel walks relation runs, which the generic one cannot: TEMP_OPT_DEBUG 101 keeps d/dh generic)
+    const bool runs = wbytes > 65536 && option(TEMP_OPT_DEBUG) != 101;
+    if (lpr == 64 && (MODE == MODE_FWD || runs) && !rgcn_scalar_off())
       TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg_s<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D,
                   out, partial);
     else
       TEMP_LAUNCH((MODE == MODE_FWD ? K_RGCN_AGG_FWD : K_RGCN_AGG_DX), (k_rgcn_agg<S, MODE, false>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, n_rel_rows, nnorm, D, lpr,
                        out, partial);
   }
+  return false;
 }
 
 static void launch_fixup(const TempEdgeView& v, const float* partial, int width, float* out, hipStream_t st) {
@@ -735,11 +740,12 @@ static int run_agg(int mode, const TempEdgeView& v, const TempMembers* mb, const
                    const float* nnorm, int d_in, int d_out, int num_bases, float* out, float* partial, hipStream_t st) {
   if (v.n_chunks == 0) return TEMP_OK;
   int S = 0;
+  bool fixed = false;
   const int wres = (mode == MODE_FWD) ? d_out : d_in;
   if (fast_shape(d_in, d_out, num_bases, &S)) {
 #define TEMP_AGG(SS)                                                                                   \
-  if (mode == MODE_FWD) launch_agg<SS, MODE_FWD>(v, mb, 0, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st); \
-  else launch_agg<SS, MODE_DX>(v, mb, 1, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st);
+  if (mode == MODE_FWD) fixed = launch_agg<SS, MODE_FWD>(v, mb, 0, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st); \
+  else fixed = launch_agg<SS, MODE_DX>(v, mb, 1, feat, ldf, ids, W, n_rel_rows, nnorm, d_in, out, partial, st);
     if (S == 1) { TEMP_AGG(1) } else if (S == 2) { TEMP_AGG(2) } else { TEMP_AGG(4) }
 #undef TEMP_AGG
   } else {
@@ -753,7 +759,7 @@ static int run_agg(int mode, const TempEdgeView& v, const TempMembers* mb, const
       TEMP_LAUNCH(K_RGCN_AGG_DX, (k_rgcn_agg_generic<MODE_DX>), dim3(grid), dim3(256), 0, st, v, feat, ldf, ids, W, nnorm, d_in, d_out, si, so,
                          out, partial);
   }
-  launch_fixup(v, partial, wres, out, st);
+  if (!fixed) launch_fixup(v, partial, wres, out, st);
   return launch_status();
 }
 

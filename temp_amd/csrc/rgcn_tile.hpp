@@ -33,6 +33,7 @@ struct TileArgs {
   const int32_t* node_off;                                   // member tables (device), chunk_off of THIS view
   const int32_t* edge_off;
   const int32_t* chunk_off;
+  const int32_t* fix_off;                                    // [n_members + 1] of THIS view, or nullptr: fix-up by its own launch
   int n_members;
   int fs4, n_slices;                                         // float4 columns of the widest slice (= LDS row stride), slices per row
   int off_x, off_g, off_w, off_ea, off_eb, off_cm, off_misc; // LDS byte offsets
@@ -72,6 +73,9 @@ inline bool tile_plan(const TempMembers& mb, int view, int D, int S, int rows2, 
     t->node_off = mb.node_off;
     t->edge_off = mb.edge_off;
     t->chunk_off = mb.chunk_off + (size_t)view * (mb.n_members + 1);
+    // in-block fix-up: node views only, and only while no entry can be "long" for k_fixup<4, 4, 256> (its block-cooperative
+    // walk sums in another order; a member's hub has at most max_edges / TEMP_CHUNK partial rows)
+    t->fix_off = (view < 2 && mb.fix_off && mb.max_edges / TEMP_CHUNK < 256) ? mb.fix_off + (size_t)view * (mb.n_members + 1) : nullptr;
     t->prof = nullptr;
     return true;
   }
@@ -405,6 +409,37 @@ __global__ void __launch_bounds__(TILE_THREADS) k_rgcn_agg_t(TempEdgeView v, Til
     }
   }
   TILE_STAMP(6);
+  // ---- the member's multi-chunk segments: all their partial rows were written by THIS block (a member's chunks never leave
+  // it), so their ordered sums are taken here instead of by a k_fixup launch behind the kernel: same walk, same order, same bits
+  if (t.fix_off) {
+    __syncthreads();                                          // (workgroup-scope: the walkers' partial rows are visible to the block)
+    const int f0 = t.fix_off[b.m], nfx = t.fix_off[b.m + 1] - f0;
+    for (int i = tid; i < nfx * b.nf4; i += nthr) {
+      const int fi = f0 + i / b.nf4, c = (b.f4_0 + i % b.nf4) * 4;
+      const int seg = v.fix_seg[fi], s0 = v.fix_slot[fi], cnt = v.fix_cnt[fi];
+      // fixup_walk's additions in fixup_walk's order, with 32 instead of 8 rows in flight: a hub's hundred partial rows are four
+      // memory round trips on the block's tail instead of fifteen
+      const float* pr = partial + (size_t)s0 * D + c;
+      float4 acc = zero4();
+      int r = 0;
+      for (; r + 32 <= cnt; r += 32) {
+        float4 q[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) q[u] = ld4(pr + (size_t)(r + u) * D);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = add4(acc, q[u]);
+      }
+      for (; r + 8 <= cnt; r += 8) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = ld4(pr + (size_t)(r + u) * D);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = add4(acc, q[u]);
+      }
+      for (; r < cnt; ++r) acc = add4(acc, ld4(pr + (size_t)r * D));
+      st4(out + (size_t)seg * D + c, acc);
+    }
+  }
   if (t.prof) { __syncthreads(); TILE_STAMP(7); }
 }
 

@@ -618,9 +618,11 @@ def union_graph_packed(snap, n_rel_rows, device):
     # workgroup per (member, feature slice) with the member's rows staged in LDS
     M = len(metas)
     nck = rows[:, [_COL[("by_dst", "chunk_seg")], _COL[("by_src", "chunk_seg")], _COL[("by_rel", "chunk_seg")]]].T      # (3, M) chunks per member
-    tab = np.zeros((5, M + 1), dtype=np.int32)
+    nfx = rows[:, [_COL[("by_dst", "fix_seg")], _COL[("by_src", "fix_seg")]]].T                                          # (2, M) fix-up entries per member
+    tab = np.zeros((7, M + 1), dtype=np.int32)
     tab[0], tab[1] = snap.node_off, snap.edge_off
-    tab[2:, 1:] = np.cumsum(nck, axis=1)
+    tab[2:5, 1:] = np.cumsum(nck, axis=1)
+    tab[5:7, 1:] = np.cumsum(nfx, axis=1)                     # (the node views' fix lists are member-major: TempMembers.fix_off)
     members = dict(n_members=M, max_nodes=int(max(snap.node_sizes)) if M else 0, max_edges=int(np.diff(snap.edge_off).max()) if M else 0,
                    max_chunks=[int(x) for x in nck.max(axis=1)] if M else [0, 0, 0], table=_lib.to_device(tab.reshape(-1), device))
     counts["_members"] = members
@@ -768,7 +770,7 @@ class _DeviceGraph:
             for i in range(3):
                 mb.max_chunks[i] = members["max_chunks"][i]
             tb = members["table"].data_ptr()
-            mb.node_off, mb.edge_off, mb.chunk_off = tb, tb + 4 * (M + 1), tb + 8 * (M + 1)
+            mb.node_off, mb.edge_off, mb.chunk_off, mb.fix_off = tb, tb + 4 * (M + 1), tb + 8 * (M + 1), tb + 20 * (M + 1)
         for vn, cnt in counts.items():
             ev = getattr(g, vn)
             for fld, val in cnt.items():

@@ -640,7 +640,13 @@ def test_tiled_edge_kernels_bit_identical_gpu(D, B, hip_backend):
     mb = dg.c.members
     M = len(parts)
     assert mb.n_members == M and mb.max_nodes == max(p.n for p in parts)
-    tab = dg._members["table"].cpu().numpy().reshape(5, M + 1)
+    tab = dg._members["table"].cpu().numpy().reshape(7, M + 1)
+    for vi, vn in enumerate(("by_dst", "by_src")):                    # fix-up entries per member (TempMembers.fix_off): member-major lists
+        fseg = dg.view_tensor(vn, "fix_seg").cpu().numpy()
+        fo = tab[5 + vi]
+        assert fo[0] == 0 and fo[-1] == fseg.shape[0]
+        for m in range(M):
+            assert ((fseg[fo[m]:fo[m + 1]] >= tab[0][m]) & (fseg[fo[m]:fo[m + 1]] < tab[0][m + 1])).all(), (vn, m)
     assert np.array_equal(tab[0], g.node_off) and np.array_equal(tab[1], g.edge_off)
     for vi, vn in enumerate(("by_dst", "by_src", "by_rel")):
         seg, beg, end = (dg.view_tensor(vn, k).cpu().numpy() for k in ("chunk_seg", "chunk_beg", "chunk_end"))
