@@ -330,7 +330,7 @@ class HipBackend:
     def gru_chain_bwd(self, tabs, saved_all, ups, lam, variant, packs, b_hhs, dgi, dgh):
         d = saved_all.shape[2]
         c, keep = self._chain_desc(tabs, d, variant, lam, saved_all.shape[1] * d, packs, b_hhs)
-        ups = [_f32(u, "upstream") for u in ups]
+        ups = [_f32(u, "upstream") if u is not None else None for u in ups]      # (None: that block of rows has no upstream gradient)
         arr = (ctypes.c_void_p * max(len(ups), 1))(*[u.data_ptr() if u is not None else None for u in ups])
         rc = self.lib.temp_gru_chain_bwd(ctypes.byref(c), _ptr(saved_all), len(ups), arr, _ptr(dgi), _ptr(dgh), _stream())
         _lib.check(rc, "temp_gru_chain_bwd")

@@ -657,13 +657,17 @@ static inline void launch_bx_g(int kid, const PanelBatch<Epi>& batch, int count,
 }
 
 // weights-resident kernel (gemm_bxr.hpp) for short K; temp_set_option(TEMP_OPT_GEMM_RESIDENT, 0): always the slab-staged kernels
+// pk == nullptr: no packed weights -- every block splits its own slice of B (gemm_bxr.hpp)
 template <class Epi>
-static inline bool launch_bxr(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st, const BxPacked& pk) {
+static inline bool launch_bxr(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st, const BxPacked* pkp) {
   if (!option(TEMP_OPT_GEMM_RESIDENT) || g.K > BXR_MAX_SLABS * 16 || g.K < 72) return false;
   int max_m = 0;
   for (int i = 0; i < count; ++i) max_m = batch.p[i].M > max_m ? batch.p[i].M : max_m;
   BxrGeom rg;
   if (!bxr_plan(g.N, g.K, g.lda, max_m, &rg)) return false;
+  rg.ldb = g.ldb; rg.trans_b = g.trans_b;
+  BxPacked pk;
+  for (int i = 0; i < PANEL_MAXP; ++i) pk.b[i] = pkp ? pkp->b[i] : nullptr;
   static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bxr<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, BXR_LDS_BYTES) == hipSuccess;
   if (!granted) { (void)hipGetLastError(); return false; }
   const size_t lds = (size_t)rg.n_slabs * BXR_G * 192 * 16 + BXR_BIAS_BYTES;
@@ -673,9 +677,9 @@ static inline bool launch_bxr(int kid, const PanelBatch<Epi>& batch, int count, 
 
 template <class Epi>
 int launch_gemm_bx(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, int G, hipStream_t st) {
+  if (launch_bxr(kid, batch, count, g, st, nullptr)) return launch_status();      // short K: weights resident, split inside the block
   BxPacked pk;
   const bool packed = bx_pack_batch(batch, count, g, st, &pk);
-  if (packed && launch_bxr(kid, batch, count, g, st, pk)) return launch_status();
   const BxPacked* pp = packed ? &pk : nullptr;
   switch (G) {
     case 1: launch_bx_g<1, Epi>(kid, batch, count, g, st, pp); break;

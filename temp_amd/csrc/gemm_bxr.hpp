@@ -33,6 +33,7 @@ __device__ unsigned long long g_bxr_rt[256 * 8 * 2];       // s_memrealtime (100
 
 struct BxrGeom {
   int N, K, lda, n_tiles, n_slabs, n_groups;
+  int ldb, trans_b;                                          // B as the caller stores it (blocks split their own slice: no pack launch)
   int per_xcd;                                               // 32-row panels per XCD (of the largest problem)
   unsigned char slot_group[32], slot_rank[32], group_slots[8];
   unsigned char group_t0[8], group_nt[8];                    // first column tile and tile count (<= BXR_G) of every group
@@ -336,7 +337,45 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
   if (p_lo >= p_hi) return;                                   // (uniform) nothing for this XCD in this problem
   // ---- the group's planes of B for all of K: slab s = gt * 192 consecutive 16-byte pieces of the packed matrix (<= 2 per thread);
   // four slabs = up to eight loads in flight per thread (a load-wait-store loop of 20 dependent L2 round trips cost ~25 us)
-  {
+  if (packed.b[blockIdx.y] == nullptr) {
+    // no packed copy: the block cuts its OWN slice of B (<= 4 tiles x 13 slabs x 64 sixteen-byte items = 6.5 items per thread, 36
+    // VALU instructions each) straight from the fp32 matrix -- the pack launch in front of every weights-resident product is gone
+    const float* __restrict__ B = pb.B;
+    const int items = g.n_slabs * gt * 64, ldb = g.ldb;
+    constexpr int UN = 4;
+    for (int i0 = threadIdx.x; i0 < items; i0 += UN * BXR_WAVES * 64) {
+      float4 v0[UN], v1[UN];
+      int dst[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int it = i0 + u * BXR_WAVES * 64;
+        const int itc = min(it, items - 1);
+        const int ln = itc & 63, sj = itc >> 6, sl = sj / gt, j = sj - sl * gt;
+        const int k = 16 * sl + 8 * (ln >> 5), n = (t0 + j) * 32 + (ln & 31);
+        dst[u] = it < items ? sl * (BXR_G * 192) + j * 192 + ln : -1;
+        v0[u] = zero4(); v1[u] = zero4();
+        if (n < g.N && k < g.K) {                               // K % 8 == 0: the octet is entirely in or out
+          if (g.trans_b) {
+            const float* q = B + (size_t)n * ldb + k;
+            v0[u] = ld4(q); v1[u] = ld4(q + 4);
+          } else {
+            const float* q = B + (size_t)k * ldb + n;
+            const size_t l = (size_t)ldb;
+            v0[u] = make_float4(q[0], q[l], q[2 * l], q[3 * l]);
+            v1[u] = make_float4(q[4 * l], q[5 * l], q[6 * l], q[7 * l]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (dst[u] < 0) continue;
+        bx_u32x4 H, Mi, L;
+        bx_split8(v0[u], v1[u], H, Mi, L);
+        bx_u32x4* d = bxr_lds + dst[u];
+        d[0] = H; d[64] = Mi; d[128] = L;
+      }
+    }
+  } else {
     const bx_u32x4* __restrict__ src = packed.b[blockIdx.y] + (size_t)t0 * 192;
     const int per = gt * 192, NS = g.n_slabs;
     const size_t sstride = (size_t)g.n_tiles * 192;

@@ -294,6 +294,8 @@ class _GruChainFn(torch.autograd.Function):
                 cells.append(dict(gi=gi[it.h0:it.h0 + it.n], prev=prev, prev_idx=pidx, dt=dt, w_hh=w_hh, b_hh=b_hh,
                                   h_out=H[it.h0:it.h0 + it.n], row0=it.h0))
             be.gru_cell_fwd_multi(cells, lam, variant, saved)
+        ctx.set_materialize_grads(False)             # states nobody differentiates (the history handed to the all-entity pass in an
+                                                     # encoder-only step) come back as None, not as zero-filled (n, d) tensors
         ctx.save_for_backward(x_all, saved, *[w for ws in W for w in ws])
         ctx.prog, ctx.lam, ctx.variant, ctx.n_rnn, ctx.G, ctx.want = prog, lam, variant, n_rnn, G, want
         ctx.tabs, ctx.packs = tabs, packs
@@ -312,7 +314,7 @@ class _GruChainFn(torch.autograd.Function):
         prog, lam, variant, G = ctx.prog, ctx.lam, ctx.variant, ctx.G
         dev, d, N = x_all.device, x_all.shape[1], prog.n_total
         if ctx.want is None:
-            dH = d_outs[0].contiguous()
+            dH = d_outs[0].contiguous() if d_outs[0] is not None else torch.zeros(N, d, dtype=torch.float32, device=dev)
             up = lambda i, it: dH[it.h0:it.h0 + it.n]
         else:
             given = {i: g.contiguous() for i, g in zip(ctx.want, d_outs) if g is not None}
