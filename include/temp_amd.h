@@ -21,6 +21,14 @@
  *     apart from the explicit switches of temp_set_option() and the bench-only trace),
  *     so forward may run on one thread and backward on PyTorch's autograd thread.
  *   - "nullable" arguments may be NULL.
+ *   - Arithmetic of the dense products (TEMP_OPT_MFMA_BF16X3 = 1, the default): a product C = A . B whose row count (summed
+ *     over the problems of one launch) is >= 16 384 runs on the bf16 matrix pipe as six products of an exact three-way split of
+ *     both fp32 operands (fp32-equivalent accuracy: the dropped terms are below one fp32 rounding per product); below that
+ *     row count the same call runs on the fp32 MFMA instructions.  The two agree to fp32 rounding, not bit for bit, so the
+ *     same layer is bit-different on either side of the 16 384-row line; within one shape every result is bitwise repeatable.
+ *     Non-finite inputs: the fp32 kernels propagate them as IEEE arithmetic does.  In the split kernels a non-finite operand
+ *     (either side) makes every output that depends on it NON-FINITE -- NaN where fp32 arithmetic may give +-inf: the infinite
+ *     piece of the split meets zero pieces of the other operand (inf . 0) -- and leaves all other outputs bit-identical.
  */
 #ifndef TEMP_AMD_H
 #define TEMP_AMD_H

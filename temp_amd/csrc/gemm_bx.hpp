@@ -51,6 +51,11 @@ __device__ __forceinline__ void bx_split8(const float4 a, const float4 b, bx_u32
   bx_split2(b.x, b.y, h, m, l); H[2] = h; M[2] = m; L[2] = l;
   bx_split2(b.z, b.w, h, m, l); H[3] = h; M[3] = m; L[3] = l;
 }
+// Non-finite operands.  A guard in the split (h = +-inf, m = l = 0) does NOT restore IEEE propagation: the six products pair
+// the infinite piece with the OTHER operand's m and l pieces, which are exactly 0 for many finite values (any value with <= 8
+// significant bits), and inf . 0 = NaN.  So the contract is the one stated in include/temp_amd.h: a non-finite operand makes the
+// outputs that depend on it non-finite (NaN where fp32 arithmetic may give +-inf), and nothing else changes
+// (tests/test_gpu_parity_r2.py::test_split_operand_gemm_nonfinite_weights_gpu).
 __device__ __forceinline__ bx_bf16x8 bx_frag(const bx_u32x4 v) { return __builtin_bit_cast(bx_bf16x8, v); }
 
 // acc += w . a with the six significant products, small terms first (w = weights-side fragment, a = activations-side)

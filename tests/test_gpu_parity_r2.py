@@ -955,6 +955,34 @@ def test_large_linear_weights_resident_vs_fp64(hip_backend, M, K, N, trans_b):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K,N,trans_b", [(200, 200, True), (200, 600, True), (600, 200, False)])
+def test_split_operand_gemm_nonfinite_weights_gpu(hip_backend, K, N, trans_b):
+    """Non-finite weights in the split kernels (include/temp_amd.h, Conventions): the output columns that depend on an infinite or
+    NaN weight are non-finite in every row (NaN where fp32 arithmetic gives +-inf: inf meets zero pieces of the other operand),
+    every other column stays equal to the all-finite run bit for bit.  Weights-resident kernel (K = 200, in-block split) and
+    slab-staged kernel (K = 600, pack launch)."""
+    g = torch.Generator().manual_seed(K + N)
+    M = 20000
+    a = (torch.rand(M, K, generator=g) + 0.5).cuda()                     # positive: one infinite weight decides a column's sign
+    b = (torch.randn(N, K, generator=g) * 0.3) if trans_b else (torch.randn(K, N, generator=g) * 0.3)
+    clean = hip_backend.linear(a, b.cuda(), trans_b)
+    bad = b.clone()
+    cols = (3, 77, N - 1)
+    vals = (float("inf"), float("-inf"), float("nan"))
+    for c, v in zip(cols, vals):
+        if trans_b:
+            bad[c, 5] = v
+        else:
+            bad[5, c] = v
+    got = hip_backend.linear(a, bad.cuda(), trans_b)
+    for c in cols:
+        assert not torch.isfinite(got[:, c]).any(), c
+    keep = torch.ones(N, dtype=torch.bool)
+    keep[list(cols)] = False
+    assert torch.equal(got[:, keep.cuda()], clean[:, keep.cuda()])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Ms,K,N", [
     ([184, 120, 0, 200, 184, 96], 10488, 200),     # ICEWS05-15-like d_q = d_scores . all_entities: split over K, two launches
     ([300], 7128, 200),                            # one problem, three row panels
