@@ -12,6 +12,7 @@ from temp_amd import _lib
 from temp_amd import backend as TB
 from temp_amd.snapshot import Snapshot
 from tests.cpu_backend import CpuTestBackend
+from oracle import temp_oracle as O           # checker only (oracle/temp_oracle.py: the restatement pinned by the reference's goldens)
 from tests.encoder_cases import check_G2, check_G4, check_G6, check_G7
 from tests.golden_util import assert_close
 
@@ -104,6 +105,19 @@ def test_rgcn_layer_vs_oracle(case, hip_backend):
     assert_close(gd[2], wd[2], 2e-5, 1e-5 * scale, "d_loop %s" % (case,))
     if bias:
         assert_close(gd[3], wd[3], 2e-5, 1e-5 * scale, "d_bias %s" % (case,))
+    # the ORACLE itself (models/RGCN.py:53-104 restated, autograd for the gradients), not only the test backend
+    # (run in fp64: a hub sums thousands of messages, and two fp32 summation orders differ by more than the 1e-5 bar)
+    if E:
+        og = O.SnapGraph(n, g.src, g.dst, g.rel, np.arange(n))
+        og.nnorm, og.enorm = og.nnorm.double(), og.enorm.double()
+        leaves = [t.double().requires_grad_(True) for t in (h, w, lw)] + ([b.double().requires_grad_(True)] if bias else [])
+        oy = O.rgcn_layer(leaves[0], og, leaves[1], leaves[2], B, leaves[3] if bias else None, 'relu' if act else None)
+        oy.backward(gy.double())
+        f32 = lambda t: t.detach().float()
+        assert_close(got, f32(oy), 1e-5, 5e-6, "rgcn_fwd vs oracle %s" % (case,))
+        assert_close(gd[0], f32(leaves[0].grad), 1e-5, 5e-6, "d_h vs oracle %s" % (case,))
+        assert_close(gd[1], f32(leaves[1].grad), 2e-5, 1e-5 * scale, "d_weight vs oracle %s" % (case,))
+        assert_close(gd[2], f32(leaves[2].grad), 2e-5, 1e-5 * scale, "d_loop vs oracle %s" % (case,))
 
 
 def test_rgcn_fused_gather_ids(hip_backend):
@@ -137,6 +151,13 @@ def test_rgcn_isolated_vs_oracle(n, D, act, bias, hip_backend):
     assert_close(gd[1], wd[1], 2e-5, 1e-5 * scale, "iso d_loop")
     if bias:
         assert_close(gd[2], wd[2], 2e-5, 1e-5 * scale, "iso d_bias")
+    if n:                                                    # the oracle (models/RGCN.py:78-89 restated)
+        eo, lo = e.clone().requires_grad_(True), lw.clone().requires_grad_(True)
+        oy = O.rgcn_layer_isolated(eo, lo, b, 'relu' if act else None)
+        oy.backward(gy)
+        assert_close(got, oy.detach(), 1e-5, 5e-6, "iso fwd vs oracle")
+        assert_close(gd[0], eo.grad, 1e-5, 5e-6, "iso d_e vs oracle")
+        assert_close(gd[1], lo.grad, 2e-5, 1e-5 * scale, "iso d_loop vs oracle")
 
 
 @pytest.mark.parametrize("n,D,variant,learn,use_idx", [
@@ -163,6 +184,11 @@ def test_gru_step_vs_oracle(n, D, variant, learn, use_idx, hip_backend):
     want, saved_c = cpu.gru_fwd(x, prev, idx, dt, 0.1, wb, w_ih, w_hh, b_ih, b_hh, variant)
     got, saved = hip_backend.gru_fwd(cu(x), cu(prev), cu(idx), cu(dt), 0.1, cu(wb), cu(w_ih), cu(w_hh), cu(b_ih), cu(b_hh), variant)
     assert_close(got, want, 1e-5, 2e-6, "gru fwd")
+    if n:                                                    # the oracle (models/RRGCN.py:77-89 / models/GRU_cell.py:18-30 restated)
+        pv = prev if idx is None else prev[idx.long().clamp(min=0)] * (idx >= 0).float().view(-1, 1)
+        hdec = O.decay_hidden(pv, dt, 0.1, (wb[0], wb[1]) if learn else None)
+        oy = (O.gru_type1 if variant == 1 else O.gru_torch)(x, hdec, w_ih, w_hh, b_ih, b_hh)
+        assert_close(got, oy, 1e-5, 2e-6, "gru fwd vs oracle")
     wd = cpu.gru_bwd(x, prev, idx, dt, 0.1, wb, w_ih, w_hh, saved_c, gy, variant)
     gd = hip_backend.gru_bwd(cu(x), cu(prev), cu(idx), cu(dt), 0.1, cu(wb), cu(w_ih), cu(w_hh), saved, cu(gy), variant)
     scale = max(1.0, float(n) ** 0.5)
