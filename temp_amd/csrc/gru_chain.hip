@@ -132,10 +132,14 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
         // with the NEXT slab's plane at once: 3 to 5 rounds (TPW MFMAs each) of L2 latency cover with a single buffer.
         const bx_u32x4* wp = reinterpret_cast<const bx_u32x4*>(R.wf);
         const int NS = NQ >> 1;
-        bx_u32x4 wh[TPW], wm[TPW], wl[TPW];
+        bx_u32x4 wh[TPW] = {}, wm[TPW] = {}, wl[TPW] = {};
+        // (a wave's tile slot past the last tile keeps whatever its registers hold: its products are never stored, and its
+        //  share of the plane stream -- 1/20 of the forward's, 1/8 of the backward's -- stays in L2)
+        const bool dup_loads = (a.dbg & 128) != 0;
         auto wload = [&](bx_u32x4 (&w)[TPW], int sl, int pl) {
 #pragma unroll
-          for (int j = 0; j < TPW; ++j) w[j] = wp[((size_t)(sl * NT + tidx[j]) * 3 + pl) * 64 + lane];
+          for (int j = 0; j < TPW; ++j)
+            if (tval[j] || dup_loads) w[j] = wp[((size_t)(sl * NT + tidx[j]) * 3 + pl) * 64 + lane];
         };
         // Every CU of an XCD walks the same 720 KB of planes; started at the same slab they ask the same L2 lines at the same
         // time.  The walk of a block starts at its own slab (k order of a sum is free; fixed per block, so results stay
@@ -394,10 +398,12 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
         // L2 latency cover.  NQb is a multiple of 4, so the slab count is even.
         const bx_u32x4* wp = reinterpret_cast<const bx_u32x4*>(R.wb);
         const int NS = NQb >> 1;
-        bx_u32x4 wh0[TPWB], wm0[TPWB], wl0[TPWB], wh1[TPWB], wm1[TPWB], wl1[TPWB];
+        bx_u32x4 wh0[TPWB] = {}, wm0[TPWB] = {}, wl0[TPWB] = {}, wh1[TPWB] = {}, wm1[TPWB] = {}, wl1[TPWB] = {};
+        const bool dup_loads = (a.dbg & 128) != 0;
         auto wload = [&](bx_u32x4 (&w)[TPWB], int sl, int pl) {
 #pragma unroll
-          for (int j = 0; j < TPWB; ++j) w[j] = wp[((size_t)(sl * NTb + tidx[j]) * 3 + pl) * 64 + lane];
+          for (int j = 0; j < TPWB; ++j)
+            if (tval[j] || dup_loads) w[j] = wp[((size_t)(sl * NTb + tidx[j]) * 3 + pl) * 64 + lane];
         };
         const int rot = (a.dbg & 64) ? 0 : 2 * ((int)(blockIdx.x >> 3) % (NS >> 1));     // per-block start of the slab walk (see the forward kernel)
         wload(wh0, rot, 0); wload(wm0, rot, 1); wload(wl0, rot, 2);

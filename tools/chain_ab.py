@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""GPU box: A/B of the window-chain kernels' development switches on ONE box (boxes differ by a few per cent), headline shape.
+ChainArgs.dbg = TEMP_OPT_DEBUG >> 8: bit 6 every block starts its W_hh slab walk at slab 0 (round 3), bit 7 a wave's tile slot past
+the last tile loads a duplicate tile's planes (round 3).   python tools/chain_ab.py [--steps 5]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    a = ap.parse_args()
+    from temp_amd import _lib, synthetic
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    w = synthetic.workload("S-gdelt", seed=0)
+    model = bench.build_model(w, dev)
+    model.sample_rng = np.random.default_rng(2)
+    wb = model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0), w["L"], train=True)
+    st = bench.GraphStep(lambda: model.run(wb)[0], list(model.parameters()), graph=False)
+    for bits, what in ((0, "product"), (64, "no slab rotation"), (128, "duplicate-tile loads"), (192, "round 3 (both)"), (0, "product (again)")):
+        lib.temp_set_option(_lib.OPT_DEBUG, bits << 8)
+        for _ in range(2):
+            st.eager()
+        torch.cuda.synchronize()
+        tr = bench.traced_steps(st.eager, a.steps, lib)
+        print("%-26s fwd %7.1f us   bwd %7.1f us" % (what, 1e3 * tr["k_gru_chain_fwd"]["avg_ms"], 1e3 * tr["k_gru_chain_bwd"]["avg_ms"]), flush=True)
+    lib.temp_set_option(_lib.OPT_DEBUG, 0)
+
+
+if __name__ == "__main__":
+    main()
