@@ -879,7 +879,7 @@ def main():
     # a longer replay of the same graph when the timed region was short (the driver's 20 steps are 50 ms: box-to-box noise is larger
     # than the 1-3 % steps a round works on); reported beside the headline, never instead of it
     long_ms = None
-    if rank == 0 and world == 1 and not sharded and a.steps < 200:
+    if rank == 0 and world == 1 and not sharded and a.steps < 200 and a.trace_steps > 0 and not a.no_graph:      # (not in counter / eager runs)
         for _ in range(5):
             step()
         torch.cuda.synchronize()

@@ -53,6 +53,9 @@ def main():
         fam[base][0] += v["launches"]
         fam[base][1] += v["traffic_bytes_per_launch"] * v["launches"]
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else None        # encoder steps the profiled process executed
+    chain = sum(v["launches"] for k, v in out.items() if k.startswith("k_gru_chain_fwd"))
+    if chain:                                                      # one forward chain launch per encoder step: count them instead of trusting the caller
+        steps = chain
     doc = dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1 --no-graph",
                corrections="FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE raw; KiB -> bytes",
                kernels=out, families={k: dict(launches=v[0], traffic_bytes_per_launch=v[1] / v[0]) for k, v in fam.items()})
