@@ -223,7 +223,7 @@ int64_t temp_host_snapshot_pack(int64_t n, int64_t E, const int64_t* src, const 
   w = pack_view(E, src, dst, rel, n, chunk, true, packed + off, sizes + 9, n_partial + 1, out_deg.data(), nullptr, nullptr);
   if (w < 0) return -1;
   off += w;
-  w = pack_view(E, rel, src, dst, n_rel_rows, chunk_rel, false, packed + off, sizes + 18, n_partial + 2, nullptr, rel_chunks, &rank);
+  w = pack_view(E, rel, src, dst, n_rel_rows, chunk_rel, true, packed + off, sizes + 18, n_partial + 2, nullptr, rel_chunks, &rank);
   if (w < 0) return -1;
   off += w;
   for (size_t i = 0; i < rank.size(); ++i) packed[off + (int64_t)i] = rank[i];

@@ -283,13 +283,14 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* 
         const float nn = nnorm[b_l];
         s_l = nn * nn;
       }
+      // Destination runs: the view lists a relation's edges in destination order, so the edges into a hub are one run -- its dz
+      // row (and norm) is read ONCE and, by linearity, the run's source rows are summed before the outer product.
+      unsigned long long starts = 0ull;
+      {
+        const int prev = __shfl_up(b_l, 1);
+        starts = __builtin_amdgcn_ballot_w64(lane < cnt && (lane == 0 || b_l != prev));
+      }
       if (!active) continue;
-      auto edge = [&](int e, float4& xx, float4& g) {
-        const int src = __builtin_amdgcn_readlane(a_l, e), dst = __builtin_amdgcn_readlane(b_l, e);
-        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_l), e));
-        xx = ld4(x + (size_t)src * D + f);
-        g = scale4(ld4(dz + (size_t)dst * D + f), sc);
-      };
       auto mac = [&](const float4 xx, const float4 g) {
         if (S == 1) {
           acc[0].x = fmaf(xx.x, g.x, acc[0].x);
@@ -311,6 +312,33 @@ __global__ void __launch_bounds__(256) k_rgcn_dw_s(TempEdgeView v, const float* 
           acc[2] = fma4(xx.z, g, acc[2]);
           acc[3] = fma4(xx.w, g, acc[3]);
         }
+      };
+      if (2 * __builtin_popcountll(starts) <= cnt) {          // runs of two and more on average: the run walk
+        int e = 0;
+        while (e < cnt) {
+          const unsigned long long later = e < 63 ? (starts >> (e + 1)) << (e + 1) : 0ull;
+          const int end = later ? __builtin_ctzll(later) : cnt;
+          const int dst = __builtin_amdgcn_readlane(b_l, e);
+          const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_l), e));
+          const float4 g = scale4(ld4(dz + (size_t)dst * D + f), sc);
+          auto row = [&](int i) { return ld4(x + (size_t)__builtin_amdgcn_readlane(a_l, i) * D + f); };
+          float4 xs = zero4();
+          int i = e;
+          for (; i + 4 <= end; i += 4) {
+            const float4 x0 = row(i), x1 = row(i + 1), x2 = row(i + 2), x3 = row(i + 3);
+            xs = add4(add4(xs, x0), add4(add4(x1, x2), x3));
+          }
+          for (; i < end; ++i) xs = add4(xs, row(i));
+          mac(xs, g);
+          e = end;
+        }
+        continue;
+      }
+      auto edge = [&](int e, float4& xx, float4& g) {
+        const int src = __builtin_amdgcn_readlane(a_l, e), dst = __builtin_amdgcn_readlane(b_l, e);
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_l), e));
+        xx = ld4(x + (size_t)src * D + f);
+        g = scale4(ld4(dz + (size_t)dst * D + f), sc);
       };
       int e = 0;
       for (; e + 4 <= cnt; e += 4) {

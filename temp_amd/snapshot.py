@@ -88,7 +88,7 @@ class Snapshot:
                 raise ValueError("relation id outside [0, %d)" % n_rel_rows)
             # (a node's edges in relation order: the chunks of a hub are runs of one relation -- see host_planner.cpp)
             v = dict(by_dst=build_view(self.dst, self.src, self.rel, self.n, sort_b=True), by_src=build_view(self.src, self.dst, self.rel, self.n, sort_b=True),
-                     by_rel=build_view(self.rel, self.src, self.dst, n_rel_rows, chunk=_lib.CHUNK_REL),
+                     by_rel=build_view(self.rel, self.src, self.dst, n_rel_rows, chunk=_lib.CHUNK_REL, sort_b=True),   # (a relation's edges in destination order)
                      in_deg=np.bincount(self.dst, minlength=self.n).astype(np.int32),
                      out_deg=np.bincount(self.src, minlength=self.n).astype(np.int32))
             v["rel_chunks"] = np.bincount(v["by_rel"]["chunk_seg"], minlength=n_rel_rows).astype(np.int64)
@@ -179,14 +179,14 @@ class Snapshot:
 
     def device_edge_ids(self, device):
         """[3, E] int32 on `device`: original edge id of every position of the by-dst / by-src / by-rel view (stable sorts of the
-        edge list by (dst, rel) / (src, rel) / rel), uploaded once per snapshot."""
+        edge list by (dst, rel) / (src, rel) / (rel, dst)), uploaded once per snapshot."""
         key = ("eid", str(device))
         t = self._dev.get(key)
         if t is None:
             with _lib.create_lock:
                 t = self._dev.get(key)
                 if t is None:
-                    eid = np.stack([np.lexsort((self.rel, self.dst)), np.lexsort((self.rel, self.src)), np.argsort(self.rel, kind="stable")]).astype(np.int32) \
+                    eid = np.stack([np.lexsort((self.rel, self.dst)), np.lexsort((self.rel, self.src)), np.lexsort((self.dst, self.rel))]).astype(np.int32) \
                         if self.number_of_edges() else np.zeros((3, 0), np.int32)
                     t = _lib.to_device(eid, device)
                     _lib.publish(device)
@@ -367,7 +367,7 @@ def build_view_tiled(seg, a, b, n_seg, tile, chunk=_lib.CHUNK):
     tile = np.asarray(tile, dtype=np.int64)
     n_tile = int(tile.max()) + 1 if tile.shape[0] else 1
     key = tile * n_seg + seg
-    order = np.argsort(key, kind="stable")
+    order = np.lexsort((np.asarray(b, dtype=np.int64), key))                  # inside a (tile, segment) group: ascending b (destination runs)
     counts = np.bincount(key, minlength=n_tile * n_seg).astype(np.int64)      # edges per (tile, seg) group
     ptr = np.concatenate([[0], np.cumsum(counts)])
     nch = (counts + chunk - 1) // chunk
@@ -407,7 +407,7 @@ def by_rel_view(snap, n_rel_rows):
     E, n = snap.number_of_edges(), snap.n
     tiles = E // (REL_GROUP_EDGES * max(n_rel_rows, 1))
     if tiles <= 1 or n == 0:
-        return build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL)
+        return build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL, sort_b=True)
     width = -(-n // tiles)
     return build_view_tiled(snap.rel, snap.src, snap.dst, n_rel_rows, np.asarray(snap.dst, dtype=np.int64) // width, chunk=_lib.CHUNK_REL)
 
@@ -471,7 +471,7 @@ def union_views(snap, n_rel_rows):
     if E // (REL_GROUP_EDGES * max(n_rel_rows, 1)) > 1:                  # GDELT-like: a relation has many edges per snapshot
         views["by_rel"] = _concat_rel_views(lv, no, np.append(eo, E), n_rel_rows)
     else:                                                               # few edges per relation: one global sort (cheap at this size)
-        views["by_rel"] = build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL)
+        views["by_rel"] = build_view(snap.rel, snap.src, snap.dst, n_rel_rows, chunk=_lib.CHUNK_REL, sort_b=True)
     cat = lambda k: np.concatenate([g[k] for g in lv]) if lv else np.zeros(0, np.int32)
     return views, cat("in_deg"), cat("out_deg")
 
