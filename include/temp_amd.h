@@ -305,6 +305,13 @@ int temp_gru_input_gates(int n, int d, int variant, const float* x, const float*
  * are bit-identical to `count` calls of temp_gru_input_gates. */
 int temp_gru_input_gates_multi(int count, const int* ns, int d, int variant, const float* const* xs, const float* const* w_ihs,
                                const float* const* b_ihs, float* const* gis, void* stream);
+/* ... with the rows of problem i gathered: gis[i] row j = xs[i][x_idx[i][j]] . W_ih^T + b_ih (x_idx: HOST array of device int32
+ * tables, an entry may be NULL = rows in order; indices >= 0).  Used to compute the gates of every DISTINCT input row of a
+ * window chain once (TempGruChain.gi_index maps chain rows to gi rows).  Within one arithmetic (Conventions: the 16 384-row
+ * switch looks at the rows of the whole launch) a row's result does not depend on where it is computed: gates[gi_index[i]] is then bit-identical to
+ * temp_gru_input_gates_multi's row i. */
+int temp_gru_input_gates_gather_multi(int count, const int* ns, int d, int variant, const float* const* xs, const int32_t* const* x_idx,
+                                      const float* const* w_ihs, const float* const* b_ihs, float* const* gis, void* stream);
 int temp_gru_cell_fwd(int n, int d, int variant, const float* gi, const float* prev, const int32_t* prev_idx /*nullable*/,
                       const float* dt, float lambda, const float* w_hh, const float* b_hh,
                       float* h_out, float* saved, size_t saved_plane, void* stream);
@@ -370,6 +377,9 @@ typedef struct TempGruChain {
   int32_t n_rnn;
   const float* packed[TEMP_CHAIN_MAX_RNN];   /* temp_gru_chain_pack of each GRU's W_hh */
   const float* b_hh[TEMP_CHAIN_MAX_RNN];
+  const int32_t* gi_index;               /* nullable [N_total]: row of `gi` that holds row i's input gates.  Chain rows that read the
+                                          * same input row share one gi row (temp_gru_input_gates_gather_multi computes each once);
+                                          * NULL: gi has N_total rows, row i's gates in row i.  Forward only: dgi stays per row. */
 } TempGruChain;
 int temp_gru_chain_supported(int d);
 size_t temp_gru_chain_pack_floats(int d);                                   /* floats of one packed W_hh */

@@ -62,7 +62,8 @@ CHAIN_MAX_STEPS = 64
 class TempGruChain(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int32), ("variant", ctypes.c_int32), ("n_panels", ctypes.c_int32), ("n_steps", ctypes.c_int32),
                 ("max_steps", ctypes.c_int32), ("panel", c_vp), ("rows", c_vp), ("sinfo", c_vp), ("dt", c_vp), ("lambda_", ctypes.c_float),
-                ("saved_plane", ctypes.c_size_t), ("n_rnn", ctypes.c_int32), ("packed", c_vp * CHAIN_MAX_RNN), ("b_hh", c_vp * CHAIN_MAX_RNN)]
+                ("saved_plane", ctypes.c_size_t), ("n_rnn", ctypes.c_int32), ("packed", c_vp * CHAIN_MAX_RNN), ("b_hh", c_vp * CHAIN_MAX_RNN),
+                ("gi_index", c_vp)]
 
 
 class TempSubsampleJob(ctypes.Structure):
@@ -121,6 +122,7 @@ SYMBOLS = {
     "temp_decay_rows": (_I, [_I, _I, c_vp, c_vp, _F, c_vp, c_vp]),
     "temp_gru_input_gates": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_input_gates_multi": (_I, [_I, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_input_gates_gather_multi": (_I, [_I, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_cell_fwd": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_gru_cell_bwd": (_I, [_I, _I, _I, c_vp, _SZ, c_vp, c_vp, c_vp, c_vp, _F, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_cell_fwd_multi": (_I, [_I, ctypes.POINTER(TempGruCellFwd), _I, _I, _F, _SZ, c_vp]),

@@ -196,19 +196,27 @@ class HipBackend:
         rc = self.lib.temp_gru_input_gates(x.shape[0], x.shape[1], variant, _ptr(x), _ptr(w_ih), _ptr(b_ih), _ptr(out), _stream())
         _lib.check(rc, "temp_gru_input_gates")
 
-    def gru_input_gates_multi(self, xs, w_ihs, b_ihs, variant, outs):
+    def gru_input_gates_multi(self, xs, w_ihs, b_ihs, variant, outs, x_idx=None):
         """gi_i = x_i . W_ih_i^T + b_ih_i for every (row block, weight set) pair in one launch per four problems
-        (include/temp_amd.h: temp_gru_input_gates_multi)."""
+        (include/temp_amd.h: temp_gru_input_gates_multi); x_idx: per problem an int32 table of the x rows to take (the out
+        block has one row per entry; temp_gru_input_gates_gather_multi)."""
         k = len(xs)
         xs = [_f32(x, "x") for x in xs]
         w_ihs, b_ihs = [_f32(w, "w_ih") for w in w_ihs], [_f32(b, "b_ih") for b in b_ihs]
         d = xs[0].shape[1]
-        for x, w, o in zip(xs, w_ihs, outs):
-            assert x.shape[1] == d and o.is_contiguous() and o.shape == (x.shape[0], w.shape[0]) and w.shape == w_ihs[0].shape
+        idx = [None] * k if x_idx is None else [None if t is None else _i32(t, "x_idx") for t in x_idx]
+        rows = [x.shape[0] if t is None else t.shape[0] for x, t in zip(xs, idx)]
+        for x, w, o, n in zip(xs, w_ihs, outs, rows):
+            assert x.shape[1] == d and o.is_contiguous() and o.shape == (n, w.shape[0]) and w.shape == w_ihs[0].shape
         arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
-        ns = (ctypes.c_int * k)(*[x.shape[0] for x in xs])
-        rc = self.lib.temp_gru_input_gates_multi(k, ns, d, variant, arr(xs), arr(w_ihs), arr(b_ihs), arr(outs), _stream())
-        _lib.check(rc, "temp_gru_input_gates_multi")
+        ns = (ctypes.c_int * k)(*rows)
+        if x_idx is None:
+            rc = self.lib.temp_gru_input_gates_multi(k, ns, d, variant, arr(xs), arr(w_ihs), arr(b_ihs), arr(outs), _stream())
+            _lib.check(rc, "temp_gru_input_gates_multi")
+            return
+        ia = (ctypes.c_void_p * k)(*[None if t is None else t.data_ptr() for t in idx])
+        rc = self.lib.temp_gru_input_gates_gather_multi(k, ns, d, variant, arr(xs), ia, arr(w_ihs), arr(b_ihs), arr(outs), _stream())
+        _lib.check(rc, "temp_gru_input_gates_gather_multi")
 
     def gru_cell_fwd(self, gi, prev, prev_idx, dt, lam, w_hh, b_hh, variant, h_out, saved_all, row0):
         """h_out (n,d) and rows [row0, row0+n) of every plane of saved_all (5, N, d) are written."""
@@ -321,9 +329,12 @@ class HipBackend:
             c.packed[i], c.b_hh[i] = pk.data_ptr(), b.data_ptr()
         return c, keep
 
-    def gru_chain_fwd(self, tabs, gi, lam, variant, packs, b_hhs, h_out, saved_all):
+    def gru_chain_fwd(self, tabs, gi, lam, variant, packs, b_hhs, h_out, saved_all, gi_index=None):
         d = saved_all.shape[2]
         c, keep = self._chain_desc(tabs, d, variant, lam, saved_all.shape[1] * d, packs, b_hhs)
+        if gi_index is not None:
+            assert gi_index.shape[0] == saved_all.shape[1]
+            c.gi_index = _i32(gi_index, "gi_index").data_ptr()
         rc = self.lib.temp_gru_chain_fwd(ctypes.byref(c), _ptr(_f32(gi, "gi")), _ptr(h_out), _ptr(saved_all), _stream())
         _lib.check(rc, "temp_gru_chain_fwd")
 

@@ -175,6 +175,8 @@ class BiDynamicRGCN(DynamicRGCN):
         inst.append(GruInstance(nt, nf + nt + nb, 1, last, tb.prev_idx, tb.dt))
         hist_b, out_b = last, len(inst) - 1
         wb.program = GruProgram(inst)
+        wb.program.x_src = chain                  # x row i is layer-output row chain[i]: the input gates are computed once per
+                                                  # distinct row of a direction (GruProgram.gi_shared)
         assert len(wb.program.groups) <= 2
         wb.out_inst = [out_f, out_b]
         wb.hist_inst = [hist_f, hist_b]

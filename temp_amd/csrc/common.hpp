@@ -155,7 +155,8 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 
 // count <= 4 products  out_i[M_i, N] = bias_i + A_i[M_i, K] . B_i^T  (B_i stored [N, K]) of one shape class in ONE launch (the input
 // gates of both directions of the window chain: the second problem's blocks fill the CUs the first one's tail leaves idle)
-int gemm_bias_multi(int kid, int count, const int* Ms, int N, int K, const float* const* As, int lda, const float* const* Bs, int ldb,
+int gemm_bias_multi(int kid, int count, const int* Ms, int N, int K, const float* const* As, const int32_t* const* a_idxs /*nullable*/, int lda,
+                    const float* const* Bs, int ldb,
                     const float* const* biases, float* const* outs, int ldo, hipStream_t st);
 
 // dst[row, :] = src[row, :] * keep-scale(row, col)   (the masked gradient of a dropped-out self-loop message)

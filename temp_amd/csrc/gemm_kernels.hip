@@ -81,14 +81,14 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
   return launch_gemm_panel(kid, M, N, K, A, lda, a_idx, B, ldb, trans_b, epi, st);
 }
 
-int gemm_bias_multi(int kid, int count, const int* Ms, int N, int K, const float* const* As, int lda, const float* const* Bs, int ldb,
-                    const float* const* biases, float* const* outs, int ldo, hipStream_t st) {
+int gemm_bias_multi(int kid, int count, const int* Ms, int N, int K, const float* const* As, const int32_t* const* a_idxs, int lda,
+                    const float* const* Bs, int ldb, const float* const* biases, float* const* outs, int ldo, hipStream_t st) {
   if (count <= 0 || count > PANEL_MAXP) return TEMP_E_BADARG;
   PanelBatch<EpiAddBiasAct> batch;
   for (int i = 0; i < PANEL_MAXP; ++i) {
     const int k = i < count ? i : 0;
     const EpiAddBiasAct epi{nullptr, 0, nullptr, biases[k], TEMP_ACT_NONE, outs[k], ldo};
-    batch.p[i] = PanelProblem<EpiAddBiasAct>{i < count ? Ms[k] : 0, As[k], nullptr, Bs[k], epi};
+    batch.p[i] = PanelProblem<EpiAddBiasAct>{i < count ? Ms[k] : 0, As[k], a_idxs ? a_idxs[k] : nullptr, Bs[k], epi};
   }
   return launch_gemm_panel_multi(kid, batch, count, N, K, lda, ldb, 1, st);
 }

@@ -30,6 +30,7 @@ struct ChainArgs {
   int D, n_panels, max_steps, dbg;
   const int32_t* panel; const int32_t* rows; const int32_t* sinfo;
   const float* dt;
+  const int32_t* gi_index;
   float lambda;
   size_t plane;
   ChainRnn rnn[TEMP_CHAIN_MAX_RNN];
@@ -285,7 +286,8 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
           const int e = tabb[s * CH_SLOTS + ps * MW + mw];
           erow[ps] = e;
           const bool ok = e >= 0 && cact;
-          const float* src = gi + (ok ? (size_t)(e & CH_ROW_MASK) * G + col : 0);
+          const int er = e & CH_ROW_MASK;
+          const float* src = gi + (ok ? (size_t)(a.gi_index ? a.gi_index[er] : er) * G + col : 0);
           if (VARIANT == TEMP_GRU_TORCH) { g0[ps] = ld4(src); g1[ps] = ld4(src + (ok ? D : 0)); g2[ps] = ld4(src + (ok ? 2 * D : 0)); }
           else { g0[ps] = zero4(); g1[ps] = zero4(); g2[ps] = ld4(src); }
         }
@@ -633,7 +635,7 @@ static ChainArgs chain_args(const TempGruChain* c) {
   ChainArgs a = {};
   const ChainGeom g = chain_geom(c->d);
   a.D = c->d; a.n_panels = c->n_panels; a.max_steps = c->max_steps; a.panel = c->panel; a.rows = c->rows; a.sinfo = c->sinfo; a.dt = c->dt;
-  a.lambda = c->lambda; a.plane = c->saved_plane; a.dbg = option(TEMP_OPT_DEBUG) >> 8;      // development A/B switches (bit 6: no per-block rotation of the slab walk); 0 in every product run
+  a.lambda = c->lambda; a.plane = c->saved_plane; a.gi_index = c->gi_index; a.dbg = option(TEMP_OPT_DEBUG) >> 8;      // development A/B switches (bit 6: no per-block rotation of the slab walk); 0 in every product run
   for (int i = 0; i < c->n_rnn; ++i) {
     a.rnn[i].wf = (const float4*)c->packed[i];
     a.rnn[i].wb = (const float4*)c->packed[i] + (chain_bx(c->d) ? (size_t)(g.NQ >> 1) * g.NT * 192 : (size_t)g.NT * g.NQ * 64);

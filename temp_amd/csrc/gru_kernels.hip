@@ -695,8 +695,8 @@ int temp_gru_input_gates(int n, int d, int variant, const float* x, const float*
                            (hipStream_t)stream);
 }
 
-int temp_gru_input_gates_multi(int count, const int* ns, int d, int variant, const float* const* xs, const float* const* w_ihs,
-                               const float* const* b_ihs, float* const* gis, void* stream) {
+int temp_gru_input_gates_gather_multi(int count, const int* ns, int d, int variant, const float* const* xs, const int32_t* const* x_idx,
+                                      const float* const* w_ihs, const float* const* b_ihs, float* const* gis, void* stream) {
   if (count < 0 || d <= 0 || (count > 0 && (!ns || !xs || !w_ihs || !b_ihs || !gis))) return TEMP_E_BADARG;
   if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
@@ -705,10 +705,16 @@ int temp_gru_input_gates_multi(int count, const int* ns, int d, int variant, con
     if (ns[i] < 0 || !w_ihs[i] || !b_ihs[i] || (ns[i] > 0 && (!xs[i] || !gis[i]))) return TEMP_E_BADARG;
   for (int i0 = 0; i0 < count; i0 += 4) {                    // four problems per launch
     const int c = count - i0 < 4 ? count - i0 : 4;
-    const int rc = gemm_bias_multi(K_GEMM_GRU_GI, c, ns + i0, gi_w, d, xs + i0, d, w_ihs + i0, d, b_ihs + i0, gis + i0, gi_w, (hipStream_t)stream);
+    const int rc = gemm_bias_multi(K_GEMM_GRU_GI, c, ns + i0, gi_w, d, xs + i0, x_idx ? x_idx + i0 : nullptr, d, w_ihs + i0, d, b_ihs + i0,
+                                   gis + i0, gi_w, (hipStream_t)stream);
     if (rc) return rc;
   }
   return TEMP_OK;
+}
+
+int temp_gru_input_gates_multi(int count, const int* ns, int d, int variant, const float* const* xs, const float* const* w_ihs,
+                               const float* const* b_ihs, float* const* gis, void* stream) {
+  return temp_gru_input_gates_gather_multi(count, ns, d, variant, xs, nullptr, w_ihs, b_ihs, gis, stream);
 }
 
 int temp_gru_cell_fwd(int n, int d, int variant, const float* gi, const float* prev, const int32_t* prev_idx, const float* dt, float lambda,

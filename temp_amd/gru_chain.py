@@ -215,6 +215,38 @@ class GruProgram:
                                      sinfo=buf[cuts[2]:cuts[3]], dt_bits=buf[cuts[3]:cuts[4]])
         return tabs
 
+    def gi_shared(self, device):
+        """Input-gate sharing of a program whose x rows repeat (`x_src`, set by the owner of the program: a label per x row,
+        equal labels = equal rows -- e.g. the layer-output row a chain row was gathered from; an entity visited at p positions
+        of a window whose snapshot at those positions is the same appears p times).  The gates are a function of the x row
+        alone, so each group computes them once per DISTINCT row:
+          -> dict(rep [per group: int32 device table, x row (inside the group) of every distinct row],
+                  g0 [per group: first row of the group's block in the shared gi buffer], rows (total distinct rows),
+                  gi_index int32 device [n_total]: gi row of chain row i  (TempGruChain.gi_index))
+        or None when there is nothing to share (no labels, or fewer than 1 row in 8 repeats).  Cached per device."""
+        src = getattr(self, "x_src", None)
+        if src is None:
+            return None
+        c = getattr(self, "_gi_shared", None)
+        if c is not None and c[0] == str(device):
+            return c[1]
+        src = np.asarray(src)
+        reps, g0, index, total = [], [], np.zeros(self.n_total, dtype=np.int32), 0
+        for g in self.groups:
+            assert g["x1"] - g["x0"] == g["h1"] - g["h0"]
+            _, first, inv = np.unique(src[g["x0"]:g["x1"]], return_index=True, return_inverse=True)
+            reps.append(first.astype(np.int32))
+            g0.append(total)
+            index[g["h0"]:g["h1"]] = total + inv.reshape(-1)
+            total += first.size
+        res = None
+        if total * 8 <= self.n_total * 7:
+            buf = _lib.to_device(np.concatenate(reps + [index]), device)
+            cuts = np.cumsum([0] + [r.size for r in reps])
+            res = dict(rep=[buf[cuts[i]:cuts[i + 1]] for i in range(len(reps))], g0=g0, rows=int(total), gi_index=buf[cuts[-1]:])
+        self._gi_shared = (str(device), res)
+        return res
+
     def constants(self, device, d):
         """(zero previous-state row, all -1 row map long enough for any first-position instance), created once per program."""
         key = (str(device), int(d))
@@ -262,8 +294,20 @@ class _GruChainFn(torch.autograd.Function):
         tabs = None
         if CHAIN_KERNELS and hasattr(be, "gru_chain_fwd") and n_rnn <= _lib.CHAIN_MAX_RNN and be.gru_chain_supported(d):
             tabs = prog.chain_tables(dev, want)
-        gi = torch.empty(N, G, dtype=torch.float32, device=dev)
-        if len(prog.groups) > 1 and hasattr(be, "gru_input_gates_multi"):    # both directions' input gates in one launch
+        share = prog.gi_shared(dev) if tabs is not None else None        # gates once per distinct x row (chain kernels only)
+        gi_index = None
+        if share is not None:
+            gi_index = share["gi_index"]
+            gi = torch.empty(share["rows"], G, dtype=torch.float32, device=dev)
+            cut = share["g0"] + [share["rows"]]
+            be.gru_input_gates_multi([x_all[g["x0"]:g["x1"]] for g in prog.groups], [W[g["rnn"]][0] for g in prog.groups],
+                                     [W[g["rnn"]][2] for g in prog.groups], variant, [gi[cut[i]:cut[i + 1]] for i in range(len(prog.groups))],
+                                     x_idx=share["rep"])
+        else:
+            gi = torch.empty(N, G, dtype=torch.float32, device=dev)
+        if share is not None:
+            pass
+        elif len(prog.groups) > 1 and hasattr(be, "gru_input_gates_multi"):    # both directions' input gates in one launch
             be.gru_input_gates_multi([x_all[g["x0"]:g["x1"]] for g in prog.groups], [W[g["rnn"]][0] for g in prog.groups],
                                      [W[g["rnn"]][2] for g in prog.groups], variant, [gi[g["h0"]:g["h1"]] for g in prog.groups])
         else:
@@ -276,7 +320,7 @@ class _GruChainFn(torch.autograd.Function):
         if tabs is not None:
             packs = be.gru_chain_pack_multi([W[r][1] for r in range(n_rnn)]) if hasattr(be, "gru_chain_pack_multi") else \
                 [be.gru_chain_pack(W[r][1]) for r in range(n_rnn)]
-            be.gru_chain_fwd(tabs, gi, lam, variant, packs, [W[r][3] for r in range(n_rnn)], H, saved)
+            be.gru_chain_fwd(tabs, gi, lam, variant, packs, [W[r][3] for r in range(n_rnn)], H, saved, gi_index=gi_index)
         else:
             tens = prog.upload(dev)
             zero, none_idx = prog.constants(dev, d)
@@ -371,6 +415,7 @@ def prepare_program(prog, device, d, n_rnn, want):
     kernels' panel tables for the `want` set the run will ask for, or -- when the program goes through the per-position
     launches -- the row maps of every instance."""
     if chain_kernels_usable(d, n_rnn) and prog.chain_tables(device, tuple(want) if want is not None else None) is not None:
+        prog.gi_shared(device)
         return
     prog.upload(device)
 

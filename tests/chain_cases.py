@@ -38,10 +38,18 @@ def make_rnns(n, d, type1, seed):
     return [GRUCell(input_size=d, hidden_size=d) if type1 else nn.GRU(input_size=d, hidden_size=d, num_layers=1) for _ in range(n)]
 
 
-def run_program(prog, n_x, d, rnns, device, want, type1, seed, chain_kernels=True):
-    """-> (outputs of the wanted instances, d_x, [grads of every GRU parameter])."""
+def run_program(prog, n_x, d, rnns, device, want, type1, seed, chain_kernels=True, x_src=None):
+    """-> (outputs of the wanted instances, d_x, [grads of every GRU parameter]).
+    x_src (int labels, one per x row): the x rows are gathered from a table with one random row per label, so rows with equal
+    labels are equal, d_x is the gradient of that table, and the program is labelled (GruProgram.x_src: the chain path then
+    computes the input gates once per distinct row)."""
     g = torch.Generator().manual_seed(seed)
-    x = (torch.randn(n_x, d, generator=g) * 0.5).to(device).requires_grad_(True)
+    leaf = x = (torch.randn(n_x if x_src is None else int(np.max(x_src)) + 1, d, generator=g) * 0.5).to(device).requires_grad_(True)
+    prog.__dict__.pop("_gi_shared", None)
+    prog.__dict__.pop("x_src", None)
+    if x_src is not None:
+        x = leaf[torch.from_numpy(np.asarray(x_src)).long().to(device)]
+        prog.x_src = np.asarray(x_src)
     mods = [m.to(device) for m in rnns]
     for m in mods:
         m.zero_grad()
@@ -58,7 +66,7 @@ def run_program(prog, n_x, d, rnns, device, want, type1, seed, chain_kernels=Tru
     finally:
         GC.CHAIN_KERNELS = old
     grads = [p.grad.detach().cpu().clone() for m in mods for p in m.parameters()]
-    return [o.detach().cpu() for o in outs], x.grad.detach().cpu(), grads
+    return [o.detach().cpu() for o in outs], leaf.grad.detach().cpu(), grads
 
 
 def check_plan_invariants(prog):

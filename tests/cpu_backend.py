@@ -192,6 +192,11 @@ class CpuTestBackend:
     def gru_input_gates(self, x, w_ih, b_ih, variant, out):
         out.copy_(torch.mm(x.detach(), w_ih.detach().t()) + b_ih.detach())
 
+    def gru_input_gates_multi(self, xs, w_ihs, b_ihs, variant, outs, x_idx=None):
+        for i, (x, w, b, o) in enumerate(zip(xs, w_ihs, b_ihs, outs)):
+            t = None if x_idx is None else x_idx[i]
+            self.gru_input_gates(x if t is None else x[t.long()], w, b, variant, o)
+
     def gru_cell_fwd(self, gi, prev, prev_idx, dt, lam, w_hh, b_hh, variant, h_out, saved_all, row0):
         n, d = h_out.shape
         if prev is None:                                        # zero-state cell
@@ -310,8 +315,10 @@ class CpuTestBackend:
         return (tabs["panel"].view(P, 4).long(), tabs["rows"].view(S, _lib.CHAIN_TRACKS).long(), tabs["sinfo"].view(S, 4).long(),
                 tabs["dt_bits"].view(torch.float32))
 
-    def gru_chain_fwd(self, tabs, gi, lam, variant, packs, b_hhs, h_out, saved_all):
+    def gru_chain_fwd(self, tabs, gi, lam, variant, packs, b_hhs, h_out, saved_all, gi_index=None):
         panel, rows, sinfo, dt = self._chain_tables(tabs)
+        if gi_index is not None:                   # TempGruChain.gi_index: chain rows that share an input row share a gi row
+            gi = gi[gi_index.long()]
         d = saved_all.shape[2]
         mask = _lib.CHAIN_HAS_PREV - 1
         for rnn, s0, ns, _ in panel.tolist():

@@ -55,6 +55,42 @@ def test_chain_tables_reproduce_per_position_path(type1, want):
         assert_close(x, y, 1e-4, 1e-5, "GRU parameter gradient")
 
 
+def shared_labels(prog, n_x, n_labels, seed):
+    """x-row labels with many repeats inside each group of a program (an entity whose snapshot row is shared by positions)."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, n_labels, n_x)
+
+
+@pytest.mark.parametrize("type1", [False, True])
+def test_shared_input_gates_reproduce_per_row_gates(type1):
+    """GruProgram.gi_shared / TempGruChain.gi_index: a program whose x rows repeat computes the input gates once per distinct
+    row of a group and the chain reads them through gi_index -- the same states and gradients as the per-position path, which
+    computes the gates of every row."""
+    d = 16
+    prog, n_x = random_program(9)
+    labels = shared_labels(prog, n_x, n_x // 3, 5)
+    rnns = make_rnns(2, d, type1, 3)
+    a = run_program(prog, n_x, d, rnns, torch.device("cpu"), None, type1, 11, chain_kernels=True, x_src=labels)
+    sh = prog.gi_shared(torch.device("cpu"))
+    assert sh is not None and sh["rows"] < prog.n_total
+    idx = sh["gi_index"].numpy()
+    for gi, g in enumerate(prog.groups):                       # gi_index: per group, equal labels <=> equal gi rows; rep points at one of them
+        lab = labels[g["x0"]:g["x1"]]
+        loc = idx[g["h0"]:g["h1"]] - sh["g0"][gi]
+        assert loc.min() == 0 and loc.max() == len(np.unique(lab)) - 1
+        assert np.array_equal(lab[sh["rep"][gi].numpy()][loc], lab)
+    b = run_program(prog, n_x, d, rnns, torch.device("cpu"), None, type1, 11, chain_kernels=False, x_src=labels)
+    assert getattr(prog, "_gi_shared", None) is None          # the per-position path never asks
+    for x, y in zip(a[0], b[0]):
+        assert_close(x, y, 1e-5, 1e-6, "states")
+    assert_close(a[1], b[1], 1e-5, 1e-6, "d_x")
+    for x, y in zip(a[2], b[2]):
+        assert_close(x, y, 1e-4, 1e-5, "GRU parameter gradient")
+    prog.x_src = np.arange(n_x)                                # nothing repeats: no sharing
+    prog.__dict__.pop("_gi_shared", None)
+    assert prog.gi_shared(torch.device("cpu")) is None
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_chain_tracks_planner_library_matches_numpy(seed):
     """temp_host_chain_tracks (C++) == GruProgram._chain_plan_numpy, bit for bit: random chains with births, deaths, re-entries

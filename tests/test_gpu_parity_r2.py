@@ -306,6 +306,59 @@ def test_chain_kernels_vs_reference_and_per_position_path(d, type1, kw, want):
             assert_close(a, b, 1e-4, 2e-5 * max(1.0, float(b.abs().max())), "GRU parameter gradient vs " + name)
 
 
+@pytest.mark.parametrize("d,type1", [(200, False), (40, True)])
+def test_chain_shared_input_gates_gpu(d, type1):
+    """TempGruChain.gi_index + temp_gru_input_gates_gather_multi: a program whose x rows repeat (an entity whose snapshot row
+    serves several positions) computes the gates once per distinct row.  States, d_x and the GRU gradients against the
+    per-position launches (gates of every row); and the shared run against the unshared chain run: the states are BIT-identical
+    (a gi row does not depend on where in the launch it is computed; both gate GEMMs sit below the 16 384-row switch)."""
+    from tests.chain_cases import make_rnns, random_program, run_program
+    prog, n_x = random_program(23, n_chain=2, K=7, E=300, lo=100, hi=300)
+    labels = np.random.default_rng(3).integers(0, n_x // 3, n_x)
+    rnns = make_rnns(2, d, type1, 5)
+    shared = run_program(prog, n_x, d, rnns, DEV, None, type1, 17, chain_kernels=True, x_src=labels)
+    sh = prog.gi_shared(DEV)
+    assert sh is not None and sh["rows"] * 8 <= prog.n_total * 7
+    steps = run_program(prog, n_x, d, rnns, DEV, None, type1, 17, chain_kernels=False, x_src=labels)
+    for a, b in zip(shared[0], steps[0]):
+        assert_close(a, b, 1e-4 if type1 else 1e-5, 2e-5 if type1 else 2e-6, "states vs per-position launches")
+    assert_close(shared[1], steps[1], 1e-4, 2e-5 * max(1.0, float(steps[1].abs().max())), "d_x")
+    for a, b in zip(shared[2], steps[2]):
+        assert_close(a, b, 1e-4, 2e-5 * max(1.0, float(b.abs().max())), "GRU parameter gradient")
+    # the same rows without the labels: every row's gates computed, same chain kernels
+    g = torch.Generator().manual_seed(17)
+    leaf = (torch.randn(int(labels.max()) + 1, d, generator=g) * 0.5)
+    from temp_amd import gru_chain as GC
+    prog.__dict__.pop("_gi_shared", None)
+    prog.__dict__.pop("x_src", None)
+    out = GC.gru_chain(leaf[torch.from_numpy(labels).long()].to(DEV), prog, [m.to(DEV) for m in rnns], 0.1, type1, None)
+    for i, it in enumerate(prog.inst):
+        assert torch.equal(out[it.h0:it.h0 + it.n].cpu(), shared[0][i]), i
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gru_input_gates_gather_multi_gpu(variant, hip_backend):
+    """temp_gru_input_gates_gather_multi == temp_gru_input_gates_multi on the rows gathered beforehand (bit-identical: the same
+    kernels on the same rows), with repeats, a NULL table next to real ones, row counts on both sides of the split switch."""
+    from temp_amd import _lib
+    D = 200
+    G = 3 * D if variant == _lib.GRU_TORCH else D
+    gen = torch.Generator(device="cpu").manual_seed(77 + variant)
+    for rows, picks in (((50000, 41000), (30000, 20000)), ((900, 400, 77), (300, None, 500))):
+        xs = [torch.randn(n, D, generator=gen).to(DEV) for n in rows]
+        ws = [((torch.rand(G, D, generator=gen) - 0.5) * 0.3).to(DEV) for _ in rows]
+        bs = [((torch.rand(G, generator=gen) - 0.5) * 0.3).to(DEV) for _ in rows]
+        idx = [None if k is None else torch.randint(0, n, (k,), generator=gen).to(torch.int32).to(DEV) for n, k in zip(rows, picks)]
+        taken = [x if t is None else x[t.long()].contiguous() for x, t in zip(xs, idx)]
+        want = [torch.empty(t.shape[0], G, device=DEV) for t in taken]
+        hip_backend.gru_input_gates_multi(taken, ws, bs, variant, want)
+        got = [torch.full((t.shape[0], G), float("nan"), device=DEV) for t in taken]
+        hip_backend.gru_input_gates_multi(xs, ws, bs, variant, got, x_idx=idx)
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert torch.equal(a, b), (rows, k, float((a - b).abs().max()))
+
+
 def test_chain_kernels_bitwise_repeatable():
     from tests.chain_cases import make_rnns, random_program, run_program
     prog, n_x = random_program(41, n_chain=2, K=8, E=500, lo=300, hi=500)
