@@ -79,11 +79,15 @@ class HipBackend:
         return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
     # ---- RGCN layer ----------------------------------------------------------------------------
-    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act, drop=None):
+    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act, drop=None, out=None):
+        """out: optional contiguous (n_nodes, d_out) fp32 destination (e.g. a row range of a larger matrix)."""
         h, weight, loop_w, bias = _f32(h, "h"), _f32(weight, "weight"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
         h_ids = _i32(h_ids, "h_ids")
         d_in, d_out = loop_w.shape
-        out = torch.empty(dg.n_nodes, d_out, dtype=torch.float32, device=h.device)
+        if out is None:
+            out = torch.empty(dg.n_nodes, d_out, dtype=torch.float32, device=h.device)
+        elif out.shape != (dg.n_nodes, d_out) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != h.device:
+            raise _lib.TempAmdError("rgcn_fwd: `out` must be a contiguous fp32 (n_nodes, d_out) matrix on the layer's device")
         nb = self.lib.temp_rgcn_fwd_workspace(dg.ref(), d_out)
         ws = self._ws(nb, h.device)
         rc = self.lib.temp_rgcn_fwd(dg.ref(), _ptr(h), _ptr(h_ids), d_in, d_out, num_bases, weight.shape[0], _ptr(weight),

@@ -55,6 +55,7 @@ class DynamicRGCN(TKG_Module):
         self.use_batched_path = True
         self.use_gru_chain = True
         self.dedup_snapshots = True
+        self.use_rec_stack = True             # reference-default flags (both layers recurrent): one autograd node (rec_stack.py)
         self.device_subsample = True          # training-time edge subsets drawn and applied on the GPU (host sampler when False)
 
     def build_model(self):
@@ -70,6 +71,18 @@ class DynamicRGCN(TKG_Module):
         enc = self.ent_encoder
         return (self.use_batched_path and enc.rec_only_last_layer and isinstance(enc.layer_2, GRRGCNLayer)
                 and not (enc.layer_2.post_aggregation or enc.layer_2.post_ensemble or enc.layer_2.impute))
+
+    def _can_stack(self):
+        """Both layers recurrent (the reference's default: no --rec-only-last-layer) on the plain uni-directional GRU model:
+        the position loop runs as ONE autograd node with layer 1's RGCN and all GRU GEMMs that do not depend on the
+        recurrence hoisted out of it (rec_stack.py).  Anything else keeps the reference-granular loop."""
+        enc = self.ent_encoder
+        l1, l2 = enc.layer_1, enc.layer_2
+        return (type(self) is DynamicRGCN and self.use_rec_stack and self.use_batched_path and not enc.rec_only_last_layer
+                and isinstance(l1, GRRGCNLayer) and isinstance(l2, GRRGCNLayer) and not l1._extra() and not l2._extra()
+                and l1.decay_spec() is None and l2.decay_spec() is None and not enc.use_time_embedding
+                and getattr(l1, "num_layers", 1) == 1 and l1._post_act is None and l2._post_act is None
+                and l1.inv_temperature == l2.inv_temperature)
 
     def _gather_prev(self, prev_out, idx_t, n):
         if prev_out is None:
@@ -137,6 +150,19 @@ class DynamicRGCN(TKG_Module):
         _, out = self._encode_step(wb.target, first, second)
         return out, (first, second)
 
+    def _run_stack(self, wb):
+        """The same loop as _run_generic as one autograd node (rec_stack.py): layer 1's RGCN over the union of the distinct
+        snapshots, then per position cell 1 -> RGCN 2 -> cell 2; both cells read h2 of the position before."""
+        from .rec_stack import rec_stack
+        enc, dev = self.ent_encoder, self._device()
+        y1 = enc.layer_1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
+        if wb.visit_rows is not None:
+            y1 = TF.gather_rows(y1, wb.visit_rows, wb.visit_inv)
+        graphs = [st.batched().device_graph(dev, 2 * self.num_rels) for st in wb.steps]
+        got = rec_stack(y1, wb.program, graphs, enc.layer_1.rnn, enc.layer_2, self._chain_want(wb))
+        hist = got[1] if wb.hist_inst >= 0 else None
+        return got[0], (hist, hist)
+
     # ---------------------------------------------------------------------------------------------
     # batched path
     # ---------------------------------------------------------------------------------------------
@@ -203,6 +229,7 @@ class DynamicRGCN(TKG_Module):
         tgt = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
         wb.target = self._target_step(wb.plan, wb.rows, tgt)
         wb.batched = self._can_batch()
+        wb.stack = not wb.batched and self._can_stack()
         wb.steps = wb.plan.steps + [wb.target]
         self._upload(wb, dev)
         if train:
@@ -212,7 +239,7 @@ class DynamicRGCN(TKG_Module):
     def _upload(self, wb, dev):
         wb.program = None
         wb.visit_rows = wb.visit_rows_host = None
-        if wb.batched:
+        if wb.batched or getattr(wb, "stack", False):
             if self.dedup_snapshots:
                 wb.g_all, vr, wb.total_rows = concat_steps_dedup(wb.steps)
                 wb.visit_rows_host = vr                  # the device copy + its inverse only where `run` gathers by them
@@ -224,7 +251,13 @@ class DynamicRGCN(TKG_Module):
             wb.ids_all = _lib.to_device(wb.g_all.gids.astype(np.int32), dev)
             wb.ids_inv = TF.gather_inverse(wb.g_all.gids, self.num_ents, dev)        # static ids: deterministic embedding gradient
             wb.g_all.device_graph(dev, 2 * self.num_rels)
-            if self._can_chain():
+            if getattr(wb, "stack", False):          # layer 2 runs per position: every position's own union graph as well
+                for st in wb.steps:
+                    st.batched().device_graph(dev, 2 * self.num_rels)
+                self._build_program(wb)
+                wb.program.upload(dev)
+                wb.program.constants(dev, self.embed_size)
+            elif self._can_chain():
                 self._build_program(wb)
                 prepare_program(wb.program, dev, self.embed_size, len(wb.out_inst), self._chain_want(wb))
         else:
@@ -240,6 +273,8 @@ class DynamicRGCN(TKG_Module):
 
     def run(self, wb):
         """Device work of one encoder pass -> (target rows (sum n_b, D), final history outputs)."""
+        if getattr(wb, "stack", False):
+            return self._run_stack(wb)
         return (self._run_batched if wb.batched else self._run_generic)(wb)
 
     def encode(self, t_list, seq_len, train=True, target_edge_ids=None):

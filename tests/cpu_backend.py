@@ -69,7 +69,10 @@ class CpuTestBackend:
     name = "cpu-test"
 
     # ---- RGCN ---------------------------------------------------------------------------------
-    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act, drop=None):
+    def rgcn_fwd(self, dg, h, h_ids, weight, loop_w, bias, num_bases, act, drop=None, out=None):
+        if out is not None:
+            out.copy_(self.rgcn_fwd(dg, h, h_ids, weight, loop_w, bias, num_bases, act, drop))
+            return out
         h, weight, loop_w = h.detach(), weight.detach(), loop_w.detach()
         d_in, d_out = loop_w.shape
         si, so = d_in // num_bases, d_out // num_bases

@@ -247,6 +247,20 @@ def test_window_loss_and_grads_golden_gpu(name):
     check_window(name, DEV)
 
 
+def test_default_flags_position_loop_golden_gpu():
+    """The reference's default flags (both layers recurrent; G10_uni_grrgcn) through the reference-granular loop of
+    RRGCN.forward calls; the test above takes the same golden through the one-node loop (temp_amd/rec_stack.py)."""
+    m = check_window("G10_uni_grrgcn", DEV, stack=False)
+    assert m._can_stack() is False
+
+
+@pytest.mark.parametrize("type1,width", [(False, None), (True, None), (False, 200)])
+def test_default_flags_stack_equals_generic_gpu(type1, width):
+    """(width 200: the split-operand GEMMs and the 200-wide cell kernels; 100 bases of 2 x 2 blocks)"""
+    from tests.window_cases import check_stack_equals_generic
+    check_stack_equals_generic("G10_uni_grrgcn", DEV, type1, width)
+
+
 @pytest.mark.parametrize("name", ["G10_uni_grrgcn_rol", "G10_bi_grrgcn_rol"])
 def test_batched_equals_generic_gpu(name):
     check_batched_equals_generic(name, DEV)

@@ -84,6 +84,16 @@ def test_batched_equals_generic(name):
     check_batched_equals_generic(name, torch.device("cpu"))
 
 
+def test_default_flags_position_loop_golden():
+    check_window("G10_uni_grrgcn", torch.device("cpu"), stack=False)
+
+
+@pytest.mark.parametrize("type1", [False, True])
+def test_default_flags_stack_equals_generic(type1):
+    from tests.window_cases import check_stack_equals_generic
+    check_stack_equals_generic("G10_uni_grrgcn", torch.device("cpu"), type1)
+
+
 def test_static_rgcn_golden():
     check_static(torch.device("cpu"))
 

@@ -56,7 +56,7 @@ def state_dict_from_oracle(model):
     return sd
 
 
-def build_window_model(z, device, batched=True, chain=True):
+def build_window_model(z, device, batched=True, chain=True, stack=True):
     s = slice_snapshots()
     module, rec_only, D, B, L = str(z["module"]), bool(z["rec_only"]), int(z["D"]), int(z["B"]), int(z["L"])
     cfg = dict(module=module, n_bases=B, inv_temperature=0.1, rec_only_last_layer=rec_only, use_time_embedding=bool(z["te"]))
@@ -71,6 +71,7 @@ def build_window_model(z, device, batched=True, chain=True):
     m.load_state_dict(state_dict_from_oracle(model), strict=True)
     m.use_batched_path = batched
     m.use_gru_chain = chain
+    m.use_rec_stack = stack
     return m.to(device)
 
 
@@ -81,9 +82,9 @@ def window_inputs(z):
     return edge_ids, samples
 
 
-def check_window(name, device, batched=True):
+def check_window(name, device, batched=True, stack=True):
     z = load(name)
-    m = build_window_model(z, device, batched)
+    m = build_window_model(z, device, batched, stack=stack)
     edge_ids, samples = window_inputs(z)
     t_list = torch.tensor([int(t) for t in z["t_list"]])
     loss = m(t_list, target_edge_ids=edge_ids, samples=samples)
@@ -131,6 +132,41 @@ def check_batched_equals_generic(name, device):
             assert_close(a, b, 1e-5, 2e-6, name + " batched vs generic")
         assert_close(outs[0][1], other[1], 5e-5, 3e-6, name + " d_ent batched vs generic")
         assert_close(outs[0][2], other[2], 5e-5, 3e-6, name + " d_weight batched vs generic")
+
+
+def check_stack_equals_generic(name, device, type1=False, width=None):
+    """Both layers recurrent (the reference's default flags): the one-node position loop (temp_amd/rec_stack.py) must
+    reproduce the reference-granular loop of RRGCN.forward calls -- loss, embedding / relation gradients and the gradient of
+    every encoder parameter -- on the golden's windows, edge subsamples and negative samples."""
+    z = load(name)
+    assert not bool(z["rec_only"])
+    edge_ids, samples = window_inputs(z)
+    t_list = torch.tensor([int(t) for t in z["t_list"]])
+    res = []
+    for stack in (False, True):
+        if type1 or width:                         # (no golden for the type-1 cell / this width at window level: same seed, both paths)
+            s = slice_snapshots()
+            D, B, L = int(width or z["D"]), (int(width) // 2 if width else int(z["B"])), int(z["L"])
+            args = make_args(module=str(z["module"]), rec_only_last_layer=False, embed_size=D, hidden_size=D, n_bases=B, train_seq_len=L,
+                             test_seq_len=L, negative_rate=int(z["neg"]), type1=type1)
+            torch.manual_seed(11)
+            m = DynamicRGCN(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+            for k, p in m.named_parameters():      # the cell draws its weights from N(0, 1) like the reference's: two stacked recurrent
+                if "rnn" in k and type1:           # layers over 8 positions amplify fp32 summation-order noise to 3e-4 of the gradients;
+                    p.data.mul_(0.2)               # at a fifth of the scale the two paths agree to 1e-7 (same arithmetic, other order)
+        else:
+            m = build_window_model(z, device, True)
+        m.use_rec_stack = stack
+        wb = m.prepare(t_list, int(z["L"]), True, edge_ids)
+        assert bool(wb.stack) == stack and not wb.batched and (wb.program is not None) == stack
+        loss = m.run_loss(wb, samples)
+        loss.backward()
+        res.append((loss.detach().cpu(), {k: v.grad.detach().cpu().clone() for k, v in m.named_parameters() if v.grad is not None}))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0.item() - l1.item()) < 2e-5 * abs(l0.item()), (l0.item(), l1.item())
+    assert set(g0) == set(g1) and len(g0) >= 10
+    for k in g0:
+        assert_close(g1[k], g0[k], 1e-4, 3e-6 * max(1.0, float(g0[k].abs().max())), name + " stack vs generic: d_" + k)
 
 
 def check_static(device):
