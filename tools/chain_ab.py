@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: A/B of the window-chain kernels' development switches on ONE box (boxes differ by a few per cent), headline shape.
 ChainArgs.dbg = TEMP_OPT_DEBUG >> 8: bit 6 every block starts its W_hh slab walk at slab 0 (round 3), bit 7 a wave's tile slot past
-the last tile loads a duplicate tile's planes (round 3).   python tools/chain_ab.py [--steps 5]"""
+the last tile loads a duplicate tile's planes (round 3).  Then the input gates once per distinct row (GruProgram.gi_shared) against
+the gates of every chain row.  (Non-temporal loads / stores of the row streams were tried the same way: +-3 %, inside the run-to-run
+spread -- not kept.)   python tools/chain_ab.py [--steps 5]"""
 import argparse
 import os
 import sys
@@ -34,6 +36,22 @@ def main():
         tr = bench.traced_steps(st.eager, a.steps, lib)
         print("%-26s fwd %7.1f us   bwd %7.1f us" % (what, 1e3 * tr["k_gru_chain_fwd"]["avg_ms"], 1e3 * tr["k_gru_chain_bwd"]["avg_ms"]), flush=True)
     lib.temp_set_option(_lib.OPT_DEBUG, 0)
+    # input gates once per distinct row (GruProgram.gi_shared) against gates of every chain row
+    prog = wb.program
+    src = prog.x_src
+    for share in (True, False, True):
+        prog.__dict__.pop("_gi_shared", None)
+        if share:
+            prog.x_src = src
+        else:
+            prog.__dict__.pop("x_src", None)
+        for _ in range(2):
+            st.eager()
+        torch.cuda.synchronize()
+        tr = bench.traced_steps(st.eager, a.steps, lib)
+        gi = [v for k, v in tr.items() if "gru_gi" in k]
+        print("shared input gates %-5s  fwd %7.1f us   gi GEMM %7.1f us   step kernels %.3f ms" % (
+            share, 1e3 * tr["k_gru_chain_fwd"]["avg_ms"], 1e3 * sum(v["ms_per_step"] for v in gi), sum(v["ms_per_step"] for v in tr.values())), flush=True)
 
 
 if __name__ == "__main__":

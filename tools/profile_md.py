@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Write profiles/<tag>_bench_kernel_stats.{md,csv} from a rocprofv3 --kernel-trace --stats run of bench.py.
-    python tools/profile_md.py <stats.csv> <bench_line.json> <tag> "<command>" <process_steps>
+    python tools/profile_md.py <stats.csv> <bench_line.json> <tag> "<command>" <process_steps | auto>
 """
 import csv
 import json
@@ -16,9 +16,11 @@ def short(name):
 
 
 def main():
-    stats, line, tag, cmd, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
+    stats, line, tag, cmd, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5]
     d = json.loads(open(line).read().strip().splitlines()[-1])
     rows = list(csv.DictReader(open(stats)))
+    # "auto": one k_gru_chain_fwd launch per encoder step of the process
+    steps = sum(int(x["Calls"]) for x in rows if "k_gru_chain_fwd" in x["Name"]) if steps == "auto" else int(steps)
     shutil.copy(stats, "profiles/%s_bench_kernel_stats.csv" % tag)
     json.dump(d, open("profiles/%s_bench_line.json" % tag, "w"), indent=1)
     r = d["roofline"]
