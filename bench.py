@@ -851,7 +851,10 @@ def main():
                 roof["traffic_source"] = "static: profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)"
                 roof["algorithmic_per_launch"] = cst["flops" if roof["bound"] == "mfma" else "bytes"] / max(tr[dom]["launches_per_step"], 1e-9)
         roof.update(avg_launch_ms=tr[dom]["avg_ms"], launches_per_step=tr[dom]["launches_per_step"],
-                    share_of_kernel_time=tr[dom]["ms_per_step"] / total_ms, traced_kernel_ms_per_step=total_ms)
+                    share_of_kernel_time=tr[dom]["ms_per_step"] / total_ms, traced_kernel_ms_per_step=total_ms,
+                    timing="HIP events around every launch (library event trace on the launch stream) of %d EAGER steps run right after the "
+                           "timed region; inside the HIP-graph replays of the timed region the same kernel runs 5-10 %% faster "
+                           "(rocprofv3, profiles/r04_bench_kernel_stats.md and r04_step_sequence.txt; tools/tn_timing_probe.py)" % a.trace_steps)
         # whole-step view against the HBM roofline with SURVEY 8d's byte model (2 RGCN layers + 1 GRU cell, fwd+bwd, fp32, int32 ids):
         #   per edge 2*(12D+24) B, per RGCN node row 2*(20D+16) B, per GRU row 32D+4 B.
         # (a) as the survey states it, per snapshot-edge VISIT (every visit pays its RGCN bytes), and
