@@ -458,7 +458,7 @@ def shbm_main(a, lib, device):
                config=dict(workload="S-hbm", nodes=n, edges=E, relations=R, embed=D, n_bases=B, host_prepare_s=prep,
                            what="one RGCN layer fwd+bwd on one snapshot (the full window in this regime: --workload S-hbm-window)"),
                roofline=roof, kernels=kernels, cpu_baseline=None)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 class GraphStep:
@@ -636,6 +636,26 @@ def _cpu_model():
     return "unknown"
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """stdout carries ONE line, the result: libraries that write to file descriptor 1 on their own (RCCL prints a version banner
+    when a communicator is created -- every multi-GPU run, and the one-rank sharded measurement of `extra`) are pointed at
+    stderr for the rest of the process, and emit() writes the JSON line to the original stdout."""
+    global _JSON_OUT
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    _JSON_OUT = os.fdopen(real, "w")
+
+
+def emit(obj):
+    f = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    f.write(json.dumps(obj) + "\n")
+    f.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -676,6 +696,7 @@ def main():
     a = ap.parse_args()
     if a.cpu_probe:
         return cpu_probe_main(a)
+    claim_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -704,10 +725,10 @@ def main():
     if a.workload == "S-hbm-window":                 # the HBM-regime window on its own (profiling runs): same object as extra.hbm_window
         if rank == 0:
             r = hbm_window(a, device, lib)
-            print(json.dumps(dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=15, one full bi window in the HBM regime", value=r["edges_per_s"], unit="edges/s",
+            emit(dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=15, one full bi window in the HBM regime", value=r["edges_per_s"], unit="edges/s",
                                   n_gpus=1, steps=r["steps"], warmup=1, ms_per_step=r["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None,
                                   dtype="f32", data="synthetic", config=dict(workload="S-hbm-window", **{k: r[k] for k in ("nodes_per_snapshot", "edges_per_snapshot", "relations", "embed", "edge_visits_per_step", "what")}),
-                                  roofline=r["roofline"], kernels=r["kernels"], cpu_baseline=None, detail=r)), flush=True)
+                                  roofline=r["roofline"], kernels=r["kernels"], cpu_baseline=None, detail=r))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -952,13 +973,13 @@ def main():
                                fp32_mfma_ms_per_step=fp32_ms, ms_per_step_400_replays=long_ms),
                    roofline=roof, cpu_baseline=cpu, north_star_sharded=ns_result, extra=extra)
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
-        # that the JSON line is the LAST line of stdout
+        # that the JSON line is the LAST (and, with claim_stdout, the only) line of stdout
         sys.stdout.flush()
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
