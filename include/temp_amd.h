@@ -340,6 +340,16 @@ size_t temp_gru_weight_grads_workspace(int n, int d, int variant);
 int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float* hdec, const float* dgi, const float* dgh,
                           const float* w_ih, float* d_x /*nullable*/, float* d_w_ih, float* d_w_hh, float* d_b_ih, float* d_b_hh,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The same for `count` <= 4 GRUs of one width in ONE weight-gradient launch + ONE reduction + ONE d_x launch (both directions of a
+ * bidirectional window chain, models/BiRRGCN.py:206-221): d_w = [2 count, 3d, d] holds d_W_ih_0, d_W_hh_0, d_W_ih_1, ...,
+ * d_b = [2 count, 3d] the bias gradients in the same order; xs / hdecs / dgis / dghs / w_ihs / d_xs are HOST arrays of device
+ * pointers (a d_xs entry may be NULL).  nn.GRU gate layout only; TEMP_E_UNSUPPORTED (nothing launched) for shapes that need the
+ * per-GRU call (type-1 cell, small row counts, a GRU whose rows all start from the zero state: hdecs[i] NULL).  Same sums as the
+ * per-GRU call up to the order of the row slices. */
+size_t temp_gru_weight_grads_multi_workspace(int count, const int* ns, int d, int variant);
+int temp_gru_weight_grads_multi(int count, const int* ns, int d, int variant, const float* const* xs, const float* const* hdecs,
+                                const float* const* dgis, const float* const* dghs, const float* const* w_ihs, float* const* d_xs,
+                                float* d_w, float* d_b, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Persistent window chain: ALL positions of the recurrence in ONE launch per direction of time.

@@ -129,6 +129,8 @@ SYMBOLS = {
     "temp_gru_cell_bwd_multi": (_I, [_I, ctypes.POINTER(TempGruCellBwd), _I, _I, _F, _SZ, c_vp]),
     "temp_gru_weight_grads_workspace": (_SZ, [_I, _I, _I]),
     "temp_gru_weight_grads": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
+    "temp_gru_weight_grads_multi_workspace": (ctypes.c_size_t, [_I, c_vp, _I, _I]),
+    "temp_gru_weight_grads_multi": (_I, [_I, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "temp_gru_chain_supported": (_I, [_I]),
     "temp_gru_chain_pack_floats": (_SZ, [_I]),
     "temp_gru_chain_pack": (_I, [_I, c_vp, c_vp, c_vp]),

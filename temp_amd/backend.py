@@ -364,6 +364,32 @@ class HipBackend:
         _lib.check(rc, "temp_gru_weight_grads")
         return d_w_ih, d_w_hh, d_b_ih, d_b_hh
 
+    def gru_weight_grads_multi(self, xs, hdecs, dgis, dghs, w_ihs, variant, d_xs):
+        """Weight / bias gradients and d_x of SEVERAL GRUs of one width in one weight-gradient launch (include/temp_amd.h:
+        temp_gru_weight_grads_multi) -> [(d_w_ih, d_w_hh, d_b_ih, d_b_hh)] per GRU, or None when the library takes this shape
+        through the per-GRU call (nothing launched)."""
+        k = len(xs)
+        if k < 2 or k > 4 or variant != _lib.GRU_TORCH or any(h is None for h in hdecs):
+            return None
+        d = xs[0].shape[1]
+        dev = xs[0].device
+        ns = (ctypes.c_int * k)(*[x.shape[0] for x in xs])
+        nb = self.lib.temp_gru_weight_grads_multi_workspace(k, ns, d, variant)
+        if nb == 0:
+            return None
+        keep = [[_f32(t, "operand") for t in ts] for ts in (xs, hdecs, dgis, dghs, w_ihs)]
+        arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+        dx = (ctypes.c_void_p * k)(*[None if t is None else t.data_ptr() for t in d_xs])
+        d_w = torch.empty(2 * k, 3 * d, d, dtype=torch.float32, device=dev)
+        d_b = torch.empty(2 * k, 3 * d, dtype=torch.float32, device=dev)
+        ws = self._ws(nb, dev)
+        rc = self.lib.temp_gru_weight_grads_multi(k, ns, d, variant, arr(keep[0]), arr(keep[1]), arr(keep[2]), arr(keep[3]), arr(keep[4]), dx,
+                                                  _ptr(d_w), _ptr(d_b), _ptr(ws), ws.numel(), _stream())
+        if rc == 2:                                   # TEMP_E_UNSUPPORTED: nothing was launched
+            return None
+        _lib.check(rc, "temp_gru_weight_grads_multi")
+        return [(d_w[2 * i], d_w[2 * i + 1], d_b[2 * i], d_b[2 * i + 1]) for i in range(k)]
+
     # ---- plain GEMMs + candidate cross-entropy (link-prediction loss) ---------------------------------
     def linear(self, a, b, trans_b):
         """a[M,K] . b  (b is [K,N], or [N,K] when trans_b)."""

@@ -444,7 +444,9 @@ int gemm_tn_multi(int count, const int* Ms, int Ka, int Nb, const float* const* 
     for (int i = 0; i < 8; ++i) {
       const int k = i < count ? i : 0;
       b.M[i] = i < count ? Ms[k] : 0; b.A[i] = As[k]; b.B[i] = Bs[k]; b.part[i] = (float*)ws + (size_t)k * S * Ka * Nb;
+      b.bpart[i] = nullptr;
     }
+    b.pstride = (size_t)Ka * Nb; b.bstride = (size_t)Ka;
     const int bpp = 8 * ceil_div(S, 8) * kab8, nt = ceil_div(Nb, 32);
     if (nt == 7) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<7>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
     else if (nt == 6) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<6>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
@@ -475,6 +477,55 @@ int gemm_tn_multi(int count, const int* Ms, int Ka, int Nb, const float* const* 
 #undef TEMP_TN_MULTI
   if (S > 1)
     for (int i = 0; i < count; ++i) reduce_slices(S, (size_t)Ka * Nb, Nb, (float*)ws + (size_t)i * S * Ka * Nb, outs[i], ldo, st);
+  return launch_status();
+}
+
+// count <= 8 weight-gradient products of ONE shape class with their bias column sums (out_i[Ka,Nb] = A_i^T B_i, bias_i[ka] =
+// sum_m A_i[m, ka]) in ONE launch of the split-operand kernel and ONE reduction: outs / biases are contiguous ([count][Ka][Nb],
+// [count][Ka]) and the partials of a slice lie side by side ([slice][product][Ka*Nb]), so the reduction sees one long array.
+// The slices are cut so that all products' blocks fit the chip at once (256 / (count * row blocks) slices per product): the same
+// MFMA work as `count` launches, without their boundaries, with count x fewer partials.  TEMP_E_UNSUPPORTED for shapes the
+// split-operand kernel does not take (the caller loops over gemm_tn).
+static int tn_multi_bias_slices(int count, int max_m, int kab8) {
+  // (product, slice) pairs are dealt round-robin to the eight XCDs, kab8 blocks each: at most 32 blocks (CUs) per XCD
+  int per_xcd = 32 / kab8;
+  if (per_xcd < 1) per_xcd = 1;
+  int S = 8 * per_xcd / (count > 0 ? count : 1);
+  const int cap = tn_bx8_slices(max_m, kab8);
+  if (S > cap) S = cap;
+  return S < 1 ? 1 : S;
+}
+size_t gemm_tn_multi_bias_workspace(int count, int max_m, int Ka, int Nb) {
+  const size_t S = (size_t)tn_multi_bias_slices(count, max_m, ceil_div(Ka, 256));
+  return align_up(S * count * Ka * Nb * sizeof(float), 256) + align_up(S * count * Ka * sizeof(float), 256);
+}
+int gemm_tn_multi_bias(int count, const int* Ms, int Ka, int Nb, const float* const* As, int lda, const float* const* Bs, int ldb, float* outs,
+                       float* biases, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (count <= 0 || count > 8 || Ka <= 0 || Nb <= 0 || Ka % 4 || Nb % 4 || lda % 4 || ldb % 4) return TEMP_E_UNSUPPORTED;
+  int max_m = 0;
+  for (int i = 0; i < count; ++i) max_m = Ms[i] > max_m ? Ms[i] : max_m;
+  const TnCfg c = tn_cfg(max_m, Ka, Nb);
+  if (!(c.split == 2 && c.nbb == 1 && tn_bx_ok(max_m, Ka, Nb, lda, ldb) && tn_bx8_ok(Ka) && gemm_tn_can_fuse_bias(Nb))) return TEMP_E_UNSUPPORTED;
+  const int nt = ceil_div(Nb, 32);
+  if (nt < 5 || nt > 7) return TEMP_E_UNSUPPORTED;
+  const int kab8 = ceil_div(Ka, 256), S = tn_multi_bias_slices(count, max_m, kab8);
+  if (!ws || ws_bytes < gemm_tn_multi_bias_workspace(count, max_m, Ka, Nb)) return TEMP_E_WORKSPACE;
+  int rps = ceil_div(max_m, S);
+  rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
+  float* part = (float*)ws;
+  float* bpart = (float*)((char*)ws + align_up((size_t)S * count * Ka * Nb * sizeof(float), 256));
+  TnBxBatch b;
+  for (int i = 0; i < 8; ++i) {
+    const int k = i < count ? i : 0;
+    b.M[i] = i < count ? Ms[k] : 0; b.A[i] = As[k]; b.B[i] = Bs[k];
+    b.part[i] = part + (size_t)k * Ka * Nb; b.bpart[i] = bpart + (size_t)k * Ka;
+  }
+  b.pstride = (size_t)count * Ka * Nb; b.bstride = (size_t)count * Ka;
+  const int grid = 8 * ceil_div(S * count, 8) * kab8;          // blocks_per_problem = 0: pairs dealt over the XCDs (gemm_tn_bx.hpp)
+  if (nt == 7) TEMP_LAUNCH(K_GEMM_TN_BX8, (k_gemm_tn_bx8_multi<7>), dim3(grid), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, 0);
+  else if (nt == 6) TEMP_LAUNCH(K_GEMM_TN_BX8, (k_gemm_tn_bx8_multi<6>), dim3(grid), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, 0);
+  else TEMP_LAUNCH(K_GEMM_TN_BX8, (k_gemm_tn_bx8_multi<5>), dim3(grid), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, 0);
+  reduce_slices(S, (size_t)count * Ka * Nb, Nb, part, outs, Nb, st, (size_t)count * Ka, bpart, biases);
   return launch_status();
 }
 

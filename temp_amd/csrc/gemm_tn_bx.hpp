@@ -245,7 +245,10 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx(int M, int Ka, int 
 template <int NT, int VAR>
 __device__ __forceinline__ void tn_bx8_body(int M, int Ka, int Nb, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                             int rows_per_slice, int kab, int n_slices, float* __restrict__ part,
-                                            float* __restrict__ bias_part, unsigned long long* dbg, const int block_id) {
+                                            float* __restrict__ bias_part, unsigned long long* dbg, const int block_id,
+                                            const size_t pstride, const size_t bstride) {
+  // pstride / bstride: floats between two slices' partials (Ka * Nb / Ka for one product; the multi launch interleaves the
+  // products of a slice so that ONE reduction sums all of them)
   constexpr int ITEMS_A = 128 * 2, ITEMS_B = NT * 16 * 2, ITEMS = ITEMS_A + ITEMS_B;   // (column pair, m-octet)
   constexpr int LDS_ITEMS = (8 + NT) * 192;                   // 16-byte fragment items of a slab: A tiles, then B tiles
   static_assert(ITEMS <= TNBX_THREADS, "one staging item per thread");
@@ -444,7 +447,7 @@ __device__ __forceinline__ void tn_bx8_body(int M, int Ka, int Nb, const float* 
     // lane (li, hh) holds output row ka0 + li; register quad q of tile t holds columns (t_beg + t)*32 + 8q + 4hh .. +3
     const int row = ka_blk + kt * 32 + li;
     if (row >= Ka) return;
-    float* p = part + (size_t)slice * Ka * Nb + (size_t)row * Nb;
+    float* p = part + (size_t)slice * pstride + (size_t)row * Nb;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
 #pragma unroll
@@ -452,7 +455,7 @@ __device__ __forceinline__ void tn_bx8_body(int M, int Ka, int Nb, const float* 
         const int c = (t_beg + t) * 32 + 8 * qd + 4 * hh;
         if constexpr (VAR & 2) { if (acc[t][4 * qd] == 12345.678f) st4(p, zero4()); continue; }
         if (c < Nb) st4(p + c, make_float4(acc[t][4 * qd], acc[t][4 * qd + 1], acc[t][4 * qd + 2], acc[t][4 * qd + 3]));
-        else if (bias_part && c == Nb) bias_part[(size_t)slice * Ka + row] = acc[t][4 * qd];
+        else if (bias_part && c == Nb) bias_part[(size_t)slice * bstride + row] = acc[t][4 * qd];
       }
     }
   };
@@ -464,18 +467,29 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8(int M, int Ka, int
                                                              const float* __restrict__ B, int ldb, int rows_per_slice, int kab,
                                                              int n_slices, float* __restrict__ part, float* __restrict__ bias_part,
                                                              unsigned long long* dbg = nullptr) {
-  tn_bx8_body<NT, VAR>(M, Ka, Nb, A, lda, B, ldb, rows_per_slice, kab, n_slices, part, bias_part, dbg, (int)blockIdx.x);
+  tn_bx8_body<NT, VAR>(M, Ka, Nb, A, lda, B, ldb, rows_per_slice, kab, n_slices, part, bias_part, dbg, (int)blockIdx.x, (size_t)Ka * Nb, (size_t)Ka);
 }
 
 // Several products of one shape class in ONE launch (gemm_kernels.hip: gemm_tn_multi): blocks_per_problem (a multiple of 8, so a
 // block's XCD is the same as in a launch of its own) consecutive blocks per problem.
-struct TnBxBatch { int M[8]; const float* A[8]; const float* B[8]; float* part[8]; };
+struct TnBxBatch { int M[8]; const float* A[8]; const float* B[8]; float* part[8]; float* bpart[8]; size_t pstride, bstride; };
 template <int NT>
 __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8_multi(TnBxBatch b, int Ka, int Nb, int lda, int ldb, int rows_per_slice, int kab,
                                                                    int n_slices, int blocks_per_problem) {
-  const int prob = blockIdx.x / blocks_per_problem;
-  tn_bx8_body<NT, 0>(b.M[prob], Ka, Nb, b.A[prob], lda, b.B[prob], ldb, rows_per_slice, kab, n_slices, b.part[prob], nullptr, nullptr,
-                     (int)blockIdx.x - prob * blocks_per_problem);
+  if (blocks_per_problem > 0) {
+    const int prob = blockIdx.x / blocks_per_problem;
+    tn_bx8_body<NT, 0>(b.M[prob], Ka, Nb, b.A[prob], lda, b.B[prob], ldb, rows_per_slice, kab, n_slices, b.part[prob], b.bpart[prob], nullptr,
+                       (int)blockIdx.x - prob * blocks_per_problem, b.pstride, b.bstride);
+    return;
+  }
+  // blocks_per_problem = 0: the (product, slice) pairs of ALL products are dealt round-robin to the XCDs -- with per-product
+  // dealing, 4 products x 21 slices put 36 blocks on the 32 CUs of five XCDs and the launch took two rounds
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int kb = q % kab, unit = (q / kab) * 8 + xcd;
+  const int prob = unit / n_slices, slice = unit - prob * n_slices;
+  if (prob >= 8 || b.M[prob] <= 0) return;
+  tn_bx8_body<NT, 0>(b.M[prob], Ka, Nb, b.A[prob], lda, b.B[prob], ldb, rows_per_slice, kab, n_slices, b.part[prob], b.bpart[prob], nullptr,
+                     ((slice >> 3) * kab + kb) * 8 + (slice & 7), b.pstride, b.bstride);
 }
 
 // shapes this kernel takes: one column block of 5..7 tiles (the split-2 configuration of tn_cfg), even pairs

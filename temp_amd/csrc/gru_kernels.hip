@@ -818,4 +818,42 @@ int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float
                           colsum_workspace(n, 3 * d), (hipStream_t)stream);
 }
 
+size_t temp_gru_weight_grads_multi_workspace(int count, const int* ns, int d, int variant) {
+  if (count <= 0 || count > 4 || !ns || d <= 0 || variant != TEMP_GRU_TORCH) return 0;
+  int max_n = 0;
+  for (int i = 0; i < count; ++i) max_n = ns[i] > max_n ? ns[i] : max_n;
+  return gemm_tn_multi_bias_workspace(2 * count, max_n, 3 * d, d);
+}
+
+int temp_gru_weight_grads_multi(int count, const int* ns, int d, int variant, const float* const* xs, const float* const* hdecs,
+                                const float* const* dgis, const float* const* dghs, const float* const* w_ihs, float* const* d_xs,
+                                float* d_w, float* d_b, void* workspace, size_t workspace_bytes, void* stream) {
+  if (count <= 0 || count > 4 || !ns || !xs || !hdecs || !dgis || !dghs || !w_ihs || !d_xs || !d_w || !d_b) return TEMP_E_BADARG;
+  if (variant != TEMP_GRU_TORCH || d % 4) return TEMP_E_UNSUPPORTED;       // (the type-1 cell's dgi is [n, d]: two shape classes)
+  int max_n = 0;
+  for (int i = 0; i < count; ++i) {
+    if (ns[i] <= 0 || !xs[i] || !hdecs[i] || !dgis[i] || !dghs[i] || !w_ihs[i]) return TEMP_E_UNSUPPORTED;
+    max_n = ns[i] > max_n ? ns[i] : max_n;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // the products first (they decide whether this path applies at all), then the d_x panel launch
+  int Ms[8];
+  const float* As[8];
+  const float* Bs[8];
+  for (int i = 0; i < count; ++i) {
+    Ms[2 * i] = Ms[2 * i + 1] = ns[i];
+    As[2 * i] = dgis[i]; Bs[2 * i] = xs[i];                      // d_W_ih = dgi^T x
+    As[2 * i + 1] = dghs[i]; Bs[2 * i + 1] = hdecs[i];           // d_W_hh = dgh^T hdec
+  }
+  int rc = gemm_tn_multi_bias(2 * count, Ms, 3 * d, d, As, 3 * d, Bs, d, d_w, d_b, workspace, workspace_bytes, st);
+  if (rc) return rc;
+  PanelBatch<EpiStore> batch;
+  int nx = 0;
+  for (int i = 0; i < count; ++i)
+    if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], dgis[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}};
+  for (int i = nx; i < PANEL_MAXP && nx > 0; ++i) { batch.p[i] = batch.p[0]; batch.p[i].M = 0; }
+  if (nx > 0) rc = launch_gemm_panel_multi(K_GEMM_GRU_DX, batch, nx, d, 3 * d, 3 * d, d, 0, st);       // d_x = dgi . W_ih
+  return rc ? rc : launch_status();
+}
+
 }  // extern "C"

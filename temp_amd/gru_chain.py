@@ -21,6 +21,7 @@ from .backend import get_backend
 
 
 CHAIN_KERNELS = True        # A/B switch: False keeps the per-position launches (temp_gru_cell_*_multi)
+WEIGHT_GRADS_MULTI = True   # A/B switch: False computes each GRU's weight gradients with its own launches (temp_gru_weight_grads)
 
 
 class GruInstance:
@@ -386,13 +387,31 @@ class _GruChainFn(torch.autograd.Function):
         d_x_all = torch.empty_like(x_all)
         written = np.zeros(x_all.shape[0], dtype=bool)
         grads = [None] * (4 * ctx.n_rnn)
-        for g in prog.groups:
+        groups = list(prog.groups)
+        zero_state = [all(it.prev < 0 for it in prog.inst if it.group == gi) for gi in range(len(groups))]    # hdec = 0 on every row
+        # several GRUs with disjoint x rows (the two directions of a bidirectional chain): ONE weight-gradient launch, ONE reduction
+        # and ONE d_x launch for all of them
+        multi = None
+        disjoint = all(groups[a]["x1"] <= groups[b]["x0"] or groups[b]["x1"] <= groups[a]["x0"] for a in range(len(groups)) for b in range(a))
+        if (len(groups) > 1 and disjoint and not any(zero_state) and len({g["rnn"] for g in groups}) == len(groups)
+                and WEIGHT_GRADS_MULTI and hasattr(be, "gru_weight_grads_multi")):
+            xsl = [slice(g["x0"], g["x1"]) for g in groups]
+            hsl = [slice(g["h0"], g["h1"]) for g in groups]
+            multi = be.gru_weight_grads_multi([x_all[a] for a in xsl], [saved[4, b] for b in hsl], [dgi[b] for b in hsl], [dgh[b] for b in hsl],
+                                              [W[g["rnn"]][0] for g in groups], variant, [d_x_all[a] for a in xsl])
+        if multi is not None:
+            for g, gw in zip(groups, multi):
+                written[g["x0"]:g["x1"]] = True
+                for k in range(4):
+                    grads[4 * g["rnn"] + k] = gw[k]
+            groups = []
+        for g in groups:
+            gi_ = prog.groups.index(g)
             xs, hs = slice(g["x0"], g["x1"]), slice(g["h0"], g["h1"])
             first = not written[xs].any()
             assert first or written[xs].all()
             tgt = d_x_all[xs] if first else torch.empty(g["x1"] - g["x0"], d, dtype=torch.float32, device=dev)
-            zero_state = all(it.prev < 0 for it in prog.inst if it.group == prog.groups.index(g))     # hdec = 0 on every row
-            gw = be.gru_weight_grads(x_all[xs], None if zero_state else saved[4, hs], dgi[hs], dgh[hs], W[g["rnn"]][0], variant, tgt)
+            gw = be.gru_weight_grads(x_all[xs], None if zero_state[gi_] else saved[4, hs], dgi[hs], dgh[hs], W[g["rnn"]][0], variant, tgt)
             if not first:
                 d_x_all[xs] += tgt
             written[xs] = True

@@ -102,8 +102,14 @@ class _RecStackFn(torch.autograd.Function):
                                         dgi=dgi1[sl], dgh=dgh1[sl], decv=decv1[sl], d_prev=dp1[sl])], lam, variant, saved1)
         d_y1 = torch.empty_like(y1)
         zero_state = all(it.prev < 0 for it in prog.inst)                            # hdec = 0 on every row
-        gw1 = be.gru_weight_grads(y1, None if zero_state else saved1[4], dgi1, dgh1, wi1, variant, d_y1)
-        gw2 = be.gru_weight_grads(Y2, None if zero_state else saved2[4], dgi2, dgh2, wi2, variant, None)
+        multi = None
+        if not zero_state and hasattr(be, "gru_weight_grads_multi"):               # both GRUs in one weight-gradient launch
+            multi = be.gru_weight_grads_multi([y1, Y2], [saved1[4], saved2[4]], [dgi1, dgi2], [dgh1, dgh2], [wi1, wi2], variant, [d_y1, None])
+        if multi is not None:
+            gw1, gw2 = multi
+        else:
+            gw1 = be.gru_weight_grads(y1, None if zero_state else saved1[4], dgi1, dgh1, wi1, variant, d_y1)
+            gw2 = be.gru_weight_grads(Y2, None if zero_state else saved2[4], dgi2, dgh2, wi2, variant, None)
         if d_w2 is None:
             d_w2, d_loop2 = torch.zeros_like(w2), torch.zeros_like(loop2)
             d_bias2 = torch.zeros(loop2.shape[1], dtype=torch.float32, device=dev) if ctx.has_bias else None

@@ -381,6 +381,11 @@ class CpuTestBackend:
                 dprev[act] = dp
                 nxt_has = act & (((e >> 30) & 1) == 1)
 
+    def gru_weight_grads_multi(self, xs, hdecs, dgis, dghs, w_ihs, variant, d_xs):
+        if variant != _lib.GRU_TORCH or any(h is None for h in hdecs):
+            return None
+        return [self.gru_weight_grads(x, h, a, b, w, variant, dx) for x, h, a, b, w, dx in zip(xs, hdecs, dgis, dghs, w_ihs, d_xs)]
+
     def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
         if d_x is not None:
             d_x.copy_(torch.mm(dgi, w_ih.detach()))

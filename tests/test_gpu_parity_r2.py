@@ -359,6 +359,38 @@ def test_gru_input_gates_gather_multi_gpu(variant, hip_backend):
             assert torch.equal(a, b), (rows, k, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("rows", [(60000, 58000), (20000, 20000, 17000), (900, 700)])
+def test_gru_weight_grads_multi_gpu(rows, hip_backend):
+    """temp_gru_weight_grads_multi (both directions' d_W_ih, d_W_hh, bias gradients and d_x: ONE weight-gradient launch, ONE
+    reduction, ONE d_x launch) against the per-GRU call: the same products over other row slices -> fp32 summation-order
+    differences only, and both against fp64.  Small row counts are outside the split-operand kernel: None, nothing launched."""
+    from temp_amd import _lib
+    D = 200
+    gen = torch.Generator(device="cpu").manual_seed(11 + len(rows))
+    mk = lambda n, w, s=1.0: (torch.randn(n, w, generator=gen) * s).to(DEV)
+    xs, hd = [mk(n, D) for n in rows], [mk(n, D) for n in rows]
+    dgi, dgh = [mk(n, 3 * D, 0.1) for n in rows], [mk(n, 3 * D, 0.1) for n in rows]
+    ws = [((torch.rand(3 * D, D, generator=gen) - 0.5) * 0.3).to(DEV) for _ in rows]
+    dxm = [torch.full((n, D), float("nan"), device=DEV) for n in rows]
+    got = hip_backend.gru_weight_grads_multi(xs, hd, dgi, dgh, ws, _lib.GRU_TORCH, dxm)
+    if min(rows) < 4096:
+        assert got is None
+        return
+    assert got is not None and len(got) == len(rows)
+    torch.cuda.synchronize()
+    for k, n in enumerate(rows):
+        dx1 = torch.empty(n, D, device=DEV)
+        one = hip_backend.gru_weight_grads(xs[k], hd[k], dgi[k], dgh[k], ws[k], _lib.GRU_TORCH, dx1)
+        assert torch.equal(dx1, dxm[k]), "d_x: the same panel kernel on the same rows"
+        want = (dgi[k].double().t() @ xs[k].double(), dgh[k].double().t() @ hd[k].double(), dgi[k].double().sum(0), dgh[k].double().sum(0))
+        scale = (dgi[k].abs().double().t() @ xs[k].abs().double(), dgh[k].abs().double().t() @ hd[k].abs().double(),
+                 dgi[k].abs().double().sum(0), dgh[k].abs().double().sum(0))
+        for a, b, w, sc in zip(got[k], one, want, scale):
+            assert a.shape == b.shape and torch.isfinite(a).all()
+            for t in (a, b):
+                assert float(((t.double() - w).abs() / sc.clamp_min(1e-30)).max()) < 2e-6
+
+
 def test_chain_kernels_bitwise_repeatable():
     from tests.chain_cases import make_rnns, random_program, run_program
     prog, n_x = random_program(41, n_chain=2, K=8, E=500, lo=300, hi=500)

@@ -54,5 +54,29 @@ def main():
             share, 1e3 * tr["k_gru_chain_fwd"]["avg_ms"], 1e3 * sum(v["ms_per_step"] for v in gi), sum(v["ms_per_step"] for v in tr.values())), flush=True)
 
 
+def weight_grads_ab(steps=200):
+    """Both directions' weight gradients in one launch (temp_gru_weight_grads_multi) against one set of launches per GRU: the whole
+    step as a HIP graph, alternating, on this box."""
+    from temp_amd import gru_chain as GC, synthetic
+    dev = torch.device("cuda", 0)
+    w = synthetic.workload("S-gdelt", seed=0)
+    model = bench.build_model(w, dev)
+    model.sample_rng = np.random.default_rng(2)
+    wb = model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0), w["L"], train=True)
+    res = {}
+    for rep in range(2):
+        for flag in (True, False):
+            GC.WEIGHT_GRADS_MULTI = flag
+            st = bench.GraphStep(lambda: model.run(wb)[0], list(model.parameters()), graph=True)
+            res.setdefault(flag, []).append(st.time(steps, 20))
+    GC.WEIGHT_GRADS_MULTI = True
+    for flag, v in res.items():
+        print("weight gradients of both directions in one launch: %-5s  step %s ms (graph replays)" % (flag, ", ".join("%.3f" % x for x in v)), flush=True)
+
+
 if __name__ == "__main__":
+    if "--weight-grads" in sys.argv:
+        sys.argv.remove("--weight-grads")
+        weight_grads_ab()
+        sys.exit(0)
     main()
