@@ -74,7 +74,31 @@ def weight_grads_ab(steps=200):
         print("weight gradients of both directions in one launch: %-5s  step %s ms (graph replays)" % (flag, ", ".join("%.3f" % x for x in v)), flush=True)
 
 
+def debug_ab(value, what, steps=200):
+    """The whole step as a HIP graph with TEMP_OPT_DEBUG = 0 against `value` (a development switch of the library), alternating."""
+    from temp_amd import _lib, synthetic
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    w = synthetic.workload("S-gdelt", seed=0)
+    model = bench.build_model(w, dev)
+    model.sample_rng = np.random.default_rng(2)
+    wb = model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0), w["L"], train=True)
+    res = {}
+    for rep in range(2):
+        for v in (0, value):
+            lib.temp_set_option(_lib.OPT_DEBUG, v)
+            st = bench.GraphStep(lambda: model.run(wb)[0], list(model.parameters()), graph=True)
+            res.setdefault(v, []).append(st.time(steps, 20))
+    lib.temp_set_option(_lib.OPT_DEBUG, 0)
+    for v, t in res.items():
+        print("%s: TEMP_OPT_DEBUG %-4d step %s ms (graph replays)" % (what, v, ", ".join("%.3f" % x for x in t)), flush=True)
+
+
 if __name__ == "__main__":
+    if "--debug" in sys.argv:
+        i = sys.argv.index("--debug")
+        debug_ab(int(sys.argv[i + 1]), " ".join(sys.argv[i + 2:]) or "switch")
+        sys.exit(0)
     if "--weight-grads" in sys.argv:
         sys.argv.remove("--weight-grads")
         weight_grads_ab()
