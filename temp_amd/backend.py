@@ -369,7 +369,7 @@ class HipBackend:
         temp_gru_weight_grads_multi) -> [(d_w_ih, d_w_hh, d_b_ih, d_b_hh)] per GRU, or None when the library takes this shape
         through the per-GRU call (nothing launched)."""
         k = len(xs)
-        if k < 2 or k > 4 or variant != _lib.GRU_TORCH or any(h is None for h in hdecs):
+        if k < 1 or k > 4 or variant != _lib.GRU_TORCH or any(h is None for h in hdecs):
             return None
         d = xs[0].shape[1]
         dev = xs[0].device

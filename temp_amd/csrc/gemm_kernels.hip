@@ -487,10 +487,8 @@ int gemm_tn_multi(int count, const int* Ms, int Ka, int Nb, const float* const* 
 // MFMA work as `count` launches, without their boundaries, with count x fewer partials.  TEMP_E_UNSUPPORTED for shapes the
 // split-operand kernel does not take (the caller loops over gemm_tn).
 static int tn_multi_bias_slices(int count, int max_m, int kab8) {
-  // (product, slice) pairs are dealt round-robin to the eight XCDs, kab8 blocks each: at most 32 blocks (CUs) per XCD
-  int per_xcd = 32 / kab8;
-  if (per_xcd < 1) per_xcd = 1;
-  int S = 8 * per_xcd / (count > 0 ? count : 1);
+  // 256 blocks, one per CU: tn_multi_units() (product, slice) pairs of kab8 row blocks each (gemm_tn_bx.hpp)
+  int S = tn_multi_units(kab8) / (count > 0 ? count : 1);
   const int cap = tn_bx8_slices(max_m, kab8);
   if (S > cap) S = cap;
   return S < 1 ? 1 : S;
@@ -507,7 +505,7 @@ int gemm_tn_multi_bias(int count, const int* Ms, int Ka, int Nb, const float* co
   const TnCfg c = tn_cfg(max_m, Ka, Nb);
   if (!(c.split == 2 && c.nbb == 1 && tn_bx_ok(max_m, Ka, Nb, lda, ldb) && tn_bx8_ok(Ka) && gemm_tn_can_fuse_bias(Nb))) return TEMP_E_UNSUPPORTED;
   const int nt = ceil_div(Nb, 32);
-  if (nt < 5 || nt > 7) return TEMP_E_UNSUPPORTED;
+  if (nt < 5 || nt > 7 || tn_multi_units(ceil_div(Ka, 256)) < count) return TEMP_E_UNSUPPORTED;
   const int kab8 = ceil_div(Ka, 256), S = tn_multi_bias_slices(count, max_m, kab8);
   if (!ws || ws_bytes < gemm_tn_multi_bias_workspace(count, max_m, Ka, Nb)) return TEMP_E_WORKSPACE;
   int rps = ceil_div(max_m, S);
@@ -521,7 +519,7 @@ int gemm_tn_multi_bias(int count, const int* Ms, int Ka, int Nb, const float* co
     b.part[i] = part + (size_t)k * Ka * Nb; b.bpart[i] = bpart + (size_t)k * Ka;
   }
   b.pstride = (size_t)count * Ka * Nb; b.bstride = (size_t)count * Ka;
-  const int grid = 8 * ceil_div(S * count, 8) * kab8;          // blocks_per_problem = 0: pairs dealt over the XCDs (gemm_tn_bx.hpp)
+  const int grid = 256;                                        // blocks_per_problem = 0: pairs dealt over the XCDs (gemm_tn_bx.hpp)
   if (nt == 7) TEMP_LAUNCH(K_GEMM_TN_BX8, (k_gemm_tn_bx8_multi<7>), dim3(grid), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, 0);
   else if (nt == 6) TEMP_LAUNCH(K_GEMM_TN_BX8, (k_gemm_tn_bx8_multi<6>), dim3(grid), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, 0);
   else TEMP_LAUNCH(K_GEMM_TN_BX8, (k_gemm_tn_bx8_multi<5>), dim3(grid), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, 0);

@@ -482,14 +482,24 @@ __global__ void __launch_bounds__(TNBX_THREADS) k_gemm_tn_bx8_multi(TnBxBatch b,
                        (int)blockIdx.x - prob * blocks_per_problem, b.pstride, b.bstride);
     return;
   }
-  // blocks_per_problem = 0: the (product, slice) pairs of ALL products are dealt round-robin to the XCDs -- with per-product
-  // dealing, 4 products x 21 slices put 36 blocks on the 32 CUs of five XCDs and the launch took two rounds
+  // blocks_per_problem = 0: the (product, slice) pairs of ALL products are dealt to the XCDs, 32 blocks (CUs) each -- with
+  // per-product dealing, 4 products x 21 slices put 36 blocks on the 32 CUs of five XCDs and the launch took two rounds.
+  // An XCD takes per = 32 / kab whole pairs (their kab row blocks share the pair's B slab in that XCD's L2); the 32 - per * kab
+  // blocks it has left take row blocks of further pairs that straddle XCDs (tn_multi_units(): the host's count of pairs).
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int kb = q % kab, unit = (q / kab) * 8 + xcd;
+  const int per = 32 / kab, left = 32 - per * kab;
+  int unit, kb;
+  if (q < per * kab) { unit = xcd * per + q / kab; kb = q % kab; }
+  else { const int r = xcd * left + (q - per * kab); unit = 8 * per + r / kab; kb = r % kab; }
   const int prob = unit / n_slices, slice = unit - prob * n_slices;
-  if (prob >= 8 || b.M[prob] <= 0) return;
+  if (q >= 32 || prob >= 8 || b.M[prob] <= 0) return;
   tn_bx8_body<NT, 0>(b.M[prob], Ka, Nb, b.A[prob], lda, b.B[prob], ldb, rows_per_slice, kab, n_slices, b.part[prob], b.bpart[prob], nullptr,
                      ((slice >> 3) * kab + kb) * 8 + (slice & 7), b.pstride, b.bstride);
+}
+// (product, slice) pairs one launch of 256 blocks takes: whole pairs per XCD + the pairs made of the XCDs' left-over blocks
+inline int tn_multi_units(int kab) {
+  const int per = 32 / kab, left = 32 - per * kab;
+  return kab > 32 ? 0 : 8 * per + (8 * left) / kab;
 }
 
 // shapes this kernel takes: one column block of 5..7 tiles (the split-2 configuration of tn_cfg), even pairs

@@ -389,11 +389,11 @@ class _GruChainFn(torch.autograd.Function):
         grads = [None] * (4 * ctx.n_rnn)
         groups = list(prog.groups)
         zero_state = [all(it.prev < 0 for it in prog.inst if it.group == gi) for gi in range(len(groups))]    # hdec = 0 on every row
-        # several GRUs with disjoint x rows (the two directions of a bidirectional chain): ONE weight-gradient launch, ONE reduction
-        # and ONE d_x launch for all of them
+        # GRUs with disjoint x rows (the two directions of a bidirectional chain, or the one GRU of a uni-directional one): ONE
+        # weight-gradient launch for all d_W_ih / d_W_hh products, ONE reduction and ONE d_x launch
         multi = None
         disjoint = all(groups[a]["x1"] <= groups[b]["x0"] or groups[b]["x1"] <= groups[a]["x0"] for a in range(len(groups)) for b in range(a))
-        if (len(groups) > 1 and disjoint and not any(zero_state) and len({g["rnn"] for g in groups}) == len(groups)
+        if (groups and disjoint and not any(zero_state) and len({g["rnn"] for g in groups}) == len(groups)
                 and WEIGHT_GRADS_MULTI and hasattr(be, "gru_weight_grads_multi")):
             xsl = [slice(g["x0"], g["x1"]) for g in groups]
             hsl = [slice(g["h0"], g["h1"]) for g in groups]
