@@ -359,7 +359,7 @@ def test_gru_input_gates_gather_multi_gpu(variant, hip_backend):
             assert torch.equal(a, b), (rows, k, float((a - b).abs().max()))
 
 
-@pytest.mark.parametrize("rows", [(60000, 58000), (20000, 20000, 17000), (900, 700)])
+@pytest.mark.parametrize("rows", [(60000, 58000), (20000, 20000, 17000), (900, 700), (30001,), (9000, 8000, 7000, 6004)])
 def test_gru_weight_grads_multi_gpu(rows, hip_backend):
     """temp_gru_weight_grads_multi (both directions' d_W_ih, d_W_hh, bias gradients and d_x: ONE weight-gradient launch, ONE
     reduction, ONE d_x launch) against the per-GRU call: the same products over other row slices -> fp32 summation-order
@@ -372,6 +372,8 @@ def test_gru_weight_grads_multi_gpu(rows, hip_backend):
     dgi, dgh = [mk(n, 3 * D, 0.1) for n in rows], [mk(n, 3 * D, 0.1) for n in rows]
     ws = [((torch.rand(3 * D, D, generator=gen) - 0.5) * 0.3).to(DEV) for _ in rows]
     dxm = [torch.full((n, D), float("nan"), device=DEV) for n in rows]
+    if len(rows) == 4:
+        dxm[2] = None                                  # a GRU whose input gradient nobody needs (rec_stack's second layer)
     got = hip_backend.gru_weight_grads_multi(xs, hd, dgi, dgh, ws, _lib.GRU_TORCH, dxm)
     if min(rows) < 4096:
         assert got is None
@@ -381,7 +383,12 @@ def test_gru_weight_grads_multi_gpu(rows, hip_backend):
     for k, n in enumerate(rows):
         dx1 = torch.empty(n, D, device=DEV)
         one = hip_backend.gru_weight_grads(xs[k], hd[k], dgi[k], dgh[k], ws[k], _lib.GRU_TORCH, dx1)
-        assert torch.equal(dx1, dxm[k]), "d_x: the same panel kernel on the same rows"
+        if dxm[k] is not None:
+            # (a launch picks its kernels by the rows of ALL its problems, a single call by its own: bit-identical when both agree)
+            if min(rows) >= 16384 or sum(rows) < 16384:
+                assert torch.equal(dx1, dxm[k]), "d_x: the same panel kernel on the same rows"
+            else:
+                assert float((dx1 - dxm[k]).abs().max()) < 1e-4 * float(dx1.abs().max())
         want = (dgi[k].double().t() @ xs[k].double(), dgh[k].double().t() @ hd[k].double(), dgi[k].double().sum(0), dgh[k].double().sum(0))
         scale = (dgi[k].abs().double().t() @ xs[k].abs().double(), dgh[k].abs().double().t() @ hd[k].abs().double(),
                  dgi[k].abs().double().sum(0), dgh[k].abs().double().sum(0))
