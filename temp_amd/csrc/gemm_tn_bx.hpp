@@ -505,8 +505,10 @@ inline int tn_multi_units(int kab) {
 // shapes this kernel takes: one column block of 5..7 tiles (the split-2 configuration of tn_cfg), even pairs
 inline bool tn_bx_ok(int M, int Ka, int Nb, int lda, int ldb) {
   const int nt = ceil_div(Nb, 32);
-  const long long span = (long long)M * (lda > ldb ? lda : ldb);          // 32-bit element offsets
-  return bx_enabled() && nt >= 5 && nt <= 7 && Ka % 4 == 0 && Nb % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && M >= 4096 && span < (1ll << 31);
+  // (the 128-row kernel keeps 32-bit element offsets; the wide one -- Ka > 256 -- forms a 64-bit row base per slab)
+  const long long span = (long long)M * (lda > ldb ? lda : ldb);
+  return bx_enabled() && nt >= 5 && nt <= 7 && Ka % 4 == 0 && Nb % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && M >= 4096 &&
+         (Ka > 256 || span < (1ll << 31));
 }
 // m-slices: the kab row blocks of a slice run on one XCD (32 CUs), so an XCD takes floor(32 / kab) slices at a time
 inline int tn_bx_slices(int M, int kab) {

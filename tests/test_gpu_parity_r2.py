@@ -398,6 +398,34 @@ def test_gru_weight_grads_multi_gpu(rows, hip_backend):
                 assert float(((t.double() - w).abs() / sc.clamp_min(1e-30)).max()) < 2e-6
 
 
+def test_gru_weight_grads_beyond_2g_elements_gpu(hip_backend):
+    """A weight-gradient product whose dgi has more than 2^31 elements (3.6 M rows x 600: one direction of the HBM-regime window,
+    bench.py extra.hbm_window) stays on the split-operand kernel (64-bit row bases): the whole product against the sum of its two
+    halves, each below 2^31 elements, through the same entry point."""
+    from temp_amd import _lib
+    D, n = 200, 3_600_000
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x, hd = torch.randn(n, D, device=DEV, generator=g), torch.randn(n, D, device=DEV, generator=g)
+    dgi, dgh = torch.randn(n, 3 * D, device=DEV, generator=g) * 0.1, torch.randn(n, 3 * D, device=DEV, generator=g) * 0.1
+    w = (torch.rand(3 * D, D, device=DEV, generator=g) - 0.5) * 0.3
+    assert dgi.numel() > 2 ** 31
+    lib = _lib.load()
+    t0 = lib.temp_trace_begin(64)
+    whole = hip_backend.gru_weight_grads_multi([x], [hd], [dgi], [dgh], [w], _lib.GRU_TORCH, [None])
+    import ctypes
+    ids, ms, cnt = (ctypes.c_int32 * 64)(), (ctypes.c_float * 64)(), ctypes.c_int32(0)
+    lib.temp_trace_end(ids, ms, 64, ctypes.byref(cnt))
+    names = [lib.temp_trace_kernel_name(ids[i]).decode() for i in range(cnt.value)]
+    assert whole is not None and "k_gemm_tn_bx8" in names, names
+    h = n // 2
+    parts = [hip_backend.gru_weight_grads(x[a:b], hd[a:b], dgi[a:b], dgh[a:b], w, _lib.GRU_TORCH, None) for a, b in ((0, h), (h, n))]
+    torch.cuda.synchronize()
+    for k in range(4):
+        want = parts[0][k].double() + parts[1][k].double()
+        err = float((whole[0][k].double() - want).abs().max())
+        assert err < 3e-5 * float(want.abs().max()) + 1e-3, (k, err, float(want.abs().max()))
+
+
 def test_chain_kernels_bitwise_repeatable():
     from tests.chain_cases import make_rnns, random_program, run_program
     prog, n_x = random_program(41, n_chain=2, K=8, E=500, lo=300, hi=500)
