@@ -803,10 +803,10 @@ static bool launch_dw_tile(const TempEdgeView& v, const TileArgs& t, const float
 }
 
 static int run_dw(const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz, const float* nnorm, int d_in, int d_out, int num_bases,
-                  int n_rel_rows, float* dW, float* partial, hipStream_t st, bool zeroed = false) {
+                  int n_rel_rows, float* dW, float* partial, hipStream_t st) {
   const int si = d_in / num_bases, so = d_out / num_bases;
   const size_t wrow = (size_t)num_bases * si * so;
-  if (!zeroed && hipMemsetAsync(dW, 0, (size_t)n_rel_rows * wrow * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+  if (hipMemsetAsync(dW, 0, (size_t)n_rel_rows * wrow * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
   if (v.n_chunks == 0) return TEMP_OK;
   int S = 0;
   TileArgs ta;
@@ -930,17 +930,10 @@ struct SideScope {
 static int dw_forked(SideScope& sc, const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz,
                      const float* nnorm, int d_in, int d_out, int num_bases, int n_rel_rows, float* dW, float* partial) {
   SideStream* ss = sc.ss;
-  // d_weight is zeroed on the CALLER's stream, before the fork: as the first command of the side stream the little fill kernel
-  // queued behind the d/dh kernel that starts at the same moment and held d/dweight back for milliseconds on HBM-sized graphs
-  // (2.3 ms at 2^16 nodes per snapshot) -- the overlap this branch exists for started late
-  // (small graphs keep the fill on the side stream: there it costs nothing, here 5 us of the caller's critical path)
-  const bool pre = v.n_edges > (1 << 20);
-  const size_t wbytes = (size_t)n_rel_rows * num_bases * (d_in / num_bases) * (d_out / num_bases) * sizeof(float);
-  if (pre && hipMemsetAsync(dW, 0, wbytes, sc.st) != hipSuccess) return TEMP_E_LAUNCH;
   if (hipEventRecord(ss->fork, sc.st) != hipSuccess) return TEMP_E_LAUNCH;
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return TEMP_E_LAUNCH;
   sc.forked = true;                              // from here on the side stream depends on the caller's: it must be joined
-  const int rc = run_dw(v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, ss->s, pre);
+  const int rc = run_dw(v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, ss->s);
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return TEMP_E_LAUNCH;
   return rc;
 }
