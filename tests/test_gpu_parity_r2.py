@@ -190,6 +190,63 @@ def test_full_size_training_loss_vs_oracle_gpu(workload, n_windows):
         _assert_grad_close(got, ref, "%s+loss d %s" % (workload, name), max_bad=0.0, frob=6e-6, frob_clean=6e-6)
 
 
+def test_full_size_default_flags_training_loss_vs_oracle_gpu():
+    """BASELINE config 2 with the reference's DEFAULT flags (no --rec-only-last-layer: both layers recurrent,
+    models/RRGCN.py:179-181, F7 aliasing) at its own size -- S-icews14, L = 8, D = 200 -- through the one-node position loop
+    (temp_amd/rec_stack.py: RGCN_1 of all visits hoisted, both GRUs' weight gradients in one launch) against the oracle in fp64:
+    training loss with the ComplEx scorer, fixed subsample and negatives, and every parameter gradient incl. layer 1's GRU."""
+    import bench
+    from temp_amd import synthetic
+    from temp_amd.dynamic_rgcn import DynamicRGCN
+    w = synthetic.workload("S-icews14", seed=0)
+    args = bench.make_args(w, "GRRGCN")
+    args.rec_only_last_layer = False
+    torch.manual_seed(3)
+    model = DynamicRGCN(args, w["num_ents"], w["num_rels"], w["snapshots"], w["snapshots"], w["snapshots"]).to(DEV)
+    targets = sorted(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:3], reverse=True)
+    L, N = w["L"], w["num_ents"]
+    rng = np.random.default_rng(13)
+    edge_ids, samples = [], []
+    for t in targets:
+        g = w["snapshots"][t]
+        E = g.number_of_edges()
+        edge_ids.append(np.sort(rng.choice(E, E // 2, replace=False)))
+        P = min(E, 300)
+        pos = rng.choice(E, P, replace=False)
+        trip = torch.from_numpy(np.stack([g.src[pos], g.rel[pos], g.dst[pos]], axis=1)).long()
+        nt, nh = torch.from_numpy(rng.integers(0, N, (P, 41))), torch.from_numpy(rng.integers(0, N, (P, 41)))
+        nt[:, 0] = torch.from_numpy(g.gids[g.dst[pos]])
+        nh[:, 0] = torch.from_numpy(g.gids[g.src[pos]])
+        samples.append((trip, nt, nh))
+    wb = model.prepare(torch.tensor(targets), L, True, edge_ids)
+    assert wb.stack and not wb.batched
+    loss = model.run_loss(wb, samples)
+    loss.backward()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
+    cfg = dict(module="GRRGCN", n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=False, use_time_embedding=False)
+    om = O.model_from_state_dict(sd, cfg)
+    gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
+    for v in O.leaf_tensors(om).values():
+        v.requires_grad_(True)
+    tgt = [O.edge_subgraph(gd[t], torch.from_numpy(e)) for t, e in zip(targets, edge_ids)]
+    want, _ = O.uni_forward_loss(om, cfg, gd, targets, sorted(gd.keys()), L, tgt, samples, score="complex")
+    want.backward()
+    print("full-size default-flags training loss: HIP %.7f  oracle(fp64) %.7f" % (loss.item(), want.item()))
+    assert abs(loss.item() - want.item()) <= 2e-5 * abs(want.item()), (loss.item(), want.item())
+    enc, oe = model.ent_encoder, om["ent_encoder"]
+    checks = [("ent_embeds", model.ent_embeds.grad, om["ent_embeds"].grad), ("rel_embeds", model.rel_embeds.grad, om["rel_embeds"].grad)]
+    for ln in ("layer_1", "layer_2"):
+        lay, q = getattr(enc, ln), oe[ln]
+        checks += [(ln + ".weight", lay.weight.grad, q["weight"].grad), (ln + ".loop_weight", lay.loop_weight.grad, q["loop_weight"].grad)]
+        r = q["rnn"][0]
+        checks += [(ln + ".rnn.w_hh", lay.rnn.weight_hh_l0.grad, r["w_hh"].grad), (ln + ".rnn.w_ih", lay.rnn.weight_ih_l0.grad, r["w_ih"].grad),
+                   (ln + ".rnn.b_hh", lay.rnn.bias_hh_l0.grad, r["b_hh"].grad), (ln + ".rnn.b_ih", lay.rnn.bias_ih_l0.grad, r["b_ih"].grad)]
+    for name, got, ref in checks:
+        assert got is not None and ref is not None, name
+        _assert_grad_close(got, ref, "default flags d " + name, max_bad=1e-4, frob=1e-4, frob_clean=2e-5)
+
+
 @pytest.mark.parametrize("workload,n_windows", [("S-gdelt", 2)])
 def test_full_size_attention_windows_vs_oracle_gpu(workload, n_windows):
     """Config 5 at the headline size: BiSelfAttentionRGCN (8-head attention of every target node over its window history)
