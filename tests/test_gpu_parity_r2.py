@@ -82,13 +82,31 @@ def test_full_size_windows_vs_oracle_gpu(workload, n_windows, dim):
     step (distinct snapshots once, table layer, one GRU chain program) against the oracle (0.3 s per window on the CPU).
     dim = 128 / 64: the reference's shipped grid (embed = n_bases, 1 x 1 blocks): other tile counts of every MFMA kernel, the
     permute-based edge kernels, the fp32 weight-gradient kernel."""
-    import bench
     from temp_amd import synthetic
     w = synthetic.workload(workload, seed=0)
     if dim is not None:
         w["D"], w["B"] = dim, dim
-    model = bench.build_model(w, DEV)
     targets = sorted(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:n_windows], reverse=True)
+    _bi_windows_vs_oracle(w, targets, workload)
+
+
+def test_hbm_window_shape_vs_oracle_gpu():
+    """bench.py's extra.hbm_window (= --workload S-hbm-window) at reduced size: the same generator (power-law snapshots of 2^k
+    nodes / 2^(k+4) edges, 230 relations: the relation table beyond LDS, hub nodes with multi-chunk segments and relation runs),
+    the same BiGRRGCN batched step with bsz = 1 -- here k = 12 and L = 5 (9 snapshot visits) so that the fp64 oracle finishes in
+    seconds -- target embeddings and every gradient."""
+    from temp_amd import synthetic
+    k, L, R = 12, 5, 230
+    N, E = 1 << k, 1 << (k + 4)
+    snaps = synthetic.make_snapshots(N, R, E, N, 2 * L - 1, seed=0)
+    w = dict(name="S-hbm-window", num_ents=N, num_rels=R, edges_per_snap=E, nodes_per_snap=N, num_times=2 * L - 1, D=200, B=100, L=L, bsz=1,
+             module="BiGRRGCN", snapshots=snaps)
+    _bi_windows_vs_oracle(w, [L - 1], "S-hbm-window(k=12, L=5)")
+
+
+def _bi_windows_vs_oracle(w, targets, workload):
+    import bench
+    model = bench.build_model(w, DEV)
     L, D = w["L"], w["D"]
     # ---- HIP path ---------------------------------------------------------------------------------------------------
     wb = model.prepare(targets, L, train=False)
