@@ -639,6 +639,51 @@ def _cpu_model():
 _JSON_OUT = None
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself as when no launcher has set WORLD_SIZE: one process per GPU of
+    this node under torch.distributed.run (the reference's axis: Lightning DDP, models/TKG_Module.py:162-179, launcher_2gpu.sh:8),
+    rendezvous on 127.0.0.1 (a container hostname may not resolve).  The children see RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    and rank 0 alone prints the JSON line."""
+    port = port or int(os.environ.get("TEMP_BENCH_MASTER_PORT", "0")) or _free_port()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    import subprocess
+    cmd = launch_command(n, argv)
+    sys.stderr.write("[bench] WORLD_SIZE unset and --gpus %d: launching %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)                  # the ranks inherit stdout: rank 0's JSON line is this process's one line
+
+
+def rendezvous_only(a, rank, world):
+    """--rendezvous-only: prove that the launch path forms an N-rank group (tests/test_bench_launch.py runs it without a GPU)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl" if gpu else "gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)], device="cuda" if gpu else "cpu")
+    dist.all_reduce(t)
+    if rank == 0:
+        emit(dict(rendezvous=world, backend="nccl" if gpu else "gloo", rank_sum=t.item(), gpus=a.gpus))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def claim_stdout():
     """stdout carries ONE line, the result: libraries that write to file descriptor 1 on their own (RCCL prints a version banner
     when a communicator is created -- every multi-GPU run, and the one-rank sharded measurement of `extra`) are pointed at
@@ -693,18 +738,30 @@ def main():
                     help="extra.hbm_window: nodes per snapshot = 2^k, edges = 2^(k+4), bi L=15 bsz=1 (0: skip; 18 needs ~110 GB of HBM and ~1 min of host planning)")
     ap.add_argument("--hbm-window-steps", type=int, default=3)
     ap.add_argument("--cpu-probe", action="store_true", help="(internal) child process of the all-cores CPU probe: no GPU")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="(test hook) join the process group (nccl with a GPU, gloo without), all-reduce the rank ids, print one line and exit")
     a = ap.parse_args()
     if a.cpu_probe:
         return cpu_probe_main(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started plainly: start the N ranks ourselves (one process per GPU on this node)
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     claim_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (a.gpus, a.gpus))
+    if a.rendezvous_only:
+        return rendezvous_only(a, rank, world)
+    assert world == a.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    # one process per GPU.  TEMP_BENCH_DIST_BACKEND=gloo is a test hook for one-GPU boxes: RCCL refuses two ranks on one device, gloo
+    # moves the same device tensors through host staging, so `--gpus 2` walks the whole multi-rank control flow (every collective of
+    # every rank, in order) on ONE GPU -- a functional check of the launch path, never a measurement.
+    dist_backend = os.environ.get("TEMP_BENCH_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    assert local_rank < n_dev or dist_backend != "nccl", "rank %d has no GPU of its own (%d visible)" % (local_rank, n_dev)
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -712,7 +769,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     from temp_amd import _lib, synthetic
     from temp_amd import backend as TB
@@ -826,11 +883,16 @@ def main():
         dist.all_reduce(e)
         edges = float(e.item())
     value = edges * a.steps / elapsed
+    if dist is not None and rank != 0:
+        # Everything below is rank 0's own work (kernel trace, CPU baseline, the line) and contains NO collective: the other ranks
+        # leave the group here instead of waiting minutes inside one.
+        dist.destroy_process_group()
+        return
 
     roof = None
     cpu = None
     if rank == 0 and a.trace_steps > 0 and not sharded:
-        tr = traced_steps(step_eager, a.trace_steps, lib)        # per-kernel events need eager launches
+        tr = traced_steps(step_eager_local, a.trace_steps, lib)  # per-kernel events need eager launches; this rank's kernels only (no all-reduce: the peers have left)
         costs = algorithmic_costs(wb, w["D"], bi, w["D"] // w["B"])
         total_ms = sum(v["ms_per_step"] for v in tr.values())
         dom = max(tr, key=lambda k: tr[k]["ms_per_step"])

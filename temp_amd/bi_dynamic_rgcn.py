@@ -98,9 +98,9 @@ class BiDynamicRGCN(DynamicRGCN):
             want = self._chain_want(wb)
             # y2 = relu(.) (models/BiRRGCN.py:202-203) is read by ONE consumer here, the gather into chain order: the ReLU's
             # adjoint rides in that gather's backward (one pass less over the (n, d) gradient)
-            fold = l2.relu_fused() and wb.chain_inv is not None
+            # (support is decided BEFORE the conv: ONE flag drops the mask from the layer's backward and hands it to the gather's)
+            fold = l2.relu_fused() and TF.relu_gather_supported(l2.out_feat, wb.chain_inv)
             y2 = l2.conv(wb.g_all, y1, grad_premasked=fold)
-            fold = fold and TF.relu_gather_supported(y2, wb.chain_inv)
             wb.last_x = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv, relu_table=fold)          # GRU input rows in chain order
             got = dict(zip(want, gru_chain(wb.last_x, prog, [l2.forward_rnn, l2.backward_rnn], lam,
                                            isinstance(l2.forward_rnn, GRUCell), want=want)))

@@ -168,6 +168,7 @@ bool gemm_tn_can_fuse_bias(int Nb);
 int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int ldb,
             float* out, int ldo, void* ws, size_t ws_bytes, hipStream_t st, float* bias_out = nullptr);
 // count <= 8 products of one shape class + their bias column sums in one launch and one reduction (gemm_kernels.hip)
+bool gemm_tn_multi_bias_supported(int count, int max_m, int Ka, int Nb, int lda, int ldb);
 size_t gemm_tn_multi_bias_workspace(int count, int max_m, int Ka, int Nb);
 int gemm_tn_multi_bias(int count, const int* Ms, int Ka, int Nb, const float* const* As, int lda, const float* const* Bs, int ldb, float* outs,
                        float* biases, void* ws, size_t ws_bytes, hipStream_t st);

@@ -493,19 +493,24 @@ static int tn_multi_bias_slices(int count, int max_m, int kab8) {
   if (S > cap) S = cap;
   return S < 1 ? 1 : S;
 }
+// the ONE support predicate of the multi-product launch (workspace query and launch agree: a non-zero size means "supported")
+bool gemm_tn_multi_bias_supported(int count, int max_m, int Ka, int Nb, int lda, int ldb) {
+  if (count <= 0 || count > 8 || max_m <= 0 || Ka <= 0 || Nb <= 0 || Ka % 4 || Nb % 4 || lda % 4 || ldb % 4) return false;
+  const TnCfg c = tn_cfg(max_m, Ka, Nb);
+  if (!(c.split == 2 && c.nbb == 1 && tn_bx_ok(max_m, Ka, Nb, lda, ldb) && tn_bx8_ok(Ka) && gemm_tn_can_fuse_bias(Nb))) return false;
+  const int nt = ceil_div(Nb, 32);
+  return nt >= 5 && nt <= 7 && tn_multi_units(ceil_div(Ka, 256)) >= count;
+}
 size_t gemm_tn_multi_bias_workspace(int count, int max_m, int Ka, int Nb) {
   const size_t S = (size_t)tn_multi_bias_slices(count, max_m, ceil_div(Ka, 256));
   return align_up(S * count * Ka * Nb * sizeof(float), 256) + align_up(S * count * Ka * sizeof(float), 256);
 }
 int gemm_tn_multi_bias(int count, const int* Ms, int Ka, int Nb, const float* const* As, int lda, const float* const* Bs, int ldb, float* outs,
                        float* biases, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (count <= 0 || count > 8 || Ka <= 0 || Nb <= 0 || Ka % 4 || Nb % 4 || lda % 4 || ldb % 4) return TEMP_E_UNSUPPORTED;
   int max_m = 0;
-  for (int i = 0; i < count; ++i) max_m = Ms[i] > max_m ? Ms[i] : max_m;
-  const TnCfg c = tn_cfg(max_m, Ka, Nb);
-  if (!(c.split == 2 && c.nbb == 1 && tn_bx_ok(max_m, Ka, Nb, lda, ldb) && tn_bx8_ok(Ka) && gemm_tn_can_fuse_bias(Nb))) return TEMP_E_UNSUPPORTED;
+  for (int i = 0; i < count && i < 8; ++i) max_m = Ms[i] > max_m ? Ms[i] : max_m;
+  if (!gemm_tn_multi_bias_supported(count, max_m, Ka, Nb, lda, ldb)) return TEMP_E_UNSUPPORTED;
   const int nt = ceil_div(Nb, 32);
-  if (nt < 5 || nt > 7 || tn_multi_units(ceil_div(Ka, 256)) < count) return TEMP_E_UNSUPPORTED;
   const int kab8 = ceil_div(Ka, 256), S = tn_multi_bias_slices(count, max_m, kab8);
   if (!ws || ws_bytes < gemm_tn_multi_bias_workspace(count, max_m, Ka, Nb)) return TEMP_E_WORKSPACE;
   int rps = ceil_div(max_m, S);

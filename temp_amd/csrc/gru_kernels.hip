@@ -821,7 +821,12 @@ int temp_gru_weight_grads(int n, int d, int variant, const float* x, const float
 size_t temp_gru_weight_grads_multi_workspace(int count, const int* ns, int d, int variant) {
   if (count <= 0 || count > 4 || !ns || d <= 0 || variant != TEMP_GRU_TORCH) return 0;
   int max_n = 0;
-  for (int i = 0; i < count; ++i) max_n = ns[i] > max_n ? ns[i] : max_n;
+  for (int i = 0; i < count; ++i) {
+    if (ns[i] <= 0) return 0;
+    max_n = ns[i] > max_n ? ns[i] : max_n;
+  }
+  // 0 = "this shape does not take the one-launch path" (same predicate as the launch: the caller allocates nothing and falls back)
+  if (d % 4 || !gemm_tn_multi_bias_supported(2 * count, max_n, 3 * d, d, 3 * d, d)) return 0;
   return gemm_tn_multi_bias_workspace(2 * count, max_n, 3 * d, d);
 }
 

@@ -877,10 +877,11 @@ struct SideStream {
 #define SIDE_POOL 16
 static SideStream* side_acquire(hipStream_t st) {
   static SideStream pool[SIDE_POOL];
-  static std::mutex mu;                          // guards creation only
+  static std::mutex mu;                          // guards the scan AND creation: an entry's state fields are read and written under it
   if (!option(TEMP_OPT_OVERLAP)) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);          // (a handful of backward calls per step: the lock costs nothing next to a launch)
   // first choice: the entry this (device, stream) used before -- a captured graph then sees the same side stream on every capture
   for (int pass = 0; pass < 2; ++pass) {
     for (int i = 0; i < SIDE_POOL; ++i) {
@@ -889,9 +890,8 @@ static SideStream* side_acquire(hipStream_t st) {
       const bool fresh = !p.tried;
       const bool any = p.tried && p.ok && p.dev == dev;
       if (!(pass == 0 ? mine : (fresh || any))) continue;
-      if (p.busy.test_and_set(std::memory_order_acquire)) continue;
+      if (p.busy.test_and_set(std::memory_order_acquire)) continue;      // (released without the lock, by the call that holds it)
       if (!p.tried) {
-        std::lock_guard<std::mutex> lock(mu);
         p.tried = true;
         p.dev = dev;
         p.ok = hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) == hipSuccess &&
@@ -911,18 +911,25 @@ static SideStream* side_acquire(hipStream_t st) {
 struct SideScope {
   SideStream* ss;
   hipStream_t st;
-  bool forked = false;
+  bool forked = false;                           // the side stream waits on the caller's: it must be joined
+  bool join_recorded = false;                    // ss->join was recorded AFTER this call's work (waiting on it otherwise = a stale event)
   SideScope(hipStream_t stream) : ss(side_acquire(stream)), st(stream) {}
   SideScope(const SideScope&) = delete;
   SideScope& operator=(const SideScope&) = delete;
-  int join() {                                   // explicit join on the regular path: its status is the call's status
+  // Join the forked branch back into the caller's stream.  If recording the join event failed the branch cannot be joined by an
+  // event; outside a capture the side stream is drained on the host instead (slow, correct), and the call reports the failure.
+  int join() {
     if (!ss || !forked) return TEMP_OK;
     forked = false;
+    if (!join_recorded) {
+      (void)hipStreamSynchronize(ss->s);
+      return TEMP_E_LAUNCH;
+    }
     return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? TEMP_OK : TEMP_E_LAUNCH;
   }
   ~SideScope() {
     if (!ss) return;
-    if (forked) (void)hipStreamWaitEvent(st, ss->join, 0);
+    (void)join();
     ss->busy.clear(std::memory_order_release);
   }
 };
@@ -935,6 +942,7 @@ static int dw_forked(SideScope& sc, const TempEdgeView& v, const TempMembers* mb
   sc.forked = true;                              // from here on the side stream depends on the caller's: it must be joined
   const int rc = run_dw(v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, ss->s);
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return TEMP_E_LAUNCH;
+  sc.join_recorded = true;
   return rc;
 }
 

@@ -148,8 +148,9 @@ class _GatherRowsFn(torch.autograd.Function):
 
 
 def relu_gather_supported(table, inverse):
-    """True when gather_rows(table, ., inverse, relu_table=True) is available for this table."""
-    return inverse is not None and table.shape[1] % 4 == 0 and table.shape[1] <= 256
+    """True when gather_rows(table, ., inverse, relu_table=True) is available for this table (a tensor, or its width)."""
+    d = table if isinstance(table, int) else table.shape[1]
+    return inverse is not None and d % 4 == 0 and d <= 256
 
 
 def gather_rows(table, idx, inverse=None, relu_table=False):

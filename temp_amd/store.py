@@ -12,7 +12,7 @@ resident with ONE host-to-device copy (GDELT-shaped: 366 snapshots x 0.3 MB), af
 assembled on the GPU (temp_assemble_views) and the training-time edge subsets are drawn there too (temp_subsample_views).
 
 File layout (little endian), all offsets in the header are in BYTES from the start of the file:
-    magic "TSNAPST1" | int64 header[16] = {version, num_ents, num_rels, T, n_rel_rows, chunk, chunk_rel, n_sections, 0...}
+    magic "TSNAPST1" | int64 header[16] = {version (= VERSION below), num_ents, num_rels, T, n_rel_rows, chunk, chunk_rel, n_sections, 0...}
     int64 section table [n_sections][2] = {offset, length in elements}; sections in the order of `_SECTIONS` below.
 """
 import os
@@ -25,6 +25,12 @@ from . import _lib
 from .snapshot import Snapshot, _PACK_NAMES
 
 MAGIC = b"TSNAPST1"
+# Layout version of the PACKED VIEWS inside the file.  2 (round 4): inside a node's segment the by-destination / by-source views list
+# the edges in relation order and a relation's edges are listed in destination order (snapshot.py, host planner `sort_b`); the
+# device edge-id tables (Snapshot.device_edge_ids) assume that order, so a version-1 file -- views in plain segment order -- would
+# make temp_subsample_views keep DIFFERENT edge sets in the three views without any error.  Such files are refused; rewrite them
+# with write_store() (the original-order edge lists they hold are unchanged).
+VERSION = 2
 SPLITS = ("train", "valid", "test")
 # name -> dtype; per-split sections are prefixed with the split name
 _SECTIONS = [("times", np.int64), ("node_ptr", np.int64), ("gids", np.int64)] + \
@@ -64,7 +70,7 @@ def write_store(path, graph_dict_train, graph_dict_val, graph_dict_test, num_ent
         sec[s + "/pack_partial"] = np.asarray(partial, np.int64).reshape(T, 3)
         sec[s + "/rel_chunks"] = np.asarray(relch, np.int64).reshape(T, n_rel_rows)
     header = np.zeros(16, np.int64)
-    header[:8] = [1, num_ents, num_rels, T, n_rel_rows, _lib.CHUNK, _lib.CHUNK_REL, len(_SECTIONS)]
+    header[:8] = [VERSION, num_ents, num_rels, T, n_rel_rows, _lib.CHUNK, _lib.CHUNK_REL, len(_SECTIONS)]
     table = np.zeros((len(_SECTIONS), 2), np.int64)
     off = len(MAGIC) + header.nbytes + table.nbytes
     blobs = []
@@ -121,7 +127,10 @@ class SnapshotStore:
         assert bytes(self.mm[:8]) == MAGIC, "not a temp_amd snapshot store"
         header = np.frombuffer(self.mm, dtype=np.int64, count=16, offset=8)
         version, self.num_ents, self.num_rels, self.T, self.n_rel_rows, chunk, chunk_rel, n_sec = (int(x) for x in header[:8])
-        assert version == 1 and chunk == _lib.CHUNK and chunk_rel == _lib.CHUNK_REL and n_sec == len(_SECTIONS), "store written for another layout"
+        if version != VERSION:
+            raise ValueError("%s: snapshot store layout version %d, this library reads version %d (the order of the packed edge views "
+                             "changed): rebuild the file with temp_amd.store.write_store()" % (path, version, VERSION))
+        assert chunk == _lib.CHUNK and chunk_rel == _lib.CHUNK_REL and n_sec == len(_SECTIONS), "store written for another layout"
         table = np.frombuffer(self.mm, dtype=np.int64, count=2 * n_sec, offset=8 + 128).reshape(n_sec, 2)
         self.sec = {}
         for (name, dt), (off, cnt) in zip(_SECTIONS, table):

@@ -110,3 +110,20 @@ def test_store_round_trip_and_window_golden(tmp_path):
     finally:
         WC._SLICE.clear()
         WC._SLICE.update(saved)
+
+
+def test_store_of_an_older_view_order_is_refused(tmp_path):
+    """A file whose header carries layout version 1 (views in plain segment order, before the relation-ordered views) must not
+    load: the device edge-id tables assume the new order."""
+    from temp_amd.store import VERSION, SnapshotStore, write_store
+    from tests.window_cases import slice_snapshots
+    s = slice_snapshots()
+    path = str(tmp_path / "old.tsnap")
+    few = lambda d: {t: d[t] for t in list(d.keys())[:3]}
+    write_store(path, few(s["tr"]), few(s["va"]), few(s["te"]), s["num_e"], s["num_r"])
+    assert VERSION >= 2 and SnapshotStore(path).T == 3
+    raw = bytearray(open(path, "rb").read())
+    raw[8:16] = np.int64(1).tobytes()
+    open(path, "wb").write(raw)
+    with pytest.raises(ValueError, match="layout version 1"):
+        SnapshotStore(path)

@@ -599,3 +599,29 @@ def check_post_ensemble_loss(device):
     assert abs(loss.item() - want.item()) < 3e-6 * abs(want.item())
     loss.backward()
     assert m.ent_embeds.grad.abs().sum() > 0 and m.ent_encoder.layer_2.forward_rnn.weight_hh_l0.grad.abs().sum() > 0
+
+
+def check_wide_batched_equals_generic(device, width=260, n_bases=130, module="BiGRRGCN"):
+    """Widths the ReLU-folding gather does not take (> 256 columns): layer 2's ReLU adjoint must stay in the layer's own backward
+    (the fold flag was decided before the width check, so the mask was applied by neither node).  Batched + chain
+    against the reference-granular loop, same seed: outputs and every parameter gradient."""
+    s = slice_snapshots()
+    t_list = torch.tensor([20, 15, 9, 3])
+    res = []
+    for batched, chain in ((False, False), (True, True)):
+        args = make_args(module=module, rec_only_last_layer=True, embed_size=width, hidden_size=width, n_bases=n_bases, train_seq_len=6,
+                         test_seq_len=6)
+        torch.manual_seed(13)
+        cls = BiDynamicRGCN if module.startswith("Bi") else DynamicRGCN
+        m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+        m.use_batched_path, m.use_gru_chain = batched, chain
+        m.sample_rng = np.random.default_rng(3)
+        per_graph, *_ = m.encode(t_list, 6, True)
+        sum((e * e * (i + 1)).sum() for i, e in enumerate(per_graph)).backward()
+        res.append(([e.detach().cpu() for e in per_graph], {k: v.grad.detach().cpu().clone() for k, v in m.named_parameters() if v.grad is not None}))
+    (o0, g0), (o1, g1) = res
+    for a, b in zip(o0, o1):
+        assert_close(b, a, 1e-5, 2e-6, "wide batched vs generic")
+    assert set(g0) == set(g1) and len(g0) >= 8
+    for k in g0:
+        assert_close(g1[k], g0[k], 1e-4, 3e-6 * max(1.0, float(g0[k].abs().max())), "wide batched vs generic: d_" + k)
