@@ -351,6 +351,20 @@ int temp_gru_weight_grads_multi(int count, const int* ns, int d, int variant, co
                                 const float* const* dgis, const float* const* dghs, const float* const* w_ihs, float* const* d_xs,
                                 float* d_w, float* d_b, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight / bias gradients and d_x of `count` <= 4 GRUs from their gate-gradient matrices g4s[i] = [ns[i]][4d] (temp_gru_chain_bwd_g4):
+ *   d_W_ih = [dr dz dn_i]^T x,  d_W_hh = [dr dz dn_h]^T hdec,  d_b_* = the column sums,  d_x = [dr dz dn_i] . W_ih
+ * (the backward of the GRU step, models/RRGCN.py:84) -- ONE weight-gradient launch (k_gru_wgrad: both products of every GRU read
+ * their columns of the one matrix through a column map; the row-wise sums take their fragments through LDS transpose reads, no
+ * operand is turned in registers), ONE deterministic reduction over the row slices, ONE d_x launch.  Output layout as
+ * temp_gru_weight_grads_multi: d_w = [2 count][3d][d] (d_W_ih_0, d_W_hh_0, d_W_ih_1, ...), d_b = [2 count][3d].  xs / hdecs / g4s /
+ * w_ihs / d_xs: HOST arrays of device pointers (a d_xs entry may be NULL).  The workspace query returns 0 and the call
+ * TEMP_E_UNSUPPORTED (nothing launched) for shapes that take the dgi / dgh calls: d % 8 != 0, d % 32 == 0, d > 256, fewer than 16 384
+ * rows in all, TEMP_OPT_MFMA_BF16X3 off.  fp32-equivalent arithmetic (six bf16 MFMA products of the exact operand split). */
+size_t temp_gru_grads_g4_workspace(int count, const int* ns, int d);
+int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
+                      const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Persistent window chain: ALL positions of the recurrence in ONE launch per direction of time.
  *
@@ -400,6 +414,11 @@ int temp_gru_chain_pack_multi(int count, int d, const float* const* w_hh, float*
 int temp_gru_chain_fwd(const TempGruChain* c, const float* gi, float* h_out, float* saved, void* stream);
 int temp_gru_chain_bwd(const TempGruChain* c, const float* saved, int n_up, const float* const* up /* HOST array of device pointers */,
                        float* dgi, float* dgh, void* stream);
+/* The same backward with the gate gradients written ONCE (round 5; nn.GRU gate layout only):
+ *   g4 [n_rows][4d] = [dr | dz | dn_i | dn_h]  -- dgi = columns 0 .. 3d-1, dgh = columns 0 .. 2d-1 and 3d .. 4d-1 (two thirds of dgh
+ * repeated dgi: 1 600 bytes per row less to write at d = 200).  Bit-identical values.  Consumed by temp_gru_grads_g4. */
+int temp_gru_chain_bwd_g4(const TempGruChain* c, const float* saved, int n_up, const float* const* up /* HOST array of device pointers */,
+                          float* g4, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row gather / scatter helpers of the window loop

@@ -137,6 +137,9 @@ SYMBOLS = {
     "temp_gru_chain_pack_multi": (_I, [_I, _I, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp]),
     "temp_gru_chain_fwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_chain_bwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp]),
+    "temp_gru_chain_bwd_g4": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp]),
+    "temp_gru_grads_g4_workspace": (ctypes.c_size_t, [_I, c_vp, _I]),
+    "temp_gru_grads_g4": (_I, [_I, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_segment_sum_rows_workspace": (_SZ, [_I, _I, _I]),

@@ -350,6 +350,46 @@ class HipBackend:
         rc = self.lib.temp_gru_chain_bwd(ctypes.byref(c), _ptr(saved_all), len(ups), arr, _ptr(dgi), _ptr(dgh), _stream())
         _lib.check(rc, "temp_gru_chain_bwd")
 
+    def gru_chain_bwd_g4(self, tabs, saved_all, ups, lam, variant, packs, b_hhs, g4):
+        """The chain backward with the gate gradients written once: g4 [N, 4d] = [dr | dz | dn_i | dn_h] (include/temp_amd.h:
+        temp_gru_chain_bwd_g4; nn.GRU gate layout)."""
+        d = saved_all.shape[2]
+        c, keep = self._chain_desc(tabs, d, variant, lam, saved_all.shape[1] * d, packs, b_hhs)
+        ups = [_f32(u, "upstream") if u is not None else None for u in ups]
+        arr = (ctypes.c_void_p * max(len(ups), 1))(*[u.data_ptr() if u is not None else None for u in ups])
+        rc = self.lib.temp_gru_chain_bwd_g4(ctypes.byref(c), _ptr(saved_all), len(ups), arr, _ptr(g4), _stream())
+        _lib.check(rc, "temp_gru_chain_bwd_g4")
+
+    def gru_grads_g4_supported(self, ns, d, variant):
+        """True when gru_grads_g4 takes GRUs of these row counts and this width (then the chain backward should write g4)."""
+        k = len(ns)
+        if k < 1 or k > 4 or variant != _lib.GRU_TORCH:
+            return False
+        return self.lib.temp_gru_grads_g4_workspace(k, (ctypes.c_int * k)(*[int(n) for n in ns]), int(d)) > 0
+
+    def gru_grads_g4(self, xs, hdecs, g4s, w_ihs, d_xs):
+        """Weight / bias gradients and d_x of several GRUs of one width from their gate-gradient matrices (include/temp_amd.h:
+        temp_gru_grads_g4) -> [(d_w_ih, d_w_hh, d_b_ih, d_b_hh)] per GRU."""
+        k = len(xs)
+        d = xs[0].shape[1]
+        dev = xs[0].device
+        ns = (ctypes.c_int * k)(*[x.shape[0] for x in xs])
+        nb = self.lib.temp_gru_grads_g4_workspace(k, ns, d)
+        if nb == 0:
+            raise ValueError("temp_gru_grads_g4: unsupported shape (check gru_grads_g4_supported first)")
+        keep = [[_f32(t, "operand") for t in ts] for ts in (xs, hdecs, w_ihs)]
+        for g in g4s:
+            assert g.dtype == torch.float32 and g.is_contiguous() and g.shape[1] == 4 * d
+        arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+        dx = (ctypes.c_void_p * k)(*[None if t is None else t.data_ptr() for t in d_xs])
+        d_w = torch.empty(2 * k, 3 * d, d, dtype=torch.float32, device=dev)
+        d_b = torch.empty(2 * k, 3 * d, dtype=torch.float32, device=dev)
+        ws = self._ws(nb, dev)
+        rc = self.lib.temp_gru_grads_g4(k, ns, d, arr(keep[0]), arr(keep[1]), arr(g4s), arr(keep[2]), dx, _ptr(d_w), _ptr(d_b), _ptr(ws),
+                                        ws.numel(), _stream())
+        _lib.check(rc, "temp_gru_grads_g4")
+        return [(d_w[2 * i], d_w[2 * i + 1], d_b[2 * i], d_b[2 * i + 1]) for i in range(k)]
+
     def gru_weight_grads(self, x, hdec, dgi, dgh, w_ih, variant, d_x):
         n, d = x.shape
         w_ih = _f32(w_ih, "w_ih")

@@ -1114,7 +1114,7 @@ const char* temp_trace_kernel_name(int id) {
                                 "k_gru_bwd_gates", "k_gemm_panel<gru_dx>", "k_gemm_panel<gru_dprev>", "k_gather_rows",
                                 "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>", "k_gemm_panel<gru_gi>",
                                 "k_gemm_panel<linear>", "k_gather_ce", "k_sa_attn_fwd", "k_sa_attn_bwd", "k_gru_chain_fwd", "k_gru_chain_bwd",
-                                "k_gru_chain_pack", "k_bx_pack", "k_gemm_tn_bx8", "k_gemm_tn_bx"};
+                                "k_gru_chain_pack", "k_bx_pack", "k_gemm_tn_bx8", "k_gemm_tn_bx", "k_gru_wgrad"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 

@@ -350,7 +350,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd(ChainArgs a, co
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------
-template <int VARIANT, int TPWB, int MW, int BX>
+// G4 = 1 (nn.GRU gate layout): the gate gradients are written ONCE, as dgi = [n][4d] = [dr | dz | dn_i | dn_h] (dgh unused) -- two
+// thirds of dgh repeat dgi; the weight-gradient and d_x kernels address their columns of the one matrix (gru_wgrad.hpp).
+template <int VARIANT, int TPWB, int MW, int BX, int G4 = 0>
 __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, ChainUps ups, const float* __restrict__ saved,
                                                                   float* __restrict__ dgi, float* __restrict__ dgh) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -604,10 +606,15 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd(ChainArgs a, Ch
           float* arow = ab + (size_t)slot * ldA + col;
           st4(arow, dr_pre); st4(arow + D, dz_pre); st4(arow + 2 * D, dhn);
           st4(gzb + (size_t)slot * ldz + col, gz);
+          if constexpr (G4) {
+            const size_t b4 = row * 4 * D + col;
+            st4(dgi + b4, dr_pre); st4(dgi + b4 + D, dz_pre); st4(dgi + b4 + 2 * D, dn_pre); st4(dgi + b4 + 3 * D, dhn);
+          } else {
           const size_t b3 = row * 3 * D + col;
           if (VARIANT == TEMP_GRU_TORCH) { st4(dgi + b3, dr_pre); st4(dgi + b3 + D, dz_pre); st4(dgi + b3 + 2 * D, dn_pre); }
           else st4(dgi + row * D + col, dn_pre);
           st4(dgh + b3, dr_pre); st4(dgh + b3 + D, dz_pre); st4(dgh + b3 + 2 * D, dhn);
+          }
         }
         __syncthreads();      // A
         if (s > 0) prefetch(s - 1);            // issued behind the barrier (the matrix waves start at once), in flight while they
@@ -672,19 +679,19 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
   return launch_status();
 }
 
-template <int VARIANT, int TPWB>
+template <int VARIANT, int TPWB, int G4 = 0>
 static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float* saved, float* dgi, float* dgh, hipStream_t st) {
   static bool attr = false;
   static bool attr_bx = false;
   const size_t lds = chain_lds_bwd(a.D, a.max_steps);
   if (chain_bx(a.D)) {
-    auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 1>;
+    auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 1, G4>;
     int rc = chain_lds_attr(kernel, lds, &attr_bx);
     if (rc) return rc;
     TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds, st, a, ups, saved, dgi, dgh);
     return launch_status();
   }
-  auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 0>;
+  auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 0, G4>;
   int rc = chain_lds_attr(kernel, lds, &attr);
   if (rc) return rc;
   TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds, st, a, ups, saved, dgi, dgh);
@@ -773,6 +780,23 @@ int temp_gru_chain_fwd(const TempGruChain* c, const float* gi, float* h_out, flo
   if (c->variant == TEMP_GRU_TORCH) { TEMP_CHAIN_FWD(TEMP_GRU_TORCH) }
   TEMP_CHAIN_FWD(TEMP_GRU_TYPE1)
 #undef TEMP_CHAIN_FWD
+}
+
+int temp_gru_chain_bwd_g4(const TempGruChain* c, const float* saved, int n_up, const float* const* up, float* g4, void* stream) {
+  int rc = chain_check(c);
+  if (rc) return rc;
+  if (n_up < 0 || n_up > TEMP_CHAIN_MAX_UP || (n_up > 0 && !up)) return TEMP_E_BADARG;
+  if (c->variant != TEMP_GRU_TORCH) return TEMP_E_UNSUPPORTED;        // (the type-1 cell's dgi is [n, d])
+  if (c->n_panels == 0) return TEMP_OK;
+  if (!saved || !g4) return TEMP_E_BADARG;
+  const ChainArgs a = chain_args(c);
+  ChainUps ups = {};
+  for (int i = 0; i < n_up; ++i) ups.p[i] = up[i];
+  hipStream_t st = (hipStream_t)stream;
+  const int tpw = ceil_div(chain_geom(c->d).NTb, 4);
+  if (tpw == 1) return launch_chain_bwd<TEMP_GRU_TORCH, 1, 1>(a, ups, saved, g4, nullptr, st);
+  if (tpw == 2) return launch_chain_bwd<TEMP_GRU_TORCH, 2, 1>(a, ups, saved, g4, nullptr, st);
+  return TEMP_E_UNSUPPORTED;
 }
 
 int temp_gru_chain_bwd(const TempGruChain* c, const float* saved, int n_up, const float* const* up, float* dgi, float* dgh, void* stream) {

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "gemm_wres.hpp"
 #include "gru_math.hpp"
+#include "gru_wgrad.hpp"
 
 namespace temp {
 
@@ -534,6 +535,30 @@ static GruBwdWs carve_gru(int n, int d, int variant, char* base) {
 
 using namespace temp;
 
+// ---- GRU gradients of a window chain from the ONE gate-gradient matrix g4 = [n][4d] = [dr | dz | dn_i | dn_h] -------------------
+static bool grads_g4_plan(int count, const int* ns, int d, WgArgs* a) {
+  if (count <= 0 || count > WG_MAXG || !ns || d <= 0 || !bx_enabled()) return false;
+  int max_n = 0;
+  long long rows = 0;
+  for (int i = 0; i < count; ++i) {
+    if (ns[i] <= 0) return false;
+    max_n = ns[i] > max_n ? ns[i] : max_n;
+    rows += ns[i];
+  }
+  if (rows < BX_MIN_ROWS) return false;                          // (few rows: the per-GRU fp32 kernels win)
+  const int nt = ceil_div(d, 32);
+  if (nt < 1 || nt > 8) return false;
+  return wg_plan(count, d, max_n, a);
+}
+
+template <int NT>
+static int launch_gru_wgrad(const WgArgs& a, hipStream_t st) {
+  static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_wgrad<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes(NT)) == hipSuccess;
+  if (!granted) { (void)hipGetLastError(); return TEMP_E_UNSUPPORTED; }
+  TEMP_LAUNCH(K_GRU_WGRAD, (k_gru_wgrad<NT>), dim3(8 * a.per_xcd * a.P), dim3(WG_THREADS), wg_lds_bytes(NT), st, a);
+  return TEMP_OK;
+}
+
 extern "C" {
 
 static int launch_gru_fwd_batch(const GruFwdBatch& batch, int count, int d, int variant, bool hoisted, float lambda, const float* decay_wb,
@@ -858,6 +883,55 @@ int temp_gru_weight_grads_multi(int count, const int* ns, int d, int variant, co
     if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], dgis[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}};
   for (int i = nx; i < PANEL_MAXP && nx > 0; ++i) { batch.p[i] = batch.p[0]; batch.p[i].M = 0; }
   if (nx > 0) rc = launch_gemm_panel_multi(K_GEMM_GRU_DX, batch, nx, d, 3 * d, 3 * d, d, 0, st);       // d_x = dgi . W_ih
+  return rc ? rc : launch_status();
+}
+
+size_t temp_gru_grads_g4_workspace(int count, const int* ns, int d) {
+  WgArgs a = {};
+  if (!grads_g4_plan(count, ns, d, &a)) return 0;                // 0 = "this shape takes the dgi / dgh calls" (nothing to allocate)
+  return wg_workspace(a).total;
+}
+
+int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
+                      const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (count <= 0 || count > WG_MAXG || !ns || !xs || !hdecs || !g4s || !w_ihs || !d_xs || !d_w || !d_b) return TEMP_E_BADARG;
+  WgArgs a = {};
+  if (!grads_g4_plan(count, ns, d, &a)) return TEMP_E_UNSUPPORTED;
+  for (int i = 0; i < count; ++i) {
+    if (!xs[i] || !hdecs[i] || !g4s[i] || !w_ihs[i]) return TEMP_E_UNSUPPORTED;
+    a.g[i] = WgGroup{ns[i], g4s[i], xs[i], hdecs[i]};
+  }
+  const WgWs ws = wg_workspace(a);
+  if (!workspace || workspace_bytes < ws.total) return TEMP_E_WORKSPACE;
+  char* base = (char*)workspace;
+  a.part = (float*)(base + ws.part); a.bpart = (float*)(base + ws.bpart);
+  a.part2 = (float*)(base + ws.part2); a.bpart2 = (float*)(base + ws.bpart2);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  switch (ceil_div(d, 32)) {
+    case 1: rc = launch_gru_wgrad<1>(a, st); break;
+    case 2: rc = launch_gru_wgrad<2>(a, st); break;
+    case 3: rc = launch_gru_wgrad<3>(a, st); break;
+    case 4: rc = launch_gru_wgrad<4>(a, st); break;
+    case 5: rc = launch_gru_wgrad<5>(a, st); break;
+    case 6: rc = launch_gru_wgrad<6>(a, st); break;
+    case 7: rc = launch_gru_wgrad<7>(a, st); break;
+    default: rc = launch_gru_wgrad<8>(a, st); break;
+  }
+  if (rc) return rc;
+  const int Ka = 3 * d, R0 = a.tail ? 256 * a.fb : Ka, S2 = a.tail ? a.S * a.P : 0;
+  const long long quads = (long long)2 * count * Ka * (d / 4);
+  int gx = ceil_div(quads, 256);
+  if (gx > 2048) gx = 2048;
+  TEMP_LAUNCH(K_REDUCE_SLICES, k_gru_wgrad_reduce, dim3(gx), dim3(256), 0, st, 2 * count, Ka, d, a.S, a.part, a.bpart, R0, S2, a.part2, a.bpart2, d_w, d_b);
+  // d_x = [dr dz dn_i] . W_ih: the first 3d columns of a g4 row (row stride 4d)
+  PanelBatch<EpiStore> batch;
+  int nx = 0;
+  for (int i = 0; i < count; ++i)
+    if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], g4s[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}};
+  for (int i = nx; i < PANEL_MAXP && nx > 0; ++i) { batch.p[i] = batch.p[0]; batch.p[i].M = 0; }
+  if (nx > 0) rc = launch_gemm_panel_multi(K_GEMM_GRU_DX, batch, nx, d, 3 * d, 4 * d, d, 0, st);
   return rc ? rc : launch_status();
 }
 

@@ -22,6 +22,7 @@ from .backend import get_backend
 
 CHAIN_KERNELS = True        # A/B switch: False keeps the per-position launches (temp_gru_cell_*_multi)
 WEIGHT_GRADS_MULTI = True   # A/B switch: False computes each GRU's weight gradients with its own launches (temp_gru_weight_grads)
+GATE_GRADS_ONCE = True      # A/B switch: False keeps dgi + dgh as two matrices (temp_gru_chain_bwd + temp_gru_weight_grads_multi)
 
 
 class GruInstance:
@@ -364,6 +365,34 @@ class _GruChainFn(torch.autograd.Function):
         else:
             given = {i: g.contiguous() for i, g in zip(ctx.want, d_outs) if g is not None}
             up = lambda i, it: given.get(i)                  # None: no upstream gradient for this instance's rows
+        groups = list(prog.groups)
+        zero_state = [all(it.prev < 0 for it in prog.inst if it.group == gi) for gi in range(len(groups))]    # hdec = 0 on every row
+        # GRUs with disjoint x rows (the two directions of a bidirectional chain, or the one GRU of a uni-directional one): ONE
+        # weight-gradient launch for all d_W_ih / d_W_hh products, ONE reduction and ONE d_x launch
+        disjoint = all(groups[a]["x1"] <= groups[b]["x0"] or groups[b]["x1"] <= groups[a]["x0"] for a in range(len(groups)) for b in range(a))
+        one_launch = bool(groups and disjoint and not any(zero_state) and len({g["rnn"] for g in groups}) == len(groups) and WEIGHT_GRADS_MULTI)
+        # ... and when the library takes these shapes, the chain backward writes its gate gradients ONCE, [dr | dz | dn_i | dn_h]
+        # (two thirds of dgh repeat dgi), for temp_gru_grads_g4
+        once = bool(one_launch and GATE_GRADS_ONCE and ctx.tabs is not None and hasattr(be, "gru_grads_g4")
+                    and be.gru_grads_g4_supported([g["h1"] - g["h0"] for g in groups], d, variant))
+        if once:
+            g4 = torch.empty(N, 4 * d, dtype=torch.float32, device=dev)
+            ups = [dH] if ctx.want is None else [given.get(i) for i in ctx.want]
+            be.gru_chain_bwd_g4(ctx.tabs, saved, ups, lam, variant, ctx.packs, [W[r][3] for r in range(ctx.n_rnn)], g4)
+            d_x_all = torch.empty_like(x_all)
+            xsl = [slice(g["x0"], g["x1"]) for g in groups]
+            hsl = [slice(g["h0"], g["h1"]) for g in groups]
+            multi = be.gru_grads_g4([x_all[a] for a in xsl], [saved[4, b] for b in hsl], [g4[b] for b in hsl], [W[g["rnn"]][0] for g in groups],
+                                    [d_x_all[a] for a in xsl])
+            grads = [None] * (4 * ctx.n_rnn)
+            covered = np.zeros(x_all.shape[0], dtype=bool)
+            for g, gw in zip(groups, multi):
+                covered[g["x0"]:g["x1"]] = True
+                for k in range(4):
+                    grads[4 * g["rnn"] + k] = gw[k]
+            if not covered.all():
+                d_x_all[torch.from_numpy(~covered).to(dev)] = 0
+            return (d_x_all, None, None, None, None, None) + tuple(grads)
         dgi = torch.empty(N, G, dtype=torch.float32, device=dev)
         dgh = torch.empty(N, 3 * d, dtype=torch.float32, device=dev)
         if ctx.tabs is not None:
@@ -387,14 +416,8 @@ class _GruChainFn(torch.autograd.Function):
         d_x_all = torch.empty_like(x_all)
         written = np.zeros(x_all.shape[0], dtype=bool)
         grads = [None] * (4 * ctx.n_rnn)
-        groups = list(prog.groups)
-        zero_state = [all(it.prev < 0 for it in prog.inst if it.group == gi) for gi in range(len(groups))]    # hdec = 0 on every row
-        # GRUs with disjoint x rows (the two directions of a bidirectional chain, or the one GRU of a uni-directional one): ONE
-        # weight-gradient launch for all d_W_ih / d_W_hh products, ONE reduction and ONE d_x launch
         multi = None
-        disjoint = all(groups[a]["x1"] <= groups[b]["x0"] or groups[b]["x1"] <= groups[a]["x0"] for a in range(len(groups)) for b in range(a))
-        if (groups and disjoint and not any(zero_state) and len({g["rnn"] for g in groups}) == len(groups)
-                and WEIGHT_GRADS_MULTI and hasattr(be, "gru_weight_grads_multi")):
+        if one_launch and hasattr(be, "gru_weight_grads_multi"):
             xsl = [slice(g["x0"], g["x1"]) for g in groups]
             hsl = [slice(g["h0"], g["h1"]) for g in groups]
             multi = be.gru_weight_grads_multi([x_all[a] for a in xsl], [saved[4, b] for b in hsl], [dgi[b] for b in hsl], [dgh[b] for b in hsl],

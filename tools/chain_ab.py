@@ -74,6 +74,37 @@ def weight_grads_ab(steps=200):
         print("weight gradients of both directions in one launch: %-5s  step %s ms (graph replays)" % (flag, ", ".join("%.3f" % x for x in v)), flush=True)
 
 
+def gate_grads_ab(steps=200):
+    """Gate gradients written once (temp_gru_chain_bwd_g4 + temp_gru_grads_g4: k_gru_wgrad) against dgi + dgh (temp_gru_chain_bwd +
+    temp_gru_weight_grads_multi): the whole step as a HIP graph, alternating, on this box; then the kernels of an eager step."""
+    from temp_amd import _lib, gru_chain as GC, synthetic
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    w = synthetic.workload("S-gdelt", seed=0)
+    model = bench.build_model(w, dev)
+    model.sample_rng = np.random.default_rng(2)
+    wb = model.prepare(synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0), w["L"], train=True)
+    res = {}
+    for rep in range(3):
+        for flag in (True, False):
+            GC.GATE_GRADS_ONCE = flag
+            st = bench.GraphStep(lambda: model.run(wb)[0], list(model.parameters()), graph=True)
+            res.setdefault(flag, []).append(st.time(steps, 20))
+    for flag, v in res.items():
+        print("gate gradients once: %-5s  step %s ms (graph replays)" % (flag, ", ".join("%.3f" % x for x in v)), flush=True)
+    for flag in (True, False):
+        GC.GATE_GRADS_ONCE = flag
+        st = bench.GraphStep(lambda: model.run(wb)[0], list(model.parameters()), graph=False)
+        for _ in range(2):
+            st.eager()
+        torch.cuda.synchronize()
+        tr = bench.traced_steps(st.eager, 5, lib)
+        keys = ("k_gru_chain_bwd", "k_gru_wgrad", "k_gemm_tn_bx8", "k_gemm_panel<gru_dx>", "k_reduce_slices")
+        print("gate gradients once: %-5s  " % flag + "  ".join("%s %.1f us" % (k, 1e3 * tr[k]["ms_per_step"]) for k in keys if k in tr)
+              + "  all kernels %.3f ms" % sum(v["ms_per_step"] for v in tr.values()), flush=True)
+    GC.GATE_GRADS_ONCE = True
+
+
 def debug_ab(value, what, steps=200):
     """The whole step as a HIP graph with TEMP_OPT_DEBUG = 0 against `value` (a development switch of the library), alternating."""
     from temp_amd import _lib, synthetic
@@ -98,6 +129,9 @@ if __name__ == "__main__":
     if "--debug" in sys.argv:
         i = sys.argv.index("--debug")
         debug_ab(int(sys.argv[i + 1]), " ".join(sys.argv[i + 2:]) or "switch")
+        sys.exit(0)
+    if "--gate-grads" in sys.argv:
+        gate_grads_ab()
         sys.exit(0)
     if "--weight-grads" in sys.argv:
         sys.argv.remove("--weight-grads")

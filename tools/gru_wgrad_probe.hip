@@ -1,6 +1,6 @@
-// Probe: k_gru_wgrad_planes (weight gradients from pre-split gate planes, LDS transpose reads) -- semantics of
-// ds_read_b64_tr_b16, correctness against fp64, timing and ablations at the headline shape.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I temp_amd/csrc -I include tools/wgrad_planes_probe.hip -o tools/build/wgrad_planes_probe
+// Probe: k_gru_wgrad (GRU weight gradients from the one gate-gradient matrix, LDS transpose reads) -- semantics of
+// ds_read_b64_tr_b16, correctness against fp64, timing, ablations and the shader clock at the headline shape.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I temp_amd/csrc -I include tools/gru_wgrad_probe.hip -o tools/build/gru_wgrad_probe
 #include "common.hpp"
 #include <cstdio>
 #include <cstring>
@@ -8,7 +8,7 @@
 #include <cmath>
 #include <algorithm>
 #include <type_traits>
-#include "wgrad_planes.hpp"
+#include "gru_wgrad.hpp"
 using namespace temp;
 int temp::trace_open(int, hipStream_t) { return -1; }
 void temp::trace_close(int, hipStream_t) {}
@@ -60,7 +60,7 @@ static void tr_semantics() {
                     h_out[16], h_out[17], h_out[18], h_out[19], h_out[64], h_out[65], h_out[66], h_out[67]); }
 }
 
-static void split_host(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+[[maybe_unused]] static void split_host(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
   unsigned bx; memcpy(&bx, &x, 4);
   const unsigned hb = bx & 0xffff0000u; float hf; memcpy(&hf, &hb, 4);
   const float r1 = x - hf; unsigned b1; memcpy(&b1, &r1, 4);
@@ -75,43 +75,60 @@ static void run_case(int count, int M, int d) {
   if (!wg_plan(count, d, M, &a)) { printf("plan refused\n"); return; }
   const int Ka = 3 * d;
   const size_t N = (size_t)count * M;
-  a.gp_plane = N * 4 * d;
   std::vector<float> g4(N * 4 * d), x(N * d), hd(N * d);
   unsigned st = 777u + M;
   auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.f - 0.5f; };
   for (auto& v : g4) v = rnd() * expf(3.f * rnd());
   for (auto& v : x) v = rnd() * 2.f;
   for (auto& v : hd) v = rnd() * 2.f;
-  std::vector<unsigned short> gp(3 * N * 4 * d);
-  for (size_t i = 0; i < N * 4 * d; ++i) split_host(g4[i], gp[i], gp[N * 4 * d + i], gp[2 * N * 4 * d + i]);
-  unsigned short* d_gp; float *d_x, *d_h, *part, *bpart;
-  (void)hipMalloc(&d_gp, gp.size() * 2 + 4096); (void)hipMalloc(&d_x, x.size() * 4); (void)hipMalloc(&d_h, hd.size() * 4);
-  const size_t pfl = (size_t)a.S * 2 * count * Ka * d, bfl = (size_t)a.S * 2 * count * Ka;
-  (void)hipMalloc(&part, pfl * 4); (void)hipMalloc(&bpart, bfl * 4);
-  (void)hipMemset(part, 0xff, pfl * 4); (void)hipMemset(bpart, 0xff, bfl * 4);
-  (void)hipMemcpy(d_gp, gp.data(), gp.size() * 2, hipMemcpyHostToDevice);
+  float *d_x, *d_h, *part, *bpart, *d_g4;
+  (void)hipMalloc(&d_g4, g4.size() * 4 + 4096); (void)hipMemcpy(d_g4, g4.data(), g4.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMalloc(&d_x, x.size() * 4); (void)hipMalloc(&d_h, hd.size() * 4);
+  const WgWs ws = wg_workspace(a);
+  char* d_ws; float *d_w, *d_b;
+  (void)hipMalloc(&d_ws, ws.total); (void)hipMemset(d_ws, 0xff, ws.total);
+  (void)hipMalloc(&d_w, (size_t)2 * count * Ka * d * 4); (void)hipMalloc(&d_b, (size_t)2 * count * Ka * 4);
+  part = (float*)(d_ws + ws.part); bpart = (float*)(d_ws + ws.bpart);
+  a.part2 = (float*)(d_ws + ws.part2); a.bpart2 = (float*)(d_ws + ws.bpart2);
   (void)hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(d_h, hd.data(), hd.size() * 4, hipMemcpyHostToDevice);
-  for (int g = 0; g < count; ++g) a.g[g] = WgGroup{M, d_gp + (size_t)g * M * 4 * d, d_x + (size_t)g * M * d, d_h + (size_t)g * M * d};
+  for (int g = 0; g < count; ++g) a.g[g] = WgGroup{M, d_g4 + (size_t)g * M * 4 * d, d_x + (size_t)g * M * d, d_h + (size_t)g * M * d};
   a.part = part; a.bpart = bpart;
   const int grid = 8 * a.per_xcd * a.P;
   const size_t lds = wg_lds_bytes(NT);
-  printf("count %d M %d d %d: T %d fb %d r %d mixed %d P %d per_xcd %d S %d rows/slice %d grid %d lds %zu\n", count, M, d, a.T, a.fb, a.r, a.mixed, a.P, a.per_xcd, a.S,
-         a.rows_per_slice, grid, lds);
+  printf("count %d M %d d %d: T %d fb %d r %d mixed %d tail %d P %d per_xcd %d S %d rows/slice %d (tail share %d) grid %d lds %zu\n", count, M, d, a.T, a.fb, a.r, a.mixed,
+         a.tail, a.P, a.per_xcd, a.S, a.rows_per_slice, a.rows_per_tail, grid, lds);
 #define SETATTR(K) if (hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) printf("setattr failed\n");
-  SETATTR((k_gru_wgrad_planes<NT, 0>))
-  auto run = [&]() { hipLaunchKernelGGL((k_gru_wgrad_planes<NT, 0>), dim3(grid), dim3(WG_THREADS), lds, 0, a); };
+  SETATTR((k_gru_wgrad<NT, 0>))
+  auto run = [&]() { hipLaunchKernelGGL((k_gru_wgrad<NT, 0>), dim3(grid), dim3(WG_THREADS), lds, 0, a); };
   run();
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return; }
   const float t = time_ms(run);
   const double flops = 2.0 * N * Ka * d * 2;
-  printf("  k_gru_wgrad_planes: %.4f ms  = %.1f TFLOP/s algorithmic (%.3f of the bf16/6 roof)\n", t, flops / t / 1e9, flops / t / 1e9 / (2500.0 / 6));
-#define ABL(V) { SETATTR((k_gru_wgrad_planes<NT, V>)) auto f = [&]() { hipLaunchKernelGGL((k_gru_wgrad_planes<NT, V>), dim3(grid), dim3(WG_THREADS), lds, 0, a); }; printf("  VAR %3d: %.4f ms\n", V, time_ms(f)); }
-  if (M >= 50000) { ABL(1) ABL(5) ABL(8) ABL(256) ABL(512) ABL(768) ABL(1024) ABL(1280) ABL(1536) ABL(1792) ABL(0) ABL(256) ABL(512) ABL(768) ABL(1024) ABL(1280) ABL(1536) ABL(1792) }
+  printf("  k_gru_wgrad: %.4f ms  = %.1f TFLOP/s algorithmic (%.3f of the bf16/6 roof)\n", t, flops / t / 1e9, flops / t / 1e9 / (2500.0 / 6));
+#define ABL(V) { SETATTR((k_gru_wgrad<NT, V>)) auto f = [&]() { hipLaunchKernelGGL((k_gru_wgrad<NT, V>), dim3(grid), dim3(WG_THREADS), lds, 0, a); }; printf("  VAR %3d: %.4f ms\n", V, time_ms(f)); }
+  if (M >= 50000) {
+    ABL(0) ABL(256) ABL(1) ABL(5) ABL(8) ABL(0) ABL(256)
+    run(); (void)hipDeviceSynchronize();
+    unsigned long long* dbg; (void)hipMalloc(&dbg, 16 * 8 * 512); a.dbg = dbg;
+#define CLK(V) { (void)hipMemset(dbg, 0, 16 * 8 * 512); SETATTR((k_gru_wgrad<NT, V>)) hipLaunchKernelGGL((k_gru_wgrad<NT, V>), dim3(grid), dim3(WG_THREADS), lds, 0, a); (void)hipDeviceSynchronize(); \
+      std::vector<unsigned long long> h(2 * 8 * 512); (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost); double c = 0, r = 0; int n = 0; \
+      double rmax = 0, rb[8] = {0}; int nb[8] = {0}; \
+      for (size_t i = 0; i < h.size(); i += 2) if (h[i + 1]) { c += h[i]; r += h[i + 1]; ++n; rmax = std::max(rmax, (double)h[i + 1]); \
+        const int blk = (int)(i / 16), bq = (blk >> 3) % a.P; rb[bq] += h[i + 1]; nb[bq]++; } \
+      printf("  VAR %3d: %d waves, mean loop %.0f shader cycles = %.1f us (100 MHz counter) -> %.2f GHz; slowest wave %.1f us; by workgroup of the pair:", V, n, c / n, r / n / 100.0, c / r / 10.0, rmax / 100.0); \
+      for (int q = 0; q < a.P; ++q) printf(" %.1f", nb[q] ? rb[q] / nb[q] / 100.0 : 0.0); printf(" us\n"); }
+    CLK(64) CLK(320) CLK(69) CLK(65) CLK(64) CLK(320)
+    a.dbg = nullptr; (void)hipFree(dbg);
+  }
   run(); (void)hipDeviceSynchronize();
-  std::vector<float> hp(pfl), hb(bfl);
-  (void)hipMemcpy(hp.data(), part, pfl * 4, hipMemcpyDeviceToHost);
-  (void)hipMemcpy(hb.data(), bpart, bfl * 4, hipMemcpyDeviceToHost);
+  const int R0 = a.tail ? 256 * a.fb : Ka, S2 = a.tail ? a.S * a.P : 0;
+  auto reduce = [&]() { hipLaunchKernelGGL(k_gru_wgrad_reduce, dim3(256), dim3(256), 0, 0, 2 * count, Ka, d, a.S, part, bpart, R0, S2, a.part2, a.bpart2, d_w, d_b); };
+  reduce();
+  printf("  k_gru_wgrad_reduce: %.4f ms\n", time_ms(reduce));
+  std::vector<float> hw((size_t)2 * count * Ka * d), hbias((size_t)2 * count * Ka);
+  (void)hipMemcpy(hw.data(), d_w, hw.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hbias.data(), d_b, hbias.size() * 4, hipMemcpyDeviceToHost);
   double worst = 0, worst_b = 0;
   int checked = 0;
   for (int g = 0; g < count; ++g)
@@ -125,18 +142,17 @@ static void run_case(int count, int M, int d) {
             const double av = g4[((size_t)g * M + m) * 4 * d + acol], bv = B[((size_t)g * M + m) * d + nb];
             ref += av * bv; mag += fabs(av * bv);
           }
-          double got = 0;
-          for (int s = 0; s < a.S; ++s) got += hp[((size_t)s * 2 * count + 2 * g + prod) * Ka * d + (size_t)ka * d + nb];
+          const double got = hw[((size_t)(2 * g + prod) * Ka + ka) * d + nb];
           worst = std::max(worst, fabs(got - ref) / mag);
           ++checked;
         }
-        double ref = 0, mag = 0, got = 0;
+        double ref = 0, mag = 0;
         for (int m = 0; m < M; ++m) { const double av = g4[((size_t)g * M + m) * 4 * d + acol]; ref += av; mag += fabs(av); }
-        for (int s = 0; s < a.S; ++s) got += hb[((size_t)s * 2 * count + 2 * g + prod) * Ka + ka];
+        const double got = hbias[(size_t)(2 * g + prod) * Ka + ka];
         worst_b = std::max(worst_b, fabs(got - ref) / mag);
       }
   printf("  %d sampled outputs: max |err| / sum|a||b| = %.3e   bias sums: %.3e\n", checked, worst, worst_b);
-  (void)hipFree(d_gp); (void)hipFree(d_x); (void)hipFree(d_h); (void)hipFree(part); (void)hipFree(bpart);
+  (void)hipFree(d_g4); (void)hipFree(d_x); (void)hipFree(d_h); (void)hipFree(d_ws); (void)hipFree(d_w); (void)hipFree(d_b);
 }
 
 int main() {
