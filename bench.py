@@ -16,7 +16,8 @@ one bucket after backward.
 
 Extra objects on the JSON line:
   extra         short secondary measurements of the same process (never the headline): the step with the link-prediction loss,
-                the self-attention encoder (config 5), the snapshot-sharded north-star step on one RCCL rank, and the FULL
+                the self-attention encoder (config 5), the snapshot-sharded north-star step on one RCCL rank, BASELINE configs 1-3
+                at their own sizes (static RGCN; GRRGCN with the reference's default flags; post-ensemble BiGRRGCN), and the FULL
                 window in the HBM regime (S-hbm-window: bi L=15 bsz=1 over 2^18-node / 2^22-edge snapshots, 230 relations --
                 the regime BASELINE's "% HBM roofline" is named after; its own roofline object uses SURVEY 8d's byte model)
   roofline      dominant kernel (largest share of traced kernel time): algorithmic bytes (or
@@ -571,9 +572,70 @@ def extra_measurements(a, w, model, wb, targets, device, lib):
         return dict(what="north-star snapshot-sharded step on ONE RCCL rank (three HIP graphs around the two exchanges + grad all-reduce)",
                     ms_per_step=r["ms_per_step"], edges_per_s=r["value"], launch=r["launch"], rccl_ranks=r["rccl_ranks"], steps=steps)
 
+    def launches_of(step_fn):
+        tr = traced_steps(step_fn, 1, lib)
+        return int(round(sum(v["launches_per_step"] for v in tr.values()))), sum(v["ms_per_step"] for v in tr.values())
+
+    def other_config(name):
+        """BASELINE.json configs 1-3 at their own sizes, each one short timed loop of the TRAINING step
+        (encoder + all-entity pass + ComplEx loss, forward + backward) on one resident batch."""
+        from temp_amd.sampling import CorruptTriples
+        if name == "config1_static":                 # ICEWS14 SRGCN, seq_len 1 (baselines/StaticRGCN.py:36-89)
+            from temp_amd.static_rgcn import StaticRGCN
+            w2 = synthetic.workload("S-icews14", seed=0)
+            args = make_args(w2, "SRGCN")
+            torch.manual_seed(1)
+            m2 = StaticRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
+            m2.sample_rng = np.random.default_rng(2)
+            m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+            tl = torch.tensor(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3))
+            edge_visits = int(sum(int(0.5 * w2["snapshots"][int(t)].number_of_edges()) for t in tl))
+            st = GraphStep(lambda: m2(tl), [p for p in m2.parameters()], graph=False)       # (forward() plans on the host: eager)
+            what = ("StaticRGCN (2-layer RGCN, bias, ReLU; 50 % target edges), S-icews14 shape, bsz 8: forward() + backward per step, host "
+                    "planning of the batch included (the class has no prepare / run split)")
+        elif name == "config2_default_flags":        # ICEWS14 GRRGCN seq_len 8, the reference's default flags (utils/args.py:38)
+            from temp_amd.dynamic_rgcn import DynamicRGCN
+            w2 = synthetic.workload("S-icews14", seed=0)
+            args = make_args(w2, "GRRGCN")
+            args.rec_only_last_layer = False
+            torch.manual_seed(1)
+            m2 = DynamicRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
+            m2.sample_rng = np.random.default_rng(2)
+            m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+            wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
+            fixed = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
+            edge_visits = int(wb2.n_edge_visits)
+            st = GraphStep(lambda: m2.run_loss(wb2, fixed), [p for p in m2.parameters()], graph=not a.no_graph)
+            what = ("DynamicRGCN / GRRGCN, rec_only_last_layer=False (BOTH layers recurrent: the position loop as one autograd node, "
+                    "rec_stack.py), L=8, bsz 8, S-icews14 shape, encoder + loss, fixed negatives")
+        else:                                        # ICEWS05-15 BiGRRGCN seq_len 15 --rec-only-last-layer --post-ensemble
+            from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN
+            w2 = synthetic.workload("S-icews0515", seed=0)
+            args = make_args(w2, "BiGRRGCN")
+            args.post_ensemble = True
+            torch.manual_seed(1)
+            m2 = PostEnsembleBiDynamicRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
+            m2.sample_rng = np.random.default_rng(2)
+            m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+            wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
+            fixed = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
+            # the mixing weights come from frequency tables of utils/DropEdge.py (out of scope: the caller supplies them): 0.5 each
+            wts = [(torch.full((smp[0].shape[0],), 0.5, device=device), torch.full((smp[0].shape[0],), 0.5, device=device)) for smp in fixed]
+            edge_visits = int(wb2.n_edge_visits)
+            st = GraphStep(lambda: m2.run_loss(wb2, fixed, wts), [p for p in m2.parameters()], graph=not a.no_graph)
+            what = ("PostEnsembleBiDynamicRGCN (BiGRRGCN --rec-only-last-layer --post-ensemble), L=15, bsz 8, S-icews0515 shape, encoder "
+                    "(local + temporal streams) + ensemble loss, fixed negatives, mixing weights 0.5")
+        n = max(10, min(steps, 30))
+        ms = st.time(n, 3)
+        nl, kms = launches_of(st.eager)
+        return dict(what=what, ms_per_step=ms, edges_per_s=edge_visits / (ms * 1e-3), edge_visits_per_step=edge_visits,
+                    launch="hip-graph replay" if st.graph is not None else "eager", steps=n, launches_per_step=nl, kernel_ms_per_step=kms)
+
     guarded("with_loss", with_loss)
     guarded("attention", attention)
     guarded("sharded_1rank", sharded)
+    for cfg_name in ("config1_static", "config2_default_flags", "config3_post_ensemble"):
+        guarded(cfg_name, lambda cfg_name=cfg_name: other_config(cfg_name))
     if a.hbm_window_log2_nodes > 0:
         guarded("hbm_window", lambda: hbm_window(a, device, lib))
     return out

@@ -198,7 +198,7 @@ class BiDynamicRGCN(DynamicRGCN):
         wb.target, wb.target_b = self._bi_target(plan_f, plan_b, wb.rows, tgt)
         wb.batched = self._can_batch()
         wb.steps = plan_f.steps + plan_b.steps + [wb.target]
-        self._upload(wb, dev)
+        self._upload(wb, dev, train)
         if wb.program is None:
             wb.target_b.tensors(dev)
         if train:

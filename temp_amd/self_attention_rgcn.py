@@ -72,11 +72,14 @@ class SelfAttentionRGCN(DynamicRGCN):
         wb.target_times = [r[-1] for r in wb.rows]
         # distinct history snapshots, in first-use order
         # (--random-dropout: every training visit is its own 80 % edge subsample, so visits are keyed per window)
+        # (self-loop dropout drawing: the reference encodes every history visit on its own, models/SelfAttentionRGCN.py:97-120, so
+        #  every visit has its own mask -- visits are keyed per window then, too)
         resample = train and self.random_dropout
+        per_visit = resample or not self._share_visits(train)
         node_row, hist_graphs, hist_ts, off = {}, [], [], 0
         for b, times in enumerate(wb.hist_times):
             for t in times:
-                key = (b, t) if resample else t
+                key = (b, t) if per_visit else t
                 if t is not None and key not in node_row:
                     g = self.graph_dict_train[t]
                     if resample:
@@ -89,7 +92,7 @@ class SelfAttentionRGCN(DynamicRGCN):
                     off += g.n
         wb.n_hist_rows = off
         none_row = np.full(N, -1, dtype=np.int32)
-        idx_all = [np.stack([node_row[(b, t) if resample else t] if t is not None else none_row for t in times], axis=1) if times
+        idx_all = [np.stack([node_row[(b, t) if per_visit else t] if t is not None else none_row for t in times], axis=1) if times
                    else np.zeros((N, 0), np.int32) for b, times in enumerate(wb.hist_times)]                     # bsz x (N, Th)
         idx_tgt = [idx_all[b][g.gids] for b, g in enumerate(wb.targets)]
         all_graphs = hist_graphs + list(wb.targets)

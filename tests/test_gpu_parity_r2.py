@@ -1241,3 +1241,17 @@ def test_linear_tn_multi_vs_fp64(hip_backend, Ms, Ka, Nb):
             assert float(((o.double() - want).abs() / scale.clamp_min(1e-30)).max()) < 2e-6
         else:
             assert float(o.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: dropout and the shared RGCN pass of overlapping windows (verdict r4 item 4)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("module", ["GRRGCN", "BiGRRGCN"])
+def test_dropout_visits_are_independent_gpu(module):
+    from tests.window_cases import check_dropout_visits_are_independent
+    check_dropout_visits_are_independent(DEV, module)
+
+
+def test_dropout_visits_self_attention_gpu():
+    from tests.window_cases import check_dropout_visits_self_attention
+    check_dropout_visits_self_attention(DEV)

@@ -11,7 +11,7 @@ from temp_amd import backend as TB
 from temp_amd.window import ChainPlan, window_times
 from tests.cpu_backend import CpuTestBackend
 from tests.golden_util import load
-from tests.window_cases import (check_batched_equals_generic, check_wide_batched_equals_generic, check_evaluate, check_sa_dense_api, check_sa_evaluate, check_sa_window,
+from tests.window_cases import (check_batched_equals_generic, check_dropout_visits_are_independent, check_dropout_visits_self_attention, check_wide_batched_equals_generic, check_evaluate, check_sa_dense_api, check_sa_evaluate, check_sa_window,
                                 check_static, check_window, slice_snapshots)
 from oracle import temp_oracle as O
 
@@ -436,3 +436,12 @@ def test_post_ensemble_own_ratio_golden(name, batched):
 def test_relu_fold_is_off_for_widths_beyond_the_gather_kernels():
     """D = 260 > 256: the chain gather cannot carry layer 2's ReLU adjoint, so the layer keeps it."""
     check_wide_batched_equals_generic(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("module", ["GRRGCN", "BiGRRGCN"])
+def test_dropout_visits_are_independent(module):
+    check_dropout_visits_are_independent(torch.device("cpu"), module)
+
+
+def test_dropout_visits_self_attention():
+    check_dropout_visits_self_attention(torch.device("cpu"))

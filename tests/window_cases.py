@@ -625,3 +625,89 @@ def check_wide_batched_equals_generic(device, width=260, n_bases=130, module="Bi
     assert set(g0) == set(g1) and len(g0) >= 8
     for k in g0:
         assert_close(g1[k], g0[k], 1e-4, 3e-6 * max(1.0, float(g0[k].abs().max())), "wide batched vs generic: d_" + k)
+
+
+def check_dropout_visits_are_independent(device, module="BiGRRGCN", p=0.1):
+    """Self-loop dropout (models/RGCN.py:57-59) draws one mask per encoder call; the reference calls the encoder per window position
+    (models/DynamicRGCN.py:156-174), so two windows that visit the same snapshot get DIFFERENT masks.  While dropout draws, no visit
+    may share its RGCN rows with another (the batched path used to convolve a shared snapshot once: one mask for all its visits);
+    without dropout -- p = 0, or eval mode -- sharing stays on and the results are bit-identical to the shared computation."""
+    s = slice_snapshots()
+    t_list = torch.tensor([20, 19, 17])                  # overlapping windows: snapshots 12..19 are visited by two or three of them
+    L = 8
+
+    def build(pdrop, train_mode):
+        args = make_args(module=module, rec_only_last_layer=True, embed_size=32, hidden_size=32, n_bases=16, train_seq_len=L, test_seq_len=L,
+                         dropout=pdrop)
+        torch.manual_seed(21)
+        cls = BiDynamicRGCN if module.startswith("Bi") else DynamicRGCN
+        m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+        m.train(train_mode)
+        m.sample_rng = np.random.default_rng(3)
+        return m
+
+    def visit_rows_of(wb, t):
+        """[(first visit row, n)] of every visit of snapshot t among the history steps"""
+        out = []
+        for st in wb.steps[:-1]:
+            off = st.row0
+            for g, tt in zip(st.graphs, st.times):
+                if tt == t:
+                    out.append((off, g.n))
+                off += g.n
+        return out
+
+    # p = 0: shared; p > 0 in eval mode: shared, bit-identical to p = 0
+    m0 = build(0.0, True)
+    wb0 = m0.prepare(t_list, L, True)
+    assert wb0.shared_visits and wb0.visit_rows_host is not None, "overlapping windows share snapshots"
+    out0, _ = m0.run(wb0)
+    me = build(p, False)
+    wbe = me.prepare(t_list, L, True)
+    assert wbe.shared_visits
+    oute, _ = me.run(wbe)
+    assert torch.equal(out0, oute)
+    # p > 0 in training mode: nothing shared, the visits of one snapshot see different masks
+    m1 = build(p, True)
+    wb1 = m1.prepare(t_list, L, True)
+    assert not wb1.shared_visits and wb1.visit_rows_host is None
+    assert wb1.n_edges_distinct == wb1.n_edge_visits > wb0.n_edges_distinct
+    torch.manual_seed(5)
+    out1, _ = m1.run(wb1)
+    assert not torch.equal(out1, out0)
+    x1, x0 = wb1.last_x.detach(), wb0.last_x.detach()      # GRU input rows (layer-2 outputs) in chain order
+    rows1 = wb1.chain_rows_host if getattr(wb1, "chain_rows_host", None) is not None else None
+    vis = [v for t in (15, 16, 17) for v in [visit_rows_of(wb1, t)] if len(v) >= 2]
+    assert vis, "the batch has snapshots visited by several windows"
+    if rows1 is None and x1.shape[0] == wb1.total_rows:      # (uni-directional model: chain order = visit order)
+        for v in vis:
+            (a, n), (b, _) = v[0], v[1]
+            va, vb = x1[a:a + n], x1[b:b + n]
+            assert float((va != vb).float().mean()) > 0.3, "two visits of one snapshot must not share a dropout mask"
+            assert torch.equal(x0[a:a + n], x0[b:b + n]), "without dropout the visits are the same rows"
+    # the dropped run is an unbiased perturbation of the dropout-free one at the layer-1 level; end to end it stays close
+    rel = float((out1.detach() - out0.detach()).norm() / out0.detach().norm())
+    assert 1e-3 < rel < 0.5, rel
+    loss = (out1 * out1).sum()
+    loss.backward()
+    assert all(torch.isfinite(q.grad).all() for q in m1.parameters() if q.grad is not None)
+
+
+def check_dropout_visits_self_attention(device, p=0.1):
+    """The same rule for the self-attention models (models/SelfAttentionRGCN.py:97-120 encodes every history visit on its own): while
+    dropout draws, a history snapshot shared by overlapping windows is encoded once per window."""
+    s = slice_snapshots()
+    t_list, L = torch.tensor([20, 19, 17]), 6
+    rows = {}
+    for pdrop, mode in ((0.0, True), (p, False), (p, True)):
+        args = make_args(module="SARGCN", rec_only_last_layer=True, embed_size=32, hidden_size=32, n_bases=16, train_seq_len=L, test_seq_len=L,
+                         dropout=pdrop, use_time_embedding=True)
+        torch.manual_seed(21)
+        m = SelfAttentionRGCN(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+        m.train(mode)
+        m.sample_rng = np.random.default_rng(3)
+        wb = m.prepare(t_list, L, True)
+        rows[(pdrop, mode)] = wb.n_hist_rows
+        out = m.run(wb)
+        assert torch.isfinite(out[0] if isinstance(out, (tuple, list)) else out).all()
+    assert rows[(0.0, True)] == rows[(p, False)] < rows[(p, True)]
