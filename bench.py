@@ -620,7 +620,7 @@ def extra_measurements(a, w, model, wb, targets, device, lib):
             wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
             fixed = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
             # the mixing weights come from frequency tables of utils/DropEdge.py (out of scope: the caller supplies them): 0.5 each
-            wts = [(torch.full((smp[0].shape[0],), 0.5, device=device), torch.full((smp[0].shape[0],), 0.5, device=device)) for smp in fixed]
+            wts = [(torch.full((smp[0].shape[0], 1), 0.5, device=device), torch.full((smp[0].shape[0], 1), 0.5, device=device)) for smp in fixed]
             edge_visits = int(wb2.n_edge_visits)
             st = GraphStep(lambda: m2.run_loss(wb2, fixed, wts), [p for p in m2.parameters()], graph=not a.no_graph)
             what = ("PostEnsembleBiDynamicRGCN (BiGRRGCN --rec-only-last-layer --post-ensemble), L=15, bsz 8, S-icews0515 shape, encoder "
@@ -796,8 +796,9 @@ def main():
     ap.add_argument("--shbm-log2-nodes", type=int, default=20)
     ap.add_argument("--shbm-log2-edges", type=int, default=24)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (`extra`: loss, attention, sharded on one rank, HBM-regime window)")
-    ap.add_argument("--hbm-window-log2-nodes", type=int, default=18,
-                    help="extra.hbm_window: nodes per snapshot = 2^k, edges = 2^(k+4), bi L=15 bsz=1 (0: skip; 18 needs ~110 GB of HBM and ~1 min of host planning)")
+    ap.add_argument("--hbm-window-log2-nodes", type=int, default=19,
+                    help="extra.hbm_window: nodes per snapshot = 2^k, edges = 2^(k+4), bi L=15 bsz=1 (0: skip; 19 = the largest window one "
+                         "288-GB GPU holds: 166 GiB peak, ~85 s of host generation + planning; 18: 83 GiB, ~35 s; 20 does not fit)")
     ap.add_argument("--hbm-window-steps", type=int, default=3)
     ap.add_argument("--cpu-probe", action="store_true", help="(internal) child process of the all-cores CPU probe: no GPU")
     ap.add_argument("--rendezvous-only", action="store_true",

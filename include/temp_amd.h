@@ -204,6 +204,21 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
                   float* d_h, float* d_weight, float* d_loop_w, float* d_bias /*nullable*/,
                   void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream);
 
+/* The two halves of temp_rgcn_bwd, for a layer INSIDE a recurrence (the reference's default flags: both layers recurrent,
+ * models/RRGCN.py:179-204): d_h position by position, the weight gradients once over the union of all positions' graphs.
+ *   temp_rgcn_bwd_dh:      d_h [n_nodes, d_in] only.  act == TEMP_ACT_RELU: the ReLU-masked gradient is written to dz_out
+ *                          [n_nodes, d_out] (required then); with dropout the masked gradient of the self-loop message is written
+ *                          to dzm_out (required then).  act == TEMP_ACT_NONE without dropout: both may be NULL (dz = d_out_grad).
+ *   temp_rgcn_bwd_weights: d_weight / d_loop_w / d_bias from h [n_nodes, d_in], dz (the masked gradient) and dzm (NULL: = dz) --
+ *                          the same kernels temp_rgcn_bwd runs, on whatever graph the rows belong to (a union of positions).
+ * Workspace: temp_rgcn_bwd_workspace of the graph. */
+int temp_rgcn_bwd_dh(const TempGraph* g, const float* out /*nullable unless relu*/, const float* d_out_grad, int d_in, int d_out, int num_bases,
+                     int n_rel_rows, const float* weight, const float* loop_w, int act, float* d_h, float* dz_out /*nullable*/,
+                     float* dzm_out /*nullable*/, void* workspace, size_t workspace_bytes, const TempDropout* drop, void* stream);
+int temp_rgcn_bwd_weights(const TempGraph* g, const float* h, const float* dz, const float* dzm /*nullable*/, int d_in, int d_out, int num_bases,
+                          int n_rel_rows, int has_bias, float* d_weight, float* d_loop_w, float* d_bias /*nullable*/, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Same layer when its input is a ROW GATHER of a table, h = table[ids]  (layer 1 of every TeMP encoder:
  * g.ndata['h'] = ent_embeds[g.ndata['id']], models/DynamicRGCN.py:93).  h is never materialised:

@@ -107,6 +107,8 @@ SYMBOLS = {
     "temp_rgcn_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_rgcn_bwd_workspace": (_SZ, [_G, _I, _I, _I, _I]),
     "temp_rgcn_bwd": (_I, [_G, c_vp, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp, c_vp]),
+    "temp_rgcn_bwd_dh": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, _I, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp, c_vp]),
+    "temp_rgcn_bwd_weights": (_I, [_G, c_vp, c_vp, c_vp, _I, _I, _I, _I, _I, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),
     "temp_rgcn_table_fwd_workspace": (_SZ, [_G, _I, _I]),
     "temp_rgcn_table_fwd": (_I, [_G, c_vp, c_vp, _I, _I, _I, _I, _I, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _SZ, c_vp, c_vp]),
     "temp_rgcn_table_bwd_workspace": (_SZ, [_G, _I, _I, _I, _I]),

@@ -112,6 +112,34 @@ class HipBackend:
         _lib.check(rc, "temp_rgcn_bwd")
         return d_h, d_w, d_loop, d_bias
 
+    def rgcn_bwd_dh(self, dg, out, d_out_grad, weight, loop_w, num_bases, act, drop=None, dz_out=None, dzm_out=None):
+        """d_h of a layer only (include/temp_amd.h: temp_rgcn_bwd_dh); dz_out / dzm_out receive the masked gradients the weight
+        pass (rgcn_bwd_weights) reads, where the activation / the dropout make them differ from d_out_grad."""
+        g = _f32(d_out_grad, "d_out")
+        weight, loop_w = _f32(weight, "weight"), _f32(loop_w, "loop_weight")
+        d_in, d_out = loop_w.shape
+        dev = g.device
+        d_h = torch.empty(dg.n_nodes, d_in, dtype=torch.float32, device=dev)
+        ws = self._ws(self.lib.temp_rgcn_bwd_workspace(dg.ref(), d_in, d_out, num_bases, weight.shape[0]), dev)
+        rc = self.lib.temp_rgcn_bwd_dh(dg.ref(), _ptr(out), _ptr(g), d_in, d_out, num_bases, weight.shape[0], _ptr(weight), _ptr(loop_w), act,
+                                       _ptr(d_h), _ptr(dz_out), _ptr(dzm_out), _ptr(ws), ws.numel(), _drop(drop), _stream())
+        _lib.check(rc, "temp_rgcn_bwd_dh")
+        return d_h
+
+    def rgcn_bwd_weights(self, dg, h, dz, dzm, weight_like, loop_like, has_bias, num_bases):
+        """(d_weight, d_loop_w, d_bias) of a layer from its input rows and the masked output gradients over ANY graph the rows
+        belong to -- the union of all positions of a recurrence (include/temp_amd.h: temp_rgcn_bwd_weights)."""
+        h, dz = _f32(h, "h"), _f32(dz, "dz")
+        d_in, d_out = loop_like.shape
+        dev = h.device
+        d_w, d_loop = torch.empty_like(weight_like), torch.empty_like(loop_like)
+        d_bias = torch.empty(d_out, dtype=torch.float32, device=dev) if has_bias else None
+        ws = self._ws(self.lib.temp_rgcn_bwd_workspace(dg.ref(), d_in, d_out, num_bases, weight_like.shape[0]), dev)
+        rc = self.lib.temp_rgcn_bwd_weights(dg.ref(), _ptr(h), _ptr(dz), _ptr(dzm), d_in, d_out, num_bases, weight_like.shape[0], int(has_bias),
+                                            _ptr(d_w), _ptr(d_loop), _ptr(d_bias), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "temp_rgcn_bwd_weights")
+        return d_w, d_loop, d_bias
+
     def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act, drop=None):
         """Layer on h = table[ids] without materialising h (include/temp_amd.h: temp_rgcn_table_fwd)."""
         table, weight, loop_w, bias = _f32(table, "table"), _f32(weight, "weight"), _f32(loop_w, "loop_weight"), _f32(bias, "bias")
@@ -431,12 +459,13 @@ class HipBackend:
         return [(d_w[2 * i], d_w[2 * i + 1], d_b[2 * i], d_b[2 * i + 1]) for i in range(k)]
 
     # ---- plain GEMMs + candidate cross-entropy (link-prediction loss) ---------------------------------
-    def linear(self, a, b, trans_b):
-        """a[M,K] . b  (b is [K,N], or [N,K] when trans_b)."""
+    def linear(self, a, b, trans_b, out=None):
+        """a[M,K] . b  (b is [K,N], or [N,K] when trans_b); out: an (M, N) contiguous tensor to write into."""
         a, b = _f32(a, "a"), _f32(b, "b")
         M, K = a.shape
         N = b.shape[0] if trans_b else b.shape[1]
-        c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=a.device)
+        assert c.shape == (M, N) and c.is_contiguous() and c.dtype == torch.float32
         rc = self.lib.temp_linear(M, N, K, _ptr(a), K, _ptr(b), b.shape[1], int(trans_b), _ptr(c), N, _stream())
         _lib.check(rc, "temp_linear")
         return c

@@ -1193,4 +1193,68 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
   return side.join();
 }
 
+// The two halves of temp_rgcn_bwd for a layer that sits INSIDE a recurrence (both layers recurrent, models/RRGCN.py:179-204):
+// d_h is needed position by position, the weight / bias gradients are sums over ALL positions -- one pass over the union of the
+// positions' graphs afterwards instead of a relation-weight kernel, a fix-up, two reductions, a column sum and three additions
+// per position.
+int temp_rgcn_bwd_dh(const TempGraph* g, const float* out, const float* d_out_grad, int d_in, int d_out, int num_bases, int n_rel_rows,
+                     const float* weight, const float* loop_w, int act, float* d_h, float* dz_out, float* dzm_out, void* workspace,
+                     size_t workspace_bytes, const TempDropout* drop, void* stream) {
+  if (!g || !d_out_grad || !weight || !loop_w || !d_h) return TEMP_E_BADARG;
+  if (d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
+  if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
+  if (act != TEMP_ACT_NONE && act != TEMP_ACT_RELU) return TEMP_E_BADARG;
+  if (act == TEMP_ACT_RELU && (!out || !dz_out)) return TEMP_E_BADARG;       // the masked gradient is an output: the weight pass reads it
+  if (!view_ok(g->by_src) || (g->n_nodes > 0 && (!g->nnorm || !g->out_deg))) return TEMP_E_BADARG;
+  if (!workspace || workspace_bytes < temp_rgcn_bwd_workspace(g, d_in, d_out, num_bases, n_rel_rows)) return TEMP_E_WORKSPACE;
+  if (g->n_nodes == 0) return TEMP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  BwdWs w = carve_bwd(g, d_in, d_out, num_bases, (char*)workspace);
+  const float* dz = d_out_grad;
+  int rc;
+  if (act == TEMP_ACT_RELU) {
+    rc = relu_bwd((size_t)g->n_nodes * d_out, out, d_out_grad, dz_out, st);
+    if (rc) return rc;
+    dz = dz_out;
+  }
+  rc = run_agg(MODE_DX, g->by_src, members_of(g), dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
+  if (rc) return rc;
+  const DropSpec ds = drop_spec(drop);
+  const float* dzm = dz;
+  if (ds.p > 0.f) {
+    if (!dzm_out) return TEMP_E_BADARG;                          // (the weight pass needs the masked gradient of the self-loop message)
+    rc = mask_rows(g->n_nodes, d_out, dz, dzm_out, ds, st);
+    if (rc) return rc;
+    dzm = dzm_out;
+  }
+  return gemm_add_bias_act(K_GEMM_LOOP_DX, g->n_nodes, d_in, d_out, dzm, d_out, nullptr, loop_w, d_out, 1, d_h, d_in, g->out_deg, nullptr, TEMP_ACT_NONE,
+                           d_h, d_in, st);
+}
+
+int temp_rgcn_bwd_weights(const TempGraph* g, const float* h, const float* dz, const float* dzm, int d_in, int d_out, int num_bases, int n_rel_rows,
+                          int has_bias, float* d_weight, float* d_loop_w, float* d_bias, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !h || !dz || !d_weight || !d_loop_w) return TEMP_E_BADARG;
+  if (d_in <= 0 || d_out <= 0 || num_bases <= 0 || n_rel_rows <= 0) return TEMP_E_BADARG;
+  if (d_in % num_bases || d_out % num_bases || d_in % 4 || d_out % 4) return TEMP_E_UNSUPPORTED;
+  if (has_bias && !d_bias) return TEMP_E_BADARG;
+  if (!view_ok(g->by_rel) || (g->n_nodes > 0 && !g->nnorm)) return TEMP_E_BADARG;
+  if (g->by_rel.n_seg != n_rel_rows) return TEMP_E_BADARG;
+  if (!workspace || workspace_bytes < temp_rgcn_bwd_workspace(g, d_in, d_out, num_bases, n_rel_rows)) return TEMP_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t wrow = (size_t)num_bases * (d_in / num_bases) * (d_out / num_bases);
+  if (g->n_nodes == 0) {
+    if (hipMemsetAsync(d_weight, 0, (size_t)n_rel_rows * wrow * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    if (hipMemsetAsync(d_loop_w, 0, (size_t)d_in * d_out * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    if (has_bias && hipMemsetAsync(d_bias, 0, (size_t)d_out * sizeof(float), st) != hipSuccess) return TEMP_E_LAUNCH;
+    return TEMP_OK;
+  }
+  BwdWs w = carve_bwd(g, d_in, d_out, num_bases, (char*)workspace);
+  int rc = run_dw(g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
+  if (rc) return rc;
+  rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dzm ? dzm : dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
+  if (rc) return rc;
+  if (has_bias) rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
+  return rc ? rc : launch_status();
+}
+
 }  // extern "C"

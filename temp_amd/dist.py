@@ -351,8 +351,10 @@ class SnapshotShardedEncoder:
             out_inst.append(len(inst) - 1)
         x_rows.append(t_rows)
         sb.program = GruProgram(inst)
-        prepare_program(sb.program, dev, m.embed_size, len(plans), out_inst)
         x_index = np.concatenate(x_rows) if x_rows else np.zeros(0, np.int64)
+        sb.program.x_src = x_index                  # x row i is canonical node-state row x_index[i]: a snapshot visited at several positions of
+                                                    # this rank's windows shares its input gates (GruProgram.gi_shared), as on one GPU
+        prepare_program(sb.program, dev, m.embed_size, len(plans), out_inst)
         sb.x_index = torch.from_numpy(x_index).to(dev)
         sb.x_index32 = sb.x_index.to(torch.int32)
         sb.x_inv = TF.gather_inverse(x_index, int(canon_off[-1]), dev)                      # y2_all has one row per canonical visit row
@@ -366,13 +368,20 @@ class SnapshotShardedEncoder:
         m = self.model
         enc = m.ent_encoder
         y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table
-        return enc.layer_2.conv(sb.g_local, y1)
+        # layer 2's ReLU (models/BiRRGCN.py:202-203): its adjoint rides in the backward of the ONE consumer of the gathered states,
+        # the row gather of chain_on_gathered -- the mask is a function of the state row alone, so every rank masks its piece of
+        # a row's gradient with the same mask and the rank-ordered sum of the pieces is the masked sum
+        return enc.layer_2.conv(sb.g_local, y1, grad_premasked=self._relu_fold(sb))
+
+    def _relu_fold(self, sb):
+        l2 = self.model.ent_encoder.layer_2
+        return bool(l2.relu_fused() and TF.relu_gather_supported(l2.out_feat, sb.x_inv))
 
     def chain_on_gathered(self, sb, y2_all):
         """Part 2: GRU inputs of this rank's windows out of the gathered node states + the window-sharded recurrence
         -> target-position embeddings of this rank's windows."""
         l2 = self.model.ent_encoder.layer_2
-        x = TF.gather_rows(y2_all, sb.x_index32, sb.x_inv)                                   # deterministic adjoint (segment sum)
+        x = TF.gather_rows(y2_all, sb.x_index32, sb.x_inv, relu_table=self._relu_fold(sb))   # deterministic adjoint (segment sum, ReLU mask folded in)
         rnns = [l2.forward_rnn, l2.backward_rnn] if hasattr(l2, "forward_rnn") else [l2.rnn]
         pieces = gru_chain(x, sb.program, rnns, l2.inv_temperature, isinstance(rnns[0], GRUCell), want=list(sb.out_inst))
         out = None

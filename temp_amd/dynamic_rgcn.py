@@ -169,7 +169,8 @@ class DynamicRGCN(TKG_Module):
         if wb.visit_rows is not None:
             y1 = TF.gather_rows(y1, wb.visit_rows, wb.visit_inv)
         graphs = [st.batched().device_graph(dev, 2 * self.num_rels) for st in wb.steps]
-        got = rec_stack(y1, wb.program, graphs, enc.layer_1.rnn, enc.layer_2, self._chain_want(wb))
+        g_union = wb.g_visits.device_graph(dev, 2 * self.num_rels) if getattr(wb, "g_visits", None) is not None else None
+        got = rec_stack(y1, wb.program, graphs, enc.layer_1.rnn, enc.layer_2, self._chain_want(wb), g_union)
         hist = got[1] if wb.hist_inst >= 0 else None
         return got[0], (hist, hist)
 
@@ -265,6 +266,10 @@ class DynamicRGCN(TKG_Module):
             if getattr(wb, "stack", False):          # layer 2 runs per position: every position's own union graph as well
                 for st in wb.steps:
                     st.batched().device_graph(dev, 2 * self.num_rels)
+                # ... and the union of ALL visits in program row order (layer 2's weight gradients in one pass, rec_stack.py): the
+                # layer-1 graph itself when no snapshot is shared between visits
+                wb.g_visits = wb.g_all if wb.visit_rows_host is None else concat_steps(wb.steps)[0]
+                wb.g_visits.device_graph(dev, 2 * self.num_rels)
                 self._build_program(wb)
                 wb.program.upload(dev)
                 wb.program.constants(dev, self.embed_size)

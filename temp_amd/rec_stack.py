@@ -25,7 +25,7 @@ from .functional import ACTS
 
 class _RecStackFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y1, prog, graphs, cfg, want, w2, loop2, bias2, *gru):
+    def forward(ctx, y1, prog, graphs, g_union, cfg, want, w2, loop2, bias2, *gru):
         be = get_backend()
         dev, d = y1.device, y1.shape[1]
         N = prog.n_total
@@ -59,7 +59,7 @@ class _RecStackFn(torch.autograd.Function):
             be.gru_cell_fwd_multi([dict(cell, gi=gi2[sl], w_hh=wh2, b_hh=bh2, h_out=H2[sl])], lam, variant, saved2)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(y1, H1, Y2, saved1, saved2, w2, loop2, wi1, wh1, wi2, wh2)
-        ctx.prog, ctx.graphs, ctx.cfg, ctx.want, ctx.has_bias = prog, graphs, cfg, want, bias2 is not None
+        ctx.prog, ctx.graphs, ctx.cfg, ctx.want, ctx.has_bias, ctx.g_union = prog, graphs, cfg, want, bias2 is not None, g_union
         return tuple(H2[prog.inst[i].h0:prog.inst[i].h0 + prog.inst[i].n] for i in want)
 
     @staticmethod
@@ -75,6 +75,18 @@ class _RecStackFn(torch.autograd.Function):
         decv1, decv2, dp1, dp2 = new(N), new(N), new(N, d), new(N, d)
         tens = prog.upload(dev)
         d_w2 = d_loop2 = d_bias2 = None
+        # RGCN_2's weight / bias gradients are sums over ALL positions: with the union graph of the positions at hand (row order =
+        # program order) and a backend that has the split backward, the loop computes d_h1 only and keeps every position's masked
+        # output gradient; ONE pass over the union afterwards forms the weight gradients (per position it took a relation-weight
+        # kernel, its fix-up, two reductions, a column sum and three additions)
+        hoist = ctx.g_union is not None and hasattr(be, "rgcn_bwd_dh")
+        relu = act == ACTS["relu"]
+        any_drop = any(dr is not None for dr in drops)
+        assert not any_drop or all(dr is not None for dr in drops), "dropout draws at every position or at none"
+        if hoist:
+            DY2 = new(N, d)
+            DZ = new(N, d) if relu else DY2
+            DZM = new(N, d) if any_drop else None
         for i in range(len(prog.inst) - 1, -1, -1):
             it = prog.inst[i]
             if it.n == 0:
@@ -89,17 +101,24 @@ class _RecStackFn(torch.autograd.Function):
             cell = dict(row0=it.h0, n=it.n, dt=dt, no_prev=it.prev < 0)
             be.gru_cell_bwd_multi([dict(cell, dh_up=given.get(i), d_prev_next=d_next, next_idx=ni if nxt is not None else None, w_hh=wh2,
                                         dgi=dgi2[sl], dgh=dgh2[sl], decv=decv2[sl], d_prev=dp2[sl])], lam, variant, saved2)
-            d_y2 = be.linear(dgi2[sl], wi2, False)                                  # (n, G) . (G, d)
-            d_h1, dw, dl, db = be.rgcn_bwd(graphs[i], H1[sl], Y2[sl], d_y2, w2, loop2, ctx.has_bias, nb, act, drops[i])
-            if d_w2 is None:
-                d_w2, d_loop2, d_bias2 = dw, dl, db
+            if hoist:
+                d_y2 = be.linear(dgi2[sl], wi2, False, out=DY2[sl])                 # (n, G) . (G, d)
+                d_h1 = be.rgcn_bwd_dh(graphs[i], Y2[sl], d_y2, w2, loop2, nb, act, drops[i], dz_out=DZ[sl] if relu else None,
+                                      dzm_out=DZM[sl] if (any_drop and drops[i] is not None) else None)
             else:
-                d_w2 += dw
-                d_loop2 += dl
-                if db is not None:
-                    d_bias2 += db
+                d_y2 = be.linear(dgi2[sl], wi2, False)                              # (n, G) . (G, d)
+                d_h1, dw, dl, db = be.rgcn_bwd(graphs[i], H1[sl], Y2[sl], d_y2, w2, loop2, ctx.has_bias, nb, act, drops[i])
+                if d_w2 is None:
+                    d_w2, d_loop2, d_bias2 = dw, dl, db
+                else:
+                    d_w2 += dw
+                    d_loop2 += dl
+                    if db is not None:
+                        d_bias2 += db
             be.gru_cell_bwd_multi([dict(cell, dh_up=d_h1, d_prev_next=None, next_idx=None, w_hh=wh1,
                                         dgi=dgi1[sl], dgh=dgh1[sl], decv=decv1[sl], d_prev=dp1[sl])], lam, variant, saved1)
+        if hoist and N > 0:
+            d_w2, d_loop2, d_bias2 = be.rgcn_bwd_weights(ctx.g_union, H1, DZ, DZM, w2, loop2, ctx.has_bias, nb)
         d_y1 = torch.empty_like(y1)
         zero_state = all(it.prev < 0 for it in prog.inst)                            # hdec = 0 on every row
         multi = None
@@ -113,13 +132,14 @@ class _RecStackFn(torch.autograd.Function):
         if d_w2 is None:
             d_w2, d_loop2 = torch.zeros_like(w2), torch.zeros_like(loop2)
             d_bias2 = torch.zeros(loop2.shape[1], dtype=torch.float32, device=dev) if ctx.has_bias else None
-        return (d_y1, None, None, None, None, d_w2, d_loop2, d_bias2) + tuple(gw1) + tuple(gw2)
+        return (d_y1, None, None, None, None, None, d_w2, d_loop2, d_bias2) + tuple(gw1) + tuple(gw2)
 
 
-def rec_stack(y1, prog, graphs, rnn1, layer2, want):
+def rec_stack(y1, prog, graphs, rnn1, layer2, want, g_union=None):
     """y1: layer-1 RGCN output of every visit row (program row order).  prog: GruProgram of ONE chain (instance i =
     executed position i).  graphs: device graph of every position (layer 2 runs on them).  rnn1: layer 1's GRU; layer2:
-    the second GRRGCNLayer (weights, GRU, dropout, activation).  want: instances whose h2 rows are returned.
+    the second GRRGCNLayer (weights, GRU, dropout, activation).  want: instances whose h2 rows are returned.  g_union: device graph
+    of ALL positions' graphs batched in program row order (optional: layer 2's weight gradients are then formed in one pass).
     -> tuple of (n_i, d) tensors."""
     from .gru_cell import GRUCell
     type1 = isinstance(rnn1, GRUCell)
@@ -129,4 +149,4 @@ def rec_stack(y1, prog, graphs, rnn1, layer2, want):
             [rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0]
     cfg = dict(lam=float(layer2.inv_temperature), variant=_lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH, num_bases=layer2.num_bases,
                act=ACTS[layer2._act], drops=[layer2._drop() for _ in graphs])
-    return _RecStackFn.apply(y1, prog, list(graphs), cfg, tuple(want), layer2.weight, layer2.loop_weight, layer2._bias(), *ws)
+    return _RecStackFn.apply(y1, prog, list(graphs), g_union, cfg, tuple(want), layer2.weight, layer2.loop_weight, layer2._bias(), *ws)

@@ -1255,3 +1255,62 @@ def test_dropout_visits_are_independent_gpu(module):
 def test_dropout_visits_self_attention_gpu():
     from tests.window_cases import check_dropout_visits_self_attention
     check_dropout_visits_self_attention(DEV)
+
+
+def test_full_size_static_rgcn_vs_oracle_gpu():
+    """BASELINE config 1 at its own size (verdict r4 item 5): StaticRGCN -- two RGCN layers with bias, ReLU on the second, no
+    recurrence (baselines/StaticRGCN.py:36-89, models/RGCN.py:145-164) -- on the S-icews14 shape (7 128 entities, 230 relations =
+    460 weight rows, D = 200, 100 bases), bsz 8, 50 % target-edge subsample (fixed draw), ComplEx loss with fixed negatives, against
+    the oracle in fp64: training loss to 2e-5, the target embeddings to 1e-5, every parameter gradient."""
+    import bench
+    from temp_amd import synthetic
+    from temp_amd.static_rgcn import StaticRGCN
+    w = synthetic.workload("S-icews14", seed=0)
+    args = bench.make_args(w, "SRGCN")
+    torch.manual_seed(4)
+    snaps = w["snapshots"]
+    model = StaticRGCN(args, w["num_ents"], w["num_rels"], snaps, snaps, snaps).to(DEV)
+    with torch.no_grad():                               # (h_bias starts at zero in the reference: give the bias path something to do)
+        for l in (model.ent_encoder.layer_1, model.ent_encoder.layer_2):
+            l.h_bias.uniform_(-0.2, 0.2)
+    targets = synthetic.default_targets(w["num_times"], w["L"], 8, 0)
+    N = w["num_ents"]
+    rng = np.random.default_rng(12)
+    edge_ids, samples = [], []
+    NEG = 60
+    for t in targets:
+        g = snaps[t]
+        E = g.number_of_edges()
+        edge_ids.append(np.sort(rng.choice(E, E // 2, replace=False)))
+        P = min(E, 400)
+        pos = rng.choice(E, P, replace=False)
+        trip = torch.from_numpy(np.stack([g.src[pos], g.rel[pos], g.dst[pos]], axis=1)).long()
+        nt = torch.from_numpy(rng.integers(0, N, (P, 1 + NEG)))
+        nh = torch.from_numpy(rng.integers(0, N, (P, 1 + NEG)))
+        nt[:, 0] = torch.from_numpy(g.gids[g.dst[pos]])
+        nh[:, 0] = torch.from_numpy(g.gids[g.src[pos]])
+        samples.append((trip, nt, nh))
+    loss = model(torch.tensor(targets), target_edge_ids=edge_ids, samples=samples)
+    rows = model._last_rows.detach().cpu()
+    loss.backward()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
+    cfg = dict(module="SRGCN", n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
+    om = O.model_from_state_dict(sd, cfg)
+    gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in snaps.items()}
+    for v in O.leaf_tensors(om).values():
+        v.requires_grad_(True)
+    tgt = [O.edge_subgraph(gd[t], torch.from_numpy(e)) for t, e in zip(targets, edge_ids)]
+    want, per_graph = O.static_forward_loss(om, cfg, gd, targets, tgt, samples, score="complex")
+    want.backward()
+    print("full-size static RGCN training loss: HIP %.7f  oracle(fp64) %.7f  rel diff %.2e" % (loss.item(), want.item(), abs(loss.item() - want.item()) / abs(want.item())))
+    assert abs(loss.item() - want.item()) <= 2e-5 * abs(want.item()), (loss.item(), want.item())
+    assert_close(rows, torch.cat(per_graph).detach(), 1e-5, 3e-6, "static RGCN target embeddings")
+    enc, eo = model.ent_encoder, om["ent_encoder"]
+    checks = [("ent_embeds", model.ent_embeds.grad, om["ent_embeds"].grad), ("rel_embeds", model.rel_embeds.grad, om["rel_embeds"].grad)]
+    for ln in ("layer_1", "layer_2"):
+        for k in ("weight", "loop_weight", "h_bias"):
+            checks.append(("%s.%s" % (ln, k), getattr(getattr(enc, ln), k).grad, eo[ln][k].grad))
+    for name, got, ref in checks:
+        assert got is not None and ref is not None, name
+        _assert_grad_close(got, ref, "static RGCN + loss d " + name, max_bad=0.0, frob=6e-6, frob_clean=6e-6)
