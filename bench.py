@@ -53,10 +53,20 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guid
 # products of an exact three-way operand split (temp_amd/csrc/gemm_bx.hpp; fp32-equivalent accuracy): their roof is the bf16 pipe
 # divided by six.  temp_set_option(TEMP_OPT_MFMA_BF16X3, 0) (or TEMP_MFMA=f32 in the environment at load time) keeps them on the
 # fp32 MFMA kernels (round-1 arithmetic); MFMA_MODE is read from the library in main().
-BX_KERNELS = ("k_gemm_panel", "k_gemm_tn_bx", "k_gru_chain_fwd", "k_gru_chain_bwd")   # (k_gemm_tn itself is the fp32 MFMA kernel of the small products; the chain kernels run the split products when d % 8 == 0)
+BX_KERNELS = ("k_gemm_panel", "k_gemm_tn_bx", "k_gru_chain_fwd", "k_gru_chain_bwd", "k_gru_wgrad")   # (k_gemm_tn itself is the fp32 MFMA kernel of the small products; the chain kernels run the split products when d % 8 == 0)
 MFMA_MODE = "bf16x3"
 OPT_MFMA_BF16X3 = 0            # include/temp_amd.h: TEMP_OPT_MFMA_BF16X3
 CPU_THREADS = 16               # cpu_baseline leg (--cpu-threads)
+
+
+def profile_file(stem):
+    """profiles/<round>_<stem> of the latest round that has it (static counter summaries: rocprofv3 --pmc runs cannot be taken from
+    inside this process)."""
+    for tag in ("r05", "r04"):
+        p = os.path.join(REPO, "profiles", "%s_%s" % (tag, stem))
+        if os.path.exists(p):
+            return p
+    return os.path.join(REPO, "profiles", "r05_%s" % stem)
 
 
 
@@ -152,6 +162,9 @@ def algorithmic_costs(wb, D, bi, S=2):
     # weight gradients, one entry per KERNEL (trace ids follow the kernels since round 4): the four 3d x d products of the two GRUs
     # (k_gemm_tn_bx8: d_W_ih = dgi^T x, d_W_hh = dgh^T hdec), layer 2's loop weight (k_gemm_tn_bx), the table layer's (k_gemm_tn)
     c["k_gemm_tn_bx8"] = dict(bytes=n_gru * (2 * row + 6 * row), flops=2 * 2 * n_gru * 3 * D * D)
+    # round 5: the same four products from the ONE gate-gradient matrix g4 = [dr | dz | dn_i | dn_h] (k_gru_wgrad): x, hdec and the
+    # 4 d gate columns once each (the shared [dr dz] columns are counted once: what an ideal kernel reads)
+    c["k_gru_wgrad"] = dict(bytes=n_gru * (2 * row + 4 * row), flops=2 * 2 * n_gru * 3 * D * D)
     c["k_gemm_tn_bx"] = dict(bytes=n * 2 * row, flops=2 * n * D * D)
     c["k_gemm_tn"] = dict(bytes=nt * 2 * row, flops=2 * nt * D * D)
     c["k_relu_bwd"] = dict(bytes=n * 3 * row, flops=0)
@@ -164,7 +177,7 @@ def algorithmic_costs(wb, D, bi, S=2):
     # persistent window chain (one launch per direction of time for ALL positions): forward reads gi (3 rows) and writes h + 5 saved
     # planes; backward reads the 5 planes (+ upstream rows) and writes dgi + dgh (6 rows); 6 n D^2 flop each (W_hh product)
     c["k_gru_chain_fwd"] = dict(bytes=n_gru * (3 * row + 6 * row), flops=6 * n_gru * D * D)
-    c["k_gru_chain_bwd"] = dict(bytes=n_gru * (5 * row + 6 * row), flops=6 * n_gru * D * D)
+    c["k_gru_chain_bwd"] = dict(bytes=n_gru * (5 * row + 4 * row), flops=6 * n_gru * D * D)      # (round 5: g4 = 4 gate rows, was dgi + dgh = 6)
     c["k_gru_chain_pack"] = dict(bytes=4 * 2 * 3 * D * D * 4, flops=0)
     c["k_bx_pack"] = dict(bytes=(2 * D * D + 2 * 2 * 3 * D * D) * (4 + 6), flops=0)      # weights in as fp32, out as three bf16 planes
     if hasattr(wb, "idx_tgt"):                    # attention mixer over the target rows (encoder-only step)
@@ -176,7 +189,7 @@ def algorithmic_costs(wb, D, bi, S=2):
     return c
 
 
-MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd", "k_gru_chain_fwd", "k_gru_chain_bwd")   # (prefixes)
+MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd", "k_gru_chain_fwd", "k_gru_chain_bwd", "k_gru_wgrad")   # (prefixes)
 
 
 def traced_steps(step_fn, n_steps, lib):
@@ -672,7 +685,8 @@ def hbm_window(a, device, lib):
     ach = wb.n_edge_visits * bpe / (ms * 1e-3) / 1e9
     mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
     edge_visits, node_visits = int(wb.n_edge_visits), int(wb.n_node_visits)
-    pmc_path = os.path.join(REPO, "profiles", "r04_pmc_traffic_hbm_window.json")
+    # (counter passes exist for the window sizes of the rounds that took them: r04 at 2^18 nodes, r05 at 2^19)
+    pmc_path = os.path.join(REPO, "profiles", "%s_pmc_traffic_hbm_window.json" % {18: "r04", 19: "r05"}.get(k, "none"))
     traffic = json.load(open(pmc_path)).get("step_traffic_bytes") if os.path.exists(pmc_path) else None
     del st, wb, model, snaps
     torch.cuda.empty_cache()
@@ -681,8 +695,8 @@ def hbm_window(a, device, lib):
                 edges_per_s=ach * 1e9 / bpe, steps=steps,
                 roofline=dict(bound="hbm", model="SURVEY 8d: 4848 + 14436 (n/E) bytes per snapshot-edge visit", bytes_per_edge_visit=bpe,
                               achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                              traffic=traffic, traffic_source=("static: profiles/r04_pmc_traffic_hbm_window.json (rocprofv3 --pmc passes of this "
-                                                               "workload, bytes per step)" if traffic else None),
+                              traffic=traffic, traffic_source=("static: profiles/%s (rocprofv3 --pmc passes of this workload, bytes per step)"
+                                                               % os.path.basename(pmc_path) if traffic else None),
                               frac_from_counters=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None),
                 kernels={k_: dict(ms=v["ms_per_step"], launches=v["launches_per_step"], share=v["ms_per_step"] / total) for k_, v in top},
                 traced_kernel_ms=total, peak_memory_gib=mem, host_generate_s=gen_s, host_prepare_s=prep_s)
@@ -971,7 +985,7 @@ def main():
         # HBM-side bytes per launch: measured separately with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in their own passes,
         # tools/pmc_summary.py) on this same workload and committed under profiles/ -- counters cannot be collected from inside this
         # process, so these are STATIC numbers and say so.
-        pmc_path = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
+        pmc_path = profile_file("pmc_traffic.json")
         pmc = json.load(open(pmc_path)) if (os.path.exists(pmc_path) and a.workload == "S-gdelt" and a.encoder == "gru" and not a.with_loss) else None
 
         def pmc_traffic(name):
@@ -1015,12 +1029,12 @@ def main():
             if tb is not None:
                 r["traffic"] = tb
                 r["traffic_unit"] = "bytes/launch"
-                r["traffic_source"] = "static: profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)"
+                r["traffic_source"] = "static: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)" % os.path.basename(pmc_path)
             r["algorithmic_per_launch"] = cst["flops" if r["bound"] == "mfma" else "bytes"] / max(tr[name]["launches_per_step"], 1e-9)
             r.update(avg_launch_ms=tr[name]["avg_ms"], launches_per_step=tr[name]["launches_per_step"], share_of_kernel_time=tr[name]["ms_per_step"] / total_ms)
             if r["bound"] == "hbm" and r["traffic"] is not None and r["traffic"] < 0.5 * r["algorithmic_per_launch"]:
                 r["note"] = ("the byte model charges every edge a row from HBM; this kernel stages a member snapshot's rows in LDS once and the "
-                             "counters see %.0f %% of the model's bytes: it is bound by the LDS walk's instruction issue (DESIGN.md section 3), "
+                             "counters see %.0f %% of the model's bytes: it is bound by the LDS walk's instruction issue (HISTORY.md section 3), "
                              "not by HBM -- read `frac` as work rate against the survey's model, `traffic` as what HBM saw"
                              % (100.0 * r["traffic"] / r["algorithmic_per_launch"]))
             return r
@@ -1032,7 +1046,7 @@ def main():
         roof.update(traced_kernel_ms_per_step=total_ms,
                     timing="HIP events around every launch (library event trace on the launch stream) of %d EAGER steps run right after the "
                            "timed region; inside the HIP-graph replays of the timed region the same kernel runs 5-10 %% faster "
-                           "(rocprofv3, profiles/r04_bench_kernel_stats.md and r04_step_sequence.txt; tools/tn_timing_probe.py)" % a.trace_steps)
+                           "(rocprofv3, profiles/r05_bench_kernel_stats.md and r05_step_sequence.txt)" % a.trace_steps)
         # whole-step view against the HBM roofline with SURVEY 8d's byte model (2 RGCN layers + 1 GRU cell, fwd+bwd, fp32, int32 ids):
         #   per edge 2*(12D+24) B, per RGCN node row 2*(20D+16) B, per GRU row 32D+4 B.
         # (a) as the survey states it, per snapshot-edge VISIT (every visit pays its RGCN bytes), and
@@ -1056,7 +1070,7 @@ def main():
         if pmc and pmc.get("step_traffic_bytes"):
             roof["step_traffic_bytes"] = pmc["step_traffic_bytes"]
             roof["step_traffic_over_algorithmic"] = pmc["step_traffic_bytes"] / bytes_dedup
-            roof["step_traffic_source"] = "static: profiles/r04_pmc_traffic.json"
+            roof["step_traffic_source"] = "static: profiles/%s" % os.path.basename(pmc_path)
     # a longer replay of the same graph when the timed region was short (the driver's 20 steps are 50 ms: box-to-box noise is larger
     # than the 1-3 % steps a round works on); reported beside the headline, never instead of it
     long_ms = None

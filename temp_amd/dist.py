@@ -367,7 +367,7 @@ class SnapshotShardedEncoder:
         """Part 1: the two RGCN layers on this rank's snapshots -> y2 (n_local, D), attached to the autograd graph."""
         m = self.model
         enc = m.ent_encoder
-        y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table (DESIGN 3b)
+        y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table (HISTORY.md 3b)
         # layer 2's ReLU (models/BiRRGCN.py:202-203): its adjoint rides in the backward of the ONE consumer of the gathered states,
         # the row gather of chain_on_gathered -- the mask is a function of the state row alone, so every rank masks its piece of
         # a row's gradient with the same mask and the rank-ordered sum of the pieces is the masked sum

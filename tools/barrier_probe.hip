@@ -1,4 +1,4 @@
-// Grid-barrier latency on MI355X (development probe; sizing of a persistent window-chain kernel).
+// Grid-barrier latency on MI355X (development probe; sizing of a persistent window-chain kernel, HISTORY.md section 4).
 //   hipcc --offload-arch=gfx950 -O3 tools/barrier_probe.hip -o tools/barrier_probe
 // A monotonic counter in device memory: every block adds 1 after a release fence and spins (acquire) until the counter reaches
 // round * blocks.  Spins are bounded, so a non-co-resident launch reports a timeout instead of hanging the GPU.

@@ -2,7 +2,7 @@
 # GPU box: every committed measurement of a round in ONE gpurun call; results under gpurun_out/final_<tag>/ (copied to profiles/
 # by hand afterwards).  Order matters: the counter passes first -- bench.py reads profiles/<tag>_pmc_traffic*.json for the
 # (static-marked) traffic fields of the lines taken after them.
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 out=gpurun_out/final_$tag
 mkdir -p $out

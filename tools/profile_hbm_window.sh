@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the HBM-regime window (bench.py --workload S-hbm-window = extra.hbm_window of the default line): rocprofv3 kernel stats
 # and FETCH_SIZE / WRITE_SIZE in their own counter-only passes (2 timed + 1 warm-up + 1 traced = 4 steps per process).
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_hbmw -o bench -- python bench.py --workload S-hbm-window --hbm-window-steps 2 > gpurun_out/prof_${tag}_hbmw_line.json 2> gpurun_out/prof_${tag}_hbmw.err

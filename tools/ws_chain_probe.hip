@@ -1,5 +1,5 @@
 // Feasibility probe (NOT product code): the forward window chain with W_hh STATIONARY in the register files of a cluster of four
-// workgroups instead of streamed from L2 per panel-position (last paragraph).
+// workgroups instead of streamed from L2 per panel-position (HISTORY.md 3c, last paragraph).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpurun_out/ws_chain_probe tools/ws_chain_probe.hip && gpurun_out/ws_chain_probe
 //
