@@ -587,7 +587,8 @@ def extra_measurements(a, w, model, wb, targets, device, lib):
 
     def launches_of(step_fn):
         tr = traced_steps(step_fn, 1, lib)
-        return int(round(sum(v["launches_per_step"] for v in tr.values()))), sum(v["ms_per_step"] for v in tr.values())
+        top = {k: dict(ms=round(v["ms_per_step"], 4), launches=int(round(v["launches_per_step"]))) for k, v in sorted(tr.items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]}
+        return int(round(sum(v["launches_per_step"] for v in tr.values()))), sum(v["ms_per_step"] for v in tr.values()), top
 
     def other_config(name):
         """BASELINE.json configs 1-3 at their own sizes, each one short timed loop of the TRAINING step
@@ -640,9 +641,10 @@ def extra_measurements(a, w, model, wb, targets, device, lib):
                     "(local + temporal streams) + ensemble loss, fixed negatives, mixing weights 0.5")
         n = max(10, min(steps, 30))
         ms = st.time(n, 3)
-        nl, kms = launches_of(st.eager)
+        nl, kms, top = launches_of(st.eager)
         return dict(what=what, ms_per_step=ms, edges_per_s=edge_visits / (ms * 1e-3), edge_visits_per_step=edge_visits,
-                    launch="hip-graph replay" if st.graph is not None else "eager", steps=n, launches_per_step=nl, kernel_ms_per_step=kms)
+                    launch="hip-graph replay" if st.graph is not None else "eager", steps=n, launches_per_step=nl, kernel_ms_per_step=kms,
+                    top_kernels=top)
 
     guarded("with_loss", with_loss)
     guarded("attention", attention)

@@ -282,6 +282,64 @@ class _BatchedLinkPredictionFn(torch.autograd.Function):
         return d_ent, d_rel, d_big, None, None
 
 
+class _BatchedEnsembleLinkPredictionFn(torch.autograd.Function):
+    """_BatchedLinkPredictionFn for the score-level ensemble of the post-ensemble models (combined_scores,
+    models/PostDynamicRGCN.py:404-406, 425-428): TWO streams (local = pre-GRU, temporal = post-GRU) score against their own
+    all-entity stacks, the scores are mixed row by row with w (local) and 1 - w (temporal) on the (rows, N) matrices, then the
+    candidate cross-entropy.  Same launches per stream as the plain node (folded query, score GEMMs of all windows as
+    multi-problem launches -- k-sliced where the rows are few against 10 000 entities -- one candidate CE), one mix pass."""
+
+    @staticmethod
+    def forward(ctx, loc_rows, rec_rows, rel, big_loc, big_rec, w, kind, inp):
+        be = get_backend()
+        N = big_loc.shape[0] // len(inp["splits"])
+        live = [(b, a0, a1) for b, (a0, a1) in enumerate(inp["splits"]) if a1 > a0]
+        qs, sc = [], []
+        for rows, big in ((loc_rows, big_loc), (rec_rows, big_rec)):
+            q = be.bilinear_query_fwd(kind, rows, inp["known"], rel, inp["rel"], inp["is_tail"])
+            s = torch.empty(q.shape[0], N, dtype=torch.float32, device=q.device)
+            be.linear_multi([q[a0:a1] for _, a0, a1 in live], [big[b * N:(b + 1) * N] for b, _, _ in live], True, s)
+            qs.append(q)
+            sc.append(s)
+        mixed = torch.lerp(sc[1], sc[0], w)                          # w (rows, 1): w * local + (1 - w) * temporal
+        loss_rows, lse = be.gather_ce_fwd(mixed, inp["cand"])
+        ctx.save_for_backward(loc_rows, rec_rows, rel, big_loc, big_rec, w, qs[0], qs[1], sc[0], sc[1], mixed, lse)
+        ctx.kind, ctx.inp, ctx.live, ctx.N = kind, inp, live, N
+        return (loss_rows * inp["weights"]).sum()
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        loc_rows, rec_rows, rel, big_loc, big_rec, w, q_l, q_r, s_l, s_r, mixed, lse = ctx.saved_tensors
+        inp, live, N = ctx.inp, ctx.live, ctx.N
+        be = get_backend()
+        d_m = be.gather_ce_bwd(mixed, inp["cand"], lse, d_loss.reshape(1).contiguous(), 1.0, inp["weights"])
+        d_sl = d_m * w
+        d_sr = d_m - d_sl
+        d_w = (d_m * (s_l - s_r)).sum(dim=1, keepdim=True) if ctx.needs_input_grad[5] else None
+        outs, d_rel = [], None
+        for rows, big, q, d_s in ((loc_rows, big_loc, q_l, d_sl), (rec_rows, big_rec, q_r, d_sr)):
+            d_q = torch.empty_like(q)
+            d_big = torch.empty_like(big) if len(live) == len(inp["splits"]) else torch.zeros_like(big)
+            be.linear_multi([d_s[a0:a1] for _, a0, a1 in live], [big[b * N:(b + 1) * N] for b, _, _ in live], False, d_q)
+            if hasattr(be, "linear_tn_multi"):
+                be.linear_tn_multi([d_s[a0:a1] for _, a0, a1 in live], [q[a0:a1] for _, a0, a1 in live], [d_big[b * N:(b + 1) * N] for b, _, _ in live])
+            else:
+                for b, a0, a1 in live:
+                    be.linear_tn(d_s[a0:a1], q[a0:a1], out=d_big[b * N:(b + 1) * N])
+            dk, dr = be.bilinear_query_bwd(ctx.kind, rows, inp["known"], rel, inp["rel"], inp["is_tail"], d_q)
+            outs.append((be.segment_sum_rows(dk, inp["known_inv"][0], inp["known_inv"][1], rows.shape[0]), d_big))
+            d_rel = dr if d_rel is None else d_rel + dr
+        d_rel = be.segment_sum_rows(d_rel, inp["rel_inv"][0], inp["rel_inv"][1], rel.shape[0])
+        return outs[0][0], outs[1][0], d_rel, outs[0][1], outs[1][1], d_w, None, None
+
+
+def batched_ensemble_link_prediction(loc_rows, rec_rows, rel, big_loc, big_rec, w, kind, inputs):
+    """sum over windows of the ensemble CE_tail + CE_head; `w` (rows, 1) = weight of the LOCAL stream of every stacked query row
+    (per window: [tail rows: weight_object ; head rows: weight_subject]); `inputs` = TKG_Module.loss_inputs(...)."""
+    return _BatchedEnsembleLinkPredictionFn.apply(loc_rows.contiguous(), rec_rows.contiguous(), rel, big_loc.contiguous(), big_rec.contiguous(),
+                                                  w.reshape(-1, 1).to(loc_rows.dtype).contiguous(), kind, inputs)
+
+
 def batched_link_prediction(ent_rows, rel, big, kind, inputs):
     """sum over windows of CE_tail + CE_head (models/DynamicRGCN.py:186-193) for a bilinear scorer `kind`
     ('distmult' | 'complex'); `inputs` = TKG_Module.loss_inputs(...)."""
@@ -292,6 +350,41 @@ def candidate_cross_entropy_batched(query, cand, splits, row_w, all_embeds):
     """query (R, D), cand (R, C) int32, splits = [(row_begin, row_end)] per window, row_w (R,) = weight of every row's loss
     (1 / P_b for a mean per window and direction), all_embeds = list of (N, D) per window."""
     return _BatchedCandidateCEFn.apply(query, cand, splits, row_w, *all_embeds)
+
+
+class _MixedCandidateCEFn(torch.autograd.Function):
+    """mean_p CE( w_p * (q_loc[p] . A_loc[cand[p, :]]^T) + (1 - w_p) * (q_rec[p] . A_rec[cand[p, :]]^T), label 0 ): the score-level
+    ensemble of the post-ensemble models (combined_scores, models/PostDynamicRGCN.py:404-406, 425-428) without the
+    (P, 1 + neg, D) gathers: both streams score against ALL entities (two small GEMMs), the mix is one pass over the (P, N) score
+    matrices, the candidate CE reads the mixed matrix."""
+
+    @staticmethod
+    def forward(ctx, q_loc, all_loc, q_rec, all_rec, w, cand):
+        be = get_backend()
+        s_loc = be.linear(q_loc, all_loc, True)                      # (P, N)
+        s_rec = be.linear(q_rec, all_rec, True)
+        mixed = torch.lerp(s_rec, s_loc, w)                          # w (P, 1): w * loc + (1 - w) * rec
+        loss_rows, lse = be.gather_ce_fwd(mixed, cand)
+        ctx.save_for_backward(q_loc, all_loc, q_rec, all_rec, w, cand, s_loc, s_rec, mixed, lse)
+        return loss_rows.mean()
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        q_loc, all_loc, q_rec, all_rec, w, cand, s_loc, s_rec, mixed, lse = ctx.saved_tensors
+        be = get_backend()
+        d_mixed = be.gather_ce_bwd(mixed, cand, lse, d_loss.reshape(1).contiguous(), 1.0 / max(mixed.shape[0], 1))
+        d_loc = d_mixed * w
+        d_rec = d_mixed - d_loc
+        d_w = (d_mixed * (s_loc - s_rec)).sum(dim=1, keepdim=True) if ctx.needs_input_grad[4] else None
+        return (be.linear(d_loc, all_loc, False), be.linear_tn(d_loc, q_loc), be.linear(d_rec, all_rec, False), be.linear_tn(d_rec, q_rec),
+                d_w, None)
+
+
+def candidate_cross_entropy_mixed(q_loc, all_loc, q_rec, all_rec, w, cand):
+    """Score-level ensemble CE (see _MixedCandidateCEFn).  w: (P, 1) mixing weight of the local stream; cand: int32 (P, C), column
+    0 is the true entity."""
+    return _MixedCandidateCEFn.apply(q_loc.contiguous(), all_loc.contiguous(), q_rec.contiguous(), all_rec.contiguous(),
+                                     w.reshape(-1, 1).to(q_loc.dtype).contiguous(), cand)
 
 
 def candidate_cross_entropy(query, all_embeds, cand):

@@ -27,6 +27,35 @@ from .dynamic_rgcn import DynamicRGCN
 from .rrgcn import GRRGCNLayer
 
 
+def _dev_cached(owner, key, device, make):
+    """A host array uploaded ONCE per (owner, key, device): `owner` is an object that lives as long as the array is valid (the
+    prepared batch's ChainPlan, a Snapshot).  The per-window index uploads of the all-entity pass used to be issued inside every
+    step: a host-to-device copy per window made the step un-capturable as a HIP graph and host-bound (23 ms for 8 ms of kernels at
+    the S-icews0515 shape)."""
+    cache = owner.__dict__.setdefault("_dev_cache", {})
+    k = (key, str(device))
+    t = cache.get(k)
+    if t is None:
+        t = cache[k] = make().to(device)
+    return t
+
+
+def _gids_dev(g, device):
+    return _dev_cached(g, "gids", device, lambda: torch.from_numpy(np.ascontiguousarray(g.gids)))
+
+
+def _final_index(plan, b, device):
+    """(row of every entity in the last history output of window b or -1, time gaps (N, 1)) of a plan, on the device."""
+    def make_idx():
+        row_of, _ = plan.final_all(b, plan.seq_len - 1)
+        return torch.from_numpy(row_of.astype(np.int32))
+
+    def make_dt():
+        _, dt = plan.final_all(b, plan.seq_len - 1)
+        return torch.from_numpy(np.ascontiguousarray(dt)).view(-1, 1)
+    return _dev_cached(plan, ("final_idx", b), device, make_idx), _dev_cached(plan, ("final_dt", b), device, make_dt)
+
+
 def _rows_or_zero(rows, idx_t, n, d, like):
     return like.new_zeros(n, d) if rows is None else TF.gather_rows(rows, idx_t)
 
@@ -134,8 +163,48 @@ class _PostWindowMixin:
             return self.calc_score(ent_embed[triplets[:, 0]], r, all_embeds_g[neg_samples], mode='tail')
         return self.calc_score(all_embeds_g[neg_samples], r, ent_embed[triplets[:, 2]], mode='head')
 
+    def batched_ensemble_loss(self, wb, locs, recs, alls, samples, weights):
+        """The ensemble loss of ALL windows as one fused node (functional.batched_ensemble_link_prediction), or None when the scorer
+        / shapes need the per-window path.  locs / recs: per-window target rows of the two streams; alls: per window (all_loc,
+        all_rec); weights: per window (weight_subject (P, 1), weight_object (P, 1))."""
+        name = self.args.score_function
+        D = self.embed_size
+        if not (self.fused_loss and name in ("distmult", "complex") and self.num_ents % 4 == 0 and D % (8 if name == "complex" else 4) == 0):
+            return None
+        dev = self._device()
+        cache = getattr(wb, "_ens_inputs", None)
+        if cache is None or cache[0] is not samples:                 # index tensors are static for a given sample set
+            offs = np.concatenate([[0], np.cumsum(wb.target.sizes)])[:-1]
+            n_rows = int(sum(wb.target.sizes))
+            cache = wb._ens_inputs = (samples, self.loss_inputs([int(o) for o in offs], samples, dev, n_rows, self.rel_embeds.shape[0],
+                                                                head_as_tail=self.head_scored_as_tail))
+        inp = cache[1]
+        if inp is None:
+            return torch.cat(locs).sum() * 0.0
+        w = torch.cat([torch.cat([wo.reshape(-1, 1), ws.reshape(-1, 1)]) for (ws, wo), smp in zip(weights, samples) if smp[0].shape[0] > 0]).to(dev)
+        big_loc, big_rec = torch.cat([a for a, _ in alls], dim=0), torch.cat([a for _, a in alls], dim=0)
+        return TF.batched_ensemble_link_prediction(torch.cat(locs), torch.cat(recs), self.rel_embeds, big_loc, big_rec, w, name, inp)
+
     def ensemble_loss(self, loc, rec, all_loc, all_rec, triplets, neg_tail, neg_head, w_subject, w_object):
         """loss_tail + loss_head of one target graph, models/PostDynamicRGCN.py:335-349 + combined_scores :404-406."""
+        name = self.args.score_function
+        P = triplets.shape[0]
+        if self.fused_loss and name in ("distmult", "complex") and all_loc.shape[0] % 4 == 0 and P > 0:
+            # both corruption directions stacked into one (2P)-row operand per stream; the two streams share the candidate lists and
+            # the per-row mixing weights, so the mix happens on the (2P, N) score matrices (functional._MixedCandidateCEFn)
+            from . import scores
+            t32 = triplets.to(torch.int32)
+            r = TF.gather_rows(self.rel_embeds, t32[:, 1].contiguous())
+            head_known = t32[:, 0] if self.head_scored_as_tail else t32[:, 2]          # (the reference's quirk: see head_scored_as_tail)
+            head_mode = "tail" if self.head_scored_as_tail else "head"
+            idx = torch.cat([t32[:, 0], head_known]).contiguous()
+            qs = []
+            for rows in (loc, rec):
+                known = TF.gather_rows(rows, idx)
+                qs.append(torch.cat([scores.bilinear_query(name, known[:P], r, "tail"), scores.bilinear_query(name, known[P:], r, head_mode)], dim=0))
+            w = torch.cat([w_object.reshape(-1, 1), w_subject.reshape(-1, 1)], dim=0)
+            cand = torch.cat([neg_tail, neg_head], dim=0).to(torch.int32).contiguous()
+            return 2.0 * TF.candidate_cross_entropy_mixed(qs[0], all_loc, qs[1], all_rec, w, cand)
         labels = torch.zeros(triplets.shape[0], dtype=torch.int64, device=triplets.device)
         out = 0
         for neg, tail, w in ((neg_tail, True, w_object), (neg_head, False, w_subject)):
@@ -193,18 +262,17 @@ class ImputeDynamicRGCN(_PostWindowMixin, DynamicRGCN):
     # -- all-entity pass ---------------------------------------------------------------------------------------------------
     def _final_prevs(self, plan, b, hist, loc):
         dev, N, D = self._device(), self.num_ents, self.embed_size
-        row_of, dt = plan.final_all(b, plan.seq_len - 1)
-        idx = torch.from_numpy(row_of.astype(np.int32)).to(dev)
+        idx, dt = _final_index(plan, b, dev)
         p1 = _rows_or_zero(hist[0], idx, N, D, self.ent_embeds)
         p2 = p1 if hist[1] is hist[0] else _rows_or_zero(hist[1], idx, N, D, self.ent_embeds)
         pl = _rows_or_zero(loc, idx, N, D, self.ent_embeds)
-        return p1, p2, pl, torch.from_numpy(dt).view(-1, 1).to(dev)
+        return p1, p2, pl, dt
 
     def get_all_embeds_Gt(self, convoluted_embeds, g, t, plan, b, hist, hist_loc=None):
         """ImputeDynamicRGCN.get_all_embeds_Gt, models/PostDynamicRGCN.py:24-31."""
         p1, p2, pl, dt = self._final_prevs(plan, b, hist, hist_loc)
         all_embeds = self.ent_encoder.forward_isolated_impute(self.ent_embeds, p1, p2, dt, t, pl)
-        return all_embeds.index_copy(0, torch.from_numpy(g.gids).to(self._device()), convoluted_embeds)
+        return all_embeds.index_copy(0, _gids_dev(g, self._device()), convoluted_embeds)
 
     def run_loss(self, wb, samples=None):
         """ImputeDynamicRGCN.forward, models/PostDynamicRGCN.py:80-96."""
@@ -254,7 +322,7 @@ class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
         """PostDynamicRGCN.get_all_embeds_Gt, models/PostDynamicRGCN.py:160-174 -> (all_loc, all_rec)."""
         p1, p2, pl, dt = self._final_prevs(plan, b, hist, hist_loc)
         a_loc, a_rec = self.ent_encoder.forward_post_ensemble_isolated(self.ent_embeds, p1, p2, dt, t, pl)
-        gid = torch.from_numpy(g.gids).to(self._device())
+        gid = _gids_dev(g, self._device())
         return a_loc.index_copy(0, gid, convoluted_loc), a_rec.index_copy(0, gid, convoluted_rec)
 
     def run_loss(self, wb, samples=None, ensemble_weights=None):
@@ -265,11 +333,17 @@ class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
         if samples is None:
             samples = self.draw_samples(wb)
         loss = 0
+        alls, wts = [], []
         for i, g in enumerate(wb.graphs):
             t = wb.rows[i][-1]
+            alls.append(self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
+            wts.append(ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), t, g))
+        fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)          # all windows' losses as one node
+        if fused is not None:
+            return fused
+        for i, g in enumerate(wb.graphs):
             triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
-            a_loc, a_rec = self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc)
-            ws, wo = ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(triplets, t, g)
+            (a_loc, a_rec), (ws, wo) = alls[i], wts[i]
             loss = loss + self.ensemble_loss(locs[i], recs[i], a_loc, a_rec, triplets, neg_tail, neg_head, ws.to(dev), wo.to(dev))
         return loss
 
@@ -340,18 +414,17 @@ class ImputeBiDynamicRGCN(_PostWindowMixin, BiDynamicRGCN):
         dev, N, D = self._device(), self.num_ents, self.embed_size
         out = []
         for plan, h, loc in zip(plans, hist, hist_loc if hist_loc is not None else (None, None)):
-            row_of, dt = plan.final_all(b, plan.seq_len - 1)
-            idx = torch.from_numpy(row_of.astype(np.int32)).to(dev)
+            idx, dt = _final_index(plan, b, dev)
             p1 = _rows_or_zero(h[0], idx, N, D, self.ent_embeds)
             p2 = p1 if h[1] is h[0] else _rows_or_zero(h[1], idx, N, D, self.ent_embeds)
-            out.append((p1, p2, _rows_or_zero(loc, idx, N, D, self.ent_embeds), torch.from_numpy(dt).view(-1, 1).to(dev)))
+            out.append((p1, p2, _rows_or_zero(loc, idx, N, D, self.ent_embeds), dt))
         return out
 
     def get_all_embeds_Gt(self, convoluted_embeds, g, t, plans, b, hist, hist_loc=None):
         """ImputeBiDynamicRGCN.get_all_embeds_Gt, models/PostBiDynamicRGCN.py:29-39."""
         (f1, f2, fl, dtf), (b1, b2, bl, dtb) = self._final_prevs(plans, b, hist, hist_loc)
         all_embeds = self.ent_encoder.forward_isolated_impute(self.ent_embeds, f1, f2, dtf, b1, b2, dtb, t, fl, bl)
-        return all_embeds.index_copy(0, torch.from_numpy(g.gids).to(self._device()), convoluted_embeds)
+        return all_embeds.index_copy(0, _gids_dev(g, self._device()), convoluted_embeds)
 
     def run_loss(self, wb, samples=None):
         """ImputeBiDynamicRGCN.forward, models/PostBiDynamicRGCN.py:103-124."""
@@ -402,7 +475,7 @@ class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
         """PostBiDynamicRGCN.get_all_embeds_Gt, models/PostBiDynamicRGCN.py:176-190 -> (all_loc, all_rec)."""
         (f1, f2, fl, dtf), (b1, b2, bl, dtb) = self._final_prevs(plans, b, hist, hist_loc)
         a_loc, a_rec = self.ent_encoder.forward_post_ensemble_isolated(self.ent_embeds, f1, f2, dtf, b1, b2, dtb, t, fl, bl)
-        gid = torch.from_numpy(g.gids).to(self._device())
+        gid = _gids_dev(g, self._device())
         return a_loc.index_copy(0, gid, convoluted_loc), a_rec.index_copy(0, gid, convoluted_rec)
 
     def run_loss(self, wb, samples=None, ensemble_weights=None):
@@ -413,11 +486,17 @@ class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
         if samples is None:
             samples = self.draw_samples(wb)
         loss = 0
+        alls, wts = [], []
         for i, g in enumerate(wb.graphs):
             t = wb.rows[i][-1]
+            alls.append(self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
+            wts.append(ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), t, g))
+        fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)          # all windows' losses as one node
+        if fused is not None:
+            return fused
+        for i, g in enumerate(wb.graphs):
             triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
-            a_loc, a_rec = self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc)
-            ws, wo = ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(triplets, t, g)
+            (a_loc, a_rec), (ws, wo) = alls[i], wts[i]
             loss = loss + self.ensemble_loss(locs[i], recs[i], a_loc, a_rec, triplets, neg_tail, neg_head, ws.to(dev), wo.to(dev))
         return loss
 

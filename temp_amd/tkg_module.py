@@ -115,7 +115,7 @@ class TKG_Module(nn.Module):
                 + self.train_link_prediction(ent_embed, triplets, neg_head, labels, all_embeds_g, corrupt_tail=False))
 
     @staticmethod
-    def loss_inputs(row_offsets, samples, dev, n_rows=None, n_rel_rows=None):
+    def loss_inputs(row_offsets, samples, dev, n_rows=None, n_rel_rows=None, head_as_tail=False):
         """Index tensors of the batched loss for one set of samples (static for a prepared batch, so callers cache it):
         per graph the stacked operand is [tail queries (P rows); head queries (P rows)].  `n_rows` / `n_rel_rows` (the row
         counts of the target-embedding stack and of rel_embeds) add the inverse maps the deterministic backward reduces over."""
@@ -127,9 +127,12 @@ class TKG_Module(nn.Module):
                 splits.append((row, row))
                 continue
             t = trip.to(dev)
-            known.append(torch.cat([t[:, 0], t[:, 2]]) + row_offsets[b])
+            # head_as_tail: the reference's PostEnsembleBiDynamicRGCN scores the head-corruption candidates as tails of the true
+            # subject (models/PostBiDynamicRGCN.py:294-295; post_dynamic_rgcn._PostWindowMixin.head_scored_as_tail)
+            known.append(torch.cat([t[:, 0], t[:, 0] if head_as_tail else t[:, 2]]) + row_offsets[b])
             rel.append(torch.cat([t[:, 1], t[:, 1]]))
-            tail.append(torch.cat([torch.ones(P, dtype=torch.int32, device=dev), torch.zeros(P, dtype=torch.int32, device=dev)]))
+            tail.append(torch.cat([torch.ones(P, dtype=torch.int32, device=dev),
+                                   (torch.ones if head_as_tail else torch.zeros)(P, dtype=torch.int32, device=dev)]))
             cand.append(neg_tail.to(dev)); cand.append(neg_head.to(dev))
             splits.append((row, row + 2 * P))
             weights.append(torch.full((2 * P,), 1.0 / P, dtype=torch.float32, device=dev))

@@ -1314,3 +1314,9 @@ def test_full_size_static_rgcn_vs_oracle_gpu():
     for name, got, ref in checks:
         assert got is not None and ref is not None, name
         _assert_grad_close(got, ref, "static RGCN + loss d " + name, max_bad=0.0, frob=6e-6, frob_clean=6e-6)
+
+
+@pytest.mark.parametrize("head_as_tail", [False, True])
+def test_fused_ensemble_loss_equals_reference_shaped_gpu(head_as_tail):
+    from tests.window_cases import check_fused_ensemble_loss
+    check_fused_ensemble_loss(DEV, head_as_tail)

@@ -711,3 +711,34 @@ def check_dropout_visits_self_attention(device, p=0.1):
         out = m.run(wb)
         assert torch.isfinite(out[0] if isinstance(out, (tuple, list)) else out).all()
     assert rows[(0.0, True)] == rows[(p, False)] < rows[(p, True)]
+
+
+def check_fused_ensemble_loss(device, head_as_tail):
+    """ensemble_loss through the fused node (functional._MixedCandidateCEFn: scores of both streams against ALL entities, mixed on
+    the score matrices) against the reference-shaped formulation (gather (P, 1 + neg, D) candidates per stream, mix, CE;
+    models/PostDynamicRGCN.py:335-349, 404-406): value and every gradient, incl. the mixing weights'."""
+    from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN, PostEnsembleDynamicRGCN
+    s = slice_snapshots()
+    cls = PostEnsembleBiDynamicRGCN if head_as_tail else PostEnsembleDynamicRGCN
+    args = make_args(module="BiGRRGCN" if head_as_tail else "GRRGCN", rec_only_last_layer=True, post_ensemble=True)
+    torch.manual_seed(8)
+    m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+    assert m.head_scored_as_tail == head_as_tail
+    gen = torch.Generator().manual_seed(3)
+    N, D, n, P, C = s["num_e"], 32, 60, 37, 21
+    mk = lambda *shape: (torch.randn(*shape, generator=gen) * 0.4).to(device).requires_grad_(True)
+    res = []
+    for fused in (False, True):
+        gen.manual_seed(3)
+        loc, rec, a_loc, a_rec = mk(n, D), mk(n, D), mk(N, D), mk(N, D)
+        ws, wo = torch.sigmoid(mk(P, 1)).detach().requires_grad_(True), torch.sigmoid(mk(P, 1)).detach().requires_grad_(True)
+        trip = torch.stack([torch.randint(0, n, (P,), generator=gen), torch.randint(0, 2 * s["num_r"], (P,), generator=gen),
+                            torch.randint(0, n, (P,), generator=gen)], dim=1).to(device)
+        nt, nh = torch.randint(0, N, (P, C), generator=gen).to(device), torch.randint(0, N, (P, C), generator=gen).to(device)
+        m.fused_loss = fused
+        m.zero_grad()
+        loss = m.ensemble_loss(loc, rec, a_loc, a_rec, trip, nt, nh, ws, wo)
+        loss.backward()
+        res.append([loss.detach()] + [t.grad.detach().clone() for t in (loc, rec, a_loc, a_rec, ws, wo, m.rel_embeds)])
+    for a, b, what in zip(res[0], res[1], ("loss", "d_loc", "d_rec", "d_all_loc", "d_all_rec", "d_w_subject", "d_w_object", "d_rel")):
+        assert_close(b, a, 2e-5, 1e-6, "fused ensemble loss: " + what)
