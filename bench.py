@@ -792,6 +792,8 @@ def main():
                          "direct all-gather of per-snapshot node states before the recurrent chain (BASELINE north_star; three HIP graphs around the two exchanges); "
                          "'both' (default) = the headline `value` is the windows mode and the snapshot-sharded measurement rides along "
                          "under `north_star_sharded`")
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="N > 1, --shard both: seconds the snapshot-sharded measurement may take "
+                                                                       "before the headline line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the cpu_baseline leg (16 = the measured optimum on the 256-thread box)")
     ap.add_argument("--no-fp32-mfma-compare", action="store_true",
@@ -882,11 +884,6 @@ def main():
     from temp_amd.dist import SnapshotShardedEncoder, allreduce_gradients
     sharded = dist is not None and a.shard == "snapshots"
     ns_result = None
-    if dist is not None and a.shard == "both" and a.encoder == "gru" and not a.with_loss:
-        try:
-            ns_result = measure_sharded(model, w, world, rank, device, a.steps, a.warmup, dist, graphs=not a.no_graph)
-        except Exception as e:                      # never lose the headline line to the secondary measurement
-            ns_result = dict(error="%s: %s" % (type(e).__name__, e))
     targets = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], rank)
     params = [p for p in model.parameters()]
     t0 = time.perf_counter()
@@ -962,6 +959,37 @@ def main():
         dist.all_reduce(e)
         edges = float(e.item())
     value = edges * a.steps / elapsed
+    if dist is not None and a.shard == "both" and a.encoder == "gru" and not a.with_loss:
+        # The snapshot-sharded measurement (north_star's variant) runs AFTER the headline, under a watchdog: its point-to-point
+        # exchange has never met more than one GPU (one-GPU boxes), and a rank stuck in it must not cost the headline line.  When
+        # the timer fires, every rank is stuck in the same place: rank 0 prints the line with what it has and all ranks leave.
+        import threading
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0:
+                emit(dict(metric="edges/sec (fwd+bwd) RGCN+GRU seq_len=%d" % w["L"], value=value, unit="edges/s", n_gpus=world, steps=a.steps,
+                          warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                          dtype="f32", data="synthetic",
+                          config=dict(workload=w["name"], encoder=w["module"], rec_only_last_layer=True, seq_len=w["L"], windows_per_gpu=w["bsz"],
+                                      embed=w["D"], n_bases=w["B"], parallelism="dp%d(windows)+grad-allreduce" % world,
+                                      rccl_ranks=dist.get_world_size(), launch="hip-graph replay" if graph is not None else "eager"),
+                          roofline=None, cpu_baseline=None,
+                          north_star_sharded=dict(error="the snapshot-sharded measurement did not finish within %d s (watchdog); the headline "
+                                                        "above was measured before it" % a.sharded_timeout)))
+            os._exit(0)
+
+        timer = threading.Timer(a.sharded_timeout, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            ns_result = measure_sharded(model, w, world, rank, device, a.steps, a.warmup, dist, graphs=not a.no_graph)
+        except Exception as e:                      # never lose the headline line to the secondary measurement
+            ns_result = dict(error="%s: %s" % (type(e).__name__, e))
+        finished.set()
+        timer.cancel()
     if dist is not None and rank != 0:
         # Everything below is rank 0's own work (kernel trace, CPU baseline, the line) and contains NO collective: the other ranks
         # leave the group here instead of waiting minutes inside one.
