@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import functional as TF
 from .bi_dynamic_rgcn import BiDynamicRGCN
 from .birrgcn import BiGRRGCNLayer
@@ -162,6 +163,32 @@ class _PostWindowMixin:
         if corrupt_tail:
             return self.calc_score(ent_embed[triplets[:, 0]], r, all_embeds_g[neg_samples], mode='tail')
         return self.calc_score(all_embeds_g[neg_samples], r, ent_embed[triplets[:, 2]], mode='head')
+
+    def batched_all_embeds_post(self, wb, out, hist, base):
+        """(all_loc, all_rec) of EVERY window in one pass, or None (per-window get_all_embeds_Gt then).  Without imputation the
+        temporal all-entity matrix is the base model's (models/BiRRGCN.py:259-293 runs the same isolated trunk + GRUs as
+        forward_isolated), so base.all_embeds_batched applies -- zero-state GRU rows once per entity, own rows only for the
+        (window, entity) pairs that carry a state; the local one is the isolated trunk Iso2(Iso1(E)) -- the same N rows for every
+        window -- with each window's target rows written over it (one static row map)."""
+        enc = self.ent_encoder
+        if getattr(enc, "impute", False) or not wb.batched or not base._fused_all_entity_ok(self, wb):
+            return None
+        dev = self._device()
+        B, N, D = len(wb.graphs), self.num_ents, self.embed_size
+        big_rec = base.all_embeds_batched(self, wb, out, hist)                          # (B, N, D)
+        m = getattr(wb, "_asm_loc", None)
+        if m is None:
+            sizes = [g.n for g in wb.graphs]
+            n_out = int(sum(sizes))
+            off = np.concatenate([[0], np.cumsum(sizes)])
+            asm = np.broadcast_to(n_out + np.arange(N, dtype=np.int64)[None, :], (B, N)).copy()
+            for b, g in enumerate(wb.graphs):
+                asm[b, g.gids] = off[b] + np.arange(g.n)
+            asm = asm.reshape(-1)
+            m = wb._asm_loc = (_lib.to_device(asm.astype(np.int32), dev), TF.gather_inverse(asm, n_out + N, dev))
+        x = enc.layer_2.conv_isolated(enc.layer_1.conv_isolated(self.ent_embeds))       # local stream of an entity outside the graph
+        big_loc = TF.gather_rows(torch.cat([wb.out_loc, x], dim=0), m[0], m[1]).view(B, N, D)
+        return big_loc, big_rec
 
     def batched_ensemble_loss(self, wb, locs, recs, alls, samples, weights):
         """The ensemble loss of ALL windows as one fused node (functional.batched_ensemble_link_prediction), or None when the scorer
@@ -334,9 +361,10 @@ class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
             samples = self.draw_samples(wb)
         loss = 0
         alls, wts = [], []
+        both = self.batched_all_embeds_post(wb, out, hist, DynamicRGCN)
         for i, g in enumerate(wb.graphs):
             t = wb.rows[i][-1]
-            alls.append(self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
+            alls.append((both[0][i], both[1][i]) if both is not None else self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
             wts.append(ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), t, g))
         fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)          # all windows' losses as one node
         if fused is not None:
@@ -487,9 +515,10 @@ class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
             samples = self.draw_samples(wb)
         loss = 0
         alls, wts = [], []
+        both = self.batched_all_embeds_post(wb, out, hist, BiDynamicRGCN)
         for i, g in enumerate(wb.graphs):
             t = wb.rows[i][-1]
-            alls.append(self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
+            alls.append((both[0][i], both[1][i]) if both is not None else self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
             wts.append(ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), t, g))
         fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)          # all windows' losses as one node
         if fused is not None:
