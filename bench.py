@@ -536,6 +536,83 @@ class GraphStep:
         return 1e3 * (time.perf_counter() - t0) / steps
 
 
+def launches_of(step_fn, lib):
+    tr = traced_steps(step_fn, 1, lib)
+    top = {k: dict(ms=round(v["ms_per_step"], 4), launches=int(round(v["launches_per_step"]))) for k, v in sorted(tr.items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]}
+    return int(round(sum(v["launches_per_step"] for v in tr.values()))), sum(v["ms_per_step"] for v in tr.values()), top
+
+def other_config(name, a, device, lib, steps):
+    """BASELINE.json configs 1-3 at their own sizes, each one short timed loop of the TRAINING step
+    (encoder + all-entity pass + ComplEx loss, forward + backward) on one resident batch."""
+    from temp_amd import synthetic
+    from temp_amd.sampling import CorruptTriples
+    if name == "config1_static":                 # ICEWS14 SRGCN, seq_len 1 (baselines/StaticRGCN.py:36-89)
+        from temp_amd.static_rgcn import StaticRGCN
+        w2 = synthetic.workload("S-icews14", seed=0)
+        args = make_args(w2, "SRGCN")
+        torch.manual_seed(1)
+        m2 = StaticRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
+        m2.sample_rng = np.random.default_rng(2)
+        m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+        wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3))
+        edge_visits = int(wb2.n_edge_visits)
+        with torch.no_grad():                                                              # one draw of negatives, then fixed (no autograd
+            m2.run_loss(wb2)                                                               # graph may outlive this call: see GraphStep)
+        fixed_cand = m2._last_plan[1]
+        st = GraphStep(lambda: m2.run_loss(wb2, fixed_cand), [p for p in m2.parameters()], graph=not a.no_graph)
+        what = ("StaticRGCN (2-layer RGCN, bias, ReLU; 50 % target edges), S-icews14 shape, bsz 8, seq_len 1: encoder + all-entity pass + "
+                "ComplEx loss on one prepared batch, fixed negatives")
+    elif name == "config2_default_flags":        # ICEWS14 GRRGCN seq_len 8, the reference's default flags (utils/args.py:38)
+        from temp_amd.dynamic_rgcn import DynamicRGCN
+        w2 = synthetic.workload("S-icews14", seed=0)
+        args = make_args(w2, "GRRGCN")
+        args.rec_only_last_layer = False
+        torch.manual_seed(1)
+        m2 = DynamicRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
+        m2.sample_rng = np.random.default_rng(2)
+        m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+        wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
+        fixed = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
+        edge_visits = int(wb2.n_edge_visits)
+        st = GraphStep(lambda: m2.run_loss(wb2, fixed), [p for p in m2.parameters()], graph=not a.no_graph)
+        what = ("DynamicRGCN / GRRGCN, rec_only_last_layer=False (BOTH layers recurrent: the position loop as one autograd node, "
+                "rec_stack.py), L=8, bsz 8, S-icews14 shape, encoder + loss, fixed negatives")
+    else:                                        # ICEWS05-15 BiGRRGCN seq_len 15 --rec-only-last-layer --post-ensemble
+        from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN
+        w2 = synthetic.workload("S-icews0515", seed=0)
+        args = make_args(w2, "BiGRRGCN")
+        args.post_ensemble = True
+        torch.manual_seed(1)
+        m2 = PostEnsembleBiDynamicRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
+        m2.sample_rng = np.random.default_rng(2)
+        m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+        wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
+        fixed = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
+        # the mixing weights come from frequency tables of utils/DropEdge.py (out of scope: the caller supplies them): 0.5 each
+        wts = [(torch.full((smp[0].shape[0], 1), 0.5, device=device), torch.full((smp[0].shape[0], 1), 0.5, device=device)) for smp in fixed]
+        edge_visits = int(wb2.n_edge_visits)
+        st = GraphStep(lambda: m2.run_loss(wb2, fixed, wts), [p for p in m2.parameters()], graph=not a.no_graph)
+        what = ("PostEnsembleBiDynamicRGCN (BiGRRGCN --rec-only-last-layer --post-ensemble), L=15, bsz 8, S-icews0515 shape, encoder "
+                "(local + temporal streams) + ensemble loss, fixed negatives, mixing weights 0.5")
+    n = max(10, min(steps, 30))
+    ms = st.time(n, 3)
+    nl, kms, top = launches_of(st.eager, lib)
+    return dict(what=what, ms_per_step=ms, edges_per_s=edge_visits / (ms * 1e-3), edge_visits_per_step=edge_visits,
+                launch="hip-graph replay" if st.graph is not None else "eager", steps=n, launches_per_step=nl, kernel_ms_per_step=kms,
+                top_kernels=top)
+
+
+
+def extra_child_main(a):
+    claim_stdout()
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    from temp_amd import _lib
+    lib = _lib.load()
+    out = other_config(a.extra_child, a, torch.device("cuda", 0), lib, max(20, min(a.steps, 100)))
+    emit(out)
+
+
 def extra_measurements(a, w, model, wb, targets, device, lib):
     """Secondary measurements of the default run (rank 0, one GPU), each a short object; a failure is reported in its object and
     never costs the headline line."""
@@ -585,72 +662,22 @@ def extra_measurements(a, w, model, wb, targets, device, lib):
         return dict(what="north-star snapshot-sharded step on ONE RCCL rank (three HIP graphs around the two exchanges + grad all-reduce)",
                     ms_per_step=r["ms_per_step"], edges_per_s=r["value"], launch=r["launch"], rccl_ranks=r["rccl_ranks"], steps=steps)
 
-    def launches_of(step_fn):
-        tr = traced_steps(step_fn, 1, lib)
-        top = {k: dict(ms=round(v["ms_per_step"], 4), launches=int(round(v["launches_per_step"]))) for k, v in sorted(tr.items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]}
-        return int(round(sum(v["launches_per_step"] for v in tr.values()))), sum(v["ms_per_step"] for v in tr.values()), top
-
-    def other_config(name):
-        """BASELINE.json configs 1-3 at their own sizes, each one short timed loop of the TRAINING step
-        (encoder + all-entity pass + ComplEx loss, forward + backward) on one resident batch."""
-        from temp_amd.sampling import CorruptTriples
-        if name == "config1_static":                 # ICEWS14 SRGCN, seq_len 1 (baselines/StaticRGCN.py:36-89)
-            from temp_amd.static_rgcn import StaticRGCN
-            w2 = synthetic.workload("S-icews14", seed=0)
-            args = make_args(w2, "SRGCN")
-            torch.manual_seed(1)
-            m2 = StaticRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
-            m2.sample_rng = np.random.default_rng(2)
-            m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
-            tl = torch.tensor(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3))
-            edge_visits = int(sum(int(0.5 * w2["snapshots"][int(t)].number_of_edges()) for t in tl))
-            st = GraphStep(lambda: m2(tl), [p for p in m2.parameters()], graph=False)       # (forward() plans on the host: eager)
-            what = ("StaticRGCN (2-layer RGCN, bias, ReLU; 50 % target edges), S-icews14 shape, bsz 8: forward() + backward per step, host "
-                    "planning of the batch included (the class has no prepare / run split)")
-        elif name == "config2_default_flags":        # ICEWS14 GRRGCN seq_len 8, the reference's default flags (utils/args.py:38)
-            from temp_amd.dynamic_rgcn import DynamicRGCN
-            w2 = synthetic.workload("S-icews14", seed=0)
-            args = make_args(w2, "GRRGCN")
-            args.rec_only_last_layer = False
-            torch.manual_seed(1)
-            m2 = DynamicRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
-            m2.sample_rng = np.random.default_rng(2)
-            m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
-            wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
-            fixed = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
-            edge_visits = int(wb2.n_edge_visits)
-            st = GraphStep(lambda: m2.run_loss(wb2, fixed), [p for p in m2.parameters()], graph=not a.no_graph)
-            what = ("DynamicRGCN / GRRGCN, rec_only_last_layer=False (BOTH layers recurrent: the position loop as one autograd node, "
-                    "rec_stack.py), L=8, bsz 8, S-icews14 shape, encoder + loss, fixed negatives")
-        else:                                        # ICEWS05-15 BiGRRGCN seq_len 15 --rec-only-last-layer --post-ensemble
-            from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN
-            w2 = synthetic.workload("S-icews0515", seed=0)
-            args = make_args(w2, "BiGRRGCN")
-            args.post_ensemble = True
-            torch.manual_seed(1)
-            m2 = PostEnsembleBiDynamicRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(device)
-            m2.sample_rng = np.random.default_rng(2)
-            m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
-            wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
-            fixed = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
-            # the mixing weights come from frequency tables of utils/DropEdge.py (out of scope: the caller supplies them): 0.5 each
-            wts = [(torch.full((smp[0].shape[0], 1), 0.5, device=device), torch.full((smp[0].shape[0], 1), 0.5, device=device)) for smp in fixed]
-            edge_visits = int(wb2.n_edge_visits)
-            st = GraphStep(lambda: m2.run_loss(wb2, fixed, wts), [p for p in m2.parameters()], graph=not a.no_graph)
-            what = ("PostEnsembleBiDynamicRGCN (BiGRRGCN --rec-only-last-layer --post-ensemble), L=15, bsz 8, S-icews0515 shape, encoder "
-                    "(local + temporal streams) + ensemble loss, fixed negatives, mixing weights 0.5")
-        n = max(10, min(steps, 30))
-        ms = st.time(n, 3)
-        nl, kms, top = launches_of(st.eager)
-        return dict(what=what, ms_per_step=ms, edges_per_s=edge_visits / (ms * 1e-3), edge_visits_per_step=edge_visits,
-                    launch="hip-graph replay" if st.graph is not None else "eager", steps=n, launches_per_step=nl, kernel_ms_per_step=kms,
-                    top_kernels=top)
-
     guarded("with_loss", with_loss)
     guarded("attention", attention)
     guarded("sharded_1rank", sharded)
+    def config_in_child(name):
+        """The other BASELINE configs build their own models and capture their own HIP graphs: each runs in a child process, so
+        that nothing it does (a capture that goes wrong ends the process, not with an exception) can cost the headline line."""
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--extra-child", name, "--steps", str(steps)] + (["--no-graph"] if a.no_graph else [])
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return dict(error="child process ended with code %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ""))
+        return json.loads(lines[-1])
+
     for cfg_name in ("config1_static", "config2_default_flags", "config3_post_ensemble"):
-        guarded(cfg_name, lambda cfg_name=cfg_name: other_config(cfg_name))
+        guarded(cfg_name, lambda cfg_name=cfg_name: config_in_child(cfg_name))
     if a.hbm_window_log2_nodes > 0:
         guarded("hbm_window", lambda: hbm_window(a, device, lib))
     return out
@@ -819,11 +846,14 @@ def main():
                          "288-GB GPU holds: 166 GiB peak, ~85 s of host generation + planning; 18: 83 GiB, ~35 s; 20 does not fit)")
     ap.add_argument("--hbm-window-steps", type=int, default=3)
     ap.add_argument("--cpu-probe", action="store_true", help="(internal) child process of the all-cores CPU probe: no GPU")
+    ap.add_argument("--extra-child", default="", help="(internal) child process of one `extra.config*` measurement: prints its JSON object")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="(test hook) join the process group (nccl with a GPU, gloo without), all-reduce the rank ids, print one line and exit")
     a = ap.parse_args()
     if a.cpu_probe:
         return cpu_probe_main(a)
+    if a.extra_child:
+        return extra_child_main(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` started plainly: start the N ranks ourselves (one process per GPU on this node)
         raise SystemExit(self_launch(a.gpus, sys.argv[1:]))

@@ -85,12 +85,9 @@ class StaticRGCN(TKG_Module):
                 and not self.ent_encoder.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
                 and self.num_ents % 4 == 0)
 
-    def _fused_forward(self, ts, g_list, out):
-        """All windows' losses as ONE fused node (functional.batched_link_prediction), like the recurrent models: the isolated
-        pass RGCN.forward_isolated(ent_embeds) does not depend on the window (no time embedding), so it runs once; every
-        window's all-entity matrix is [its graph's rows ; the table] through one static row map; positives / operand
-        indices / known-true slices are planned on the host and the negatives of all graphs come from one launch."""
-        from .backend import get_backend
+    def _fused_plan(self, ts, g_list):
+        """Host half of the fused loss of a batch (static for the batch): the row map that assembles every window's all-entity
+        matrix from [its graph's rows ; the isolated table], positives / operand indices / known-true slices."""
         from .sampling import TrueSetStore, plan_batch_loss
         dev = self.ent_embeds.device
         N, B = self.num_ents, len(g_list)
@@ -104,15 +101,65 @@ class StaticRGCN(TKG_Module):
         if store is None or store.device != dev:
             store = self._true_store = TrueSetStore(self.graph_dict_train, N, dev)
         plan = plan_batch_loss(store, ts, g_list, off_out[:-1], self.args.num_pos_facts, self.sample_rng, n_out, int(self.rel_embeds.shape[0]), dev)
+        return dict(plan=plan, asm=_lib.to_device(asm.reshape(-1).astype(np.int32), dev), asm_inv=TF.gather_inverse(asm.reshape(-1), n_out + N, dev),
+                    B=B, t0=ts[0])
+
+    def _fused_loss(self, fp, out, cand=None):
+        """All windows' losses as ONE fused node (functional.batched_link_prediction), like the recurrent models: the isolated
+        pass RGCN.forward_isolated(ent_embeds) does not depend on the window (no time embedding), so it runs once; every
+        window's all-entity matrix is [its graph's rows ; the table] through one static row map; the negatives of all graphs
+        come from one launch (`cand`: a fixed draw to reuse, else a fresh one per call)."""
+        from .backend import get_backend
+        plan = fp["plan"]
         if plan is None:
             return out.sum() * 0.0
-        table = self.ent_encoder.forward_isolated(self.ent_embeds, ts[0])
-        big = TF.gather_rows(torch.cat([out, table], dim=0), _lib.to_device(asm.reshape(-1).astype(np.int32), dev),
-                             TF.gather_inverse(asm.reshape(-1), n_out + N, dev))
-        cand = get_backend().corrupt_sample(int(self.seed_rng.integers(1 << 62)), plan["truth"], plan["lo"], plan["hi"], plan["ids"],
-                                            self.args.negative_rate, N)
+        N = self.num_ents
+        table = self.ent_encoder.forward_isolated(self.ent_embeds, fp["t0"])
+        big = TF.gather_rows(torch.cat([out, table], dim=0), fp["asm"], fp["asm_inv"])
+        if cand is None:
+            cand = get_backend().corrupt_sample(int(self.seed_rng.integers(1 << 62)), plan["truth"], plan["lo"], plan["hi"], plan["ids"],
+                                                self.args.negative_rate, N)
         self._last_plan = (plan, cand)
-        return self.batched_link_prediction(out, dict(plan, cand=cand), big.view(B, N, big.shape[1]))
+        return self.batched_link_prediction(out, dict(plan, cand=cand), big.view(fp["B"], N, big.shape[1]))
+
+    def _fused_forward(self, ts, g_list, out):
+        return self._fused_loss(self._fused_plan(ts, g_list), out)
+
+    # -- prepare / run split (what the recurrent models have: everything that depends only on the batch is planned and uploaded once,
+    #    the device work of a step can then be replayed -- bench.py captures it as a HIP graph) --------------------------------------
+    def prepare(self, t_list, target_edge_ids=None):
+        """-> a prepared batch: the 50 % edge subsamples (baselines/StaticRGCN.py:60-89), their union graph on the device, the
+        entity ids, and -- when the fused loss applies -- its host plan."""
+        dev = self.ent_embeds.device
+        wb = type("StaticBatch", (), {})()
+        wb.ts = [int(t) for t in t_list]
+        wb.g_list = [self.graph_dict_train[t] for t in wb.ts]
+        graphs = []
+        for i, g in enumerate(wb.g_list):
+            E = g.number_of_edges()
+            idx = target_edge_ids[i] if target_edge_ids is not None else _hostlib.sample_subset(E, int(0.5 * E), self.sample_rng)
+            graphs.append(g.edge_subgraph(idx))
+        wb.bg = S.batch(graphs)
+        wb.bg.device_graph(dev, 2 * self.num_rels)
+        wb.ids = torch.from_numpy(wb.bg.gids.astype(np.int32)).to(dev)
+        wb.sizes = [g.n for g in wb.g_list]
+        wb.n_edge_visits = int(sum(g.number_of_edges() for g in graphs))
+        wb.fused = self._fused_plan(wb.ts, wb.g_list) if self._fused_loss_ok() else None
+        return wb
+
+    def run(self, wb):
+        """Device work of the encoder on a prepared batch -> the (sum n_b, D) target rows."""
+        wb.bg.ndata['h'] = TF.gather_rows(self.ent_embeds, wb.ids)
+        out = self.ent_encoder(wb.bg, wb.ts, wb.sizes)
+        self._last_rows = out.ndata['h']
+        return out.ndata['h']
+
+    def run_loss(self, wb, cand=None):
+        """Encoder + fused loss on a prepared batch (cand: fixed negatives, e.g. the draw of an earlier call: self._last_plan[1])."""
+        rows = self.run(wb)
+        if wb.fused is None:
+            raise NotImplementedError("run_loss needs the fused loss (bilinear scorer, no time embedding); use forward()")
+        return self._fused_loss(wb.fused, rows, cand)
 
     def forward(self, t_list, target_edge_ids=None, samples=None):
         """baselines/StaticRGCN.py:36-46."""

@@ -1320,3 +1320,8 @@ def test_full_size_static_rgcn_vs_oracle_gpu():
 def test_fused_ensemble_loss_equals_reference_shaped_gpu(head_as_tail):
     from tests.window_cases import check_fused_ensemble_loss
     check_fused_ensemble_loss(DEV, head_as_tail)
+
+
+def test_static_prepare_split_equals_forward_gpu():
+    from tests.window_cases import check_static_prepare_split
+    check_static_prepare_split(DEV)

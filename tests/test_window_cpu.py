@@ -11,7 +11,7 @@ from temp_amd import backend as TB
 from temp_amd.window import ChainPlan, window_times
 from tests.cpu_backend import CpuTestBackend
 from tests.golden_util import load
-from tests.window_cases import (check_batched_equals_generic, check_dropout_visits_are_independent, check_dropout_visits_self_attention, check_fused_ensemble_loss, check_wide_batched_equals_generic, check_evaluate, check_sa_dense_api, check_sa_evaluate, check_sa_window,
+from tests.window_cases import (check_batched_equals_generic, check_dropout_visits_are_independent, check_dropout_visits_self_attention, check_fused_ensemble_loss, check_static_prepare_split, check_wide_batched_equals_generic, check_evaluate, check_sa_dense_api, check_sa_evaluate, check_sa_window,
                                 check_static, check_window, slice_snapshots)
 from oracle import temp_oracle as O
 
@@ -450,3 +450,7 @@ def test_dropout_visits_self_attention():
 @pytest.mark.parametrize("head_as_tail", [False, True])
 def test_fused_ensemble_loss_equals_reference_shaped(head_as_tail):
     check_fused_ensemble_loss(torch.device("cpu"), head_as_tail)
+
+
+def test_static_prepare_split_equals_forward():
+    check_static_prepare_split(torch.device("cpu"))

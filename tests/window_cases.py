@@ -742,3 +742,31 @@ def check_fused_ensemble_loss(device, head_as_tail):
         res.append([loss.detach()] + [t.grad.detach().clone() for t in (loc, rec, a_loc, a_rec, ws, wo, m.rel_embeds)])
     for a, b, what in zip(res[0], res[1], ("loss", "d_loc", "d_rec", "d_all_loc", "d_all_rec", "d_w_subject", "d_w_object", "d_rel")):
         assert_close(b, a, 2e-5, 1e-6, "fused ensemble loss: " + what)
+
+
+def check_static_prepare_split(device):
+    """StaticRGCN.prepare + run_loss (the replayable split) == forward() on the same draws: same edge subsamples, same positives
+    (same sampler state), the negatives of the forward() call handed to run_loss."""
+    s = slice_snapshots()
+    args = make_args(module="SRGCN", embed_size=32, hidden_size=32, n_bases=16)
+    torch.manual_seed(5)
+    m = StaticRGCN(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+    t_list = torch.tensor([20, 15, 9, 3])
+    rng = np.random.default_rng(4)
+    ids = [np.sort(rng.choice(s["tr"][int(t)].number_of_edges(), s["tr"][int(t)].number_of_edges() // 2, replace=False)) for t in t_list]
+    m.sample_rng = np.random.default_rng(9)
+    loss = m(t_list, target_edge_ids=ids)
+    loss.backward()
+    cand = m._last_plan[1]
+    want = [loss.detach().clone()] + [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]
+    m.zero_grad()
+    m.sample_rng = np.random.default_rng(9)
+    wb = m.prepare(t_list, ids)
+    for _ in range(2):                                   # a prepared batch can be run any number of times
+        m.zero_grad()
+        l2 = m.run_loss(wb, cand)
+        l2.backward()
+        got = [l2.detach().clone()] + [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
