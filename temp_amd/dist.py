@@ -136,10 +136,13 @@ def allgather_rows(local, out, bounds, world, rank, group=None):
     `out` is caller-owned (a static buffer when the surrounding compute is replayed from HIP graphs).  On RCCL `req.wait()` orders
     the CURRENT STREAM behind the transfers (the host does not block); on gloo it blocks the host, which is what a CPU run needs."""
     global P2P_BATCHES
+    mine = out[bounds[rank]:bounds[rank + 1]]
+    in_place = local.shape[0] > 0 and local.data_ptr() == mine.data_ptr()        # the layer already wrote its rows where they belong
     if LOOPBACK_P2P and local.shape[0] > 0:
-        _self_exchange(out[bounds[rank]:bounds[rank + 1]], local.contiguous(), rank, group)
-    else:
-        out[bounds[rank]:bounds[rank + 1]] = local
+        src = local.clone() if in_place else local.contiguous()
+        _self_exchange(mine, src, rank, group)
+    elif not in_place:
+        mine.copy_(local)
     ops = []
     for q in range(world):
         if q == rank:
@@ -155,16 +158,18 @@ def allgather_rows(local, out, bounds, world, rank, group=None):
     return out
 
 
-def allgather_rows_adjoint(d_all, pieces, bounds, world, rank, group=None):
+def allgather_rows_adjoint(d_all, pieces, bounds, world, rank, group=None, out=None):
     """Adjoint of allgather_rows: block q of every rank's `d_all` goes to rank q, which sums the pieces in RANK ORDER
-    (deterministic).  `pieces` is a caller-owned (world, n_local, d) buffer.  -> (n_local, d)"""
+    (deterministic).  `pieces` is a caller-owned (world, n_local, d) buffer (slot `rank` stays unused unless the loop-back
+    test switch is on: this rank's own piece is read where it lies, in `d_all`); `out`: caller-owned (n_local, d) result
+    buffer (a static one when the surrounding compute is replayed from HIP graphs).  -> (n_local, d)"""
     lo, hi = bounds[rank], bounds[rank + 1]
     n_local = hi - lo
     global P2P_BATCHES
+    own = d_all[lo:hi]
     if LOOPBACK_P2P and n_local > 0:
-        _self_exchange(pieces[rank], d_all[lo:hi], rank, group)
-    else:
-        pieces[rank] = d_all[lo:hi]
+        _self_exchange(pieces[rank], own, rank, group)
+        own = pieces[rank]
     ops = []
     for q in range(world):
         if q == rank:
@@ -177,10 +182,18 @@ def allgather_rows_adjoint(d_all, pieces, bounds, world, rank, group=None):
         P2P_BATCHES += 1
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    mine = pieces[0]
-    for q in range(1, world):                        # fixed order: the sum does not depend on arrival order
-        mine = mine + pieces[q]
-    return mine
+    part = lambda q: own if q == rank else pieces[q]
+    if world == 1:
+        if out is None:
+            return own
+        out.copy_(own)
+        return out
+    if out is None:
+        out = torch.empty_like(own)
+    torch.add(part(0), part(1), out=out)             # fixed order: the sum does not depend on arrival order
+    for q in range(2, world):
+        out.add_(part(q))
+    return out
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -294,10 +307,22 @@ class SnapshotShardedEncoder:
         sb.gather_bytes = int(canon_off[-1]) * self.model.embed_size * 4   # bytes every rank ends up holding after the all-gather
         sb.n_edge_visits_local = int(sum(g.number_of_edges() for g in mine))
         sb.n_edge_visits_global = int(sum(g.number_of_edges() for _, _, g in visits))
-        # local chain program: for every plan, the sub-chain over this rank's windows
-        inst, x_rows, out_sizes = [], [], []
+        # centre / target rows of this rank's windows (forward order)
+        tw = local_windows(bsz)
+        t_rows, t_sizes = [], []
+        ti = len(steps) - 1
+        for b in tw:
+            r0 = first_row[(ti, b)]
+            t_rows.append(np.arange(r0, r0 + tgt[b].n))
+            t_sizes.append(tgt[b].n)
+        t_rows = np.concatenate(t_rows) if t_rows else np.zeros(0, np.int64)
+        n_t = int(sum(t_sizes))
+        # local chain program: for every plan (direction), the sub-chain over this rank's windows followed by its target instance.
+        # Each direction's x and h rows are ONE contiguous run -- the target rows are indexed once per direction, as the one-GPU
+        # model copies them (bi_dynamic_rgcn.py) -- so the program has one group per GRU with disjoint x rows: the chain backward
+        # writes its gate gradients once and all weight gradients are one launch (gru_chain.py backward)
+        inst, x_rows, out_inst = [], [], []
         x_off = 0
-        last = []
         step_base = 0
         for pi, plan in enumerate(plans):
             nwin = plan.bsz
@@ -322,20 +347,7 @@ class SnapshotShardedEncoder:
                     prev_inst = len(inst) - 1
                     x_rows.append(rows_idx)
                     x_off += st.n_rows
-            last.append((prev_inst, sub, keep, fwd_of))
             step_base += len(plan.steps)
-        # centre / target instances over this rank's windows (forward order)
-        tw = local_windows(bsz)
-        t_rows, t_sizes = [], []
-        ti = len(steps) - 1
-        for b in tw:
-            r0 = first_row[(ti, b)]
-            t_rows.append(np.arange(r0, r0 + tgt[b].n))
-            t_sizes.append(tgt[b].n)
-        t_rows = np.concatenate(t_rows) if t_rows else np.zeros(0, np.int64)
-        n_t = int(sum(t_sizes))
-        out_inst = []
-        for pi, (prev_inst, sub, keep, fwd_of) in enumerate(last):
             pidx, dts = [], []
             for b in tw:
                 if sub is not None:
@@ -349,7 +361,8 @@ class SnapshotShardedEncoder:
             dts = np.concatenate(dts) if dts else np.zeros(0, np.float32)
             inst.append(GruInstance(n_t, x_off, pi, prev_inst, pidx, dts))
             out_inst.append(len(inst) - 1)
-        x_rows.append(t_rows)
+            x_rows.append(t_rows)
+            x_off += n_t
         sb.program = GruProgram(inst)
         x_index = np.concatenate(x_rows) if x_rows else np.zeros(0, np.int64)
         sb.program.x_src = x_index                  # x row i is canonical node-state row x_index[i]: a snapshot visited at several positions of
@@ -363,15 +376,16 @@ class SnapshotShardedEncoder:
 
     # ---------------------------------------------------------------------------------------------
     # The step in three compute parts around the two exchanges (ShardedStep replays each part as ONE HIP graph):
-    def local_layers(self, sb):
-        """Part 1: the two RGCN layers on this rank's snapshots -> y2 (n_local, D), attached to the autograd graph."""
+    def local_layers(self, sb, out=None):
+        """Part 1: the two RGCN layers on this rank's snapshots -> y2 (n_local, D), attached to the autograd graph.
+        out: this rank's row range of the exchange buffer (ShardedStep): layer 2 writes there, no copy before the all-gather."""
         m = self.model
         enc = m.ent_encoder
         y1 = enc.layer_1.conv_table(sb.g_local, m.ent_embeds, sb.ids_local, sb.ids_inv)     # layer 1 on the embedding table (HISTORY.md 3b)
         # layer 2's ReLU (models/BiRRGCN.py:202-203): its adjoint rides in the backward of the ONE consumer of the gathered states,
         # the row gather of chain_on_gathered -- the mask is a function of the state row alone, so every rank masks its piece of
         # a row's gradient with the same mask and the rank-ordered sum of the pieces is the masked sum
-        return enc.layer_2.conv(sb.g_local, y1, grad_premasked=self._relu_fold(sb))
+        return enc.layer_2.conv(sb.g_local, y1, grad_premasked=self._relu_fold(sb), out=out)
 
     def _relu_fold(self, sb):
         l2 = self.model.ent_encoder.layer_2
@@ -431,7 +445,8 @@ class ShardedStep:
 
     # -- the three parts (they communicate through attributes so that a capture and an eager call are the same code) ------
     def _part_a(self):
-        self.y2 = self.enc.local_layers(self.sb)
+        b = self.sb.row_bounds
+        self.y2 = self.enc.local_layers(self.sb, out=self.y2_all[b[self.rank]:b[self.rank + 1]] if self.n_local > 0 else None)
 
     def _part_b(self):
         leaf = self.y2_all.detach().requires_grad_(True)
@@ -449,7 +464,7 @@ class ShardedStep:
         allgather_rows(self.y2.detach(), self.y2_all, self.sb.row_bounds, self.world, self.rank, self.group)
 
     def _exchange_bwd(self):
-        self.d_local.copy_(allgather_rows_adjoint(self.d_all, self.pieces, self.sb.row_bounds, self.world, self.rank, self.group))
+        allgather_rows_adjoint(self.d_all, self.pieces, self.sb.row_bounds, self.world, self.rank, self.group, out=self.d_local)
 
     def _eager(self):
         for p in self.params:

@@ -18,9 +18,9 @@ ACTS = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU}
 
 class _RGCNLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, weight, loop_w, bias, dg, num_bases, act, drop, grad_premasked):
+    def forward(ctx, h, weight, loop_w, bias, dg, num_bases, act, drop, grad_premasked, dest):
         be = get_backend()
-        out = be.rgcn_fwd(dg, h, None, weight, loop_w, bias, num_bases, act, drop)
+        out = be.rgcn_fwd(dg, h, None, weight, loop_w, bias, num_bases, act, drop, out=dest)
         ctx.save_for_backward(h, weight, loop_w, out)
         ctx.dg, ctx.num_bases, ctx.has_bias, ctx.drop = dg, num_bases, bias is not None, drop
         # grad_premasked: the ONLY consumer of `out` folds the activation's adjoint into the gradient it returns
@@ -33,13 +33,16 @@ class _RGCNLayerFn(torch.autograd.Function):
         h, weight, loop_w, out = ctx.saved_tensors
         d_h, d_w, d_loop, d_bias = get_backend().rgcn_bwd(ctx.dg, h, out, d_out.contiguous(), weight, loop_w, ctx.has_bias,
                                                           ctx.num_bases, ctx.act, ctx.drop)
-        return d_h, d_w, d_loop, d_bias, None, None, None, None, None
+        return d_h, d_w, d_loop, d_bias, None, None, None, None, None, None
 
 
-def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None, drop=None, grad_premasked=False):
+def rgcn_layer(h, dg, weight, loop_w, bias, num_bases, act=None, drop=None, grad_premasked=False, out=None):
     """out = act(nnorm^2 * sum_in h_u BD(W_r) [+bias] + dropout(h W_loop)) on a device graph `dg`.
-    drop = (p, seed) or None: dropout of the self-loop message (models/RGCN.py:57-59), mask = hash(seed, row, col)."""
-    return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act], drop, bool(grad_premasked and act == "relu"))
+    drop = (p, seed) or None: dropout of the self-loop message (models/RGCN.py:57-59), mask = hash(seed, row, col).
+    out: optional caller-owned contiguous (n_nodes, d_out) destination that no autograd graph knows (e.g. this rank's row range
+    of the exchange buffer of temp_amd.dist): the layer writes its result there instead of allocating."""
+    return _RGCNLayerFn.apply(h, weight, loop_w, bias, dg, num_bases, ACTS[act], drop, bool(grad_premasked and act == "relu"),
+                              None if out is None else out.detach())
 
 
 class _RGCNTableLayerFn(torch.autograd.Function):

@@ -67,12 +67,12 @@ class RGCNLayer(nn.Module):
     def _bias(self):
         return self.h_bias if self.bias else None
 
-    def conv(self, g, h, grad_premasked=False):
+    def conv(self, g, h, grad_premasked=False, out=None):
         """The fused layer on node features `h` of graph `g` (models/RGCN.py:53-70).  grad_premasked: see TF.rgcn_layer (only
         meaningful for a fused ReLU; the caller guarantees the single masking consumer)."""
         dg = g.device_graph(h.device, self.num_rels)
         out = TF.rgcn_layer(h, dg, self.weight, self.loop_weight, self._bias(), self.num_bases, self._act, self._drop(),
-                            grad_premasked=grad_premasked and self._post_act is None)
+                            grad_premasked=grad_premasked and self._post_act is None, out=out if self._post_act is None else None)
         return self._post_act(out) if self._post_act is not None else out
 
     def relu_fused(self):

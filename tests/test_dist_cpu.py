@@ -53,6 +53,11 @@ def _worker(rank, world, port, name, mode, q):
         if mode == "snapshots":
             enc = SnapshotShardedEncoder(m)
             sb = enc.prepare(torch.tensor(t_list), L, True, edge_ids)
+            # one group per GRU, disjoint x rows: the shape on which the chain backward writes its gate gradients once and
+            # every weight gradient is one launch (the shape of the one-GPU program; gru_chain.py backward)
+            groups = sb.program.groups
+            assert len(groups) == len({g["rnn"] for g in groups}) <= 2
+            assert all(a["x1"] <= b["x0"] for a, b in zip(groups, groups[1:]))
             out = enc.run(sb)
             pieces = list(out.split(sb.target_sizes)) if sb.target_sizes else []
             wins = sb.target_windows
