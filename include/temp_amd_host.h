@@ -91,6 +91,12 @@ int temp_host_sample_subset(int64_t n, int64_t k, uint64_t seed, int64_t* out);
  *   seg_ptr[n_rows + 1], order[count of non-negative entries];  returns that count, or -1 on a bad argument. */
 int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, int32_t* seg_ptr, int32_t* order);
 
+/* Distinct labels of labels[0..n) (all in [0, n_labels)) in ascending label order -- numpy.unique(labels, return_index=True,
+ * return_inverse=True) in O(n + n_labels): first[k] = position of the first occurrence of the k-th distinct label, inv[i] = k
+ * of labels[i].  (Which chain rows share their GRU input gates: rows gathered from the same layer-output row,
+ * temp_amd/gru_chain.py GruProgram.gi_shared.)  first[n], inv[n]; returns the number of distinct labels, or -1 on a bad argument. */
+int64_t temp_host_unique_labels(int64_t n, const int64_t* labels, int64_t n_labels, int32_t* first, int32_t* inv);
+
 /* Track / panel tables of the persistent window-chain kernels (include/temp_amd.h: TempGruChain; replaces the per-position
  * history bookkeeping of models/DynamicRGCN.py:35-54 for the chain kernels).  Chain c = instances chain_inst[chain_off[c] ..
  * chain_off[c+1]) in position order; instance i has inst_n[i] rows starting at row inst_h0[i] of the step's row space and uses GRU

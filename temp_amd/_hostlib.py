@@ -23,6 +23,7 @@ SYMBOLS = {
     "temp_host_union_plan": (_I64, [_I64, _I64, _P, _P, _P, _I64, _P, _I64, _P]),
     "temp_host_sample_subset": (ctypes.c_int, [_I64, _I64, ctypes.c_uint64, _P]),
     "temp_host_gather_inverse": (_I64, [_I64, _P, _I64, _P, _P]),
+    "temp_host_unique_labels": (_I64, [_I64, _P, _I64, _P, _P]),
     "temp_host_chain_plan": (ctypes.c_int, [ctypes.c_int, _I64, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "temp_host_chain_tracks": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P]),
 }
@@ -144,6 +145,18 @@ def gather_inverse(idx, n_rows):
     if cnt < 0:
         raise ValueError("temp_host_gather_inverse: index outside [.., %d)" % n_rows)
     return both[:n_rows + 1 + cnt], int(cnt)
+
+
+def unique_labels(labels, n_labels):
+    """See temp_host_unique_labels -> (first int32 [k], inverse int32 [n]): numpy.unique(labels, return_index=True,
+    return_inverse=True)[1:] for labels in [0, n_labels)."""
+    labels = _i64(labels).reshape(-1)
+    n = int(labels.shape[0])
+    first, inv = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32)
+    k = load().temp_host_unique_labels(n, labels.ctypes.data, int(n_labels), first.ctypes.data, inv.ctypes.data)
+    if k < 0:
+        raise ValueError("temp_host_unique_labels: label outside [0, %d)" % n_labels)
+    return first[:k], inv[:n]
 
 
 def snapshot_pack(n, src, dst, rel, nnorm, n_rel_rows, chunk, chunk_rel):

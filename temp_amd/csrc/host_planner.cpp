@@ -369,6 +369,23 @@ int64_t temp_host_gather_inverse(int64_t n, const int64_t* idx, int64_t n_rows, 
   return seg_ptr[n_rows];
 }
 
+int64_t temp_host_unique_labels(int64_t n, const int64_t* labels, int64_t n_labels, int32_t* first, int32_t* inv) {
+  if (n < 0 || n_labels < 0 || (n > 0 && (!labels || !first || !inv))) return -1;
+  std::vector<int32_t> slot((size_t)n_labels, -1);           // first position of a label, then its rank
+  for (int64_t i = 0; i < n; ++i) {
+    if (labels[i] < 0 || labels[i] >= n_labels) return -1;
+    if (slot[(size_t)labels[i]] < 0) slot[(size_t)labels[i]] = (int32_t)i;
+  }
+  int64_t k = 0;
+  for (int64_t l = 0; l < n_labels; ++l)
+    if (slot[(size_t)l] >= 0) {
+      first[k] = slot[(size_t)l];
+      slot[(size_t)l] = (int32_t)k++;
+    }
+  for (int64_t i = 0; i < n; ++i) inv[i] = slot[(size_t)labels[i]];
+  return k;
+}
+
 // Track / panel tables of the persistent window-chain kernels (GruProgram.chain_plan, temp_amd/gru_chain.py): every row of every
 // instance of a chain gets a TRACK -- it inherits its predecessor's (prev >= 0), otherwise takes the lowest track no row of its
 // instance inherits, new tracks when none is free -- and tracks are cut into panels of `T`; a panel's steps are the positions at

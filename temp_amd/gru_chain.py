@@ -234,10 +234,11 @@ class GruProgram:
             return c[1]
         src = np.asarray(src)
         reps, g0, index, total = [], [], np.zeros(self.n_total, dtype=np.int32), 0
+        n_labels = int(src.max()) + 1 if src.size else 0
         for g in self.groups:
             assert g["x1"] - g["x0"] == g["h1"] - g["h0"]
-            _, first, inv = np.unique(src[g["x0"]:g["x1"]], return_index=True, return_inverse=True)
-            reps.append(first.astype(np.int32))
+            first, inv = _hostlib.unique_labels(src[g["x0"]:g["x1"]], n_labels)     # (numpy.unique's first / inverse, O(n))
+            reps.append(first)
             g0.append(total)
             index[g["h0"]:g["h1"]] = total + inv.reshape(-1)
             total += first.size

@@ -16,7 +16,7 @@ def test_host_library_exports_every_declared_symbol():
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(temp_host_[a-z0-9_]+)\s*\(", src)))
     lib = _hostlib.load()
-    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 9
+    assert names == sorted(_hostlib.SYMBOLS) and len(names) == 10
     for n in names:
         assert hasattr(lib, n)
     assert lib.temp_host_abi_version() == 2
@@ -82,6 +82,18 @@ def test_gather_inverse_matches_stable_argsort(n, n_rows):
     assert both[0] == 0 and np.array_equal(both[1:n_rows + 1], np.cumsum(np.bincount(idx[keep], minlength=n_rows)))
     with pytest.raises(ValueError):
         _hostlib.gather_inverse(np.array([n_rows]), n_rows)
+
+
+@pytest.mark.parametrize("n,n_labels", [(0, 5), (1, 1), (1000, 300), (60000, 47000), (300, 90000)])
+def test_unique_labels_matches_numpy_unique(n, n_labels):
+    rng = np.random.default_rng(n + n_labels)
+    labels = rng.integers(0, n_labels, n)
+    first, inv = _hostlib.unique_labels(labels, n_labels)
+    _, f2, i2 = np.unique(labels, return_index=True, return_inverse=True)
+    assert first.dtype == np.int32 and inv.dtype == np.int32
+    assert np.array_equal(first, f2) and np.array_equal(inv, i2.reshape(-1))
+    with pytest.raises(ValueError):
+        _hostlib.unique_labels(np.array([n_labels]), n_labels)
 
 
 @pytest.mark.parametrize("n,E,R2,hub", [(500, 7475, 40, True), (227, 200, 460, False), (30, 0, 6, False), (1, 5, 2, False), (64, 3000, 3, True)])
