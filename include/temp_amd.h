@@ -71,7 +71,9 @@ enum {
   TEMP_OPT_GRU_STREAM = 4,  /* 1: force the streaming GRU cell kernel                          [TEMP_GRU_STREAM=1 -> 1] default 0 */
   TEMP_OPT_RGCN_TILE = 5,   /* 1: aggregation and d/dh stage a member snapshot's rows in LDS when the graph carries member tables
                                2: the weight-gradient kernel too (slower at the measured shapes)
-                               0: always gather through L2 (bit-identical results)             [TEMP_RGCN_TILE=0 -> 0]  default 1 */
+                               3: the weight-gradient kernel with the gradient rows in LDS and the x rows read through L2 (same
+                                  bits as 2; no faster than the gather kernel at the measured shapes)
+                               0: always gather through L2 (bit-identical results)             [TEMP_RGCN_TILE=<n>]    default 1 */
   TEMP_OPT_DEBUG = 6,       /* development ablations inside instrumented kernels; 0 (off) in every product run          default 0 */
   TEMP_OPT_OVERLAP = 7,     /* 1: a layer's backward launches the relation-weight gradient on a library-owned side stream (fork /
                                join events on the caller's stream: a parallel branch under HIP-graph capture) so that it overlaps

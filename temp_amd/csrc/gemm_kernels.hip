@@ -1097,7 +1097,7 @@ static const bool g_options_init = [] {
   if ((e = getenv("TEMP_RGCN_SCALAR")) && e[0] == '0') g_options[TEMP_OPT_RGCN_SCALAR] = 0;
   if ((e = getenv("TEMP_GEMM_STREAM")) && e[0] == '1') g_options[TEMP_OPT_GEMM_STREAM] = 1;
   if ((e = getenv("TEMP_GRU_STREAM")) && e[0] == '1') g_options[TEMP_OPT_GRU_STREAM] = 1;
-  if ((e = getenv("TEMP_RGCN_TILE")) && e[0] == '0') g_options[TEMP_OPT_RGCN_TILE] = 0;
+  if ((e = getenv("TEMP_RGCN_TILE")) && e[0] >= '0' && e[0] <= '9') g_options[TEMP_OPT_RGCN_TILE] = atoi(e);
   if ((e = getenv("TEMP_OVERLAP")) && e[0] == '0') g_options[TEMP_OPT_OVERLAP] = 0;
   if ((e = getenv("TEMP_GEMM_RESIDENT")) && e[0] == '0') g_options[TEMP_OPT_GEMM_RESIDENT] = 0;
   if ((e = getenv("TEMP_DEBUG"))) g_options[TEMP_OPT_DEBUG] = atoi(e);

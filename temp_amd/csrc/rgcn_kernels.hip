@@ -802,6 +802,17 @@ static bool launch_dw_tile(const TempEdgeView& v, const TileArgs& t, const float
   return true;
 }
 
+template <int S>
+static bool launch_dw_hybrid(const TempEdgeView& v, const TileArgs& t, const float* x, const int32_t* x_ids, const float* dz, const float* nnorm, int D,
+                             float* dW, float* partial, hipStream_t st) {
+  static const bool granted = tile_grant_lds(k_rgcn_dw_h<S>, TILE_LDS_MAX);
+  if (!granted) { (void)hipGetLastError(); return false; }
+  const int grid = 8 * ceil_div(t.n_members, 8) * t.n_slices;
+  TEMP_LAUNCH(K_RGCN_DW, (k_rgcn_dw_h<S>), dim3(grid), dim3(TILE_THREADS), t.lds_bytes, st, v, t, x, x_ids, dz, nnorm, D, dW, partial);
+  g_tile_launches.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+
 static int run_dw(const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz, const float* nnorm, int d_in, int d_out, int num_bases,
                   int n_rel_rows, float* dW, float* partial, hipStream_t st) {
   const int si = d_in / num_bases, so = d_out / num_bases;
@@ -812,7 +823,14 @@ static int run_dw(const TempEdgeView& v, const TempMembers* mb, const float* x, 
   TileArgs ta;
   // (measured at the S-gdelt shape: with TWO row sets in LDS the slices get narrow -- 7-8 of a walker's 16 lanes work -- and the
   // tiled weight-gradient kernel is slower than the L2-gather kernel, 151 against 110-120 us: only TEMP_OPT_RGCN_TILE = 2 takes it)
-  if (fast_shape(d_in, d_out, num_bases, &S) && mb && option(TEMP_OPT_RGCN_TILE) >= 2 && n_rel_rows <= 65535 && v.n_partial < 0xffffff &&
+  if (fast_shape(d_in, d_out, num_bases, &S) && mb && option(TEMP_OPT_RGCN_TILE) >= 3 && n_rel_rows <= 65535 && v.n_partial < 0xffffff &&
+      tile_plan(*mb, 2, d_in, S, 0, 0, 4, &ta) &&
+      (S == 1 ? launch_dw_hybrid<1>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st)
+              : S == 2 ? launch_dw_hybrid<2>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st) : launch_dw_hybrid<4>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st))) {
+    // dz rows in LDS, x rows from L2 (rgcn_tile.hpp: k_rgcn_dw_h).  Measured at the S-gdelt shape, alone on the chip: 98 us
+    // against 101 for k_rgcn_dw_s (and 106 for d/dh): no gain -- these kernels are bound by the per-block staging + chunk walk
+    // of 2.6 rounds of workgroups, not by the L2 gathers -- so only TEMP_OPT_RGCN_TILE = 3 takes it
+  } else if (fast_shape(d_in, d_out, num_bases, &S) && mb && option(TEMP_OPT_RGCN_TILE) == 2 && n_rel_rows <= 65535 && v.n_partial < 0xffffff &&
       tile_plan(*mb, 2, d_in, S, 1, 0, 2, &ta) &&
       (S == 1 ? launch_dw_tile<1>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st)
               : S == 2 ? launch_dw_tile<2>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st) : launch_dw_tile<4>(v, ta, x, x_ids, dz, nnorm, d_in, dW, partial, st))) {

@@ -523,4 +523,120 @@ __global__ void __launch_bounds__(TILE_THREADS) k_rgcn_dw_t(TempEdgeView v, Tile
   }
 }
 
+// d/dweight with ONE staged row set: the dz rows (pre-scaled by nnorm[dst]^2) of the slice in LDS -- 13 float4 per row, four
+// slices, as in the d/dh kernel -- and the x row of every edge read from global memory (L2) through the edge's RESOLVED row index
+// (node -> table row done while staging: layer 1 reads the embedding table).  Half the L2 gathers of k_rgcn_dw_s (which fetches
+// both rows per edge) and none of the narrow slices of k_rgcn_dw_t (two row sets in LDS: 7-8 float4 wide).  U edges of a walker
+// are in flight; the products are added in edge order, so chunk partials are BIT-IDENTICAL to k_rgcn_dw_s / k_rgcn_dw_t.
+template <int S>
+__global__ void __launch_bounds__(TILE_THREADS) k_rgcn_dw_h(TempEdgeView v, TileArgs t, const float* __restrict__ x, const int32_t* __restrict__ x_ids,
+                                                            const float* __restrict__ dz, const float* __restrict__ nnorm, int D,
+                                                            float* __restrict__ dW, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+  float4* Gs = reinterpret_cast<float4*>(tile_lds + t.off_x);
+  unsigned short* Eg = reinterpret_cast<unsigned short*>(tile_lds + t.off_ea);      // local dst node of the edge (row of Gs)
+  unsigned* Ex = reinterpret_cast<unsigned*>(tile_lds + t.off_eb);                  // global x row of the edge
+  uint2* cm = reinterpret_cast<uint2*>(tile_lds + t.off_cm);
+  int* misc = reinterpret_cast<int*>(tile_lds + t.off_misc);
+  const int D4 = D >> 2;
+  TileBlock b;
+  if (!tile_block(t, D4, b)) return;
+  const int tid = threadIdx.x, nthr = blockDim.x, fs4 = t.fs4;
+  for (int i = tid; i < TILE_MISC_INTS; i += nthr) misc[i] = 0;
+  tile_stage_rows<true>(Gs, t, b, dz, D, nullptr, nnorm);
+  {
+    constexpr int U = 8;
+    for (int i = tid; i < b.em; i += U * nthr) {
+      int a[U], bb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = b.e0 + min(i + u * nthr, b.em - 1);
+        a[u] = v.a[e];
+        bb[u] = v.b[e];
+      }
+      if (x_ids) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = x_ids[a[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i + u * nthr < b.em) { Ex[i + u * nthr] = (unsigned)a[u]; Eg[i + u * nthr] = (unsigned short)(bb[u] - b.n0); }
+    }
+  }
+  __syncthreads();
+  tile_sort_chunks(cm, misc, v, b, 0);
+
+  const int lane = tid & 63;
+  int g, lr;
+  tile_lane(lane, g, lr);
+  const bool lane_ok = lr < b.nf4;
+  int* queue = misc + 2 * (TILE_LMAX + 2);
+  const unsigned char* gl = reinterpret_cast<const unsigned char*>(Gs + lr);
+  const float* xl = x + (size_t)(b.f4_0 + (lane_ok ? lr : 0)) * 4;
+  const unsigned xrow = (unsigned)fs4 * 16u;
+  const int wrow = D * S;
+  constexpr int U = 8;
+  for (;;) {
+    int task = 0;
+    if (lane == 0) task = atomicAdd(queue, 1);
+    task = __builtin_amdgcn_readfirstlane(task);
+    const int k = task * 4 + g;
+    if (task * 4 >= b.nc) break;
+    const bool has = lane_ok && k < b.nc;
+    const uint2 mt = has ? cm[k] : make_uint2(0u, 0xffffffu);
+    const int beg = mt.x & 0xffffu, seg = mt.x >> 16, len = mt.y >> 24;
+    const unsigned slot = mt.y & 0xffffffu;
+    float4 acc[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) acc[q] = zero4();
+    const unsigned short* eg = Eg + beg;
+    const unsigned* ex = Ex + beg;
+    for (int j = 0; j < len; j += U) {
+      float4 xx[U], gg[U];
+      unsigned xr[U], gr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = min(j + u, len - 1);                   // past the end: the last edge again (its product is not added)
+        xr[u] = ex[jj];
+        gr[u] = eg[jj];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) xx[u] = ld4(xl + (size_t)xr[u] * D);
+#pragma unroll
+      for (int u = 0; u < U; ++u) gg[u] = *reinterpret_cast<const float4*>(gl + __umul24(gr[u], xrow));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j + u < len) {
+          const float4 a4 = xx[u], g4 = gg[u];
+          if (S == 1) {
+            acc[0].x = fmaf(a4.x, g4.x, acc[0].x);
+            acc[0].y = fmaf(a4.y, g4.y, acc[0].y);
+            acc[0].z = fmaf(a4.z, g4.z, acc[0].z);
+            acc[0].w = fmaf(a4.w, g4.w, acc[0].w);
+          } else if (S == 2) {
+            acc[0].x = fmaf(a4.x, g4.x, acc[0].x);
+            acc[0].y = fmaf(a4.x, g4.y, acc[0].y);
+            acc[0].z = fmaf(a4.y, g4.x, acc[0].z);
+            acc[0].w = fmaf(a4.y, g4.y, acc[0].w);
+            acc[S > 1 ? 1 : 0].x = fmaf(a4.z, g4.z, acc[S > 1 ? 1 : 0].x);
+            acc[S > 1 ? 1 : 0].y = fmaf(a4.z, g4.w, acc[S > 1 ? 1 : 0].y);
+            acc[S > 1 ? 1 : 0].z = fmaf(a4.w, g4.z, acc[S > 1 ? 1 : 0].z);
+            acc[S > 1 ? 1 : 0].w = fmaf(a4.w, g4.w, acc[S > 1 ? 1 : 0].w);
+          } else {
+            acc[0] = fma4(a4.x, g4, acc[0]);
+            acc[S > 1 ? 1 : 0] = fma4(a4.y, g4, acc[S > 1 ? 1 : 0]);
+            acc[S > 2 ? 2 : 0] = fma4(a4.z, g4, acc[S > 2 ? 2 : 0]);
+            acc[S > 3 ? 3 : 0] = fma4(a4.w, g4, acc[S > 3 ? 3 : 0]);
+          }
+        }
+      }
+    }
+    if (has) {
+      float* dst = ((slot == 0xffffffu) ? dW + (size_t)seg * wrow : partial + (size_t)slot * wrow) + (size_t)(b.f4_0 + lr) * 4 * S;
+#pragma unroll
+      for (int q = 0; q < S; ++q) st4(dst + 4 * q, acc[q]);
+    }
+  }
+}
+
 }  // namespace temp

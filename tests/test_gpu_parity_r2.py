@@ -873,6 +873,10 @@ def test_tiled_edge_kernels_bit_identical_gpu(D, B, hip_backend):
     n0 = lib.temp_tile_launches()
     tiled = run()
     assert lib.temp_tile_launches() - n0 == 6, "the LDS-tiled kernels were not launched"
+    lib.temp_set_option(_lib.OPT_RGCN_TILE, 3)                # 3: d/dweight with the gradient rows in LDS and the x rows read from L2
+    n0 = lib.temp_tile_launches()
+    hybrid = run()
+    assert lib.temp_tile_launches() - n0 == 6, "the hybrid weight-gradient kernel was not launched"
     lib.temp_set_option(_lib.OPT_RGCN_TILE, 0)
     try:
         n1 = lib.temp_tile_launches()
@@ -880,6 +884,8 @@ def test_tiled_edge_kernels_bit_identical_gpu(D, B, hip_backend):
         assert lib.temp_tile_launches() == n1
     finally:
         lib.temp_set_option(_lib.OPT_RGCN_TILE, prev)
+    for i, (a, c) in enumerate(zip(tiled, hybrid)):           # same chunks, same edge order inside a chunk: the same bits
+        assert torch.equal(a, c), ("tiled vs hybrid", i, float((a - c).abs().max()))
     assert len(tiled) == len(gathered)
     for i, (a, c) in enumerate(zip(tiled, gathered)):
         if tuple(a.shape) == tuple(wt.shape):   # the relation-weight gradient: the gather kernel sums a destination run's source rows
