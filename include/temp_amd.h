@@ -451,8 +451,10 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
  * seg_ptr [n_seg+1] / order [n_rows] = the gather indices grouped by table row (built once on the host;
  * ids < 0 are left out, so n_rows may be smaller than the gather).
  * No atomics; d % 4 == 0, d <= 256.  Tables with very long segments (>= 512 rows per segment on average, e.g. the
- * relation table under the loss) are reduced in two deterministic stages through `workspace`
- * (temp_segment_sum_rows_workspace bytes; 0 for ordinary shapes; NULL falls back to one block per segment). */
+ * relation table under the loss) are reduced in two deterministic stages through `workspace`; segmentations of 2-32 rows per
+ * segment on average are summed over fixed 64-row pieces of `order` (skew-proof: a hub entity's thousands of rows are many
+ * pieces, not one wave's loop) with the piece partials in `workspace`
+ * (temp_segment_sum_rows_workspace bytes; 0 for the other shapes; NULL falls back to one wave / one block per segment). */
 size_t temp_segment_sum_rows_workspace(int n_seg, int n_rows, int d);
 int temp_segment_sum_rows(int n_seg, int n_rows, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, float* out,
                           void* workspace, size_t workspace_bytes, void* stream);

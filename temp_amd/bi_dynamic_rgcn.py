@@ -259,6 +259,7 @@ class BiDynamicRGCN(DynamicRGCN):
             d = S.upload_packed(host, dev, np.int32)
             f32 = lambda t: t.view(torch.float32).view(-1, 1)
             wb.all_maps = [dict(n_prev=n_prev, ent=d["ent"], idx_f=d["idx_f"], idx_b=d["idx_b"], dt_f=f32(d["dt_f"]), dt_b=f32(d["dt_b"]),
+                                idx_f_host=host["idx_f"], idx_b_host=host["idx_b"],
                                 asm=d["asm"], ent_inv=TF.gather_inverse(ee, N, dev) if n_prev else None,
                                 asm_inv=TF.gather_inverse(asm.reshape(-1), n_out + n_prev + N if wb.n_inactive else n_out, dev))]
         return wb.all_maps
@@ -285,8 +286,10 @@ class BiDynamicRGCN(DynamicRGCN):
             def both(layer, x, pf, pb):
                 lam, dec = layer.inv_temperature, layer.decay_spec()
                 none = torch.full_like(m["idx_f"], -1)
-                return run_rnn(layer.forward_rnn, x, pf if pf is not None else zero, m["dt_f"], lam, dec, m["idx_f"] if pf is not None else none) + \
-                    run_rnn(layer.backward_rnn, x, pb if pb is not None else zero, m["dt_b"], lam, dec, m["idx_b"] if pb is not None else none)
+                return run_rnn(layer.forward_rnn, x, pf if pf is not None else zero, m["dt_f"], lam, dec, m["idx_f"] if pf is not None else none,
+                               self._pair_inverse(m, "idx_f", pf) if pf is not None else None) + \
+                    run_rnn(layer.backward_rnn, x, pb if pb is not None else zero, m["dt_b"], lam, dec, m["idx_b"] if pb is not None else none,
+                            self._pair_inverse(m, "idx_b", pb) if pb is not None else None)
             h1p = both(l1, TF.gather_rows(iso1, m["ent"], m["ent_inv"]), f1, b1)
             parts.append(both(l2, l2.conv_isolated(h1p), f2, b2))
         parts.append(self._zero_state_rows(l2.forward_rnn, x2, l2) + self._zero_state_rows(l2.backward_rnn, x2, l2))

@@ -1354,6 +1354,97 @@ __global__ void __launch_bounds__(256) k_segment_sum_fin(int n_seg, int S, int d
   out[i] = relu_of ? relu_gate4(relu_of[i], acc) : acc;
 }
 
+// Segment sum over FIXED PIECES of the row list (skewed segmentations: the adjoint of a gather of Zipf-distributed entity rows has
+// a few segments of hundreds to thousands of rows among thousands of short ones, and a wave per segment takes as long as the
+// longest).  Wave c sums the rows order[32 c .. 32 c + 32) segment by segment, in row order -- all 32 row loads are issued before
+// the first addition: one memory round trip per piece -- a segment that lies inside the piece is written to `out`; the FIRST and
+// the LAST segment of the piece, when they reach beyond it, go to part[c][0] / part[c][1].  k_segment_sum_pieces_fin then adds the
+// pieces of every such segment in piece order (and zero-fills the empty segments): fixed pieces, fixed order => bit-repeatable.
+// Lanes = float4 columns (d4 <= 64).
+#define SEGSUM_PIECE 32
+#define SEGSUM_PIECE_LOG2 5
+__global__ void __launch_bounds__(256) k_segment_sum_pieces(int n_seg, int n_rows, int d4, const int32_t* __restrict__ seg_ptr,
+                                                            const int32_t* __restrict__ order, const float4* __restrict__ src,
+                                                            const int32_t* __restrict__ row_mask, const float4* __restrict__ relu_of,
+                                                            float4* __restrict__ out, float4* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int r0 = c * SEGSUM_PIECE;
+  n_rows = min(n_rows, seg_ptr[n_seg]);                                    // (the rows there are: order[] holds exactly seg_ptr[n_seg])
+  if (r0 >= n_rows) return;
+  const int r1 = min(r0 + SEGSUM_PIECE, n_rows);
+  const bool col_ok = lane < d4;
+  const int col = col_ok ? lane : 0;
+  int mine = (r0 + lane < r1) ? order[r0 + lane] : -1;
+  if (row_mask && mine >= 0 && row_mask[mine] <= 0) mine = -1;             // masked rows were never written by their producer
+  float4 v[SEGSUM_PIECE];
+#pragma unroll
+  for (int u = 0; u < SEGSUM_PIECE; ++u) {
+    const int r = __builtin_amdgcn_readlane(mine, u);
+    v[u] = r >= 0 ? src[(size_t)r * d4 + col] : zero4();
+  }
+  // the segment of row r0 (wave-uniform binary search: seg_ptr is non-decreasing)
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_ptr[mid + 1] > r0) hi = mid; else lo = mid + 1;
+  }
+  int sg = lo, sb = seg_ptr[sg], se = seg_ptr[sg + 1];
+  float4 acc = zero4();
+  auto flush = [&]() {
+    if (!col_ok) return;
+    if (sb >= r0 && se <= r1) out[(size_t)sg * d4 + lane] = relu_of ? relu_gate4(relu_of[(size_t)sg * d4 + lane], acc) : acc;
+    else part[((size_t)c * 2 + (sb <= r0 ? 0 : 1)) * d4 + lane] = acc;
+  };
+#pragma unroll
+  for (int u = 0; u < SEGSUM_PIECE; ++u) {
+    const int row = r0 + u;
+    if (row < r1) {
+      if (row == se) {                                                     // (wave-uniform) the next non-empty segment starts here
+        flush();
+        do { ++sg; se = seg_ptr[sg + 1]; } while (se <= row);
+        sb = seg_ptr[sg];
+        acc = zero4();
+      }
+      acc = add4(acc, v[u]);
+    }
+  }
+  flush();
+}
+
+__global__ void __launch_bounds__(256) k_segment_sum_pieces_fin(int n_seg, int d4, const int32_t* __restrict__ seg_ptr, const float4* __restrict__ part,
+                                                                const float4* __restrict__ relu_of, float4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const bool col_ok = lane < d4;
+  for (int s = wave; s < n_seg; s += nwaves) {
+    const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+    if (end <= beg) {
+      if (col_ok) out[(size_t)s * d4 + lane] = zero4();
+      continue;
+    }
+    const int cb = beg >> SEGSUM_PIECE_LOG2, ce = (end - 1) >> SEGSUM_PIECE_LOG2;
+    if (cb == ce) continue;                                                // inside one piece: written by the walk
+    float4 acc = zero4();
+    if (col_ok) {
+      acc = part[((size_t)cb * 2 + ((beg & (SEGSUM_PIECE - 1)) == 0 ? 0 : 1)) * d4 + lane];  // first piece: its last segment, unless it starts the piece
+      int c = cb + 1;
+      for (; c + 16 <= ce + 1; c += 16) {
+        float4 q[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q[u] = part[(size_t)(c + u) * 2 * d4 + lane];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = add4(acc, q[u]);
+      }
+      for (; c <= ce; ++c) acc = add4(acc, part[(size_t)c * 2 * d4 + lane]);
+      out[(size_t)s * d4 + lane] = relu_of ? relu_gate4(relu_of[(size_t)s * d4 + lane], acc) : acc;
+    }
+  }
+}
+
+// rows per segment between the short-segment kernel's and the block-per-segment kernels' ranges: fixed pieces (robust to skew)
+static bool segsum_pieces(int n_seg, long long n_rows, int d4) { return d4 <= 64 && n_rows > 2LL * n_seg && n_rows <= 32LL * n_seg && n_rows < (1LL << 31) - 64; }
+
 static int segsum_splits(int n_seg, long long n_rows) {
   if (n_seg <= 0 || n_rows < 512LL * n_seg) return 1;
   int S = 2048 / n_seg;
@@ -1363,7 +1454,9 @@ static int segsum_splits(int n_seg, long long n_rows) {
 
 size_t segment_sum_rows_workspace(int n_seg, long long n_rows, int d) {
   const int S = segsum_splits(n_seg, n_rows);
-  return S > 1 ? (size_t)n_seg * S * d * sizeof(float) : 0;
+  if (S > 1) return (size_t)n_seg * S * d * sizeof(float);
+  if (segsum_pieces(n_seg, n_rows, d / 4)) return (size_t)ceil_div(n_rows, (long long)SEGSUM_PIECE) * 2 * d * sizeof(float);
+  return 0;
 }
 
 int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* order, const float* src, const int32_t* row_mask, float* out,
@@ -1374,6 +1467,15 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
   if (S > 1 && d4 <= 64 && ws && ws_bytes >= segment_sum_rows_workspace(n_seg, n_rows_hint, d)) {
     TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_part, dim3(S, n_seg), dim3(256), 0, st, S, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)ws);
     TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_fin, dim3(ceil_div((long long)n_seg * d4, 256)), dim3(256), 0, st, n_seg, S, d4, (const float4*)ws, relu_of, (float4*)out);
+    return launch_status();
+  }
+  if (S <= 1 && segsum_pieces(n_seg, n_rows_hint, d4) && ws && ws_bytes >= segment_sum_rows_workspace(n_seg, n_rows_hint, d)) {
+    const int n_pieces = (int)ceil_div(n_rows_hint, (long long)SEGSUM_PIECE);
+    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_pieces, dim3(ceil_div(n_pieces, 4)), dim3(256), 0, st, n_seg, (int)n_rows_hint, d4, seg_ptr, order,
+                (const float4*)src, row_mask, relu_of, (float4*)out, (float4*)ws);
+    int grid = ceil_div(n_seg, 4);
+    if (grid > 2048) grid = 2048;
+    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_pieces_fin, dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, (const float4*)ws, relu_of, (float4*)out);
     return launch_status();
   }
   if (n_rows_hint > 32LL * n_seg && d4 <= 64) {

@@ -450,14 +450,25 @@ class DynamicRGCN(TKG_Module):
                     n_src = n_prev + N
                 host["ent%d" % d], host["idx%d" % d], host["asm%d" % d] = ee, row_of[bb, ee], asm.reshape(-1)
                 host["dt%d" % d] = gap[bb, ee].astype(np.float32).view(np.int32)           # float bits ride in the int32 pack
-                meta.append((n_prev, n_src, ee, asm.reshape(-1)))
+                meta.append((n_prev, n_src, ee, asm.reshape(-1), row_of[bb, ee]))
             dd = S.upload_packed(host, dev, np.int32)
             wb.all_maps = []
-            for d, (n_prev, n_src, ee, asm) in enumerate(meta):
-                wb.all_maps.append(dict(n_prev=n_prev, ent=dd["ent%d" % d], idx=dd["idx%d" % d], dt=dd["dt%d" % d].view(torch.float32).view(-1, 1),
+            for d, (n_prev, n_src, ee, asm, idx_host) in enumerate(meta):
+                wb.all_maps.append(dict(n_prev=n_prev, ent=dd["ent%d" % d], idx=dd["idx%d" % d], dt=dd["dt%d" % d].view(torch.float32).view(-1, 1), idx_host=idx_host,
                                         asm=dd["asm%d" % d], ent_inv=TF.gather_inverse(ee, N, dev) if n_prev else None,
                                         asm_inv=TF.gather_inverse(asm, n_src if wb.n_inactive else n_out, dev)))
         return wb.all_maps
+
+    @staticmethod
+    def _pair_inverse(m, key, prev):
+        """Inverse of the pairs' history-row map m[key] over the rows of `prev` (a (window, entity) pair continues from its OWN
+        last history row, so the map is injective): the adjoint of the previous-state gather is then a gather
+        (TF.gru_step prev_inv).  Built on first use, cached on the batch's map; None if the rows repeat after all."""
+        c = m.setdefault("_inv", {})
+        k = (key, int(prev.shape[0]))
+        if k not in c:
+            c[k] = TF.injective_inverse(m[key + "_host"], prev.shape[0], prev.device)
+        return c[k]
 
     def _assemble_all(self, wb, out, isolated):
         """-> (B, N_ents, D): per window the active rows from `out` (concatenated target rows), the rest from the
@@ -518,11 +529,12 @@ class DynamicRGCN(TKG_Module):
             parts = [out] if d == 0 else []
             if m["n_prev"]:
                 if l1_rec:                                    # the pair's own first-layer state, then the second layer's input
-                    y1p = run_rnn(l1.rnn, TF.gather_rows(iso1, m["ent"], m["ent_inv"]), hist[0], m["dt"], l1.inv_temperature, l1.decay_spec(), m["idx"])
+                    y1p = run_rnn(l1.rnn, TF.gather_rows(iso1, m["ent"], m["ent_inv"]), hist[0], m["dt"], l1.inv_temperature, l1.decay_spec(), m["idx"],
+                                  self._pair_inverse(m, "idx", hist[0]))
                     xp = l2.conv_isolated(y1p)
                 else:
                     xp = TF.gather_rows(x, m["ent"], m["ent_inv"])
-                parts.append(run_rnn(rnn, xp, H, m["dt"], lam, dec, m["idx"]))
+                parts.append(run_rnn(rnn, xp, H, m["dt"], lam, dec, m["idx"], self._pair_inverse(m, "idx", H)))
             parts.append(self._zero_state_rows(rnn, x, l2))                      # GRU(x_e, 0): one row per entity, every window
             g = TF.gather_rows(torch.cat(parts, dim=0), m["asm"], m["asm_inv"])
             big = g if big is None else big + g

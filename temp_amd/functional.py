@@ -8,6 +8,7 @@ Each Function is one reference op with its hand-written backward:
   linear          nn.Linear without bias (q/k/v projections)   models/SARGCN.py:16-18,32-34
   history_attention   SARGCNLayer.attention over the active history rows   models/SARGCN.py:25-53
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -89,7 +90,7 @@ def rgcn_isolated(e, loop_w, bias, act=None, drop=None):
 
 class _GRUStepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, prev, dt, w_ih, w_hh, b_ih, b_hh, decay_w, decay_b, prev_idx, lam, variant):
+    def forward(ctx, x, prev, dt, w_ih, w_hh, b_ih, b_hh, decay_w, decay_b, prev_idx, lam, variant, prev_inv=None):
         be = get_backend()
         wb = None
         if decay_w is not None:
@@ -98,6 +99,7 @@ class _GRUStepFn(torch.autograd.Function):
         h_out, saved = be.gru_fwd(x, prev, prev_idx, dt, lam, wb, w_ih, w_hh, b_ih, b_hh, variant)
         ctx.save_for_backward(x, prev, dt, w_ih, w_hh, saved, wb if wb is not None else x.new_zeros(0))
         ctx.prev_idx, ctx.lam, ctx.variant, ctx.learn = prev_idx, lam, variant, wb is not None
+        ctx.prev_inv = prev_inv
         ctx.wshape = decay_w.shape if decay_w is not None else None
         ctx.bshape = decay_b.shape if decay_b is not None else None
         return h_out
@@ -110,20 +112,36 @@ class _GRUStepFn(torch.autograd.Function):
             x, prev, ctx.prev_idx, dt, ctx.lam, wb if ctx.learn else None, w_ih, w_hh, saved, d_h.contiguous(), ctx.variant)
         if ctx.prev_idx is None:
             d_prev = d_prev_rows
+        elif ctx.prev_inv is not None:                        # injective row map: the adjoint of the gather is a gather through the
+            d_prev = be.gather_rows(d_prev_rows, ctx.prev_inv)   # inverse map (-1 -> zero row): one pass, no atomics, no zero fill
         else:
             d_prev = torch.zeros_like(prev)
             be.scatter_add_rows(d_prev_rows, ctx.prev_idx, d_prev)
         d_dw = d_wb[0].reshape(ctx.wshape) if ctx.learn else None
         d_db = d_wb[1].reshape(ctx.bshape) if ctx.learn else None
-        return d_x, d_prev, None, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_dw, d_db, None, None, None
+        return d_x, d_prev, None, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_dw, d_db, None, None, None, None
 
 
-def gru_step(x, prev, dt, w_ih, w_hh, b_ih, b_hh, lam, decay=None, prev_idx=None, type1=False):
+def gru_step(x, prev, dt, w_ih, w_hh, b_ih, b_hh, lam, decay=None, prev_idx=None, type1=False, prev_inv=None):
     """h' = GRU(x, prev[prev_idx] * exp(-lam*dt))  (learnable decay when `decay` = (weight, bias)).
-    prev_idx: optional int32 tensor, -1 => zero previous state."""
+    prev_idx: optional int32 tensor, -1 => zero previous state.
+    prev_inv: optional int32 tensor [rows of prev], the inverse of an INJECTIVE prev_idx (prev_inv[prev_idx[i]] = i, -1 for rows
+    nobody continues from; injective_inverse()): the gradient of `prev` is then one gather instead of a zero fill + atomic scatter."""
     dw, db = decay if decay is not None else (None, None)
     return _GRUStepFn.apply(x, prev, dt, w_ih, w_hh, b_ih, b_hh, dw, db, prev_idx, float(lam),
-                            _lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH)
+                            _lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH, prev_inv)
+
+
+def injective_inverse(idx_np, n_rows, device):
+    """int32 device tensor inv [n_rows] with inv[idx[i]] = i (-1 where no i maps) for a host index list whose non-negative
+    entries are pairwise distinct, or None when they are not (the caller then keeps the scatter-add adjoint)."""
+    idx = np.asarray(idx_np).reshape(-1)
+    ok = idx >= 0
+    inv = np.full(int(n_rows), -1, dtype=np.int32)
+    inv[idx[ok]] = np.nonzero(ok)[0].astype(np.int32)
+    if int((inv >= 0).sum()) != int(ok.sum()):
+        return None
+    return _lib.to_device(inv, device)
 
 
 class _GatherRowsFn(torch.autograd.Function):

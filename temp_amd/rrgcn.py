@@ -10,16 +10,16 @@ from .gru_cell import GRUCell
 from .rgcn import RGCNLayer
 
 
-def run_rnn(rnn, x, prev, dt, lam, decay, prev_idx=None):
+def run_rnn(rnn, x, prev, dt, lam, decay, prev_idx=None, prev_inv=None):
     """`self.rnn(x[None], decayed_prev.expand(num_layers, ...))` -> hidden[-1]
     (models/RRGCN.py:84-85).  `rnn` is an nn.GRU used as a parameter container (never called) or
     the type-1 GRUCell; every stacked layer restarts from the same decayed previous state."""
     if isinstance(rnn, GRUCell):
-        return TF.gru_step(x, prev, dt, rnn.weight_ih, rnn.weight_hh, rnn.bias_ih, rnn.bias_hh, lam, decay, prev_idx, type1=True)
+        return TF.gru_step(x, prev, dt, rnn.weight_ih, rnn.weight_hh, rnn.bias_ih, rnn.bias_hh, lam, decay, prev_idx, type1=True, prev_inv=prev_inv)
     inp = x
     for k in range(rnn.num_layers):
         inp = TF.gru_step(inp, prev, dt, getattr(rnn, 'weight_ih_l%d' % k), getattr(rnn, 'weight_hh_l%d' % k),
-                          getattr(rnn, 'bias_ih_l%d' % k), getattr(rnn, 'bias_hh_l%d' % k), lam, decay, prev_idx)
+                          getattr(rnn, 'bias_ih_l%d' % k), getattr(rnn, 'bias_hh_l%d' % k), lam, decay, prev_idx, prev_inv=prev_inv)
     return inp
 
 
