@@ -378,6 +378,33 @@ def test_segment_sum_matches_scatter_and_is_deterministic(rows, n, d, hip_backen
     assert_close(a, want.float(), 1e-5, 1e-5 * max(1.0, (n / max(rows, 1)) ** 0.5), "segment sum")
 
 
+@pytest.mark.parametrize("rows,n,d,a,relu", [(4000, 48000, 200, 1.2, False), (7691, 48013, 200, 1.1, True), (300, 5000, 64, 1.5, True),
+                                             (1000, 2001, 256, 2.0, False)])
+def test_segment_sum_skewed_segments_gpu(rows, n, d, a, relu, hip_backend):
+    """Zipf-distributed gather indices (a hub segment of thousands of rows among short and EMPTY ones: the loss path's known-entity
+    gather): the fixed-piece kernels (2-32 rows per segment on average) against an fp64 index_add, with and without the folded
+    ReLU adjoint; bit-repeatable."""
+    from temp_amd import functional as TF
+    rng = np.random.default_rng(rows + n)
+    p = 1.0 / np.arange(1, rows + 1) ** a
+    idx = rng.permutation(rows)[rng.choice(rows, size=n, p=p / p.sum())].astype(np.int32)
+    idx[rng.integers(0, n, n // 50)] = -1
+    src = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+    table = torch.from_numpy(rng.standard_normal((rows, d)).astype(np.float32)).to(DEV).relu() if relu else None
+    seg_ptr, order = TF.gather_inverse(idx, rows, DEV)
+    cnt = np.bincount(idx[idx >= 0], minlength=rows)
+    assert cnt.max() > 40 * max(1.0, np.median(cnt)) and (cnt == 0).any()
+    run = lambda: hip_backend.segment_sum_rows(src, seg_ptr, order, rows, relu_of=table)
+    got = run()
+    assert torch.equal(got, run())
+    want = torch.zeros(rows, d, dtype=torch.float64)
+    keep = torch.from_numpy(idx >= 0)
+    want.index_add_(0, torch.from_numpy(idx.astype(np.int64))[keep], src.cpu().double()[keep])
+    if relu:
+        want = want * (table.cpu() > 0)
+    assert_close(got, want.float(), 1e-5, 2e-6 * float(cnt.max()) ** 0.5 + 1e-5, "skewed segment sum")
+
+
 @pytest.mark.parametrize("n_table,n,E,D,B,R2,bias,act", [(500, 3000, 40000, 200, 100, 40, False, 0), (7128, 900, 2500, 200, 100, 460, True, 1),
                                                           (64, 300, 900, 32, 8, 10, True, 1), (50, 20, 0, 16, 8, 6, False, 0)])
 def test_rgcn_table_layer_equals_gather_then_layer(n_table, n, E, D, B, R2, bias, act, hip_backend):
