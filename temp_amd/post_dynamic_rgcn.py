@@ -193,7 +193,9 @@ class _PostWindowMixin:
     def batched_ensemble_loss(self, wb, locs, recs, alls, samples, weights):
         """The ensemble loss of ALL windows as one fused node (functional.batched_ensemble_link_prediction), or None when the scorer
         / shapes need the per-window path.  locs / recs: per-window target rows of the two streams; alls: per window (all_loc,
-        all_rec); weights: per window (weight_subject (P, 1), weight_object (P, 1))."""
+        all_rec), or the pair of (B, N_ents, D) tensors of batched_all_embeds_post as they are (no per-window slices: every slice
+        is a zero-filled (B, N_ents, D) gradient and an addition in the backward); weights: per window (weight_subject (P, 1),
+        weight_object (P, 1))."""
         name = self.args.score_function
         D = self.embed_size
         if not (self.fused_loss and name in ("distmult", "complex") and self.num_ents % 4 == 0 and D % (8 if name == "complex" else 4) == 0):
@@ -209,7 +211,10 @@ class _PostWindowMixin:
         if inp is None:
             return torch.cat(locs).sum() * 0.0
         w = torch.cat([torch.cat([wo.reshape(-1, 1), ws.reshape(-1, 1)]) for (ws, wo), smp in zip(weights, samples) if smp[0].shape[0] > 0]).to(dev)
-        big_loc, big_rec = torch.cat([a for a, _ in alls], dim=0), torch.cat([a for _, a in alls], dim=0)
+        if isinstance(alls, tuple):
+            big_loc, big_rec = alls[0].reshape(-1, D), alls[1].reshape(-1, D)
+        else:
+            big_loc, big_rec = torch.cat([a for a, _ in alls], dim=0), torch.cat([a for _, a in alls], dim=0)
         return TF.batched_ensemble_link_prediction(torch.cat(locs), torch.cat(recs), self.rel_embeds, big_loc, big_rec, w, name, inp)
 
     def ensemble_loss(self, loc, rec, all_loc, all_rec, triplets, neg_tail, neg_head, w_subject, w_object):
@@ -360,15 +365,19 @@ class PostEnsembleDynamicRGCN(ImputeDynamicRGCN):
         if samples is None:
             samples = self.draw_samples(wb)
         loss = 0
-        alls, wts = [], []
+        wts = [ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), wb.rows[i][-1], g)
+               for i, g in enumerate(wb.graphs)]
         both = self.batched_all_embeds_post(wb, out, hist, DynamicRGCN)
-        for i, g in enumerate(wb.graphs):
-            t = wb.rows[i][-1]
-            alls.append((both[0][i], both[1][i]) if both is not None else self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
-            wts.append(ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), t, g))
-        fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)          # all windows' losses as one node
-        if fused is not None:
-            return fused
+        if both is not None:
+            fused = self.batched_ensemble_loss(wb, locs, recs, both, samples, wts)      # all windows' losses as one node, on the (B, N, D) tensors
+            if fused is not None:
+                return fused
+        alls = [(both[0][i], both[1][i]) if both is not None else self.get_all_embeds_Gt(locs[i], recs[i], g, wb.rows[i][-1], wb.plan, i, hist, wb.hist_loc)
+                for i, g in enumerate(wb.graphs)]
+        if both is None:
+            fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)
+            if fused is not None:
+                return fused
         for i, g in enumerate(wb.graphs):
             triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
             (a_loc, a_rec), (ws, wo) = alls[i], wts[i]
@@ -514,15 +523,19 @@ class PostEnsembleBiDynamicRGCN(ImputeBiDynamicRGCN):
         if samples is None:
             samples = self.draw_samples(wb)
         loss = 0
-        alls, wts = [], []
+        wts = [ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), wb.rows[i][-1], g)
+               for i, g in enumerate(wb.graphs)]
         both = self.batched_all_embeds_post(wb, out, hist, BiDynamicRGCN)
-        for i, g in enumerate(wb.graphs):
-            t = wb.rows[i][-1]
-            alls.append((both[0][i], both[1][i]) if both is not None else self.get_all_embeds_Gt(locs[i], recs[i], g, t, wb.plan, i, hist, wb.hist_loc))
-            wts.append(ensemble_weights[i] if ensemble_weights is not None else self.calc_ensemble_ratio(samples[i][0].to(dev), t, g))
-        fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)          # all windows' losses as one node
-        if fused is not None:
-            return fused
+        if both is not None:
+            fused = self.batched_ensemble_loss(wb, locs, recs, both, samples, wts)      # all windows' losses as one node, on the (B, N, D) tensors
+            if fused is not None:
+                return fused
+        alls = [(both[0][i], both[1][i]) if both is not None else self.get_all_embeds_Gt(locs[i], recs[i], g, wb.rows[i][-1], wb.plan, i, hist, wb.hist_loc)
+                for i, g in enumerate(wb.graphs)]
+        if both is None:
+            fused = self.batched_ensemble_loss(wb, locs, recs, alls, samples, wts)
+            if fused is not None:
+                return fused
         for i, g in enumerate(wb.graphs):
             triplets, neg_tail, neg_head = (x.to(dev) for x in samples[i])
             (a_loc, a_rec), (ws, wo) = alls[i], wts[i]
