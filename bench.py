@@ -699,6 +699,8 @@ def hbm_window(a, device, lib):
     model = build_model(w, device)
     model.sample_rng = np.random.default_rng(2)
     t0 = time.perf_counter()
+    from temp_amd import snapshot as S_
+    S_.prepack_parallel(list(snaps.values()), 2 * R, threads=8)       # (the 29 snapshots' sorted views: host work, several at a time)
     wb = model.prepare([L - 1], L, train=True)
     torch.cuda.synchronize()
     prep_s = time.perf_counter() - t0

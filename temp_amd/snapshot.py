@@ -170,8 +170,18 @@ class Snapshot:
         return dg
 
     def stored_pack(self, n_rel_rows):
-        """(packed, sizes, n_partial, rel_chunks) when the packed views were precomputed (StoredSnapshot), else None."""
-        return None
+        """(packed, sizes, n_partial, rel_chunks) when the packed views were precomputed (StoredSnapshot, or prepack()), else None."""
+        return self.__dict__.get("_pack", {}).pop(int(n_rel_rows), None)
+
+    def prepack(self, n_rel_rows):
+        """Build the packed views on the host NOW, outside the creation lock (device_views then only uploads): lets several
+        snapshots be packed by several threads -- the pack is one call into the host planner library, which runs without the
+        interpreter lock (prepack_parallel)."""
+        if self._dev or self._views.get(int(n_rel_rows)) is not None or type(self).stored_pack is not Snapshot.stored_pack:
+            return
+        from . import _hostlib
+        self.__dict__.setdefault("_pack", {})[int(n_rel_rows)] = _hostlib.snapshot_pack(self.n, self.src, self.dst, self.rel, self.nnorm, n_rel_rows,
+                                                                                      _lib.CHUNK, _lib.CHUNK_REL)
 
     def adopt_device_pack(self, buf, device, n_rel_rows):
         """Hand this snapshot a device-resident copy of its packed views (a slice of a whole-store upload)."""
@@ -794,3 +804,16 @@ class _DeviceGraph:
 
     def ref(self):
         return ctypes.byref(self.c)
+
+
+def prepack_parallel(snapshots, n_rel_rows, threads=8):
+    """Snapshot.prepack of many (large) snapshots on a pool of threads: first use of an HBM-sized window otherwise packs its
+    29 snapshots one after the other under the creation lock."""
+    from concurrent.futures import ThreadPoolExecutor
+    snaps = [g for g in snapshots if g is not None]
+    if len(snaps) < 2 or threads < 2:
+        for g in snaps:
+            g.prepack(n_rel_rows)
+        return
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda g: g.prepack(n_rel_rows), snaps))
