@@ -157,13 +157,17 @@ class SelfAttentionRGCN(DynamicRGCN):
         y1 = l1.conv_table(wb.g_all, self.ent_embeds, wb.ids_all, wb.ids_inv)
         y2 = l2.conv(wb.g_all, y1)
         s = y2 + TF.gather_rows(l2.time_embed, wb.time_rows, wb.time_inv)
-        kv2 = l2.project_kv(s[:R])
-        second = l2.attend(s[R:], kv2, wb.idx_tgt, wb.time_diff, wb.inv_tgt)
+        # (split, not two slices: the backward of a split is ONE concatenation of the two gradients; two slices are two zero-filled
+        # full-size gradients, two copies and an addition)
+        s_hist, s_tgt = s.split([R, s.shape[0] - R])
+        kv2 = l2.project_kv(s_hist)
+        second = l2.attend(s_tgt, kv2, wb.idx_tgt, wb.time_diff, wb.inv_tgt)
         if enc.rec_only_last_layer:
             return second, (None, kv2)
         f = y1 + TF.gather_rows(l1.time_embed, wb.time_rows, wb.time_inv)
-        kv1 = l1.project_kv(f[:R])
-        first = l1.attend(f[R:], kv1, wb.idx_tgt, wb.time_diff, wb.inv_tgt)
+        f_hist, f_tgt = f.split([R, f.shape[0] - R])
+        kv1 = l1.project_kv(f_hist)
+        first = l1.attend(f_tgt, kv1, wb.idx_tgt, wb.time_diff, wb.inv_tgt)
         return jk_max(first, second), (kv1, kv2)
 
     def all_embeds_batched(self, wb, out, tables):
