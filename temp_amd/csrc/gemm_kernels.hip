@@ -776,6 +776,80 @@ __global__ void __launch_bounds__(256) k_gather_ce_fwd_cnt(int C, int N, const f
   }
 }
 
+// The same for SHORT score rows (N <= 1024: GDELT's 500 entities under 48 000 loss rows): one WAVE per row, four rows per
+// workgroup -- no workgroup barriers, no cross-wave reductions; a wave's LDS operations complete in issue order, so its zero fill,
+// its integer atomics and its reads of the counters need no barrier between them.
+__device__ __forceinline__ float wave_reduce_f(float v, bool is_max) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int* gather_ce_wave_counts(int* cnt_all, int N, int C, const int32_t* __restrict__ crow) {
+  const int lane = threadIdx.x & 63;
+  int* cnt = cnt_all + (threadIdx.x >> 6) * N;
+  for (int i = lane; i < N; i += 64) cnt[i] = 0;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int k = lane; k < C; k += 64) atomicAdd(&cnt[crow[k]], 1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return cnt;
+}
+
+__global__ void __launch_bounds__(256) k_gather_ce_fwd_cnt_w(int P, int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
+                                                             float* __restrict__ loss_rows, float* __restrict__ lse_rows) {
+  extern __shared__ int cnt_all[];
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= P) return;
+  const float* srow = scores + (size_t)p * N;
+  const int32_t* crow = cand + (size_t)p * C;
+  const int* cnt = gather_ce_wave_counts(cnt_all, N, C, crow);
+  float mx = -INFINITY;
+  float sv[16];                                                           // the row's scores of this lane (N <= 1024): read once
+  int cv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = lane + 64 * u;
+    cv[u] = i < N ? cnt[i] : 0;
+    sv[u] = i < N ? srow[i] : 0.f;
+    if (cv[u]) mx = fmaxf(mx, sv[u]);
+  }
+  mx = wave_reduce_f(mx, true);
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (cv[u]) sum += (float)cv[u] * expf(sv[u] - mx);
+  sum = wave_reduce_f(sum, false);
+  if (lane == 0) {
+    const float lse = mx + logf(sum);
+    lse_rows[p] = lse;
+    loss_rows[p] = lse - srow[crow[0]];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gather_ce_bwd_w(int P, int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
+                                                         const float* __restrict__ lse_rows, const float* __restrict__ scale_ptr, float inv_rows,
+                                                         const float* __restrict__ row_scale, float* __restrict__ d_scores) {
+  extern __shared__ int cnt_all[];
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= P) return;
+  const float* srow = scores + (size_t)p * N;
+  const int32_t* crow = cand + (size_t)p * C;
+  const int* cnt = gather_ce_wave_counts(cnt_all, N, C, crow);
+  const float lse = lse_rows[p];
+  const float scale = scale_ptr[0] * (row_scale ? row_scale[p] : inv_rows);
+  const int truth = crow[0];
+  float* drow = d_scores + (size_t)p * N;
+  for (int i = lane; i < N; i += 64) {
+    const int c = cnt[i];
+    float g = c ? (float)c * expf(srow[i] - lse) : 0.f;
+    if (i == truth) g -= 1.f;
+    drow[i] = g * scale;
+  }
+}
+
 // d_scores[p, e] = scale * (cnt[e] * softmax(e) - [e == cand[p,0]])   (row written once, coalesced; multiplicities counted
 // with integer LDS atomics, so the result does not depend on the order the candidates are visited in)
 __global__ void __launch_bounds__(256) k_gather_ce_bwd(int C, int N, const float* __restrict__ scores, const int32_t* __restrict__ cand,
@@ -1711,7 +1785,9 @@ int temp_linear_tn_multi(int count, const TempLinearProblem* probs, int Ka, int 
 int temp_gather_ce_fwd(int P, int C, int N, const float* scores, const int32_t* cand, float* loss_rows, float* lse_rows, void* stream) {
   if (P < 0 || C <= 0 || N <= 0 || (P > 0 && (!scores || !cand || !loss_rows || !lse_rows))) return TEMP_E_BADARG;
   if (P == 0) return TEMP_OK;
-  if (2 * (long long)C >= N && (size_t)N * sizeof(int) <= 64 * 1024)
+  if (2 * (long long)C >= N && N <= 1024)
+    TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_fwd_cnt_w, dim3(ceil_div(P, 4)), dim3(256), (size_t)4 * N * sizeof(int), (hipStream_t)stream, P, C, N, scores, cand, loss_rows, lse_rows);
+  else if (2 * (long long)C >= N && (size_t)N * sizeof(int) <= 64 * 1024)
     TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_fwd_cnt, dim3(P), dim3(256), (size_t)N * sizeof(int), (hipStream_t)stream, C, N, scores, cand, loss_rows, lse_rows);
   else
     TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_fwd, dim3(P), dim3(256), 0, (hipStream_t)stream, C, N, scores, cand, loss_rows, lse_rows);
@@ -1723,6 +1799,11 @@ int temp_gather_ce_bwd(int P, int C, int N, const float* scores, const int32_t* 
   if (P < 0 || C <= 0 || N <= 0 || !scale || (P > 0 && (!scores || !cand || !lse_rows || !d_scores))) return TEMP_E_BADARG;
   if ((size_t)N * sizeof(float) > 160 * 1024 - 1024) return TEMP_E_UNSUPPORTED;
   if (P == 0) return TEMP_OK;
+  if (N <= 1024) {
+    TEMP_LAUNCH(K_GATHER_CE, k_gather_ce_bwd_w, dim3(ceil_div(P, 4)), dim3(256), (size_t)4 * N * sizeof(int), (hipStream_t)stream, P, C, N, scores, cand, lse_rows, scale,
+                inv_rows, row_scale, d_scores);
+    return launch_status();
+  }
   const size_t lds = (size_t)N * sizeof(float);
   if (lds > 65536) {
     if (hipFuncSetAttribute((const void*)k_gather_ce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEMP_E_LAUNCH;
