@@ -112,3 +112,32 @@ def test_self_loop_dropout_semantics_and_gradients():
     (prop + layer.h_bias.detach() + torch.mm(h2, lw2) * m).backward(gy)
     assert torch.allclose(h.grad, h2.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(layer.loop_weight.grad, lw2.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_gru_step_injective_previous_state_adjoint():
+    """TF.gru_step with prev_inv (the inverse of an injective previous-state map): the gradient of `prev` is one gather through the
+    inverse instead of a zero fill + scatter-add -- same values; a map with a repeated row has no inverse (None)."""
+    from temp_amd import functional as TF
+    rng = np.random.default_rng(3)
+    n, n_prev, d = 40, 90, 16
+    idx = rng.permutation(n_prev)[:n].astype(np.int64)
+    idx[rng.integers(0, n, 6)] = -1                                   # rows without a previous state
+    assert TF.injective_inverse(np.array([3, 5, 3]), 8, "cpu") is None
+    inv = TF.injective_inverse(idx, n_prev, "cpu")
+    ok = idx >= 0
+    assert inv.dtype == torch.int32 and int((inv >= 0).sum()) == int(ok.sum())
+    assert np.array_equal(idx[inv.numpy()[idx[ok]]], idx[ok])
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    w = [f(3 * d, d) * 0.3, f(3 * d, d) * 0.3, f(3 * d) * 0.1, f(3 * d) * 0.1]
+    x, prev, dt, up = f(n, d), f(n_prev, d), torch.from_numpy(rng.integers(1, 5, (n, 1)).astype(np.float32)), f(n, d)
+    pidx = torch.from_numpy(idx.astype(np.int32))
+    grads = []
+    for pinv in (None, inv):
+        xs, ps = x.clone().requires_grad_(True), prev.clone().requires_grad_(True)
+        h = TF.gru_step(xs, ps, dt, *w, 0.1, None, pidx, prev_inv=pinv)
+        h.backward(up)
+        grads.append((h.detach(), xs.grad, ps.grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    untouched = np.setdiff1d(np.arange(n_prev), idx[ok])
+    assert float(grads[1][2][untouched].abs().max()) == 0.0

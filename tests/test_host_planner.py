@@ -158,3 +158,24 @@ def test_union_plan_matches_numpy(M, R, piece):
     assert (int(sm[0]), int(sm[1]), int(sm[2])) == (info["n_desc"], info["n_pieces"], info["n_fix"]) and int(sm[3]) == int(info["out_base"][-1])
     assert np.array_equal(sm[4:32], info["out_base"]) and np.array_equal(sm[35:62], info["totals"])
     assert tuple(int(x) for x in sm[65:68]) == info["partial"]
+
+
+def test_prepacked_snapshot_views_equal_lazy_ones():
+    """Snapshot.prepack (the packed views built ahead of first use, outside the creation lock; prepack_parallel for many) hands
+    device_views the same buffer the lazy path builds."""
+    import torch
+    from temp_amd import snapshot as S
+    rng = np.random.default_rng(9)
+    snaps = []
+    for k in range(5):
+        n, E, R2 = 300 + 17 * k, 4000 + 100 * k, 40
+        snaps.append((n, rng.integers(0, n, E), rng.integers(0, n, E), rng.integers(0, R2, E), rng.permutation(10 * n)[:n]))
+    lazy = [S.Snapshot(*a) for a in snaps]
+    early = [S.Snapshot(*a) for a in snaps]
+    S.prepack_parallel(early, 40, threads=3)
+    assert all(40 in g.__dict__.get("_pack", {}) for g in early)
+    for a, b in zip(lazy, early):
+        da, db = a.device_views("cpu", 40), b.device_views("cpu", 40)
+        assert torch.equal(da["_buf"], db["_buf"]) and not b.__dict__["_pack"]
+    early[0].prepack(40)                                              # already resident: nothing to do
+    assert not early[0].__dict__["_pack"]
