@@ -112,11 +112,15 @@ class BiDynamicRGCN(DynamicRGCN):
             y2 = TF.gather_rows(y2, wb.visit_rows, getattr(wb, "visit_inv", None))
         wb.last_x = y2
 
+        # every position's rows of y2 (forward steps, backward steps, target rows) from ONE split (TF.row_spans)
+        order = sorted([(st.row0, st.n_rows) for st in list(plan_f.steps) + list(plan_b.steps)] + [(tf.row0, tf.n_rows)])
+        x_of = dict(zip(order, TF.row_spans(y2, order)))
+
         def chain(plan, rnn):
             H = None
             for st in plan.steps:
                 _, pidx, dt = st.tensors(dev)
-                x = y2[st.row0:st.row0 + st.n_rows]
+                x = x_of[(st.row0, st.n_rows)]
                 prev = H if H is not None else x.new_zeros(1, x.shape[1])
                 H = run_rnn(rnn, x, prev, dt, lam, dec, pidx)
                 if enc.use_time_embedding:
@@ -125,7 +129,7 @@ class BiDynamicRGCN(DynamicRGCN):
 
         Hf = chain(plan_f, l2.forward_rnn)
         Hb = chain(plan_b, l2.backward_rnn)
-        x = y2[tf.row0:tf.row0 + tf.n_rows]
+        x = x_of[(tf.row0, tf.n_rows)]
         _, pf, dtf = tf.tensors(dev)
         _, pb, dtb = tb.tensors(dev)
         zero = x.new_zeros(1, x.shape[1])

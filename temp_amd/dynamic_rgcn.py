@@ -214,9 +214,8 @@ class DynamicRGCN(TKG_Module):
             hist = got[1] if wb.hist_inst >= 0 else None
             return got[0], (hist, hist)
         H, hist = None, None
-        for st in wb.steps:
+        for st, x in zip(wb.steps, TF.row_spans(y2, [(st.row0, st.n_rows) for st in wb.steps])):
             _, pidx, dt = st.tensors(dev)
-            x = y2[st.row0:st.row0 + st.n_rows]
             prev = H if H is not None else x.new_zeros(1, x.shape[1])
             H = run_rnn(l2.rnn, x, prev, dt, l2.inv_temperature, l2.decay_spec(), pidx)
             if enc.use_time_embedding:

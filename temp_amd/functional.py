@@ -185,6 +185,20 @@ def gather_rows(table, idx, inverse=None, relu_table=False):
     return _GatherRowsFn.apply(table, idx, inverse, bool(relu_table))
 
 
+def row_spans(y, spans):
+    """Row ranges [(row0, n), ...] of `y` for several consumers.  When the ranges tile y in order they come from ONE split -- its
+    adjoint is one concatenation of the consumers' gradients; separate slices each cost a zero-filled full-size gradient, a copy
+    and an addition in the backward (the per-position loops hand every position its rows of one layer output)."""
+    off = 0
+    for r0, n in spans:
+        if r0 != off:
+            return [y[r0:r0 + n] for r0, n in spans]
+        off += n
+    if off != y.shape[0]:
+        return [y[r0:r0 + n] for r0, n in spans]
+    return list(y.split([n for _, n in spans]))
+
+
 def gather_inverse(idx_np, n_rows, device):
     """(seg_ptr int32 [n_rows+1], order int32) grouping the positions of a gather index list by table row
     (positions of negative entries are left out): a stable counting sort in the host planner library
