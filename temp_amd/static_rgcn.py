@@ -41,7 +41,8 @@ class StaticRGCN(TKG_Module):
                 graphs.append(g.edge_subgraph(idx))
         bg = S.batch(graphs)
         ids = torch.from_numpy(bg.gids.astype(np.int32)).to(self.ent_embeds.device)
-        bg.ndata['h'] = TF.gather_rows(self.ent_embeds, ids)
+        # (static ids: the gather's adjoint is a deterministic segment sum, not an atomic scatter -- entities repeat across graphs)
+        bg.ndata['h'] = TF.gather_rows(self.ent_embeds, ids, TF.gather_inverse(bg.gids, self.num_ents, self.ent_embeds.device))
         sizes = [g.n for g in graph_train_list]
         out = self.ent_encoder(bg, [int(t) for t in t_list], sizes)
         self._last_rows = out.ndata['h']                      # the unsplit (sum n_b, D) rows (the fused loss consumes them whole)
@@ -142,6 +143,7 @@ class StaticRGCN(TKG_Module):
         wb.bg = S.batch(graphs)
         wb.bg.device_graph(dev, 2 * self.num_rels)
         wb.ids = torch.from_numpy(wb.bg.gids.astype(np.int32)).to(dev)
+        wb.ids_inv = TF.gather_inverse(wb.bg.gids, self.num_ents, dev)      # deterministic adjoint of the embedding gather
         wb.sizes = [g.n for g in wb.g_list]
         wb.n_edge_visits = int(sum(g.number_of_edges() for g in graphs))
         wb.fused = self._fused_plan(wb.ts, wb.g_list) if self._fused_loss_ok() else None
@@ -149,7 +151,7 @@ class StaticRGCN(TKG_Module):
 
     def run(self, wb):
         """Device work of the encoder on a prepared batch -> the (sum n_b, D) target rows."""
-        wb.bg.ndata['h'] = TF.gather_rows(self.ent_embeds, wb.ids)
+        wb.bg.ndata['h'] = TF.gather_rows(self.ent_embeds, wb.ids, wb.ids_inv)
         out = self.ent_encoder(wb.bg, wb.ts, wb.sizes)
         self._last_rows = out.ndata['h']
         return out.ndata['h']
