@@ -63,8 +63,9 @@ const char* temp_error_string(int code);
  * when the library is loaded, overrides the default (kept for runs that cannot call into the library first).
  * temp_set_option returns the previous value, or -1 for an unknown key; temp_get_option -1 for an unknown key. */
 enum {
-  TEMP_OPT_MFMA_BF16X3 = 0, /* 1: large fp32 products as six bf16 MFMA products of an exact 3-way operand split (gemm_bx.hpp)
-                               0: every product on the fp32 MFMA kernels                   [TEMP_MFMA=f32 -> 0]       default 1 */
+  TEMP_OPT_MFMA_BF16X3 = 0, /* 1: large fp32 products on the 16-bit matrix pipes through an operand split with fp32-equivalent accuracy
+                               (which split: TEMP_OPT_MFMA_F16X2);  0: every product on the fp32 MFMA kernels
+                                                                                           [TEMP_MFMA=f32 -> 0]       default 1 */
   TEMP_OPT_TN_SPLIT = 1,    /* 1: weight-gradient blocks of 4 row tiles x (4+3) column tiles  [TEMP_TN_SPLIT=0 -> 0]  default 1 */
   TEMP_OPT_RGCN_SCALAR = 2, /* 1: wide-row edge kernels keep per-edge quantities in SGPRs     [TEMP_RGCN_SCALAR=0 -> 0] default 1 */
   TEMP_OPT_GEMM_STREAM = 3, /* 1: force the streaming row-panel GEMM instead of weights-resident [TEMP_GEMM_STREAM=1 -> 1] default 0 */
@@ -82,7 +83,11 @@ enum {
   TEMP_OPT_GEMM_RESIDENT = 8, /* 1: large fp32 products with K <= 208 keep the packed weights of four column tiles resident in LDS and
                                stream row panels through them (gemm_bxr.hpp); 0: one row tile per block, weights staged per slab
                                                                                                [TEMP_GEMM_RESIDENT=0 -> 0] default 1 */
-  TEMP_OPT_COUNT = 9
+  TEMP_OPT_MFMA_F16X2 = 9,  /* (with TEMP_OPT_MFMA_BF16X3 = 1)  1: where a kernel exists, three f16 MFMA products of the scaled two-way
+                               split (split_f16.hpp: per-row / per-column power-of-two scales, residual <= one fp32 rounding);
+                               0: six bf16 MFMA products of the exact three-way split everywhere (gemm_bx.hpp)
+                                                                                           [TEMP_MFMA=bf16x3 -> 0]    default 1 */
+  TEMP_OPT_COUNT = 10
 };
 int temp_set_option(int key, int value);
 int temp_get_option(int key);
@@ -381,6 +386,14 @@ size_t temp_gru_grads_g4_workspace(int count, const int* ns, int d);
 int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
                       const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* Round 6: the same with the keys temp_gru_chain_bwd_g4_keys hands out (HOST arrays of `count` device pointers; NULL arrays or
+ * TEMP_OPT_MFMA_F16X2 = 0: exactly temp_gru_grads_g4).  g4_col_keys[i]: [4d] keys bounding the column magnitudes of g4s[i];
+ * g4_row_keys[i]: [ns[i]] keys of the rows' max |[dr dz dn_i]|.  With them the products run as three f16 MFMA products of the
+ * scaled two-way split (split_f16.hpp) instead of six bf16 products; hdecs must be decayed GRU states (|hdec| < 4: they are split
+ * with the constant scale 2^14).  Same workspace. */
+int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
+                           const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, const uint32_t* const* g4_row_keys,
+                           const uint32_t* const* g4_col_keys, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Persistent window chain: ALL positions of the recurrence in ONE launch per direction of time.
@@ -436,6 +449,17 @@ int temp_gru_chain_bwd(const TempGruChain* c, const float* saved, int n_up, cons
  * repeated dgi: 1 600 bytes per row less to write at d = 200).  Bit-identical values.  Consumed by temp_gru_grads_g4. */
 int temp_gru_chain_bwd_g4(const TempGruChain* c, const float* saved, int n_up, const float* const* up /* HOST array of device pointers */,
                           float* g4, void* stream);
+/* Round 6: the same, also handing out what the consumers of g4 need to split it for the f16 pipe (temp_gru_grads_g4_keys):
+ *   row_keys [N_total]    : per row the largest magnitude of [dr dz dn_i] as an unsigned key (the fp32 bits with the sign cleared;
+ *                           integer order = magnitude order)
+ *   col_keys [n_rnn + n_panels][4d] : rows 0 .. n_rnn - 1 = per GRU and column of g4 a key that BOUNDS the column's largest magnitude
+ *                           (integer maxima: order-independent, bit-repeatable); the n_panels rows behind them are scratch (every
+ *                           panel's own maxima, reduced by a second small launch); no initialisation needed
+ * temp_gru_chain_keys_supported(d): 1 when the chain kernels of this width produce keys (f16 arithmetic selected and its LDS
+ * images fit); otherwise this call returns TEMP_E_UNSUPPORTED and the caller uses temp_gru_chain_bwd_g4. */
+int temp_gru_chain_keys_supported(int d);
+int temp_gru_chain_bwd_g4_keys(const TempGruChain* c, const float* saved, int n_up, const float* const* up, float* g4,
+                               uint32_t* row_keys, uint32_t* col_keys, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row gather / scatter helpers of the window loop

@@ -39,7 +39,7 @@ class TempGraph(ctypes.Structure):
 
 
 ABI_VERSION = 2            # include/temp_amd.h: TEMP_ABI_VERSION (2: TempGraph.members, chain pipeline option)
-OPT_MFMA_BF16X3, OPT_TN_SPLIT, OPT_RGCN_SCALAR, OPT_GEMM_STREAM, OPT_GRU_STREAM, OPT_RGCN_TILE, OPT_DEBUG, OPT_OVERLAP, OPT_GEMM_RESIDENT = range(9)
+OPT_MFMA_BF16X3, OPT_TN_SPLIT, OPT_RGCN_SCALAR, OPT_GEMM_STREAM, OPT_GRU_STREAM, OPT_RGCN_TILE, OPT_DEBUG, OPT_OVERLAP, OPT_GEMM_RESIDENT, OPT_MFMA_F16X2 = range(10)
 
 
 class TempGruCellFwd(ctypes.Structure):
@@ -140,6 +140,9 @@ SYMBOLS = {
     "temp_gru_chain_fwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, c_vp, c_vp, c_vp]),
     "temp_gru_chain_bwd": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp]),
     "temp_gru_chain_bwd_g4": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp]),
+    "temp_gru_chain_keys_supported": (_I, [_I]),
+    "temp_gru_chain_bwd_g4_keys": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp]),
+    "temp_gru_grads_g4_keys": (_I, [_I, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "temp_gru_grads_g4_workspace": (ctypes.c_size_t, [_I, c_vp, _I]),
     "temp_gru_grads_g4": (_I, [_I, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),

@@ -378,13 +378,26 @@ class HipBackend:
         rc = self.lib.temp_gru_chain_bwd(ctypes.byref(c), _ptr(saved_all), len(ups), arr, _ptr(dgi), _ptr(dgh), _stream())
         _lib.check(rc, "temp_gru_chain_bwd")
 
-    def gru_chain_bwd_g4(self, tabs, saved_all, ups, lam, variant, packs, b_hhs, g4):
+    def gru_chain_keys_supported(self, d):
+        """True when the chain backward of this width hands out the row / column keys of g4 (f16 two-way split selected)."""
+        return bool(self.lib.temp_gru_chain_keys_supported(int(d)))
+
+    def gru_chain_bwd_g4(self, tabs, saved_all, ups, lam, variant, packs, b_hhs, g4, keys=None):
         """The chain backward with the gate gradients written once: g4 [N, 4d] = [dr | dz | dn_i | dn_h] (include/temp_amd.h:
-        temp_gru_chain_bwd_g4; nn.GRU gate layout)."""
+        temp_gru_chain_bwd_g4; nn.GRU gate layout).  keys = (row_keys int32 [N], col_keys int32 [n_rnn + n_panels, 4d]; rows 0 .. n_rnn - 1 are the result): also the
+        magnitude keys the consumers of g4 split it with (temp_gru_chain_bwd_g4_keys)."""
         d = saved_all.shape[2]
         c, keep = self._chain_desc(tabs, d, variant, lam, saved_all.shape[1] * d, packs, b_hhs)
         ups = [_f32(u, "upstream") if u is not None else None for u in ups]
         arr = (ctypes.c_void_p * max(len(ups), 1))(*[u.data_ptr() if u is not None else None for u in ups])
+        if keys is not None:
+            row_keys, col_keys = keys
+            assert row_keys.dtype == torch.int32 and col_keys.dtype == torch.int32 and col_keys.is_contiguous()
+            assert row_keys.numel() == saved_all.shape[1] and col_keys.numel() == (len(packs) + tabs["n_panels"]) * 4 * d
+            rc = self.lib.temp_gru_chain_bwd_g4_keys(ctypes.byref(c), _ptr(saved_all), len(ups), arr, _ptr(g4), _ptr(row_keys), _ptr(col_keys),
+                                                     _stream())
+            _lib.check(rc, "temp_gru_chain_bwd_g4_keys")
+            return
         rc = self.lib.temp_gru_chain_bwd_g4(ctypes.byref(c), _ptr(saved_all), len(ups), arr, _ptr(g4), _stream())
         _lib.check(rc, "temp_gru_chain_bwd_g4")
 
@@ -395,9 +408,10 @@ class HipBackend:
             return False
         return self.lib.temp_gru_grads_g4_workspace(k, (ctypes.c_int * k)(*[int(n) for n in ns]), int(d)) > 0
 
-    def gru_grads_g4(self, xs, hdecs, g4s, w_ihs, d_xs):
+    def gru_grads_g4(self, xs, hdecs, g4s, w_ihs, d_xs, row_keys=None, col_keys=None):
         """Weight / bias gradients and d_x of several GRUs of one width from their gate-gradient matrices (include/temp_amd.h:
-        temp_gru_grads_g4) -> [(d_w_ih, d_w_hh, d_b_ih, d_b_hh)] per GRU."""
+        temp_gru_grads_g4) -> [(d_w_ih, d_w_hh, d_b_ih, d_b_hh)] per GRU.  row_keys / col_keys: per GRU the int32 key tensors of
+        gru_chain_bwd_g4(keys=...) ([n_i] and [4d]); with them the products run on the f16 pipe (temp_gru_grads_g4_keys)."""
         k = len(xs)
         d = xs[0].shape[1]
         dev = xs[0].device
@@ -413,6 +427,14 @@ class HipBackend:
         d_w = torch.empty(2 * k, 3 * d, d, dtype=torch.float32, device=dev)
         d_b = torch.empty(2 * k, 3 * d, dtype=torch.float32, device=dev)
         ws = self._ws(nb, dev)
+        if row_keys is not None and col_keys is not None:
+            for rk, ck, x in zip(row_keys, col_keys, xs):
+                assert rk.dtype == torch.int32 and ck.dtype == torch.int32 and rk.is_contiguous() and ck.is_contiguous()
+                assert rk.numel() == x.shape[0] and ck.numel() == 4 * d
+            rc = self.lib.temp_gru_grads_g4_keys(k, ns, d, arr(keep[0]), arr(keep[1]), arr(g4s), arr(keep[2]), dx, _ptr(d_w), _ptr(d_b),
+                                                 arr(row_keys), arr(col_keys), _ptr(ws), ws.numel(), _stream())
+            _lib.check(rc, "temp_gru_grads_g4_keys")
+            return [(d_w[2 * i], d_w[2 * i + 1], d_b[2 * i], d_b[2 * i + 1]) for i in range(k)]
         rc = self.lib.temp_gru_grads_g4(k, ns, d, arr(keep[0]), arr(keep[1]), arr(g4s), arr(keep[2]), dx, _ptr(d_w), _ptr(d_b), _ptr(ws),
                                         ws.numel(), _stream())
         _lib.check(rc, "temp_gru_grads_g4")

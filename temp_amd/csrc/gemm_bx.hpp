@@ -578,6 +578,9 @@ __global__ void __launch_bounds__(BX_THREADS, (G <= 4 ? 3 : 2)) k_gemm_bxp(Panel
 
 // temp_set_option(TEMP_OPT_MFMA_BF16X3, 0) keeps every product on the fp32 MFMA kernels (A/B runs, bit-comparison against round 1)
 inline bool bx_enabled() { return option(TEMP_OPT_MFMA_BF16X3) != 0; }
+// ... and among the split kernels, temp_set_option(TEMP_OPT_MFMA_F16X2, 0) keeps the six-product bf16 split where a three-product
+// f16 kernel exists (split_f16.hpp)
+inline bool hx_enabled() { return bx_enabled() && option(TEMP_OPT_MFMA_F16X2) != 0; }
 
 // Scratch slot for the packed weights of one launch on `st` (gemm_kernels.hip): nullptr when `bytes` exceed a slot or every
 // slot belongs to another stream -- the caller then uses the kernel that splits B itself.

@@ -1165,8 +1165,10 @@ static std::atomic<int> g_options[TEMP_OPT_COUNT];
 static const bool g_options_init = [] {
   g_options[TEMP_OPT_MFMA_BF16X3] = 1; g_options[TEMP_OPT_TN_SPLIT] = 1; g_options[TEMP_OPT_RGCN_SCALAR] = 1;
   g_options[TEMP_OPT_GEMM_STREAM] = 0; g_options[TEMP_OPT_GRU_STREAM] = 0; g_options[TEMP_OPT_RGCN_TILE] = 1; g_options[TEMP_OPT_DEBUG] = 0; g_options[TEMP_OPT_OVERLAP] = 1; g_options[TEMP_OPT_GEMM_RESIDENT] = 1;
+  g_options[TEMP_OPT_MFMA_F16X2] = 1;
   const char* e;
-  if ((e = getenv("TEMP_MFMA")) && e[0] == 'f') g_options[TEMP_OPT_MFMA_BF16X3] = 0;
+  if ((e = getenv("TEMP_MFMA")) && e[0] == 'f' && e[1] == '3') g_options[TEMP_OPT_MFMA_BF16X3] = 0;      // f32
+  if ((e = getenv("TEMP_MFMA")) && e[0] == 'b') g_options[TEMP_OPT_MFMA_F16X2] = 0;                       // bf16x3
   if ((e = getenv("TEMP_TN_SPLIT")) && e[0] == '0') g_options[TEMP_OPT_TN_SPLIT] = 0;
   if ((e = getenv("TEMP_RGCN_SCALAR")) && e[0] == '0') g_options[TEMP_OPT_RGCN_SCALAR] = 0;
   if ((e = getenv("TEMP_GEMM_STREAM")) && e[0] == '1') g_options[TEMP_OPT_GEMM_STREAM] = 1;

@@ -25,9 +25,10 @@ namespace temp {
 #define CH_ROW_MASK (TEMP_CHAIN_HAS_PREV - 1)
 #define CH_LDS_LIMIT (160 * 1024)
 
-struct ChainRnn { const float4* wf; const float4* wb; const float* b_hh; };
+struct ChainRnn { const float4* wf; const float4* wb; const float* b_hh; const unsigned* kf; const unsigned* kb; };   // kf / kb: column keys of the f16 planes (gru_chain_hx.hpp)
 struct ChainArgs {
   int D, n_panels, max_steps, dbg;
+  int n_rnn_keys;                        // GRUs of the chain (rows of the column-key result in front of the per-panel partials)
   const int32_t* panel; const int32_t* rows; const int32_t* sinfo;
   const float* dt;
   const int32_t* gi_index;
@@ -55,6 +56,10 @@ __host__ __device__ inline ChainGeom chain_geom(int D) {
 // `ms` = the longest panel of the launch (<= CH_MAX_STEPS)
 inline size_t chain_lds_fwd(int D, int ms) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.lda + 2 * CH_SLOTS * g.ldh + (2 * CH_SLOTS + 1) * (size_t)ms) * 4; }
 inline size_t chain_lds_bwd(int D, int ms) { ChainGeom g = chain_geom(D); return ((size_t)CH_SLOTS * g.ldA + 2 * CH_SLOTS * g.ldz + (2 * CH_SLOTS + 3) * (size_t)ms) * 4; }
+
+}  // namespace temp
+#include "gru_chain_hx.hpp"
+namespace temp {
 
 // ---- W_hh -> fragment order ---------------------------------------------------------------------------------------
 // forward  piece (tile, q, lane): float4 e -> W_hh[tile*32 + li][8q + 4hh + e]      (gate column x k)
@@ -637,16 +642,29 @@ static int chain_check(const TempGruChain* c) {
 
 // the products of the chain run on the bf16 matrix pipe (three-way split) unless TEMP_MFMA=f32 or d is not a multiple of 8
 static bool chain_bx(int d) { return bx_enabled() && d % 8 == 0; }
+// ... and on the f16 pipe as three products of the scaled two-way split (gru_chain_hx.hpp) unless TEMP_MFMA=bf16x3 or its LDS images do not fit
+static bool chain_hx(int d) {
+  if (!chain_bx(d) || !hx_enabled()) return false;
+  const ChainGeomHx g = chain_geom_hx(d);
+  return chain_lds_fwd_hx(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && chain_lds_bwd_hx(d, CH_MAX_STEPS) <= CH_LDS_LIMIT && g.NT <= 20 && g.NTb <= 8;   // (six tiles per matrix wave: the two register sets spill)
+}
 
 static ChainArgs chain_args(const TempGruChain* c) {
   ChainArgs a = {};
   const ChainGeom g = chain_geom(c->d);
   a.D = c->d; a.n_panels = c->n_panels; a.max_steps = c->max_steps; a.panel = c->panel; a.rows = c->rows; a.sinfo = c->sinfo; a.dt = c->dt;
-  a.lambda = c->lambda; a.plane = c->saved_plane; a.gi_index = c->gi_index; a.dbg = option(TEMP_OPT_DEBUG) >> 8;      // development A/B switches (bit 6: no per-block rotation of the slab walk); 0 in every product run
+  a.n_rnn_keys = c->n_rnn; a.lambda = c->lambda; a.plane = c->saved_plane; a.gi_index = c->gi_index; a.dbg = option(TEMP_OPT_DEBUG) >> 8;      // development A/B switches (bit 6: no per-block rotation of the slab walk); 0 in every product run
   for (int i = 0; i < c->n_rnn; ++i) {
     a.rnn[i].wf = (const float4*)c->packed[i];
     a.rnn[i].wb = (const float4*)c->packed[i] + (chain_bx(c->d) ? (size_t)(g.NQ >> 1) * g.NT * 192 : (size_t)g.NT * g.NQ * 64);
     a.rnn[i].b_hh = c->b_hh[i];
+    a.rnn[i].kf = a.rnn[i].kb = nullptr;
+    if (chain_hx(c->d)) {
+      const ChainGeomHx gx = chain_geom_hx(c->d);
+      a.rnn[i].wb = (const float4*)c->packed[i] + chain_hx_fwd_items(c->d);
+      a.rnn[i].kf = (const unsigned*)((const float4*)c->packed[i] + chain_hx_fwd_items(c->d) + chain_hx_bwd_items(c->d));
+      a.rnn[i].kb = a.rnn[i].kf + gx.NT * 32;
+    }
   }
   return a;
 }
@@ -664,6 +682,15 @@ template <int VARIANT, int TPW>
 static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float* saved, hipStream_t st) {
   static bool attr = false;
   static bool attr_bx = false;
+  static bool attr_hx = false;
+  if (chain_hx(a.D)) {
+    const size_t lds_hx = chain_lds_fwd_hx(a.D, a.max_steps);
+    auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW, 4>;
+    int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
+    if (rc) return rc;
+    TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds_hx, st, a, gi, h, saved);
+    return launch_status();
+  }
   const size_t lds = chain_lds_fwd(a.D, a.max_steps);
   if (chain_bx(a.D)) {
     auto kernel = k_gru_chain_fwd<VARIANT, TPW, 4, 1>;
@@ -680,9 +707,21 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
 }
 
 template <int VARIANT, int TPWB, int G4 = 0>
-static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float* saved, float* dgi, float* dgh, hipStream_t st) {
+static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float* saved, float* dgi, float* dgh, hipStream_t st,
+                            unsigned* row_keys = nullptr, unsigned* col_keys = nullptr) {
   static bool attr = false;
   static bool attr_bx = false;
+  static bool attr_hx = false;
+  if (chain_hx(a.D)) {
+    const size_t lds_hx = chain_lds_bwd_hx(a.D, a.max_steps);
+    auto kernel = k_gru_chain_bwd_hx<VARIANT, TPWB, 8, G4>;
+    int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
+    if (rc) return rc;
+    TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds_hx, st, a, ups, saved, dgi, dgh, row_keys, col_keys);
+    if (col_keys) TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_keys_reduce, dim3(ceil_div(4 * a.D, 32), a.n_rnn_keys), dim3(1024), 0, st, a.n_panels, 4 * a.D, col_keys + (size_t)a.n_rnn_keys * 4 * a.D, col_keys, a.panel, 4);
+    return launch_status();
+  }
+  if (row_keys || col_keys) return TEMP_E_UNSUPPORTED;          // (only the f16 kernels produce keys: ask temp_gru_chain_keys_supported first)
   const size_t lds = chain_lds_bwd(a.D, a.max_steps);
   if (chain_bx(a.D)) {
     auto kernel = k_gru_chain_bwd<VARIANT, TPWB, 8, 1, G4>;
@@ -715,13 +754,16 @@ size_t temp_gru_chain_pack_floats(int d) {
   const size_t f32 = ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64 * 4;
   // three bf16 planes in fragment order: (slabs of 16 k) x tiles x 192 sixteen-byte items, forward then backward
   const size_t bx = ((size_t)(g.NQ >> 1) * g.NT + (size_t)(g.NQb >> 1) * g.NTb) * 192 * 4;
-  return f32 > bx ? f32 : bx;                          // either arithmetic (TEMP_MFMA) fits the caller's buffer
+  const size_t hx = chain_hx_pack_floats(d);           // two f16 planes + column keys (gru_chain_hx.hpp)
+  const size_t m = f32 > bx ? f32 : bx;
+  return m > hx ? m : hx;                              // any arithmetic (TEMP_MFMA) fits the caller's buffer
 }
 
 int temp_gru_chain_pack(int d, const float* w_hh, float* packed, void* stream) {
   if (d <= 0 || !w_hh || !packed) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
   const ChainGeom g = chain_geom(d);
+  if (chain_hx(d)) return temp_gru_chain_pack_multi(1, d, &w_hh, &packed, stream);
   if (chain_bx(d)) {
     // forward: gate column x k = W_hh as stored ([3d][d], k contiguous); backward: k = gate column, state column = W_hh as [K][N]
     const int nsf = g.NQ >> 1, nsb = g.NQb >> 1;
@@ -744,6 +786,22 @@ int temp_gru_chain_pack_multi(int count, int d, const float* const* w_hh, float*
   if (count <= 0 || count > TEMP_CHAIN_MAX_RNN || d <= 0 || !w_hh || !packed) return TEMP_E_BADARG;
   for (int i = 0; i < count; ++i) if (!w_hh[i] || !packed[i]) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
+  if (chain_hx(d)) {
+    // two f16 planes with per-column scales: forward (gate column x k: W_hh as stored), backward (k = gate column, state column:
+    // W_hh as [K][N], its slab count rounded up to the kernel's multiple of four), then the keys of both
+    const ChainGeomHx gx = chain_geom_hx(d);
+    HxPackJobs jobs = {};
+    for (int i = 0; i < count; ++i) {
+      hx_u32x4* pf = reinterpret_cast<hx_u32x4*>(packed[i]);
+      hx_u32x4* pb = pf + chain_hx_fwd_items(d);
+      unsigned* kf = reinterpret_cast<unsigned*>(pb + chain_hx_bwd_items(d));
+      if (jobs.count + 2 > HX_PACK_JOBS) { hx_pack_launch(jobs, K_GRU_CHAIN_PACK, (hipStream_t)stream); jobs = HxPackJobs{}; }
+      hx_pack_jobs_add(jobs, w_hh[i], pf, kf, d, 3 * d, d, 1);
+      hx_pack_jobs_add(jobs, w_hh[i], pb, kf + gx.NT * 32, 3 * d, d, d, 0, gx.NSb);
+    }
+    hx_pack_launch(jobs, K_GRU_CHAIN_PACK, (hipStream_t)stream);
+    return launch_status();
+  }
   if (!chain_bx(d) || 2 * count > BX_PACK_JOBS) {
     for (int i = 0; i < count; ++i) { const int rc = temp_gru_chain_pack(d, w_hh[i], packed[i], stream); if (rc) return rc; }
     return TEMP_OK;
@@ -796,6 +854,26 @@ int temp_gru_chain_bwd_g4(const TempGruChain* c, const float* saved, int n_up, c
   const int tpw = ceil_div(chain_geom(c->d).NTb, 4);
   if (tpw == 1) return launch_chain_bwd<TEMP_GRU_TORCH, 1, 1>(a, ups, saved, g4, nullptr, st);
   if (tpw == 2) return launch_chain_bwd<TEMP_GRU_TORCH, 2, 1>(a, ups, saved, g4, nullptr, st);
+  return TEMP_E_UNSUPPORTED;
+}
+
+int temp_gru_chain_keys_supported(int d) { return d > 0 && chain_hx(d) ? 1 : 0; }
+
+int temp_gru_chain_bwd_g4_keys(const TempGruChain* c, const float* saved, int n_up, const float* const* up, float* g4, uint32_t* row_keys,
+                               uint32_t* col_keys, void* stream) {
+  int rc = chain_check(c);
+  if (rc) return rc;
+  if (n_up < 0 || n_up > TEMP_CHAIN_MAX_UP || (n_up > 0 && !up)) return TEMP_E_BADARG;
+  if (c->variant != TEMP_GRU_TORCH || !chain_hx(c->d)) return TEMP_E_UNSUPPORTED;
+  if (c->n_panels == 0) return TEMP_OK;
+  if (!saved || !g4) return TEMP_E_BADARG;
+  const ChainArgs a = chain_args(c);
+  ChainUps ups = {};
+  for (int i = 0; i < n_up; ++i) ups.p[i] = up[i];
+  hipStream_t st = (hipStream_t)stream;
+  const int tpw = ceil_div(chain_geom(c->d).NTb, 4);
+  if (tpw == 1) return launch_chain_bwd<TEMP_GRU_TORCH, 1, 1>(a, ups, saved, g4, nullptr, st, row_keys, col_keys);
+  if (tpw == 2) return launch_chain_bwd<TEMP_GRU_TORCH, 2, 1>(a, ups, saved, g4, nullptr, st, row_keys, col_keys);
   return TEMP_E_UNSUPPORTED;
 }
 

@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include "gemm_wres.hpp"
 #include "gru_math.hpp"
-#include "gru_wgrad.hpp"
+#include "gru_wgrad_hx.hpp"
 
 namespace temp {
 
@@ -552,6 +552,14 @@ static bool grads_g4_plan(int count, const int* ns, int d, WgArgs* a) {
 }
 
 template <int NT>
+static int launch_gru_wgrad_hx(const WgArgs& a, const WgxKeys& keys, hipStream_t st) {
+  static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_wgrad_hx<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, wgx_lds_bytes(NT)) == hipSuccess;
+  if (!granted) { (void)hipGetLastError(); return TEMP_E_UNSUPPORTED; }
+  TEMP_LAUNCH(K_GRU_WGRAD, (k_gru_wgrad_hx<NT>), dim3(8 * a.per_xcd * a.P), dim3(WG_THREADS), wgx_lds_bytes(NT), st, a, keys);
+  return TEMP_OK;
+}
+
+template <int NT>
 static int launch_gru_wgrad(const WgArgs& a, hipStream_t st) {
   static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_wgrad<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes(NT)) == hipSuccess;
   if (!granted) { (void)hipGetLastError(); return TEMP_E_UNSUPPORTED; }
@@ -895,6 +903,12 @@ size_t temp_gru_grads_g4_workspace(int count, const int* ns, int d) {
 int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
                       const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, void* workspace, size_t workspace_bytes,
                       void* stream) {
+  return temp_gru_grads_g4_keys(count, ns, d, xs, hdecs, g4s, w_ihs, d_xs, d_w, d_b, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
+                           const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, const uint32_t* const* g4_row_keys,
+                           const uint32_t* const* g4_col_keys, void* workspace, size_t workspace_bytes, void* stream) {
   if (count <= 0 || count > WG_MAXG || !ns || !xs || !hdecs || !g4s || !w_ihs || !d_xs || !d_w || !d_b) return TEMP_E_BADARG;
   WgArgs a = {};
   if (!grads_g4_plan(count, ns, d, &a)) return TEMP_E_UNSUPPORTED;
@@ -909,6 +923,27 @@ int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, c
   a.part2 = (float*)(base + ws.part2); a.bpart2 = (float*)(base + ws.bpart2);
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  bool hx = hx_enabled() && g4_col_keys != nullptr;
+  for (int i = 0; i < count && hx; ++i) hx = g4_col_keys[i] != nullptr;
+  if (hx) {
+    // f16 arithmetic (gru_wgrad_hx.hpp): the column keys of g4 come from the chain backward; those of x are taken here, one pass
+    WgxKeys keys = {};
+    unsigned* xk = (unsigned*)(base + ws.xkeys);
+    for (int i = 0; i < count; ++i) {
+      keys.g[i] = g4_col_keys[i]; keys.x[i] = xk + (size_t)i * d;
+      launch_absmax_keys(ns[i], d, xs[i], d, nullptr, xk + (size_t)i * d, xk + (size_t)count * d + (size_t)i * ABSMAX_BLOCKS * d, st);
+    }
+    switch (ceil_div(d, 32)) {
+      case 1: rc = launch_gru_wgrad_hx<1>(a, keys, st); break;
+      case 2: rc = launch_gru_wgrad_hx<2>(a, keys, st); break;
+      case 3: rc = launch_gru_wgrad_hx<3>(a, keys, st); break;
+      case 4: rc = launch_gru_wgrad_hx<4>(a, keys, st); break;
+      case 5: rc = launch_gru_wgrad_hx<5>(a, keys, st); break;
+      case 6: rc = launch_gru_wgrad_hx<6>(a, keys, st); break;
+      case 7: rc = launch_gru_wgrad_hx<7>(a, keys, st); break;
+      default: rc = launch_gru_wgrad_hx<8>(a, keys, st); break;
+    }
+  } else
   switch (ceil_div(d, 32)) {
     case 1: rc = launch_gru_wgrad<1>(a, st); break;
     case 2: rc = launch_gru_wgrad<2>(a, st); break;
@@ -919,6 +954,7 @@ int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, c
     case 7: rc = launch_gru_wgrad<7>(a, st); break;
     default: rc = launch_gru_wgrad<8>(a, st); break;
   }
+  (void)g4_row_keys;
   if (rc) return rc;
   const int Ka = 3 * d, R0 = a.tail ? 256 * a.fb : Ka, S2 = a.tail ? a.S * a.P : 0;
   const long long quads = (long long)2 * count * Ka * (d / 4);

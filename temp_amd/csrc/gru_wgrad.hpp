@@ -447,7 +447,7 @@ inline bool wg_plan(int count, int d, int max_m, WgArgs* a) {
   return true;
 }
 // workspace: [part | bpart | part2 | bpart2]
-struct WgWs { size_t part, bpart, part2, bpart2, total; };
+struct WgWs { size_t part, bpart, part2, bpart2, xkeys, total; };      // xkeys: [count][d] column keys of the x operands (gru_wgrad_hx.hpp)
 inline WgWs wg_workspace(const WgArgs& a) {
   const size_t Ka = 3 * (size_t)a.d, np = 2 * (size_t)a.count;
   const size_t Rt = a.tail ? Ka - 256 * (size_t)a.fb : 0, S2 = a.tail ? (size_t)a.S * a.P : 0;
@@ -456,7 +456,8 @@ inline WgWs wg_workspace(const WgArgs& a) {
   w.bpart = align_up((size_t)a.S * np * Ka * a.d * sizeof(float), 256);
   w.part2 = w.bpart + align_up((size_t)a.S * np * Ka * sizeof(float), 256);
   w.bpart2 = w.part2 + align_up(S2 * np * Rt * a.d * sizeof(float), 256);
-  w.total = w.bpart2 + align_up(S2 * np * Rt * sizeof(float), 256);
+  w.xkeys = w.bpart2 + align_up(S2 * np * Rt * sizeof(float), 256);
+  w.total = w.xkeys + align_up((size_t)a.count * (1 + 256) * a.d * sizeof(unsigned), 256);      // [count][d] keys + [count][256 blocks][d] partials
   return w;
 }
 

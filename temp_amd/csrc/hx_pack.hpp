@@ -1,0 +1,166 @@
+// Weights for the f16 two-way split (split_f16.hpp): per-column keys (the column's largest magnitude) and the two f16 planes in
+// MFMA fragment order.
+//
+//   keys[n]                                       = hx_abs_bits of max_k |B[k][n]|   (0 for n >= N up to the tile padding)
+//   packed[((s * n_tiles + t) * 2 + p) * 64 + lane] = 16 bytes: plane p (0: h, 1: l) of B[k = 16 s + 8 hh .. + 7][n = 32 t + li] . hx_scale(keys[n])
+//                                                   (zero past K / N);  li = lane & 31, hh = lane >> 5
+// B is given as [K][N] row-major (trans = 0) or stored as [N][K] (trans = 1), leading dimension ldb.  A product then unscales
+// column n of its result by hx_inv_scale(keys[n]).
+#pragma once
+#include "common.hpp"
+#include "split_f16.hpp"
+
+namespace temp {
+
+#define HX_PACK_JOBS 8
+struct HxPackJob { const float* B; hx_u32x4* out; unsigned* keys; int K, N, n_tiles, n_slabs, ldb, trans, unit0, kblock0; };
+struct HxPackJobs { HxPackJob j[HX_PACK_JOBS]; int count, total_units, total_kblocks; };
+
+inline size_t hx_packed_items(int N, int K) { return (size_t)ceil_div(K, 16) * ceil_div(N, 32) * 128; }   // 16-byte items
+
+// n_slabs > ceil(K / 16): zero slabs behind the matrix (a kernel that walks its slabs in groups)
+inline void hx_pack_jobs_add(HxPackJobs& jobs, const float* B, hx_u32x4* out, unsigned* keys, int K, int N, int ldb, int trans, int n_slabs = 0) {
+  HxPackJob& j = jobs.j[jobs.count++];
+  j.B = B; j.out = out; j.keys = keys; j.K = K; j.N = N; j.n_tiles = ceil_div(N, 32); j.n_slabs = n_slabs > 0 ? n_slabs : ceil_div(K, 16); j.ldb = ldb; j.trans = trans;
+  j.unit0 = jobs.total_units; j.kblock0 = jobs.total_kblocks;
+  jobs.total_units += j.n_tiles * j.n_slabs;
+  jobs.total_kblocks += j.n_tiles;
+}
+
+__device__ __forceinline__ const HxPackJob& hx_job_of(const HxPackJobs& jobs, int idx, bool by_kblock, int& local) {
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < HX_PACK_JOBS; ++i)
+    if (i < jobs.count && idx >= (by_kblock ? jobs.j[i].kblock0 : jobs.j[i].unit0)) ji = i;
+  local = idx - (by_kblock ? jobs.j[ji].kblock0 : jobs.j[ji].unit0);
+  return jobs.j[ji];
+}
+
+// one block (1024 threads) per 32-column tile of a job; every load instruction reads whole 128-byte lines:
+//   trans = 1 (B stored [N][K]): thread (c, j) reads the float4 pieces j, j + 32, .. of row 32 t + c
+//   trans = 0 (B stored [K][N]): thread (g, c) reads element (k = g, g + 32, .., column 32 t + c), eight loads in flight
+static __global__ void __launch_bounds__(1024) k_hx_keys(HxPackJobs jobs) {
+  __shared__ unsigned sm[32][33];
+  int t;
+  const HxPackJob& jb = hx_job_of(jobs, blockIdx.x, true, t);
+  const int K = jb.K, N = jb.N, ldb = jb.ldb;
+  const float* __restrict__ B = jb.B;
+  unsigned key = 0;
+  int c, g;
+  if (jb.trans) {
+    c = threadIdx.x >> 5; g = threadIdx.x & 31;
+    const int n = 32 * t + c;
+    if (n < N) {
+      const float* p = B + (size_t)n * ldb;
+      if ((K & 3) == 0 && (ldb & 3) == 0) {
+        for (int q0 = g; q0 < (K >> 2); q0 += 128) {
+          float4 v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const int q = q0 + 32 * i; v[i] = q < (K >> 2) ? ld4(p + 4 * q) : zero4(); }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) key = max(key, hx_abs_bits4(v[i]));
+        }
+      } else {
+        for (int k = g; k < K; k += 32) key = max(key, hx_abs_bits(p[k]));
+      }
+    }
+  } else {
+    g = threadIdx.x >> 5; c = threadIdx.x & 31;
+    const int n = 32 * t + c;
+    if (n < N) {
+      const float* p = B + n;
+      for (int k0 = g; k0 < K; k0 += 256) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int k = k0 + 32 * i; v[i] = k < K ? p[(size_t)k * ldb] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) key = max(key, hx_abs_bits(v[i]));
+      }
+    }
+  }
+  sm[g][c] = key;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    key = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) key = max(key, sm[i][threadIdx.x]);
+    jb.keys[32 * t + threadIdx.x] = key;                          // (keys holds n_tiles * 32 entries)
+  }
+}
+
+// one wave per (slab, tile) unit of a job (after k_hx_keys on the same stream)
+static __global__ void __launch_bounds__(256) k_hx_pack(HxPackJobs jobs) {
+  const int lane = threadIdx.x & 63, hh = lane >> 5, li = lane & 31;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= jobs.total_units) return;
+  int st;
+  const HxPackJob& jb = hx_job_of(jobs, unit, false, st);
+  const int s = st / jb.n_tiles, t = st - s * jb.n_tiles;
+  const int k = 16 * s + 8 * hh, n = 32 * t + li;
+  float4 v0 = zero4(), v1 = zero4();
+  if (n < jb.N && k < jb.K) {                                // K % 8 == 0: the octet is entirely in or out
+    if (jb.trans) {
+      const float* p = jb.B + (size_t)n * jb.ldb + k;
+      v0 = ld4(p); v1 = ld4(p + 4);
+    } else {
+      const float* p = jb.B + (size_t)k * jb.ldb + n;
+      const size_t l = (size_t)jb.ldb;
+      v0 = make_float4(p[0], p[l], p[2 * l], p[3 * l]);
+      v1 = make_float4(p[4 * l], p[5 * l], p[6 * l], p[7 * l]);
+    }
+  }
+  hx_u32x4 H, L;
+  hx_split8(v0, v1, hx_scale(jb.keys[n]), H, L);
+  hx_u32x4* d = jb.out + (size_t)st * 128 + lane;
+  d[0] = H; d[64] = L;
+}
+
+inline void hx_pack_launch(const HxPackJobs& jobs, int kid, hipStream_t st) {
+  if (!jobs.count) return;
+  TEMP_LAUNCH(kid, k_hx_keys, dim3(jobs.total_kblocks), dim3(1024), 0, st, jobs);
+  TEMP_LAUNCH(kid, k_hx_pack, dim3(ceil_div(jobs.total_units, 4)), dim3(256), 0, st, jobs);
+}
+
+// all-reduce of an unsigned maximum over the 64 lanes of a wave (every lane active): rows of 16 by DPP, the four rows through
+// scalar registers -> a wave-uniform value
+__device__ __forceinline__ unsigned hx_wave_max(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1, 0, 3, 2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2, 3, 0, 1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));   // row_mirror
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+
+// out[r][c] = max over the partial rows p < n_part (owned by r: owner == nullptr or owner[owner_stride * p] == r) of part[p][c].
+// grid (ceil(cols / 32), n_out), 1024 threads: thread (pg, c) takes p = pg, pg + 32, .. with eight loads in flight, then one LDS pass
+// (one thread per column walking all partials was a chain of n_part / 8 L2 round trips: 77 us for 250 x 800).
+static __global__ void __launch_bounds__(1024) k_keys_reduce(int n_part, int cols, const unsigned* __restrict__ part, unsigned* __restrict__ out,
+                                                             const int32_t* __restrict__ owner, int owner_stride) {
+  __shared__ unsigned sm[32][33];
+  const int cl = threadIdx.x & 31, pg = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, r = blockIdx.y;
+  unsigned key = 0;
+  if (c < cols) {
+    for (int p0 = pg; p0 < n_part; p0 += 256) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 32 * u;
+        v[u] = (p < n_part && (!owner || owner[(size_t)owner_stride * p] == r)) ? part[(size_t)p * cols + c] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) key = max(key, v[u]);
+    }
+  }
+  sm[pg][cl] = key;
+  __syncthreads();
+  if (threadIdx.x < 32 && blockIdx.x * 32 + threadIdx.x < cols) {
+    key = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) key = max(key, sm[i][threadIdx.x]);
+    out[(size_t)r * cols + blockIdx.x * 32 + threadIdx.x] = key;
+  }
+}
+
+}  // namespace temp

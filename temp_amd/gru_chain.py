@@ -22,6 +22,7 @@ from .backend import get_backend
 
 CHAIN_KERNELS = True        # A/B switch: False keeps the per-position launches (temp_gru_cell_*_multi)
 WEIGHT_GRADS_MULTI = True   # A/B switch: False computes each GRU's weight gradients with its own launches (temp_gru_weight_grads)
+KEYED_GRADS = True          # A/B switch: False keeps the consumers of g4 on the six-product bf16 split (no keys from the chain backward)
 GATE_GRADS_ONCE = True      # A/B switch: False keeps dgi + dgh as two matrices (temp_gru_chain_bwd + temp_gru_weight_grads_multi)
 
 
@@ -379,12 +380,17 @@ class _GruChainFn(torch.autograd.Function):
         if once:
             g4 = torch.empty(N, 4 * d, dtype=torch.float32, device=dev)
             ups = [dH] if ctx.want is None else [given.get(i) for i in ctx.want]
-            be.gru_chain_bwd_g4(ctx.tabs, saved, ups, lam, variant, ctx.packs, [W[r][3] for r in range(ctx.n_rnn)], g4)
+            # (f16 arithmetic: the chain backward also hands out the magnitude keys of g4 -- per row, per GRU and column -- that the
+            #  weight-gradient and d_x products split it with; integer maxima, so bit-repeatable)
+            keyed = bool(KEYED_GRADS and hasattr(be, "gru_chain_keys_supported") and be.gru_chain_keys_supported(d))
+            keys = (torch.empty(N, dtype=torch.int32, device=dev), torch.empty(ctx.n_rnn + ctx.tabs["n_panels"], 4 * d, dtype=torch.int32, device=dev)) if keyed else None
+            be.gru_chain_bwd_g4(ctx.tabs, saved, ups, lam, variant, ctx.packs, [W[r][3] for r in range(ctx.n_rnn)], g4, **({"keys": keys} if keyed else {}))
             d_x_all = torch.empty_like(x_all)
             xsl = [slice(g["x0"], g["x1"]) for g in groups]
             hsl = [slice(g["h0"], g["h1"]) for g in groups]
+            kw = dict(row_keys=[keys[0][b] for b in hsl], col_keys=[keys[1][g["rnn"]] for g in groups]) if keyed else {}
             multi = be.gru_grads_g4([x_all[a] for a in xsl], [saved[4, b] for b in hsl], [g4[b] for b in hsl], [W[g["rnn"]][0] for g in groups],
-                                    [d_x_all[a] for a in xsl])
+                                    [d_x_all[a] for a in xsl], **kw)
             grads = [None] * (4 * ctx.n_rnn)
             covered = np.zeros(x_all.shape[0], dtype=bool)
             for g, gw in zip(groups, multi):
