@@ -94,6 +94,9 @@ int temp_get_option(int key);
 /* Diagnostic: how often a launch found no scratch slot for its packed weights / k-slice partials (more than 8 busy streams
  * on one device) and took the scratch-free kernels instead.  0 in every supported configuration. */
 long long temp_scratch_refused(void);
+/* Diagnostic: launches of f16-split kernels (TEMP_OPT_MFMA_F16X2) so far in this process -- a test's proof that the product it
+ * checked did not silently take the six-product bf16 route. */
+long long temp_f16_launches(void);
 /* Diagnostic: edge-kernel launches (aggregation, d/dh, d/dweight) that took the LDS-tiled path (TempMembers present, member fits). */
 long long temp_tile_launches(void);
 /* Development only: a device buffer of `words` int64 into which instrumented kernels write cycle-counter stamps (NULL: off).
@@ -393,7 +396,9 @@ int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, c
  * with the constant scale 2^14).  Same workspace. */
 int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
                            const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, const uint32_t* const* g4_row_keys,
-                           const uint32_t* const* g4_col_keys, void* workspace, size_t workspace_bytes, void* stream);
+                           const uint32_t* const* g4_col_keys, const uint32_t* const* x_col_keys /* nullable (array or entries): [d] keys
+                           bounding the column magnitudes of xs[i], e.g. from temp_gather_rows_keys; else taken here with one pass */,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Persistent window chain: ALL positions of the recurrence in ONE launch per direction of time.
@@ -469,6 +474,24 @@ int temp_gru_chain_bwd_g4_keys(const TempGruChain* c, const float* saved, int n_
  *   scatter_add:  table[idx[i]] += src[i]  for idx[i] >= 0 (atomic, rows may repeat)
  * ---------------------------------------------------------------------------------------------- */
 int temp_gather_rows(int n, int d, const float* table, const int32_t* idx, float* out, void* stream);
+/* Magnitude keys (round 6, split_f16.hpp): the key of a value is its fp32 bit pattern with the sign cleared, so integer order is
+ * magnitude order and a maximum of keys does not depend on the order it is taken in.  A consumer that runs a product as three f16
+ * MFMA products scales every row (activations) / column (a sum over rows) by the power of two its key gives.
+ *   temp_absmax_keys      : row_keys[n] (nullable) = key of every row's largest magnitude; col_keys (nullable) = [d] keys bounding
+ *                           every column's largest magnitude, followed by temp_keys_cols_size(d) - d words of scratch (the buffer
+ *                           holds temp_keys_cols_size(d) words; nothing to initialise).  d % 4 == 0, d <= 256.
+ *   temp_gather_rows_keys : temp_gather_rows that also hands out the keys of its OUTPUT rows / columns (same buffers).
+ *   temp_linear_keys      : temp_linear with the row keys of A (nullable: taken inside when the product is wide or deep enough to pay
+ *                           for the pass, else the six-product bf16 kernels run).
+ *   temp_gru_input_gates_gather_multi_keys : x_keys[i] = row keys of xs[i] by source row (nullable array / entries). */
+size_t temp_keys_cols_size(int d);
+int temp_absmax_keys(int n, int d, const float* x, int ldx, uint32_t* row_keys, uint32_t* col_keys, void* stream);
+int temp_gather_rows_keys(int n, int d, const float* table, const int32_t* idx, float* out, uint32_t* row_keys, uint32_t* col_keys, void* stream);
+int temp_linear_keys(int M, int N, int K, const float* A, int lda, const uint32_t* a_keys, const float* B, int ldb, int trans_b, float* C, int ldc,
+                     void* stream);
+int temp_gru_input_gates_gather_multi_keys(int count, const int* ns, int d, int variant, const float* const* xs, const int32_t* const* x_idx,
+                                           const uint32_t* const* x_keys, const float* const* w_ihs, const float* const* b_ihs, float* const* gis,
+                                           void* stream);
 int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, float* table, void* stream);
 /* Deterministic adjoint of a gather with a STATIC index list (the ids of a prepared window batch):
  *   out[s] = sum_{j in [seg_ptr[s], seg_ptr[s+1])} src[order[j]]      out: [n_seg, d] fully written (empty segment = 0)

@@ -101,6 +101,7 @@ SYMBOLS = {
     "temp_set_option": (_I, [_I, _I]),
     "temp_get_option": (_I, [_I]),
     "temp_scratch_refused": (ctypes.c_longlong, []),
+    "temp_f16_launches": (ctypes.c_longlong, []),
     "temp_tile_launches": (ctypes.c_longlong, []),
     "temp_set_debug_buffer": (None, [c_vp, _SZ]),
     "temp_rgcn_fwd_workspace": (_SZ, [_G, _I]),
@@ -142,10 +143,15 @@ SYMBOLS = {
     "temp_gru_chain_bwd_g4": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp]),
     "temp_gru_chain_keys_supported": (_I, [_I]),
     "temp_gru_chain_bwd_g4_keys": (_I, [ctypes.POINTER(TempGruChain), c_vp, _I, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp]),
-    "temp_gru_grads_g4_keys": (_I, [_I, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "temp_gru_grads_g4_keys": (_I, [_I, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "temp_gru_grads_g4_workspace": (ctypes.c_size_t, [_I, c_vp, _I]),
     "temp_gru_grads_g4": (_I, [_I, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "temp_gather_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
+    "temp_keys_cols_size": (_SZ, [_I]),
+    "temp_absmax_keys": (_I, [_I, _I, c_vp, _I, c_vp, c_vp, c_vp]),
+    "temp_gather_rows_keys": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "temp_linear_keys": (_I, [_I, _I, _I, c_vp, _I, c_vp, c_vp, _I, _I, c_vp, _I, c_vp]),
+    "temp_gru_input_gates_gather_multi_keys": (_I, [_I, c_vp, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "temp_scatter_add_rows": (_I, [_I, _I, c_vp, c_vp, c_vp, c_vp]),
     "temp_segment_sum_rows_workspace": (_SZ, [_I, _I, _I]),
     "temp_segment_sum_rows": (_I, [_I, _I, _I, c_vp, c_vp, c_vp, c_vp, c_vp, _SZ, c_vp]),

@@ -228,7 +228,7 @@ class HipBackend:
         rc = self.lib.temp_gru_input_gates(x.shape[0], x.shape[1], variant, _ptr(x), _ptr(w_ih), _ptr(b_ih), _ptr(out), _stream())
         _lib.check(rc, "temp_gru_input_gates")
 
-    def gru_input_gates_multi(self, xs, w_ihs, b_ihs, variant, outs, x_idx=None):
+    def gru_input_gates_multi(self, xs, w_ihs, b_ihs, variant, outs, x_idx=None, x_keys=None):
         """gi_i = x_i . W_ih_i^T + b_ih_i for every (row block, weight set) pair in one launch per four problems
         (include/temp_amd.h: temp_gru_input_gates_multi); x_idx: per problem an int32 table of the x rows to take (the out
         block has one row per entry; temp_gru_input_gates_gather_multi)."""
@@ -242,11 +242,19 @@ class HipBackend:
             assert x.shape[1] == d and o.is_contiguous() and o.shape == (n, w.shape[0]) and w.shape == w_ihs[0].shape
         arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
         ns = (ctypes.c_int * k)(*rows)
-        if x_idx is None:
+        if x_idx is None and x_keys is None:
             rc = self.lib.temp_gru_input_gates_multi(k, ns, d, variant, arr(xs), arr(w_ihs), arr(b_ihs), arr(outs), _stream())
             _lib.check(rc, "temp_gru_input_gates_multi")
             return
         ia = (ctypes.c_void_p * k)(*[None if t is None else t.data_ptr() for t in idx])
+        if x_keys is not None:                           # row keys of every xs[i] by SOURCE row (int32 [x_i rows]): f16 arithmetic
+            for x, t in zip(xs, x_keys):
+                assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == x.shape[0]
+            ka = (ctypes.c_void_p * k)(*[t.data_ptr() for t in x_keys])
+            rc = self.lib.temp_gru_input_gates_gather_multi_keys(k, ns, d, variant, arr(xs), ia if x_idx is not None else None, ka, arr(w_ihs),
+                                                                 arr(b_ihs), arr(outs), _stream())
+            _lib.check(rc, "temp_gru_input_gates_gather_multi_keys")
+            return
         rc = self.lib.temp_gru_input_gates_gather_multi(k, ns, d, variant, arr(xs), ia, arr(w_ihs), arr(b_ihs), arr(outs), _stream())
         _lib.check(rc, "temp_gru_input_gates_gather_multi")
 
@@ -408,7 +416,7 @@ class HipBackend:
             return False
         return self.lib.temp_gru_grads_g4_workspace(k, (ctypes.c_int * k)(*[int(n) for n in ns]), int(d)) > 0
 
-    def gru_grads_g4(self, xs, hdecs, g4s, w_ihs, d_xs, row_keys=None, col_keys=None):
+    def gru_grads_g4(self, xs, hdecs, g4s, w_ihs, d_xs, row_keys=None, col_keys=None, x_col_keys=None):
         """Weight / bias gradients and d_x of several GRUs of one width from their gate-gradient matrices (include/temp_amd.h:
         temp_gru_grads_g4) -> [(d_w_ih, d_w_hh, d_b_ih, d_b_hh)] per GRU.  row_keys / col_keys: per GRU the int32 key tensors of
         gru_chain_bwd_g4(keys=...) ([n_i] and [4d]); with them the products run on the f16 pipe (temp_gru_grads_g4_keys)."""
@@ -431,8 +439,13 @@ class HipBackend:
             for rk, ck, x in zip(row_keys, col_keys, xs):
                 assert rk.dtype == torch.int32 and ck.dtype == torch.int32 and rk.is_contiguous() and ck.is_contiguous()
                 assert rk.numel() == x.shape[0] and ck.numel() == 4 * d
+            xk = None
+            if x_col_keys is not None:
+                for t in x_col_keys:
+                    assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == d
+                xk = arr(x_col_keys)
             rc = self.lib.temp_gru_grads_g4_keys(k, ns, d, arr(keep[0]), arr(keep[1]), arr(g4s), arr(keep[2]), dx, _ptr(d_w), _ptr(d_b),
-                                                 arr(row_keys), arr(col_keys), _ptr(ws), ws.numel(), _stream())
+                                                 arr(row_keys), arr(col_keys), xk, _ptr(ws), ws.numel(), _stream())
             _lib.check(rc, "temp_gru_grads_g4_keys")
             return [(d_w[2 * i], d_w[2 * i + 1], d_b[2 * i], d_b[2 * i + 1]) for i in range(k)]
         rc = self.lib.temp_gru_grads_g4(k, ns, d, arr(keep[0]), arr(keep[1]), arr(g4s), arr(keep[2]), dx, _ptr(d_w), _ptr(d_b), _ptr(ws),
@@ -481,16 +494,31 @@ class HipBackend:
         return [(d_w[2 * i], d_w[2 * i + 1], d_b[2 * i], d_b[2 * i + 1]) for i in range(k)]
 
     # ---- plain GEMMs + candidate cross-entropy (link-prediction loss) ---------------------------------
-    def linear(self, a, b, trans_b, out=None):
-        """a[M,K] . b  (b is [K,N], or [N,K] when trans_b); out: an (M, N) contiguous tensor to write into."""
+    def linear(self, a, b, trans_b, out=None, a_keys=None):
+        """a[M,K] . b  (b is [K,N], or [N,K] when trans_b); out: an (M, N) contiguous tensor to write into.  a_keys: int32 [M], the
+        magnitude keys of a's rows (absmax_keys): the product then runs on the f16 pipe without a pass of its own (temp_linear_keys)."""
         a, b = _f32(a, "a"), _f32(b, "b")
         M, K = a.shape
         N = b.shape[0] if trans_b else b.shape[1]
         c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=a.device)
         assert c.shape == (M, N) and c.is_contiguous() and c.dtype == torch.float32
+        if a_keys is not None:
+            assert a_keys.dtype == torch.int32 and a_keys.is_contiguous() and a_keys.numel() == M
+            rc = self.lib.temp_linear_keys(M, N, K, _ptr(a), K, _ptr(a_keys), _ptr(b), b.shape[1], int(trans_b), _ptr(c), N, _stream())
+            _lib.check(rc, "temp_linear_keys")
+            return c
         rc = self.lib.temp_linear(M, N, K, _ptr(a), K, _ptr(b), b.shape[1], int(trans_b), _ptr(c), N, _stream())
         _lib.check(rc, "temp_linear")
         return c
+
+    def absmax_keys(self, x, rows=True, cols=True):
+        """Magnitude keys of a matrix (include/temp_amd.h: temp_absmax_keys) -> (row_keys int32 [n] | None, col_keys int32 [d] | None)."""
+        x = _f32(x, "x")
+        n, d = x.shape
+        rk = torch.empty(n, dtype=torch.int32, device=x.device) if rows else None
+        ck = torch.empty(self.lib.temp_keys_cols_size(d), dtype=torch.int32, device=x.device) if cols else None
+        _lib.check(self.lib.temp_absmax_keys(n, d, _ptr(x), d, _ptr(rk), _ptr(ck), _stream()), "temp_absmax_keys")
+        return rk, (ck[:d] if cols else None)
 
     def linear_t(self, a, b, trans_b, out_t):
         """out_t[N, M] = (a[M,K] . b)^T written into the contiguous matrix `out_t` (b is [K,N], or [N,K] when trans_b)."""
@@ -688,6 +716,21 @@ class HipBackend:
         rc = self.lib.temp_gather_rows(idx.shape[0], table.shape[1], _ptr(table), _ptr(idx), _ptr(out), _stream())
         _lib.check(rc, "temp_gather_rows")
         return out
+
+    def gather_rows_keys(self, table, idx):
+        """gather_rows that also returns the magnitude keys of its output: (out, row_keys int32 [n], col_keys int32 [d])."""
+        table, idx = _f32(table, "table"), _i32(idx, "idx")
+        n, d = idx.shape[0], table.shape[1]
+        out = torch.empty(n, d, dtype=torch.float32, device=table.device)
+        rk = torch.empty(n, dtype=torch.int32, device=table.device)
+        ck = torch.empty(self.lib.temp_keys_cols_size(d), dtype=torch.int32, device=table.device)
+        rc = self.lib.temp_gather_rows_keys(n, d, _ptr(table), _ptr(idx), _ptr(out), _ptr(rk), _ptr(ck), _stream())
+        _lib.check(rc, "temp_gather_rows_keys")
+        return out, rk, ck[:d]
+
+    def keys_supported(self, d):
+        """True when row / column keys of a width-d matrix are of use (f16 arithmetic on, width taken by the key kernels)."""
+        return d % 4 == 0 and d <= 256 and self.lib.temp_get_option(_lib.OPT_MFMA_F16X2) != 0 and self.lib.temp_get_option(_lib.OPT_MFMA_BF16X3) != 0
 
     def scatter_add_rows(self, src, idx, table):
         """table[idx[i]] += src[i] in place (table must be contiguous float32)."""

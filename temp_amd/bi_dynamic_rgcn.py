@@ -14,7 +14,7 @@ from . import snapshot as S
 from .birrgcn import BiGRRGCNLayer, BiRRGCN
 from .dynamic_rgcn import DynamicRGCN, WindowBatch
 from .gru_cell import GRUCell
-from .gru_chain import GruInstance, GruProgram, gru_chain
+from .gru_chain import GruInstance, GruProgram, gru_chain, chain_kernels_usable
 from .rrgcn import run_rnn
 from .window import ChainPlan, Step, window_times
 
@@ -101,9 +101,15 @@ class BiDynamicRGCN(DynamicRGCN):
             # (support is decided BEFORE the conv: ONE flag drops the mask from the layer's backward and hands it to the gather's)
             fold = l2.relu_fused() and TF.relu_gather_supported(l2.out_feat, wb.chain_inv)
             y2 = l2.conv(wb.g_all, y1, grad_premasked=fold)
-            wb.last_x = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv, relu_table=fold)          # GRU input rows in chain order
+            # (the gather also hands out the magnitude keys of the rows it writes: the f16 products of the chain scale x by them)
+            keyed = TF.gather_keys_supported(y2.shape[1]) and chain_kernels_usable(y2.shape[1], 2)
+            x_keys = None
+            if keyed:
+                wb.last_x, x_keys = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv, relu_table=fold, keys=True)
+            else:
+                wb.last_x = TF.gather_rows(y2, wb.chain_rows, wb.chain_inv, relu_table=fold)      # GRU input rows in chain order
             got = dict(zip(want, gru_chain(wb.last_x, prog, [l2.forward_rnn, l2.backward_rnn], lam,
-                                           isinstance(l2.forward_rnn, GRUCell), want=want)))
+                                           isinstance(l2.forward_rnn, GRUCell), want=want, x_keys=x_keys)))
             out = got[wb.out_inst[0]] + got[wb.out_inst[1]]
             Hf, Hb = got.get(wb.hist_inst[0]), got.get(wb.hist_inst[1])
             return out, ((Hf, Hf), (Hb, Hb))

@@ -115,6 +115,7 @@ __device__ __forceinline__ float4 drop4(const DropSpec& d, unsigned row, unsigne
 
 // process-wide kernel-selection switches (include/temp_amd.h: temp_set_option); definition in gemm_kernels.hip
 int option(int key);
+void hx_count();                            // diagnostic counter of f16-split kernel launches (temp_f16_launches)
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -157,7 +158,8 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 // gates of both directions of the window chain: the second problem's blocks fill the CUs the first one's tail leaves idle)
 int gemm_bias_multi(int kid, int count, const int* Ms, int N, int K, const float* const* As, const int32_t* const* a_idxs /*nullable*/, int lda,
                     const float* const* Bs, int ldb,
-                    const float* const* biases, float* const* outs, int ldo, hipStream_t st);
+                    const float* const* biases, float* const* outs, int ldo, hipStream_t st,
+                    const unsigned* const* a_keys = nullptr /* per problem: row keys of A by source row (gemm_hx.hpp), nullable */);
 
 // dst[row, :] = src[row, :] * keep-scale(row, col)   (the masked gradient of a dropped-out self-loop message)
 int mask_rows(int n, int d, const float* src, float* dst, const DropSpec& drop, hipStream_t st);

@@ -619,6 +619,7 @@ inline bool bx_plan(int N, int K, int lda, int ldb, int trans_b, int max_m, long
 
 }  // namespace temp
 #include "gemm_bxr.hpp"
+#include "gemm_hx.hpp"
 namespace temp {
 
 // Pack the weight matrices of the batch (problems that share B share the pack) into this stream's scratch slot.
@@ -685,7 +686,12 @@ static inline bool launch_bxr(int kid, const PanelBatch<Epi>& batch, int count, 
 
 template <class Epi>
 int launch_gemm_bx(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, int G, hipStream_t st) {
+  if (launch_hxr(kid, batch, count, g, st)) return launch_status();               // short K, f16 arithmetic: weights resident (gemm_hxr.hpp)
   if (launch_bxr(kid, batch, count, g, st, nullptr)) return launch_status();      // short K: weights resident, split inside the block
+  if (hx_supported(batch, count, g)) {                                            // three f16 products instead of six bf16 ones (gemm_hx.hpp)
+    const int rc = launch_gemm_hx(kid, batch, count, g, G, st);
+    if (rc != TEMP_E_UNSUPPORTED) return rc;
+  }
   BxPacked pk;
   const bool packed = bx_pack_batch(batch, count, g, st, &pk);
   const BxPacked* pp = packed ? &pk : nullptr;

@@ -82,13 +82,14 @@ int gemm_add_bias_act(int kid, int M, int N, int K, const float* A, int lda, con
 }
 
 int gemm_bias_multi(int kid, int count, const int* Ms, int N, int K, const float* const* As, const int32_t* const* a_idxs, int lda,
-                    const float* const* Bs, int ldb, const float* const* biases, float* const* outs, int ldo, hipStream_t st) {
+                    const float* const* Bs, int ldb, const float* const* biases, float* const* outs, int ldo, hipStream_t st,
+                    const unsigned* const* a_keys) {
   if (count <= 0 || count > PANEL_MAXP) return TEMP_E_BADARG;
   PanelBatch<EpiAddBiasAct> batch;
   for (int i = 0; i < PANEL_MAXP; ++i) {
     const int k = i < count ? i : 0;
     const EpiAddBiasAct epi{nullptr, 0, nullptr, biases[k], TEMP_ACT_NONE, outs[k], ldo};
-    batch.p[i] = PanelProblem<EpiAddBiasAct>{i < count ? Ms[k] : 0, As[k], a_idxs ? a_idxs[k] : nullptr, Bs[k], epi};
+    batch.p[i] = PanelProblem<EpiAddBiasAct>{i < count ? Ms[k] : 0, As[k], a_idxs ? a_idxs[k] : nullptr, Bs[k], epi, a_keys ? a_keys[k] : nullptr};
   }
   return launch_gemm_panel_multi(kid, batch, count, N, K, lda, ldb, 1, st);
 }
@@ -1180,6 +1181,9 @@ static const bool g_options_init = [] {
   return true;
 }();
 int option(int key) { return (key >= 0 && key < TEMP_OPT_COUNT) ? g_options[key].load(std::memory_order_relaxed) : -1; }
+static std::atomic<long long> g_hx_launches{0};
+void hx_count() { g_hx_launches.fetch_add(1, std::memory_order_relaxed); }
+long long hx_launches() { return g_hx_launches.load(std::memory_order_relaxed); }
 }  // namespace temp
 
 extern "C" {
@@ -1202,6 +1206,7 @@ int temp_set_option(int key, int value) {
 }
 int temp_get_option(int key) { return temp::option(key); }
 long long temp_scratch_refused(void) { return temp::bx_scratch_refused(); }
+long long temp_f16_launches(void) { return temp::hx_launches(); }
 
 const char* temp_error_string(int code) {
   switch (code) {
@@ -1634,9 +1639,35 @@ int temp_linear_t(int M, int N, int K, const float* A, int lda, const float* B, 
 }
 
 int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, void* stream) {
+  return temp_linear_keys(M, N, K, A, lda, nullptr, B, ldb, trans_b, C, ldc, stream);
+}
+
+int temp_linear_keys(int M, int N, int K, const float* A, int lda, const uint32_t* a_keys, const float* B, int ldb, int trans_b, float* C, int ldc,
+                     void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !B || (M > 0 && (!A || !C))) return TEMP_E_BADARG;
   if (ldc % 4) return TEMP_E_UNSUPPORTED;
-  return launch_gemm_panel(K_GEMM_LINEAR, M, N, K, A, lda, nullptr, B, ldb, trans_b, EpiPlainStore{C, ldc}, (hipStream_t)stream);
+  if (M <= 0) return TEMP_OK;
+  PanelBatch<EpiPlainStore> batch;
+  for (int i = 0; i < PANEL_MAXP; ++i) batch.p[i] = PanelProblem<EpiPlainStore>{0, nullptr, nullptr, nullptr, EpiPlainStore{C, ldc}};
+  batch.p[0] = PanelProblem<EpiPlainStore>{M, A, nullptr, B, EpiPlainStore{C, ldc}, a_keys};
+  return launch_gemm_panel_multi(K_GEMM_LINEAR, batch, 1, N, K, lda, ldb, trans_b, (hipStream_t)stream);
+}
+
+int temp_absmax_keys(int n, int d, const float* x, int ldx, uint32_t* row_keys, uint32_t* col_keys, void* stream) {
+  if (n < 0 || d <= 0 || (n > 0 && !x)) return TEMP_E_BADARG;
+  if (d % 4 || d > 256 || ldx % 4) return TEMP_E_UNSUPPORTED;
+  if (n == 0 || (!row_keys && !col_keys)) return TEMP_OK;
+  launch_absmax_keys(n, d, x, ldx, row_keys, col_keys, col_keys ? col_keys + d : nullptr, (hipStream_t)stream);
+  return launch_status();
+}
+size_t temp_keys_cols_size(int d) { return d > 0 ? (size_t)(1 + ABSMAX_BLOCKS) * d : 0; }
+
+int temp_gather_rows_keys(int n, int d, const float* table, const int32_t* idx, float* out, uint32_t* row_keys, uint32_t* col_keys, void* stream) {
+  if (n < 0 || d <= 0 || (n > 0 && (!table || !idx || !out))) return TEMP_E_BADARG;
+  if (d % 4 || d > 256) return TEMP_E_UNSUPPORTED;
+  if (n == 0) return TEMP_OK;
+  launch_gather_rows_keys(n, d, table, idx, out, row_keys, col_keys, col_keys ? col_keys + d : nullptr, (hipStream_t)stream);
+  return launch_status();
 }
 
 static int bilinear_query_args(int P, int d, int kind, const void* a, const void* b, const void* c, const void* e, const void* f) {

@@ -84,7 +84,10 @@ __device__ __forceinline__ void panel_store_b(const float4 (&reg)[PanelCfg<NT>::
 // launched together to double the waves in flight.
 #define PANEL_MAXP 4
 template <class Epi>
-struct PanelProblem { int M; const float* A; const int32_t* a_idx; const float* B; Epi epi; };
+struct PanelProblem {
+  int M; const float* A; const int32_t* a_idx; const float* B; Epi epi;
+  const unsigned* a_keys = nullptr;        // (gemm_hx.hpp) per SOURCE row of A the key of its largest magnitude; nullptr: the launcher takes them
+};
 template <class Epi>
 struct PanelBatch { PanelProblem<Epi> p[PANEL_MAXP]; };
 

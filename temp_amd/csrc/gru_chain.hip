@@ -689,6 +689,7 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
     int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
     if (rc) return rc;
     TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds_hx, st, a, gi, h, saved);
+    hx_count();
     return launch_status();
   }
   const size_t lds = chain_lds_fwd(a.D, a.max_steps);
@@ -718,6 +719,7 @@ static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float
     int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
     if (rc) return rc;
     TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds_hx, st, a, ups, saved, dgi, dgh, row_keys, col_keys);
+    hx_count();
     if (col_keys) TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_keys_reduce, dim3(ceil_div(4 * a.D, 32), a.n_rnn_keys), dim3(1024), 0, st, a.n_panels, 4 * a.D, col_keys + (size_t)a.n_rnn_keys * 4 * a.D, col_keys, a.panel, 4);
     return launch_status();
   }

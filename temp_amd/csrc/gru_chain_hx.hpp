@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
       int erow[PASSES];
       bool nxt[PASSES];
       float4 sr[PASSES], sz[PASSES], sn[PASSES], shn[PASSES], shd[PASSES];
-      unsigned ck[4] = {0u, 0u, 0u, 0u};                         // running maxima of this lane's column quad: dr, dz, dn_i, dn_h
+      unsigned ck[4][4] = {};                                    // running maxima of this lane's four columns of dr, dz, dn_i, dn_h
       auto prefetch = [&](int s) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
@@ -412,7 +412,10 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
 #undef TEMP_GATE
           const unsigned kr = cact ? hx_abs_bits4(dr_pre) : 0u, kz = cact ? hx_abs_bits4(dz_pre) : 0u;
           const unsigned kn = cact ? hx_abs_bits4(dn_pre) : 0u, kh = cact ? hx_abs_bits4(dhn) : 0u;
-          ck[0] = max(ck[0], kr); ck[1] = max(ck[1], kz); ck[2] = max(ck[2], kn); ck[3] = max(ck[3], kh);
+          if (cact) {
+            auto upd = [](unsigned (&m)[4], const float4 v) { m[0] = max(m[0], hx_abs_bits(v.x)); m[1] = max(m[1], hx_abs_bits(v.y)); m[2] = max(m[2], hx_abs_bits(v.z)); m[3] = max(m[3], hx_abs_bits(v.w)); };
+            upd(ck[0], dr_pre); upd(ck[1], dz_pre); upd(ck[2], dn_pre); upd(ck[3], dhn);
+          }
           const unsigned krz = max(kr, kz);
           const unsigned key_h = hx_wave_max(max(krz, kh));      // [dr dz dn_h]: this row of the recurrent product
           const float sc = hx_scale(key_h);
@@ -445,19 +448,18 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
         if (s > 0) prefetch(s - 1);            // issued behind the barrier (the matrix waves start at once), in flight while they
         __syncthreads();      // B             // run position s
       }
-      if (col_keys && cact) {                  // this lane's quad maxima -> the panel's column maxima (LDS), then one atomic per column
-        atomicMax(&ckey[colc], ck[0]); atomicMax(&ckey[D + colc], ck[1]); atomicMax(&ckey[2 * D + colc], ck[2]); atomicMax(&ckey[3 * D + colc], ck[3]);
+      if (col_keys && cact) {                  // this lane's column maxima -> the panel's (LDS integer maxima over the eight waves)
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicMax(&ckey[b4 * D + colc + e], ck[b4][e]);
       }
     }
     __syncthreads();
     if (col_keys) {
       // this panel's column maxima -> its own row of the partials (k_keys_reduce takes the maxima over a GRU's panels: same-address
-      // atomics from 250 workgroups on eight L2s cost ~20 us; a quad's maximum stands for its four columns -- a scale need only
-      // BOUND its column)
-      for (int i = tid; i < 4 * D; i += blockDim.x) {
-        const int blk = i / D, c = i - blk * D;
-        col_keys[((size_t)a.n_rnn_keys + p) * 4 * D + i] = ckey[blk * D + (c & ~3)];
-      }
+      // atomics from 250 workgroups on eight L2s cost ~20 us)
+      for (int i = tid; i < 4 * D; i += blockDim.x) col_keys[((size_t)a.n_rnn_keys + p) * 4 * D + i] = ckey[i];
       __syncthreads();
     }
   }

@@ -556,6 +556,7 @@ static int launch_gru_wgrad_hx(const WgArgs& a, const WgxKeys& keys, hipStream_t
   static const bool granted = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_wgrad_hx<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, wgx_lds_bytes(NT)) == hipSuccess;
   if (!granted) { (void)hipGetLastError(); return TEMP_E_UNSUPPORTED; }
   TEMP_LAUNCH(K_GRU_WGRAD, (k_gru_wgrad_hx<NT>), dim3(8 * a.per_xcd * a.P), dim3(WG_THREADS), wgx_lds_bytes(NT), st, a, keys);
+  hx_count();
   return TEMP_OK;
 }
 
@@ -730,6 +731,12 @@ int temp_gru_input_gates(int n, int d, int variant, const float* x, const float*
 
 int temp_gru_input_gates_gather_multi(int count, const int* ns, int d, int variant, const float* const* xs, const int32_t* const* x_idx,
                                       const float* const* w_ihs, const float* const* b_ihs, float* const* gis, void* stream) {
+  return temp_gru_input_gates_gather_multi_keys(count, ns, d, variant, xs, x_idx, nullptr, w_ihs, b_ihs, gis, stream);
+}
+
+int temp_gru_input_gates_gather_multi_keys(int count, const int* ns, int d, int variant, const float* const* xs, const int32_t* const* x_idx,
+                                           const uint32_t* const* x_keys, const float* const* w_ihs, const float* const* b_ihs, float* const* gis,
+                                           void* stream) {
   if (count < 0 || d <= 0 || (count > 0 && (!ns || !xs || !w_ihs || !b_ihs || !gis))) return TEMP_E_BADARG;
   if (variant != TEMP_GRU_TORCH && variant != TEMP_GRU_TYPE1) return TEMP_E_BADARG;
   if (d % 4) return TEMP_E_UNSUPPORTED;
@@ -739,7 +746,7 @@ int temp_gru_input_gates_gather_multi(int count, const int* ns, int d, int varia
   for (int i0 = 0; i0 < count; i0 += 4) {                    // four problems per launch
     const int c = count - i0 < 4 ? count - i0 : 4;
     const int rc = gemm_bias_multi(K_GEMM_GRU_GI, c, ns + i0, gi_w, d, xs + i0, x_idx ? x_idx + i0 : nullptr, d, w_ihs + i0, d, b_ihs + i0,
-                                   gis + i0, gi_w, (hipStream_t)stream);
+                                   gis + i0, gi_w, (hipStream_t)stream, x_keys ? x_keys + i0 : nullptr);
     if (rc) return rc;
   }
   return TEMP_OK;
@@ -903,12 +910,13 @@ size_t temp_gru_grads_g4_workspace(int count, const int* ns, int d) {
 int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
                       const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, void* workspace, size_t workspace_bytes,
                       void* stream) {
-  return temp_gru_grads_g4_keys(count, ns, d, xs, hdecs, g4s, w_ihs, d_xs, d_w, d_b, nullptr, nullptr, workspace, workspace_bytes, stream);
+  return temp_gru_grads_g4_keys(count, ns, d, xs, hdecs, g4s, w_ihs, d_xs, d_w, d_b, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,
                            const float* const* w_ihs, float* const* d_xs, float* d_w, float* d_b, const uint32_t* const* g4_row_keys,
-                           const uint32_t* const* g4_col_keys, void* workspace, size_t workspace_bytes, void* stream) {
+                           const uint32_t* const* g4_col_keys, const uint32_t* const* x_col_keys, void* workspace, size_t workspace_bytes,
+                           void* stream) {
   if (count <= 0 || count > WG_MAXG || !ns || !xs || !hdecs || !g4s || !w_ihs || !d_xs || !d_w || !d_b) return TEMP_E_BADARG;
   WgArgs a = {};
   if (!grads_g4_plan(count, ns, d, &a)) return TEMP_E_UNSUPPORTED;
@@ -930,7 +938,9 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
     WgxKeys keys = {};
     unsigned* xk = (unsigned*)(base + ws.xkeys);
     for (int i = 0; i < count; ++i) {
-      keys.g[i] = g4_col_keys[i]; keys.x[i] = xk + (size_t)i * d;
+      keys.g[i] = g4_col_keys[i];
+      if (x_col_keys && x_col_keys[i]) { keys.x[i] = x_col_keys[i]; continue; }     // (the caller's: e.g. from the gather that wrote x)
+      keys.x[i] = xk + (size_t)i * d;
       launch_absmax_keys(ns[i], d, xs[i], d, nullptr, xk + (size_t)i * d, xk + (size_t)count * d + (size_t)i * ABSMAX_BLOCKS * d, st);
     }
     switch (ceil_div(d, 32)) {
@@ -954,7 +964,6 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
     case 7: rc = launch_gru_wgrad<7>(a, st); break;
     default: rc = launch_gru_wgrad<8>(a, st); break;
   }
-  (void)g4_row_keys;
   if (rc) return rc;
   const int Ka = 3 * d, R0 = a.tail ? 256 * a.fb : Ka, S2 = a.tail ? a.S * a.P : 0;
   const long long quads = (long long)2 * count * Ka * (d / 4);
@@ -965,7 +974,7 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
   PanelBatch<EpiStore> batch;
   int nx = 0;
   for (int i = 0; i < count; ++i)
-    if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], g4s[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}};
+    if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], g4s[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}, (hx && g4_row_keys) ? g4_row_keys[i] : nullptr};
   for (int i = nx; i < PANEL_MAXP && nx > 0; ++i) { batch.p[i] = batch.p[0]; batch.p[i].M = 0; }
   if (nx > 0) rc = launch_gemm_panel_multi(K_GEMM_GRU_DX, batch, nx, d, 3 * d, 4 * d, d, 0, st);
   return rc ? rc : launch_status();

@@ -457,7 +457,7 @@ inline WgWs wg_workspace(const WgArgs& a) {
   w.part2 = w.bpart + align_up((size_t)a.S * np * Ka * sizeof(float), 256);
   w.bpart2 = w.part2 + align_up(S2 * np * Rt * a.d * sizeof(float), 256);
   w.xkeys = w.bpart2 + align_up(S2 * np * Rt * sizeof(float), 256);
-  w.total = w.xkeys + align_up((size_t)a.count * (1 + 256) * a.d * sizeof(unsigned), 256);      // [count][d] keys + [count][256 blocks][d] partials
+  w.total = w.xkeys + align_up((size_t)a.count * (1 + 1024) * a.d * sizeof(unsigned), 256);      // [count][d] keys + [count][ABSMAX_BLOCKS][d] partials (hx_pack.hpp)
   return w;
 }
 

@@ -5,7 +5,7 @@
 //
 // The sums run over the node rows, so the power-of-two scales are per COLUMN of each operand:
 //   g4      : col_keys[4d] of the GRU, written by the chain backward (k_gru_chain_bwd_hx: integer maxima, order-independent);
-//   x       : x_keys[d], the column maxima of the GRU's input rows (k_absmax_cols below, one pass over x, or the caller's);
+//   x       : x_keys[d], the column maxima of the GRU's input rows (k_absmax_keys below, one pass over x, or the caller's);
 //   hdec    : |dec . h| <= 1 -> the constant 2^14 (CHX_STATE_SCALE).
 // A staging thread owns the same columns in every slab, so its scales are registers; an output element is unscaled by
 // 1 / (scale of its g4 column . scale of its x / hdec column) when the slice's partial is stored -- the slices' partials are plain
@@ -313,53 +313,6 @@ __global__ void __launch_bounds__(WG_THREADS) k_gru_wgrad_hx(WgArgs a, WgxKeys k
     const WgOut out2 = {a.part2 + pslot2 * ((size_t)Rt * a.d), (size_t)Rt * a.d, a.bpart2 + pslot2 * Rt, (size_t)Rt, R0};
     wgx_body<NT, true>(a, gkeys, xkeys, wg_lds, G, m2, min(m2 + a.rows_per_tail, mbeg + a.rows_per_slice), out2, 2 * a.fb, t2.prod, t2.vt, G.x, G.hdec, true);
   }
-}
-
-// Magnitude keys of a row-major matrix X[n_rows][d] (d % 4 == 0, d <= 256) in one pass over X:
-//   row_keys[row] = key of max_c |X[row][c]|                 (nullable)
-//   col_part[b][c] = key bounding max |X[row][c]| over block b's rows (nullable; [gridDim.x][d]; a column quad shares its largest
-//                    key: a scale need only bound its column) -- k_keys_reduce takes the maxima over the blocks.  (Atomic maxima on
-//                    d addresses from every block serialise across the eight L2s: measured 165-315 us for 2 x 30 000 rows.)
-// A wave takes whole rows (lane q holds columns 4 q .. 4 q + 3: one coalesced row per load, four rows in flight), the row maximum is
-// one DPP reduction, the column maxima stay in the lane until the end.
-#define ABSMAX_BLOCKS 256
-__global__ void __launch_bounds__(256) k_absmax_keys(int n_rows, int d, const float* __restrict__ X, int ldx, unsigned* __restrict__ row_keys,
-                                                     unsigned* __restrict__ col_part) {
-  __shared__ unsigned sm[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int d4 = d >> 2;
-  const bool act = lane < d4;
-  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-  const float* xp = X + (act ? 4 * lane : 0);
-  unsigned ck = 0;
-  for (int r0 = gw; r0 < n_rows; r0 += 4 * nw) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int r = r0 + u * nw; v[u] = ld4(xp + (size_t)(r < n_rows ? r : r0) * ldx); }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = r0 + u * nw;
-      const unsigned k = act ? hx_abs_bits4(v[u]) : 0u;
-      if (r < n_rows) {                                           // (wave-uniform)
-        ck = max(ck, k);
-        if (row_keys) { const unsigned rk = hx_wave_max(k); if (lane == 0) row_keys[r] = rk; }
-      }
-    }
-  }
-  if (!col_part) return;
-  sm[wave][lane] = ck;
-  __syncthreads();
-  if (wave == 0 && act) {
-    ck = max(max(sm[0][lane], sm[1][lane]), max(sm[2][lane], sm[3][lane]));
-    *reinterpret_cast<hx_u32x4*>(col_part + (size_t)blockIdx.x * d + 4 * lane) = hx_u32x4{ck, ck, ck, ck};
-  }
-}
-inline int absmax_blocks(int n_rows) { const int b = ceil_div(n_rows, 64); return b < 1 ? 1 : (b > ABSMAX_BLOCKS ? ABSMAX_BLOCKS : b); }
-// col_keys [d] (nullable) needs col_part [absmax_blocks(n_rows)][d] as scratch
-inline void launch_absmax_keys(int n_rows, int d, const float* X, int ldx, unsigned* row_keys, unsigned* col_keys, unsigned* col_part, hipStream_t st) {
-  const int blocks = absmax_blocks(n_rows);
-  TEMP_LAUNCH(K_COLSUM, k_absmax_keys, dim3(blocks), dim3(256), 0, st, n_rows, d, X, ldx, row_keys, col_keys ? col_part : nullptr);
-  if (col_keys) TEMP_LAUNCH(K_COLSUM, k_keys_reduce, dim3(ceil_div(d, 32), 1), dim3(1024), 0, st, blocks, d, col_part, col_keys, (const int32_t*)nullptr, 0);
 }
 
 }  // namespace temp

@@ -168,13 +168,38 @@ class _GatherRowsFn(torch.autograd.Function):
         return d_table, None, None, None
 
 
+class _GatherRowsKeysFn(torch.autograd.Function):
+    """_GatherRowsFn that also returns the magnitude keys of its output (row keys [n], column keys [d]; int32, not differentiable):
+    the f16 products that read the gathered rows scale them by these (include/temp_amd.h: temp_gather_rows_keys)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, inverse, relu_table):
+        ctx.rows = table.shape[0]
+        ctx.inverse = inverse
+        ctx.relu_table = relu_table
+        ctx.save_for_backward(idx, table.detach()) if relu_table else ctx.save_for_backward(idx)
+        out, rk, ck = get_backend().gather_rows_keys(table, idx)
+        ctx.mark_non_differentiable(rk, ck)
+        return out, rk, ck
+
+    @staticmethod
+    def backward(ctx, d_out, _drk, _dck):
+        return _GatherRowsFn.backward(ctx, d_out)
+
+
+def gather_keys_supported(d):
+    """True when gather_rows(..., keys=True) is available and of use for width d on the installed backend."""
+    be = get_backend()
+    return hasattr(be, "gather_rows_keys") and be.keys_supported(d)
+
+
 def relu_gather_supported(table, inverse):
     """True when gather_rows(table, ., inverse, relu_table=True) is available for this table (a tensor, or its width)."""
     d = table if isinstance(table, int) else table.shape[1]
     return inverse is not None and d % 4 == 0 and d <= 256
 
 
-def gather_rows(table, idx, inverse=None, relu_table=False):
+def gather_rows(table, idx, inverse=None, relu_table=False, keys=False):
     """out[i] = table[idx[i]] (idx int32, -1 => zero row).  Backward: atomic scatter-add, or -- when the caller
     supplies `inverse` = gather_inverse(idx, rows) for a static index list -- a deterministic segment sum.
     relu_table=True: `table` is the ReLU output of the layer before and this gather is its ONLY consumer: the backward returns
@@ -182,6 +207,9 @@ def gather_rows(table, idx, inverse=None, relu_table=False):
     then run its own backward with grad_premasked=True (rgcn_layer)."""
     if relu_table and not relu_gather_supported(table, inverse):
         raise ValueError("relu_table needs a static inverse and a width the segment-sum kernels take")
+    if keys:                                              # -> (out, (row_keys, col_keys)): see _GatherRowsKeysFn
+        out, rk, ck = _GatherRowsKeysFn.apply(table, idx, inverse, bool(relu_table))
+        return out, (rk, ck)
     return _GatherRowsFn.apply(table, idx, inverse, bool(relu_table))
 
 

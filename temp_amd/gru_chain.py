@@ -286,7 +286,7 @@ class GruProgram:
 
 class _GruChainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_all, prog, lam, variant, n_rnn, want, *weights):
+    def forward(ctx, x_all, prog, lam, variant, n_rnn, want, x_keys, *weights):
         be = get_backend()
         dev = x_all.device
         d = x_all.shape[1]
@@ -299,6 +299,10 @@ class _GruChainFn(torch.autograd.Function):
         if CHAIN_KERNELS and hasattr(be, "gru_chain_fwd") and n_rnn <= _lib.CHAIN_MAX_RNN and be.gru_chain_supported(d):
             tabs = prog.chain_tables(dev, want)
         share = prog.gi_shared(dev) if tabs is not None else None        # gates once per distinct x row (chain kernels only)
+        # x_keys = (row keys [x rows], column keys [d]) of x_all from its producer (functional.gather_rows(keys=True)): the input-gate
+        # product and the weight gradients then run on the f16 pipe without a pass over x of their own
+        ctx.x_keys = x_keys if (x_keys is not None and tabs is not None) else None
+        gk = (lambda: dict(x_keys=[ctx.x_keys[0][g["x0"]:g["x1"]] for g in prog.groups])) if ctx.x_keys is not None else dict
         gi_index = None
         if share is not None:
             gi_index = share["gi_index"]
@@ -306,14 +310,14 @@ class _GruChainFn(torch.autograd.Function):
             cut = share["g0"] + [share["rows"]]
             be.gru_input_gates_multi([x_all[g["x0"]:g["x1"]] for g in prog.groups], [W[g["rnn"]][0] for g in prog.groups],
                                      [W[g["rnn"]][2] for g in prog.groups], variant, [gi[cut[i]:cut[i + 1]] for i in range(len(prog.groups))],
-                                     x_idx=share["rep"])
+                                     x_idx=share["rep"], **gk())
         else:
             gi = torch.empty(N, G, dtype=torch.float32, device=dev)
         if share is not None:
             pass
         elif len(prog.groups) > 1 and hasattr(be, "gru_input_gates_multi"):    # both directions' input gates in one launch
             be.gru_input_gates_multi([x_all[g["x0"]:g["x1"]] for g in prog.groups], [W[g["rnn"]][0] for g in prog.groups],
-                                     [W[g["rnn"]][2] for g in prog.groups], variant, [gi[g["h0"]:g["h1"]] for g in prog.groups])
+                                     [W[g["rnn"]][2] for g in prog.groups], variant, [gi[g["h0"]:g["h1"]] for g in prog.groups], **gk())
         else:
             for g in prog.groups:
                 w_ih, _, b_ih, _ = W[g["rnn"]]
@@ -389,6 +393,8 @@ class _GruChainFn(torch.autograd.Function):
             xsl = [slice(g["x0"], g["x1"]) for g in groups]
             hsl = [slice(g["h0"], g["h1"]) for g in groups]
             kw = dict(row_keys=[keys[0][b] for b in hsl], col_keys=[keys[1][g["rnn"]] for g in groups]) if keyed else {}
+            if keyed and ctx.x_keys is not None:
+                kw["x_col_keys"] = [ctx.x_keys[1]] * len(groups)   # (a bound over ALL rows of x_all bounds every group's rows)
             multi = be.gru_grads_g4([x_all[a] for a in xsl], [saved[4, b] for b in hsl], [g4[b] for b in hsl], [W[g["rnn"]][0] for g in groups],
                                     [d_x_all[a] for a in xsl], **kw)
             grads = [None] * (4 * ctx.n_rnn)
@@ -399,7 +405,7 @@ class _GruChainFn(torch.autograd.Function):
                     grads[4 * g["rnn"] + k] = gw[k]
             if not covered.all():
                 d_x_all[torch.from_numpy(~covered).to(dev)] = 0
-            return (d_x_all, None, None, None, None, None) + tuple(grads)
+            return (d_x_all, None, None, None, None, None, None) + tuple(grads)
         dgi = torch.empty(N, G, dtype=torch.float32, device=dev)
         dgh = torch.empty(N, 3 * d, dtype=torch.float32, device=dev)
         if ctx.tabs is not None:
@@ -450,7 +456,7 @@ class _GruChainFn(torch.autograd.Function):
                 grads[j] = gw[k] if grads[j] is None else grads[j] + gw[k]
         if not written.all():
             d_x_all[torch.from_numpy(~written).to(dev)] = 0
-        return (d_x_all, None, None, None, None, None) + tuple(grads)
+        return (d_x_all, None, None, None, None, None, None) + tuple(grads)
 
 
 def chain_kernels_usable(d, n_rnn=1):
@@ -475,8 +481,8 @@ def zero_state_program(n):
     return GruProgram([GruInstance(n, 0, 0, -1, np.full(n, -1, dtype=np.int32), np.zeros(n, dtype=np.float32))])
 
 
-def gru_chain(x_all, prog, rnns, lam, type1=False, want=None):
-    """Run a GruProgram.  `rnns`: list of modules holding (weight_ih, weight_hh, bias_ih, bias_hh)
+def gru_chain(x_all, prog, rnns, lam, type1=False, want=None, x_keys=None):
+    """Run a GruProgram.  x_keys: (row keys, column keys) of x_all from functional.gather_rows(keys=True), or None.  `rnns`: list of modules holding (weight_ih, weight_hh, bias_ih, bias_hh)
     (nn.GRU layer 0 or the type-1 GRUCell).  Returns H_all (prog.n_total, d), or -- with `want` = a list of instance ids --
     the states of just those instances (a tuple of (n_i, d) tensors; instances with 0 rows give empty tensors)."""
     ws = []
@@ -486,4 +492,4 @@ def gru_chain(x_all, prog, rnns, lam, type1=False, want=None):
         else:
             ws += [r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0]
     return _GruChainFn.apply(x_all, prog, float(lam), _lib.GRU_TYPE1 if type1 else _lib.GRU_TORCH, len(rnns),
-                             tuple(want) if want is not None else None, *ws)
+                             tuple(want) if want is not None else None, x_keys, *ws)

@@ -1,0 +1,237 @@
+"""Round 6: fp32 products as THREE f16 MFMA products of the scaled two-way operand split (temp_amd/csrc/split_f16.hpp) -- the
+magnitude keys, the keyed GEMM / input-gate / weight-gradient entry points and the window-chain kernels that hand the keys out.
+Bars are those of the six-product bf16 kernels they replace (tests/test_gpu_parity_r2.py: 1e-6 of sum |a||b| for a product over K,
+2e-6 for the chain's weight gradients), on the suite's wide data AND on range-stress data (row magnitudes 2^-30 .. 2^10, column
+magnitudes 2^-20 .. 2^5): the split is only as good as its scales.  (GRU step of GRRGCNLayer.forward, models/RRGCN.py:84;
+self-loop products models/RGCN.py:57.)"""
+import numpy as np
+import pytest
+import torch
+
+from temp_amd import _lib
+from temp_amd import backend as TB
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
+
+
+@pytest.fixture(autouse=True)
+def hip_backend():
+    TB.set_backend(None)
+    be = TB.get_backend()
+    assert be.name == "hip"
+    yield be
+    TB.set_backend(None)
+
+
+def _wide(shape, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * torch.exp(3.0 * torch.rand(shape, generator=g) - 1.5) * scale
+
+
+def _pow2(n, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.pow(2.0, torch.randint(lo, hi + 1, (n,), generator=g).double()).float()
+
+
+def _key(x):
+    """the key of a tensor's elements: fp32 bits with the sign cleared (as int64 for comparisons)"""
+    return (x.contiguous().view(torch.int32).to(torch.int64)) & 0x7FFFFFFF
+
+
+@pytest.mark.parametrize("n,d", [(30011, 200), (17, 200), (5000, 8), (4097, 256), (1, 36)])
+def test_absmax_and_gather_keys_exact_gpu(n, d, hip_backend):
+    """Row / column keys = the bits of the row's / column's largest magnitude, exactly; the keyed gather writes what temp_gather_rows writes (zero rows included) and keys its OUTPUT."""
+    be = hip_backend
+    g = torch.Generator().manual_seed(n + d)
+    x = (_wide((n, d), n, 1.0) * _pow2(n, -30, 10, d)[:, None]).to(DEV)
+    x[n // 2] = 0.0
+    rk, ck = be.absmax_keys(x)
+    torch.cuda.synchronize()
+    assert torch.equal(rk.to(torch.int64), _key(x.abs().max(dim=1).values))
+    assert torch.equal(ck.to(torch.int64), _key(x.abs().max(dim=0).values))
+    idx = torch.randint(-1, n, (2 * n + 3,), generator=g).to(torch.int32).to(DEV)
+    out, rk2, ck2 = be.gather_rows_keys(x, idx)
+    ref = be.gather_rows(x, idx)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(rk2.to(torch.int64), _key(ref.abs().max(dim=1).values))
+    assert torch.equal(ck2.to(torch.int64), _key(ref.abs().max(dim=0).values))
+    rk3, ck3 = be.absmax_keys(x)
+    assert torch.equal(rk, rk3) and torch.equal(ck, ck3)
+
+
+@pytest.mark.parametrize("M,K,N,trans_b", [
+    (20000, 200, 600, True),      # the input gates' shape: weights-resident kernel, five column groups
+    (20000, 600, 200, False),     # d_x: slab-staged kernel, one group of seven tiles
+    (33333, 208, 132, True),      # ragged row tile, five tiles
+    (17000, 72, 40, False),       # the shortest K the resident kernel takes, narrow output
+    (16384, 24, 36, False),       # K below the resident kernel's range, one and a half slabs
+    (16500, 200, 1000, True),     # wide output
+])
+@pytest.mark.parametrize("data", ["wide", "range"])
+def test_f16_split_gemm_vs_fp64_gpu(M, K, N, trans_b, data, hip_backend):
+    """temp_linear_keys (row keys from temp_absmax_keys) against fp64, relative to sum |a||b|: bar 1e-6, the bar of the bf16 split
+    (test_split_operand_gemm_vs_fp64); `range`: rows scaled by 2^-30 .. 2^10, weight columns by 2^-20 .. 2^5.  The launch must be
+    an f16 kernel (no silent bf16 route), and twice the same bits."""
+    be = hip_backend
+    lib = _lib.load()
+    a = _wide((M, K), 11, 1.0)
+    b = _wide((N, K) if trans_b else (K, N), 12, 0.2)
+    if data == "range":
+        a = a * _pow2(M, -30, 10, 5)[:, None]
+        cs = _pow2(N, -20, 5, 6)
+        b = b * (cs[:, None] if trans_b else cs[None, :])
+    a, b = a.to(DEV), b.to(DEV)
+    rk, _ = be.absmax_keys(a, cols=False) if K <= 256 and K % 4 == 0 else (None, None)
+    if rk is None:                                                    # wider than the key kernel: keys by torch (same definition)
+        rk = _key(a.abs().max(dim=1).values).to(torch.int32)
+    refused0, n0 = lib.temp_scratch_refused(), lib.temp_f16_launches()
+    out = be.linear(a, b, trans_b, a_keys=rk)
+    out2 = be.linear(a, b, trans_b, a_keys=rk)
+    torch.cuda.synchronize()
+    assert lib.temp_scratch_refused() == refused0 and lib.temp_f16_launches() == n0 + 2, "not an f16 launch"
+    assert torch.equal(out, out2)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (1400,))]).to(DEV)
+    bd = b.double().t() if trans_b else b.double()
+    ref = a[rows].double() @ bd
+    sabs = a[rows].double().abs() @ bd.abs()
+    err = ((out[rows].double() - ref).abs() / sabs.clamp_min(1e-300)).max().item()
+    assert err < 1e-6, "f16-split GEMM %dx%dx%d (%s): error %.3e of sum|a||b|" % (M, K, N, data, err)
+    # the same product without caller keys: the wide / deep ones take their own pass and give the same bits
+    if N >= 512 or K >= 512:
+        assert torch.equal(be.linear(a, b, trans_b), out)
+
+
+def test_f16_split_gemm_nonfinite_and_zero_rows_gpu(hip_backend):
+    """A non-finite weight poisons its column only; an all-zero row of A (key 0: the scale is clamped) gives an exact zero row;
+    a row with one infinite element is non-finite, its neighbours untouched."""
+    be = hip_backend
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 20000, 200, 600
+    a = (torch.rand(M, K, generator=g) + 0.5)
+    b = torch.randn(N, K, generator=g) * 0.3
+    a[77] = 0.0
+    a[99, 5] = float("inf")
+    a, b = a.to(DEV), b.to(DEV)
+    rk, _ = be.absmax_keys(a, cols=False)
+    clean = be.linear(a, b, True, a_keys=rk)
+    assert torch.equal(clean[77], torch.zeros(N, device=DEV))
+    assert not torch.isfinite(clean[99]).any()
+    keep = torch.ones(M, dtype=torch.bool, device=DEV)
+    keep[99] = False
+    assert torch.isfinite(clean[keep]).all()
+    bad = b.clone()
+    bad[3, 5], bad[77, 5], bad[N - 1, 5] = float("inf"), float("-inf"), float("nan")
+    got = be.linear(a, bad, True, a_keys=rk)
+    cols = torch.ones(N, dtype=torch.bool, device=DEV)
+    for c in (3, 77, N - 1):
+        assert not torch.isfinite(got[keep][:, c]).any()
+        cols[c] = False
+    assert torch.equal(got[keep][:, cols], clean[keep][:, cols])
+
+
+@pytest.mark.parametrize("rows,d", [((60000, 58000), 200), ((20000, 17003), 200), ((30001,), 200), ((9000, 8000, 7000, 6004), 200),
+                                     ((20000, 20000), 104), ((12000, 11000), 248)])
+@pytest.mark.parametrize("data", ["wide", "range"])
+def test_gru_grads_g4_keys_vs_fp64_gpu(rows, d, data, hip_backend):
+    """temp_gru_grads_g4_keys (f16 weight gradients + d_x) against fp64: every weight / bias gradient and d_x to 2e-6 of
+    sum |a||b| -- the bar of temp_gru_grads_g4 (tests/test_gpu_gate_grads.py) -- with the keys the chain backward would hand out
+    (per row max |[dr dz dn_i]|, per column of g4) and x column keys both from the caller and taken inside; `range`: g4 rows scaled
+    by 2^-30 .. 2^10, g4 and x columns by 2^-12 .. 2^6.  Bit-repeatable."""
+    be = hip_backend
+    lib = _lib.load()
+    gen = torch.Generator(device="cpu").manual_seed(17 + len(rows) + d)
+    mk = lambda n, w, s=1.0: (torch.randn(n, w, generator=gen) * s)
+    xs, hd = [mk(n, d) for n in rows], [(torch.rand(n, d, generator=gen) * 2 - 1) for n in rows]       # hdec: decayed GRU states, |.| <= 1
+    g4 = [mk(n, 4 * d, 0.1) * torch.exp(mk(n, 1) * 1.5) for n in rows]
+    if data == "range":
+        g4 = [t * _pow2(t.shape[0], -30, 10, 3 + i)[:, None] * _pow2(4 * d, -12, 6, 9 + i)[None, :] for i, t in enumerate(g4)]
+        xs = [t * _pow2(d, -12, 6, 21 + i)[None, :] for i, t in enumerate(xs)]
+    xs, hd, g4 = [t.to(DEV) for t in xs], [t.to(DEV) for t in hd], [t.to(DEV).contiguous() for t in g4]
+    ws = [((torch.rand(3 * d, d, generator=gen) - 0.5) * 0.3).to(DEV) for _ in rows]
+    assert be.gru_grads_g4_supported(list(rows), d, _lib.GRU_TORCH)
+    row_keys = [_key(t[:, :3 * d].abs().max(dim=1).values).to(torch.int32) for t in g4]
+    col_keys = [_key(t.abs().max(dim=0).values).to(torch.int32).contiguous() for t in g4]
+    x_col = [be.absmax_keys(t, rows=False)[1].contiguous() for t in xs]
+    dx = [torch.full((n, d), float("nan"), device=DEV) for n in rows]
+    if len(rows) == 4:
+        dx[2] = None
+    n0 = lib.temp_f16_launches()
+    got = be.gru_grads_g4(xs, hd, g4, ws, dx, row_keys=row_keys, col_keys=col_keys, x_col_keys=x_col)
+    dx2 = [None if t is None else torch.full_like(t, float("nan")) for t in dx]
+    again = be.gru_grads_g4(xs, hd, g4, ws, dx2, row_keys=row_keys, col_keys=col_keys)            # x column keys taken inside
+    assert lib.temp_f16_launches() >= n0 + 2 * (1 + (1 if any(t is not None for t in dx) else 0))      # weight gradients + d_x, twice
+    torch.cuda.synchronize()
+    for k, n in enumerate(rows):
+        G = g4[k].double()
+        dgi, dgh = G[:, :3 * d], torch.cat([G[:, :2 * d], G[:, 3 * d:]], 1)
+        want = (dgi.t() @ xs[k].double(), dgh.t() @ hd[k].double(), dgi.sum(0), dgh.sum(0))
+        scale = (dgi.abs().t() @ xs[k].abs().double(), dgh.abs().t() @ hd[k].abs().double(), dgi.abs().sum(0), dgh.abs().sum(0))
+        for a, b, w, sc in zip(got[k], again[k], want, scale):
+            assert a.shape == w.shape and torch.isfinite(a).all()
+            assert torch.equal(a, b), "bit-repeatable, and the same with the x keys taken inside"
+            assert float(((a.double() - w).abs() / sc.clamp_min(1e-300)).max()) < 2e-6
+        if dx[k] is not None:
+            assert torch.equal(dx[k], dx2[k])
+            wantx = dgi @ ws[k].double()
+            scx = dgi.abs() @ ws[k].abs().double()
+            assert float(((dx[k].double() - wantx).abs() / scx.clamp_min(1e-300)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("d", [200, 104, 32])
+def test_chain_bwd_keys_gpu(d, hip_backend):
+    """temp_gru_chain_bwd_g4_keys: the same g4 bit for bit, row keys = the bits of max |[dr dz dn_i]| of every row, column keys =
+    per GRU the bits of every column's largest magnitude over that GRU's rows; twice the same."""
+    from tests.chain_cases import random_program
+    from tests.test_gpu_gate_grads import _chain_forward
+    be = hip_backend
+    if not be.gru_chain_keys_supported(d):
+        pytest.skip("f16 chain kernels not selected for this width")
+    prog, _ = random_program(7, n_chain=2, K=6, E=300, lo=100, hi=300)
+    tabs, packs, b_hh, saved, N = _chain_forward(be, prog, d, 3)
+    up = (torch.randn(N, d, generator=torch.Generator().manual_seed(5)) * 0.3).to(DEV)
+    g4a = torch.full((N, 4 * d), float("nan"), device=DEV)
+    be.gru_chain_bwd_g4(tabs, saved, [up], 0.1, _lib.GRU_TORCH, packs, b_hh, g4a)
+    res = []
+    for _ in range(2):
+        g4 = torch.full((N, 4 * d), float("nan"), device=DEV)
+        keys = (torch.full((N,), -1, dtype=torch.int32, device=DEV), torch.full((2 + tabs["n_panels"], 4 * d), -1, dtype=torch.int32, device=DEV))
+        be.gru_chain_bwd_g4(tabs, saved, [up], 0.1, _lib.GRU_TORCH, packs, b_hh, g4, keys=keys)
+        res.append((g4, keys[0].clone(), keys[1][:2].clone()))
+    torch.cuda.synchronize()
+    g4, rk, ck = res[0]
+    assert torch.equal(g4, g4a)
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    assert torch.equal(rk.to(torch.int64), _key(g4[:, :3 * d].abs().max(dim=1).values))
+    for r, grp in enumerate(prog.groups):
+        rows = g4[grp["h0"]:grp["h1"]]
+        want = _key(rows.abs().max(dim=0).values)
+        assert torch.equal(ck[grp["rnn"]].to(torch.int64), want), r
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_input_gates_keys_vs_fp64_gpu(gather, hip_backend):
+    """temp_gru_input_gates_gather_multi_keys (both directions' gates in one launch, optional row gather, keys by SOURCE row)
+    against fp64: 1e-6 of sum |a||b| + the bias exactly added."""
+    be = hip_backend
+    g = torch.Generator().manual_seed(31)
+    d = 200
+    ns = (30000, 28000)
+    xs = [(_wide((n, d), 40 + i, 1.0) * _pow2(n, -20, 8, 50 + i)[:, None]).to(DEV) for i, n in enumerate(ns)]
+    w = [((torch.rand(3 * d, d, generator=g) - 0.5) * 0.3).to(DEV) for _ in ns]
+    b = [((torch.rand(3 * d, generator=g) - 0.5) * 0.3).to(DEV) for _ in ns]
+    keys = [be.absmax_keys(x, cols=False)[0] for x in xs]
+    idx = [torch.randint(0, n, (n // 2 + 17,), generator=g).to(torch.int32).to(DEV) for n in ns] if gather else None
+    rows = [t.shape[0] for t in idx] if gather else list(ns)
+    outs = [torch.full((r, 3 * d), float("nan"), device=DEV) for r in rows]
+    n0 = _lib.load().temp_f16_launches()
+    be.gru_input_gates_multi(xs, w, b, _lib.GRU_TORCH, outs, x_idx=idx, x_keys=keys)
+    assert _lib.load().temp_f16_launches() == n0 + 1
+    torch.cuda.synchronize()
+    for i in range(2):
+        a = xs[i][idx[i].long()] if gather else xs[i]
+        ref = a.double() @ w[i].double().t() + b[i].double()
+        sabs = a.double().abs() @ w[i].double().abs().t() + b[i].double().abs()
+        err = ((outs[i].double() - ref).abs() / sabs).max().item()
+        assert err < 1e-6, err
