@@ -685,10 +685,28 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
   static bool attr_hx = false;
   if (chain_hx(a.D)) {
     const size_t lds_hx = chain_lds_fwd_hx(a.D, a.max_steps);
-    auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW, 4>;
-    int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
-    if (rc) return rc;
-    TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds_hx, st, a, gi, h, saved);
+    // 8 + 8 waves (two matrix and two memory waves per SIMD, 128 registers each): a memory wave then has 28 stores + 12 loads
+    // in flight per position instead of 56 + 24 -- beyond the 63 a wave's counter can track, every further access waits for the oldest
+    constexpr int TPW8 = (TPW * 4 + 7) / 8 < 1 ? 1 : (TPW * 4 + 7) / 8;
+    const int cfg = (a.dbg >> 4) & 3;                          // development A/B: 0 = 8 + 8 waves, 1 = 4 + 4, 2 = 4 + 8
+    if (cfg == 1) {
+      auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW, 4, 4>;
+      int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
+      if (rc) return rc;
+      TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(512), lds_hx, st, a, gi, h, saved);
+    } else if (cfg == 2) {
+      static bool attr_48 = false;
+      auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW, 8, 4>;
+      int rc = chain_lds_attr(kernel, lds_hx, &attr_48);
+      if (rc) return rc;
+      TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(768), lds_hx, st, a, gi, h, saved);
+    } else {
+      static bool attr_88 = false;
+      auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW8, 8, 8>;
+      int rc = chain_lds_attr(kernel, lds_hx, &attr_88);
+      if (rc) return rc;
+      TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(1024), lds_hx, st, a, gi, h, saved);
+    }
     hx_count();
     return launch_status();
   }
@@ -715,10 +733,28 @@ static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float
   static bool attr_hx = false;
   if (chain_hx(a.D)) {
     const size_t lds_hx = chain_lds_bwd_hx(a.D, a.max_steps);
-    auto kernel = k_gru_chain_bwd_hx<VARIANT, TPWB, 8, G4>;
-    int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
-    if (rc) return rc;
-    TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds_hx, st, a, ups, saved, dgi, dgh, row_keys, col_keys);
+    constexpr int TPWB8 = (TPWB * 4 + 7) / 8 < 1 ? 1 : (TPWB * 4 + 7) / 8;
+    // 4 + 8 waves (168 registers); 8 + 8 waves with a ring of eight slabs -- two matrix waves per SIMD covering each other's L2
+    // latency -- leaves the memory role 128 registers: 31 spills, 374 us against 306 (development A/B: TEMP_DEBUG = 8192)
+    const int cfg = (a.dbg >> 4) & 3;
+    if (cfg == 3) {                                            // (development A/B: a ring of five slabs)
+      static bool attr_5 = false;
+      auto kernel = k_gru_chain_bwd_hx<VARIANT, TPWB, 8, G4, 4, 5>;
+      int rc = chain_lds_attr(kernel, lds_hx, &attr_5);
+      if (rc) return rc;
+      TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds_hx, st, a, ups, saved, dgi, dgh, row_keys, col_keys);
+    } else if (cfg != 2) {
+      auto kernel = k_gru_chain_bwd_hx<VARIANT, TPWB, 8, G4, 4, 4>;
+      int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
+      if (rc) return rc;
+      TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(768), lds_hx, st, a, ups, saved, dgi, dgh, row_keys, col_keys);
+    } else {
+      static bool attr_88 = false;
+      auto kernel = k_gru_chain_bwd_hx<VARIANT, TPWB8, 8, G4, 8, 8>;
+      int rc = chain_lds_attr(kernel, lds_hx, &attr_88);
+      if (rc) return rc;
+      TEMP_LAUNCH(K_GRU_CHAIN_BWD, kernel, dim3(a.n_panels), dim3(1024), lds_hx, st, a, ups, saved, dgi, dgh, row_keys, col_keys);
+    }
     hx_count();
     if (col_keys) TEMP_LAUNCH(K_GRU_CHAIN_PACK, k_keys_reduce, dim3(ceil_div(4 * a.D, 32), a.n_rnn_keys), dim3(1024), 0, st, a.n_panels, 4 * a.D, col_keys + (size_t)a.n_rnn_keys * 4 * a.D, col_keys, a.panel, 4);
     return launch_status();

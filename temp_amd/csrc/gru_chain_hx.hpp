@@ -24,7 +24,7 @@ namespace temp {
 
 struct ChainGeomHx {
   int NT, NS;        // forward: tiles of 32 gate columns (3d), slabs of 16 k (d)
-  int NTb, NSb;      // backward: tiles of 32 state columns (d), slabs of 16 k (3d) rounded up to a multiple of 4 (zero slabs)
+  int NTb, NSb;      // backward: tiles of 32 state columns (d), slabs of 16 k (3d) rounded up to a multiple of 8 (zero slabs)
   int lda, ldz;      // floats: forward product rows; backward gz / d_prev rows
   int ldp, ldpa;     // bytes: rows of the forward state planes / the backward gate-gradient planes (an odd number of 16-byte units)
   int ldh;           // floats: forward fp32 state rows
@@ -32,7 +32,7 @@ struct ChainGeomHx {
 __host__ __device__ inline ChainGeomHx chain_geom_hx(int D) {
   ChainGeomHx g;
   g.NT = (3 * D + 31) >> 5; g.NS = (D + 15) >> 4;
-  g.NTb = (D + 31) >> 5; g.NSb = (((3 * D + 15) >> 4) + 3) & ~3;
+  g.NTb = (D + 31) >> 5; g.NSb = (((3 * D + 15) >> 4) + 7) & ~7;      // (a multiple of the W ring of either wave configuration)
   g.lda = g.NT * 32 + 4; g.ldz = g.NTb * 32 + 4;
   g.ldp = g.NS * 32 + 16; g.ldpa = g.NSb * 32 + 16;
   g.ldh = g.NS * 16 + 4;
@@ -55,9 +55,10 @@ inline size_t chain_hx_pack_floats(int D) {
 }
 
 // ---- forward --------------------------------------------------------------------------------------------------------
-template <int VARIANT, int TPW, int MW>
-__global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a, const float* __restrict__ gi, float* __restrict__ H,
-                                                                     float* __restrict__ saved) {
+// NMW matrix waves (4 or 8: one or two per SIMD) with TPW = ceil(NT / NMW) tiles each, MW memory waves
+template <int VARIANT, int TPW, int MW, int NMW = 4>
+__global__ void __launch_bounds__(64 * (NMW + MW)) k_gru_chain_fwd_hx(ChainArgs a, const float* __restrict__ gi, float* __restrict__ H,
+                                                                       float* __restrict__ saved) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PASSES = CH_SLOTS / MW;
   const int D = a.D, D4 = D >> 2;
@@ -88,13 +89,13 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
     if (tid < ns) flagb[tid] = a.sinfo[4 * (size_t)(s0 + tid)];
     __syncthreads();
 
-    if (wave < 4) {
+    if (wave < NMW) {
       // ------------------------------------------------------------------ matrix role: pure MFMA + fragment reads
       const int li = lane & 31, hh = lane >> 5;
       bool tval[TPW];
       int tidx[TPW];
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) { tidx[j] = wave + 4 * j; tval[j] = tidx[j] < NT; if (!tval[j]) tidx[j] = NT - 1; }
+      for (int j = 0; j < TPW; ++j) { tidx[j] = wave + NMW * j; tval[j] = tidx[j] < NT; if (!tval[j]) tidx[j] = NT - 1; }
       f32x16 acc[TPW];
 #pragma unroll
       for (int j = 0; j < TPW; ++j)
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
       // W_hh planes of TWO slabs in registers (sets 0 / 1 alternate along the slab walk; a set is refilled with the slab two ahead as
       // soon as its plane has had its last product: L after round 0, H after round 2).
       const hx_u32x4* wp = reinterpret_cast<const hx_u32x4*>(R.wf);
-      hx_u32x4 w[2][2][TPW] = {};                               // [set][plane h, l][tile]
+      hx_u32x4 w[NMW > 4 ? 1 : 2][2][TPW] = {};                 // [set][plane h, l][tile]
       auto wload = [&](hx_u32x4 (&wr)[TPW], int sl, int pl) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
@@ -113,12 +114,12 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
       // per block, so results stay bit-repeatable)
       const int rot = (a.dbg & 64) ? 0 : (int)(blockIdx.x >> 3) % NS;
       wload(w[0][0], rot, 0); wload(w[0][1], rot, 1);
-      wload(w[1][0], rot + 1 < NS ? rot + 1 : 0, 0); wload(w[1][1], rot + 1 < NS ? rot + 1 : 0, 1);
+      if constexpr (NMW <= 4) { wload(w[1][0], rot + 1 < NS ? rot + 1 : 0, 0); wload(w[1][1], rot + 1 < NS ? rot + 1 : 0, 1); }
       const char* hrow = hpl + (size_t)li * ldp + 16 * hh;       // + plane * 32 ldp + 32 slab: k = 16 slab + 8 hh .. + 7 of track li
       const int pl1 = CH_SLOTS * ldp;
       for (int s = 0; s < ns; ++s) {
         const int flags = flagb[s];
-        if (flags & 1) {
+        if ((flags & 1) && !(a.dbg & 1)) {                      // (dbg bit 0: development ablation, no products)
           hx_u32x4 FH = *reinterpret_cast<const hx_u32x4*>(hrow + 32 * rot), FL = *reinterpret_cast<const hx_u32x4*>(hrow + pl1 + 32 * rot), NH, NL;
           // one slab out of register set SET (a compile-time index: the sets are registers, never addressed); sl1: the next slab
           // (its fragments are read now), sl2: the slab the set is refilled with
@@ -145,12 +146,17 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
           // position j + 2 -- or, behind the walk's last two slabs, with walk position j & 1 of the NEXT position (set 0 always holds
           // the even walk positions, also for an odd slab count: the loads behind the last slabs have the whole gate phase to land).
           auto at = [&](int j) { const int v = rot + j; return v < NS ? v : v - NS; };
+          if constexpr (NMW > 4) {
+            // two matrix waves per SIMD cover each other's L2 latency: ONE register set, refilled in place with the next slab
+            for (int j = 0; j < NS; ++j) slab(std::integral_constant<int, 0>(), at(j + 1 < NS ? j + 1 : 0), at(j + 1 < NS ? j + 1 : 0));
+          } else {
           int j = 0;
           for (; j + 1 < NS; j += 2) {
             slab(std::integral_constant<int, 0>(), at(j + 1), at(j + 2 < NS ? j + 2 : 0));
             slab(std::integral_constant<int, 1>(), at(j + 2 < NS ? j + 2 : 0), at(j + 3 < NS ? j + 3 : 1));
           }
           if (j < NS) slab(std::integral_constant<int, 0>(), at(0), at(0));
+          }
           // lane (li, hh) owns track li and, per register quad qq, gate columns tile*32 + 8qq + 4hh .. +3
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
       }
     } else {
       // ------------------------------------------------------------------ memory role
-      const int mw = wave - 4, c4 = lane, col = 4 * c4;
+      const int mw = wave - NMW, c4 = lane, col = 4 * c4;
       const bool cact = c4 < D4;
       const int colc = cact ? col : 0;
       const float4 bhr = ld4(R.b_hh + colc), bhz = ld4(R.b_hh + D + colc), bhn = ld4(R.b_hh + 2 * D + colc);
@@ -179,7 +185,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
         for (int ps = 0; ps < PASSES; ++ps) {
           const int e = tabb[s * CH_SLOTS + ps * MW + mw];
           erow[ps] = e;
-          const bool ok = e >= 0 && cact;
+          const bool ok = e >= 0 && cact && !(a.dbg & 4);       // (dbg bit 2: development ablation, no input-gate loads)
           const int er = e & CH_ROW_MASK;
           const float* src = gi + (ok ? (size_t)(a.gi_index ? a.gi_index[er] : er) * G + col : 0);
           if (VARIANT == TEMP_GRU_TORCH) { g0[ps] = ld4(src); g1[ps] = ld4(src + (ok ? D : 0)); g2[ps] = ld4(src + (ok ? 2 * D : 0)); }
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
           *reinterpret_cast<hx_u32x2*>(hdst) = SH;
           *reinterpret_cast<hx_u32x2*>(hdst + CH_SLOTS * ldp) = SL;
           const size_t o = row * D + col;
+          if (a.dbg & 2) continue;                              // (development ablation: no global stores)
           if (flags & 2) st4(H + o, h4);
           st4(saved + o, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
           st4(saved + plane + o, make_float4(o_z[0], o_z[1], o_z[2], o_z[3]));
@@ -251,8 +258,9 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_fwd_hx(ChainArgs a,
 // ---- backward -------------------------------------------------------------------------------------------------------
 // row_keys (nullable): [N_total] key of max |[dr dz dn_i]| of every row; col_keys (nullable): [n_rnn + n_panels][4d]: the kernel writes row
 // n_rnn + p (panel p's column maxima), k_keys_reduce (hx_pack.hpp) reduces them into rows 0 .. n_rnn - 1
-template <int VARIANT, int TPWB, int MW, int G4>
-__global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a, ChainUps ups, const float* __restrict__ saved,
+// NMW matrix waves (4 or 8: one or two per SIMD) with TPWB = ceil(NTb / NMW) tiles each; RING = slabs of W_hh held in registers
+template <int VARIANT, int TPWB, int MW, int G4, int NMW = 4, int RING = 4>
+__global__ void __launch_bounds__(64 * (NMW + MW)) k_gru_chain_bwd_hx(ChainArgs a, ChainUps ups, const float* __restrict__ saved,
                                                                      float* __restrict__ dgi, float* __restrict__ dgh,
                                                                      unsigned* __restrict__ row_keys, unsigned* __restrict__ col_keys) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -286,13 +294,13 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
     if (tid < ns) flagb[tid] = a.sinfo[4 * (size_t)(s0 + tid)];
     __syncthreads();
 
-    if (wave < 4) {
+    if (wave < NMW) {
       // ------------------------------------------------------------------ matrix role: d_prev = (dgh . W_hh + dh*z) * decay
       const int li = lane & 31, hh = lane >> 5;
       bool tval[TPWB];
       int tidx[TPWB];
 #pragma unroll
-      for (int j = 0; j < TPWB; ++j) { tidx[j] = wave + 4 * j; tval[j] = tidx[j] < NTb; if (!tval[j]) tidx[j] = NTb - 1; }
+      for (int j = 0; j < TPWB; ++j) { tidx[j] = wave + NMW * j; tval[j] = tidx[j] < NTb; if (!tval[j]) tidx[j] = NTb - 1; }
       f32x16 acc[TPWB];
 #pragma unroll
       for (int j = 0; j < TPWB; ++j)
@@ -301,27 +309,27 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
       // W_hh planes of FOUR slabs in registers (a slab is only 3 TPWB products): set q holds slab 4 i + q and is refilled with slab
       // 4 i + q + 4 as its planes fall free -- three slabs (18 products at TPWB = 2) of L2 latency cover.  NSb is a multiple of 4.
       const hx_u32x4* wp = reinterpret_cast<const hx_u32x4*>(R.wb);
-      hx_u32x4 wh[4][TPWB] = {}, wl[4][TPWB] = {};
+      hx_u32x4 wh[RING][TPWB] = {}, wl[RING][TPWB] = {};
       auto wload = [&](hx_u32x4 (&w)[TPWB], int sl, int pl) {
 #pragma unroll
         for (int j = 0; j < TPWB; ++j)
           if (tval[j]) w[j] = wp[((size_t)(sl * NTb + tidx[j]) * 2 + pl) * 64 + lane];
       };
-      const int rot = (a.dbg & 64) ? 0 : 4 * ((int)(blockIdx.x >> 3) % (NSb >> 2));     // per-block start of the slab walk
+      const int rot = (a.dbg & 64) ? 0 : RING * ((int)(blockIdx.x >> 3) % (NSb / RING));     // per-block start of the slab walk (NSb % RING == 0)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { wload(wh[q], rot + q, 0); wload(wl[q], rot + q, 1); }
+      for (int q = 0; q < RING; ++q) { wload(wh[q], rot + q, 0); wload(wl[q], rot + q, 1); }
       const char* arow = apl + (size_t)li * ldpa + 16 * hh;      // + plane * 32 ldpa + 32 slab
       const int pl1 = CH_SLOTS * ldpa;
       for (int s = ns - 1; s >= 0; --s) {
         const int flags = flagb[s];
         __syncthreads();      // A: the split gate gradients / dh*z / row scales of position s are in LDS
-        if (flags & 1) {
+        if ((flags & 1) && !(a.dbg & 1)) {                      // (dbg bit 0: development ablation, no products)
           hx_u32x4 FH = *reinterpret_cast<const hx_u32x4*>(arow + 32 * rot), FL = *reinterpret_cast<const hx_u32x4*>(arow + pl1 + 32 * rot), NH, NL;
-          for (int j = 0, sl = rot; j < NSb; j += 4) {
-            const int base2 = sl + 4 < NSb ? sl + 4 : 0;          // (after the walk's last group: the first group of the NEXT position)
+          for (int j = 0, sl = rot; j < NSb; j += RING) {
+            const int base2 = sl + RING < NSb ? sl + RING : 0;          // (after the walk's last group: the first group of the NEXT position)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int sn = (q < 3) ? sl + q + 1 : base2;
+            for (int q = 0; q < RING; ++q) {
+              const int sn = (q < RING - 1) ? sl + q + 1 : base2;
               NH = *reinterpret_cast<const hx_u32x4*>(arow + 32 * sn);
               NL = *reinterpret_cast<const hx_u32x4*>(arow + pl1 + 32 * sn);
               const hx_f16x8 ah = hx_frag(FH), al = hx_frag(FL);
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
       }
     } else {
       // ------------------------------------------------------------------ memory role: gate gradients
-      const int mw = wave - 4, c4 = lane, col = 4 * c4;
+      const int mw = wave - NMW, c4 = lane, col = 4 * c4;
       const bool cact = c4 < D4;
       const int colc = cact ? col : 0;
       int erow[PASSES];
@@ -376,7 +384,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
           int en = -1;
           if (s + 1 < ns) en = tabb[(s + 1) * CH_SLOTS + slot];
           nxt[ps] = en >= 0 && (en & CH_HAS_PREV);
-          const bool ok = e >= 0 && cact;
+          const bool ok = e >= 0 && cact && !(a.dbg & 4);       // (dbg bit 2: development ablation, every lane reads row 0)
           const size_t row = ok ? (size_t)(e & CH_ROW_MASK) : 0;
           const float* src = saved + row * D + (ok ? col : 0);
           sr[ps] = ld4(src); sz[ps] = ld4(src + plane); sn[ps] = ld4(src + 2 * plane); shn[ps] = ld4(src + 3 * plane);
@@ -412,9 +420,17 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
 #undef TEMP_GATE
           const unsigned kr = cact ? hx_abs_bits4(dr_pre) : 0u, kz = cact ? hx_abs_bits4(dz_pre) : 0u;
           const unsigned kn = cact ? hx_abs_bits4(dn_pre) : 0u, kh = cact ? hx_abs_bits4(dhn) : 0u;
-          if (cact) {
-            auto upd = [](unsigned (&m)[4], const float4 v) { m[0] = max(m[0], hx_abs_bits(v.x)); m[1] = max(m[1], hx_abs_bits(v.y)); m[2] = max(m[2], hx_abs_bits(v.z)); m[3] = max(m[3], hx_abs_bits(v.w)); };
-            upd(ck[0], dr_pre); upd(ck[1], dz_pre); upd(ck[2], dn_pre); upd(ck[3], dhn);
+          if (cact && col_keys) {
+            if constexpr (NMW > 4) {                             // (128 registers per wave: the column maxima go to LDS at once)
+              auto upl = [&](int b4, const float4 v) {
+                unsigned* k = ckey + b4 * D + col;
+                atomicMax(k, hx_abs_bits(v.x)); atomicMax(k + 1, hx_abs_bits(v.y)); atomicMax(k + 2, hx_abs_bits(v.z)); atomicMax(k + 3, hx_abs_bits(v.w));
+              };
+              upl(0, dr_pre); upl(1, dz_pre); upl(2, dn_pre); upl(3, dhn);
+            } else {
+              auto upd = [](unsigned (&m)[4], const float4 v) { m[0] = max(m[0], hx_abs_bits(v.x)); m[1] = max(m[1], hx_abs_bits(v.y)); m[2] = max(m[2], hx_abs_bits(v.z)); m[3] = max(m[3], hx_abs_bits(v.w)); };
+              upd(ck[0], dr_pre); upd(ck[1], dz_pre); upd(ck[2], dn_pre); upd(ck[3], dhn);
+            }
           }
           const unsigned krz = max(kr, kz);
           const unsigned key_h = hx_wave_max(max(krz, kh));      // [dr dz dn_h]: this row of the recurrent product
@@ -432,7 +448,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
             const unsigned key_x = hx_wave_max(max(krz, kn));    // [dr dz dn_i]: this row of d_x = g4[:, :3d] . W_ih
             if (lane == 0) row_keys[row] = key_x;
           }
-          if (cact) {
+          if (cact && !(a.dbg & 2)) {                           // (dbg bit 1: development ablation, no global stores)
             if constexpr (G4) {
               const size_t b4 = row * 4 * D + col;
               st4(dgi + b4, dr_pre); st4(dgi + b4 + D, dz_pre); st4(dgi + b4 + 2 * D, dn_pre); st4(dgi + b4 + 3 * D, dhn);
@@ -448,7 +464,7 @@ __global__ void __launch_bounds__(256 + 64 * MW) k_gru_chain_bwd_hx(ChainArgs a,
         if (s > 0) prefetch(s - 1);            // issued behind the barrier (the matrix waves start at once), in flight while they
         __syncthreads();      // B             // run position s
       }
-      if (col_keys && cact) {                  // this lane's column maxima -> the panel's (LDS integer maxima over the eight waves)
+      if (col_keys && cact && NMW <= 4) {      // this lane's column maxima -> the panel's (LDS integer maxima over the eight waves)
 #pragma unroll
         for (int b4 = 0; b4 < 4; ++b4)
 #pragma unroll

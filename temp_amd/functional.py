@@ -180,10 +180,13 @@ class _GatherRowsKeysFn(torch.autograd.Function):
         ctx.save_for_backward(idx, table.detach()) if relu_table else ctx.save_for_backward(idx)
         out, rk, ck = get_backend().gather_rows_keys(table, idx)
         ctx.mark_non_differentiable(rk, ck)
+        ctx.set_materialize_grads(False)                  # (else autograd zero-fills "gradients" for the two key tensors every step)
         return out, rk, ck
 
     @staticmethod
     def backward(ctx, d_out, _drk, _dck):
+        if d_out is None:
+            return None, None, None, None
         return _GatherRowsFn.backward(ctx, d_out)
 
 
