@@ -54,19 +54,25 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guid
 # divided by six.  temp_set_option(TEMP_OPT_MFMA_BF16X3, 0) (or TEMP_MFMA=f32 in the environment at load time) keeps them on the
 # fp32 MFMA kernels (round-1 arithmetic); MFMA_MODE is read from the library in main().
 BX_KERNELS = ("k_gemm_panel", "k_gemm_tn_bx", "k_gru_chain_fwd", "k_gru_chain_bwd", "k_gru_wgrad")   # (k_gemm_tn itself is the fp32 MFMA kernel of the small products; the chain kernels run the split products when d % 8 == 0)
-MFMA_MODE = "bf16x3"
+# Round 6: where an f16 kernel exists (temp_amd/csrc/split_f16.hpp) the same products run as THREE f16 MFMA products of the scaled
+# two-way split -- the window-chain kernels, the GRU weight gradients, the input-gate and d_x GEMMs (their operands arrive with
+# magnitude keys from their producers); the roof of those kernels is the 16-bit pipe divided by three.  The self-loop products and
+# the loop-weight gradient (no keys yet) stay on the six-product bf16 kernels.
+HX_KERNELS = ("k_gru_chain_fwd", "k_gru_chain_bwd", "k_gru_wgrad", "k_gemm_panel<gru_gi>", "k_gemm_panel<gru_dx>")
+MFMA_MODE = "bf16x3"           # "f32" | "bf16x3" | "f16x2" (main() reads the library's options)
 OPT_MFMA_BF16X3 = 0            # include/temp_amd.h: TEMP_OPT_MFMA_BF16X3
+OPT_MFMA_F16X2 = 9             # include/temp_amd.h: TEMP_OPT_MFMA_F16X2
 CPU_THREADS = 16               # cpu_baseline leg (--cpu-threads)
 
 
 def profile_file(stem):
     """profiles/<round>_<stem> of the latest round that has it (static counter summaries: rocprofv3 --pmc runs cannot be taken from
     inside this process)."""
-    for tag in ("r05", "r04"):
+    for tag in ("r06", "r05", "r04"):
         p = os.path.join(REPO, "profiles", "%s_%s" % (tag, stem))
         if os.path.exists(p):
             return p
-    return os.path.join(REPO, "profiles", "r05_%s" % stem)
+    return os.path.join(REPO, "profiles", "r06_%s" % stem)
 
 
 
@@ -193,22 +199,35 @@ MFMA_KERNELS = ("k_gemm_panel", "k_gemm_tn", "k_gru_fwd", "k_gru_chain_fwd", "k_
 
 
 def traced_steps(step_fn, n_steps, lib):
+    """Per-kernel HIP-event times of n_steps eager steps.  One trace per step; ONE EXTRA first step is run and dropped (on a fresh
+    box the first eager launch of a kernel pays its code-object load: round 5's driver line showed k_gru_wgrad at 2.68 ms in a
+    3-step mean against 0.218 ms), and every kernel's per-step time is the MEDIAN over the kept steps."""
     cap = 20000
     from temp_amd import _lib
-    _lib.check(lib.temp_trace_begin(cap), "temp_trace_begin")
-    for _ in range(n_steps):
+    per_step = []
+    for it in range(n_steps + 1):
+        _lib.check(lib.temp_trace_begin(cap), "temp_trace_begin")
         step_fn()
-    ids = (ctypes.c_int32 * cap)()
-    ms = (ctypes.c_float * cap)()
-    n = ctypes.c_int32(0)
-    _lib.check(lib.temp_trace_end(ids, ms, cap, ctypes.byref(n)), "temp_trace_end")
-    agg = {}
-    for i in range(n.value):
-        name = lib.temp_trace_kernel_name(ids[i]).decode()
-        a = agg.setdefault(name, [0, 0.0])
-        a[0] += 1
-        a[1] += ms[i]
-    return {k: dict(launches_per_step=v[0] / n_steps, ms_per_step=v[1] / n_steps, avg_ms=v[1] / v[0]) for k, v in agg.items()}
+        ids = (ctypes.c_int32 * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = ctypes.c_int32(0)
+        _lib.check(lib.temp_trace_end(ids, ms, cap, ctypes.byref(n)), "temp_trace_end")
+        if it == 0:
+            continue
+        agg = {}
+        for i in range(n.value):
+            name = lib.temp_trace_kernel_name(ids[i]).decode()
+            a = agg.setdefault(name, [0, 0.0])
+            a[0] += 1
+            a[1] += ms[i]
+        per_step.append(agg)
+    out = {}
+    for k in sorted({k for agg in per_step for k in agg}):
+        launches = float(np.median([agg.get(k, [0, 0.0])[0] for agg in per_step]))
+        tot = float(np.median([agg.get(k, [0, 0.0])[1] for agg in per_step]))
+        if launches > 0:
+            out[k] = dict(launches_per_step=launches, ms_per_step=tot, avg_ms=tot / launches)
+    return out
 
 
 def _oracle_batch_runner(om, cfg, w, gd, seed=7):
@@ -890,7 +909,7 @@ def main():
     assert TB.get_backend().name == "hip"
     global MFMA_MODE, CPU_THREADS
     CPU_THREADS = max(1, a.cpu_threads)
-    MFMA_MODE = "bf16x3" if lib.temp_get_option(OPT_MFMA_BF16X3) else "f32"
+    MFMA_MODE = ("f16x2" if lib.temp_get_option(OPT_MFMA_F16X2) else "bf16x3") if lib.temp_get_option(OPT_MFMA_BF16X3) else "f32"
 
     if a.workload == "S-hbm-window":                 # the HBM-regime window on its own (profiling runs): same object as extra.hbm_window
         if rank == 0:
@@ -1076,7 +1095,13 @@ def main():
             sec = tr[name]["ms_per_step"] * 1e-3
             if name.startswith(MFMA_KERNELS) and cst["flops"]:
                 ach = cst["flops"] / sec / 1e12                     # algorithmic (fp32) flops
-                if MFMA_MODE == "bf16x3" and name.startswith(BX_KERNELS):
+                if MFMA_MODE == "f16x2" and name.startswith(HX_KERNELS):
+                    peak = MFMA_BF16_PEAK_TFLOPS / 3.0
+                    r = dict(bound="mfma", kernel=name, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
+                             pipe="f16 MFMA, three products per fp32 product (scaled 2-way operand split): peak = %.0f / 3" % MFMA_BF16_PEAK_TFLOPS,
+                             executed_f16_tflops=3.0 * ach, frac_of_fp32_mfma_peak=ach / MFMA_F32_PEAK_TFLOPS,
+                             frac_of_bf16x3_roof=ach / (MFMA_BF16_PEAK_TFLOPS / 6.0))
+                elif MFMA_MODE in ("bf16x3", "f16x2") and name.startswith(BX_KERNELS):
                     peak = MFMA_BF16_PEAK_TFLOPS / 6.0
                     r = dict(bound="mfma", kernel=name, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
                              pipe="bf16 MFMA, six products per fp32 product (exact 3-way operand split): peak = %.0f / 6" % MFMA_BF16_PEAK_TFLOPS,
@@ -1095,20 +1120,33 @@ def main():
             r["algorithmic_per_launch"] = cst["flops" if r["bound"] == "mfma" else "bytes"] / max(tr[name]["launches_per_step"], 1e-9)
             r.update(avg_launch_ms=tr[name]["avg_ms"], launches_per_step=tr[name]["launches_per_step"], share_of_kernel_time=tr[name]["ms_per_step"] / total_ms)
             if r["bound"] == "hbm" and r["traffic"] is not None and r["traffic"] < 0.5 * r["algorithmic_per_launch"]:
+                r["bound"] = "lds-issue"
+                r["frac_of_byte_model"] = r["frac"]
+                r["frac_from_counters"] = (r["traffic"] / (tr[name]["avg_ms"] * 1e-3) / 1e9) / HBM_PEAK_GBS
                 r["note"] = ("the byte model charges every edge a row from HBM; this kernel stages a member snapshot's rows in LDS once and the "
                              "counters see %.0f %% of the model's bytes: it is bound by the LDS walk's instruction issue (HISTORY.md section 3), "
                              "not by HBM -- read `frac` as work rate against the survey's model, `traffic` as what HBM saw"
                              % (100.0 * r["traffic"] / r["algorithmic_per_launch"]))
             return r
 
-        roof = kernel_roof(dom)
-        # the kernels next in line (the first three shares are within a few per cent of each other at this shape)
+        # roofline.kernel = the LONGEST single launch among the MFMA kernels (a fixed rule: the entry cannot change its meaning by
+        # which family happens to lead the time shares; an edge kernel whose counters see a fraction of the byte model is LDS-issue
+        # bound and is listed under `others` with bound = "lds-issue" and frac_from_counters)
+        mf = [k for k in tr if k.startswith(MFMA_KERNELS) and costs.get(k, {}).get("flops")]
+        prim = max(mf, key=lambda k: tr[k]["avg_ms"]) if mf else dom
+        roof = kernel_roof(prim)
+        if roof["bound"] == "mfma":
+            # the same launch against HBM with SURVEY 8d's bytes: a persistent chain kernel is bound by neither pipe alone
+            roof["hbm_view"] = dict(algorithmic_bytes_per_launch=costs[prim]["bytes"] / max(tr[prim]["launches_per_step"], 1e-9),
+                                    achieved_gbs=costs[prim]["bytes"] / (tr[prim]["ms_per_step"] * 1e-3) / 1e9,
+                                    frac=costs[prim]["bytes"] / (tr[prim]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        roof["largest_share_kernel"] = dom
         roof["others"] = [{k: v for k, v in kernel_roof(n).items() if k not in ("pipe", "traffic_source", "traffic_unit")}
-                          for n in sorted(tr, key=lambda k: -tr[k]["ms_per_step"])[1:4] if n in costs]
+                          for n in sorted(tr, key=lambda k: -tr[k]["ms_per_step"])[:5] if n in costs and n != prim][:4]
         roof.update(traced_kernel_ms_per_step=total_ms,
                     timing="HIP events around every launch (library event trace on the launch stream) of %d EAGER steps run right after the "
-                           "timed region; inside the HIP-graph replays of the timed region the same kernel runs 5-10 %% faster "
-                           "(rocprofv3, profiles/r05_bench_kernel_stats.md and r05_step_sequence.txt)" % a.trace_steps)
+                           "timed region (one more first step dropped, medians over the kept steps); inside the HIP-graph replays of the timed region the same kernel runs 5-10 %% faster "
+                           "(rocprofv3, profiles/r06_bench_kernel_stats.md and r06_step_sequence.txt)" % a.trace_steps)
         # whole-step view against the HBM roofline with SURVEY 8d's byte model (2 RGCN layers + 1 GRU cell, fwd+bwd, fp32, int32 ids):
         #   per edge 2*(12D+24) B, per RGCN node row 2*(20D+16) B, per GRU row 32D+4 B.
         # (a) as the survey states it, per snapshot-edge VISIT (every visit pays its RGCN bytes), and
@@ -1158,7 +1196,7 @@ def main():
             print("bench: training-loop probe failed (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
 
     fp32_ms = None
-    if rank == 0 and world == 1 and not sharded and MFMA_MODE == "bf16x3" and not a.no_fp32_mfma_compare:
+    if rank == 0 and world == 1 and not sharded and MFMA_MODE in ("bf16x3", "f16x2") and not a.no_fp32_mfma_compare:
         # the same step with every product on the fp32 MFMA kernels: one library switch, same process, same batch, graph re-captured
         try:
             lib.temp_set_option(OPT_MFMA_BF16X3, 0)
@@ -1199,12 +1237,23 @@ def main():
                                        else ("hip-graph replay" if graph is not None else "eager")),
                                rccl_ranks=(dist.get_world_size() if dist is not None else 0),
                                train_loop=loop,
-                               mfma=("every large fp32 product (panel GEMMs, weight gradients, the window-chain kernels' W_hh products) on the bf16 "
+                               mfma=("large fp32 products on the 16-bit matrix pipes with fp32-equivalent accuracy: three f16 MFMA products of the scaled "
+                                     "2-way operand split (split_f16.hpp) in the window-chain kernels, the GRU weight gradients, the input-gate and "
+                                     "d_x GEMMs; six bf16 products of the exact 3-way split (gemm_bx.hpp) in the self-loop products and the loop-weight "
+                                     "gradient; small products (< 16384 rows) on the fp32 MFMA pipe" if MFMA_MODE == "f16x2" else
+                                     "every large fp32 product (panel GEMMs, weight gradients, the window-chain kernels' W_hh products) on the bf16 "
                                      "matrix pipe as six products of an exact 3-way operand split (fp32-equivalent accuracy, gemm_bx.hpp); "
                                      "small products (< 16384 rows) on the fp32 MFMA pipe" if MFMA_MODE == "bf16x3"
                                      else "fp32 MFMA everywhere (TEMP_OPT_MFMA_BF16X3 = 0)"),
                                fp32_mfma_ms_per_step=fp32_ms, ms_per_step_400_replays=long_ms),
                    roofline=roof, cpu_baseline=cpu, north_star_sharded=ns_result, extra=extra)
+        # the end-to-end figures a reader of the line's TAIL must see (the driver keeps the parsed head and the last characters):
+        # value_distinct and the training loop (a NEW batch every step) also as the LAST keys of `extra`
+        if not sharded:
+            ex = dict(out["extra"] or {})
+            ex["value_distinct"] = out["value_distinct"]
+            ex["train_loop"] = loop
+            out["extra"] = ex
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
         # that the JSON line is the LAST (and, with claim_stdout, the only) line of stdout
         sys.stdout.flush()
