@@ -156,6 +156,8 @@ def algorithmic_costs(wb, D, bi, S=2):
     nv = wb.n_node_visits
     c["k_gather_rows"] = dict(bytes=(n + nv) * (4 + 2 * row), flops=0)
     c["k_scatter_add_rows"] = dict(bytes=(n + nv) * (4 + 3 * row), flops=0)
+    c["k_segment_sum_rows"] = dict(bytes=(n + nv) * (4 + 2 * row), flops=0)      # the deterministic gather adjoints (traced as k_scatter_add_rows until round 6)
+    c["k_absmax_keys"] = dict(bytes=0, flops=0)
     c["k_rgcn_agg<fwd>"] = dict(bytes=2 * (E * (row + 8) + n * row), flops=2 * E * 2 * D * S)
     c["k_rgcn_agg<dx>"] = dict(bytes=2 * (E * (row + 12) + n * row), flops=2 * E * 2 * D * S)
     c["k_rgcn_dw"] = dict(bytes=2 * (E * (2 * row + 12)), flops=2 * E * 2 * D * S)

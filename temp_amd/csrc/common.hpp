@@ -127,7 +127,7 @@ enum KernelId {
   K_RGCN_AGG_FWD = 0, K_RGCN_AGG_DX, K_RGCN_DW, K_FIXUP, K_GEMM_LOOP_FWD, K_GEMM_LOOP_DX, K_GEMM_TN, K_REDUCE_SLICES, K_COLSUM,
   K_RELU_BWD, K_GRU_FWD, K_GRU_BWD_GATES, K_GEMM_GRU_DX, K_GEMM_GRU_DPREV, K_GATHER_ROWS, K_SCATTER_ADD, K_DECAY_GRAD, K_COPY,
   K_GEMM_ISO, K_GEMM_GRU_GI, K_GEMM_LINEAR, K_GATHER_CE, K_SA_ATTN_FWD, K_SA_ATTN_BWD, K_GRU_CHAIN_FWD, K_GRU_CHAIN_BWD,
-  K_GRU_CHAIN_PACK, K_BX_PACK, K_GEMM_TN_BX8, K_GEMM_TN_BX, K_GRU_WGRAD, K_COUNT
+  K_GRU_CHAIN_PACK, K_BX_PACK, K_GEMM_TN_BX8, K_GEMM_TN_BX, K_GRU_WGRAD, K_SEGMENT_SUM, K_KEYS, K_COUNT
 };
 int trace_open(int kernel_id, hipStream_t st);       // -> slot or -1
 void trace_close(int slot, hipStream_t st);

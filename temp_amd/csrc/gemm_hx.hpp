@@ -262,7 +262,7 @@ static inline bool hx_fill_keys(PanelBatch<Epi>& batch, int count, int K, int ld
     koff += align_up((size_t)batch.p[i].M * 4, 256);
     int blocks = ceil_div(batch.p[i].M, 16);
     if (blocks > 2048) blocks = 2048;
-    TEMP_LAUNCH(K_COLSUM, k_absmax_rows_idx, dim3(blocks), dim3(256), 0, st, batch.p[i].M, K, batch.p[i].A, lda, batch.p[i].a_idx, keys);
+    TEMP_LAUNCH(K_KEYS, k_absmax_rows_idx, dim3(blocks), dim3(256), 0, st, batch.p[i].M, K, batch.p[i].A, lda, batch.p[i].a_idx, keys);
     batch.p[i].a_keys = keys;
   }
   for (int i = count; i < PANEL_MAXP; ++i) batch.p[i].a_keys = batch.p[0].a_keys;

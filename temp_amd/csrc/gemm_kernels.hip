@@ -1194,7 +1194,7 @@ const char* temp_trace_kernel_name(int id) {
                                 "k_gru_bwd_gates", "k_gemm_panel<gru_dx>", "k_gemm_panel<gru_dprev>", "k_gather_rows",
                                 "k_scatter_add_rows", "k_decay_grad", "k_copy", "k_gemm_panel<isolated>", "k_gemm_panel<gru_gi>",
                                 "k_gemm_panel<linear>", "k_gather_ce", "k_sa_attn_fwd", "k_sa_attn_bwd", "k_gru_chain_fwd", "k_gru_chain_bwd",
-                                "k_gru_chain_pack", "k_bx_pack", "k_gemm_tn_bx8", "k_gemm_tn_bx", "k_gru_wgrad"};
+                                "k_gru_chain_pack", "k_bx_pack", "k_gemm_tn_bx8", "k_gemm_tn_bx", "k_gru_wgrad", "k_segment_sum_rows", "k_absmax_keys"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1384,7 +1384,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_segment_sum_rows_blk2(int n_seg,
 int segment_sum_rows2(int n_seg, const int32_t* seg_ptr, const int32_t* order, int d_a, const float* src_a, const int32_t* mask_a, float* out_a,
                       int d_b, const float* src_b, float* out_b, hipStream_t st, long long n_rows_hint) {
   if (d_a % 4 == 0 && d_b % 4 == 0 && d_a <= 256 && d_b <= 256 && n_rows_hint >= 96LL * n_seg) {
-    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk2<16>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(16 * 64), 0, st, n_seg, d_a / 4, d_b / 4, seg_ptr, order,
+    TEMP_LAUNCH(K_SEGMENT_SUM, k_segment_sum_rows_blk2<16>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(16 * 64), 0, st, n_seg, d_a / 4, d_b / 4, seg_ptr, order,
                 (const float4*)src_a, mask_a, (const float4*)src_b, (float4*)out_a, (float4*)out_b);
     return launch_status();
   }
@@ -1546,25 +1546,25 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
   const float4* relu_of = (const float4*)relu_src;           // out = (relu_src > 0) ? sum : 0, element by element (nullable)
   const int S = segsum_splits(n_seg, n_rows_hint);
   if (S > 1 && d4 <= 64 && ws && ws_bytes >= segment_sum_rows_workspace(n_seg, n_rows_hint, d)) {
-    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_part, dim3(S, n_seg), dim3(256), 0, st, S, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)ws);
-    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_fin, dim3(ceil_div((long long)n_seg * d4, 256)), dim3(256), 0, st, n_seg, S, d4, (const float4*)ws, relu_of, (float4*)out);
+    TEMP_LAUNCH(K_SEGMENT_SUM, k_segment_sum_part, dim3(S, n_seg), dim3(256), 0, st, S, d4, seg_ptr, order, (const float4*)src, row_mask, (float4*)ws);
+    TEMP_LAUNCH(K_SEGMENT_SUM, k_segment_sum_fin, dim3(ceil_div((long long)n_seg * d4, 256)), dim3(256), 0, st, n_seg, S, d4, (const float4*)ws, relu_of, (float4*)out);
     return launch_status();
   }
   if (S <= 1 && segsum_pieces(n_seg, n_rows_hint, d4) && ws && ws_bytes >= segment_sum_rows_workspace(n_seg, n_rows_hint, d)) {
     const int n_pieces = (int)ceil_div(n_rows_hint, (long long)SEGSUM_PIECE);
-    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_pieces, dim3(ceil_div(n_pieces, 4)), dim3(256), 0, st, n_seg, (int)n_rows_hint, d4, seg_ptr, order,
+    TEMP_LAUNCH(K_SEGMENT_SUM, k_segment_sum_pieces, dim3(ceil_div(n_pieces, 4)), dim3(256), 0, st, n_seg, (int)n_rows_hint, d4, seg_ptr, order,
                 (const float4*)src, row_mask, relu_of, (float4*)out, (float4*)ws);
     int grid = ceil_div(n_seg, 4);
     if (grid > 2048) grid = 2048;
-    TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_pieces_fin, dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, (const float4*)ws, relu_of, (float4*)out);
+    TEMP_LAUNCH(K_SEGMENT_SUM, k_segment_sum_pieces_fin, dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, (const float4*)ws, relu_of, (float4*)out);
     return launch_status();
   }
   if (n_rows_hint > 32LL * n_seg && d4 <= 64) {
     if (n_rows_hint >= 96LL * n_seg)
-      TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk<16>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(16 * 64), 0, st, n_seg, d4, seg_ptr, order,
+      TEMP_LAUNCH(K_SEGMENT_SUM, k_segment_sum_rows_blk<16>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(16 * 64), 0, st, n_seg, d4, seg_ptr, order,
                   (const float4*)src, row_mask, relu_of, (float4*)out);
     else
-      TEMP_LAUNCH(K_SCATTER_ADD, k_segment_sum_rows_blk<4>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(4 * 64), 0, st, n_seg, d4, seg_ptr, order,
+      TEMP_LAUNCH(K_SEGMENT_SUM, k_segment_sum_rows_blk<4>, dim3(n_seg < 4096 ? n_seg : 4096), dim3(4 * 64), 0, st, n_seg, d4, seg_ptr, order,
                   (const float4*)src, row_mask, relu_of, (float4*)out);
     return launch_status();
   }
@@ -1573,9 +1573,9 @@ int segment_sum_rows(int n_seg, int d, const int32_t* seg_ptr, const int32_t* or
   if (grid > 2048) grid = 2048;
 #define TEMP_SEGSUM(L)                                                                                                                      \
   do {                                                                                                                                      \
-    if (short_segs) TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows_short<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order,      \
+    if (short_segs) TEMP_LAUNCH(K_SEGMENT_SUM, (k_segment_sum_rows_short<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order,      \
                                 (const float4*)src, row_mask, relu_of, (float4*)out);                                                       \
-    else TEMP_LAUNCH(K_SCATTER_ADD, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src,   \
+    else TEMP_LAUNCH(K_SEGMENT_SUM, (k_segment_sum_rows<L>), dim3(grid), dim3(256), 0, st, n_seg, d4, seg_ptr, order, (const float4*)src,   \
                      row_mask, relu_of, (float4*)out);                                                                                      \
   } while (0)
   if (d4 <= 8) TEMP_SEGSUM(8); else if (d4 <= 16) TEMP_SEGSUM(16); else if (d4 <= 32) TEMP_SEGSUM(32); else TEMP_SEGSUM(64);

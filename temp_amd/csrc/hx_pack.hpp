@@ -289,8 +289,8 @@ inline int absmax_blocks(int n_rows) { const int b = ceil_div(n_rows, 32); retur
 // col_keys [d] (nullable) needs col_part [absmax_blocks(n_rows)][d] as scratch
 static inline void launch_absmax_keys(int n_rows, int d, const float* X, int ldx, unsigned* row_keys, unsigned* col_keys, unsigned* col_part, hipStream_t st) {
   const int blocks = absmax_blocks(n_rows);
-  TEMP_LAUNCH(K_COLSUM, (k_absmax_keys<false>), dim3(blocks), dim3(256), 0, st, n_rows, d, X, ldx, (const int32_t*)nullptr, (float*)nullptr, row_keys, col_keys ? col_part : nullptr);
-  if (col_keys) TEMP_LAUNCH(K_COLSUM, k_keys_reduce, dim3(ceil_div(d, 32), 1), dim3(1024), 0, st, blocks, d, col_part, col_keys, (const int32_t*)nullptr, 0);
+  TEMP_LAUNCH(K_KEYS, (k_absmax_keys<false>), dim3(blocks), dim3(256), 0, st, n_rows, d, X, ldx, (const int32_t*)nullptr, (float*)nullptr, row_keys, col_keys ? col_part : nullptr);
+  if (col_keys) TEMP_LAUNCH(K_KEYS, k_keys_reduce, dim3(ceil_div(d, 32), 1), dim3(1024), 0, st, blocks, d, col_part, col_keys, (const int32_t*)nullptr, 0);
 }
 
 // out[r] = table[idx[r]] (idx < 0: zero row) with the keys of the OUTPUT: row_keys [n] (nullable), col_keys [d] + col_part scratch (nullable)

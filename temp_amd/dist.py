@@ -440,7 +440,9 @@ class ShardedStep:
         self.d_local = torch.zeros(self.n_local, d, dtype=torch.float32, device=dev)
         self.out = None
         self.graphs = None
-        if graphs and dev.type == "cuda":
+        # (a step whose self-loop dropout draws is NOT captured: the masks' seeds are drawn on the host per call and would be
+        #  baked into the graphs -- every replay the same mask; rgcn.RGCNLayer._drop refuses a capture for the same reason)
+        if graphs and dev.type == "cuda" and not enc.model._dropout_active():
             self._capture()
 
     # -- the three parts (they communicate through attributes so that a capture and an eager call are the same code) ------

@@ -485,8 +485,10 @@ class DynamicRGCN(TKG_Module):
         model is the unidirectional GRU encoder with BOTH layers recurrent (the reference's default flags), where the entity
         classes of _all_maps carry over to the first layer as well."""
         enc = self.ent_encoder
+        # (not while the self-loop dropout draws: the reference runs forward_isolated per window, each with its own mask,
+        #  models/DynamicRGCN.py:56-64 -- one isolated pass for all windows would share ONE mask; the per-visit rule of _share_visits)
         plain = (not enc.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
-                 and getattr(enc.layer_2, "num_layers", 1) == 1)
+                 and getattr(enc.layer_2, "num_layers", 1) == 1 and not self._dropout_active())
         if wb.batched:
             return plain
         return (plain and self.use_batched_path and not isinstance(wb.plan, tuple) and isinstance(enc.layer_1, GRRGCNLayer)

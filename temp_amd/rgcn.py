@@ -61,6 +61,12 @@ class RGCNLayer(nn.Module):
         """(p, seed) of the self-loop dropout for THIS call (models/RGCN.py:57-59, training mode only), else None.
         The kernels derive the keep mask from the seed, so the autograd node only remembers the pair."""
         if self.dropout_p > 0 and self.training:
+            # The seed is drawn on the host and reaches the kernels by value: a HIP graph captured now would replay THIS mask on
+            # every launch (dropout would stop regularising, silently).  Refuse: callers that capture (bench GraphStep,
+            # dist.ShardedStep) fall back to eager launches for a model whose dropout draws.
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("temp_amd: the self-loop dropout (p > 0, training) draws a host seed per call and cannot be captured "
+                                   "into a HIP graph -- run this step eagerly")
             return (self.dropout_p, int(torch.randint(0, 2 ** 62, (1,)).item()))
         return None
 

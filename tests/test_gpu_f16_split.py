@@ -235,3 +235,98 @@ def test_input_gates_keys_vs_fp64_gpu(gather, hip_backend):
         sabs = a.double().abs() @ w[i].double().abs().t() + b[i].double().abs()
         err = ((outs[i].double() - ref).abs() / sabs).max().item()
         assert err < 1e-6, err
+
+
+def test_dropout_step_is_not_captured_gpu(hip_backend):
+    """the self-loop dropout draws its seed on the host, per call; captured into a HIP graph the seed would be baked in
+    and every replay would apply ONE mask.  The layer refuses the capture (callers fall back to eager launches); eager calls
+    keep drawing a new mask each time (models/RGCN.py:57-59)."""
+    from types import SimpleNamespace
+    from temp_amd.rgcn import RGCNLayer
+    import torch.nn.functional as F
+    d = 32
+    args = SimpleNamespace(inv_temperature=0.1, learnable_lambda=False, impute=False)
+    layer = RGCNLayer(args, d, d, 4, 4, [0, 1], activation=F.relu, self_loop=True, dropout=0.5).to(DEV)
+    layer.train()
+    e = torch.randn(300, d, device=DEV)
+    a, b = layer.conv_isolated(e), layer.conv_isolated(e)
+    assert not torch.equal(a, b), "two eager calls drew the same mask"
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="cannot be captured"):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            layer.conv_isolated(e)
+    torch.cuda.synchronize()
+    layer.eval()
+    g2 = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        layer.conv_isolated(e)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g2, capture_error_mode="thread_local"):                     # (eval: no draw, capture is fine)
+        out = layer.conv_isolated(e)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("name", ["config1_static", "config3_post_ensemble"])
+def test_config_step_bit_repeatable_and_atomic_free_gpu(name, hip_backend):
+    """Verdict r5 item 5: the training steps of BASELINE configs 1 (StaticRGCN, baselines/StaticRGCN.py:36-89) and 3 (BiGRRGCN
+    --post-ensemble, models/BiRRGCN.py:259-318) take no atomic scatter -- every gather adjoint is a segment sum over a static
+    inverse (traced as k_segment_sum_rows; until round 6 they shared the trace name of k_scatter_add_rows) -- and two runs of the
+    step give every gradient bit for bit."""
+    import argparse
+    import ctypes
+    import bench
+    lib = _lib.load()
+    a = argparse.Namespace(no_graph=True)
+    r = bench.other_config(name, a, DEV, lib, 10)
+    names = {k for k in r["top_kernels"]}
+    assert "k_scatter_add_rows" not in names, names
+
+    # two eager steps of the same prepared batch, gradients compared bit for bit; every launch traced
+    from temp_amd import synthetic
+    from temp_amd.sampling import CorruptTriples
+    import numpy as np
+    if name == "config1_static":
+        from temp_amd.static_rgcn import StaticRGCN
+        w2 = synthetic.workload("S-icews14", seed=0)
+        m2 = StaticRGCN(bench.make_args(w2, "SRGCN"), w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(DEV)
+        m2.sample_rng = np.random.default_rng(2)
+        m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+        wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3))
+        with torch.no_grad():
+            m2.run_loss(wb2)
+        cand = m2._last_plan[1]
+        run = lambda: m2.run_loss(wb2, cand)
+    else:
+        from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN
+        w2 = synthetic.workload("S-icews0515", seed=0)
+        args = bench.make_args(w2, "BiGRRGCN")
+        args.post_ensemble = True
+        m2 = PostEnsembleBiDynamicRGCN(args, w2["num_ents"], w2["num_rels"], w2["snapshots"], w2["snapshots"], w2["snapshots"]).to(DEV)
+        m2.sample_rng = np.random.default_rng(2)
+        m2.corrupter = CorruptTriples(m2.args, w2["snapshots"], seed=5)
+        wb2 = m2.prepare(synthetic.default_targets(w2["num_times"], w2["L"], w2["bsz"], 3), w2["L"], True)
+        fixed = [tuple(x.to(DEV) for x in smp) for smp in m2.draw_samples(wb2)]
+        wts = [(torch.full((smp[0].shape[0], 1), 0.5, device=DEV), torch.full((smp[0].shape[0], 1), 0.5, device=DEV)) for smp in fixed]
+        run = lambda: m2.run_loss(wb2, fixed, wts)
+    grads = []
+    for it in range(2):
+        for p in m2.parameters():
+            p.grad = None
+        lib.temp_trace_begin(4096)
+        loss = run()
+        loss.backward()
+        ids, ms, cnt = (ctypes.c_int32 * 4096)(), (ctypes.c_float * 4096)(), ctypes.c_int32(0)
+        lib.temp_trace_end(ids, ms, 4096, ctypes.byref(cnt))
+        traced = {lib.temp_trace_kernel_name(ids[i]).decode() for i in range(cnt.value)}
+        assert "k_scatter_add_rows" not in traced and "k_segment_sum_rows" in traced, traced
+        torch.cuda.synchronize()
+        grads.append((loss.detach().clone(), [None if p.grad is None else p.grad.clone() for p in m2.parameters()]))
+    assert torch.equal(grads[0][0], grads[1][0])
+    for g0, g1 in zip(grads[0][1], grads[1][1]):
+        assert (g0 is None) == (g1 is None)
+        if g0 is not None:
+            assert torch.equal(g0, g1)
