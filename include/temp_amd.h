@@ -496,10 +496,11 @@ int temp_scatter_add_rows(int n, int d, const float* src, const int32_t* idx, fl
 /* Deterministic adjoint of a gather with a STATIC index list (the ids of a prepared window batch):
  *   out[s] = sum_{j in [seg_ptr[s], seg_ptr[s+1])} src[order[j]]      out: [n_seg, d] fully written (empty segment = 0)
  * seg_ptr [n_seg+1] / order [n_rows] = the gather indices grouped by table row (built once on the host;
- * ids < 0 are left out, so n_rows may be smaller than the gather).
+ * ids < 0 are left out, so n_rows may be smaller than the gather).  n_rows must be EXACTLY the length of `order`
+ * (= seg_ptr[n_seg]): the piece kernels size their partials from it (a smaller value would drop the trailing rows).
  * No atomics; d % 4 == 0, d <= 256.  Tables with very long segments (>= 512 rows per segment on average, e.g. the
  * relation table under the loss) are reduced in two deterministic stages through `workspace`; segmentations of 2-32 rows per
- * segment on average are summed over fixed 64-row pieces of `order` (skew-proof: a hub entity's thousands of rows are many
+ * segment on average are summed over fixed 32-row pieces of `order` (skew-proof: a hub entity's thousands of rows are many
  * pieces, not one wave's loop) with the piece partials in `workspace`
  * (temp_segment_sum_rows_workspace bytes; 0 for the other shapes; NULL falls back to one wave / one block per segment). */
 size_t temp_segment_sum_rows_workspace(int n_seg, int n_rows, int d);

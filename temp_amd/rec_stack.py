@@ -80,6 +80,14 @@ class _RecStackFn(torch.autograd.Function):
         # output gradient; ONE pass over the union afterwards forms the weight gradients (per position it took a relation-weight
         # kernel, its fix-up, two reductions, a column sum and three additions)
         hoist = ctx.g_union is not None and hasattr(be, "rgcn_bwd_dh")
+        if hoist:
+            # the ONE pass over the union reads H1 / DZ by the union's node order: it must be the program's row order, position by
+            # position (a mismatch would give wrong d_W silently)
+            gu_n = getattr(ctx.g_union, "n_nodes", None)
+            gu_n = gu_n if gu_n is not None else getattr(ctx.g_union, "n", None)
+            assert gu_n is None or int(gu_n) == prog.n_total, "rec_stack: union graph rows != program rows"
+            sizes = [getattr(g, "n_nodes", getattr(g, "n", None)) for g in graphs]
+            assert all(s is None or int(s) == it.n for s, it in zip(sizes, prog.inst)), "rec_stack: position graphs do not match the program's instances"
         relu = act == ACTS["relu"]
         any_drop = any(dr is not None for dr in drops)
         assert not any_drop or all(dr is not None for dr in drops), "dropout draws at every position or at none"

@@ -14,3 +14,8 @@ TEMP_BENCH_FORCE_DIST=1 python bench.py $F > gpurun_out/bf_dist.json 2> gpurun_o
 python bench.py > gpurun_out/bf_default.json 2> gpurun_out/bf_default.err; python -c "
 import json
 d=json.loads(open('gpurun_out/bf_default.json').read().strip().splitlines()[-1]); print('default', d['ms_per_step'], d['value'], d['config']['train_loop'])"
+# N > 1 pre-flight on ONE GPU (verdict r5 item 8): eight processes, HIP kernels + gloo collectives, both shard modes; a functional
+# check of the launch / exchange / all-reduce path (3-4 minutes), not a measurement
+TEMP_BENCH_DIST_BACKEND=gloo timeout 1200 python bench.py --gpus 8 --steps 3 --warmup 1 --train-loop-steps 0 --no-cpu-baseline --no-extras --no-fp32-mfma-compare > gpurun_out/bf_gloo8.json 2> gpurun_out/bf_gloo8.err; python -c "
+import json
+d=json.loads(open('gpurun_out/bf_gloo8.json').read().strip().splitlines()[-1]); print('gloo x8', d['n_gpus'], d['ms_per_step'], (d.get('north_star_sharded') or {}).get('ms_per_step'))"
