@@ -194,7 +194,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise TempAmdError("libtemp_amd.so not found at %s -- run `python -m temp_amd.build` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+    # PyDLL: the interpreter lock is NOT released around a call.  Every entry point only enqueues work (microseconds); with CDLL each of
+    # the ~100 calls of a training step dropped the lock, a prefetch worker took it for a switch interval, and the step's issue code
+    # crawled behind the planner threads (a convoy: 4.8-5.7 ms per fresh-batch step for 1.4 ms of issue code).  The host planner
+    # library (_hostlib.py), whose calls run for hundreds of microseconds, keeps CDLL and runs without the lock.  TEMP_PYDLL=0: CDLL.
+    lib = ctypes.CDLL(LIB_PATH) if os.environ.get("TEMP_PYDLL", "1") == "0" else ctypes.PyDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing
         fn.restype = res
