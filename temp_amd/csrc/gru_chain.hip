@@ -25,7 +25,7 @@ namespace temp {
 #define CH_ROW_MASK (TEMP_CHAIN_HAS_PREV - 1)
 #define CH_LDS_LIMIT (160 * 1024)
 
-struct ChainRnn { const float4* wf; const float4* wb; const float* b_hh; const unsigned* kf; const unsigned* kb; const float4* wf3; const unsigned* kf3; };   // kf / kb: column keys of the f16 planes (gru_chain_hx.hpp)
+struct ChainRnn { const float4* wf; const float4* wb; const float* b_hh; const unsigned* kf; const unsigned* kb; };   // kf / kb: column keys of the f16 planes (gru_chain_hx.hpp)
 struct ChainArgs {
   int D, n_panels, max_steps, dbg;
   int n_rnn_keys;                        // GRUs of the chain (rows of the column-key result in front of the per-panel partials)
@@ -59,7 +59,6 @@ inline size_t chain_lds_bwd(int D, int ms) { ChainGeom g = chain_geom(D); return
 
 }  // namespace temp
 #include "gru_chain_hx.hpp"
-#include "gru_chain_v3.hpp"
 namespace temp {
 
 // ---- W_hh -> fragment order ---------------------------------------------------------------------------------------
@@ -659,15 +658,12 @@ static ChainArgs chain_args(const TempGruChain* c) {
     a.rnn[i].wf = (const float4*)c->packed[i];
     a.rnn[i].wb = (const float4*)c->packed[i] + (chain_bx(c->d) ? (size_t)(g.NQ >> 1) * g.NT * 192 : (size_t)g.NT * g.NQ * 64);
     a.rnn[i].b_hh = c->b_hh[i];
-    a.rnn[i].kf = a.rnn[i].kb = nullptr; a.rnn[i].wf3 = nullptr; a.rnn[i].kf3 = nullptr;
+    a.rnn[i].kf = a.rnn[i].kb = nullptr;
     if (chain_hx(c->d)) {
       const ChainGeomHx gx = chain_geom_hx(c->d);
       a.rnn[i].wb = (const float4*)c->packed[i] + chain_hx_fwd_items(c->d);
       a.rnn[i].kf = (const unsigned*)((const float4*)c->packed[i] + chain_hx_fwd_items(c->d) + chain_hx_bwd_items(c->d));
       a.rnn[i].kb = a.rnn[i].kf + gx.NT * 32;
-      // behind them: the forward planes with the gate blocks padded to whole tiles, and their keys (gru_chain_v3.hpp)
-      a.rnn[i].wf3 = (const float4*)(a.rnn[i].kb + gx.NTb * 32);
-      a.rnn[i].kf3 = (const unsigned*)(a.rnn[i].wf3 + chain_v3_items(c->d));
     }
   }
   return a;
@@ -692,17 +688,8 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
     // 8 + 8 waves (two matrix and two memory waves per SIMD, 128 registers each): a memory wave then has 28 stores + 12 loads
     // in flight per position instead of 56 + 24 -- beyond the 63 a wave's counter can track, every further access waits for the oldest
     constexpr int TPW8 = (TPW * 4 + 7) / 8 < 1 ? 1 : (TPW * 4 + 7) / 8;
-    const int cfg = (a.dbg >> 4) & 3;                          // development A/B: 0 = 8 + 8 waves, 1 = 4 + 4, 2 = 4 + 8, 3 = one role, two workgroups per CU
-    if (cfg == 3 && chain_lds_fwd_v3(a.D, a.max_steps) <= 80 * 1024 && chain_geom_v3(a.D).UT <= CHV3_WAVES) {
-      static bool attr_v3 = false;
-      ChainArgs a3 = a;
-      for (int i = 0; i < TEMP_CHAIN_MAX_RNN; ++i) { a3.rnn[i].wf = a.rnn[i].wf3; a3.rnn[i].kf = a.rnn[i].kf3; }
-      const size_t lds3 = chain_lds_fwd_v3(a.D, a.max_steps);
-      auto kernel = k_gru_chain_fwd_v3<VARIANT>;
-      int rc = chain_lds_attr(kernel, lds3, &attr_v3);
-      if (rc) return rc;
-      TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(CHV3_WAVES * 64), lds3, st, a3, gi, h, saved);
-    } else if (cfg == 1) {
+    const int cfg = (a.dbg >> 4) & 3;                          // development A/B: 0 = 8 + 8 waves, 1 = 4 + 4, 2 = 4 + 8
+    if (cfg == 1) {
       auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW, 4, 4>;
       int rc = chain_lds_attr(kernel, lds_hx, &attr_hx);
       if (rc) return rc;
@@ -749,7 +736,7 @@ static int launch_chain_bwd(const ChainArgs& a, const ChainUps& ups, const float
     constexpr int TPWB8 = (TPWB * 4 + 7) / 8 < 1 ? 1 : (TPWB * 4 + 7) / 8;
     // 4 + 8 waves (168 registers); 8 + 8 waves with a ring of eight slabs -- two matrix waves per SIMD covering each other's L2
     // latency -- leaves the memory role 128 registers: 31 spills, 374 us against 306 (development A/B: TEMP_DEBUG = 8192)
-    const int cfg = (a.dbg >> 8) & 3;
+    const int cfg = (a.dbg >> 4) & 3;
     if (cfg == 3) {                                            // (development A/B: a ring of five slabs)
       static bool attr_5 = false;
       auto kernel = k_gru_chain_bwd_hx<VARIANT, TPWB, 8, G4, 4, 5>;
@@ -805,7 +792,7 @@ size_t temp_gru_chain_pack_floats(int d) {
   const size_t f32 = ((size_t)g.NT * g.NQ + (size_t)g.NTb * g.NQb) * 64 * 4;
   // three bf16 planes in fragment order: (slabs of 16 k) x tiles x 192 sixteen-byte items, forward then backward
   const size_t bx = ((size_t)(g.NQ >> 1) * g.NT + (size_t)(g.NQb >> 1) * g.NTb) * 192 * 4;
-  const size_t hx = chain_hx_pack_floats(d) + chain_v3_pack_floats(d);   // two f16 planes + column keys (gru_chain_hx.hpp), and the padded forward planes (gru_chain_v3.hpp)
+  const size_t hx = chain_hx_pack_floats(d);           // two f16 planes + column keys (gru_chain_hx.hpp)
   const size_t m = f32 > bx ? f32 : bx;
   return m > hx ? m : hx;                              // any arithmetic (TEMP_MFMA) fits the caller's buffer
 }
@@ -846,15 +833,9 @@ int temp_gru_chain_pack_multi(int count, int d, const float* const* w_hh, float*
       hx_u32x4* pf = reinterpret_cast<hx_u32x4*>(packed[i]);
       hx_u32x4* pb = pf + chain_hx_fwd_items(d);
       unsigned* kf = reinterpret_cast<unsigned*>(pb + chain_hx_bwd_items(d));
-      if (jobs.count + 3 > HX_PACK_JOBS) { hx_pack_launch(jobs, K_GRU_CHAIN_PACK, (hipStream_t)stream); jobs = HxPackJobs{}; }
+      if (jobs.count + 2 > HX_PACK_JOBS) { hx_pack_launch(jobs, K_GRU_CHAIN_PACK, (hipStream_t)stream); jobs = HxPackJobs{}; }
       hx_pack_jobs_add(jobs, w_hh[i], pf, kf, d, 3 * d, d, 1);
       hx_pack_jobs_add(jobs, w_hh[i], pb, kf + gx.NT * 32, 3 * d, d, d, 0, gx.NSb);
-      {                                                     // forward planes with every gate block padded to whole tiles (gru_chain_v3.hpp)
-        const ChainGeomV3 g3 = chain_geom_v3(d);
-        hx_u32x4* p3 = reinterpret_cast<hx_u32x4*>(kf + (gx.NT + gx.NTb) * 32);
-        unsigned* k3 = reinterpret_cast<unsigned*>(p3 + chain_v3_items(d));
-        hx_pack_jobs_add(jobs, w_hh[i], p3, k3, d, g3.NT * 32, d, 1, 0, d, g3.UT * 32);
-      }
     }
     hx_pack_launch(jobs, K_GRU_CHAIN_PACK, (hipStream_t)stream);
     return launch_status();

@@ -13,29 +13,18 @@
 namespace temp {
 
 #define HX_PACK_JOBS 8
-struct HxPackJob { const float* B; hx_u32x4* out; unsigned* keys; int K, N, n_tiles, n_slabs, ldb, trans, unit0, kblock0;
-                   int blk, blk_pad; };      // blk > 0: the N columns are blocks of `blk` source columns, each padded to `blk_pad` packed columns (N = packed count)
+struct HxPackJob { const float* B; hx_u32x4* out; unsigned* keys; int K, N, n_tiles, n_slabs, ldb, trans, unit0, kblock0; };
 struct HxPackJobs { HxPackJob j[HX_PACK_JOBS]; int count, total_units, total_kblocks; };
 
 inline size_t hx_packed_items(int N, int K) { return (size_t)ceil_div(K, 16) * ceil_div(N, 32) * 128; }   // 16-byte items
 
 // n_slabs > ceil(K / 16): zero slabs behind the matrix (a kernel that walks its slabs in groups)
-inline void hx_pack_jobs_add(HxPackJobs& jobs, const float* B, hx_u32x4* out, unsigned* keys, int K, int N, int ldb, int trans, int n_slabs = 0,
-                             int blk = 0, int blk_pad = 0) {
+inline void hx_pack_jobs_add(HxPackJobs& jobs, const float* B, hx_u32x4* out, unsigned* keys, int K, int N, int ldb, int trans, int n_slabs = 0) {
   HxPackJob& j = jobs.j[jobs.count++];
-  j.blk = blk; j.blk_pad = blk_pad;
   j.B = B; j.out = out; j.keys = keys; j.K = K; j.N = N; j.n_tiles = ceil_div(N, 32); j.n_slabs = n_slabs > 0 ? n_slabs : ceil_div(K, 16); j.ldb = ldb; j.trans = trans;
   j.unit0 = jobs.total_units; j.kblock0 = jobs.total_kblocks;
   jobs.total_units += j.n_tiles * j.n_slabs;
   jobs.total_kblocks += j.n_tiles;
-}
-
-// source column of packed column n (-1: padding)
-__device__ __forceinline__ int hx_src_col(const HxPackJob& jb, int n) {
-  if (n >= jb.N) return -1;
-  if (jb.blk <= 0) return n;
-  const int b = n / jb.blk_pad, w = n - b * jb.blk_pad;
-  return w < jb.blk ? b * jb.blk + w : -1;
 }
 
 __device__ __forceinline__ const HxPackJob& hx_job_of(const HxPackJobs& jobs, int idx, bool by_kblock, int& local) {
@@ -139,8 +128,8 @@ static __global__ void __launch_bounds__(1024) k_hx_keys_pack(HxPackJobs jobs) {
   int c, g;
   if (jb.trans) {
     c = threadIdx.x >> 5; g = threadIdx.x & 31;
-    const int n = hx_src_col(jb, 32 * t + c);
-    if (n >= 0) {
+    const int n = 32 * t + c;
+    if (n < N) {
       const float* p = B + (size_t)n * ldb;
       if ((K & 3) == 0 && (ldb & 3) == 0) {
         for (int q0 = g; q0 < (K >> 2); q0 += 128) {
@@ -156,8 +145,8 @@ static __global__ void __launch_bounds__(1024) k_hx_keys_pack(HxPackJobs jobs) {
     }
   } else {
     g = threadIdx.x >> 5; c = threadIdx.x & 31;
-    const int n = hx_src_col(jb, 32 * t + c);
-    if (n >= 0) {
+    const int n = 32 * t + c;
+    if (n < N) {
       const float* p = B + n;
       for (int k0 = g; k0 < K; k0 += 256) {
         float v[8];
@@ -179,12 +168,12 @@ static __global__ void __launch_bounds__(1024) k_hx_keys_pack(HxPackJobs jobs) {
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, hh = lane >> 5, li = lane & 31, wave = threadIdx.x >> 6;
-  const int n = hx_src_col(jb, 32 * t + li);
+  const int n = 32 * t + li;
   const float sc = scale_l[li];
   for (int s0 = wave; s0 < jb.n_slabs; s0 += 16) {
     const int k = 16 * s0 + 8 * hh;
     float4 v0 = zero4(), v1 = zero4();
-    if (n >= 0 && k < K) {
+    if (n < N && k < K) {
       if (jb.trans) {
         const float* p = B + (size_t)n * ldb + k;
         v0 = ld4(p); v1 = ld4(p + 4);
