@@ -36,86 +36,8 @@ __device__ __forceinline__ const HxPackJob& hx_job_of(const HxPackJobs& jobs, in
   return jobs.j[ji];
 }
 
-// one block (1024 threads) per 32-column tile of a job; every load instruction reads whole 128-byte lines:
-//   trans = 1 (B stored [N][K]): thread (c, j) reads the float4 pieces j, j + 32, .. of row 32 t + c
-//   trans = 0 (B stored [K][N]): thread (g, c) reads element (k = g, g + 32, .., column 32 t + c), eight loads in flight
-static __global__ void __launch_bounds__(1024) k_hx_keys(HxPackJobs jobs) {
-  __shared__ unsigned sm[32][33];
-  int t;
-  const HxPackJob& jb = hx_job_of(jobs, blockIdx.x, true, t);
-  const int K = jb.K, N = jb.N, ldb = jb.ldb;
-  const float* __restrict__ B = jb.B;
-  unsigned key = 0;
-  int c, g;
-  if (jb.trans) {
-    c = threadIdx.x >> 5; g = threadIdx.x & 31;
-    const int n = 32 * t + c;
-    if (n < N) {
-      const float* p = B + (size_t)n * ldb;
-      if ((K & 3) == 0 && (ldb & 3) == 0) {
-        for (int q0 = g; q0 < (K >> 2); q0 += 128) {
-          float4 v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const int q = q0 + 32 * i; v[i] = q < (K >> 2) ? ld4(p + 4 * q) : zero4(); }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) key = max(key, hx_abs_bits4(v[i]));
-        }
-      } else {
-        for (int k = g; k < K; k += 32) key = max(key, hx_abs_bits(p[k]));
-      }
-    }
-  } else {
-    g = threadIdx.x >> 5; c = threadIdx.x & 31;
-    const int n = 32 * t + c;
-    if (n < N) {
-      const float* p = B + n;
-      for (int k0 = g; k0 < K; k0 += 256) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const int k = k0 + 32 * i; v[i] = k < K ? p[(size_t)k * ldb] : 0.f; }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) key = max(key, hx_abs_bits(v[i]));
-      }
-    }
-  }
-  sm[g][c] = key;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    key = 0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) key = max(key, sm[i][threadIdx.x]);
-    jb.keys[32 * t + threadIdx.x] = key;                          // (keys holds n_tiles * 32 entries)
-  }
-}
-
-// one wave per (slab, tile) unit of a job (after k_hx_keys on the same stream)
-static __global__ void __launch_bounds__(256) k_hx_pack(HxPackJobs jobs) {
-  const int lane = threadIdx.x & 63, hh = lane >> 5, li = lane & 31;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (unit >= jobs.total_units) return;
-  int st;
-  const HxPackJob& jb = hx_job_of(jobs, unit, false, st);
-  const int s = st / jb.n_tiles, t = st - s * jb.n_tiles;
-  const int k = 16 * s + 8 * hh, n = 32 * t + li;
-  float4 v0 = zero4(), v1 = zero4();
-  if (n < jb.N && k < jb.K) {                                // K % 8 == 0: the octet is entirely in or out
-    if (jb.trans) {
-      const float* p = jb.B + (size_t)n * jb.ldb + k;
-      v0 = ld4(p); v1 = ld4(p + 4);
-    } else {
-      const float* p = jb.B + (size_t)k * jb.ldb + n;
-      const size_t l = (size_t)jb.ldb;
-      v0 = make_float4(p[0], p[l], p[2 * l], p[3 * l]);
-      v1 = make_float4(p[4 * l], p[5 * l], p[6 * l], p[7 * l]);
-    }
-  }
-  hx_u32x4 H, L;
-  hx_split8(v0, v1, hx_scale(jb.keys[n]), H, L);
-  hx_u32x4* d = jb.out + (size_t)st * 128 + lane;
-  d[0] = H; d[64] = L;
-}
-
-// keys AND planes of one 32-column tile of a job in one block (1024 threads): the column maxima as in k_hx_keys, then the 16 waves
+// keys AND planes of one 32-column tile of a job in one block (1024 threads): the column maxima first (trans = 1: thread (c, j) reads the float4 pieces j, j + 32, .. of row 32 t + c; trans = 0: thread (g, c)
+// reads element (k = g, g + 32, .., column 32 t + c), eight loads in flight: every load instruction reads whole 128-byte lines), then the 16 waves
 // deal the tile's slabs among themselves (the two launches cost ~8 us each on an idle chip for a few hundred KB of work)
 static __global__ void __launch_bounds__(1024) k_hx_keys_pack(HxPackJobs jobs) {
   __shared__ unsigned sm[32][33];
