@@ -700,6 +700,12 @@ static int launch_chain_fwd(const ChainArgs& a, const float* gi, float* h, float
       int rc = chain_lds_attr(kernel, lds_hx, &attr_48);
       if (rc) return rc;
       TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(768), lds_hx, st, a, gi, h, saved);
+    } else if (cfg == 3) {                                      // (development A/B: 8 + 8 waves, TWO register sets of planes: 37 spills, 291 us against 233)
+      static bool attr_882 = false;
+      auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW8, 8, 8, 1>;
+      int rc = chain_lds_attr(kernel, lds_hx, &attr_882);
+      if (rc) return rc;
+      TEMP_LAUNCH(K_GRU_CHAIN_FWD, kernel, dim3(a.n_panels), dim3(1024), lds_hx, st, a, gi, h, saved);
     } else {
       static bool attr_88 = false;
       auto kernel = k_gru_chain_fwd_hx<VARIANT, TPW8, 8, 8>;

@@ -56,7 +56,8 @@ inline size_t chain_hx_pack_floats(int D) {
 
 // ---- forward --------------------------------------------------------------------------------------------------------
 // NMW matrix waves (4 or 8: one or two per SIMD) with TPW = ceil(NT / NMW) tiles each, MW memory waves
-template <int VARIANT, int TPW, int MW, int NMW = 4>
+// TWOSETS (NMW = 8 only): two register sets of W_hh planes instead of one, paid for by reading the state fragments just in time
+template <int VARIANT, int TPW, int MW, int NMW = 4, int TWOSETS = 0>
 __global__ void __launch_bounds__(64 * (NMW + MW)) k_gru_chain_fwd_hx(ChainArgs a, const float* __restrict__ gi, float* __restrict__ H,
                                                                        float* __restrict__ saved) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -104,7 +105,9 @@ __global__ void __launch_bounds__(64 * (NMW + MW)) k_gru_chain_fwd_hx(ChainArgs 
       // W_hh planes of TWO slabs in registers (sets 0 / 1 alternate along the slab walk; a set is refilled with the slab two ahead as
       // soon as its plane has had its last product: L after round 0, H after round 2).
       const hx_u32x4* wp = reinterpret_cast<const hx_u32x4*>(R.wf);
-      hx_u32x4 w[NMW > 4 ? 1 : 2][2][TPW] = {};                 // [set][plane h, l][tile]
+      constexpr bool ONESET = NMW > 4 && !TWOSETS;
+      constexpr bool PREF = !(NMW > 4 && TWOSETS);               // read the next slab's state fragments one slab ahead
+      hx_u32x4 w[ONESET ? 1 : 2][2][TPW] = {};                   // [set][plane h, l][tile]
       auto wload = [&](hx_u32x4 (&wr)[TPW], int sl, int pl) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
@@ -114,19 +117,26 @@ __global__ void __launch_bounds__(64 * (NMW + MW)) k_gru_chain_fwd_hx(ChainArgs 
       // per block, so results stay bit-repeatable)
       const int rot = (a.dbg & 64) ? 0 : (int)(blockIdx.x >> 3) % NS;
       wload(w[0][0], rot, 0); wload(w[0][1], rot, 1);
-      if constexpr (NMW <= 4) { wload(w[1][0], rot + 1 < NS ? rot + 1 : 0, 0); wload(w[1][1], rot + 1 < NS ? rot + 1 : 0, 1); }
+      if constexpr (!ONESET) { wload(w[1][0], rot + 1 < NS ? rot + 1 : 0, 0); wload(w[1][1], rot + 1 < NS ? rot + 1 : 0, 1); }
       const char* hrow = hpl + (size_t)li * ldp + 16 * hh;       // + plane * 32 ldp + 32 slab: k = 16 slab + 8 hh .. + 7 of track li
       const int pl1 = CH_SLOTS * ldp;
       for (int s = 0; s < ns; ++s) {
         const int flags = flagb[s];
         if ((flags & 1) && !(a.dbg & 1)) {                      // (dbg bit 0: development ablation, no products)
           hx_u32x4 FH = *reinterpret_cast<const hx_u32x4*>(hrow + 32 * rot), FL = *reinterpret_cast<const hx_u32x4*>(hrow + pl1 + 32 * rot), NH, NL;
+          int sl_cur = rot;
           // one slab out of register set SET (a compile-time index: the sets are registers, never addressed); sl1: the next slab
           // (its fragments are read now), sl2: the slab the set is refilled with
           auto slab = [&](auto set_c, int sl1, int sl2) {
             constexpr int SET = decltype(set_c)::value;
-            NH = *reinterpret_cast<const hx_u32x4*>(hrow + 32 * sl1);
-            NL = *reinterpret_cast<const hx_u32x4*>(hrow + pl1 + 32 * sl1);
+            if constexpr (PREF) {
+              NH = *reinterpret_cast<const hx_u32x4*>(hrow + 32 * sl1);
+              NL = *reinterpret_cast<const hx_u32x4*>(hrow + pl1 + 32 * sl1);
+            } else {
+              FH = *reinterpret_cast<const hx_u32x4*>(hrow + 32 * sl_cur);
+              FL = *reinterpret_cast<const hx_u32x4*>(hrow + pl1 + 32 * sl_cur);
+              sl_cur = sl1;
+            }
             const hx_f16x8 ah = hx_frag(FH), al = hx_frag(FL);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -140,13 +150,13 @@ __global__ void __launch_bounds__(64 * (NMW + MW)) k_gru_chain_fwd_hx(ChainArgs 
             for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx_frag(w[SET][0][j]), ah, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             wload(w[SET][0], sl2, 0);
-            FH = NH; FL = NL;
+            if constexpr (PREF) { FH = NH; FL = NL; }
           };
           // Walk position j = 0 .. NS - 1 visits slab (rot + j) mod NS out of set j & 1.  A set is refilled with the slab of walk
           // position j + 2 -- or, behind the walk's last two slabs, with walk position j & 1 of the NEXT position (set 0 always holds
           // the even walk positions, also for an odd slab count: the loads behind the last slabs have the whole gate phase to land).
           auto at = [&](int j) { const int v = rot + j; return v < NS ? v : v - NS; };
-          if constexpr (NMW > 4) {
+          if constexpr (ONESET) {
             // two matrix waves per SIMD cover each other's L2 latency: ONE register set, refilled in place with the next slab
             for (int j = 0; j < NS; ++j) slab(std::integral_constant<int, 0>(), at(j + 1 < NS ? j + 1 : 0), at(j + 1 < NS ? j + 1 : 0));
           } else {
