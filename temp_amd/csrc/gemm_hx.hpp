@@ -238,7 +238,7 @@ static inline bool hx_supported(const PanelBatch<Epi>& batch, int count, const B
   // A pass over A for its row keys costs ~13 us per 50 MB; the f16 kernels save ~0.2 us per (column tile x slab) of a 60 000-row
   // product.  Without caller keys the pass only pays for wide or deep products (measured: the 200 x 200 self-loop products lose
   // 10 us, the 200 x 600 gates gain 10, K = 600 gains 35).
-  if (need_keys > 0 && ceil_div(g.N, 32) < 16 && g.K < 512) return false;
+  if (need_keys > 0 && ceil_div(g.N, 32) < 16 && g.K < 512 && !(option(TEMP_OPT_DEBUG) & 0x800)) return false;      // (TEMP_DEBUG bit 11: development A/B, take the pass anyway)
   return need_keys <= BX_SLOT_BYTES - HX_KEYS_OFFSET;
 }
 
