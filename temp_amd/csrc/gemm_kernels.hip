@@ -361,6 +361,10 @@ size_t gemm_tn_workspace(int M, int Ka, int Nb) {
     sb = (size_t)tn_bx8_slices(M, ceil_div(Ka, 256));
     if (sb > S) S = sb;
   }
+  // (a product over more rows than 32-bit element offsets reach runs in row chunks, each with its own slices: tn_bx_chunks; 200-
+  //  wide operands reach that at 10.7 M rows -- leading dimensions up to 1024 floats are provided for)
+  const size_t chunks = (size_t)((long long)M * 1024 >= (1ll << 31) ? ceil_div((long long)M * 1024, (1ll << 31) - 1) : 1);
+  S *= chunks;
   return align_up(S * Ka * Nb * sizeof(float), 256) + align_up(S * Ka * sizeof(float), 256);
 }
 
@@ -394,6 +398,26 @@ int gemm_tn(int M, int Ka, int Nb, const float* A, int lda, const float* B, int 
   rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
   float* part = (float*)ws;
   float* bpart = bias_out ? (float*)((char*)ws + align_up((size_t)S * Ka * Nb * sizeof(float), 256)) : nullptr;
+  const int chunks = use_bx ? tn_bx_chunks(M, Ka, lda, ldb) : 1;
+  if (use_bx && chunks > 1) {
+    // row chunks, each a launch of its own over S slices of ITS rows; the reduction below then sums chunks x S slices in order
+    if ((lda > 1024 || ldb > 1024)) return TEMP_E_UNSUPPORTED;       // (the workspace query provides for leading dimensions <= 1024)
+    const int rows_c = ceil_div(ceil_div(M, chunks), 256) * 256;
+    int done = 0, total_s = 0;
+    for (int ci = 0; ci < chunks && done < M; ++ci) {
+      const int mc = M - done < rows_c ? M - done : rows_c;
+      const int Sc = bx8 ? tn_bx8_slices(mc, kab_bx) : tn_bx_slices(mc, c.kab);
+      int rc_ = ceil_div(mc, Sc);
+      rc_ = (rc_ + TN_MC - 1) / TN_MC * TN_MC;
+      float* bp = bias_out ? (float*)((char*)ws + align_up((size_t)chunks * S * Ka * Nb * sizeof(float), 256)) + (size_t)total_s * Ka : nullptr;
+      launch_tn_bx(mc, Ka, Nb, A + (size_t)done * lda, lda, B + (size_t)done * ldb, ldb, rc_, kab_bx, Sc, part + (size_t)total_s * Ka * Nb, bp, st);
+      done += mc;
+      total_s += Sc;
+    }
+    float* bp0 = bias_out ? (float*)((char*)ws + align_up((size_t)chunks * S * Ka * Nb * sizeof(float), 256)) : nullptr;
+    reduce_slices(total_s, (size_t)Ka * Nb, Nb, part, out, ldo, st, bias_out ? (size_t)Ka : 0, bp0, bias_out);
+    return launch_status();
+  }
   if (use_bx) launch_tn_bx(M, Ka, Nb, A, lda, B, ldb, rps, kab_bx, S, part, bpart, st);
   else if (c.nt == 7) launch_tn<7>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);
   else if (c.nt == 4) launch_tn<4>(c, M, Ka, Nb, A, lda, B, ldb, rps, part, bpart, st);

@@ -507,8 +507,16 @@ inline bool tn_bx_ok(int M, int Ka, int Nb, int lda, int ldb) {
   const int nt = ceil_div(Nb, 32);
   // (the 128-row kernel keeps 32-bit element offsets; the wide one -- Ka > 256 -- forms a 64-bit row base per slab)
   const long long span = (long long)M * (lda > ldb ? lda : ldb);
-  return bx_enabled() && nt >= 5 && nt <= 7 && Ka % 4 == 0 && Nb % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && M >= 4096 &&
-         (Ka > 256 || span < (1ll << 31));
+  (void)span;                                                   // (rows beyond the 32-bit span: gemm_tn cuts M into chunks, tn_bx_chunks)
+  return bx_enabled() && nt >= 5 && nt <= 7 && Ka % 4 == 0 && Nb % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && M >= 4096;
+}
+// The 128-row kernel forms 32-bit element offsets from its operands' bases: a product over more rows than that (the HBM-regime
+// window: 15 M rows of 200 floats) runs as `chunks` launches over row ranges, each with its own slices of the workspace; one
+// reduction over all of them.  (Until round 6 such a product fell back to the fp32 MFMA kernel: 17 ms against 8.)
+inline int tn_bx_chunks(int M, int Ka, int lda, int ldb) {
+  if (Ka > 256) return 1;                                       // the wide kernel forms a 64-bit row base per slab
+  const long long ld = lda > ldb ? lda : ldb, max_rows = ((1ll << 31) - 1) / ld / 256 * 256;
+  return (int)((M + max_rows - 1) / max_rows);
 }
 // m-slices: the kab row blocks of a slice run on one XCD (32 CUs), so an XCD takes floor(32 / kab) slices at a time
 inline int tn_bx_slices(int M, int kab) {

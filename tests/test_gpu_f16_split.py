@@ -330,3 +330,29 @@ def test_config_step_bit_repeatable_and_atomic_free_gpu(name, hip_backend):
         assert (g0 is None) == (g1 is None)
         if g0 is not None:
             assert torch.equal(g0, g1)
+
+
+def test_weight_gradient_beyond_32bit_span_gpu(hip_backend):
+    """out = a^T . b over 10.8 M rows of 200 floats (an element span of 2.16e9 > 2^31: the HBM-regime window's loop-weight gradient):
+    the split-operand kernel runs in row chunks with one ordered reduction (until round 6 this shape fell back to the fp32 MFMA
+    kernel).  Against fp64 (chunked), 2e-7 of sum |a||b| -- the bar of test_split_operand_weight_gradient_vs_fp64 -- and twice the
+    same bits."""
+    be = hip_backend
+    M, Ka, Nb = 10_800_000, 200, 200
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = torch.randn(M, Ka, generator=g, device=DEV)
+    b = torch.randn(M, Nb, generator=g, device=DEV)
+    a[-1] *= 64.0                                                  # the last row must count (a dropped tail chunk would show)
+    out = be.linear_tn(a, b)
+    out2 = be.linear_tn(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    ref = torch.zeros(Ka, Nb, dtype=torch.float64, device=DEV)
+    sabs = torch.zeros(Ka, Nb, dtype=torch.float64, device=DEV)
+    step = 1 << 20
+    for r0 in range(0, M, step):
+        ad, bd = a[r0:r0 + step].double(), b[r0:r0 + step].double()
+        ref += ad.t() @ bd
+        sabs += ad.abs().t() @ bd.abs()
+    err = ((out.double() - ref).abs() / sabs).max().item()
+    assert err < 2e-7, err
