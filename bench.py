@@ -133,7 +133,7 @@ def train_loop(model, w, steps):
         return 1e3 * dt / steps, edges / dt
 
     inline_ms, inline_eps = timed(model.prepare(b, w["L"], True) for b in batches)
-    pre_ms, pre_eps = timed(BatchPrefetcher(model, batches, seq_len=w["L"], depth=2, workers=2))
+    pre_ms, pre_eps = timed(BatchPrefetcher(model, batches, seq_len=w["L"], depth=4, workers=2))
     best = "prefetcher" if pre_ms <= inline_ms else "inline"     # which one wins depends on the load of the box's host CPUs (one GIL)
     return dict(ms_per_step=min(pre_ms, inline_ms), edges_per_s=max(pre_eps, inline_eps), mode=best, prefetcher_ms_per_step=pre_ms,
                 prefetcher_edges_per_s=pre_eps, inline_prepare_ms_per_step=inline_ms, inline_prepare_edges_per_s=inline_eps, steps=steps,

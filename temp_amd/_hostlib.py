@@ -49,7 +49,14 @@ def load():
             fn.restype, fn.argtypes = res, args
         if lib.temp_host_abi_version() != 2:
             raise RuntimeError("libtemp_host.so ABI version mismatch")
-        _lib = lib
+        from ._lib import outside_token
+
+        class _Calls:                                 # the same entry points; a prefetch worker's planning token is handed back around each call
+            pass
+        calls = _Calls()
+        for name in SYMBOLS:
+            setattr(calls, name, outside_token(getattr(lib, name)) if name != "temp_host_abi_version" else getattr(lib, name))
+        _lib = calls
     return _lib
 
 

@@ -171,6 +171,7 @@ class BiDynamicRGCN(DynamicRGCN):
         chain = np.concatenate([f_rows, t_rows, b_rows, t_rows])
         wb.chain_rows = _lib.to_device(chain.astype(np.int32), self._device())
         wb.chain_inv = TF.gather_inverse(chain, int(wb.g_all.n), self._device())
+        _lib.pause_point()
         inst = []
         last = -1
         for st in plan_f.steps:
@@ -198,17 +199,22 @@ class BiDynamicRGCN(DynamicRGCN):
         wb.rows = window_times(t_list, seq_len, self.total_time)
         rows_b = window_times(t_list, seq_len, self.total_time, ascending=True)
         plan_f = ChainPlan(wb.rows, self.graph_dict_train, self.num_ents, seq_len)
+        _lib.pause_point()                            # (between the stages of `prepare`: a prefetch worker parks here while the loop issues a step)
         plan_b = ChainPlan(rows_b, self.graph_dict_train, self.num_ents, seq_len).flipped()
+        _lib.pause_point()
         wb.plan = (plan_f, plan_b)
         if train and self.random_dropout:
             self.sample_history_graphs(plan_f)
             self.sample_history_graphs(plan_b)
         wb.graphs = [self.graph_dict_train[r[-1]] for r in wb.rows]
         tgt = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
+        _lib.pause_point()
         wb.target, wb.target_b = self._bi_target(plan_f, plan_b, wb.rows, tgt)
         wb.batched = self._can_batch()
         wb.steps = plan_f.steps + plan_b.steps + [wb.target]
+        _lib.pause_point()
         self._upload(wb, dev, train)
+        _lib.pause_point()
         if wb.program is None:
             wb.target_b.tensors(dev)
         if train:

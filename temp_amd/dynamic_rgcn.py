@@ -233,15 +233,19 @@ class DynamicRGCN(TKG_Module):
         wb = WindowBatch()
         wb.rows = window_times(t_list, seq_len, self.total_time)
         wb.plan = ChainPlan(wb.rows, self.graph_dict_train, self.num_ents, seq_len)
+        _lib.pause_point()                            # (between the stages of `prepare`: a prefetch worker parks here while the loop issues a step)
         if train and self.random_dropout:
             self.sample_history_graphs(wb.plan)
         wb.graphs = [self.graph_dict_train[r[-1]] for r in wb.rows]
         tgt = self.sample_target_graphs(wb.graphs, 0.5, target_edge_ids) if train else wb.graphs
+        _lib.pause_point()
         wb.target = self._target_step(wb.plan, wb.rows, tgt)
         wb.batched = self._can_batch()
         wb.stack = not wb.batched and self._can_stack()
         wb.steps = wb.plan.steps + [wb.target]
+        _lib.pause_point()
         self._upload(wb, dev, train)
+        _lib.pause_point()
         if train:
             self._plan_loss(wb)
         return wb
@@ -259,9 +263,12 @@ class DynamicRGCN(TKG_Module):
                 wb.visit_inv = TF.gather_inverse(vr, int(wb.g_all.n), dev) if on_dev else None
             else:
                 wb.g_all, wb.total_rows = concat_steps(wb.steps)
+            _lib.pause_point()
             wb.ids_all = _lib.to_device(wb.g_all.gids.astype(np.int32), dev)
             wb.ids_inv = TF.gather_inverse(wb.g_all.gids, self.num_ents, dev)        # static ids: deterministic embedding gradient
+            _lib.pause_point()
             wb.g_all.device_graph(dev, 2 * self.num_rels)
+            _lib.pause_point()
             if getattr(wb, "stack", False):          # layer 2 runs per position: every position's own union graph as well
                 for st in wb.steps:
                     st.batched().device_graph(dev, 2 * self.num_rels)
@@ -274,6 +281,7 @@ class DynamicRGCN(TKG_Module):
                 wb.program.constants(dev, self.embed_size)
             elif self._can_chain():
                 self._build_program(wb)
+                _lib.pause_point()
                 prepare_program(wb.program, dev, self.embed_size, len(wb.out_inst), self._chain_want(wb))
         else:
             for st in wb.steps:
@@ -368,6 +376,7 @@ class DynamicRGCN(TKG_Module):
         offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
         wb.loss_plan = plan_batch_loss(store, [r[-1] for r in wb.rows], wb.graphs, offs, self.args.num_pos_facts, self.sample_rng,
                                        int(sum(sizes)), int(self.rel_embeds.shape[0]), dev)
+        _lib.pause_point()
         if self._fused_all_entity_ok(wb):
             self._all_maps(wb)
 
@@ -431,6 +440,7 @@ class DynamicRGCN(TKG_Module):
             host, meta = {}, []
             ent = np.arange(N, dtype=np.int64)[None, :]
             for d, plan in enumerate(plans):
+                _lib.pause_point()
                 row_of = np.stack([plan.final_all(b, L - 1)[0] for b in range(B)])
                 gap = np.stack([plan.final_all(b, L - 1)[1] for b in range(B)])
                 has = ~act & (row_of >= 0)
@@ -450,6 +460,7 @@ class DynamicRGCN(TKG_Module):
                 host["ent%d" % d], host["idx%d" % d], host["asm%d" % d] = ee, row_of[bb, ee], asm.reshape(-1)
                 host["dt%d" % d] = gap[bb, ee].astype(np.float32).view(np.int32)           # float bits ride in the int32 pack
                 meta.append((n_prev, n_src, ee, asm.reshape(-1), row_of[bb, ee]))
+            _lib.pause_point()
             dd = S.upload_packed(host, dev, np.int32)
             wb.all_maps = []
             for d, (n_prev, n_src, ee, asm, idx_host) in enumerate(meta):

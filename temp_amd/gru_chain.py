@@ -189,6 +189,7 @@ class GruProgram:
         states are handed out -- their rows are written to H and receive an upstream gradient; None = all rows, one dense
         gradient).  One packed upload, cached per (device, want)."""
         plan = self.chain_plan()
+        _lib.pause_point()
         if plan is None or (want is not None and len(want) > _lib.CHAIN_MAX_UP):
             return None
         cache = self.__dict__.setdefault("_chain_tabs", {})
@@ -211,6 +212,7 @@ class GruProgram:
             for it in self.inst:
                 if it.n:
                     dt[it.h0:it.h0 + it.n] = np.asarray(it.dt, dtype=np.float32).reshape(-1)
+            _lib.pause_point()
             parts = [plan["panel"].reshape(-1), plan["rows"].reshape(-1), sinfo.reshape(-1), dt.view(np.int32)]
             buf = _lib.to_device(np.concatenate(parts), device)
             cuts = np.cumsum([0] + [p.size for p in parts])
@@ -470,6 +472,7 @@ def prepare_program(prog, device, d, n_rnn, want):
     kernels' panel tables for the `want` set the run will ask for, or -- when the program goes through the per-position
     launches -- the row maps of every instance."""
     if chain_kernels_usable(d, n_rnn) and prog.chain_tables(device, tuple(want) if want is not None else None) is not None:
+        _lib.pause_point()
         prog.gi_shared(device)
         return
     prog.upload(device)

@@ -33,8 +33,14 @@ class BatchPrefetcher:
     depend on which worker took it or when.  With one worker and batch_seeds=False the model's generator is used directly,
     exactly as by an inline `model.prepare`."""
 
-    def __init__(self, model, batches, seq_len=None, train=True, depth=2, workers=1, batch_seeds=None):
+    def __init__(self, model, batches, seq_len=None, train=True, depth=2, workers=1, batch_seeds=None, cooperative=True):
         self.model, self.batches, self.train = model, batches, train
+        # cooperative: the workers' Python pauses (between the stages of `prepare`, _lib.pause_point) while the consumer issues a
+        # step, and runs while the consumer waits for a batch -- the two halves share ONE interpreter lock, and taking it from each
+        # other every switch interval doubles the time of both (DESIGN section 8.5).  The workers' C++ planner calls run regardless.
+        self.cooperative = bool(cooperative)
+        self._gate = threading.Event()
+        self._gate.set()
         self.seq_len = seq_len if seq_len is not None else model.train_seq_len
         self.workers = max(1, int(workers))
         self.batch_seeds = (self.workers > 1) if batch_seeds is None else bool(batch_seeds)
@@ -77,6 +83,7 @@ class BatchPrefetcher:
         fatal = None
         try:
             from .tkg_module import TKG_Module
+            from . import _lib
             stream = torch.cuda.Stream(self.device) if self.device is not None else None
             while True:
                 self._slots.acquire()
@@ -90,6 +97,8 @@ class BatchPrefetcher:
                         raise t_list
                     if seed is not None:
                         TKG_Module._rng_override.rng = np.random.default_rng(seed)
+                    if self.cooperative:
+                        _lib.coop_begin(self._gate)
                     if stream is None:
                         wb = self.model.prepare(t_list, self.seq_len, self.train)
                     else:
@@ -104,6 +113,7 @@ class BatchPrefetcher:
                         self._stop = True
                 finally:
                     TKG_Module._rng_override.rng = None
+                    _lib.coop_end()
                 with self._cv:
                     self._done[i] = res
                     self._cv.notify_all()
@@ -172,7 +182,11 @@ class BatchPrefetcher:
                 raise item
             if getattr(item, "ready", None) is not None:
                 torch.cuda.current_stream(self.device).wait_event(item.ready)
-            yield item
+            self._gate.clear()                                  # the consumer issues a step: the workers' Python parks at its next stage boundary
+            try:
+                yield item
+            finally:
+                self._gate.set()                                # ... and runs while the consumer waits for the next batch (or has left the loop)
             self._retire(item)
             item = None
             i += 1

@@ -184,6 +184,7 @@ def plan_batch_loss(store, times, graphs, row_offsets, num_pos_facts, rng, n_row
                                                                  np.asarray(row_offsets, dtype=np.int64))
     if packed.shape[1] == 0:
         return None
+    _lib.pause_point()
     ends = np.cumsum(block)                                     # a graph's block = 2 P rows (+ weight-0 padding to a multiple of 4)
     splits = [(int(e - k), int(e)) for e, k in zip(ends, block)]
     tcut = np.cumsum(n_pos)

@@ -102,6 +102,7 @@ class ChainPlan:
         # row maps of every executed position in one pass of the host planner library (temp_host_chain_plan):
         # prev_idx = row in the previous executed step's output (F8: the history holds ONLY that step's nodes), dt = gap
         from . import _hostlib
+        _lib.pause_point()
         prev_idx, next_idx, dt, row_of, last = _hostlib.chain_plan(self.bsz, num_ents, [st.p for st in self.steps], [len(st.windows) for st in self.steps],
                                                          [[g.gids for g in st.graphs] for st in self.steps])
         off = 0
@@ -159,11 +160,13 @@ def concat_steps_dedup(steps):
             bases.append(base)
             sizes.append(g.n)
         off += st.n_rows
+    _lib.pause_point()
     vr = None
     if shared and bases:
         sizes = np.asarray(sizes, dtype=np.int64)
         start = np.cumsum(sizes) - sizes                         # first visit row of every visit
         vr = (np.repeat(np.asarray(bases, dtype=np.int64) - start, sizes) + np.arange(off, dtype=np.int64)).astype(np.int32)
+        _lib.pause_point()
     return S.batch(graphs), vr, off
 
 

@@ -156,6 +156,60 @@ def test_batch_prefetcher_workers_same_batches_as_one_worker():
         BatchPrefetcher(m, batches, workers=2, batch_seeds=False)
 
 
+def test_prefetcher_gate_parks_worker_python_while_consumer_issues():
+    """Cooperative hand-over (prefetch.BatchPrefetcher, _lib.pause_point): while the consumer holds the loop body the workers'
+    planning stops at its next stage boundary, so at most the batches already under way get finished; it resumes when the consumer
+    asks for the next batch; the batches are the same with the gate off."""
+    import threading
+    import time
+    from temp_amd import _lib
+    from temp_amd.prefetch import BatchPrefetcher
+    from tests.window_cases import build_window_model
+    # pause_point itself: parks on a closed gate with the token handed back, passes an open one, no-op without a gate
+    _lib.pause_point()
+    gate, seen = threading.Event(), []
+
+    def worker():
+        _lib.coop_begin(gate)
+        try:
+            seen.append("start")
+            _lib.pause_point()
+            seen.append("passed")
+        finally:
+            _lib.coop_end()
+    th = threading.Thread(target=worker)
+    th.start()
+    time.sleep(0.2)
+    assert seen == ["start"] and not _lib._py_token.locked()       # parked, token free for another worker
+    gate.set()
+    th.join(5)
+    assert seen == ["start", "passed"] and not _lib._py_token.locked()
+    z = load("G10_bi_grrgcn_rol")
+    batches = [[20, 15, 9], [18, 4], [7], [19, 12], [16, 3, 5], [11], [14, 2], [8]]
+    runs = []
+    for coop in (True, False):
+        m = build_window_model(z, torch.device("cpu"))
+        m.sample_rng = np.random.default_rng(11)
+        done = []
+        orig = m.prepare
+
+        def counted(*a, _orig=orig, **k):
+            r = _orig(*a, **k)
+            done.append(time.perf_counter())
+            return r
+        m.prepare = counted
+        got, during = [], []
+        for wb in BatchPrefetcher(m, batches, seq_len=int(z["L"]), depth=4, workers=2, batch_seeds=True, cooperative=coop):
+            n0 = len(done)
+            time.sleep(0.15)                       # "issuing a step": far longer than a prepare of these windows
+            during.append(len(done) - n0)
+            got.append(wb)
+        if coop:                                   # a worker finishes at most the stage it was in: no batch is completed start to end
+            assert sum(during) <= 2 * 2, during    # (window = depth + workers - 1 = 5 batches could have been, without the gate)
+        runs.append([(wb.n_edge_visits, [(g.src.tolist(), g.rel.tolist(), g.dst.tolist()) for g in wb.target.graphs]) for wb in got])
+    assert runs[0] == runs[1] and len(runs[0]) == len(batches)
+
+
 def test_device_negative_sampler_filters_true_triples():
     """DeviceCorruptTriples (torch ops on the model's device; here the CPU device) keeps the reference sampler's
     contract: column 0 = the true entity (global id), no sampled candidate forms a true triple of the snapshot."""
