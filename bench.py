@@ -737,8 +737,13 @@ def hbm_window(a, device, lib):
     ach = wb.n_edge_visits * bpe / (ms * 1e-3) / 1e9
     mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
     edge_visits, node_visits = int(wb.n_edge_visits), int(wb.n_node_visits)
-    # (counter passes exist for the window sizes of the rounds that took them: r04 at 2^18 nodes, r05 at 2^19)
-    pmc_path = os.path.join(REPO, "profiles", "%s_pmc_traffic_hbm_window.json" % {18: "r04", 19: "r05"}.get(k, "none"))
+    # (counter passes exist for the window sizes of the rounds that took them: r04 at 2^18 nodes, r05 / r06 at 2^19)
+    pmc_path = os.path.join(REPO, "profiles", "none")
+    for rnd in ({19: ("r06", "r05"), 18: ("r04",)}.get(k, ())):          # newest counter pass taken at this window size
+        cand = os.path.join(REPO, "profiles", "%s_pmc_traffic_hbm_window.json" % rnd)
+        if os.path.exists(cand):
+            pmc_path = cand
+            break
     traffic = json.load(open(pmc_path)).get("step_traffic_bytes") if os.path.exists(pmc_path) else None
     del st, wb, model, snaps
     torch.cuda.empty_cache()

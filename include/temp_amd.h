@@ -31,7 +31,7 @@
  *     piece of the split meets zero pieces of the other operand (inf . 0) -- and leaves all other outputs bit-identical.
  *     Round 6 (TEMP_OPT_MFMA_F16X2 = 1, the default): where an operand arrives with MAGNITUDE KEYS (the *_keys entry points below;
  *     a key = the fp32 bits of a row's / column's largest magnitude with the sign cleared) -- or the product is wide or deep enough
- *     to pay for taking them (N >= 512 or K >= 512) -- the same product runs on the f16 matrix pipe as THREE products of a two-way
+ *     to pay for taking them (N >= 512 or K >= 400) -- the same product runs on the f16 matrix pipe as THREE products of a two-way
  *     split of operands scaled by powers of two (csrc/split_f16.hpp).  Same accuracy class (<= 1e-6 of sum |a||b| against fp64,
  *     tests/test_gpu_f16_split.py), same non-finite contract; an element more than 2^17 below its row's (column's) largest keeps an
  *     ABSOLUTE error of 2^-39 of that largest value instead of a relative one.  Keys handed in must BOUND their row / column (a

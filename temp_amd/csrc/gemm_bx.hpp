@@ -591,8 +591,9 @@ bx_u32x4* bx_scratch(hipStream_t st, size_t bytes);
 
 inline size_t bx_packed_bytes(int N, int K) { return (size_t)ceil_div(K, 16) * ceil_div(N, 32) * 192 * 16; }
 
-inline bool bx_plan(int N, int K, int lda, int ldb, int trans_b, int max_m, long long total_rows, BxGeom* g, int* G) {
-  if (K % 8 || lda % 4 || ldb % 4 || N % 4 || K < 16) return false;
+// k4_ok: K % 8 == 4 is planned too (only the slab-staged f16 kernel, gemm_hx.hpp, reads A in quads; the caller checks)
+inline bool bx_plan(int N, int K, int lda, int ldb, int trans_b, int max_m, long long total_rows, BxGeom* g, int* G, bool k4_ok = false) {
+  if ((k4_ok ? K % 4 : K % 8) || lda % 4 || ldb % 4 || N % 4 || K < 16) return false;
   if (total_rows < BX_MIN_ROWS) return false;
   g->N = N; g->K = K; g->lda = lda; g->ldb = ldb; g->trans_b = trans_b;
   g->n_tiles = ceil_div(N, 32);
@@ -606,7 +607,10 @@ inline bool bx_plan(int N, int K, int lda, int ldb, int trans_b, int max_m, long
   const int gmax = g->n_tiles < 7 ? g->n_tiles : 7;
   for (int w = 1; w <= gmax; ++w) {
     const int ng = ceil_div(g->n_tiles, w);
-    const long long blocks = (long long)g->row_tiles * ng;
+    // (row tiles of ALL problems of the launch: four 7 500-row problems are 236 row tiles, not 59 -- with the largest problem's
+    //  count alone the estimate picked one-tile groups, 1 652 blocks that each split their 128 rows of A again)
+    const long long all_tiles = total_rows > 0 ? (total_rows + 127) / 128 : g->row_tiles;
+    const long long blocks = (all_tiles > g->row_tiles ? all_tiles : (long long)g->row_tiles) * ng;
     const float rounds = blocks <= 512 ? 1.f : (float)blocks / 512.f + 0.5f;       // the dispatcher back-fills: half a round of tail
     const float cost = rounds * (w + 0.5f);
     if (cost < best_cost * 0.999f || (cost <= best_cost * 1.001f && w > best)) { best_cost = cost; best = w; }

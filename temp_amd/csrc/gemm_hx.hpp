@@ -44,10 +44,10 @@ __global__ void __launch_bounds__(BX_THREADS, (G <= 4 ? 3 : 2)) k_gemm_hxp(Panel
   if (row < M) a_src = a_idx ? (long)a_idx[row] : (long)row;
   // rows past M and gathered "zero rows" (a_idx < 0) compute on row 0; the former are never stored, the latter are zeroed
   // before the epilogue.  k past K meets the zero padding of the packed B.
-  const float* aptr = A + (size_t)(a_src >= 0 ? a_src : 0) * g.lda + 8 * hh;
+  const float* aptr = A + (size_t)(a_src >= 0 ? a_src : 0) * g.lda;
   const unsigned akey = pb.a_keys[a_src >= 0 ? (keys_by_out ? (long)row : a_src) : 0];
   const float sa = hx_scale(akey);
-  const int kclamp = K - 8;                                   // last octet that may be read
+  const int kclamp = K - 4;                                   // last quad that may be read (K % 4 == 0; a quad past it meets zeros of B)
 
   f32x16 acc[G];
 #pragma unroll
@@ -69,9 +69,8 @@ __global__ void __launch_bounds__(BX_THREADS, (G <= 4 ? 3 : 2)) k_gemm_hxp(Panel
   };
   auto fetch_a = [&](float4 (&a)[2], int k0) {
     const int k = k0 + 8 * hh;
-    const float* p = aptr + (k <= kclamp ? k0 : kclamp - 8 * hh);
-    a[0] = ld4(p);
-    a[1] = ld4(p + 4);
+    a[0] = ld4(aptr + (k <= kclamp ? k : kclamp));
+    a[1] = ld4(aptr + (k + 4 <= kclamp ? k + 4 : kclamp));
   };
   float4 a1[2], a2[2];                                       // A of slabs s+1, s+2
   hx_u32x4 AH, AL, NH, NL;                                   // split A of slabs s, s+1
@@ -229,16 +228,46 @@ static __global__ void __launch_bounds__(256) k_absmax_rows_idx(int M, int K, co
   }
 }
 
+// the same for up to PANEL_MAXP problems of one launch (blockIdx.y = problem): a multi-problem product pays ONE key pass
+struct AbsRowsBatch { int M[PANEL_MAXP]; const float* A[PANEL_MAXP]; const int32_t* idx[PANEL_MAXP]; unsigned* keys[PANEL_MAXP]; };
+static __global__ void __launch_bounds__(256) k_absmax_rows_idx_multi(AbsRowsBatch b, int K, int lda) {
+  const int pr = blockIdx.y;
+  const int M = b.M[pr];
+  const float* __restrict__ A = b.A[pr];
+  const int32_t* __restrict__ a_idx = b.idx[pr];
+  unsigned* __restrict__ keys = b.keys[pr];
+  const int lane = threadIdx.x & 63, k4 = K >> 2;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  for (int r0 = gw; r0 < M; r0 += 4 * nw) {
+    float4 v[4];
+    int src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int r = r0 + u * nw; src[u] = r < M ? (a_idx ? a_idx[r] : r) : -1; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (src[u] >= 0 && lane < k4) ? ld4(A + (size_t)src[u] * lda + 4 * lane) : zero4();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * nw;
+      unsigned k = hx_abs_bits4(v[u]);
+      if (r < M) {                                            // (wave-uniform)
+        for (int c = 256 + 4 * lane; c < K; c += 256) k = max(k, src[u] >= 0 ? hx_abs_bits4(ld4(A + (size_t)src[u] * lda + c)) : 0u);
+        k = hx_wave_max(k);
+        if (lane == 0) keys[r] = k;
+      }
+    }
+  }
+}
+
 template <class Epi>
 static inline bool hx_supported(const PanelBatch<Epi>& batch, int count, const BxGeom& g) {
-  if (!hx_enabled() || g.K % 8 || g.lda % 4) return false;
+  if (!hx_enabled() || g.K % 4 || g.lda % 4) return false;
   size_t need_keys = 0;
   for (int i = 0; i < count; ++i)
     if (!batch.p[i].a_keys) need_keys += align_up((size_t)(batch.p[i].M > 0 ? batch.p[i].M : 0) * 4, 256);
   // A pass over A for its row keys costs ~13 us per 50 MB; the f16 kernels save ~0.2 us per (column tile x slab) of a 60 000-row
   // product.  Without caller keys the pass only pays for wide or deep products (measured: the 200 x 200 self-loop products lose
   // 10 us, the 200 x 600 gates gain 10, K = 600 gains 35).
-  if (need_keys > 0 && ceil_div(g.N, 32) < 16 && g.K < 512 && !(option(TEMP_OPT_DEBUG) & 0x800)) return false;      // (TEMP_DEBUG bit 11: development A/B, take the pass anyway)
+  if (need_keys > 0 && ceil_div(g.N, 32) < 16 && g.K < 400 && !(option(TEMP_OPT_DEBUG) & 0x800)) return false;      // (TEMP_DEBUG bit 11: development A/B, take the pass anyway)
   return need_keys <= BX_SLOT_BYTES - HX_KEYS_OFFSET;
 }
 
@@ -255,15 +284,27 @@ static inline bool hx_fill_keys(PanelBatch<Epi>& batch, int count, int K, int ld
   }
   if (any_own && any_given_gather) return false;
   size_t koff = HX_KEYS_OFFSET;
+  AbsRowsBatch ab = {};
+  int n_own = 0, max_own = 0, last = -1;
   for (int i = 0; i < count; ++i) {
     if (batch.p[i].M <= 0) { batch.p[i].a_keys = reinterpret_cast<const unsigned*>(slot + HX_KEYS_OFFSET); continue; }
     if (batch.p[i].a_keys) continue;
     unsigned* keys = reinterpret_cast<unsigned*>(slot + koff);
     koff += align_up((size_t)batch.p[i].M * 4, 256);
-    int blocks = ceil_div(batch.p[i].M, 16);
-    if (blocks > 2048) blocks = 2048;
-    TEMP_LAUNCH(K_KEYS, k_absmax_rows_idx, dim3(blocks), dim3(256), 0, st, batch.p[i].M, K, batch.p[i].A, lda, batch.p[i].a_idx, keys);
+    ab.M[n_own] = batch.p[i].M; ab.A[n_own] = batch.p[i].A; ab.idx[n_own] = batch.p[i].a_idx; ab.keys[n_own] = keys;
+    max_own = batch.p[i].M > max_own ? batch.p[i].M : max_own;
+    ++n_own;
+    last = i;
     batch.p[i].a_keys = keys;
+  }
+  if (n_own == 1) {
+    int blocks = ceil_div(batch.p[last].M, 16);
+    if (blocks > 2048) blocks = 2048;
+    TEMP_LAUNCH(K_KEYS, k_absmax_rows_idx, dim3(blocks), dim3(256), 0, st, ab.M[0], K, ab.A[0], lda, ab.idx[0], ab.keys[0]);
+  } else if (n_own > 1) {
+    int blocks = ceil_div(max_own, 16);
+    if (blocks > 2048 / n_own) blocks = 2048 / n_own;
+    TEMP_LAUNCH(K_KEYS, k_absmax_rows_idx_multi, dim3(blocks, n_own), dim3(256), 0, st, ab, K, lda);
   }
   for (int i = count; i < PANEL_MAXP; ++i) batch.p[i].a_keys = batch.p[0].a_keys;
   *keys_by_out = any_own ? 1 : 0;
@@ -327,7 +368,7 @@ namespace temp {
 // weights-resident f16 kernel (gemm_hxr.hpp) for short K -> false: not taken (the caller goes on to the bf16 resident kernel)
 template <class Epi>
 static inline bool launch_hxr(int kid, const PanelBatch<Epi>& batch_in, int count, const BxGeom& g, hipStream_t st) {
-  if (!option(TEMP_OPT_GEMM_RESIDENT) || g.K > BXR_MAX_SLABS * 16 || g.K < 72 || !hx_supported(batch_in, count, g)) return false;
+  if (!option(TEMP_OPT_GEMM_RESIDENT) || g.K > BXR_MAX_SLABS * 16 || g.K < 72 || g.K % 8 || !hx_supported(batch_in, count, g)) return false;
   int max_m = 0;
   for (int i = 0; i < count; ++i) max_m = batch_in.p[i].M > max_m ? batch_in.p[i].M : max_m;
   BxrGeom rg;

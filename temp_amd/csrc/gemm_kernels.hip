@@ -465,18 +465,25 @@ int gemm_tn_multi(int count, const int* Ms, int Ka, int Nb, const float* const* 
     if (!ws || ws_bytes < gemm_tn_multi_workspace(count, max_m, Ka, Nb)) return TEMP_E_WORKSPACE;
     int rps = ceil_div(max_m, S);
     rps = (rps + TN_MC - 1) / TN_MC * TN_MC;
+    // outputs that follow each other in memory (the windows' blocks of one gradient matrix): the partials of a slice lie side by
+    // side ([slice][product][Ka * Nb]) and ONE reduction sums them (count launches of a few microseconds otherwise)
+    bool adjacent = count > 1;
+    for (int i = 1; i < count; ++i) adjacent = adjacent && outs[i] == outs[i - 1] + (size_t)Ka * Nb;
     TnBxBatch b;
     for (int i = 0; i < 8; ++i) {
       const int k = i < count ? i : 0;
-      b.M[i] = i < count ? Ms[k] : 0; b.A[i] = As[k]; b.B[i] = Bs[k]; b.part[i] = (float*)ws + (size_t)k * S * Ka * Nb;
+      b.M[i] = i < count ? Ms[k] : 0; b.A[i] = As[k]; b.B[i] = Bs[k];
+      b.part[i] = (float*)ws + (adjacent ? (size_t)k * Ka * Nb : (size_t)k * S * Ka * Nb);
       b.bpart[i] = nullptr;
     }
-    b.pstride = (size_t)Ka * Nb; b.bstride = (size_t)Ka;
+    b.pstride = (adjacent ? (size_t)count : (size_t)1) * Ka * Nb; b.bstride = (size_t)Ka;
     const int bpp = 8 * ceil_div(S, 8) * kab8, nt = ceil_div(Nb, 32);
     if (nt == 7) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<7>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
     else if (nt == 6) TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<6>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
     else TEMP_LAUNCH(K_GEMM_TN, (k_gemm_tn_bx8_multi<5>), dim3(bpp * count), dim3(TNBX_THREADS), 0, st, b, Ka, Nb, lda, ldb, rps, kab8, S, bpp);
-    for (int i = 0; i < count; ++i) reduce_slices(S, (size_t)Ka * Nb, Nb, (float*)ws + (size_t)i * S * Ka * Nb, outs[i], ldo, st);
+    if (adjacent) reduce_slices(S, (size_t)count * Ka * Nb, Nb, (float*)ws, outs[0], ldo, st);
+    else
+      for (int i = 0; i < count; ++i) reduce_slices(S, (size_t)Ka * Nb, Nb, (float*)ws + (size_t)i * S * Ka * Nb, outs[i], ldo, st);
     return launch_status();
   }
   if (!(c.split == 2 && c.nt == 7) && !(c.split == 1 && (c.nt == 7 || c.nt == 4 || c.nt == 2 || c.nt == 1))) return TEMP_E_UNSUPPORTED;

@@ -342,6 +342,11 @@ int launch_gemm_panel_multi(int kid, const PanelBatch<Epi>& batch, int count, in
       BxGeom bg;
       int G;
       if (bx_plan(N, K, lda, ldb, trans_b, max_m, rows, &bg, &G)) return launch_gemm_bx(kid, batch, count, bg, G, st);
+      // K = 4 (mod 8) -- e.g. a product over 500 entities: the slab-staged f16 kernel reads A in quads, the bf16 kernels do not
+      if (K % 8 == 4 && bx_plan(N, K, lda, ldb, trans_b, max_m, rows, &bg, &G, true) && hx_supported(batch, count, bg)) {
+        const int rc = launch_gemm_hx(kid, batch, count, bg, G, st);
+        if (rc != TEMP_E_UNSUPPORTED) return rc;
+      }
     }
   }
   WresGeom g;

@@ -96,14 +96,16 @@ static __global__ void __launch_bounds__(1024) k_hx_keys_pack(HxPackJobs jobs) {
     const int k = 16 * s0 + 8 * hh;
     float4 v0 = zero4(), v1 = zero4();
     if (n < N && k < K) {
+      const bool full = k + 4 < K;                           // (K % 4 == 0: the last octet of a K that is no multiple of 8 is half)
       if (jb.trans) {
         const float* p = B + (size_t)n * ldb + k;
-        v0 = ld4(p); v1 = ld4(p + 4);
+        v0 = ld4(p);
+        if (full) v1 = ld4(p + 4);
       } else {
         const float* p = B + (size_t)k * ldb + n;
         const size_t l = (size_t)ldb;
         v0 = make_float4(p[0], p[l], p[2 * l], p[3 * l]);
-        v1 = make_float4(p[4 * l], p[5 * l], p[6 * l], p[7 * l]);
+        if (full) v1 = make_float4(p[4 * l], p[5 * l], p[6 * l], p[7 * l]);
       }
     }
     hx_u32x4 H, L;

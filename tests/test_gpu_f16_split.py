@@ -68,6 +68,8 @@ def test_absmax_and_gather_keys_exact_gpu(n, d, hip_backend):
     (17000, 72, 40, False),       # the shortest K the resident kernel takes, narrow output
     (16384, 24, 36, False),       # K below the resident kernel's range, one and a half slabs
     (16500, 200, 1000, True),     # wide output
+    (29900, 500, 200, False),     # d_q = d_scores . all_entities over 500 entities: K = 4 (mod 8), slab-staged kernel reads A in quads
+    (17001, 36, 72, True),        # K = 4 (mod 8), short
 ])
 @pytest.mark.parametrize("data", ["wide", "range"])
 def test_f16_split_gemm_vs_fp64_gpu(M, K, N, trans_b, data, hip_backend):
@@ -99,8 +101,45 @@ def test_f16_split_gemm_vs_fp64_gpu(M, K, N, trans_b, data, hip_backend):
     err = ((out[rows].double() - ref).abs() / sabs.clamp_min(1e-300)).max().item()
     assert err < 1e-6, "f16-split GEMM %dx%dx%d (%s): error %.3e of sum|a||b|" % (M, K, N, data, err)
     # the same product without caller keys: the wide / deep ones take their own pass and give the same bits
-    if N >= 512 or K >= 512:
+    if N >= 512 or K >= 400:
         assert torch.equal(be.linear(a, b, trans_b), out)
+
+
+def test_multi_problem_products_one_key_pass_and_one_reduction_gpu(hip_backend):
+    """The loss's per-window products as multi-problem launches: d_q_b = d_scores_b . all_b (four problems, K = 500 entities, keys
+    taken by ONE pass over all problems) and d_all_b = d_scores_b^T . q_b (adjacent outputs: the slices' partials side by side, ONE
+    reduction) against fp64; the same bits twice, and the same bits whether the outputs are adjacent or apart."""
+    be = hip_backend
+    lib = _lib.load()
+    Ms, N, D = [7474, 7001, 7474, 5000], 500, 200
+    ds = [_wide((m, N), 20 + i, 1e-3).to(DEV) for i, m in enumerate(Ms)]
+    ents = _wide((len(Ms) * N, D), 31, 0.3).to(DEV)
+    q = [_wide((m, D), 40 + i, 0.5).to(DEV) for i, m in enumerate(Ms)]
+    d_q = torch.empty(sum(Ms), D, device=DEV)
+    n0 = lib.temp_f16_launches()
+    be.linear_multi(ds, [ents[i * N:(i + 1) * N] for i in range(len(Ms))], False, d_q)
+    torch.cuda.synchronize()
+    assert lib.temp_f16_launches() == n0 + 1, "the K = 500 products did not take the f16 kernel"
+    off = 0
+    for i, m in enumerate(Ms):
+        e = ents[i * N:(i + 1) * N].double()
+        ref, sabs = ds[i].double() @ e, ds[i].double().abs() @ e.abs()
+        err = ((d_q[off:off + m].double() - ref).abs() / sabs.clamp_min(1e-300)).max().item()
+        assert err < 1e-6, "d_q of problem %d: %.3e" % (i, err)
+        off += m
+    again = torch.empty_like(d_q)
+    be.linear_multi(ds, [ents[i * N:(i + 1) * N] for i in range(len(Ms))], False, again)
+    assert torch.equal(again, d_q)
+    d_all = torch.empty(len(Ms) * N, D, device=DEV)
+    be.linear_tn_multi(ds, q, [d_all[i * N:(i + 1) * N] for i in range(len(Ms))])
+    apart = [torch.empty(N, D, device=DEV) for _ in Ms]                 # outputs that do not follow each other: a reduction each
+    be.linear_tn_multi(ds, q, apart)
+    torch.cuda.synchronize()
+    for i in range(len(Ms)):
+        ref, sabs = ds[i].double().t() @ q[i].double(), ds[i].double().abs().t() @ q[i].double().abs()
+        err = ((d_all[i * N:(i + 1) * N].double() - ref).abs() / sabs.clamp_min(1e-300)).max().item()
+        assert err < 1e-6, "d_all of problem %d: %.3e" % (i, err)
+        assert torch.equal(apart[i], d_all[i * N:(i + 1) * N])
 
 
 def test_f16_split_gemm_nonfinite_and_zero_rows_gpu(hip_backend):
