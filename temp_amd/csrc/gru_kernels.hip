@@ -12,6 +12,7 @@
 #include "gemm_wres.hpp"
 #include "gru_math.hpp"
 #include "gru_wgrad_hx.hpp"
+#include "side_stream.hpp"
 
 namespace temp {
 
@@ -933,6 +934,20 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
   int rc;
   bool hx = hx_enabled() && g4_col_keys != nullptr;
   for (int i = 0; i < count && hx; ++i) hx = g4_col_keys[i] != nullptr;
+  // d_x = [dr dz dn_i] . W_ih: the first 3d columns of a g4 row (row stride 4d).  It reads g4 and W_ih only -- nothing the weight
+  // gradients write -- so it runs on the side stream beside them (side_stream.hpp; a parallel branch of a captured graph): its weight
+  // pack, its tail and the weight gradients' slice reduction then overlap the other branch's matrix work.
+  PanelBatch<EpiStore> batch;
+  int nx = 0;
+  for (int i = 0; i < count; ++i)
+    if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], g4s[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}, (hx && g4_row_keys) ? g4_row_keys[i] : nullptr};
+  for (int i = nx; i < PANEL_MAXP && nx > 0; ++i) { batch.p[i] = batch.p[0]; batch.p[i].M = 0; }
+  SideScope side(st);
+  const bool beside = nx > 0 && !(option(TEMP_OPT_DEBUG) & 0x10000) && side_fork(side);      // (TEMP_DEBUG bit 16: A/B, d_x in-stream)
+  if (beside) {
+    rc = launch_gemm_panel_multi(K_GEMM_GRU_DX, batch, nx, d, 3 * d, 4 * d, d, 0, side.ss->s);
+    if (!side_done(side) || rc) return rc ? rc : TEMP_E_LAUNCH;          // (~SideScope joins or drains the branch)
+  }
   if (hx) {
     // f16 arithmetic (gru_wgrad_hx.hpp): the column keys of g4 come from the chain backward; those of x are taken here, one pass
     WgxKeys keys = {};
@@ -970,12 +985,10 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
   int gx = ceil_div(quads, 256);
   if (gx > 2048) gx = 2048;
   TEMP_LAUNCH(K_REDUCE_SLICES, k_gru_wgrad_reduce, dim3(gx), dim3(256), 0, st, 2 * count, Ka, d, a.S, a.part, a.bpart, R0, S2, a.part2, a.bpart2, d_w, d_b);
-  // d_x = [dr dz dn_i] . W_ih: the first 3d columns of a g4 row (row stride 4d)
-  PanelBatch<EpiStore> batch;
-  int nx = 0;
-  for (int i = 0; i < count; ++i)
-    if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], g4s[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}, (hx && g4_row_keys) ? g4_row_keys[i] : nullptr};
-  for (int i = nx; i < PANEL_MAXP && nx > 0; ++i) { batch.p[i] = batch.p[0]; batch.p[i].M = 0; }
+  if (beside) {
+    const int jr = side.join();
+    return jr ? jr : launch_status();
+  }
   if (nx > 0) rc = launch_gemm_panel_multi(K_GEMM_GRU_DX, batch, nx, d, 3 * d, 4 * d, d, 0, st);
   return rc ? rc : launch_status();
 }

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <mutex>
 #include "common.hpp"
+#include "side_stream.hpp"
 
 namespace temp {
 
@@ -873,95 +874,24 @@ __global__ void __launch_bounds__(256) k_loop_gather_epi(int n, int d4, const in
   }
 }
 
-// ---- side stream for the weight-gradient edge kernel ---------------------------------------------------------------------------
-// In a layer's backward the relation-weight gradient (k_rgcn_dw + its fix-up: an L2-gather kernel of small blocks, ~110 us at the
-// S-gdelt shape) depends only on dz, like the d/dh aggregation, the self-loop product and the loop-weight gradient -- kernels
-// bound by LDS or by the matrix pipe.  It is launched on a per-device side stream between a fork event and a join event, so it
-// fills the CUs' spare wave slots under those kernels instead of queueing behind them.  Same kernels, same results.  The events
-// are ordinary stream dependencies: inside a HIP-graph capture they become a parallel branch of the graph.  The stream and the two
-// events are created once per device, on first use (never inside a capture: every captured step is preceded by warm-up runs);
-// nothing is synchronised.  temp_set_option(TEMP_OPT_OVERLAP, 0): off.
-struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  hipStream_t owner = nullptr;                   // caller stream this entry last served (an entry is re-used by the same stream)
-  int dev = -1;
-  bool ok = false, tried = false;
-  std::atomic_flag busy = ATOMIC_FLAG_INIT;      // held for the duration of ONE backward call
-};
-// A small pool per process: an entry (side stream + its two events) serves one backward call at a time.  Two host threads that
-// run backward passes concurrently (different caller streams, or even the same one) never share events; when every entry is
-// busy the call simply runs the weight gradient in-stream.
-#define SIDE_POOL 16
-static SideStream* side_acquire(hipStream_t st) {
-  static SideStream pool[SIDE_POOL];
-  static std::mutex mu;                          // guards the scan AND creation: an entry's state fields are read and written under it
-  if (!option(TEMP_OPT_OVERLAP)) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);          // (a handful of backward calls per step: the lock costs nothing next to a launch)
-  // first choice: the entry this (device, stream) used before -- a captured graph then sees the same side stream on every capture
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int i = 0; i < SIDE_POOL; ++i) {
-      SideStream& p = pool[i];
-      const bool mine = p.tried && p.ok && p.dev == dev && p.owner == st;
-      const bool fresh = !p.tried;
-      const bool any = p.tried && p.ok && p.dev == dev;
-      if (!(pass == 0 ? mine : (fresh || any))) continue;
-      if (p.busy.test_and_set(std::memory_order_acquire)) continue;      // (released without the lock, by the call that holds it)
-      if (!p.tried) {
-        p.tried = true;
-        p.dev = dev;
-        p.ok = hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&p.join, hipEventDisableTiming) == hipSuccess;
-        if (!p.ok) (void)hipGetLastError();
-      }
-      if (p.ok && p.dev == dev) { p.owner = st; return &p; }
-      p.busy.clear(std::memory_order_release);
-    }
-  }
-  return nullptr;
-}
-// One backward call's use of a side stream: whatever path leaves the call, a branch that was forked is joined back into the
-// caller's stream (an un-joined branch would invalidate a HIP-graph capture and leave d_weight in flight behind the return)
-// and the entry is released.
-struct SideScope {
-  SideStream* ss;
-  hipStream_t st;
-  bool forked = false;                           // the side stream waits on the caller's: it must be joined
-  bool join_recorded = false;                    // ss->join was recorded AFTER this call's work (waiting on it otherwise = a stale event)
-  SideScope(hipStream_t stream) : ss(side_acquire(stream)), st(stream) {}
-  SideScope(const SideScope&) = delete;
-  SideScope& operator=(const SideScope&) = delete;
-  // Join the forked branch back into the caller's stream.  If recording the join event failed the branch cannot be joined by an
-  // event; outside a capture the side stream is drained on the host instead (slow, correct), and the call reports the failure.
-  int join() {
-    if (!ss || !forked) return TEMP_OK;
-    forked = false;
-    if (!join_recorded) {
-      (void)hipStreamSynchronize(ss->s);
-      return TEMP_E_LAUNCH;
-    }
-    return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? TEMP_OK : TEMP_E_LAUNCH;
-  }
-  ~SideScope() {
-    if (!ss) return;
-    (void)join();
-    ss->busy.clear(std::memory_order_release);
-  }
-};
 // run_dw on the side stream, forked from the caller's stream; joined by SideScope
+// `tail` (nullable): more work of the call that depends only on what the fork has seen, issued on the side stream behind run_dw
+template <class Tail>
 static int dw_forked(SideScope& sc, const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz,
-                     const float* nnorm, int d_in, int d_out, int num_bases, int n_rel_rows, float* dW, float* partial) {
+                     const float* nnorm, int d_in, int d_out, int num_bases, int n_rel_rows, float* dW, float* partial, Tail tail) {
   SideStream* ss = sc.ss;
   if (hipEventRecord(ss->fork, sc.st) != hipSuccess) return TEMP_E_LAUNCH;
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return TEMP_E_LAUNCH;
   sc.forked = true;                              // from here on the side stream depends on the caller's: it must be joined
-  const int rc = run_dw(v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, ss->s);
+  int rc = run_dw(v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, ss->s);
+  if (!rc) rc = tail(ss->s);
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return TEMP_E_LAUNCH;
   sc.join_recorded = true;
   return rc;
+}
+static int dw_forked(SideScope& sc, const TempEdgeView& v, const TempMembers* mb, const float* x, const int32_t* x_ids, const float* dz,
+                     const float* nnorm, int d_in, int d_out, int num_bases, int n_rel_rows, float* dW, float* partial) {
+  return dw_forked(sc, v, mb, x, x_ids, dz, nnorm, d_in, d_out, num_bases, n_rel_rows, dW, partial, [](hipStream_t) { return (int)TEMP_OK; });
 }
 
 struct TableBwdWs {
@@ -1181,14 +1111,24 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
   }
   SideScope side(st);                            // relation-weight gradient beside the rest of the backward (see SideStream)
   SideStream* ss = side.ss;
+  const DropSpec ds = drop_spec(drop);
+  // without dropout the loop-weight and bias gradients read only h and dz, like the relation-weight gradient: they follow it on the
+  // side stream (the relation-weight kernel ends ~80 us before the d/dh aggregation at the S-gdelt shape: the loop-weight product
+  // then runs beside the aggregation's tail and the self-loop product instead of behind them)
+  const bool tail_beside = ss && !(ds.p > 0.f) && !(option(TEMP_OPT_DEBUG) & 0x20000);       // (TEMP_DEBUG bit 17: A/B, in-stream)
   if (ss) {
-    rc = dw_forked(side, g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw);
+    rc = dw_forked(side, g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw,
+                   [&](hipStream_t s2) {
+                     if (!tail_beside) return (int)TEMP_OK;
+                     int r2 = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dz, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, s2);
+                     if (!r2 && has_bias) r2 = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, s2);
+                     return r2;
+                   });
     if (rc) return rc;
   }
   // d_h (aggregation part) over the by-src view, then d_h = (out_deg>0 ? d_h : 0) + dz . loop_w^T
   rc = run_agg(MODE_DX, g->by_src, members_of(g), dz, d_out, nullptr, weight, n_rel_rows, g->nnorm, d_in, d_out, num_bases, d_h, w.part_dx, st);
   if (rc) return rc;
-  const DropSpec ds = drop_spec(drop);
   const float* dzm = dz;                       // gradient of the (dropped-out) self-loop message
   if (ds.p > 0.f) {
     rc = mask_rows(g->n_nodes, d_out, dz, w.dzm, ds, st);
@@ -1202,11 +1142,13 @@ int temp_rgcn_bwd(const TempGraph* g, const float* h, const float* out, const fl
     rc = run_dw(g->by_rel, members_of(g), h, nullptr, dz, g->nnorm, d_in, d_out, num_bases, n_rel_rows, d_weight, w.part_dw, st);
     if (rc) return rc;
   }
-  rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dzm, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
-  if (rc) return rc;
-  if (has_bias) {
-    rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
+  if (!tail_beside) {
+    rc = gemm_tn(g->n_nodes, d_in, d_out, h, d_in, dzm, d_out, d_loop_w, d_out, w.tn, w.tn_bytes, st);
     if (rc) return rc;
+    if (has_bias) {
+      rc = colsum(g->n_nodes, d_out, dz, d_out, d_bias, w.cs, w.cs_bytes, st);
+      if (rc) return rc;
+    }
   }
   return side.join();
 }
