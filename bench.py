@@ -1090,7 +1090,7 @@ def main():
                 elif name == "k_rgcn_dw":
                     if k.startswith("k_rgcn_dw"):
                         hits.append(v)
-                elif k == name or k.startswith(name + "<") or k.startswith(name + "_multi<"):
+                elif k == name or k.startswith(name + "<") or k.startswith(name + "_multi<") or k.startswith(name + "_hx<"):       # (_hx: the f16 kernels of round 6 under the family's trace name)
                     hits.append(v)
             n_l = sum(h["launches"] for h in hits)
             return sum(h["traffic_bytes_per_launch"] * h["launches"] for h in hits) / n_l if n_l else None
