@@ -935,15 +935,17 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
   bool hx = hx_enabled() && g4_col_keys != nullptr;
   for (int i = 0; i < count && hx; ++i) hx = g4_col_keys[i] != nullptr;
   // d_x = [dr dz dn_i] . W_ih: the first 3d columns of a g4 row (row stride 4d).  It reads g4 and W_ih only -- nothing the weight
-  // gradients write -- so it runs on the side stream beside them (side_stream.hpp; a parallel branch of a captured graph): its weight
-  // pack, its tail and the weight gradients' slice reduction then overlap the other branch's matrix work.
+  // gradients write -- so it MAY run on the side stream beside them (side_stream.hpp; a parallel branch of a captured graph).
+  // Measured (same-box A/B, S-gdelt): 4 us of a 1.97-ms step -- two matrix-pipe kernels at the power cap share the pipe, only the
+  // weight pack, the slice reduction and the tails overlap -- while every per-kernel duration of the branch grows by the time it
+  // waits for CUs (k_gemm_hxp 124 -> 357 us in the rocprof statistics).  Off by default: TEMP_DEBUG bit 16 turns it on.
   PanelBatch<EpiStore> batch;
   int nx = 0;
   for (int i = 0; i < count; ++i)
     if (d_xs[i]) batch.p[nx++] = PanelProblem<EpiStore>{ns[i], g4s[i], nullptr, w_ihs[i], EpiStore{d_xs[i], d}, (hx && g4_row_keys) ? g4_row_keys[i] : nullptr};
   for (int i = nx; i < PANEL_MAXP && nx > 0; ++i) { batch.p[i] = batch.p[0]; batch.p[i].M = 0; }
   SideScope side(st);
-  const bool beside = nx > 0 && !(option(TEMP_OPT_DEBUG) & 0x10000) && side_fork(side);      // (TEMP_DEBUG bit 16: A/B, d_x in-stream)
+  const bool beside = nx > 0 && (option(TEMP_OPT_DEBUG) & 0x10000) && side_fork(side);
   if (beside) {
     rc = launch_gemm_panel_multi(K_GEMM_GRU_DX, batch, nx, d, 3 * d, 4 * d, d, 0, side.ss->s);
     if (!side_done(side) || rc) return rc ? rc : TEMP_E_LAUNCH;          // (~SideScope joins or drains the branch)

@@ -171,14 +171,18 @@ static __global__ void __launch_bounds__(1024) k_keys_reduce(int n_part, int col
 #define ABSMAX_BLOCKS 1024
 // GATHER: row r reads X[idx[r]] (idx < 0: a zero row) and the kernel also WRITES the gathered row to out[r] (temp_gather_rows with
 // the keys of its output for free).
+// ABSMAX_WAVES waves per block: the column maxima of a block's waves are combined in LDS, so a launch leaves gridDim.x partial
+// rows for k_keys_reduce -- with 16-wave blocks a quarter of what 4-wave blocks leave for the same number of waves in flight
+// (the reduction over 1 024 partial rows was a 14-us kernel on the step's critical path; over 256 it is launch latency).
+#define ABSMAX_WAVES 16
 template <bool GATHER>
-__global__ void __launch_bounds__(256) k_absmax_keys(int n_rows, int d, const float* __restrict__ X, int ldx, const int32_t* __restrict__ idx,
+__global__ void __launch_bounds__(64 * ABSMAX_WAVES) k_absmax_keys(int n_rows, int d, const float* __restrict__ X, int ldx, const int32_t* __restrict__ idx,
                                                      float* __restrict__ out, unsigned* __restrict__ row_keys, unsigned* __restrict__ col_part) {
-  __shared__ hx_u32x4 sm[4][64];
+  __shared__ hx_u32x4 sm[ABSMAX_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d4 = d >> 2;
   const bool act = lane < d4;
-  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  const int gw = blockIdx.x * ABSMAX_WAVES + wave, nw = gridDim.x * ABSMAX_WAVES;
   const float* xp = X + (act ? 4 * lane : 0);
   unsigned ck[4] = {0u, 0u, 0u, 0u};
   for (int r0 = gw; r0 < n_rows; r0 += 4 * nw) {
@@ -205,15 +209,16 @@ __global__ void __launch_bounds__(256) k_absmax_keys(int n_rows, int d, const fl
   if (wave == 0 && act) {
     hx_u32x4 m = sm[0][lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) { const hx_u32x4 o = sm[w][lane]; m[0] = max(m[0], o[0]); m[1] = max(m[1], o[1]); m[2] = max(m[2], o[2]); m[3] = max(m[3], o[3]); }
+    for (int w = 1; w < ABSMAX_WAVES; ++w) { const hx_u32x4 o = sm[w][lane]; m[0] = max(m[0], o[0]); m[1] = max(m[1], o[1]); m[2] = max(m[2], o[2]); m[3] = max(m[3], o[3]); }
     *reinterpret_cast<hx_u32x4*>(col_part + (size_t)blockIdx.x * d + 4 * lane) = m;
   }
 }
-inline int absmax_blocks(int n_rows) { const int b = ceil_div(n_rows, 32); return b < 1 ? 1 : (b > ABSMAX_BLOCKS ? ABSMAX_BLOCKS : b); }
+// (ABSMAX_BLOCKS stays the bound the scratch sizes are computed from -- temp_keys_cols_size; launches use at most 256 blocks of 16 waves)
+inline int absmax_blocks(int n_rows) { const int b = ceil_div(n_rows, 8 * ABSMAX_WAVES); return b < 1 ? 1 : (b > ABSMAX_BLOCKS / 4 ? ABSMAX_BLOCKS / 4 : b); }
 // col_keys [d] (nullable) needs col_part [absmax_blocks(n_rows)][d] as scratch
 static inline void launch_absmax_keys(int n_rows, int d, const float* X, int ldx, unsigned* row_keys, unsigned* col_keys, unsigned* col_part, hipStream_t st) {
   const int blocks = absmax_blocks(n_rows);
-  TEMP_LAUNCH(K_KEYS, (k_absmax_keys<false>), dim3(blocks), dim3(256), 0, st, n_rows, d, X, ldx, (const int32_t*)nullptr, (float*)nullptr, row_keys, col_keys ? col_part : nullptr);
+  TEMP_LAUNCH(K_KEYS, (k_absmax_keys<false>), dim3(blocks), dim3(64 * ABSMAX_WAVES), 0, st, n_rows, d, X, ldx, (const int32_t*)nullptr, (float*)nullptr, row_keys, col_keys ? col_part : nullptr);
   if (col_keys) TEMP_LAUNCH(K_KEYS, k_keys_reduce, dim3(ceil_div(d, 32), 1), dim3(1024), 0, st, blocks, d, col_part, col_keys, (const int32_t*)nullptr, 0);
 }
 
@@ -221,7 +226,7 @@ static inline void launch_absmax_keys(int n_rows, int d, const float* X, int ldx
 static inline void launch_gather_rows_keys(int n, int d, const float* table, const int32_t* idx, float* out, unsigned* row_keys, unsigned* col_keys,
                                            unsigned* col_part, hipStream_t st) {
   const int blocks = absmax_blocks(n);
-  TEMP_LAUNCH(K_GATHER_ROWS, (k_absmax_keys<true>), dim3(blocks), dim3(256), 0, st, n, d, table, d, idx, out, row_keys, col_keys ? col_part : nullptr);
+  TEMP_LAUNCH(K_GATHER_ROWS, (k_absmax_keys<true>), dim3(blocks), dim3(64 * ABSMAX_WAVES), 0, st, n, d, table, d, idx, out, row_keys, col_keys ? col_part : nullptr);
   if (col_keys) TEMP_LAUNCH(K_GATHER_ROWS, k_keys_reduce, dim3(ceil_div(d, 32), 1), dim3(1024), 0, st, blocks, d, col_part, col_keys, (const int32_t*)nullptr, 0);
 }
 
