@@ -322,6 +322,14 @@ __device__ __forceinline__ void bxr_wave(const PanelProblem<Epi>& pb, const BxrG
   }
 }
 
+// An epilogue may limit the COLUMNS of B its problem really has (`int n_valid`, <= the launch's N): the problems of one launch
+// then share N = the widest and a block never reads rows of B (trans_b = 1) past its own problem's (EpiPlainStoreT: the loss's
+// score products written transposed, gemm_kernels.hip).
+template <class Epi, class = void> struct EpiColLimit { static __device__ __forceinline__ int get(const Epi&, int n) { return n; } };
+template <class Epi> struct EpiColLimit<Epi, decltype((void)Epi::has_n_valid)> {
+  static __device__ __forceinline__ int get(const Epi& e, int n) { return e.n_valid < n ? e.n_valid : n; }
+};
+
 // VAR is 0 in the library; tools/bxr_probe.hip instantiates ablations (bit0: no A loads, bit1: no epilogue traffic, bit2: no MFMAs,
 // bit3: no operand split) and, with BXR_PROBE defined, s_memtime stamps per wave
 template <class Epi, int VAR = 0>
@@ -342,6 +350,7 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
     // VALU instructions each) straight from the fp32 matrix -- the pack launch in front of every weights-resident product is gone
     const float* __restrict__ B = pb.B;
     const int items = g.n_slabs * gt * 64, ldb = g.ldb;
+    const int n_lim = EpiColLimit<Epi>::get(pb.epi, g.N);
     constexpr int UN = 4;
     for (int i0 = threadIdx.x; i0 < items; i0 += UN * BXR_WAVES * 64) {
       float4 v0[UN], v1[UN];
@@ -354,7 +363,7 @@ __global__ void __launch_bounds__(BXR_WAVES * 64, 2) k_gemm_bxr(PanelBatch<Epi> 
         const int k = 16 * sl + 8 * (ln >> 5), n = (t0 + j) * 32 + (ln & 31);
         dst[u] = it < items ? sl * (BXR_G * 192) + j * 192 + ln : -1;
         v0[u] = zero4(); v1[u] = zero4();
-        if (n < g.N && k < g.K) {                               // K % 8 == 0: the octet is entirely in or out
+        if (n < n_lim && k < g.K) {                             // K % 8 == 0: the octet is entirely in or out
           if (g.trans_b) {
             const float* q = B + (size_t)n * ldb + k;
             v0[u] = ld4(q); v1[u] = ld4(q + 4);

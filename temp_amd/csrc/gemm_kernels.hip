@@ -1654,19 +1654,24 @@ struct EpiPartialStore {
 // C^T written: out[col * ldo + row].  A lane of the weights-resident kernel owns one row and four consecutive columns, so for a
 // fixed column the 32 lanes of a half-wave write 32 consecutive floats: coalesced 128-B segments.
 struct EpiPlainStoreT {
+  static constexpr int has_n_valid = 1;          // (gemm_bxr.hpp EpiColLimit: the weights-resident kernel reads no row of B past n_valid)
   float* out; int ldo;
+  int n_valid;                                   // columns this problem has (<= the launch's N; columns past it are not stored)
   struct RowCtx {};
   __device__ __forceinline__ RowCtx row_ctx(int) const { return RowCtx(); }
   __device__ __forceinline__ float4 pre4(const RowCtx&, int, int) const { return zero4(); }
   __device__ __forceinline__ void fin4(const RowCtx&, int row, int col, float4 acc, float4) const {
     float* o = out + (size_t)col * ldo + row;
-    o[0] = acc.x; o[ldo] = acc.y; o[2 * (size_t)ldo] = acc.z; o[3 * (size_t)ldo] = acc.w;
+    if (col + 3 < n_valid) { o[0] = acc.x; o[ldo] = acc.y; o[2 * (size_t)ldo] = acc.z; o[3 * (size_t)ldo] = acc.w; return; }
+    if (col < n_valid) o[0] = acc.x;
+    if (col + 1 < n_valid) o[ldo] = acc.y;
+    if (col + 2 < n_valid) o[2 * (size_t)ldo] = acc.z;
   }
 };
 
 int temp_linear_t(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* Ct, int ldct, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !B || (M > 0 && (!A || !Ct)) || ldct < M) return TEMP_E_BADARG;
-  return launch_gemm_panel(K_GEMM_LINEAR, M, N, K, A, lda, nullptr, B, ldb, trans_b, EpiPlainStoreT{Ct, ldct}, (hipStream_t)stream);
+  return launch_gemm_panel(K_GEMM_LINEAR, M, N, K, A, lda, nullptr, B, ldb, trans_b, EpiPlainStoreT{Ct, ldct, N}, (hipStream_t)stream);
 }
 
 int temp_linear(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, void* stream) {
@@ -1782,6 +1787,29 @@ int temp_linear_multi(int count, const TempLinearProblem* probs, int N, int K, i
               if (probs[i0 + i].M > 0)
                 reduce_slices(S, (size_t)probs[i0 + i].M * ldc, ldc, part[i], probs[i0 + i].C, ldc, (hipStream_t)stream);
           }
+          if (launch_status() != TEMP_OK) return TEMP_E_LAUNCH;
+          continue;
+        }
+      }
+    }
+    // Few rows against MANY columns (scores_b = q_b . all_b^T: a few hundred queries x 7 000 - 10 000 entities per window): the
+    // row panels of such a problem are mostly padding and every block streams its own tile of B.  Taken as C^T = B . A^T the
+    // entities are the ROWS (tens of thousands over the launch's windows) and the queries the resident weights of the split-operand
+    // kernel (gemm_bxr.hpp), the result written transposed -- 57 -> 25 us per four-window launch at the S-icews0515 shape.  The
+    // windows' query counts differ: the launch takes the widest, every problem carries its own limit (EpiPlainStoreT::n_valid).
+    if (trans_b && N >= 2048 && bx_enabled() && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 && !(option(TEMP_OPT_DEBUG) & 0x40000)) {      // (TEMP_DEBUG bit 18: A/B, as stored)
+      int max_m = 0, min_m = 1 << 30;
+      for (int i = 0; i < n; ++i) { const int M = probs[i0 + i].M; max_m = M > max_m ? M : max_m; min_m = M < min_m ? M : min_m; }
+      const int Nt = (max_m + 3) & ~3;
+      BxGeom bg;
+      int G;
+      if (min_m > 0 && max_m <= 1024 && bx_plan(Nt, K, ldb, lda, 1, N, (long long)n * N, &bg, &G)) {
+        PanelBatch<EpiPlainStoreT> tb;
+        for (int i = 0; i < PANEL_MAXP; ++i) {
+          const TempLinearProblem& q = probs[i0 + (i < n ? i : 0)];
+          tb.p[i] = PanelProblem<EpiPlainStoreT>{i < n ? N : 0, q.B, nullptr, q.A, EpiPlainStoreT{q.C, ldc, q.M}};
+        }
+        if (launch_bxr(K_GEMM_LINEAR, tb, n, bg, (hipStream_t)stream, nullptr)) {
           if (launch_status() != TEMP_OK) return TEMP_E_LAUNCH;
           continue;
         }

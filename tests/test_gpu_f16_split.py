@@ -395,3 +395,28 @@ def test_weight_gradient_beyond_32bit_span_gpu(hip_backend):
         sabs += ad.abs().t() @ bd.abs()
     err = ((out.double() - ref).abs() / sabs).max().item()
     assert err < 2e-7, err
+
+
+@pytest.mark.parametrize("Ms,N", [([184, 150, 184, 1], 7128), ([400, 400, 399, 400, 37, 400, 400, 400], 10488), ([1024, 3], 4100)])
+def test_skinny_score_products_transposed_route_gpu(Ms, N, hip_backend):
+    """scores_b = q_b . all_b^T with a few hundred query rows against thousands of entities runs as (all_b . q_b^T)^T on the
+    weights-resident split-operand kernel, written transposed; every window keeps its own row count (ragged, not multiples of 4):
+    against fp64 at the products' bar, nothing outside a problem's rows written, the same bits twice."""
+    be = hip_backend
+    K = 200
+    q = [_wide((m, K), 50 + i, 0.5).to(DEV) for i, m in enumerate(Ms)]
+    ents = [_wide((N, K), 70 + i, 0.3).to(DEV) for i in range(len(Ms))]
+    out = torch.full((sum(Ms) + 2, N), 7.0, device=DEV)
+    be.linear_multi(q, ents, True, out[:sum(Ms)])
+    torch.cuda.synchronize()
+    assert torch.all(out[sum(Ms):] == 7.0)                     # the rows behind the last problem are untouched
+    off = 0
+    for i, m in enumerate(Ms):
+        ref = q[i].double() @ ents[i].double().t()
+        sabs = q[i].double().abs() @ ents[i].double().abs().t()
+        err = ((out[off:off + m].double() - ref).abs() / sabs.clamp_min(1e-300)).max().item()
+        assert err < 1e-6, "scores of problem %d (%d x %d): %.3e" % (i, m, N, err)
+        off += m
+    again = torch.empty(sum(Ms), N, device=DEV)
+    be.linear_multi(q, ents, True, again)
+    assert torch.equal(again, out[:sum(Ms)])
