@@ -397,7 +397,7 @@ def test_weight_gradient_beyond_32bit_span_gpu(hip_backend):
     assert err < 2e-7, err
 
 
-@pytest.mark.parametrize("Ms,N", [([184, 150, 184, 1], 7128), ([400, 400, 399, 400, 37, 400, 400, 400], 10488), ([1024, 3], 4100)])
+@pytest.mark.parametrize("Ms,N", [([184, 150, 184, 1], 7128), ([400, 400, 399, 400, 37, 400, 400, 400], 10488), ([1024, 3], 4100), ([184] * 8, 10488)])
 def test_skinny_score_products_transposed_route_gpu(Ms, N, hip_backend):
     """scores_b = q_b . all_b^T with a few hundred query rows against thousands of entities runs as (all_b . q_b^T)^T on the
     weights-resident split-operand kernel, written transposed; every window keeps its own row count (ragged, not multiples of 4):
@@ -420,3 +420,14 @@ def test_skinny_score_products_transposed_route_gpu(Ms, N, hip_backend):
     again = torch.empty(sum(Ms), N, device=DEV)
     be.linear_multi(q, ents, True, again)
     assert torch.equal(again, out[:sum(Ms)])
+    # the same windows' d_all_b = d_scores_b^T . q_b (few rows, thousands of output rows; the fp32 kernel: the split-operand one
+    # measured slower at this depth, 3.40 against 3.06 ms for the config-3 step), one launch
+    if len(Ms) <= 8 and min(Ms) >= 32:
+        ds = [_wide((m, N), 90 + i, 1e-3).to(DEV) for i, m in enumerate(Ms)]
+        d_all = torch.empty(len(Ms) * N, K, device=DEV)
+        be.linear_tn_multi(ds, q, [d_all[i * N:(i + 1) * N] for i in range(len(Ms))])
+        torch.cuda.synchronize()
+        for i in range(len(Ms)):
+            ref, sabs = ds[i].double().t() @ q[i].double(), ds[i].double().abs().t() @ q[i].double().abs()
+            err = ((d_all[i * N:(i + 1) * N].double() - ref).abs() / sabs.clamp_min(1e-300)).max().item()
+            assert err < 1e-6, "d_all of problem %d: %.3e" % (i, err)
