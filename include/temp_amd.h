@@ -83,9 +83,10 @@ enum {
                                   bits as 2; no faster than the gather kernel at the measured shapes)
                                0: always gather through L2 (bit-identical results)             [TEMP_RGCN_TILE=<n>]    default 1 */
   TEMP_OPT_DEBUG = 6,       /* development ablations inside instrumented kernels; 0 (off) in every product run          default 0 */
-  TEMP_OPT_OVERLAP = 7,     /* 1: a layer's backward launches the relation-weight gradient on a library-owned side stream (fork /
-                               join events on the caller's stream: a parallel branch under HIP-graph capture) so that it overlaps
-                               the d/dh aggregation and the self-loop products; 0: everything on the caller's stream
+  TEMP_OPT_OVERLAP = 7,     /* 1: a layer's backward launches the relation-weight gradient -- and, without dropout, the loop-weight
+                               and bias gradients behind it -- on a library-owned side stream (fork / join events on the caller's
+                               stream: a parallel branch under HIP-graph capture) so that they overlap the d/dh aggregation and
+                               the self-loop product; 0: everything on the caller's stream
                                                                                                [TEMP_OVERLAP=0 -> 0]    default 1 */
   TEMP_OPT_GEMM_RESIDENT = 8, /* 1: large fp32 products with K <= 208 keep the packed weights of four column tiles resident in LDS and
                                stream row panels through them (gemm_bxr.hpp); 0: one row tile per block, weights staged per slab
