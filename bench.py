@@ -274,8 +274,8 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_batches=16):
     """The oracle (port of the reference's op sequence, dense re-zeroed history kept) on the host cores, on the SAME batch the
     GPU step encodes: the rank-0 targets as ONE batch of bsz windows, target graphs at 50 % of their edges, fwd+bwd, repeated
     until at least `min_seconds` of CPU work has been timed.  `all_cores` is a second, bounded measurement with every hardware
-    thread of the box (one window, in a child process with a timeout: torch's intra-op pool makes the oracle's many small ops
-    slower, not faster, beyond ~16 threads)."""
+    CPU this process may use (_cpu_quota: the cgroup's quota, 16 on the GPU boxes whose hosts show 256 threads): several processes of
+    16 torch threads side by side when the quota allows it (cpu_all_cores_parallel), else the figure above IS all of them."""
     from oracle import temp_oracle as O
     nthreads = min(os.cpu_count() or 1, CPU_THREADS)
     torch.set_num_threads(nthreads)
@@ -293,8 +293,17 @@ def cpu_baseline(model, w, device_targets, min_seconds=12.0, max_batches=16):
         dt = time.perf_counter() - t0
         if dt >= min_seconds or nb >= max_batches:
             break
-    return dict(value=edges / dt, unit="edges/s", cores=nthreads, host_threads=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
-                all_cores=cpu_all_cores_probe(w),
+    quota = _cpu_quota()
+    if quota >= 2 * nthreads:                       # more CPUs than one process uses well: several processes side by side
+        allc = cpu_all_cores_parallel(w, threads_per_process=nthreads, processes=quota // nthreads)
+    else:
+        allc = dict(cores=quota, value=edges / dt, unit="edges/s", same_as="value",
+                    note="this process may use %d CPUs at once (cgroup CPU quota; the host shows %d hardware threads): the %d-thread figure is every "
+                         "core it has.  More busy threads are throttled -- measured with tools/cpu_scale_probe.py: 16 processes x 16 threads deliver "
+                         "0.07 M edge visits/s, ONE process with 256 torch threads does not finish a window in 45 s" % (quota, os.cpu_count() or 1, nthreads))
+    return dict(value=edges / dt, unit="edges/s", cores=nthreads, host_threads=os.cpu_count(), cpu_quota_cores=quota, cpu_model=_cpu_model(), kind="port",
+                all_cores=allc,
+                all_cores_one_process=cpu_all_cores_probe(w) if os.environ.get("TEMP_BENCH_CPU_ONE_PROCESS_PROBE") else None,
                 sample="%d batches of %d windows of %s (the step's own targets, target graphs at 50 %% of their edges): %d snapshot visits, "
                        "%d edge visits, fwd+bwd, %.1f s" % (nb, len(device_targets), w["name"], visits, edges, dt))
 
@@ -309,13 +318,77 @@ def cpu_probe_main(a):
     cfg = dict(module=w["module"], n_bases=w["B"], inv_temperature=0.1, rec_only_last_layer=True, use_time_embedding=False)
     om = O.init_model(cfg, w["num_ents"], w["num_rels"], w["num_times"], w["D"], seed=1)
     gd = {t: O.SnapGraph(g.n, g.src, g.dst, g.rel, g.gids) for t, g in w["snapshots"].items()}
-    run = _oracle_batch_runner(om, cfg, w, gd)
+    run = _oracle_batch_runner(om, cfg, w, gd, seed=7 + a.cpu_probe_rank)
+    if a.cpu_probe_seconds > 0:
+        # one of several processes that share the host (cpu_all_cores_parallel): whole batches of bsz windows, this process's own
+        # targets, until the time is up; every finished batch is reported at once (a process stopped early has still counted)
+        t = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], a.cpu_probe_rank)
+        run(t[:1])                                  # warm-up
+        print(json.dumps(dict(stage="ready")), flush=True)
+        t0 = time.perf_counter()
+        while True:
+            tb = time.perf_counter()
+            e, v = run(t)
+            now = time.perf_counter()
+            print(json.dumps(dict(stage="batch", seconds=now - tb, edges=e, visits=v, t_end=now - t0)), flush=True)
+            if now - t0 >= a.cpu_probe_seconds:
+                break
+        return
     t = synthetic.default_targets(w["num_times"], w["L"], w["bsz"], 0)[:1]
     print(json.dumps(dict(stage="ready", edges_per_window=None)), flush=True)
     t0 = time.perf_counter()
     e, v = run(t)
     dt = time.perf_counter() - t0
     print(json.dumps(dict(stage="done", seconds=dt, edges=e, visits=v, threads=torch.get_num_threads())), flush=True)
+
+
+def cpu_all_cores_parallel(w, threads_per_process=16, seconds=14.0, timeout_s=75.0, processes=None):
+    """Every CPU this process may use on the oracle, the way it scales: `processes` (default cpu_count / 16) PROCESSES of 16 torch
+    threads each (the measured optimum of one process), each encoding whole batches of bsz windows (its own targets, fwd + bwd) for `seconds`;
+    value = all edge visits of the batches that finished / the span they finished in; per-batch times give the median.  The
+    intra-op pool of ONE process does not use 256 threads (cpu_all_cores_probe: one window does not finish in 45 s)."""
+    import subprocess
+    n = os.cpu_count() or 1
+    procs = max(1, processes if processes else n // threads_per_process)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads_per_process), MKL_NUM_THREADS=str(threads_per_process))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-probe", "--cpu-threads", str(threads_per_process), "--workload", w["name"],
+           "--cpu-probe-seconds", str(seconds)]
+    t0 = time.perf_counter()
+    ps = []
+    try:
+        for r in range(procs):
+            ps.append(subprocess.Popen(cmd + ["--cpu-probe-rank", str(r)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True))
+    except OSError as e:
+        for p in ps:
+            p.kill()
+        return dict(cores=n, value=None, note="probe not started: %s" % e)
+    outs = []
+    for p in ps:
+        left = max(1.0, timeout_s - (time.perf_counter() - t0))
+        try:
+            out, _ = p.communicate(timeout=left)
+        except subprocess.TimeoutExpired:
+            p.kill()                                # exactly the children started above
+            out, _ = p.communicate()
+        outs.append(out or "")
+    batches, edges, span = [], 0, 0.0
+    for out in outs:
+        for line in out.splitlines():
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if d.get("stage") == "batch":
+                batches.append(d["seconds"])
+                edges += d["edges"]
+                span = max(span, d["t_end"])
+    if not batches:
+        return dict(cores=n, processes=procs, value=None, unit="edges/s", note="no batch finished within %.0f s" % timeout_s)
+    med = float(np.median(batches))
+    return dict(cores=procs * threads_per_process, processes=procs, threads_per_process=threads_per_process, value=edges / span, unit="edges/s",
+                batches=len(batches), median_batch_s=med, span_s=span,
+                sample="%d processes x %d torch threads, each whole batches of %d windows of %s (its own targets, target graphs at 50 %% of their edges), "
+                       "fwd+bwd: %d batches, %d edge visits in %.1f s; median batch %.2f s" % (procs, threads_per_process, w["bsz"], w["name"], len(batches), edges, span, med))
 
 
 def cpu_all_cores_probe(w, timeout_s=45.0):
@@ -759,6 +832,26 @@ def hbm_window(a, device, lib):
                 traced_kernel_ms=total, peak_memory_gib=mem, host_generate_s=gen_s, host_prepare_s=prep_s)
 
 
+def _cpu_quota():
+    """CPUs this process may use at once: the cgroup's CPU quota (cpu.max of cgroup v2 / cfs_quota_us of v1), else the affinity
+    mask's size.  (The GPU boxes show 256 hardware threads and a quota of 16: more than 16 busy threads are throttled, which is
+    why 16 torch threads are the oracle's optimum there and why an `all 256 threads` run does not finish.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(float(q) / float(per)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -874,6 +967,8 @@ def main():
                          "288-GB GPU holds: 166 GiB peak, ~85 s of host generation + planning; 18: 83 GiB, ~35 s; 20 does not fit)")
     ap.add_argument("--hbm-window-steps", type=int, default=3)
     ap.add_argument("--cpu-probe", action="store_true", help="(internal) child process of the all-cores CPU probe: no GPU")
+    ap.add_argument("--cpu-probe-seconds", type=float, default=0.0, help="(internal) --cpu-probe: whole batches for this many seconds (0: one window)")
+    ap.add_argument("--cpu-probe-rank", type=int, default=0, help="(internal) --cpu-probe: which targets this process takes")
     ap.add_argument("--extra-child", default="", help="(internal) child process of one `extra.config*` measurement: prints its JSON object")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="(test hook) join the process group (nccl with a GPU, gloo without), all-reduce the rank ids, print one line and exit")
