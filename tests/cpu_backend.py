@@ -129,6 +129,46 @@ class CpuTestBackend:
         d_bias = dz.sum(0) if has_bias else None
         return d_h, d_w, d_loop, d_bias
 
+    # the two halves of rgcn_bwd for a layer inside a recurrence (HipBackend.rgcn_bwd_dh / rgcn_bwd_weights; rec_stack.py's hoist)
+    def rgcn_bwd_dh(self, dg, out, d_out_grad, weight, loop_w, num_bases, act, drop=None, dz_out=None, dzm_out=None):
+        weight, loop_w = weight.detach(), loop_w.detach()
+        d_in, d_out = loop_w.shape
+        si, so = d_in // num_bases, d_out // num_bases
+        nn = dg.nnorm.cpu()[:dg.n_nodes]
+        dz = d_out_grad.detach()
+        if act == _lib.ACT_RELU:
+            dz = torch.where(out.detach() > 0, dz, torch.zeros_like(dz))
+            dz_out.copy_(dz)                       # (the weight pass reads the masked gradient: an output of this half)
+
+        def dx_edge(dst, rel):
+            w = weight.index_select(0, rel).view(-1, si, so)
+            g = (dz[dst] * (nn[dst] ** 2).view(-1, 1)).view(-1, so, 1)
+            return torch.bmm(w, g).view(-1, d_in)
+
+        d_h = _chunk_reduce(dg, 'by_src', dx_edge, d_in, dg.n_nodes, dz.dtype)
+        has_out = dg.out_deg.cpu().long() > 0
+        m = drop_mask(drop, dz.shape[0], dz.shape[1])
+        dzm = dz * m if m is not None else dz
+        if m is not None and dzm_out is not None:
+            dzm_out.copy_(dzm)
+        return torch.where(has_out.view(-1, 1), d_h, torch.zeros_like(d_h)) + torch.mm(dzm, loop_w.t())
+
+    def rgcn_bwd_weights(self, dg, h, dz, dzm, weight_like, loop_like, has_bias, num_bases):
+        h, dz = h.detach(), dz.detach()
+        dzm = dz if dzm is None else dzm.detach()
+        d_in, d_out = loop_like.shape
+        si, so = d_in // num_bases, d_out // num_bases
+        nn = dg.nnorm.cpu()[:dg.n_nodes]
+
+        def dw_edge(src, dst):
+            g = (dz[dst] * (nn[dst] ** 2).view(-1, 1)).view(-1, num_bases, 1, so)
+            x = h[src].view(-1, num_bases, si, 1)
+            return (x * g).reshape(src.shape[0], -1)
+
+        d_w = _chunk_reduce(dg, 'by_rel', dw_edge, num_bases * si * so, weight_like.shape[0], h.dtype)
+        d_w = torch.where(torch.isnan(d_w), torch.zeros_like(d_w), d_w)      # kernel memsets dW first
+        return d_w, torch.mm(h.t(), dzm), (dz.sum(0) if has_bias else None)
+
     def rgcn_table_fwd(self, dg, table, ids, weight, loop_w, bias, num_bases, act, drop=None):
         return self.rgcn_fwd(dg, table.detach()[ids.long()], None, weight, loop_w, bias, num_bases, act, drop)
 
@@ -381,6 +421,26 @@ class CpuTestBackend:
                 dprev[act] = dp
                 nxt_has = act & (((e >> 30) & 1) == 1)
 
+    # the gate gradients written once, g4 = [dr | dz | dn_i | dn_h] (HipBackend.gru_chain_bwd_g4 / gru_grads_g4: nn.GRU layout only)
+    def gru_grads_g4_supported(self, ns, d, variant):
+        return 1 <= len(ns) <= 4 and variant == _lib.GRU_TORCH and all(n > 0 for n in ns)
+
+    def gru_chain_bwd_g4(self, tabs, saved_all, ups, lam, variant, packs, b_hhs, g4, keys=None):
+        assert keys is None, "the CPU test backend has no magnitude keys (f16 arithmetic is the HIP library's)"
+        N, d = saved_all.shape[1], saved_all.shape[2]
+        dgi, dgh = torch.zeros(N, 3 * d), torch.zeros(N, 3 * d)
+        self.gru_chain_bwd(tabs, saved_all, ups, lam, variant, packs, b_hhs, dgi, dgh)
+        g4.copy_(torch.cat([dgi, dgh[:, 2 * d:]], 1))
+
+    def gru_grads_g4(self, xs, hdecs, g4s, w_ihs, d_xs, row_keys=None, col_keys=None, x_col_keys=None):
+        out = []
+        for x, hdec, g4, w_ih, d_x in zip(xs, hdecs, g4s, w_ihs, d_xs):
+            d = x.shape[1]
+            dgi = g4[:, :3 * d]
+            dgh = torch.cat([g4[:, :2 * d], g4[:, 3 * d:]], 1)
+            out.append(self.gru_weight_grads(x, hdec, dgi, dgh, w_ih, _lib.GRU_TORCH, d_x))
+        return out
+
     def gru_weight_grads_multi(self, xs, hdecs, dgis, dghs, w_ihs, variant, d_xs):
         if variant != _lib.GRU_TORCH or any(h is None for h in hdecs):
             return None
@@ -393,8 +453,12 @@ class CpuTestBackend:
         return torch.mm(dgi.t(), x.detach()), d_w_hh, dgi.sum(0), dgh.sum(0)
 
     # ---- plain GEMMs + candidate cross-entropy ------------------------------------------------
-    def linear(self, a, b, trans_b):
-        return torch.mm(a.detach(), b.detach().t() if trans_b else b.detach())
+    def linear(self, a, b, trans_b, out=None, a_keys=None):
+        r = torch.mm(a.detach(), b.detach().t() if trans_b else b.detach())
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
 
     def linear_tn(self, a, b, out=None):
         r = torch.mm(a.detach().t(), b.detach())
