@@ -76,16 +76,16 @@ def profile_file(stem):
 
 
 
-def make_args(w, module):
+def make_args(w, module, dropout=0.0):
     return argparse.Namespace(
-        n_bases=w["B"], dropout=0.0, inv_temperature=0.1, learnable_lambda=False, impute=False, post_aggregation=False,
+        n_bases=w["B"], dropout=dropout, inv_temperature=0.1, learnable_lambda=False, impute=False, post_aggregation=False,
         post_ensemble=False, num_layers=1, type1=False, rec_only_last_layer=True, use_time_embedding=False, module=module,
         embed_size=w["D"], hidden_size=w["D"], num_pos_facts=3000, negative_rate=500, score_function="complex",
         train_seq_len=w["L"], test_seq_len=w["L"], use_cuda=True, debug=True, edge_dropout=False, random_dropout=False,
         use_embed_for_non_active=False, lr=1e-3, seed=0, batch_size=w["bsz"])
 
 
-def build_model(w, device, encoder="gru"):
+def build_model(w, device, encoder="gru", dropout=0.0):
     from temp_amd.bi_dynamic_rgcn import BiDynamicRGCN
     from temp_amd.dynamic_rgcn import DynamicRGCN
     from temp_amd.self_attention_rgcn import BiSelfAttentionRGCN, SelfAttentionRGCN
@@ -96,7 +96,7 @@ def build_model(w, device, encoder="gru"):
     else:
         cls = BiDynamicRGCN if bi else DynamicRGCN
     snaps = w["snapshots"]
-    m = cls(make_args(w, w["module"]), w["num_ents"], w["num_rels"], snaps, snaps, snaps)
+    m = cls(make_args(w, w["module"], dropout), w["num_ents"], w["num_rels"], snaps, snaps, snaps)
     return m.to(device)
 
 
@@ -756,7 +756,30 @@ def extra_measurements(a, w, model, wb, targets, device, lib):
         return dict(what="north-star snapshot-sharded step on ONE RCCL rank (three HIP graphs around the two exchanges + grad all-reduce)",
                     ms_per_step=r["ms_per_step"], edges_per_s=r["value"], launch=r["launch"], rccl_ranks=r["rccl_ranks"], steps=steps)
 
+    def default_dropout():
+        """The training step with the reference's DEFAULT dropout (0.1 on the self-loop message, utils/args.py:17; SURVEY 8d measures
+        at 0): every visit and every window's isolated pass draws its own mask, so no snapshot is shared between windows and the step
+        is not captured (the masks' seeds are drawn per call) -- eager launches, beside the same step without dropout, also eager."""
+        from temp_amd.sampling import CorruptTriples
+        m2 = build_model(w, device, dropout=0.1)
+        m2.train()
+        m2.sample_rng = np.random.default_rng(2)
+        m2.corrupter = CorruptTriples(m2.args, w["snapshots"], seed=5)
+        wb2 = m2.prepare(targets, w["L"], train=True)
+        fixed2 = [tuple(x.to(device) for x in smp) for smp in m2.draw_samples(wb2)]
+        st2 = GraphStep(lambda: m2.run_loss(wb2, fixed2), [p for p in m2.parameters()], graph=False)
+        ms2 = st2.time(steps, warm)
+        model.corrupter = CorruptTriples(model.args, w["snapshots"], seed=5)
+        fixed0 = [tuple(x.to(device) for x in smp) for smp in model.draw_samples(wb)]
+        st0 = GraphStep(lambda: model.run_loss(wb, fixed0), params, graph=False)
+        ms0 = st0.time(steps, warm)
+        return dict(what="encoder + all-entity pass + loss, fwd+bwd, dropout 0.1 (the reference's default): per-visit masks, nothing shared between "
+                         "windows, eager launches", ms_per_step=ms2, edges_per_s=wb2.n_edge_visits / (ms2 * 1e-3), launch="eager",
+                    rgcn_node_rows=int(wb2.n_nodes_distinct), node_visits=int(wb2.n_node_visits),
+                    no_dropout_eager_ms_per_step=ms0, steps=steps)
+
     guarded("with_loss", with_loss)
+    guarded("default_dropout", default_dropout)
     guarded("attention", attention)
     guarded("sharded_1rank", sharded)
     def config_in_child(name):

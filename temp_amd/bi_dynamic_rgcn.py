@@ -236,8 +236,9 @@ class BiDynamicRGCN(DynamicRGCN):
         if wb.batched:
             return super()._fused_all_entity_ok(wb)
         enc = self.ent_encoder
+        # (this variant keeps ONE isolated pass per entity: not while the self-loop dropout draws -- every window then needs its own mask)
         return (self.use_batched_path and not enc.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
-                and isinstance(enc.layer_1, BiGRRGCNLayer) and isinstance(enc.layer_2, BiGRRGCNLayer)
+                and isinstance(enc.layer_1, BiGRRGCNLayer) and isinstance(enc.layer_2, BiGRRGCNLayer) and not self._all_rep()
                 and getattr(enc.layer_2, "num_layers", 1) == 1 and not (enc.layer_1._extra() or enc.layer_2._extra()))
 
     def _all_maps(self, wb):

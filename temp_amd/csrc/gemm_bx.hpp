@@ -674,6 +674,10 @@ static inline void launch_bx_g(int kid, const PanelBatch<Epi>& batch, int count,
 template <class Epi>
 static inline bool launch_bxr(int kid, const PanelBatch<Epi>& batch, int count, const BxGeom& g, hipStream_t st, const BxPacked* pkp) {
   if (!option(TEMP_OPT_GEMM_RESIDENT) || g.K > BXR_MAX_SLABS * 16 || g.K < 72) return false;
+  // An epilogue with the raw-load interface that does NOT start the accumulators at its addend (the self-loop product with dropout:
+  // the mask applies to the product alone) keeps the addend of four tiles in 64 registers of its own beside the operand stages: the
+  // kernel spills (551 us for 116 000 x 200 x 200 against 100 without dropout) -- such products take the slab-staged kernels.
+  if (EpiRawPre<Epi>::value && !EpiAccInit<Epi>::value && !(option(TEMP_OPT_DEBUG) & 0x200000)) return false;      // (TEMP_DEBUG bit 21: A/B)
   int max_m = 0;
   for (int i = 0; i < count; ++i) max_m = batch.p[i].M > max_m ? batch.p[i].M : max_m;
   BxrGeom rg;

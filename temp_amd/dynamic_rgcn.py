@@ -425,11 +425,23 @@ class DynamicRGCN(TKG_Module):
         Per chain plan (direction): the pairs with a previous state (entity, history row, time gap) and the map that assembles
         the (B, N_ents) rows from [encoder output ; pair rows ; table]; for the second direction of a bidirectional encoder
         the active rows map to -1 (the encoder output already holds both directions' sum)."""
-        if getattr(wb, "all_maps", None) is None:
+        rep = self._all_rep()
+        if getattr(wb, "all_maps", None) is None or getattr(wb, "all_rep", False) != rep:
             dev = self._device()
             N, B = self.num_ents, len(wb.graphs)
             plans = wb.plan if isinstance(wb.plan, tuple) else (wb.plan,)
             L = plans[0].seq_len
+            # rep (the self-loop dropout draws): the reference runs forward_isolated per window, each with its own mask
+            # (models/DynamicRGCN.py:56-64, models/RGCN.py:78-89), so nothing of the isolated pass is shared between windows: the
+            # once-per-entity table becomes a (window, entity) table of B * N_ents rows -- the kernels' masks are a function of
+            # (seed, row, column), so ONE launch over those rows gives every window its own mask
+            T = B * N if rep else N
+            tab = (np.arange(B * N, dtype=np.int64).reshape(B, N) if rep else np.broadcast_to(np.arange(N, dtype=np.int64)[None, :], (B, N)))
+            wb.all_rep = rep
+            if rep:
+                ids = np.tile(np.arange(N, dtype=np.int32), B)
+                wb.all_rep_ids = _lib.to_device(ids, dev)
+                wb.all_rep_inv = TF.gather_inverse(ids, N, dev)
             act = np.zeros((B, N), dtype=bool)
             sizes = [g.n for g in wb.graphs]
             n_out = int(sum(sizes))
@@ -438,7 +450,6 @@ class DynamicRGCN(TKG_Module):
                 act[b, g.gids] = True
             wb.n_inactive = int(B * N - act.sum())
             host, meta = {}, []
-            ent = np.arange(N, dtype=np.int64)[None, :]
             for d, plan in enumerate(plans):
                 _lib.pause_point()
                 row_of = np.stack([plan.final_all(b, L - 1)[0] for b in range(B)])
@@ -447,25 +458,27 @@ class DynamicRGCN(TKG_Module):
                 bb, ee = np.nonzero(has)                                   # window-major
                 n_prev = int(bb.shape[0])
                 if d == 0:
-                    asm = np.broadcast_to(n_out + n_prev + ent, (B, N)).copy()
+                    asm = (n_out + n_prev + tab).copy()
                     asm[has] = n_out + np.arange(n_prev)
                     for b, g in enumerate(wb.graphs):
                         asm[b, g.gids] = off_out[b] + np.arange(g.n)
-                    n_src = n_out + n_prev + N
+                    n_src = n_out + n_prev + T
                 else:
-                    asm = np.broadcast_to(n_prev + ent, (B, N)).copy()
+                    asm = (n_prev + tab).copy()
                     asm[has] = np.arange(n_prev)
                     asm[act] = -1
-                    n_src = n_prev + N
-                host["ent%d" % d], host["idx%d" % d], host["asm%d" % d] = ee, row_of[bb, ee], asm.reshape(-1)
-                host["dt%d" % d] = gap[bb, ee].astype(np.float32).view(np.int32)           # float bits ride in the int32 pack
-                meta.append((n_prev, n_src, ee, asm.reshape(-1), row_of[bb, ee]))
+                    n_src = n_prev + T
+                if rep:
+                    ee = bb * N + ee                                           # the pair's row of the (window, entity) table
+                host["ent%d" % d], host["idx%d" % d], host["asm%d" % d] = ee, row_of[bb, ee % N], asm.reshape(-1)
+                host["dt%d" % d] = gap[bb, ee % N].astype(np.float32).view(np.int32)       # float bits ride in the int32 pack
+                meta.append((n_prev, n_src, ee, asm.reshape(-1), row_of[bb, ee % N]))
             _lib.pause_point()
             dd = S.upload_packed(host, dev, np.int32)
             wb.all_maps = []
             for d, (n_prev, n_src, ee, asm, idx_host) in enumerate(meta):
                 wb.all_maps.append(dict(n_prev=n_prev, ent=dd["ent%d" % d], idx=dd["idx%d" % d], dt=dd["dt%d" % d].view(torch.float32).view(-1, 1), idx_host=idx_host,
-                                        asm=dd["asm%d" % d], ent_inv=TF.gather_inverse(ee, N, dev) if n_prev else None,
+                                        asm=dd["asm%d" % d], ent_inv=TF.gather_inverse(ee, T, dev) if n_prev else None,
                                         asm_inv=TF.gather_inverse(asm, n_src if wb.n_inactive else n_out, dev)))
         return wb.all_maps
 
@@ -496,14 +509,19 @@ class DynamicRGCN(TKG_Module):
         model is the unidirectional GRU encoder with BOTH layers recurrent (the reference's default flags), where the entity
         classes of _all_maps carry over to the first layer as well."""
         enc = self.ent_encoder
-        # (not while the self-loop dropout draws: the reference runs forward_isolated per window, each with its own mask,
-        #  models/DynamicRGCN.py:56-64 -- one isolated pass for all windows would share ONE mask; the per-visit rule of _share_visits)
+        # (while the self-loop dropout draws the isolated pass runs over (window, entity) rows, every window with its own mask:
+        #  _all_rep / _all_maps -- the reference's default is dropout 0.1, utils/args.py:17)
         plain = (not enc.use_time_embedding and not getattr(self.args, "use_embed_for_non_active", False)
-                 and getattr(enc.layer_2, "num_layers", 1) == 1 and not self._dropout_active())
+                 and getattr(enc.layer_2, "num_layers", 1) == 1)
         if wb.batched:
             return plain
         return (plain and self.use_batched_path and not isinstance(wb.plan, tuple) and isinstance(enc.layer_1, GRRGCNLayer)
                 and isinstance(enc.layer_2, GRRGCNLayer) and not (enc.layer_1._extra() or enc.layer_2._extra()))
+
+    def _all_rep(self):
+        """The batched all-entity pass keeps one row per (window, entity) instead of one per entity: while the dropout draws
+        (`_force_all_rep`: tests compare the two layouts without dropout)."""
+        return bool(self._dropout_active() or getattr(self, "_force_all_rep", False))
 
     def _zero_state_rows(self, rnn, x, layer):
         """GRU(x, 0) over all rows of x: input-gate GEMM + pointwise cell (gru_chain.zero_state_program); the general
@@ -532,7 +550,8 @@ class DynamicRGCN(TKG_Module):
         if wb.n_inactive == 0:
             return TF.gather_rows(out, maps[0]["asm"], maps[0]["asm_inv"]).view(B, N, out.shape[1])
         l1_rec = isinstance(l1, GRRGCNLayer)
-        iso1 = l1.conv_isolated(self.ent_embeds)
+        E = TF.gather_rows(self.ent_embeds, wb.all_rep_ids, wb.all_rep_inv) if wb.all_rep else self.ent_embeds      # (window, entity) rows
+        iso1 = l1.conv_isolated(E)
         t1 = self._zero_state_rows(l1.rnn, iso1, l1) if l1_rec else iso1
         x = l2.conv_isolated(t1)
         lam, dec = l2.inv_temperature, l2.decay_spec()

@@ -171,7 +171,9 @@ class _PostWindowMixin:
         (window, entity) pairs that carry a state; the local one is the isolated trunk Iso2(Iso1(E)) -- the same N rows for every
         window -- with each window's target rows written over it (one static row map)."""
         enc = self.ent_encoder
-        if getattr(enc, "impute", False) or not wb.batched or not base._fused_all_entity_ok(self, wb):
+        # (not while the self-loop dropout draws: the local stream below is ONE isolated pass per entity, the reference's
+        #  forward_post_ensemble_isolated runs per window with its own mask)
+        if getattr(enc, "impute", False) or not wb.batched or not base._fused_all_entity_ok(self, wb) or self._all_rep():
             return None
         dev = self._device()
         B, N, D = len(wb.graphs), self.num_ents, self.embed_size

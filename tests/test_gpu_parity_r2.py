@@ -1258,6 +1258,13 @@ def test_dropout_visits_are_independent_gpu(module):
     check_dropout_visits_are_independent(DEV, module)
 
 
+@pytest.mark.parametrize("module,rol", [("BiGRRGCN", True), ("GRRGCN", True), ("GRRGCN", False)])
+def test_dropout_all_entity_pass_keeps_windows_apart_gpu(module, rol):
+    """round 6: the batched all-entity pass under the reference's default dropout (0.1): one row per (window, entity)"""
+    from tests.window_cases import check_dropout_all_entity_pass
+    check_dropout_all_entity_pass(DEV, module, rol)
+
+
 def test_dropout_visits_self_attention_gpu():
     from tests.window_cases import check_dropout_visits_self_attention
     check_dropout_visits_self_attention(DEV)

@@ -508,3 +508,9 @@ def test_fused_ensemble_loss_equals_reference_shaped(head_as_tail):
 
 def test_static_prepare_split_equals_forward():
     check_static_prepare_split(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("module,rol", [("BiGRRGCN", True), ("GRRGCN", True), ("GRRGCN", False)])
+def test_dropout_all_entity_pass_keeps_windows_apart(module, rol):
+    from tests.window_cases import check_dropout_all_entity_pass
+    check_dropout_all_entity_pass(torch.device("cpu"), module, rol)

@@ -770,3 +770,69 @@ def check_static_prepare_split(device):
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+def check_dropout_all_entity_pass(device, module="BiGRRGCN", rec_only_last_layer=True, p=0.1):
+    """The batched all-entity pass (get_all_embeds_Gt of every window at once) while the self-loop dropout draws: the reference runs
+    forward_isolated per window, each with its own mask (models/DynamicRGCN.py:56-64, models/RGCN.py:78-89), so the pass keeps one row
+    per (window, entity) and ONE launch gives every window its own mask.
+      * the (window, entity) layout itself, WITHOUT dropout (`_force_all_rep`): same all-entity matrix, loss and gradients as the
+        one-row-per-entity layout;
+      * with dropout: the fused pass is taken, rows of an entity that is inactive and never seen in two windows differ between them,
+        the loss is finite and stays close to the dropout-free one, every parameter gets a gradient."""
+    s = slice_snapshots()
+    t_list = torch.tensor([20, 19, 17])
+    L = 8
+
+    def build(pdrop):
+        args = make_args(module=module, rec_only_last_layer=rec_only_last_layer, embed_size=32, hidden_size=32, n_bases=16, train_seq_len=L,
+                         test_seq_len=L, dropout=pdrop, negative_rate=20, num_pos_facts=60)
+        torch.manual_seed(21)
+        cls = BiDynamicRGCN if module.startswith("Bi") else DynamicRGCN
+        m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+        m.train(True)
+        m.sample_rng = np.random.default_rng(3)
+        m.seed_rng = np.random.default_rng(4)
+        return m
+
+    def step(m, force):
+        m._force_all_rep = force
+        wb = m.prepare(t_list, L, True)
+        assert m._fused_all_entity_ok(wb)
+        out, hist = m.run(wb)
+        big = m.all_embeds_batched(wb, out, hist)
+        m.zero_grad()
+        loss = m.run_loss(wb)
+        loss.backward()
+        return wb, big.detach(), float(loss.detach()), {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    wb0, big0, loss0, g0 = step(build(0.0), False)
+    wb1, big1, loss1, g1 = step(build(0.0), True)
+    assert not getattr(wb0, "all_rep", False) and wb1.all_rep
+    assert torch.allclose(big0, big1, rtol=1e-5, atol=1e-6), float((big0 - big1).abs().max())
+    assert abs(loss0 - loss1) <= 1e-5 * abs(loss0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        err = float((g0[k] - g1[k]).norm() / (g0[k].norm() + 1e-12))
+        assert err < 2e-5, (k, err)
+    m = build(p)
+    torch.manual_seed(9)
+    wbp, bigp, lossp, gp = step(m, False)
+    assert wbp.all_rep and m._dropout_active()
+    B, N = bigp.shape[0], bigp.shape[1]
+    act = np.zeros((B, N), dtype=bool)
+    for b, g in enumerate(wbp.graphs):
+        act[b, g.gids] = True
+    plans = wbp.plan if isinstance(wbp.plan, tuple) else (wbp.plan,)
+    seen = np.zeros((B, N), dtype=bool)
+    for pl in plans:
+        seen |= np.stack([pl.final_all(b, L - 1)[0] for b in range(B)]) >= 0
+    free = ~act & ~seen                            # entities whose row comes from the table in that window
+    both = np.nonzero(free[0] & free[1])[0]
+    assert both.size > 3, "the slice has entities outside two windows' graphs and histories"
+    same0 = torch.equal(big0[0, both], big0[1, both])
+    assert same0, "without dropout those rows are the same in every window"
+    frac = float((bigp[0, both] != bigp[1, both]).float().mean())
+    assert frac > 0.3, "two windows must not share a dropout mask in the isolated pass (%.2f of the elements differ)" % frac
+    assert np.isfinite(lossp) and abs(lossp - loss0) < 0.5 * abs(loss0)
+    assert set(gp) == set(g0) and all(torch.isfinite(v).all() for v in gp.values())
