@@ -77,6 +77,7 @@ def profile_file(stem):
 
 
 def make_args(w, module, dropout=0.0):
+    dropout = float(os.environ.get("TEMP_BENCH_DROPOUT", dropout))       # (experiments: any configuration with the self-loop dropout drawing; run with --no-graph)
     return argparse.Namespace(
         n_bases=w["B"], dropout=dropout, inv_temperature=0.1, learnable_lambda=False, impute=False, post_aggregation=False,
         post_ensemble=False, num_layers=1, type1=False, rec_only_last_layer=True, use_time_embedding=False, module=module,

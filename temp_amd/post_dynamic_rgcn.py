@@ -171,24 +171,27 @@ class _PostWindowMixin:
         (window, entity) pairs that carry a state; the local one is the isolated trunk Iso2(Iso1(E)) -- the same N rows for every
         window -- with each window's target rows written over it (one static row map)."""
         enc = self.ent_encoder
-        # (not while the self-loop dropout draws: the local stream below is ONE isolated pass per entity, the reference's
-        #  forward_post_ensemble_isolated runs per window with its own mask)
-        if getattr(enc, "impute", False) or not wb.batched or not base._fused_all_entity_ok(self, wb) or self._all_rep():
+        if getattr(enc, "impute", False) or not wb.batched or not base._fused_all_entity_ok(self, wb):
             return None
         dev = self._device()
         B, N, D = len(wb.graphs), self.num_ents, self.embed_size
         big_rec = base.all_embeds_batched(self, wb, out, hist)                          # (B, N, D)
+        # while the self-loop dropout draws, the local stream too keeps one row per (window, entity): the reference's
+        # forward_post_ensemble_isolated runs per window with its own mask (base._all_maps has set wb.all_rep / all_rep_ids)
+        rep = bool(getattr(wb, "all_rep", False))
         m = getattr(wb, "_asm_loc", None)
-        if m is None:
+        if m is None or m[2] != rep:
             sizes = [g.n for g in wb.graphs]
             n_out = int(sum(sizes))
             off = np.concatenate([[0], np.cumsum(sizes)])
-            asm = np.broadcast_to(n_out + np.arange(N, dtype=np.int64)[None, :], (B, N)).copy()
+            tab = np.arange(B * N, dtype=np.int64).reshape(B, N) if rep else np.broadcast_to(np.arange(N, dtype=np.int64)[None, :], (B, N))
+            asm = (n_out + tab).copy()
             for b, g in enumerate(wb.graphs):
                 asm[b, g.gids] = off[b] + np.arange(g.n)
             asm = asm.reshape(-1)
-            m = wb._asm_loc = (_lib.to_device(asm.astype(np.int32), dev), TF.gather_inverse(asm, n_out + N, dev))
-        x = enc.layer_2.conv_isolated(enc.layer_1.conv_isolated(self.ent_embeds))       # local stream of an entity outside the graph
+            m = wb._asm_loc = (_lib.to_device(asm.astype(np.int32), dev), TF.gather_inverse(asm, n_out + (B * N if rep else N), dev), rep)
+        E = TF.gather_rows(self.ent_embeds, wb.all_rep_ids, wb.all_rep_inv) if rep else self.ent_embeds
+        x = enc.layer_2.conv_isolated(enc.layer_1.conv_isolated(E))                     # local stream of an entity outside the graph
         big_loc = TF.gather_rows(torch.cat([wb.out_loc, x], dim=0), m[0], m[1]).view(B, N, D)
         return big_loc, big_rec
 

@@ -1265,6 +1265,12 @@ def test_dropout_all_entity_pass_keeps_windows_apart_gpu(module, rol):
     check_dropout_all_entity_pass(DEV, module, rol)
 
 
+@pytest.mark.parametrize("bi", [False, True])
+def test_post_ensemble_all_entity_pass_window_entity_layout_gpu(bi):
+    from tests.window_cases import check_post_ensemble_rep_layout
+    check_post_ensemble_rep_layout(DEV, bi)
+
+
 def test_dropout_visits_self_attention_gpu():
     from tests.window_cases import check_dropout_visits_self_attention
     check_dropout_visits_self_attention(DEV)

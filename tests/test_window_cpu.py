@@ -514,3 +514,9 @@ def test_static_prepare_split_equals_forward():
 def test_dropout_all_entity_pass_keeps_windows_apart(module, rol):
     from tests.window_cases import check_dropout_all_entity_pass
     check_dropout_all_entity_pass(torch.device("cpu"), module, rol)
+
+
+@pytest.mark.parametrize("bi", [False, True])
+def test_post_ensemble_all_entity_pass_window_entity_layout(bi):
+    from tests.window_cases import check_post_ensemble_rep_layout
+    check_post_ensemble_rep_layout(torch.device("cpu"), bi)

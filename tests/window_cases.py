@@ -836,3 +836,59 @@ def check_dropout_all_entity_pass(device, module="BiGRRGCN", rec_only_last_layer
     assert frac > 0.3, "two windows must not share a dropout mask in the isolated pass (%.2f of the elements differ)" % frac
     assert np.isfinite(lossp) and abs(lossp - loss0) < 0.5 * abs(loss0)
     assert set(gp) == set(g0) and all(torch.isfinite(v).all() for v in gp.values())
+
+
+def check_post_ensemble_rep_layout(device, bi):
+    """The post-ensemble models' batched all-entity pass ((all_loc, all_rec) of every window at once) in the (window, entity) layout it
+    takes while the self-loop dropout draws: WITHOUT dropout (`_force_all_rep`) it reproduces the one-row-per-entity layout -- both
+    matrices, the ensemble loss and every gradient; WITH dropout the fused pass is still taken and two windows' rows of an entity
+    outside both graphs differ in the local stream."""
+    from temp_amd.post_dynamic_rgcn import PostEnsembleBiDynamicRGCN, PostEnsembleDynamicRGCN
+    from temp_amd.sampling import CorruptTriples
+    s = slice_snapshots()
+    cls, base = (PostEnsembleBiDynamicRGCN, BiDynamicRGCN) if bi else (PostEnsembleDynamicRGCN, DynamicRGCN)
+    t_list, L = torch.tensor([20, 19, 17]), 8
+
+    def build(pdrop):
+        args = make_args(module="BiGRRGCN" if bi else "GRRGCN", rec_only_last_layer=True, post_ensemble=True, embed_size=32, hidden_size=32,
+                         n_bases=16, train_seq_len=L, test_seq_len=L, dropout=pdrop, negative_rate=20, num_pos_facts=60)
+        torch.manual_seed(8)
+        m = cls(args, s["num_e"], s["num_r"], s["tr"], s["va"], s["te"]).to(device)
+        m.train(True)
+        m.sample_rng = np.random.default_rng(3)
+        m.corrupter = CorruptTriples(m.args, s["tr"], seed=5)
+        return m
+
+    def step(m, force):
+        m._force_all_rep = force
+        wb = m.prepare(t_list, L, True)
+        smp = [tuple(x.to(device) for x in t) for t in m.draw_samples(wb)]
+        wts = [(torch.full((t[0].shape[0], 1), 0.5, device=device), torch.full((t[0].shape[0], 1), 0.5, device=device)) for t in smp]
+        out, hist = m.run(wb)
+        both = m.batched_all_embeds_post(wb, out, hist, base)
+        assert both is not None
+        m.zero_grad()
+        loss = m.run_loss(wb, smp, wts)
+        loss.backward()
+        return wb, both[0].detach(), both[1].detach(), float(loss.detach()), {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    wb0, loc0, rec0, l0, g0 = step(build(0.0), False)
+    wb1, loc1, rec1, l1, g1 = step(build(0.0), True)
+    assert wb1.all_rep and not getattr(wb0, "all_rep", False)
+    assert torch.allclose(loc0, loc1, rtol=1e-5, atol=1e-6) and torch.allclose(rec0, rec1, rtol=1e-5, atol=1e-6)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        err = float((g0[k] - g1[k]).norm() / (g0[k].norm() + 1e-12))
+        assert err < 2e-5, (k, err)
+    wbp, locp, recp, lp, gp = step(build(0.1), False)
+    assert wbp.all_rep
+    B, N = locp.shape[0], locp.shape[1]
+    act = np.zeros((B, N), dtype=bool)
+    for b, g in enumerate(wbp.graphs):
+        act[b, g.gids] = True
+    both_out = np.nonzero(~act[0] & ~act[1])[0]
+    assert both_out.size > 3
+    assert torch.equal(loc0[0, both_out], loc0[1, both_out])
+    assert float((locp[0, both_out] != locp[1, both_out]).float().mean()) > 0.3, "the local stream of two windows must not share a dropout mask"
+    assert np.isfinite(lp) and all(torch.isfinite(v).all() for v in gp.values())
