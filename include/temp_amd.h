@@ -391,7 +391,7 @@ int temp_gru_weight_grads_multi(int count, const int* ns, int d, int variant, co
  * operand is turned in registers), ONE deterministic reduction over the row slices, ONE d_x launch.  Output layout as
  * temp_gru_weight_grads_multi: d_w = [2 count][3d][d] (d_W_ih_0, d_W_hh_0, d_W_ih_1, ...), d_b = [2 count][3d].  xs / hdecs / g4s /
  * w_ihs / d_xs: HOST arrays of device pointers (a d_xs entry may be NULL).  The workspace query returns 0 and the call
- * TEMP_E_UNSUPPORTED (nothing launched) for shapes that take the dgi / dgh calls: d % 8 != 0, d % 32 == 0, d > 256, fewer than 16 384
+ * TEMP_E_UNSUPPORTED (nothing launched) for shapes that take the dgi / dgh calls: d % 8 != 0, d >= 256, fewer than 16 384
  * rows in all, TEMP_OPT_MFMA_BF16X3 off.  fp32-equivalent arithmetic (six bf16 MFMA products of the exact operand split). */
 size_t temp_gru_grads_g4_workspace(int count, const int* ns, int d);
 int temp_gru_grads_g4(int count, const int* ns, int d, const float* const* xs, const float* const* hdecs, const float* const* g4s,

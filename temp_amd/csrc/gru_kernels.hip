@@ -547,7 +547,7 @@ static bool grads_g4_plan(int count, const int* ns, int d, WgArgs* a) {
     rows += ns[i];
   }
   if (rows < BX_MIN_ROWS) return false;                          // (few rows: the per-GRU fp32 kernels win)
-  const int nt = ceil_div(d, 32);
+  const int nt = wg_col_tiles(d);
   if (nt < 1 || nt > 8) return false;
   return wg_plan(count, d, max_n, a);
 }
@@ -960,7 +960,7 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
       keys.x[i] = xk + (size_t)i * d;
       launch_absmax_keys(ns[i], d, xs[i], d, nullptr, xk + (size_t)i * d, xk + (size_t)count * d + (size_t)i * ABSMAX_BLOCKS * d, st);
     }
-    switch (ceil_div(d, 32)) {
+    switch (wg_col_tiles(d)) {
       case 1: rc = launch_gru_wgrad_hx<1>(a, keys, st); break;
       case 2: rc = launch_gru_wgrad_hx<2>(a, keys, st); break;
       case 3: rc = launch_gru_wgrad_hx<3>(a, keys, st); break;
@@ -971,7 +971,7 @@ int temp_gru_grads_g4_keys(int count, const int* ns, int d, const float* const* 
       default: rc = launch_gru_wgrad_hx<8>(a, keys, st); break;
     }
   } else
-  switch (ceil_div(d, 32)) {
+  switch (wg_col_tiles(d)) {
     case 1: rc = launch_gru_wgrad<1>(a, st); break;
     case 2: rc = launch_gru_wgrad<2>(a, st); break;
     case 3: rc = launch_gru_wgrad<3>(a, st); break;

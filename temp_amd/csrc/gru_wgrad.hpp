@@ -423,8 +423,11 @@ __global__ void __launch_bounds__(256) k_gru_wgrad_reduce(int nprod, int Ka, int
 }
 
 // host side: the decomposition of `count` GRUs of width d, the longest with max_m rows
+inline int wg_col_tiles(int d) { return ceil_div(d + 1, 32); }
 inline bool wg_plan(int count, int d, int max_m, WgArgs* a) {
-  if (count <= 0 || count > WG_MAXG || d % 8 || d % 32 == 0 || d > 256 || max_m <= 0) return false;   // (d % 32 == 0 leaves no padding column for the bias sums)
+  // (the bias sums ride on a column of ones at column d of the x / hdec images: the launch takes wg_col_tiles(d) = ceil((d + 1) / 32)
+  //  column tiles, i.e. one more than the data needs when d is a multiple of 32 -- the reference's default width is 128)
+  if (count <= 0 || count > WG_MAXG || d % 8 || d >= 256 || max_m <= 0) return false;
   a->count = count; a->d = d;
   a->T = ceil_div(3 * d, 32); a->fb = a->T / 8; a->r = a->T % 8;
   a->mixed = a->r > 0 && 2 * a->r <= 8;

@@ -22,6 +22,7 @@ WORKLOADS = {
     "S-icews0515": (10488, 251, 92, 110, 64, 200, 100, 15, 8, "BiGRRGCN"),
     "S-hbm":       (1 << 20, 230, 1 << 24, 1 << 20, 32, 200, 100, 15, 1, "BiGRRGCN"),
     "S-tiny":      (64, 6, 300, 40, 24, 16, 8, 4, 3, "BiGRRGCN"),
+    "S-gdelt-d128": (500, 20, 7475, 500, 366, 128, 128, 15, 8, "BiGRRGCN"),     # the reference's DEFAULT widths (utils/args.py:13-14,27: embed 128, 128 bases = 1 x 1 blocks)
 }
 
 

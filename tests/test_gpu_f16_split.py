@@ -171,7 +171,7 @@ def test_f16_split_gemm_nonfinite_and_zero_rows_gpu(hip_backend):
 
 
 @pytest.mark.parametrize("rows,d", [((60000, 58000), 200), ((20000, 17003), 200), ((30001,), 200), ((9000, 8000, 7000, 6004), 200),
-                                     ((20000, 20000), 104), ((12000, 11000), 248)])
+                                     ((20000, 20000), 104), ((12000, 11000), 248), ((30000, 27001), 128), ((17000,), 64), ((9000, 9000), 224)])
 @pytest.mark.parametrize("data", ["wide", "range"])
 def test_gru_grads_g4_keys_vs_fp64_gpu(rows, d, data, hip_backend):
     """temp_gru_grads_g4_keys (f16 weight gradients + d_x) against fp64: every weight / bias gradient and d_x to 2e-6 of

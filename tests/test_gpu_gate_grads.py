@@ -60,7 +60,8 @@ def test_chain_bwd_g4_equals_dgi_dgh_bitwise_gpu(d, hip_backend):
 
 
 @pytest.mark.parametrize("rows,d", [((60000, 58000), 200), ((20000, 17003), 200), ((30001,), 200), ((9000, 8000, 7000, 6004), 200),
-                                     ((20000, 20000), 104), ((9000, 9000, 9000), 136), ((12000, 11000), 248), ((40000,), 40)])
+                                     ((20000, 20000), 104), ((9000, 9000, 9000), 136), ((12000, 11000), 248), ((40000,), 40),
+                                     ((30000, 27001), 128), ((17000,), 64), ((9000, 9000), 224)])      # d % 32 == 0: one more column tile for the ones column
 def test_gru_grads_g4_vs_fp64_gpu(rows, d, hip_backend):
     """temp_gru_grads_g4 against fp64 products of the same operands: every weight / bias gradient to 2e-6 of sum |a||b| (the bar of
     the split-operand kernels), d_x equal to the d_x of the dgi / dgh call on the first 3d columns; ragged row counts (a last slab
@@ -99,7 +100,8 @@ def test_gru_grads_g4_vs_fp64_gpu(rows, d, hip_backend):
 def test_gru_grads_g4_refuses_what_it_does_not_take_gpu(hip_backend):
     be = hip_backend
     assert not be.gru_grads_g4_supported([900, 700], 200, _lib.GRU_TORCH)              # few rows: the fp32 kernels
-    assert not be.gru_grads_g4_supported([30000], 128, _lib.GRU_TORCH)                 # d % 32 == 0: no padding column for the bias sums
+    assert be.gru_grads_g4_supported([30000], 128, _lib.GRU_TORCH)                     # d % 32 == 0 (the reference's default width): an extra column tile carries the bias sums
+    assert not be.gru_grads_g4_supported([30000], 256, _lib.GRU_TORCH)                 # nine column tiles with the ones column
     assert not be.gru_grads_g4_supported([30000], 100, _lib.GRU_TORCH)                 # d % 8
     assert not be.gru_grads_g4_supported([30000], 200, _lib.GRU_TYPE1)
     lib = _lib.load()
